@@ -1,0 +1,276 @@
+"""ctypes binding of include/agc_hip.h (libagc_hip.so).
+
+This is plumbing for tests and bench.py: numpy arrays for host buffers, raw
+device pointers (e.g. torch tensors' data_ptr()) for HBM buffers.  There is no
+fallback: if the library is missing or no HIP device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libagc_hip.so")
+
+OK, ENODEV, EINVAL, ENOMEM, ECAP, ENOREF = 0, -1, -2, -3, -4, -5
+K_SCAN, K_INDEX, K_ENCODE, K_ESTIMATE, K_COSTVEC, K_REVCOMP, K_PREPROCESS, K_REFSTORE = range(8)
+K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore"]
+
+# every symbol include/agc_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "agc_hip_create", "agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_sync",
+    "agc_hip_timing_enable", "agc_hip_timing_reset", "agc_hip_timing_get",
+    "agc_hip_preprocess_dev",
+    "agc_hip_splitters_set", "agc_hip_splitters_insert", "agc_hip_splitters_count",
+    "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
+    "agc_hip_ref_register", "agc_hip_ref_register_batch_dev", "agc_hip_ref_get", "agc_hip_ref_index_get",
+    "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch",
+    "agc_hip_lz_estimate_batch_dev", "agc_hip_lz_estimate_batch",
+    "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
+    "agc_hip_ref_lag_counts_dev",
+]
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+class AgcHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"agc_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libagc_hip.so; raises if it was not built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; importing torch
+    # first makes libagc_hip.so bind to that already-loaded runtime (same SONAME) instead of
+    # pulling in a second copy from /opt/rocm, after which torch would see no GPUs.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m agc_amd.build` (hipcc, gfx950) first")
+    L = C.CDLL(LIB_PATH)
+    L.agc_hip_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.agc_hip_destroy.argtypes = [vp]
+    L.agc_hip_destroy.restype = None
+    L.agc_hip_last_error.argtypes = [vp]
+    L.agc_hip_last_error.restype = C.c_char_p
+    L.agc_hip_abi_version.restype = C.c_uint32
+    L.agc_hip_sync.argtypes = [vp]
+    L.agc_hip_timing_enable.argtypes = [vp, C.c_int]
+    L.agc_hip_timing_reset.argtypes = [vp]
+    L.agc_hip_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
+    L.agc_hip_preprocess_dev.argtypes = [vp, vp, C.c_uint64, vp, u64p]
+    L.agc_hip_splitters_set.argtypes = [vp, u64p, C.c_uint64]
+    L.agc_hip_splitters_insert.argtypes = [vp, u64p, C.c_uint64]
+    L.agc_hip_splitters_count.argtypes = [vp]
+    L.agc_hip_splitters_count.restype = C.c_uint64
+    scan_tail = [u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
+    L.agc_hip_scan_contigs_dev.argtypes = [vp, vp] + scan_tail
+    L.agc_hip_scan_contigs.argtypes = [vp, u8p] + scan_tail
+    L.agc_hip_ref_register.argtypes = [vp, C.c_uint32, u8p, C.c_uint32, C.c_uint32]
+    L.agc_hip_ref_register_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, C.c_uint32]
+    L.agc_hip_ref_get.argtypes = [vp, C.c_uint32, u8p, C.c_uint32, u32p]
+    L.agc_hip_ref_index_get.argtypes = [vp, C.c_uint32, u32p, C.c_uint64, u64p, C.POINTER(C.c_int)]
+    L.agc_hip_lz_encode_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
+    L.agc_hip_lz_encode_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
+    L.agc_hip_lz_estimate_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u32p, u32p]
+    L.agc_hip_lz_estimate_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u32p, u32p]
+    L.agc_hip_lz_cost_vector_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u8p, u32p]
+    L.agc_hip_lz_cost_vector_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u8p, u32p]
+    L.agc_hip_ref_lag_counts_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u32p, u32p]
+    for s in SYMBOLS:
+        f = getattr(L, s)
+        if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _a(x, dt):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Context:
+    """One agc_hip_ctx (one GPU, one stream)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = vp()
+        rc = self.L.agc_hip_create(C.byref(h), device)
+        if rc != OK:
+            raise AgcHipError(rc, "agc_hip_create failed (no HIP device?)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.agc_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise AgcHipError(rc, self.L.agc_hip_last_error(self.h).decode())
+
+    # ---- timing -----------------------------------------------------------
+    def timing(self, on=True):
+        self._chk(self.L.agc_hip_timing_enable(self.h, int(on)))
+        self._chk(self.L.agc_hip_timing_reset(self.h))
+
+    def timing_get(self):
+        out = {}
+        for i, n in enumerate(K_NAMES):
+            ms = C.c_double()
+            ln = C.c_uint64()
+            self._chk(self.L.agc_hip_timing_get(self.h, i, C.byref(ms), C.byref(ln)))
+            out[n] = (ms.value, ln.value)
+        return out
+
+    # ---- a1 -----------------------------------------------------------------
+    def preprocess_dev(self, d_raw, n_raw, d_codes):
+        n = C.c_uint64()
+        self._chk(self.L.agc_hip_preprocess_dev(self.h, d_raw, n_raw, d_codes, C.byref(n)))
+        return n.value
+
+    # ---- splitters / scan ---------------------------------------------------
+    def splitters_set(self, kmers):
+        k = _a(kmers, np.uint64)
+        self._chk(self.L.agc_hip_splitters_set(self.h, _p(k, u64p), k.size))
+
+    def splitters_insert(self, kmers):
+        k = _a(kmers, np.uint64)
+        self._chk(self.L.agc_hip_splitters_insert(self.h, _p(k, u64p), k.size))
+
+    def splitters_count(self):
+        return int(self.L.agc_hip_splitters_count(self.h))
+
+    def _scan(self, fn, codes_arg, ctg_off, k, cap):
+        off = _a(ctg_off, np.uint64)
+        n_ctg = off.size - 1
+        while True:
+            n = C.c_uint64()
+            ctg = np.zeros(cap, np.uint32)
+            pos = np.zeros(cap, np.uint64)
+            d = np.zeros(cap, np.uint64)
+            r = np.zeros(cap, np.uint64)
+            rc = fn(self.h, codes_arg, _p(off, u64p), n_ctg, k, cap, C.byref(n), _p(ctg, u32p), _p(pos, u64p), _p(d, u64p), _p(r, u64p))
+            if rc == ECAP:
+                cap = int(n.value)
+                continue
+            self._chk(rc)
+            m = int(n.value)
+            return ctg[:m], pos[:m], d[:m], r[:m]
+
+    def scan_contigs_dev(self, d_codes, ctg_off, k, cap=1 << 16):
+        """-> (ctg, pos, dir, rc) of the accepted splitter hits."""
+        return self._scan(self.L.agc_hip_scan_contigs_dev, d_codes, ctg_off, k, cap)
+
+    def scan_contigs(self, codes, ctg_off, k, cap=1 << 16):
+        codes = _a(codes, np.uint8)
+        return self._scan(self.L.agc_hip_scan_contigs, _p(codes, u8p), ctg_off, k, cap)
+
+    # ---- references ---------------------------------------------------------
+    def ref_register(self, gid, ref, min_match_len):
+        ref = _a(ref, np.uint8)
+        self._chk(self.L.agc_hip_ref_register(self.h, gid, _p(ref, u8p), ref.size, min_match_len))
+
+    def ref_register_batch_dev(self, gids, d_base, off, length, rc, min_match_len):
+        g, o, l = _a(gids, np.uint32), _a(off, np.uint64), _a(length, np.uint32)
+        r = _a(rc, np.uint8) if rc is not None else None
+        self._chk(self.L.agc_hip_ref_register_batch_dev(self.h, g.size, _p(g, u32p), d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p), min_match_len))
+
+    def ref_get(self, gid):
+        n = C.c_uint32()
+        rc = self.L.agc_hip_ref_get(self.h, gid, None, 0, C.byref(n))
+        if rc not in (OK, ECAP):
+            self._chk(rc)
+        out = np.zeros(n.value, np.uint8)
+        self._chk(self.L.agc_hip_ref_get(self.h, gid, _p(out, u8p), out.size, C.byref(n)))
+        return out
+
+    def ref_index_get(self, gid):
+        hs = C.c_uint64()
+        is16 = C.c_int()
+        rc = self.L.agc_hip_ref_index_get(self.h, gid, None, 0, C.byref(hs), C.byref(is16))
+        if rc not in (OK, ECAP):
+            self._chk(rc)
+        out = np.zeros(hs.value, np.uint32)
+        self._chk(self.L.agc_hip_ref_index_get(self.h, gid, _p(out, u32p), out.size, C.byref(hs), C.byref(is16)))
+        return out, bool(is16.value)
+
+    # ---- parse batches ------------------------------------------------------
+    @staticmethod
+    def _batch(gids, off, length, rc):
+        g, o, l = _a(gids, np.uint32), _a(off, np.uint64), _a(length, np.uint32)
+        r = _a(rc, np.uint8) if rc is not None else None
+        assert g.size == o.size == l.size and (r is None or r.size == g.size)
+        return g, o, l, r
+
+    def _encode(self, fn, base, gids, off, length, rc, enc_cap):
+        g, o, l, r = self._batch(gids, off, length, rc)
+        if enc_cap is None:
+            enc_cap = int(l.astype(np.uint64).sum()) * 21 // 16 + 64 * g.size + 64
+        enc = np.empty(enc_cap, np.uint8)
+        eoff = np.zeros(g.size + 1, np.uint64)
+        self._chk(fn(self.h, g.size, _p(g, u32p), base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(enc, u8p), enc_cap, _p(eoff, u64p)))
+        return enc[:int(eoff[-1])], eoff
+
+    def lz_encode_batch_dev(self, d_base, gids, off, length, rc=None, enc_cap=None):
+        """-> (enc bytes, enc_off[n+1])"""
+        return self._encode(self.L.agc_hip_lz_encode_batch_dev, d_base, gids, off, length, rc, enc_cap)
+
+    def lz_encode_batch(self, text, gids, off, length, rc=None, enc_cap=None):
+        text = _a(text, np.uint8)
+        return self._encode(self.L.agc_hip_lz_encode_batch, _p(text, u8p), gids, off, length, rc, enc_cap)
+
+    def _estimate(self, fn, base, gids, off, length, rc):
+        g, o, l, r = self._batch(gids, off, length, rc)
+        cost = np.zeros(g.size, np.uint32)
+        peak = np.zeros(g.size, np.uint32)
+        self._chk(fn(self.h, g.size, _p(g, u32p), base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(cost, u32p), _p(peak, u32p)))
+        return cost, peak
+
+    def lz_estimate_batch_dev(self, d_base, gids, off, length, rc=None):
+        return self._estimate(self.L.agc_hip_lz_estimate_batch_dev, d_base, gids, off, length, rc)
+
+    def lz_estimate_batch(self, text, gids, off, length, rc=None):
+        text = _a(text, np.uint8)
+        return self._estimate(self.L.agc_hip_lz_estimate_batch, _p(text, u8p), gids, off, length, rc)
+
+    def _costvec(self, fn, base, gids, off, length, rc, prefix):
+        g, o, l, r = self._batch(gids, off, length, rc)
+        pf = _a(prefix, np.uint8)
+        costs = np.zeros(int(l.astype(np.uint64).sum()), np.uint32)
+        self._chk(fn(self.h, g.size, _p(g, u32p), base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(pf, u8p), _p(costs, u32p)))
+        return costs
+
+    def lz_cost_vector_batch_dev(self, d_base, gids, off, length, rc, prefix):
+        return self._costvec(self.L.agc_hip_lz_cost_vector_batch_dev, d_base, gids, off, length, rc, prefix)
+
+    def lz_cost_vector_batch(self, text, gids, off, length, rc, prefix):
+        text = _a(text, np.uint8)
+        return self._costvec(self.L.agc_hip_lz_cost_vector_batch, _p(text, u8p), gids, off, length, rc, prefix)
+
+    def ref_lag_counts_dev(self, d_base, off, length, rc=None):
+        o, l = _a(off, np.uint64), _a(length, np.uint32)
+        r = _a(rc, np.uint8) if rc is not None else None
+        cnt = np.zeros((o.size, 28), np.uint32)
+        cur = np.zeros((o.size, 28), np.uint32)
+        self._chk(self.L.agc_hip_ref_lag_counts_dev(self.h, o.size, d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(cnt, u32p), _p(cur, u32p)))
+        return cnt, cur

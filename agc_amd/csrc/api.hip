@@ -1,0 +1,875 @@
+// api.hip -- the C ABI of include/agc_hip.h: context, HBM arenas, kernel launches.
+// Host-side logic here is orchestration only (buffer management, sorting sparse hit
+// lists, sizing tables with the reference's double arithmetic); all symbol-level work is
+// done by the kernels in scan_kernels.hip / lz_kernels.hip.  There is no CPU fallback.
+#include "../../include/agc_hip.h"
+#include "dev_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "scan_kernels.hip"
+#include "lz_kernels.hip"
+
+using namespace agc;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct ArenaChunk {
+    uint8_t *p;
+    size_t size, used;
+};
+
+} // namespace
+
+struct agc_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // splitter set
+    std::vector<uint64_t> spl;       // host copy (unique)
+    DevBuf d_table, d_bloom;
+    uint64_t table_mask = 0;
+
+    // references
+    std::vector<RefDesc> refs;       // indexed by gid
+    DevBuf d_refs;
+    bool refs_dirty = true;
+    std::vector<ArenaChunk> arena;
+
+    // scratch
+    DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_stage, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
+        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag;
+
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double ms[AGC_HIP_K_COUNT] = {0};
+    uint64_t launches[AGC_HIP_K_COUNT] = {0};
+};
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return e_ == hipErrorOutOfMemory ? AGC_HIP_ENOMEM : AGC_HIP_ENODEV;                    \
+        }                                                                                          \
+    } while (0)
+
+#define CHK(expr)                                                                                  \
+    do {                                                                                           \
+        int r_ = (expr);                                                                           \
+        if (r_ != AGC_HIP_OK)                                                                      \
+            return r_;                                                                             \
+    } while (0)
+
+namespace {
+
+int ensure(agc_hip_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return AGC_HIP_OK;
+    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    want = (want + 255) & ~(size_t)255;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return AGC_HIP_OK;
+}
+
+int arena_alloc(agc_hip_ctx *c, size_t bytes, uint8_t **out)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (c->arena.empty() || c->arena.back().used + bytes > c->arena.back().size) {
+        size_t sz = std::max(bytes, (size_t)256 << 20);
+        uint8_t *p = nullptr;
+        HIPCHK(c, hipMalloc((void **)&p, sz + 4096)); // tail slack: 16-byte over-reads never leave the allocation
+        c->arena.push_back({p, sz, 0});
+    }
+    ArenaChunk &ch = c->arena.back();
+    *out = ch.p + ch.used;
+    ch.used += bytes;
+    return AGC_HIP_OK;
+}
+
+struct KTimer {
+    agc_hip_ctx *c;
+    int which;
+    KTimer(agc_hip_ctx *c_, int w) : c(c_), which(w)
+    {
+        if (c->timing)
+            (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~KTimer()
+    {
+        if (c->timing) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->ms[which] += ms;
+            c->launches[which] += 1;
+        }
+    }
+};
+
+int upload_refs(agc_hip_ctx *c)
+{
+    if (!c->refs_dirty)
+        return AGC_HIP_OK;
+    CHK(ensure(c, c->d_refs, std::max<size_t>(1, c->refs.size()) * sizeof(RefDesc)));
+    if (!c->refs.empty())
+        HIPCHK(c, hipMemcpyAsync(c->d_refs.p, c->refs.data(), c->refs.size() * sizeof(RefDesc), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // refs vector may be reallocated by the caller's next register
+    c->refs_dirty = false;
+    return AGC_HIP_OK;
+}
+
+uint32_t grid_for(uint32_t n_items, uint32_t per_block, uint32_t max_blocks)
+{
+    uint64_t b = ((uint64_t)n_items + per_block - 1) / per_block;
+    if (b < 1)
+        b = 1;
+    return (uint32_t)std::min<uint64_t>(b, max_blocks);
+}
+
+} // namespace
+
+// ===========================================================================
+extern "C" {
+
+uint32_t agc_hip_abi_version(void) { return 1; }
+
+int agc_hip_create(agc_hip_ctx **out, int device)
+{
+    if (!out)
+        return AGC_HIP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return AGC_HIP_ENODEV;
+    agc_hip_ctx *c = new agc_hip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return AGC_HIP_ENODEV;
+    }
+    *out = c;
+    return AGC_HIP_OK;
+}
+
+void agc_hip_destroy(agc_hip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
+                      &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
+                      &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag};
+    for (DevBuf *b : bufs)
+        if (b->p)
+            (void)hipFree(b->p);
+    for (auto &ch : c->arena)
+        (void)hipFree(ch.p);
+    if (c->ev0)
+        (void)hipEventDestroy(c->ev0);
+    if (c->ev1)
+        (void)hipEventDestroy(c->ev1);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *agc_hip_last_error(const agc_hip_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int agc_hip_sync(agc_hip_ctx *c)
+{
+    if (!c)
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+int agc_hip_timing_enable(agc_hip_ctx *c, int on)
+{
+    if (!c)
+        return AGC_HIP_EINVAL;
+    c->timing = on != 0;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_timing_reset(agc_hip_ctx *c)
+{
+    if (!c)
+        return AGC_HIP_EINVAL;
+    for (int i = 0; i < AGC_HIP_K_COUNT; ++i) {
+        c->ms[i] = 0;
+        c->launches[i] = 0;
+    }
+    return AGC_HIP_OK;
+}
+
+int agc_hip_timing_get(agc_hip_ctx *c, int which, double *ms, uint64_t *launches)
+{
+    if (!c || which < 0 || which >= AGC_HIP_K_COUNT)
+        return AGC_HIP_EINVAL;
+    if (ms)
+        *ms = c->ms[which];
+    if (launches)
+        *launches = c->launches[which];
+    return AGC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a1
+// ---------------------------------------------------------------------------
+int agc_hip_preprocess_dev(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw, uint8_t *d_codes, uint64_t *h_n_codes)
+{
+    if (!c || !h_n_codes || (n_raw && (!d_raw || !d_codes)))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    *h_n_codes = 0;
+    if (!n_raw)
+        return AGC_HIP_OK;
+    const uint64_t nb64 = (n_raw + PP_TILE - 1) / PP_TILE;
+    if (nb64 > 0x7fffffffULL)
+        return AGC_HIP_EINVAL;
+    const uint32_t nb = (uint32_t)nb64;
+    CHK(ensure(c, c->d_pp_cnt, (size_t)nb * 4));
+    CHK(ensure(c, c->d_pp_off, (size_t)nb * 8));
+    CHK(ensure(c, c->d_pp_total, 8));
+    {
+        KTimer t(c, AGC_HIP_K_PREPROCESS);
+        hipLaunchKernelGGL(pp_count_kernel, dim3(nb), dim3(256), 0, c->stream, d_raw, n_raw, (uint32_t *)c->d_pp_cnt.p);
+        hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)c->d_pp_cnt.p, nb,
+                           (uint64_t *)c->d_pp_off.p, (uint64_t *)c->d_pp_total.p);
+        hipLaunchKernelGGL(pp_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, d_raw, n_raw, (const uint64_t *)c->d_pp_off.p, d_codes);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_n_codes, c->d_pp_total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// splitters
+// ---------------------------------------------------------------------------
+static int splitters_upload(agc_hip_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t cap = 1024;
+    while (cap < 2 * (uint64_t)c->spl.size())
+        cap <<= 1;
+    std::vector<uint64_t> tab(cap, ~0ULL);
+    std::vector<uint32_t> bloom(BLOOM_WORDS, 0);
+    for (uint64_t x : c->spl) {
+        const uint64_t h = splitter_hash(x);
+        uint64_t s = h & (cap - 1);
+        while (tab[s] != ~0ULL)
+            s = (s + 1) & (cap - 1);
+        tab[s] = x;
+        uint32_t w, m;
+        bloom_slot(h, w, m);
+        bloom[w] |= m;
+    }
+    CHK(ensure(c, c->d_table, cap * 8));
+    CHK(ensure(c, c->d_bloom, BLOOM_WORDS * 4));
+    HIPCHK(c, hipMemcpyAsync(c->d_table.p, tab.data(), cap * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_bloom.p, bloom.data(), BLOOM_WORDS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->table_mask = cap - 1;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_splitters_set(agc_hip_ctx *c, const uint64_t *h_kmers, uint64_t n)
+{
+    if (!c || (n && !h_kmers))
+        return AGC_HIP_EINVAL;
+    c->spl.assign(h_kmers, h_kmers + n);
+    std::sort(c->spl.begin(), c->spl.end());
+    c->spl.erase(std::unique(c->spl.begin(), c->spl.end()), c->spl.end());
+    return splitters_upload(c);
+}
+
+int agc_hip_splitters_insert(agc_hip_ctx *c, const uint64_t *h_kmers, uint64_t n)
+{
+    if (!c || (n && !h_kmers))
+        return AGC_HIP_EINVAL;
+    c->spl.insert(c->spl.end(), h_kmers, h_kmers + n);
+    std::sort(c->spl.begin(), c->spl.end());
+    c->spl.erase(std::unique(c->spl.begin(), c->spl.end()), c->spl.end());
+    return splitters_upload(c);
+}
+
+uint64_t agc_hip_splitters_count(const agc_hip_ctx *c) { return c ? c->spl.size() : 0; }
+
+// ---------------------------------------------------------------------------
+// scan
+// ---------------------------------------------------------------------------
+int agc_hip_scan_contigs_dev(agc_hip_ctx *c, const uint8_t *d_codes, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                             uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir,
+                             uint64_t *h_hit_rc)
+{
+    if (!c || !h_ctg_off || !h_n_hits || k < 2 || k > 32)
+        return AGC_HIP_EINVAL;
+    if (cap && (!h_hit_ctg || !h_hit_pos || !h_hit_dir || !h_hit_rc))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    *h_n_hits = 0;
+    if (!c->d_table.p)
+        CHK(splitters_upload(c)); // empty set
+    const uint64_t total = n_ctg ? h_ctg_off[n_ctg] - h_ctg_off[0] : 0;
+    if (!total)
+        return AGC_HIP_OK;
+    if (!d_codes)
+        return AGC_HIP_EINVAL;
+
+    // ranges: contigs cut into pieces of range_len symbols (multiple of one 1 KiB wave step)
+    const uint64_t target_waves = 8192ULL * 4;
+    uint64_t range_len = (total / target_waves + 1023) / 1024 * 1024;
+    range_len = std::min<uint64_t>(std::max<uint64_t>(range_len, 4096), 65536);
+    std::vector<ScanRange> ranges;
+    for (uint32_t ci = 0; ci < n_ctg; ++ci) {
+        const uint64_t b = h_ctg_off[ci], e = h_ctg_off[ci + 1];
+        if (e < b)
+            return AGC_HIP_EINVAL;
+        if (e - b < k)
+            continue;
+        for (uint64_t p = b; p < e; p += range_len)
+            ranges.push_back({b, e, p, std::min(e, p + range_len)});
+    }
+    if (ranges.empty())
+        return AGC_HIP_OK;
+    if (ranges.size() > 0x7fffffffULL)
+        return AGC_HIP_EINVAL;
+    CHK(ensure(c, c->d_ranges, ranges.size() * sizeof(ScanRange)));
+    CHK(ensure(c, c->d_counter, 64));
+    HIPCHK(c, hipMemcpyAsync(c->d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), hipMemcpyHostToDevice, c->stream));
+
+    uint32_t dev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(total / 2000 + 4096, c->d_hits.cap / sizeof(ScanHit)), 1u << 30);
+    uint32_t n_found = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        CHK(ensure(c, c->d_hits, (size_t)dev_cap * sizeof(ScanHit)));
+        HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 4, c->stream));
+        ScanArgs a;
+        a.codes = d_codes;
+        a.ranges = (const ScanRange *)c->d_ranges.p;
+        a.n_ranges = (uint32_t)ranges.size();
+        a.k = k;
+        a.table = (const uint64_t *)c->d_table.p;
+        a.table_mask = c->table_mask;
+        a.bloom = (const uint32_t *)c->d_bloom.p;
+        a.hits = (ScanHit *)c->d_hits.p;
+        a.n_hits = (uint32_t *)c->d_counter.p;
+        a.cap = dev_cap;
+        const uint32_t grid = grid_for((uint32_t)ranges.size(), 16, 512);
+        {
+            KTimer t(c, AGC_HIP_K_SCAN);
+            hipLaunchKernelGGL(scan_kernel, dim3(grid), dim3(1024), 0, c->stream, a);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&n_found, c->d_counter.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_found <= dev_cap)
+            break;
+        dev_cap = n_found;
+    }
+    std::vector<ScanHit> hits(n_found);
+    if (n_found) {
+        HIPCHK(c, hipMemcpyAsync(hits.data(), c->d_hits.p, (size_t)n_found * sizeof(ScanHit), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    std::sort(hits.begin(), hits.end(), [](const ScanHit &x, const ScanHit &y) { return x.pos < y.pos; });
+
+    // accept_hits: after a hit the reference resets the k-mer (agc_compressor.cpp:2029), so the next
+    // hit of the same contig must end at least k symbols later.
+    uint64_t n_acc = 0;
+    uint32_t ci = 0;
+    bool have_last = false;
+    uint64_t last = 0;
+    for (const ScanHit &h : hits) {
+        while (ci + 1 < n_ctg && h.pos >= h_ctg_off[ci + 1]) {
+            ++ci;
+            have_last = false;
+        }
+        if (have_last && h.pos < last + k)
+            continue;
+        have_last = true;
+        last = h.pos;
+        if (n_acc < cap) {
+            h_hit_ctg[n_acc] = ci;
+            h_hit_pos[n_acc] = h.pos - h_ctg_off[ci];
+            h_hit_dir[n_acc] = h.dir;
+            h_hit_rc[n_acc] = h.rc;
+        }
+        ++n_acc;
+    }
+    *h_n_hits = n_acc;
+    return n_acc > cap ? AGC_HIP_ECAP : AGC_HIP_OK;
+}
+
+int agc_hip_scan_contigs(agc_hip_ctx *c, const uint8_t *h_codes, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                         uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir,
+                         uint64_t *h_hit_rc)
+{
+    if (!c || !h_ctg_off)
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t lo = n_ctg ? h_ctg_off[0] : 0, hi = n_ctg ? h_ctg_off[n_ctg] : 0;
+    if (hi > lo && !h_codes)
+        return AGC_HIP_EINVAL;
+    CHK(ensure(c, c->d_in, (hi - lo) + 64));
+    if (hi > lo)
+        HIPCHK(c, hipMemcpyAsync(c->d_in.p, h_codes + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint64_t> off(n_ctg + 1, 0);
+    for (uint32_t i = 0; i <= n_ctg && n_ctg; ++i)
+        off[i] = h_ctg_off[i] - lo;
+    return agc_hip_scan_contigs_dev(c, (const uint8_t *)c->d_in.p, off.data(), n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos,
+                                    h_hit_dir, h_hit_rc);
+}
+
+// ---------------------------------------------------------------------------
+// references
+// ---------------------------------------------------------------------------
+int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_gid, const uint8_t *d_base,
+                                   const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc, uint32_t min_match_len)
+{
+    if (!c || (n_refs && (!h_gid || !h_off || !h_len || !d_base)))
+        return AGC_HIP_EINVAL;
+    if (min_match_len < HASHING_STEP + 4 || min_match_len > 32)
+        return AGC_HIP_EINVAL; // key_len = mml-3 must fit 2 bits x key_len <= 58 and the wave's 64 lanes
+    if (!n_refs)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t key_len = min_match_len - HASHING_STEP + 1;
+    uint32_t max_gid = 0;
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        max_gid = std::max(max_gid, h_gid[i]);
+        if (h_gid[i] < c->refs.size() && c->refs[h_gid[i]].valid)
+            return AGC_HIP_EINVAL;
+    }
+    {
+        std::vector<uint32_t> g(h_gid, h_gid + n_refs);
+        std::sort(g.begin(), g.end());
+        if (std::adjacent_find(g.begin(), g.end()) != g.end())
+            return AGC_HIP_EINVAL;
+    }
+
+    // 1. store (optionally reverse-complemented) + pad with INVALID_SYMBOL
+    std::vector<SliceDesc> sl(n_refs);
+    std::vector<IdxBuild> jobs(n_refs);
+    size_t ref_bytes = 0;
+    std::vector<size_t> roff(n_refs);
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        roff[i] = ref_bytes;
+        ref_bytes += ((size_t)h_len[i] + key_len + REF_TAIL_PAD + 15) & ~(size_t)15;
+    }
+    uint8_t *rbase = nullptr;
+    CHK(arena_alloc(c, ref_bytes, &rbase));
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        sl[i].src = d_base + h_off[i];
+        sl[i].dst = rbase + roff[i];
+        sl[i].len = h_len[i];
+        sl[i].rc = h_rc ? h_rc[i] : 0;
+        sl[i].pad_len = key_len + REF_TAIL_PAD;
+        sl[i].pad2 = 0;
+        jobs[i].ref = rbase + roff[i];
+        jobs[i].table = nullptr;
+        jobs[i].ref_size = h_len[i];
+        jobs[i].key_len = key_len;
+        jobs[i].ht_mask = 0;
+        jobs[i].is_short = (h_len[i] / HASHING_STEP) < 65535u; // lz_diff.cpp:146
+    }
+    CHK(ensure(c, c->d_slices, (size_t)n_refs * sizeof(SliceDesc)));
+    CHK(ensure(c, c->d_jobs, (size_t)n_refs * sizeof(IdxBuild)));
+    CHK(ensure(c, c->d_counts, (size_t)n_refs * 4));
+    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n_refs * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
+    {
+        KTimer t(c, AGC_HIP_K_REFSTORE);
+        hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n_refs, 1, 65536)), dim3(256), 0, c->stream,
+                           (const SliceDesc *)c->d_slices.p, n_refs);
+    }
+    // 2. count keys -> table sizes (prepare_index, lz_diff.cpp:81-125: double division by 0.7,
+    //    round down to a power of two, double it, at least 8)
+    std::vector<uint32_t> counts(n_refs);
+    {
+        KTimer t(c, AGC_HIP_K_INDEX);
+        hipLaunchKernelGGL(idx_count_kernel, dim3(n_refs), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p,
+                           (uint32_t *)c->d_counts.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(counts.data(), c->d_counts.p, (size_t)n_refs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    size_t tab_bytes = 0;
+    std::vector<size_t> toff(n_refs);
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        uint64_t hs = (uint64_t)((double)counts[i] / 0.7);
+        while (hs & (hs - 1))
+            hs &= hs - 1;
+        hs <<= 1;
+        if (hs < 8)
+            hs = 8;
+        jobs[i].ht_mask = (uint32_t)(hs - 1);
+        toff[i] = tab_bytes;
+        tab_bytes += (size_t)hs * (jobs[i].is_short ? 4 : 8);
+        tab_bytes = (tab_bytes + 255) & ~(size_t)255;
+    }
+    uint8_t *tbase = nullptr;
+    CHK(arena_alloc(c, tab_bytes, &tbase));
+    HIPCHK(c, hipMemsetAsync(tbase, 0xFF, tab_bytes, c->stream));
+    for (uint32_t i = 0; i < n_refs; ++i)
+        jobs[i].table = tbase + toff[i];
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
+    {
+        KTimer t(c, AGC_HIP_K_INDEX);
+        hipLaunchKernelGGL(idx_insert_kernel, dim3(n_refs), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    if (c->refs.size() <= max_gid)
+        c->refs.resize((size_t)max_gid + 1, RefDesc{nullptr, nullptr, 0, 0, 0, 0, 0, 0});
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        RefDesc &r = c->refs[h_gid[i]];
+        r.ref = jobs[i].ref;
+        r.table = jobs[i].table;
+        r.ref_size = h_len[i];
+        r.ht_mask = jobs[i].ht_mask;
+        r.key_len = key_len;
+        r.min_match_len = min_match_len;
+        r.is_short = jobs[i].is_short;
+        r.valid = 1;
+    }
+    c->refs_dirty = true;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_ref_register(agc_hip_ctx *c, uint32_t gid, const uint8_t *h_ref, uint32_t n, uint32_t min_match_len)
+{
+    if (!c || (n && !h_ref))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure(c, c->d_in, (size_t)n + 64));
+    if (n)
+        HIPCHK(c, hipMemcpyAsync(c->d_in.p, h_ref, n, hipMemcpyHostToDevice, c->stream));
+    const uint64_t off = 0;
+    const uint8_t rc = 0;
+    return agc_hip_ref_register_batch_dev(c, 1, &gid, (const uint8_t *)c->d_in.p, &off, &n, &rc, min_match_len);
+}
+
+int agc_hip_ref_get(agc_hip_ctx *c, uint32_t gid, uint8_t *h_ref, uint32_t cap, uint32_t *h_n)
+{
+    if (!c || !h_n)
+        return AGC_HIP_EINVAL;
+    if (gid >= c->refs.size() || !c->refs[gid].valid)
+        return AGC_HIP_ENOREF;
+    HIPCHK(c, hipSetDevice(c->device));
+    const RefDesc &r = c->refs[gid];
+    *h_n = r.ref_size;
+    if (cap < r.ref_size)
+        return AGC_HIP_ECAP;
+    if (r.ref_size)
+        HIPCHK(c, hipMemcpy(h_ref, r.ref, r.ref_size, hipMemcpyDeviceToHost));
+    return AGC_HIP_OK;
+}
+
+int agc_hip_ref_index_get(agc_hip_ctx *c, uint32_t gid, uint32_t *h_table, uint64_t cap, uint64_t *h_ht_size, int *h_is16)
+{
+    if (!c || !h_ht_size || !h_is16)
+        return AGC_HIP_EINVAL;
+    if (gid >= c->refs.size() || !c->refs[gid].valid)
+        return AGC_HIP_ENOREF;
+    HIPCHK(c, hipSetDevice(c->device));
+    const RefDesc &r = c->refs[gid];
+    const uint64_t hs = (uint64_t)r.ht_mask + 1;
+    *h_ht_size = hs;
+    *h_is16 = r.is_short;
+    if (cap < hs)
+        return AGC_HIP_ECAP;
+    if (r.is_short) {
+        std::vector<uint32_t> t(hs);
+        HIPCHK(c, hipMemcpy(t.data(), r.table, hs * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < hs; ++i)
+            h_table[i] = t[i] == 0xFFFFFFFFu ? 0xFFFFu : (t[i] >> 16);
+    } else {
+        std::vector<uint64_t> t(hs);
+        HIPCHK(c, hipMemcpy(t.data(), r.table, hs * 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < hs; ++i)
+            h_table[i] = t[i] == ~0ULL ? 0xFFFFFFFFu : (uint32_t)(t[i] >> 32);
+    }
+    return AGC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// parse batches
+// ---------------------------------------------------------------------------
+} // extern "C"
+
+namespace {
+
+struct Batch {
+    std::vector<SegDesc> segs; // processing order (longest first); SegDesc.pad = original index
+    uint64_t out_total = 0;    // scratch units (bytes or u32s)
+};
+
+// Builds descriptors; reverse-complemented texts are materialised once in the staging buffer.
+int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+                  const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix, Batch &b)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        if (h_gid[i] >= c->refs.size() || !c->refs[h_gid[i]].valid) {
+            c->err = "group " + std::to_string(h_gid[i]) + " has no registered reference";
+            return AGC_HIP_ENOREF;
+        }
+    CHK(upload_refs(c));
+    // staging for rc texts
+    size_t stage = 0;
+    std::vector<size_t> soff(n, 0);
+    uint32_t n_rc = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (h_rc && h_rc[i]) {
+            soff[i] = stage;
+            stage += ((size_t)h_len[i] + 15) & ~(size_t)15;
+            ++n_rc;
+        }
+    if (n_rc) {
+        CHK(ensure(c, c->d_stage, stage + 64));
+        std::vector<SliceDesc> sl;
+        sl.reserve(n_rc);
+        for (uint32_t i = 0; i < n; ++i)
+            if (h_rc[i])
+                sl.push_back({d_base + h_off[i], (uint8_t *)c->d_stage.p + soff[i], h_len[i], 1u, 0u, 0u});
+        CHK(ensure(c, c->d_slices, sl.size() * sizeof(SliceDesc)));
+        HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), sl.size() * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
+        {
+            KTimer t(c, AGC_HIP_K_REVCOMP);
+            hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n_rc, 1, 65536)), dim3(256), 0, c->stream,
+                               (const SliceDesc *)c->d_slices.p, n_rc);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // sl is a local
+    }
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_len[x] > h_len[y]; });
+    std::vector<uint64_t> ooff(n);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        ooff[i] = tot;
+        if (mode == MODE_ENCODE)
+            tot += (((uint64_t)h_len[i] + 5ULL * h_len[i] / 16 + 64) + 15) & ~15ULL; // a >=16-symbol match costs <= 21 bytes
+        else if (mode == MODE_COSTVEC)
+            tot += h_len[i];
+    }
+    b.out_total = tot;
+    b.segs.resize(n);
+    for (uint32_t p = 0; p < n; ++p) {
+        const uint32_t i = order[p];
+        SegDesc &s = b.segs[p];
+        s.text = (h_rc && h_rc[i]) ? (const uint8_t *)c->d_stage.p + soff[i] : d_base + h_off[i];
+        s.out_off = ooff[i];
+        s.len = h_len[i];
+        s.ref_slot = h_gid[i];
+        s.flags = (h_prefix && h_prefix[i]) ? 1u : 0u;
+        s.pad = i;
+    }
+    CHK(ensure(c, c->d_segs, (size_t)n * sizeof(SegDesc)));
+    HIPCHK(c, hipMemcpyAsync(c->d_segs.p, b.segs.data(), (size_t)n * sizeof(SegDesc), hipMemcpyHostToDevice, c->stream));
+    CHK(ensure(c, c->d_counter, 64));
+    HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 4, c->stream));
+    CHK(ensure(c, c->d_resv, (size_t)n * 4));
+    CHK(ensure(c, c->d_resp, (size_t)n * 4));
+    return AGC_HIP_OK;
+}
+
+template <int MODE>
+int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32)
+{
+    const uint32_t grid = (n + 3) / 4; // one wave per segment, 4 waves per block
+    {
+        KTimer t(c, MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, c->stream, (const RefDesc *)c->d_refs.p,
+                           (const SegDesc *)c->d_segs.p, n, out_bytes, out_u32, (uint32_t *)c->d_resv.p, (uint32_t *)c->d_resp.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    return AGC_HIP_OK;
+}
+
+int stage_host_texts(agc_hip_ctx *c, uint32_t n, const uint8_t *h_text, const uint64_t *h_off, const uint32_t *h_len,
+                     std::vector<uint64_t> &doff)
+{
+    doff.resize(n);
+    size_t tot = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        doff[i] = tot;
+        tot += ((size_t)h_len[i] + 15) & ~(size_t)15;
+    }
+    CHK(ensure(c, c->d_in, tot + 64));
+    for (uint32_t i = 0; i < n; ++i)
+        if (h_len[i])
+            HIPCHK(c, hipMemcpyAsync((uint8_t *)c->d_in.p + doff[i], h_text + h_off[i], h_len[i], hipMemcpyHostToDevice, c->stream));
+    return AGC_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off || (n && (!h_gid || !h_off || !h_len || !d_base)))
+        return AGC_HIP_EINVAL;
+    h_enc_off[0] = 0;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Batch b;
+    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, d_base, h_off, h_len, h_rc, nullptr, b));
+    CHK(ensure(c, c->d_scratch, b.out_total + 64));
+    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)c->d_scratch.p, nullptr));
+    std::vector<uint32_t> lens(n);
+    HIPCHK(c, hipMemcpyAsync(lens.data(), c->d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i)
+        h_enc_off[i + 1] = h_enc_off[i] + lens[i];
+    const uint64_t tot = h_enc_off[n];
+    if (tot > enc_cap)
+        return AGC_HIP_ECAP;
+    if (!tot)
+        return AGC_HIP_OK;
+    if (!h_enc)
+        return AGC_HIP_EINVAL;
+    CHK(ensure(c, c->d_dstoff, (size_t)n * 8));
+    CHK(ensure(c, c->d_compact, tot));
+    HIPCHK(c, hipMemcpyAsync(c->d_dstoff.p, h_enc_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(gather_bytes_kernel, dim3(grid_for(n, 1, 8192)), dim3(256), 0, c->stream, (const uint8_t *)c->d_scratch.p,
+                       (const SegDesc *)c->d_segs.p, (const uint32_t *)c->d_resv.p, (const uint64_t *)c->d_dstoff.p, n,
+                       (uint8_t *)c->d_compact.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_enc, c->d_compact.p, tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+                                  const uint32_t *h_len, const uint8_t *h_rc, uint32_t *h_cost, uint32_t *h_peak)
+{
+    if (!c || (n && (!h_gid || !h_off || !h_len || !d_base || !h_cost)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Batch b;
+    CHK(prepare_batch(c, MODE_ESTIMATE, n, h_gid, d_base, h_off, h_len, h_rc, nullptr, b));
+    CHK(launch_parse<MODE_ESTIMATE>(c, n, nullptr, nullptr));
+    HIPCHK(c, hipMemcpyAsync(h_cost, c->d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_peak)
+        HIPCHK(c, hipMemcpyAsync(h_peak, c->d_resp.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_cost_vector_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base,
+                                     const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
+                                     const uint8_t *h_prefix_costs, uint32_t *h_costs)
+{
+    if (!c || (n && (!h_gid || !h_off || !h_len || !d_base || !h_costs)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Batch b;
+    CHK(prepare_batch(c, MODE_COSTVEC, n, h_gid, d_base, h_off, h_len, h_rc, h_prefix_costs, b));
+    CHK(ensure(c, c->d_scratch, b.out_total * 4 + 64));
+    CHK(launch_parse<MODE_COSTVEC>(c, n, nullptr, (uint32_t *)c->d_scratch.p));
+    if (b.out_total)
+        HIPCHK(c, hipMemcpyAsync(h_costs, c->d_scratch.p, b.out_total * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+// host-resident texts --------------------------------------------------------
+int agc_hip_lz_encode_batch(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *h_text, const uint64_t *h_off,
+                            const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
+{
+    if (!c || (n && (!h_text || !h_off || !h_len)))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> doff;
+    CHK(stage_host_texts(c, n, h_text, h_off, h_len, doff));
+    return agc_hip_lz_encode_batch_dev(c, n, h_gid, (const uint8_t *)c->d_in.p, doff.data(), h_len, h_rc, h_enc, enc_cap, h_enc_off);
+}
+
+int agc_hip_lz_estimate_batch(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *h_text, const uint64_t *h_off,
+                              const uint32_t *h_len, const uint8_t *h_rc, uint32_t *h_cost, uint32_t *h_peak)
+{
+    if (!c || (n && (!h_text || !h_off || !h_len)))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> doff;
+    CHK(stage_host_texts(c, n, h_text, h_off, h_len, doff));
+    return agc_hip_lz_estimate_batch_dev(c, n, h_gid, (const uint8_t *)c->d_in.p, doff.data(), h_len, h_rc, h_cost, h_peak);
+}
+
+int agc_hip_lz_cost_vector_batch(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *h_text, const uint64_t *h_off,
+                                 const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix_costs, uint32_t *h_costs)
+{
+    if (!c || (n && (!h_text || !h_off || !h_len)))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> doff;
+    CHK(stage_host_texts(c, n, h_text, h_off, h_len, doff));
+    return agc_hip_lz_cost_vector_batch_dev(c, n, h_gid, (const uint8_t *)c->d_in.p, doff.data(), h_len, h_rc, h_prefix_costs,
+                                            h_costs);
+}
+
+// ---------------------------------------------------------------------------
+// a13 helper
+// ---------------------------------------------------------------------------
+int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base, const uint64_t *h_off, const uint32_t *h_len,
+                               const uint8_t *h_rc, uint32_t *h_cnt, uint32_t *h_cur)
+{
+    if (!c || (n && (!d_base || !h_off || !h_len || !h_cnt || !h_cur)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<SliceDesc> sl(n);
+    for (uint32_t i = 0; i < n; ++i)
+        sl[i] = {d_base + h_off[i], nullptr, h_len[i], h_rc ? (uint32_t)h_rc[i] : 0u, 0u, 0u};
+    CHK(ensure(c, c->d_slices, (size_t)n * sizeof(SliceDesc)));
+    CHK(ensure(c, c->d_lag, (size_t)n * 28 * 4 * 2));
+    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
+    uint32_t *d_cnt = (uint32_t *)c->d_lag.p, *d_cur = d_cnt + (size_t)n * 28;
+    {
+        KTimer t(c, AGC_HIP_K_REFSTORE);
+        hipLaunchKernelGGL(lag_counts_kernel, dim3(n), dim3(256), 0, c->stream, (const SliceDesc *)c->d_slices.p, d_cnt, d_cur);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_cur, d_cur, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,93 @@
+// dev_common.h -- shared device structs and helpers (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace agc {
+
+constexpr uint32_t WAVE = 64;
+constexpr uint32_t HASHING_STEP = 4;     // lz_diff.h:38 (USE_SPARSE_HT)
+constexpr uint32_t MAX_NO_TRIES = 64;    // lz_diff.h:32
+constexpr uint8_t INVALID_SYMBOL = 31;   // lz_diff.h:33
+constexpr uint8_t N_CODE = 4;            // lz_diff.h:34
+constexpr uint8_t N_RUN_STARTER = 30;    // lz_diff.h:35
+constexpr uint32_t MIN_NRUN_LEN = 4;     // lz_diff.h:36
+constexpr uint32_t REF_TAIL_PAD = 64;    // bytes of INVALID_SYMBOL kept after every stored reference
+
+// One registered group reference in HBM.
+// Index entries: short form (ref/4 < 65535, lz_diff.cpp:146): u32 = pos16<<16 | fp16,
+// long form: u64 = pos32<<32 | fp32.  pos = ref position / 4 exactly as ht16/ht32
+// hold it; fp = fingerprint of the key's hash (filter only; every candidate is
+// verified against the reference bytes).  All-ones = empty.
+struct RefDesc {
+    const uint8_t *ref;   // ref_size symbols + >= key_len + REF_TAIL_PAD bytes of 31
+    const void *table;    // ht_mask+1 entries
+    uint32_t ref_size;
+    uint32_t ht_mask;
+    uint32_t key_len;
+    uint32_t min_match_len;
+    uint32_t is_short;
+    uint32_t valid;
+};
+
+// One sequence to parse.
+struct SegDesc {
+    const uint8_t *text;  // oriented symbols (already reverse-complemented if needed)
+    uint64_t out_off;     // encode: byte offset in the scratch output; cost vector: u32 offset
+    uint32_t len;
+    uint32_t ref_slot;    // index into the RefDesc array
+    uint32_t flags;       // bit0: prefix_costs (cost-vector mode)
+    uint32_t pad;
+};
+
+struct SliceDesc {
+    const uint8_t *src;
+    uint8_t *dst;
+    uint32_t len;
+    uint32_t rc;          // reverse-complement while copying
+    uint32_t pad_len;     // bytes of INVALID_SYMBOL appended after dst[len)
+    uint32_t pad2;
+};
+
+struct ScanRange {
+    uint64_t ctg_begin;   // absolute offset of the contig's first symbol
+    uint64_t ctg_end;     // absolute offset one past its last symbol
+    uint64_t begin;       // first position (absolute) whose k-mer END this range reports
+    uint64_t end;         // one past the last
+};
+
+struct ScanHit {
+    uint64_t pos;         // absolute offset of the LAST symbol of the k-mer
+    uint64_t dir;         // left-aligned, as CKmer::kmer_dir (kmer.h:284-301)
+    uint64_t rc;          // left-aligned, as CKmer::kmer_rc
+};
+
+// MurMur64Hash, src/common/utils.h:164-176 (bit-relevant: LZ index slots)
+__host__ __device__ inline uint64_t murmur64(uint64_t h)
+{
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdULL;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ULL;
+    h ^= h >> 33;
+    return h;
+}
+
+// hash of the build's own splitter table / bloom (free choice: membership is exact)
+__host__ __device__ inline uint64_t splitter_hash(uint64_t x)
+{
+    x ^= x >> 29;
+    x *= 0x9E3779B97F4A7C15ULL;
+    x ^= x >> 32;
+    return x;
+}
+
+constexpr uint32_t BLOOM_WORDS = 16384;  // 64 KiB of LDS
+
+__host__ __device__ inline void bloom_slot(uint64_t h, uint32_t &word, uint32_t &mask)
+{
+    word = (uint32_t)(h >> 50) & (BLOOM_WORDS - 1);
+    mask = (1u << ((uint32_t)(h >> 45) & 31)) | (1u << ((uint32_t)(h >> 40) & 31));
+}
+
+} // namespace agc

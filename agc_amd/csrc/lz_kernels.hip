@@ -1,0 +1,671 @@
+// lz_kernels.hip -- LZ-diff index build and parse kernels for gfx950 (wave64).
+//
+// Reference behaviour reproduced bit-exactly (file:line under the reference tree):
+//   index build  CLZDiffBase::prepare_index / make_index16/32   src/common/lz_diff.cpp:81-141, 375-428
+//   best match   CLZDiffBase::find_best_match16/32              src/common/lz_diff.cpp:287-372
+//   encode       CLZDiff_V2::Encode                             src/common/lz_diff.cpp:669-798
+//   estimate     CLZDiff_V2::Estimate                           src/common/lz_diff.cpp:839-946
+//   cost vector  CLZDiffBase::GetCodingCostVector               src/common/lz_diff.cpp:159-284
+//
+// Mapping: one wavefront parses one segment (the greedy parse is serial); the 64
+// lanes are the 64 linear probes of a hash lookup (max_no_tries = 64), and the
+// forward match extension compares 64 x 16 B per step with a ballot to find the
+// first difference.  HBM-bound byte work: no MFMA anywhere.
+#include "dev_common.h"
+
+#ifndef AGC_TRACE
+#define AGC_TRACE(code, val)
+#endif
+
+namespace agc {
+
+// ---------------------------------------------------------------------------
+// small wave helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, uint32_t src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
+}
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// spread the low 32 bits of x to the even bit positions of a 64-bit word
+__device__ __forceinline__ uint64_t spread_bits(uint64_t x)
+{
+    x &= 0xffffffffULL;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffULL;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffULL;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0fULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t first_diff_byte16(const uint4 &a, const uint4 &b)
+{
+    uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+    if (d0)
+        return (uint32_t)(__builtin_ctz(d0) >> 3);
+    if (d1)
+        return 4 + (uint32_t)(__builtin_ctz(d1) >> 3);
+    if (d2)
+        return 8 + (uint32_t)(__builtin_ctz(d2) >> 3);
+    if (d3)
+        return 12 + (uint32_t)(__builtin_ctz(d3) >> 3);
+    return 16;
+}
+
+__device__ __forceinline__ uint4 load16(const uint8_t *p)
+{
+    uint4 v;
+    __builtin_memcpy(&v, p, 16); // byte-aligned global_load_dwordx4 (unaligned access mode)
+    return v;
+}
+
+// Length of the common prefix of p[0..max_len) and q[0..max_len), whole wave.
+// Semantics of refresh::matching_length (3rd_party/refresh/string_operations/lib/
+// string_operations.h:18-69) as used by compare_fwd (lz_diff.h:264-266).
+// Reads of p and q stay inside [0, max_len) except that q may be read up to
+// max_len rounded up to the 16-byte chunk that contains a difference -- never: every
+// 16-byte load is issued only when the whole chunk lies below max_len.
+__device__ uint32_t wave_common_prefix(const uint8_t *__restrict__ p, const uint8_t *__restrict__ q, uint32_t max_len)
+{
+    const uint32_t lane = lane_id();
+    for (uint32_t base = 0;; base += WAVE * 16) {
+        const uint32_t off = base + lane * 16;
+        bool stop;
+        uint32_t so;
+        if (off >= max_len) {
+            stop = true;
+            so = 0;
+        } else if (max_len - off >= 16) {
+            uint4 a = load16(p + off), b = load16(q + off);
+            so = first_diff_byte16(a, b);
+            stop = so < 16;
+        } else {
+            const uint32_t rem = max_len - off;
+            so = 0;
+            while (so < rem && p[off + so] == q[off + so])
+                ++so;
+            stop = true;
+        }
+        const uint64_t m = __ballot(stop);
+        if (m) {
+            const uint32_t l = ctz64(m);
+            const uint32_t r = base + l * 16 + bcast_u32(so, l);
+            return r < max_len ? r : max_len;
+        }
+    }
+}
+
+// Backward extension (lz_diff.cpp:308-311): number of equal symbols walking left from
+// s[-1] / p[-1], at most lim.
+__device__ uint32_t wave_common_suffix(const uint8_t *__restrict__ s, const uint8_t *__restrict__ p, uint32_t lim)
+{
+    const uint32_t lane = lane_id();
+    for (uint32_t base = 0; base < lim; base += WAVE) {
+        const uint32_t idx = base + lane;
+        bool mism = true;
+        if (idx < lim)
+            mism = *(s - 1 - (int64_t)idx) != *(p - 1 - (int64_t)idx);
+        const uint64_t m = __ballot(mism);
+        if (m)
+            return base + ctz64(m);
+    }
+    return lim;
+}
+
+// decimal length / emission (append_int, lz_diff.h:229-262)
+__device__ __forceinline__ uint32_t dec_len_u32(uint32_t x)
+{
+    uint32_t n = 1;
+    while (x >= 10) {
+        x /= 10;
+        ++n;
+    }
+    return n;
+}
+
+// writes the decimal form of x (with '-' when negative) at out[o..); every lane computes
+// the returned length, only `writer` stores.
+__device__ uint32_t emit_int(uint8_t *out, uint32_t o, int64_t x, bool writer)
+{
+    uint32_t len = 0;
+    uint64_t ax;
+    if (x < 0) {
+        ax = (uint64_t)(-x);
+        if (writer)
+            out[o] = '-';
+        len = 1;
+    } else
+        ax = (uint64_t)x;
+    uint32_t nd = 1;
+    for (uint64_t t = ax; t >= 10; t /= 10)
+        ++nd;
+    if (writer) {
+        uint64_t t = ax;
+        for (uint32_t d = 0; d < nd; ++d) {
+            out[o + len + nd - 1 - d] = (uint8_t)('0' + (uint32_t)(t % 10));
+            t /= 10;
+        }
+    }
+    return len + nd;
+}
+
+// cost helpers ---------------------------------------------------------------
+// CLZDiff_V2::uint_len / int_len / cost_match / cost_Nrun, lz_diff.h:375-424
+__device__ __forceinline__ uint32_t v2_uint_len(uint32_t x)
+{
+    if (x < 10) return 1;
+    if (x < 100) return 2;
+    if (x < 1000) return 3;
+    if (x < 10000) return 4;
+    if (x < 100000) return 5;
+    if (x < 1000000) return 6;
+    if (x < 10000000) return 7;
+    return 8;
+}
+__device__ __forceinline__ uint32_t v2_cost_match(uint32_t mml, uint32_t ref_pos, uint32_t len, uint32_t pred_pos)
+{
+    int dif = (int)ref_pos - (int)pred_pos;
+    uint32_t r = dif >= 0 ? v2_uint_len((uint32_t)dif) : 1 + v2_uint_len((uint32_t)-dif);
+    if (len != ~0u)
+        r += 1 + v2_uint_len(len - mml);
+    return r + 1;
+}
+// CLZDiffBase::int_len / coding_cost_match / coding_cost_Nrun, lz_diff.h:159-191
+__device__ __forceinline__ uint32_t base_int_len(uint32_t x)
+{
+    if (x < 10) return 1;
+    if (x < 100) return 2;
+    if (x < 1000) return 3;
+    if (x < 10000) return 4;
+    if (x < 100000) return 5;
+    if (x < 1000000) return 6;
+    if (x < 10000000) return 7;
+    if (x < 100000000) return 8;
+    if (x < 1000000000) return 9;
+    return 10;
+}
+__device__ __forceinline__ uint32_t base_cost_match(uint32_t mml, uint32_t ref_pos, uint32_t len, uint32_t pred_pos)
+{
+    int dif = (int)ref_pos - (int)pred_pos;
+    uint32_t r = dif >= 0 ? base_int_len((uint32_t)dif) : base_int_len((uint32_t)-dif) + 1;
+    return r + base_int_len(len - mml) + 2;
+}
+
+// ---------------------------------------------------------------------------
+// The parse, one wavefront per segment.
+// ---------------------------------------------------------------------------
+enum { MODE_ENCODE = 0, MODE_ESTIMATE = 1, MODE_COSTVEC = 2 };
+
+struct ParseOut {
+    uint32_t value; // encode: delta length; estimate: cost; cost vector: number of costs
+    uint32_t peak;  // estimate: largest cost seen at a loop-top check
+};
+
+template <int MODE>
+__device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text, const uint32_t n,
+                             uint8_t *__restrict__ out, uint32_t *__restrict__ costs, const bool prefix_costs)
+{
+    const uint32_t lane = lane_id();
+    const bool writer = lane == 0;
+    const uint32_t key_len = rd.key_len;
+    const uint32_t mml = rd.min_match_len;
+    const uint8_t *__restrict__ ref = rd.ref;
+    const uint32_t ref_size = rd.ref_size;
+    const uint32_t ht_mask = rd.ht_mask;
+    ParseOut res{0, 0};
+
+    if (MODE != MODE_COSTVEC) {
+        // identical sequence (lz_diff.cpp:678-680 / 849-851)
+        if (n == ref_size && wave_common_prefix(text, ref, n) == n)
+            return res;
+    }
+
+    uint32_t i = 0, pred_pos = 0, npl = 0; // npl = no_prev_literals
+    uint32_t o = 0;                        // output cursor (bytes or costs)
+    uint32_t est = 0, peak = 0;
+
+    AGC_TRACE(3, n);
+    while (i + key_len < n) {
+        AGC_TRACE(4, i);
+        if (MODE == MODE_ESTIMATE) {
+            if (est > peak)
+                peak = est;
+        }
+        // ---- key at text[i .. i+key_len)  (get_code, lz_diff.h:58-106) ----
+        const uint8_t *tp = text + i;
+        const uint32_t s = lane < key_len ? (uint32_t)tp[lane] : 0u;
+        const uint64_t bad = __ballot(s > 3);
+        const uint32_t s0 = bcast_u32(s, 0);
+        const uint32_t max_len = n - i;
+
+        if (bad) {
+            // N-run? (get_Nrun_len, lz_diff.h:122-132)
+            uint32_t nrun = 0;
+            if ((__ballot(s == N_CODE) & 7ULL) == 7ULL) {
+                nrun = max_len; // runs to the end unless a non-N is found
+                for (uint32_t base = 3; base < max_len; base += WAVE) {
+                    const uint32_t p = base + lane;
+                    const bool not_n = p < max_len ? tp[p] != N_CODE : true;
+                    const uint64_t m = __ballot(not_n);
+                    if (m) {
+                        uint32_t e = base + ctz64(m);
+                        nrun = e < max_len ? e : max_len;
+                        break;
+                    }
+                }
+            }
+            if (nrun >= MIN_NRUN_LEN) {
+                if (MODE == MODE_ENCODE) {
+                    if (writer)
+                        out[o] = N_RUN_STARTER;
+                    o += 1;
+                    o += emit_int(out, o, (int64_t)nrun - MIN_NRUN_LEN, writer);
+                    if (writer)
+                        out[o] = N_CODE;
+                    o += 1;
+                } else if (MODE == MODE_ESTIMATE) {
+                    est += 2 + v2_uint_len(nrun); // lz_diff.h:407-410
+                } else {
+                    const uint32_t tc = 2 + base_int_len(nrun - MIN_NRUN_LEN);
+                    for (uint32_t t = lane; t < nrun; t += WAVE)
+                        costs[o + t] = 0;
+                    __builtin_amdgcn_s_waitcnt(0); // the run's zeros land before lane 0 stores its cost
+                    if (writer)
+                        costs[prefix_costs ? o : o + nrun - 1] = tc;
+                    o += nrun;
+                }
+                i += nrun;
+                npl = 0;
+            } else {
+                if (MODE == MODE_ENCODE) {
+                    if (writer)
+                        out[o] = (uint8_t)('A' + s0);
+                } else if (MODE == MODE_ESTIMATE)
+                    ++est;
+                else if (writer)
+                    costs[o] = 1;
+                ++o;
+                ++i;
+                ++pred_pos;
+                ++npl;
+            }
+            continue;
+        }
+
+        // 2-bit code, first symbol most significant
+        const uint64_t m0 = __ballot((s & 1u) != 0), m1 = __ballot((s & 2u) != 0);
+        const uint64_t r0 = __brevll(m0) >> (64 - key_len), r1 = __brevll(m1) >> (64 - key_len);
+        const uint64_t x = spread_bits(r0) | (spread_bits(r1) << 1);
+        const uint64_t h = murmur64(x);
+        const uint32_t slot = ((uint32_t)h & ht_mask);
+
+        // ---- find_best_match: 64 lanes = 64 probes ----
+        uint32_t epos;
+        bool is_empty, fp_ok;
+        if (rd.is_short) {
+            const uint32_t e = ((const uint32_t *)rd.table)[(slot + lane) & ht_mask];
+            is_empty = e == 0xFFFFFFFFu;
+            epos = e >> 16;
+            fp_ok = (e & 0xFFFFu) == (uint32_t)(h >> 48);
+        } else {
+            const uint64_t e = ((const uint64_t *)rd.table)[(slot + lane) & ht_mask];
+            is_empty = e == ~0ULL;
+            epos = (uint32_t)(e >> 32);
+            fp_ok = (uint32_t)e == (uint32_t)(h >> 32);
+        }
+        const uint64_t em = __ballot(is_empty);
+        uint64_t cand = __ballot(fp_ok && !is_empty);
+        if (em)
+            cand &= (1ULL << ctz64(em)) - 1ULL; // probes stop at the first empty slot
+
+        uint32_t len_bck = 0, len_fwd = 0, match_pos = 0;
+        uint32_t min_to_update = mml;
+        while (cand) {
+            const uint32_t j = ctz64(cand);
+            cand &= cand - 1;
+            const uint32_t h_pos = bcast_u32(epos, j) * HASHING_STEP;
+            const uint8_t *p = ref + h_pos;
+            const uint32_t f_len = wave_common_prefix(tp, p, max_len);
+            if (f_len >= key_len) {
+                const uint32_t lim = npl < h_pos ? npl : h_pos;
+                const uint32_t b_len = lim ? wave_common_suffix(tp, p, lim) : 0;
+                if (b_len + f_len > min_to_update) {
+                    len_bck = b_len;
+                    len_fwd = f_len;
+                    match_pos = h_pos;
+                    min_to_update = b_len + f_len;
+                }
+            }
+        }
+
+        if (len_bck + len_fwd < mml) {
+            // literal
+            if (MODE == MODE_ENCODE) {
+                if (writer)
+                    out[o] = (uint8_t)('A' + s0);
+            } else if (MODE == MODE_ESTIMATE)
+                ++est;
+            else if (writer)
+                costs[o] = 1;
+            ++o;
+            ++i;
+            ++pred_pos;
+            ++npl;
+            continue;
+        }
+
+        const uint32_t len = len_bck + len_fwd;
+        if (MODE == MODE_ESTIMATE) {
+            // no roll-back of the back extension here (lz_diff.cpp:926-936)
+            if (i + len == n && match_pos + len == ref_size)
+                est += v2_cost_match(mml, match_pos, ~0u, pred_pos);
+            else
+                est += v2_cost_match(mml, match_pos, len, pred_pos);
+            pred_pos = match_pos + len;
+            i += len;
+            npl = 0;
+            continue;
+        }
+
+        // roll the back extension back (lz_diff.cpp:756-766 / 246-256)
+        o -= len_bck;
+        match_pos -= len_bck;
+        pred_pos -= len_bck;
+        i -= len_bck;
+
+        if (MODE == MODE_ENCODE) {
+            if (match_pos == pred_pos && writer) {
+                // literals equal to the reference become '!' (lz_diff.cpp:769-779)
+                for (uint32_t t = 1; t < o && t < match_pos; ++t) {
+                    const uint8_t c = out[o - t];
+                    if (c < 'A' || c > 'Z')
+                        break;
+                    if ((uint8_t)(c - 'A') == ref[match_pos - t])
+                        out[o - t] = '!';
+                }
+            }
+            const bool to_end = (i + len == n) && (match_pos + len == ref_size);
+            o += emit_int(out, o, (int64_t)(int)match_pos - (int64_t)(int)pred_pos, writer);
+            if (!to_end) {
+                if (writer)
+                    out[o] = ',';
+                o += 1;
+                o += emit_int(out, o, (int64_t)len - (int64_t)mml, writer);
+            }
+            if (writer)
+                out[o] = '.';
+            o += 1;
+        } else {
+            const uint32_t tc = base_cost_match(mml, match_pos, len, pred_pos);
+            // lane 0's earlier literal costs (now rolled back) must land before the zero fill,
+            // and the zero fill before lane 0's match cost: drain the wave's stores in between
+            __builtin_amdgcn_s_waitcnt(0);
+            for (uint32_t t = lane; t < len; t += WAVE)
+                costs[o + t] = 0;
+            __builtin_amdgcn_s_waitcnt(0);
+            if (writer)
+                costs[prefix_costs ? o : o + len - 1] = tc;
+            o += len;
+        }
+        pred_pos = match_pos + len;
+        i += len;
+        npl = 0;
+    }
+
+    // tail literals (lz_diff.cpp:795-796 / 943 / 282-283)
+    if (MODE == MODE_ESTIMATE) {
+        est += n - i; // u32 wrap-around exactly as the reference
+        res.value = est;
+        res.peak = peak;
+        return res;
+    }
+    if (i < n) {
+        const uint32_t cnt = n - i; // <= key_len symbols (or the whole text when n <= key_len)
+        if (MODE == MODE_ENCODE) {
+            // one lane owns every byte of the delta: no cross-lane stores to one address
+            if (writer)
+                for (uint32_t t = 0; t < cnt; ++t)
+                    out[o + t] = (uint8_t)('A' + text[i + t]);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0);
+            for (uint32_t t = lane; t < cnt; t += WAVE)
+                costs[o + t] = 1;
+        }
+        o += cnt;
+    }
+    res.value = o;
+    return res;
+}
+
+// One wavefront per segment: wave w of block b parses segment 4*b + w of the host's
+// longest-first list (the dispatcher hands blocks out in order, so the long segments start
+// first and the short ones fill the tail).
+template <int MODE>
+__global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs,
+                                                       uint32_t n_segs, uint8_t *__restrict__ out_bytes,
+                                                       uint32_t *__restrict__ out_u32, uint32_t *__restrict__ res_value,
+                                                       uint32_t *__restrict__ res_peak)
+{
+    const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    AGC_TRACE(1, idx);
+    if (idx >= n_segs)
+        return;
+    const SegDesc sd = segs[idx];
+    const RefDesc rd = refs[sd.ref_slot];
+    AGC_TRACE(2, sd.len);
+    ParseOut r;
+    if (MODE == MODE_ENCODE)
+        r = lz_parse<MODE>(rd, sd.text, sd.len, out_bytes + sd.out_off, nullptr, false);
+    else if (MODE == MODE_ESTIMATE)
+        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, nullptr, false);
+    else
+        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, out_u32 + sd.out_off, (sd.flags & 1u) != 0);
+    AGC_TRACE(9, r.value);
+    if (lane_id() == 0) {
+        res_value[sd.pad] = r.value; // sd.pad = index in the caller's order
+        if (MODE == MODE_ESTIMATE)
+            res_peak[sd.pad] = r.peak;
+    }
+}
+
+template __global__ void lz_parse_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
+template __global__ void lz_parse_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
+template __global__ void lz_parse_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
+
+// gathers the per-segment deltas (scratch slots) into one contiguous buffer
+__global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__restrict__ scratch, const SegDesc *__restrict__ segs,
+                                                           const uint32_t *__restrict__ lens, const uint64_t *__restrict__ dst_off,
+                                                           uint32_t n_segs, uint8_t *__restrict__ dst)
+{
+    for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
+        const uint32_t orig = segs[s].pad;
+        const uint8_t *src = scratch + segs[s].out_off;
+        uint8_t *d = dst + dst_off[orig];
+        const uint32_t n = lens[orig];
+        for (uint32_t t = threadIdx.x; t < n; t += blockDim.x)
+            d[t] = src[t];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Index build.
+// ---------------------------------------------------------------------------
+struct IdxBuild {
+    const uint8_t *ref;  // padded reference
+    void *table;         // filled by the insert kernel (pre-set to all ones)
+    uint32_t ref_size;
+    uint32_t key_len;
+    uint32_t ht_mask;
+    uint32_t is_short;
+};
+
+// key at ref[i..i+key_len) or ~0 (get_code, lz_diff.h:58-106)
+__device__ __forceinline__ uint64_t key_at(const uint8_t *__restrict__ r, uint32_t key_len)
+{
+    uint64_t x = 0;
+    for (uint32_t j = 0; j < key_len; ++j) {
+        const uint32_t c = r[j];
+        if (c > 3)
+            return ~0ULL;
+        x = (x << 2) + c;
+    }
+    return x;
+}
+
+// number of valid keys at positions 0,4,8,... (the count prepare_index sizes the table by,
+// lz_diff.cpp:88-101: a key is counted where the last key_len symbols are all ACGT and the
+// key starts at a multiple of hashing_step)
+__global__ void __launch_bounds__(256) idx_count_kernel(const IdxBuild *__restrict__ jobs, uint32_t *__restrict__ counts)
+{
+    const IdxBuild jb = jobs[blockIdx.x];
+    uint32_t c = 0;
+    for (uint32_t t = threadIdx.x; (uint64_t)t * HASHING_STEP + jb.key_len <= jb.ref_size; t += blockDim.x)
+        c += key_at(jb.ref + t * HASHING_STEP, jb.key_len) != ~0ULL;
+    // block reduce
+    for (int o = 32; o > 0; o >>= 1)
+        c += __shfl_down(c, o);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// Deterministic parallel linear-probing insertion.  The reference inserts keys in
+// increasing position order, each into the first empty slot of its <= 64 probes
+// (lz_diff.cpp:375-428).  Equivalent fixpoint: every slot ends up holding the SMALLEST
+// position whose probe sequence reaches it without finding an earlier free slot -- so a
+// thread claims slots with atomicMin on (pos<<bits | fp) and carries any larger entry it
+// displaces onward.  Entries only ever decrease, which makes the result independent of
+// thread timing and identical to the sequential build.
+template <typename E, int FPBITS>
+__device__ void idx_insert_one(const IdxBuild &jb, uint32_t t)
+{
+    const uint64_t x = key_at(jb.ref + (uint64_t)t * HASHING_STEP, jb.key_len);
+    if (x == ~0ULL)
+        return;
+    E *tab = (E *)jb.table;
+    const uint64_t h = murmur64(x);
+    const E fp = FPBITS == 16 ? (E)(h >> 48) : (E)(h >> 32);
+    E cur = ((E)t << FPBITS) | fp;
+    uint32_t slot = (uint32_t)h & jb.ht_mask;
+    uint32_t tries = 0;
+    const E EMPTY = (E)~(E)0;
+    for (;;) {
+        const E old = atomicMin(&tab[slot], cur);
+        ++tries;
+        if (old == EMPTY)
+            return;
+        if (old > cur) {
+            // we took the slot from `old`: continue inserting `old` after this slot
+            cur = old;
+            const uint32_t ot = (uint32_t)(old >> FPBITS);
+            const uint64_t ox = key_at(jb.ref + (uint64_t)ot * HASHING_STEP, jb.key_len);
+            const uint32_t ohome = (uint32_t)murmur64(ox) & jb.ht_mask;
+            tries = ((slot - ohome) & jb.ht_mask) + 1;
+        }
+        if (tries >= MAX_NO_TRIES)
+            return; // dropped, as in the reference
+        slot = (slot + 1) & jb.ht_mask;
+    }
+}
+
+__global__ void __launch_bounds__(256) idx_insert_kernel(const IdxBuild *__restrict__ jobs)
+{
+    const IdxBuild jb = jobs[blockIdx.x];
+    for (uint32_t t = threadIdx.x; (uint64_t)t * HASHING_STEP < jb.ref_size; t += blockDim.x) {
+        if (jb.is_short)
+            idx_insert_one<uint32_t, 16>(jb, t);
+        else
+            idx_insert_one<unsigned long long, 32>(jb, t);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// slice copy with optional reverse complement + INVALID_SYMBOL padding
+// (reverse_complement_copy, src/common/agc_basic.cpp:282-315; prepare_gen padding,
+// src/common/lz_diff.cpp:48-53)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) slice_copy_kernel(const SliceDesc *__restrict__ jobs, uint32_t n_jobs)
+{
+    for (uint32_t s = blockIdx.x; s < n_jobs; s += gridDim.x) {
+        const SliceDesc sd = jobs[s];
+        for (uint32_t t = threadIdx.x; t < sd.len; t += blockDim.x) {
+            uint8_t c;
+            if (sd.rc) {
+                c = sd.src[sd.len - 1 - t];
+                c = c < 4 ? (uint8_t)(3 - c) : c;
+            } else
+                c = sd.src[t];
+            sd.dst[t] = c;
+        }
+        for (uint32_t t = threadIdx.x; t < sd.pad_len; t += blockDim.x)
+            sd.dst[sd.len + t] = INVALID_SYMBOL;
+    }
+}
+
+// repetitiveness probe counters (segment.h:224-247): for lag 4..31,
+// cnt = #{j : j+lag < n, d[j]==d[j+lag]}, cur = #{j : j+lag < n, d[j] < 4}
+__global__ void __launch_bounds__(256) lag_counts_kernel(const SliceDesc *__restrict__ jobs, uint32_t *__restrict__ cnt_out,
+                                                         uint32_t *__restrict__ cur_out)
+{
+    const SliceDesc sd = jobs[blockIdx.x];
+    __shared__ uint32_t s_cnt[28], s_cur[28];
+    if (threadIdx.x < 28) {
+        s_cnt[threadIdx.x] = 0;
+        s_cur[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    uint32_t cnt[28], cur[28];
+#pragma unroll
+    for (int l = 0; l < 28; ++l)
+        cnt[l] = cur[l] = 0;
+    const uint32_t n = sd.len;
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        uint8_t c = sd.rc ? sd.src[n - 1 - j] : sd.src[j];
+        if (sd.rc && c < 4)
+            c = 3 - c;
+        const uint32_t v = c < 4;
+#pragma unroll
+        for (int l = 0; l < 28; ++l) {
+            const uint32_t lag = 4 + l;
+            if (j + lag < n) {
+                uint8_t d = sd.rc ? sd.src[n - 1 - (j + lag)] : sd.src[j + lag];
+                if (sd.rc && d < 4)
+                    d = 3 - d;
+                cnt[l] += c == d;
+                cur[l] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 28; ++l) {
+        uint32_t a = cnt[l], b = cur[l];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o);
+            b += __shfl_down(b, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_cnt[l], a);
+            atomicAdd(&s_cur[l], b);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        cnt_out[blockIdx.x * 28 + threadIdx.x] = s_cnt[threadIdx.x];
+        cur_out[blockIdx.x * 28 + threadIdx.x] = s_cur[threadIdx.x];
+    }
+}
+
+} // namespace agc

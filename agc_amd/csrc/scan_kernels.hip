@@ -1,0 +1,326 @@
+// scan_kernels.hip -- splitter scan (a2-a4) and FASTA-body preprocessing (a1) for gfx950.
+//
+// Reference behaviour reproduced (file:line under the reference tree):
+//   rolling canonical k-mer   CKmer::insert_canonical / data_canonical   src/core/kmer.h:284-301, 360-362
+//   scan loop                 CAGCCompressor::compress_contig            src/core/agc_compressor.cpp:2007-2036
+//   membership                bloom_set_t::check && hash_set_lp::check   src/core/utils_adv.h:227-276, src/core/hs.h:489-497
+//   symbol codes              preprocess_raw_contig + cnv_num            src/core/agc_compressor.cpp:907-951, src/common/agc_basic.h:40-50
+//
+// Layout: every lane owns 16 consecutive symbols fetched with ONE coalesced 16-byte load
+// (a wave step covers 1 KiB of the contig); the 2-bit packed words and the non-ACGT masks
+// of the two preceding lanes arrive by cross-lane shuffles, so each symbol is read from
+// HBM exactly once.  The k-mer at the first owned position is assembled from the packed
+// words, the other 15 are rolled.  A 64 KiB bloom filter of the splitter set lives in LDS
+// (pure accelerator, like the reference's); survivors are checked in an exact
+// open-addressing table that stays L2-resident.
+//
+// The kernel reports EVERY position whose k-mer is a splitter; the reference's "reset the
+// k-mer after a hit" rule (a hit voids the next k-1 positions) is a sequential filter over
+// the sparse hit list and is applied by the host right after (api.hip: accept_hits).
+#include "dev_common.h"
+
+namespace agc {
+
+__device__ __forceinline__ uint32_t pack4(uint32_t w)
+{
+    // 4 symbols (low 2 bits of each byte, first symbol in the low byte) -> 8 bits, first symbol most significant
+    return ((w & 0x03030303u) * 0x40100401u) >> 24;
+}
+
+__device__ __forceinline__ uint32_t inv4(uint32_t w)
+{
+    // bit j set iff byte j is > 3; returned with the FIRST symbol in the most significant of 4 bits
+    uint32_t v = w & 0xFCFCFCFCu;
+    uint32_t nz = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v; // bit 7 of each byte = byte != 0
+    nz &= 0x80808080u;
+    // gather bits 7,15,23,31 -> 3,2,1,0
+    return ((nz >> 7) & 1u) << 3 | ((nz >> 15) & 1u) << 2 | ((nz >> 23) & 1u) << 1 | (nz >> 31);
+}
+
+// reverse the order of the 2-bit groups of a 64-bit word
+__device__ __forceinline__ uint64_t rev2(uint64_t x)
+{
+    x = __brevll(x);
+    return ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);
+}
+
+struct ScanArgs {
+    const uint8_t *codes;
+    const ScanRange *ranges;
+    uint32_t n_ranges;
+    uint32_t k;
+    const uint64_t *table;     // exact splitter table, ~0 = empty
+    uint64_t table_mask;
+    const uint32_t *bloom;     // BLOOM_WORDS words
+    ScanHit *hits;
+    uint32_t *n_hits;
+    uint32_t cap;
+};
+
+__global__ void __launch_bounds__(1024) scan_kernel(ScanArgs a)
+{
+    __shared__ uint32_t s_bloom[BLOOM_WORDS];
+    for (uint32_t t = threadIdx.x; t < BLOOM_WORDS; t += blockDim.x)
+        s_bloom[t] = a.bloom[t];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t k = a.k;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    const uint32_t lshift = 64 - 2 * k;
+
+    for (uint32_t r = blockIdx.x * waves_per_block + wave; r < a.n_ranges; r += gridDim.x * waves_per_block) {
+        const ScanRange rg = a.ranges[r];
+        // previous two 16-symbol chunks (packed word + invalid mask) of lanes 62/63 of the
+        // previous step; at the start: the 32 symbols before rg.begin (invalid outside the contig)
+        uint32_t carryP1 = 0, carryP2 = 0, carryI1 = 0xFFFF, carryI2 = 0xFFFF; // 1 = immediately before
+        {
+            // lanes 0 and 1 assemble the two halo chunks
+            uint32_t P = 0, I = 0xFFFF;
+            if (lane < 2) {
+                const uint64_t cb = rg.begin - 16 * (uint64_t)(lane + 1); // may wrap below 0: handled per byte
+                P = 0;
+                I = 0;
+                for (uint32_t j = 0; j < 16; ++j) {
+                    const uint64_t p = cb + j;
+                    uint32_t c = 4;
+                    if (rg.begin >= 16 * (uint64_t)(lane + 1) - j && p >= rg.ctg_begin && p < rg.begin)
+                        c = a.codes[p];
+                    P = (P << 2) | (c & 3);
+                    I = (I << 1) | (c > 3);
+                }
+            }
+            carryP1 = __shfl(P, 0);
+            carryI1 = __shfl(I, 0);
+            carryP2 = __shfl(P, 1);
+            carryI2 = __shfl(I, 1);
+        }
+
+        for (uint64_t base = rg.begin; base < rg.end; base += 1024) {
+            const uint64_t off = base + (uint64_t)lane * 16;
+            uint32_t P = 0, I = 0xFFFF;
+            uint32_t nvalid = 0; // symbols of this chunk inside the range
+            if (off < rg.end) {
+                const uint64_t rem = rg.end - off;
+                if (rem >= 16) {
+                    uint4 v;
+                    __builtin_memcpy(&v, a.codes + off, 16);
+                    P = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
+                    I = (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
+                    nvalid = 16;
+                } else {
+                    P = 0;
+                    I = 0;
+                    for (uint32_t j = 0; j < 16; ++j) {
+                        uint32_t c = 4;
+                        if (j < rem)
+                            c = a.codes[off + j];
+                        P = (P << 2) | (c & 3);
+                        I = (I << 1) | (c > 3);
+                    }
+                    nvalid = (uint32_t)rem;
+                }
+            }
+            // neighbours' chunks
+            uint32_t P1 = __shfl_up(P, 1), I1 = __shfl_up(I, 1);
+            uint32_t P2 = __shfl_up(P, 2), I2 = __shfl_up(I, 2);
+            if (lane == 0) {
+                P1 = carryP1;
+                I1 = carryI1;
+                P2 = carryP2;
+                I2 = carryI2;
+            } else if (lane == 1) {
+                P2 = carryP1;
+                I2 = carryI1;
+            }
+            carryP1 = __shfl(P, 63);
+            carryI1 = __shfl(I, 63);
+            carryP2 = __shfl(P, 62);
+            carryI2 = __shfl(I, 62);
+
+            if (nvalid) {
+                // 96-bit window: symbols -32..-17 (P2), -16..-1 (P1), 0..15 (P); symbol j of the own
+                // chunk sits at bits [2*(15-j), 2*(15-j)+1] of P.
+                const uint64_t hi = ((uint64_t)P2 << 32) | P1;   // symbols -32..-1
+                // invalid bits: bit (47 - q) <-> symbol q-32, q in 0..47
+                const uint64_t inv = ((uint64_t)I2 << 32) | ((uint64_t)I1 << 16) | I;
+
+                // k-mer ending at own symbol 0: the k symbols -(k-1)..0
+                // value (right aligned) = bits of [hi:P] >> 30, masked
+                uint64_t dir = ((hi << 2) | (P >> 30)) & kmask;
+                // reverse complement, right aligned: complement, reverse groups, align
+                uint64_t rcv = rev2(~dir) >> lshift; // ~dir flips every 2-bit symbol to 3-s; reversing puts the last symbol first
+                rcv &= kmask;
+                const uint64_t wmask = k == 32 ? 0xFFFFFFFFULL : ((1ULL << k) - 1ULL);
+
+                for (uint32_t j = 0; j < nvalid; ++j) {
+                    if (j) {
+                        const uint64_t sym = (P >> (2 * (15 - j))) & 3;
+                        dir = ((dir << 2) | sym) & kmask;
+                        rcv = (rcv >> 2) | ((3 - sym) << (2 * k - 2));
+                    }
+                    // window validity: symbols (j-k+1 .. j) of the own chunk <-> inv bits (15-j) .. (15-j+k-1)
+                    const bool valid = ((inv >> (15 - j)) & wmask) == 0;
+                    if (valid) {
+                        const uint64_t dl = dir << lshift, rl = rcv << lshift;
+                        const uint64_t can = dl < rl ? dl : rl;
+                        const uint64_t h = splitter_hash(can);
+                        uint32_t bw, bm;
+                        bloom_slot(h, bw, bm);
+                        if ((s_bloom[bw] & bm) == bm) {
+                            // exact check
+                            uint64_t slot = h & a.table_mask;
+                            for (;;) {
+                                const uint64_t e = a.table[slot];
+                                if (e == can) {
+                                    const uint32_t idx = atomicAdd(a.n_hits, 1u);
+                                    if (idx < a.cap) {
+                                        a.hits[idx].pos = off + j;
+                                        a.hits[idx].dir = dl;
+                                        a.hits[idx].rc = rl;
+                                    }
+                                    break;
+                                }
+                                if (e == ~0ULL)
+                                    break;
+                                slot = (slot + 1) & a.table_mask;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a1: raw FASTA body -> codes.  Three passes: per-block kept counts, scan of the block
+// counts (single block), scatter.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t cnv_symbol(uint8_t c)
+{
+    // cnv_num, src/common/agc_basic.h:40-50 (only consulted for c >= 64; c < 128)
+    c &= 127;
+    if (c == 64 || c == 96)
+        return 32;
+    const uint8_t u = c & 0x5F; // fold case: 'a'..'z' -> 'A'..'Z'; 123..127 -> 91..95
+    switch (u) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    case 'N': return 4;
+    case 'R': return 5;
+    case 'Y': return 6;
+    case 'S': return 7;
+    case 'W': return 8;
+    case 'K': return 9;
+    case 'M': return 10;
+    case 'B': return 11;
+    case 'D': return 12;
+    case 'H': return 13;
+    case 'V': return 14;
+    case 'U': return 15;
+    default: return 30;
+    }
+}
+
+constexpr uint32_t PP_TILE = 16384; // bytes per block
+
+__global__ void __launch_bounds__(256) pp_count_kernel(const uint8_t *__restrict__ raw, uint64_t n, uint32_t *__restrict__ block_cnt)
+{
+    const uint64_t b0 = (uint64_t)blockIdx.x * PP_TILE;
+    uint32_t c = 0;
+    for (uint32_t t = threadIdx.x * 16; t < PP_TILE; t += blockDim.x * 16) {
+        const uint64_t p = b0 + t;
+        if (p + 16 <= n) {
+            uint4 v;
+            __builtin_memcpy(&v, raw + p, 16);
+            c += __popc(((v.x >> 6) | (v.x >> 7)) & 0x01010101u);
+            c += __popc(((v.y >> 6) | (v.y >> 7)) & 0x01010101u);
+            c += __popc(((v.z >> 6) | (v.z >> 7)) & 0x01010101u);
+            c += __popc(((v.w >> 6) | (v.w >> 7)) & 0x01010101u);
+        } else {
+            for (uint32_t j = 0; j < 16 && p + j < n; ++j)
+                c += (raw[p + j] >> 6) != 0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        c += __shfl_down(c, o);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of block counts into 64-bit offsets; one block
+__global__ void __launch_bounds__(1024) pp_scan_kernel(const uint32_t *__restrict__ block_cnt, uint32_t n_blocks,
+                                                       uint64_t *__restrict__ block_off, uint64_t *__restrict__ total)
+{
+    __shared__ uint64_t s_part[1024];
+    const uint32_t per = (n_blocks + blockDim.x - 1) / blockDim.x;
+    const uint32_t b = threadIdx.x * per, e = min(b + per, n_blocks);
+    uint64_t sum = 0;
+    for (uint32_t i = b; i < e; ++i)
+        sum += block_cnt[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < blockDim.x; ++i) {
+            const uint64_t v = s_part[i];
+            s_part[i] = acc;
+            acc += v;
+        }
+        *total = acc;
+    }
+    __syncthreads();
+    uint64_t acc = s_part[threadIdx.x];
+    for (uint32_t i = b; i < e; ++i) {
+        block_off[i] = acc;
+        acc += block_cnt[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) pp_scatter_kernel(const uint8_t *__restrict__ raw, uint64_t n,
+                                                         const uint64_t *__restrict__ block_off, uint8_t *__restrict__ codes)
+{
+    // each thread owns 64 consecutive input bytes of the tile; ranks come from a block scan
+    const uint64_t b0 = (uint64_t)blockIdx.x * PP_TILE;
+    const uint64_t p0 = b0 + (uint64_t)threadIdx.x * 64;
+    uint8_t buf[64];
+    uint32_t c = 0;
+    for (uint32_t j = 0; j < 64; ++j) {
+        const uint64_t p = p0 + j;
+        uint8_t x = p < n ? raw[p] : 0;
+        buf[j] = x;
+        c += (x >> 6) != 0;
+    }
+    // exclusive scan of c over the block
+    __shared__ uint32_t s_w[4];
+    uint32_t incl = c;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o)
+            incl += v;
+    }
+    if (lane == 63)
+        s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w)
+        wbase += s_w[w];
+    uint64_t o = block_off[blockIdx.x] + wbase + incl - c;
+    for (uint32_t j = 0; j < 64; ++j) {
+        const uint8_t x = buf[j];
+        if (x >> 6)
+            codes[o++] = cnv_symbol(x);
+    }
+}
+
+} // namespace agc

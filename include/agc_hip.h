@@ -1,0 +1,170 @@
+/*
+ * agc_hip.h -- C ABI of the MI355X-native (gfx950) implementation of AGC's
+ * segment-compression hot path.  Plain pointers and sizes only; every entry
+ * point returns 0 on success and a negative AGC_HIP_E* code on failure
+ * (agc_hip_last_error() gives the text).  There is NO CPU fallback behind this
+ * interface: without a HIP device every compute call fails with AGC_HIP_ENODEV.
+ *
+ * The reference (refresh-bio/agc v3.2.2) has no FFI seam for this path; the
+ * functions below sit exactly where the reference calls its private C++
+ * members, each one citing the reference interface it replaces
+ * (file:line under the reference tree).
+ *
+ * Symbol layout: one byte per symbol, the codes of src/common/agc_basic.h:40-50
+ * (A0 C1 G2 T3 N4 IUPAC5..15, 30 other letter, 32 '@'/'`').
+ * Pointer naming: h_* = host memory, d_* = device (HBM) memory.
+ */
+#ifndef AGC_HIP_H
+#define AGC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGC_HIP_OK 0
+#define AGC_HIP_ENODEV (-1)   /* no HIP device / runtime error            */
+#define AGC_HIP_EINVAL (-2)   /* bad argument                             */
+#define AGC_HIP_ENOMEM (-3)   /* device or host allocation failed         */
+#define AGC_HIP_ECAP (-4)     /* caller-provided output buffer too small  */
+#define AGC_HIP_ENOREF (-5)   /* group id has no registered reference     */
+
+typedef struct agc_hip_ctx agc_hip_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int agc_hip_create(agc_hip_ctx **out, int device);
+void agc_hip_destroy(agc_hip_ctx *ctx);
+const char *agc_hip_last_error(const agc_hip_ctx *ctx);
+/* ABI version of this header (checked by the host bindings). */
+uint32_t agc_hip_abi_version(void);
+/* Block until every kernel / copy issued through ctx has finished. */
+int agc_hip_sync(agc_hip_ctx *ctx);
+
+/* Per-kernel timing with HIP events on the stream the kernels run on.
+ * which: one of AGC_HIP_K_*.  ms = accumulated kernel time, launches = count. */
+enum {
+    AGC_HIP_K_SCAN = 0,
+    AGC_HIP_K_INDEX = 1,
+    AGC_HIP_K_ENCODE = 2,
+    AGC_HIP_K_ESTIMATE = 3,
+    AGC_HIP_K_COSTVEC = 4,
+    AGC_HIP_K_REVCOMP = 5,
+    AGC_HIP_K_PREPROCESS = 6,
+    AGC_HIP_K_REFSTORE = 7,
+    AGC_HIP_K_COUNT = 8
+};
+int agc_hip_timing_enable(agc_hip_ctx *ctx, int on);
+int agc_hip_timing_reset(agc_hip_ctx *ctx);
+int agc_hip_timing_get(agc_hip_ctx *ctx, int which, double *ms, uint64_t *launches);
+
+/* ---- a1: raw FASTA body -> symbol codes ------------------------------- */
+/* Replaces CAGCCompressor::preprocess_raw_contig (src/core/agc_compressor.cpp:907-951):
+ * drops every byte < 64, maps the rest through cnv_num (agc_basic.h:40-50).
+ * d_raw/d_codes are device buffers of n_raw bytes; *h_n_codes receives the count. */
+int agc_hip_preprocess_dev(agc_hip_ctx *ctx, const uint8_t *d_raw, uint64_t n_raw,
+                           uint8_t *d_codes, uint64_t *h_n_codes);
+
+/* ---- S1: splitter scan (a2-a4) ---------------------------------------- */
+/* Replaces the splitter set hs_splitters + bloom_splitters
+ * (src/core/agc_compressor.h:625-626; hs.h:448-497; utils_adv.h:180-282):
+ * exact membership of canonical k-mers (left-aligned u64, kmer.h:360-362). */
+int agc_hip_splitters_set(agc_hip_ctx *ctx, const uint64_t *h_kmers, uint64_t n);
+int agc_hip_splitters_insert(agc_hip_ctx *ctx, const uint64_t *h_kmers, uint64_t n);
+uint64_t agc_hip_splitters_count(const agc_hip_ctx *ctx);
+
+/* Replaces the loop body of CAGCCompressor::compress_contig
+ * (src/core/agc_compressor.cpp:2007-2036) for a batch of contigs:
+ * d_codes holds the contigs back to back, contig c = [h_ctg_off[c], h_ctg_off[c+1]).
+ * Emits the ACCEPTED splitter hits in (contig, position) order -- i.e. after the
+ * reference's "reset the k-mer after every hit" rule -- with the k-mer at the hit
+ * (dir and rev-comp forms, both left-aligned as CKmer keeps them).
+ * Segment boundaries follow as in SURVEY.md App. A.3.
+ * Returns AGC_HIP_ECAP (and the needed count in *h_n_hits) if cap is too small. */
+int agc_hip_scan_contigs_dev(agc_hip_ctx *ctx, const uint8_t *d_codes,
+                             const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                             uint64_t cap, uint64_t *h_n_hits,
+                             uint32_t *h_hit_ctg, uint64_t *h_hit_pos,
+                             uint64_t *h_hit_dir, uint64_t *h_hit_rc);
+/* Same with host-resident contigs (copied to HBM first). */
+int agc_hip_scan_contigs(agc_hip_ctx *ctx, const uint8_t *h_codes,
+                         const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                         uint64_t cap, uint64_t *h_n_hits,
+                         uint32_t *h_hit_ctg, uint64_t *h_hit_pos,
+                         uint64_t *h_hit_dir, uint64_t *h_hit_rc);
+
+/* ---- S2: LZ-diff against group references (a10, a11, a6, a7) ---------- */
+/* A "slice" names one sequence inside a device buffer: symbols
+ * d_base[off .. off+len), read reverse-complemented when rc != 0
+ * (CAGCBasic::reverse_complement_copy, src/common/agc_basic.cpp:282-315). */
+
+/* Replaces CLZDiffBase::Prepare + prepare_index (src/common/lz_diff.cpp:48-78,
+ * 81-141, 375-428) as used by CSegment::add for the first sequence of a group
+ * (src/common/segment.cpp:41-48): keeps the reference in HBM and builds the
+ * sparse k-mer index (same slots, same 64-probe cut-off as the reference).
+ * Group ids may be registered once; re-registration returns AGC_HIP_EINVAL. */
+int agc_hip_ref_register(agc_hip_ctx *ctx, uint32_t gid, const uint8_t *h_ref,
+                         uint32_t n, uint32_t min_match_len);
+int agc_hip_ref_register_batch_dev(agc_hip_ctx *ctx, uint32_t n_refs, const uint32_t *h_gid,
+                                   const uint8_t *d_base, const uint64_t *h_off,
+                                   const uint32_t *h_len, const uint8_t *h_rc,
+                                   uint32_t min_match_len);
+/* Copies a registered reference back (GetReference, lz_diff.cpp:431-437);
+ * also returns the index for parity checks: table entries hold pos/4 exactly
+ * as ht16/ht32 do (0xFFFF / 0xFFFFFFFF = empty), widened to u32. */
+int agc_hip_ref_get(agc_hip_ctx *ctx, uint32_t gid, uint8_t *h_ref, uint32_t cap, uint32_t *h_n);
+int agc_hip_ref_index_get(agc_hip_ctx *ctx, uint32_t gid, uint32_t *h_table, uint64_t cap,
+                          uint64_t *h_ht_size, int *h_is16);
+
+/* Replaces CLZDiff_V2::Encode (src/common/lz_diff.cpp:669-798), one call for a
+ * batch of segments.  Encoded deltas are written back to back into h_enc;
+ * delta s = h_enc[h_enc_off[s] .. h_enc_off[s+1]).  An empty delta means "equal
+ * to the reference" (lz_diff.cpp:678-680). */
+int agc_hip_lz_encode_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                                const uint8_t *d_base, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc,
+                                uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
+/* Host-resident texts: text s = h_text[h_off[s] .. h_off[s]+h_len[s]). */
+int agc_hip_lz_encode_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                            const uint8_t *h_text, const uint64_t *h_off,
+                            const uint32_t *h_len, const uint8_t *h_rc,
+                            uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
+
+/* Replaces CLZDiff_V2::Estimate (src/common/lz_diff.cpp:839-946) evaluated
+ * WITHOUT a bound: h_cost[s] is the estimate with bound = ~0, h_peak[s] the
+ * largest running cost seen at a loop-top check, so the caller can replay the
+ * reference's early exit for any bound b: the bounded call would have returned
+ * early (with a value > b) iff h_peak[s] > b. */
+int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                                  const uint8_t *d_base, const uint64_t *h_off,
+                                  const uint32_t *h_len, const uint8_t *h_rc,
+                                  uint32_t *h_cost, uint32_t *h_peak);
+int agc_hip_lz_estimate_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                              const uint8_t *h_text, const uint64_t *h_off,
+                              const uint32_t *h_len, const uint8_t *h_rc,
+                              uint32_t *h_cost, uint32_t *h_peak);
+
+/* Replaces CLZDiffBase::GetCodingCostVector (src/common/lz_diff.cpp:159-284):
+ * h_costs receives sum(h_len) u32 values, segment after segment. */
+int agc_hip_lz_cost_vector_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                                     const uint8_t *d_base, const uint64_t *h_off,
+                                     const uint32_t *h_len, const uint8_t *h_rc,
+                                     const uint8_t *h_prefix_costs, uint32_t *h_costs);
+int agc_hip_lz_cost_vector_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                                 const uint8_t *h_text, const uint64_t *h_off,
+                                 const uint32_t *h_len, const uint8_t *h_rc,
+                                 const uint8_t *h_prefix_costs, uint32_t *h_costs);
+
+/* ---- a13: reference storage helpers ----------------------------------- */
+/* Repetitiveness probe of CSegment::store_in_archive (src/common/segment.h:224-247):
+ * for lag = 4..31 the pair (matches, ACGT positions); 28 values each per slice.
+ * The caller applies the double-precision 0.5 test. */
+int agc_hip_ref_lag_counts_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_base,
+                               const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
+                               uint32_t *h_cnt /* n*28 */, uint32_t *h_cur /* n*28 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGC_HIP_H */

@@ -1,0 +1,133 @@
+"""GPU parity: HIP LZ-diff kernels vs the oracle, through the C ABI (bit-exact)."""
+import numpy as np
+import pytest
+
+from tests.cases import lz_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _register(hip_ctx, cases, gid0):
+    for i, (mml, ref, _t) in enumerate(cases):
+        hip_ctx.ref_register(gid0 + i, ref, mml)
+
+
+@pytest.fixture(scope="module")
+def registered(hip_ctx):
+    cases = lz_cases()
+    # references with different min_match_len are independent groups
+    _register(hip_ctx, cases, 1000)
+    return cases
+
+
+def test_index_matches_oracle(hip_ctx, oracle, registered):
+    for i, (mml, ref, _t) in enumerate(registered):
+        tab, is16 = hip_ctx.ref_index_get(1000 + i)
+        want = oracle.LZ(ref, mml).index()
+        assert is16 == (want.dtype == np.uint16)
+        assert np.array_equal(tab.astype(np.uint32), want.astype(np.uint32)), f"case {i}"
+        assert np.array_equal(hip_ctx.ref_get(1000 + i), ref)
+
+
+def _concat(cases):
+    texts = [t for (_m, _r, t) in cases]
+    off = np.zeros(len(texts), np.uint64)
+    ln = np.array([t.size for t in texts], np.uint32)
+    off[1:] = np.cumsum(ln[:-1].astype(np.uint64) + 7)  # ragged gaps between texts
+    buf = np.full(int(off[-1] + ln[-1]) + 8, 4, np.uint8)
+    for o, t in zip(off, texts):
+        buf[int(o):int(o) + t.size] = t
+    return buf, off, ln
+
+
+def test_encode_bit_exact(hip_ctx, oracle, registered):
+    buf, off, ln = _concat(registered)
+    gids = 1000 + np.arange(len(registered))
+    enc, eoff = hip_ctx.lz_encode_batch(buf, gids, off, ln)
+    for i, (mml, ref, text) in enumerate(registered):
+        want = oracle.LZ(ref, mml).encode(text)
+        got = enc[int(eoff[i]):int(eoff[i + 1])]
+        assert np.array_equal(got, want), f"case {i} mml={mml} len={text.size}: got {got[:40].tobytes()} want {want[:40].tobytes()}"
+        if want.size:
+            dec, n = oracle.LZ(ref, mml).decode(got, text.size + 8)
+            assert n == text.size and np.array_equal(dec, text)
+
+
+def test_encode_reverse_complement(hip_ctx, oracle, registered):
+    # rc flag: the kernel must see reverse_complement_copy(text)
+    buf, off, ln = _concat(registered)
+    gids = 1000 + np.arange(len(registered))
+    rc = np.ones(len(registered), np.uint8)
+    enc, eoff = hip_ctx.lz_encode_batch(buf, gids, off, ln, rc=rc)
+    for i, (mml, ref, text) in enumerate(registered):
+        want = oracle.LZ(ref, mml).encode(oracle.rev_comp(text))
+        assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], want), f"case {i}"
+
+
+def test_estimate_and_peak(hip_ctx, oracle, registered):
+    buf, off, ln = _concat(registered)
+    gids = 1000 + np.arange(len(registered))
+    cost, peak = hip_ctx.lz_estimate_batch(buf, gids, off, ln)
+    for i, (mml, ref, text) in enumerate(registered):
+        z = oracle.LZ(ref, mml)
+        want, wpeak = z.estimate(text, want_peak=True)
+        assert int(cost[i]) == want, f"case {i}"
+        assert int(peak[i]) == wpeak, f"case {i}"
+        # replaying a bound from (cost, peak) reproduces the bounded call's accept/reject
+        for bound in (0, 10, 100, text.size // 2):
+            bounded = z.estimate(text, bound)
+            if wpeak > bound:
+                assert bounded > bound
+            else:
+                assert bounded == want
+
+
+def test_cost_vector(hip_ctx, oracle, registered):
+    buf, off, ln = _concat(registered)
+    gids = 1000 + np.arange(len(registered))
+    for prefix in (0, 1):
+        pf = np.full(len(registered), prefix, np.uint8)
+        costs = hip_ctx.lz_cost_vector_batch(buf, gids, off, ln, None, pf)
+        p = 0
+        for i, (mml, ref, text) in enumerate(registered):
+            want = oracle.LZ(ref, mml).cost_vector(text, prefix)
+            assert np.array_equal(costs[p:p + text.size], want), f"case {i} prefix={prefix}"
+            p += text.size
+
+
+def test_long_reference_u32_table(hip_ctx, oracle):
+    rng = np.random.default_rng(11)
+    from agc_amd import synth
+    ref = synth.random_seq(rng, 270_000)          # ref/4 >= 65535 -> 32-bit table (lz_diff.cpp:146)
+    text = synth.mutate(rng, ref, 0.003, n_runs=2, indels=2)
+    hip_ctx.ref_register(5000, ref, 20)
+    tab, is16 = hip_ctx.ref_index_get(5000)
+    z = oracle.LZ(ref, 20)
+    assert not is16 and np.array_equal(tab, z.index())
+    enc, eoff = hip_ctx.lz_encode_batch(text, [5000], [0], [text.size])
+    assert np.array_equal(enc, z.encode(text))
+    cost, _ = hip_ctx.lz_estimate_batch(text, [5000], [0], [text.size])
+    assert int(cost[0]) == z.estimate(text)
+
+
+def test_unregistered_group_is_an_error(hip_ctx):
+    from agc_amd import capi
+    with pytest.raises(capi.AgcHipError) as e:
+        hip_ctx.lz_encode_batch(np.zeros(100, np.uint8), [999999], [0], [100])
+    assert e.value.code == capi.ENOREF
+
+
+def test_lag_counts(hip_ctx, oracle):
+    import torch
+    rng = np.random.default_rng(3)
+    from agc_amd import synth
+    seqs = [synth.random_seq(rng, 5000), np.tile(synth.random_seq(rng, 5), 1000), synth.mutate(rng, synth.random_seq(rng, 3000), 0, n_runs=4)]
+    buf = np.concatenate(seqs)
+    off = np.cumsum([0] + [s.size for s in seqs[:-1]]).astype(np.uint64)
+    ln = np.array([s.size for s in seqs], np.uint32)
+    d = torch.from_numpy(buf).cuda()
+    for rc in (0, 1):
+        cnt, cur = hip_ctx.ref_lag_counts_dev(d.data_ptr(), off, ln, np.full(3, rc, np.uint8))
+        for i, s in enumerate(seqs):
+            wc, wu = oracle.ref_lag_counts(oracle.rev_comp(s) if rc else s)
+            assert np.array_equal(cnt[i], wc) and np.array_equal(cur[i], wu)

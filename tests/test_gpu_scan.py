@@ -1,0 +1,94 @@
+"""GPU parity: splitter scan + preprocessing kernels vs the oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+from agc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_hits(oracle, contigs, k, spl):
+    ctg, pos, d, r = [], [], [], []
+    for ci, c in enumerate(contigs):
+        s = oracle.scan_contig(c, k, spl)
+        m = s["back_full"] == 1
+        ctg += [ci] * int(m.sum())
+        pos += list((s["start"][m] + s["len"][m] - 1).astype(np.uint64))
+        d += list(s["back_dir"][m])
+        r += list(s["back_rc"][m])
+    return np.array(ctg, np.uint32), np.array(pos, np.uint64), np.array(d, np.uint64), np.array(r, np.uint64)
+
+
+@pytest.mark.parametrize("k", [17, 21, 25, 31, 32])
+def test_scan_matches_oracle(hip_ctx, oracle, k):
+    rng = np.random.default_rng(100 + k)
+    refc = [synth.random_seq(rng, int(n)) for n in (70_000, 12_345, 150_001, 40, 5)]
+    spl = oracle.determine_splitters(refc, k, 1000)
+    assert spl.size > 50
+    # sample: mutated copies + N-runs + IUPAC + contigs shorter than k + exact multiples of the 1 KiB wave step
+    contigs = [synth.mutate(rng, refc[0], 0.002, n_runs=3, iupac=5),
+               synth.mutate(rng, refc[1], 0.01),
+               synth.mutate(rng, refc[2], 0.001, indels=3),
+               refc[3].copy(), refc[4].copy(),
+               refc[0][:65536].copy(), refc[0][:1024].copy(), refc[2][:4096 + k - 1].copy()]
+    off = np.zeros(len(contigs) + 1, np.uint64)
+    off[1:] = np.cumsum([c.size for c in contigs])
+    codes = np.concatenate(contigs)
+    hip_ctx.splitters_set(spl)
+    assert hip_ctx.splitters_count() == spl.size
+    got = hip_ctx.scan_contigs(codes, off, k)
+    want = _oracle_hits(oracle, contigs, k, spl)
+    for g, w, name in zip(got, want, ("ctg", "pos", "dir", "rc")):
+        assert np.array_equal(g, w), name
+    assert want[0].size > 100
+
+
+def test_scan_dense_splitters_reset_rule(hip_ctx, oracle):
+    # every k-mer of the contig is a splitter: the reset rule must keep exactly every k-th position
+    rng = np.random.default_rng(5)
+    k = 21
+    c = synth.random_seq(rng, 20_000)
+    allk = np.zeros(c.size, np.uint64)
+    import ctypes as C
+    n = oracle.lib().agco_enumerate_kmers(c.ctypes.data_as(C.POINTER(C.c_uint8)), c.size, k, allk.ctypes.data_as(C.POINTER(C.c_uint64)))
+    spl = np.unique(allk[:n])
+    hip_ctx.splitters_set(spl)
+    got = hip_ctx.scan_contigs(c, [0, c.size], k)
+    want = _oracle_hits(oracle, [c], k, spl)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    assert np.all(np.diff(got[1].astype(np.int64)) == k)
+
+
+def test_scan_empty_and_tiny(hip_ctx):
+    hip_ctx.splitters_set(np.array([1, 2, 3], np.uint64))
+    got = hip_ctx.scan_contigs(np.zeros(0, np.uint8), [0], 31)
+    assert got[0].size == 0
+    got = hip_ctx.scan_contigs(np.zeros(10, np.uint8), [0, 3, 3, 10], 31)
+    assert got[0].size == 0
+
+
+def test_splitters_insert(hip_ctx, oracle):
+    rng = np.random.default_rng(9)
+    k = 25
+    c = synth.random_seq(rng, 50_000)
+    spl = oracle.determine_splitters([c], k, 2000)
+    half = spl[: spl.size // 2]
+    hip_ctx.splitters_set(half)
+    a = hip_ctx.scan_contigs(c, [0, c.size], k)
+    hip_ctx.splitters_insert(spl[spl.size // 2:])
+    b = hip_ctx.scan_contigs(c, [0, c.size], k)
+    wa = _oracle_hits(oracle, [c], k, np.sort(half))
+    wb = _oracle_hits(oracle, [c], k, spl)
+    assert np.array_equal(a[1], wa[1]) and np.array_equal(b[1], wb[1]) and b[1].size > a[1].size
+
+
+def test_preprocess(hip_ctx, oracle):
+    import torch
+    rng = np.random.default_rng(4)
+    body = rng.choice(np.frombuffer(b"ACGTacgtNnRYSWKMBDHVUxz@`\n\r 0123>;*-", np.uint8), size=200_003)
+    d_raw = torch.from_numpy(body).cuda()
+    d_out = torch.zeros(body.size + 64, dtype=torch.uint8, device="cuda")
+    n = hip_ctx.preprocess_dev(d_raw.data_ptr(), body.size, d_out.data_ptr())
+    want = oracle.preprocess(body)
+    assert n == want.size
+    assert np.array_equal(d_out[:n].cpu().numpy(), want)
