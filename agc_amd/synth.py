@@ -37,10 +37,16 @@ CODE2ASCII = np.frombuffer(b"ACGTNRYSWKMBDHVU", dtype=np.uint8)
 
 
 def to_fasta(path, contigs, names, width=80):
-    """contigs: list of code arrays (codes < 16)."""
+    """contigs: list of code arrays (codes < 16); 80-column lines, vectorised."""
     with open(path, "wb") as f:
         for name, c in zip(names, contigs):
             f.write(b">" + name.encode() + b"\n")
             a = CODE2ASCII[c]
-            for i in range(0, a.size, width):
-                f.write(a[i:i + width].tobytes() + b"\n")
+            full = a.size // width * width
+            if full:
+                body = np.empty((full // width, width + 1), np.uint8)
+                body[:, :width] = a[:full].reshape(-1, width)
+                body[:, width] = 10
+                f.write(body.tobytes())
+            if a.size > full:
+                f.write(a[full:].tobytes() + b"\n")

@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library loads and exports every symbol include/agc_hip.h declares; without a
+GPU every compute entry point fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "agc_hip.h")).read()
+    return sorted(set(re.findall(r"\b(agc_hip_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_header_symbols_are_exported():
+    from agc_amd import build, capi
+    build.build()
+    L = ctypes.CDLL(capi.LIB_PATH)
+    decl = _declared()
+    assert len(decl) >= 25
+    for s in decl:
+        assert hasattr(L, s), f"{s} declared in include/agc_hip.h but not exported"
+    assert sorted(capi.SYMBOLS) == decl, "agc_amd/capi.py binds a different symbol set than the header declares"
+    assert L.agc_hip_abi_version() == 1
+
+
+def test_no_device_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from agc_amd import capi
+    with pytest.raises(capi.AgcHipError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.ENODEV
+
+
+def test_product_does_not_import_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    bad = []
+    for dp, _dn, fn in os.walk(os.path.join(ROOT, "agc_amd")):
+        for f in fn:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                t = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|agc_oracle|libagc_oracle|oracle/_ref", t):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
