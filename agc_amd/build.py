@@ -30,5 +30,35 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(CSRC, "host")
+HOST_LIB = os.path.join(HERE, "libagc_host.so")
+HOST_BIN = os.path.join(HERE, "bin", "agc_amd")
+HOST_SOURCES = ["compressor.cpp", "compressor.h", "host_support.h", "capi_host.cpp", "main.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """g++ for the host-side compressor (C++17): libagc_host.so (links libagc_hip.so by $ORIGIN rpath)
+    and the agc-compatible CLI agc_amd/bin/agc_amd.  zstd is dlopen'ed at run time."""
+    build()
+    deps = [os.path.join(HOST, s) for s in HOST_SOURCES] + [LIB]
+    stale = force or not os.path.exists(HOST_LIB) or not os.path.exists(HOST_BIN) or \
+        any(os.path.getmtime(d) > min(os.path.getmtime(HOST_LIB), os.path.getmtime(HOST_BIN)) for d in deps)
+    if not stale:
+        return HOST_LIB
+    os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
+    cxx = os.environ.get("CXX", "g++")
+    common = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
+    cmd1 = common + ["-shared", os.path.join(HOST, "compressor.cpp"), os.path.join(HOST, "capi_host.cpp"), "-o", HOST_LIB,
+                     "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"]
+    cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
+                     "-Wl,-rpath,$ORIGIN/..", "-lz", "-ldl"]
+    for cmd in (cmd1, cmd2):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
+    build_host(force="--force" in sys.argv, verbose=True)
     print(build(force="--force" in sys.argv, verbose=True))

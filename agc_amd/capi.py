@@ -20,6 +20,7 @@ K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preproc
 SYMBOLS = [
     "agc_hip_create", "agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_sync",
     "agc_hip_timing_enable", "agc_hip_timing_reset", "agc_hip_timing_get",
+    "agc_hip_sample_buffer", "agc_hip_copy_to_device",
     "agc_hip_preprocess_dev",
     "agc_hip_splitters_set", "agc_hip_splitters_insert", "agc_hip_splitters_count",
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
@@ -27,6 +28,7 @@ SYMBOLS = [
     "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch",
     "agc_hip_lz_estimate_batch_dev", "agc_hip_lz_estimate_batch",
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
+    "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
     "agc_hip_ref_lag_counts_dev",
 ]
 
@@ -70,6 +72,8 @@ def load():
     L.agc_hip_timing_enable.argtypes = [vp, C.c_int]
     L.agc_hip_timing_reset.argtypes = [vp]
     L.agc_hip_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
+    L.agc_hip_sample_buffer.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.agc_hip_copy_to_device.argtypes = [vp, vp, u8p, C.c_uint64]
     L.agc_hip_preprocess_dev.argtypes = [vp, vp, C.c_uint64, vp, u64p]
     L.agc_hip_splitters_set.argtypes = [vp, u64p, C.c_uint64]
     L.agc_hip_splitters_insert.argtypes = [vp, u64p, C.c_uint64]
@@ -88,6 +92,8 @@ def load():
     L.agc_hip_lz_estimate_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_lz_cost_vector_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u8p, u32p]
     L.agc_hip_lz_cost_vector_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u8p, u32p]
+    L.agc_hip_lz_split_point_batch_dev.argtypes = [vp, C.c_uint32, u32p, u32p, vp, u64p, u32p, u8p, u8p, u8p, u8p, u32p, u32p]
+    L.agc_hip_fetch_slices_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_ref_lag_counts_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u32p, u32p]
     for s in SYMBOLS:
         f = getattr(L, s)
@@ -266,6 +272,24 @@ class Context:
     def lz_cost_vector_batch(self, text, gids, off, length, rc, prefix):
         text = _a(text, np.uint8)
         return self._costvec(self.L.agc_hip_lz_cost_vector_batch, _p(text, u8p), gids, off, length, rc, prefix)
+
+    def lz_split_point_batch_dev(self, d_base, gid1, gid2, off, length, rc1, prefix1, rc2, prefix2):
+        g1, g2, o, l = _a(gid1, np.uint32), _a(gid2, np.uint32), _a(off, np.uint64), _a(length, np.uint32)
+        r1, p1, r2, p2 = (_a(x, np.uint8) for x in (rc1, prefix1, rc2, prefix2))
+        pos = np.zeros(g1.size, np.uint32)
+        sm = np.zeros(g1.size, np.uint32)
+        self._chk(self.L.agc_hip_lz_split_point_batch_dev(self.h, g1.size, _p(g1, u32p), _p(g2, u32p), d_base, _p(o, u64p), _p(l, u32p),
+                                                          _p(r1, u8p), _p(p1, u8p), _p(r2, u8p), _p(p2, u8p), _p(pos, u32p), _p(sm, u32p)))
+        return pos, sm
+
+    def fetch_slices_dev(self, d_base, off, length, rc=None):
+        o, l = _a(off, np.uint64), _a(length, np.uint32)
+        r = _a(rc, np.uint8) if rc is not None else None
+        cap = int(l.astype(np.uint64).sum())
+        out = np.empty(cap, np.uint8)
+        ooff = np.zeros(o.size + 1, np.uint64)
+        self._chk(self.L.agc_hip_fetch_slices_dev(self.h, o.size, d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(out, u8p), cap, _p(ooff, u64p)))
+        return out, ooff
 
     def ref_lag_counts_dev(self, d_base, off, length, rc=None):
         o, l = _a(off, np.uint64), _a(length, np.uint32)

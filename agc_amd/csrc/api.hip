@@ -49,7 +49,7 @@ struct agc_hip_ctx {
 
     // scratch
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_stage, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
-        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag;
+        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample;
 
     // timing
     bool timing = false;
@@ -183,7 +183,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
-                      &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag};
+                      &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample};
     for (DevBuf *b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -235,6 +235,28 @@ int agc_hip_timing_get(agc_hip_ctx *c, int which, double *ms, uint64_t *launches
         *ms = c->ms[which];
     if (launches)
         *launches = c->launches[which];
+    return AGC_HIP_OK;
+}
+
+int agc_hip_sample_buffer(agc_hip_ctx *c, uint64_t bytes, uint8_t **d_ptr)
+{
+    if (!c || !d_ptr)
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure(c, c->d_sample, bytes + 4096));
+    *d_ptr = (uint8_t *)c->d_sample.p;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_copy_to_device(agc_hip_ctx *c, uint8_t *d_dst, const uint8_t *h_src, uint64_t n)
+{
+    if (!c || (n && (!d_dst || !h_src)))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return AGC_HIP_OK;
 }
 
@@ -841,6 +863,97 @@ int agc_hip_lz_cost_vector_batch(agc_hip_ctx *c, uint32_t n, const uint32_t *h_g
     CHK(stage_host_texts(c, n, h_text, h_off, h_len, doff));
     return agc_hip_lz_cost_vector_batch_dev(c, n, h_gid, (const uint8_t *)c->d_in.p, doff.data(), h_len, h_rc, h_prefix_costs,
                                             h_costs);
+}
+
+int agc_hip_lz_split_point_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid1, const uint32_t *h_gid2,
+                                     const uint8_t *d_base, const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc1,
+                                     const uint8_t *h_prefix1, const uint8_t *h_rc2, const uint8_t *h_prefix2, uint32_t *h_best_pos,
+                                     uint32_t *h_best_sum)
+{
+    if (!c || (n && (!h_gid1 || !h_gid2 || !d_base || !h_off || !h_len || !h_rc1 || !h_prefix1 || !h_rc2 || !h_prefix2 || !h_best_pos)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // 2n cost-vector parses: job 2s = (gid1, rc1, prefix1), job 2s+1 = (gid2, rc2, prefix2)
+    const uint32_t m = 2 * n;
+    std::vector<uint32_t> gid(m), len(m);
+    std::vector<uint64_t> off(m);
+    std::vector<uint8_t> rc(m), pf(m);
+    for (uint32_t s = 0; s < n; ++s) {
+        gid[2 * s] = h_gid1[s];
+        gid[2 * s + 1] = h_gid2[s];
+        off[2 * s] = off[2 * s + 1] = h_off[s];
+        len[2 * s] = len[2 * s + 1] = h_len[s];
+        rc[2 * s] = h_rc1[s];
+        rc[2 * s + 1] = h_rc2[s];
+        pf[2 * s] = h_prefix1[s];
+        pf[2 * s + 1] = h_prefix2[s];
+    }
+    Batch b;
+    CHK(prepare_batch(c, MODE_COSTVEC, m, gid.data(), d_base, off.data(), len.data(), rc.data(), pf.data(), b));
+    CHK(ensure(c, c->d_scratch, b.out_total * 4 + 64));
+    CHK(launch_parse<MODE_COSTVEC>(c, m, nullptr, (uint32_t *)c->d_scratch.p));
+    std::vector<SplitJob> jobs(n);
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        jobs[s].off1 = o;
+        jobs[s].off2 = o + h_len[s];
+        jobs[s].n = h_len[s];
+        jobs[s].rev1 = h_prefix1[s] ? 0u : 1u;
+        jobs[s].rev2 = h_prefix2[s] ? 1u : 0u;
+        jobs[s].pad = 0;
+        o += 2ULL * h_len[s];
+    }
+    CHK(ensure(c, c->d_jobs, (size_t)n * sizeof(SplitJob)));
+    CHK(ensure(c, c->d_dstoff, (size_t)n * 8));
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n * sizeof(SplitJob), hipMemcpyHostToDevice, c->stream));
+    uint32_t *d_pos = (uint32_t *)c->d_dstoff.p, *d_sum = d_pos + n;
+    {
+        KTimer t(c, AGC_HIP_K_COSTVEC);
+        hipLaunchKernelGGL(split_point_kernel, dim3(n), dim3(256), 0, c->stream, (const SplitJob *)c->d_jobs.p,
+                           (const uint32_t *)c->d_scratch.p, d_pos, d_sum);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_best_pos, d_pos, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_best_sum)
+        HIPCHK(c, hipMemcpyAsync(h_best_sum, d_sum, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+int agc_hip_fetch_slices_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base, const uint64_t *h_off, const uint32_t *h_len,
+                             const uint8_t *h_rc, uint8_t *h_out, uint64_t out_cap, uint64_t *h_out_off)
+{
+    if (!c || !h_out_off || (n && (!d_base || !h_off || !h_len)))
+        return AGC_HIP_EINVAL;
+    h_out_off[0] = 0;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (uint32_t i = 0; i < n; ++i)
+        h_out_off[i + 1] = h_out_off[i] + h_len[i];
+    const uint64_t tot = h_out_off[n];
+    if (tot > out_cap)
+        return AGC_HIP_ECAP;
+    if (!tot)
+        return AGC_HIP_OK;
+    if (!h_out)
+        return AGC_HIP_EINVAL;
+    CHK(ensure(c, c->d_compact, tot + 64));
+    std::vector<SliceDesc> sl(n);
+    for (uint32_t i = 0; i < n; ++i)
+        sl[i] = {d_base + h_off[i], (uint8_t *)c->d_compact.p + h_out_off[i], h_len[i], h_rc ? (uint32_t)h_rc[i] : 0u, 0u, 0u};
+    CHK(ensure(c, c->d_slices, (size_t)n * sizeof(SliceDesc)));
+    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
+    {
+        KTimer t(c, AGC_HIP_K_REVCOMP);
+        hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n, 1, 65536)), dim3(256), 0, c->stream, (const SliceDesc *)c->d_slices.p, n);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out, c->d_compact.p, tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,67 @@
+// capi_host.cpp -- plain C entry points of the host-side compressor (for bench.py / tests via ctypes).
+#include "compressor.h"
+#include <cstring>
+#include <string>
+#include <vector>
+
+using agc::CAGCCompressor;
+
+extern "C" {
+
+void *agc_cmp_new(int device)
+{
+    auto *c = new CAGCCompressor();
+    c->SetDevice(device);
+    return c;
+}
+
+void agc_cmp_delete(void *h) { delete (CAGCCompressor *)h; }
+
+// CAGCCompressor::Create (src/core/agc_compressor.h:754-756): 1 = ok, 0 = failure (message on stderr)
+int agc_cmp_create(void *h, const char *out_path, uint32_t pack_cardinality, uint32_t k, const char *ref_file, uint32_t segment_size,
+                   uint32_t min_match_len, int concatenated, int adaptive, uint32_t verbosity, uint32_t n_threads, double fallback_frac)
+{
+    return ((CAGCCompressor *)h)->Create(out_path ? out_path : "", pack_cardinality, k, ref_file ? ref_file : "", segment_size, min_match_len,
+                                         concatenated != 0, adaptive != 0, verbosity, n_threads, fallback_frac) ? 1 : 0;
+}
+
+int agc_cmp_set_splitters(void *h, const uint64_t *kmers, uint64_t n) { return ((CAGCCompressor *)h)->SetSplitters(kmers, n) ? 1 : 0; }
+
+int agc_cmp_add_sample_files(void *h, uint32_t n, const char **sample_names, const char **paths, uint32_t n_threads)
+{
+    std::vector<std::pair<std::string, std::string>> v;
+    for (uint32_t i = 0; i < n; ++i)
+        v.emplace_back(sample_names[i], paths[i]);
+    return ((CAGCCompressor *)h)->AddSampleFiles(v, n_threads) ? 1 : 0;
+}
+
+int agc_cmp_add_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const uint8_t *d_codes,
+                           const uint64_t *ctg_off)
+{
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < n_ctg; ++i)
+        names.emplace_back(contig_names[i]);
+    return ((CAGCCompressor *)h)->AddSampleDevice(sample_name, names, d_codes, ctg_off) ? 1 : 0;
+}
+
+int agc_cmp_close(void *h, uint32_t n_threads) { return ((CAGCCompressor *)h)->Close(n_threads) ? 1 : 0; }
+
+const char *agc_cmp_zstd_version(void *h) { return ((CAGCCompressor *)h)->ZstdVersion(); }
+
+void *agc_cmp_hip_ctx(void *h) { return ((CAGCCompressor *)h)->HipContext(); }
+
+// 11 counters + 8 stage times, in the order of agc::CompressorStats
+int agc_cmp_stats(void *h, double *out, uint32_t n)
+{
+    const agc::CompressorStats &s = ((CAGCCompressor *)h)->Stats();
+    const double v[] = {(double)s.bases, (double)s.segments, (double)s.new_groups, (double)s.one_splitter, (double)s.middle_tried,
+                        (double)s.middle_split, (double)s.lz_encoded, (double)s.delta_bytes, (double)s.ref_bytes, (double)s.zstd_in,
+                        (double)s.zstd_out, (double)s.archive_bytes, s.t_scan, s.t_classify, s.t_gpu_aux, s.t_register, s.t_encode,
+                        s.t_store, s.t_zstd, s.t_io};
+    const uint32_t m = sizeof(v) / sizeof(v[0]);
+    for (uint32_t i = 0; i < n && i < m; ++i)
+        out[i] = v[i];
+    return (int)m;
+}
+
+} // extern "C"

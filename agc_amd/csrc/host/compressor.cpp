@@ -1,0 +1,1460 @@
+// compressor.cpp -- see compressor.h.  Citations: file:line under the reference tree.
+#include "compressor.h"
+#include "host_support.h"
+#include "../../../include/agc_hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <iostream>
+#include <numeric>
+#include <set>
+#include <zlib.h>
+
+namespace agc {
+
+namespace {
+
+using pk_t = std::pair<uint64_t, uint64_t>;
+constexpr uint64_t NO_KMER = ~0ULL;
+constexpr uint32_t NO_RAW_GROUPS = 16; // agc_basic.h:81
+
+struct PairHash {
+    size_t operator()(const pk_t &x) const noexcept
+    {
+        uint64_t h = x.first * 0x9E3779B97F4A7C15ULL;
+        h ^= (h >> 32) ^ (x.second * 0xC2B2AE3D27D4EB4FULL);
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+
+double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// CKmer in canonical mode (src/core/kmer.h): both forms left-aligned
+struct Kmer {
+    uint64_t dir = 0, rc = 0;
+    bool full = false;
+    uint64_t data() const { return dir < rc ? dir : rc; }   // kmer.h:350-357
+    bool is_dir_oriented() const { return dir <= rc; }      // kmer.h:545-551
+    void swap_dir_rc() { std::swap(dir, rc); }              // kmer.h:554-562
+};
+
+struct Contig {
+    std::string sample, name;
+    uint64_t off = 0, len = 0; // inside the batch's device buffer
+};
+
+struct Seg { // one segment as compress_contig cuts it (agc_compressor.cpp:2007-2048)
+    uint32_t ctg;
+    uint64_t start; // relative to the contig
+    uint32_t len;
+    Kmer front, back;
+    // classification (add_segment, agc_compressor.cpp:1275-1499)
+    pk_t pk{NO_KMER, NO_KMER};
+    bool store_rc = false;
+    // one-splitter search
+    uint32_t cand_begin = 0, cand_end = 0;
+    bool back_only = false;
+    Kmer one_kmer;
+    // missing-middle search
+    int32_t mid_job = -1;
+    Kmer kmer1, kmer2;
+    bool use_rc = false;
+    uint64_t middle = NO_KMER;
+};
+
+struct Cand { // find_cand_segment_with_one_splitter, agc_compressor.cpp:1660-1690
+    pk_t pk;
+    bool use_rc;
+    uint32_t gid;
+    uint64_t ref_size;
+};
+
+struct Placed { // one entry of CBufferedSegPart (agc_compressor.h:27-536)
+    uint32_t ctg;
+    uint64_t off; // absolute offset in the device buffer
+    uint32_t len;
+    uint32_t part_no;
+    bool rc;
+    int32_t gid; // -1: new group
+    pk_t pk;
+};
+
+struct Group { // CSegment, write side (src/common/segment.{h,cpp})
+    bool exists = false;
+    uint64_t ref_size = 0; // s.size() + 1 once the reference is set (segment.cpp:46)
+    uint32_t no_seqs = 0;
+    std::vector<bytes_t> v_lzp;
+    std::vector<bytes_t> v_raw;
+    int stream_ref = -1, stream_delta = -1;
+};
+
+struct ZJob { // one archive part to produce
+    int stream_id;
+    int kind;          // 0 = reference (tuples/zstd13 or zstd19), 1 = pack (zstd17)
+    bytes_t data;      // raw bytes (reference symbols or concatenated pack)
+    bool repetitive = false;
+    bytes_t out;
+    uint64_t meta = 0;
+};
+
+// bytes2tuples, src/common/segment.h:73-138
+void bytes2tuples(const bytes_t &v, bytes_t &out)
+{
+    uint8_t me = 0;
+    for (uint8_t c : v)
+        me = std::max(me, c);
+    uint32_t nb, mult;
+    if (me < 4) {
+        nb = 4;
+        mult = 4;
+    } else if (me < 6) {
+        nb = 3;
+        mult = 6;
+    } else if (me < 16) {
+        nb = 2;
+        mult = 16;
+    } else {
+        out = v;
+        out.push_back(0x10u);
+        return;
+    }
+    out.clear();
+    out.reserve(v.size() / nb + 2);
+    size_t i = 0;
+    for (; i + nb <= v.size(); i += nb) {
+        uint8_t c = 0;
+        for (uint32_t j = 0; j < nb; ++j)
+            c = (uint8_t)(c * mult + v[i + j]);
+        out.push_back(c);
+    }
+    uint8_t c = 0;
+    for (; i < v.size(); ++i)
+        c = (uint8_t)(c * mult + v[i]);
+    out.push_back(c);
+    out.push_back((uint8_t)((nb << 4) + (v.size() % nb)));
+}
+
+// cnv_num, src/common/agc_basic.h:40-50; preprocess_raw_contig, agc_compressor.cpp:907-951
+struct CnvTable {
+    uint8_t t[256];
+    CnvTable()
+    {
+        for (int c = 0; c < 256; ++c)
+            t[c] = 30;
+        t[64] = t[96] = 32;
+        const char *named = "ACGTNRYSWKMBDHVU";
+        for (int i = 0; named[i]; ++i) {
+            t[(int)named[i]] = (uint8_t)i;
+            t[(int)named[i] + 32] = (uint8_t)i;
+        }
+        for (int c = 128; c < 256; ++c)
+            t[c] = t[c & 127];
+    }
+};
+const CnvTable g_cnv;
+
+void preprocess_raw_contig(bytes_t &ctg)
+{
+    size_t o = 0;
+    for (size_t i = 0; i < ctg.size(); ++i) {
+        uint8_t c = ctg[i];
+        if (c >> 6)
+            ctg[o++] = g_cnv.t[c];
+    }
+    ctg.resize(o);
+}
+
+// FASTA(.gz) reader with the reference's framing (src/core/genome_io.cpp:208-252): id = first
+// line minus its first character, body = every byte up to the next '>'.
+class FastaReader {
+    gzFile f = nullptr;
+    std::vector<uint8_t> buf;
+    size_t pos = 0, filled = 0;
+    bool fill()
+    {
+        pos = 0;
+        int r = gzread(f, buf.data(), (unsigned)buf.size());
+        filled = r > 0 ? (size_t)r : 0;
+        return filled != 0;
+    }
+
+public:
+    bool open(const std::string &fn)
+    {
+        f = gzopen(fn.c_str(), "rb");
+        if (!f)
+            return false;
+        gzbuffer(f, 1 << 20);
+        buf.resize(16 << 20);
+        pos = filled = 0;
+        return true;
+    }
+    void close()
+    {
+        if (f)
+            gzclose(f);
+        f = nullptr;
+    }
+    ~FastaReader() { close(); }
+    bool read_contig_raw(std::string &id, bytes_t &ctg)
+    {
+        id.clear();
+        ctg.clear();
+        if (!f)
+            return false;
+        for (;;) {
+            if (pos >= filled && !fill())
+                return false;
+            uint8_t c = buf[pos++];
+            if (c == '\n' || c == '\r')
+                break;
+            id.push_back((char)c);
+        }
+        if (!id.empty())
+            id.erase(id.begin());
+        for (;;) {
+            if (pos >= filled && !fill())
+                break;
+            const uint8_t *b = buf.data() + pos, *e = buf.data() + filled;
+            const uint8_t *q = (const uint8_t *)memchr(b, '>', (size_t)(e - b));
+            if (q) {
+                ctg.insert(ctg.end(), b, q);
+                pos = (size_t)(q - buf.data());
+                break;
+            }
+            ctg.insert(ctg.end(), b, e);
+            pos = filled;
+        }
+        return !id.empty() && !ctg.empty();
+    }
+};
+
+// rolling canonical k-mer on the host (reference preprocessing only)
+struct HostKmer {
+    uint64_t dir = 0, rc = 0;
+    uint32_t cur = 0, k;
+    explicit HostKmer(uint32_t k_) : k(k_) {}
+    void reset() { dir = rc = 0, cur = 0; }
+    void insert(uint64_t s)
+    {
+        const uint32_t shift = 64 - 2 * k;
+        const uint64_t mask = (~0ULL) << shift;
+        rc >>= 2;
+        rc += (3 - s) << 62;
+        rc &= mask;
+        if (cur == k) {
+            dir <<= 2;
+            dir += s << shift;
+        } else {
+            ++cur;
+            dir += s << (64 - 2 * cur);
+        }
+    }
+    bool full() const { return cur == k; }
+    uint64_t data() const { return dir < rc ? dir : rc; }
+};
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// determine_splitters, agc_compressor.cpp:428-563 (+ 630-704, 762-825); fallback minimizers are
+// dead code at -f 0.
+// ---------------------------------------------------------------------------
+std::vector<uint64_t> determine_splitters_host(const std::vector<bytes_t> &ref, uint32_t k, uint32_t segment_size, unsigned n_threads)
+{
+    size_t tot = 0;
+    for (auto &c : ref)
+        tot += c.size();
+    std::vector<uint64_t> km;
+    km.reserve(tot);
+    for (auto &c : ref) {
+        HostKmer h(k);
+        for (uint8_t x : c) {
+            if (x > 3)
+                h.reset();
+            else {
+                h.insert(x);
+                if (h.full())
+                    km.push_back(h.data());
+            }
+        }
+    }
+    // parallel sort: chunks + merges
+    {
+        unsigned nt = std::max(1u, std::min<unsigned>(n_threads, 64));
+        size_t n = km.size();
+        if (nt > 1 && n > (1u << 20)) {
+            std::vector<size_t> cut(nt + 1);
+            for (unsigned i = 0; i <= nt; ++i)
+                cut[i] = n * i / nt;
+            std::vector<std::thread> th;
+            for (unsigned i = 0; i < nt; ++i)
+                th.emplace_back([&, i] { std::sort(km.begin() + cut[i], km.begin() + cut[i + 1]); });
+            for (auto &t : th)
+                t.join();
+            for (unsigned step = 1; step < nt; step *= 2) {
+                std::vector<std::thread> mt;
+                for (unsigned i = 0; i + step < nt; i += 2 * step)
+                    mt.emplace_back([&, i, step] {
+                        std::inplace_merge(km.begin() + cut[i], km.begin() + cut[i + step], km.begin() + cut[std::min(nt, i + 2 * step)]);
+                    });
+                for (auto &t : mt)
+                    t.join();
+            }
+        } else
+            std::sort(km.begin(), km.end());
+    }
+    // singletons only (remove_non_singletons, :664-680)
+    size_t o = 0;
+    for (size_t i = 0; i < km.size();) {
+        size_t j = i + 1;
+        while (j < km.size() && km[j] == km[i])
+            ++j;
+        if (j == i + 1)
+            km[o++] = km[i];
+        i = j;
+    }
+    km.resize(o);
+    auto is_sing = [&](uint64_t d) { return std::binary_search(km.begin(), km.end(), d); };
+
+    std::vector<uint64_t> spl;
+    for (auto &c : ref) { // find_splitters_in_contig, :762-825
+        HostKmer h(k);
+        uint64_t current_len = segment_size;
+        size_t recent_from = 0;
+        for (size_t i = 0; i < c.size(); ++i) {
+            uint8_t x = c[i];
+            if (x > 3)
+                h.reset();
+            else {
+                h.insert(x);
+                if (h.full() && current_len >= segment_size && is_sing(h.data())) {
+                    spl.push_back(h.data());
+                    current_len = 0;
+                    h.reset();
+                    recent_from = i + 1;
+                }
+            }
+            ++current_len;
+        }
+        HostKmer t(k);
+        bool have = false;
+        uint64_t best = 0;
+        for (size_t i = recent_from; i < c.size(); ++i) {
+            uint8_t x = c[i];
+            if (x > 3) {
+                t.reset();
+                continue;
+            }
+            t.insert(x);
+            if (t.full() && is_sing(t.data())) {
+                best = t.data();
+                have = true;
+            }
+        }
+        if (have)
+            spl.push_back(best);
+    }
+    std::sort(spl.begin(), spl.end());
+    spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
+    return spl;
+}
+
+// ===========================================================================
+struct CAGCCompressor::Impl {
+    int device = 0;
+    agc_hip_ctx *hip = nullptr;
+    ZstdApi zstd;
+    std::unique_ptr<ThreadPool> pool;
+    std::vector<std::unique_ptr<ZstdCtx>> zctx;
+
+    bool created = false;
+    uint32_t pack_cardinality = 50, k = 31, segment_size = 60000, mml = 20, verbosity = 0;
+    bool concatenated = false, adaptive = false;
+
+    ArchiveWriter ar;
+    CollectionV3 coll;
+    std::vector<uint64_t> splitters;
+
+    std::unordered_map<pk_t, int32_t, PairHash> map_segments;                 // agc_compressor.h:628
+    std::unordered_map<uint64_t, std::vector<uint64_t>> terminators;          // agc_compressor.h:629
+    std::vector<Group> groups;                                                // v_segments
+    uint32_t no_segments = 0;
+    uint32_t processed_samples = 0;
+    size_t cnt_contigs_in_sample = 0;
+
+    CompressorStats st;
+
+    void err(const std::string &m) { std::cerr << m << std::endl; }
+    bool hip_ok(int rc, const char *what)
+    {
+        if (rc == AGC_HIP_OK)
+            return true;
+        err(std::string(what) + ": " + agc_hip_last_error(hip) + " (code " + std::to_string(rc) + ")");
+        return false;
+    }
+
+    // -----------------------------------------------------------------------
+    bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base);
+    void finish_groups();
+    void run_jobs(std::vector<ZJob> &jobs);
+    void make_pack_job(std::vector<ZJob> &jobs, Group &g, std::vector<bytes_t> &v);
+    void after_registration();
+};
+
+CAGCCompressor::CAGCCompressor() : p(new Impl) {}
+CAGCCompressor::~CAGCCompressor()
+{
+    if (p->hip)
+        agc_hip_destroy(p->hip);
+}
+
+bool CAGCCompressor::SetDevice(int device)
+{
+    if (p->hip)
+        return false;
+    p->device = device;
+    return true;
+}
+
+const CompressorStats &CAGCCompressor::Stats() const { return p->st; }
+const char *CAGCCompressor::ZstdVersion() const { return p->zstd.h ? p->zstd.versionString() : ""; }
+agc_hip_ctx *CAGCCompressor::HipContext() { return p->hip; }
+
+bool CAGCCompressor::SetSplitters(const uint64_t *kmers, uint64_t n)
+{
+    if (!p->created)
+        return false;
+    p->splitters.assign(kmers, kmers + n);
+    std::sort(p->splitters.begin(), p->splitters.end());
+    p->splitters.erase(std::unique(p->splitters.begin(), p->splitters.end()), p->splitters.end());
+    return p->hip_ok(agc_hip_splitters_set(p->hip, p->splitters.data(), p->splitters.size()), "splitters_set");
+}
+
+bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinality, uint32_t kmer_length, const std::string &reference_file_name,
+                            uint32_t segment_size, uint32_t min_match_len, bool concatenated_genomes, bool adaptive_compression,
+                            uint32_t verbosity, uint32_t no_threads, double fallback_frac)
+{
+    Impl &I = *p;
+    if (I.created)
+        return false;
+    if (adaptive_compression) {
+        I.err("adaptive mode (-a) is not implemented in this round");
+        return false;
+    }
+    if (fallback_frac != 0.0) {
+        I.err("fallback minimizers (-f) are not implemented");
+        return false;
+    }
+    I.pack_cardinality = pack_cardinality;
+    I.k = kmer_length;
+    I.segment_size = segment_size;
+    I.mml = min_match_len;
+    I.concatenated = concatenated_genomes;
+    I.adaptive = adaptive_compression;
+    I.verbosity = verbosity;
+
+    std::string e;
+    if (!I.zstd.load(e)) {
+        I.err(e);
+        return false;
+    }
+    if (!I.hip) {
+        int rc = agc_hip_create(&I.hip, I.device);
+        if (rc != AGC_HIP_OK) {
+            I.err("no HIP device: the MI355X path has no CPU fallback (agc_hip_create = " + std::to_string(rc) + ")");
+            return false;
+        }
+    }
+    unsigned nt = std::max(1u, no_threads);
+    I.pool.reset(new ThreadPool(nt));
+    for (unsigned i = 0; i < nt; ++i)
+        I.zctx.emplace_back(new ZstdCtx(&I.zstd));
+    I.created = true;
+
+    if (!reference_file_name.empty()) {
+        FastaReader fr;
+        if (!fr.open(reference_file_name)) {
+            I.err("Cannot open file: " + reference_file_name);
+            I.created = false;
+            return false;
+        }
+        std::vector<bytes_t> ref;
+        std::string id;
+        bytes_t c;
+        while (fr.read_contig_raw(id, c)) {
+            preprocess_raw_contig(c);
+            ref.emplace_back(std::move(c));
+            c.clear();
+        }
+        auto spl = determine_splitters_host(ref, I.k, I.segment_size, nt);
+        if (!SetSplitters(spl.data(), spl.size()))
+            return false;
+        if (I.verbosity > 1)
+            std::cerr << "No. of splitters: " << spl.size() << std::endl;
+    }
+
+    if (!I.ar.open(file_name)) {
+        I.err("Cannot create archive " + file_name);
+        I.created = false;
+        return false;
+    }
+    I.coll.set_archive(&I.ar, &I.zstd, I.segment_size, I.k);
+    I.map_segments[{NO_KMER, NO_KMER}] = 0;
+    I.groups.resize(NO_RAW_GROUPS);
+    for (I.no_segments = 0; I.no_segments < NO_RAW_GROUPS; ++I.no_segments) {
+        Group &g = I.groups[I.no_segments];
+        g.exists = true;
+        g.stream_delta = I.ar.register_stream(ss_delta_name(I.no_segments));
+        g.no_seqs = 1;                  // add_raw({0x7f}), agc_compressor.cpp:2313-2321
+        g.v_raw.push_back(bytes_t{0x7f});
+    }
+    I.coll.reset_prev_sample_name();
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// store_in_archive(pack), segment.h:258-280: sequences + 0xFF separators -> zstd 17
+void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, std::vector<bytes_t> &v)
+{
+    ZJob j;
+    j.stream_id = g.stream_delta;
+    j.kind = 1;
+    size_t n = 0;
+    for (auto &x : v)
+        n += x.size() + 1;
+    j.data.reserve(n);
+    for (auto &x : v) {
+        j.data.insert(j.data.end(), x.begin(), x.end());
+        j.data.push_back(0xff);
+    }
+    jobs.emplace_back(std::move(j));
+}
+
+// add_to_archive / add_to_archive_tuples, segment.h:172-215; store_in_archive(ref) :218-255
+void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs)
+{
+    double t0 = now();
+    pool->parallel_for(jobs.size(), [&](size_t i, unsigned tid) {
+        ZJob &j = jobs[i];
+        ZstdCtx &z = *zctx[tid];
+        const bytes_t *src = &j.data;
+        bytes_t tuples;
+        int level = 17;
+        uint8_t marker = 0;
+        if (j.kind == 0) {
+            if (!j.repetitive) {
+                bytes2tuples(j.data, tuples);
+                src = &tuples;
+                level = 13;
+                marker = 1;
+            } else
+                level = 19;
+        }
+        size_t bound = zstd.compressBound(src->size());
+        bytes_t packed(bound + 1);
+        uint32_t ps = (uint32_t)z.compress(packed.data(), bound, src->data(), src->size(), level);
+        packed[ps] = marker;
+        if (ps + 1u < (uint32_t)j.data.size()) {
+            packed.resize((size_t)ps + 1);
+            j.out = std::move(packed);
+            j.meta = j.data.size();
+        } else {
+            j.out = j.data;
+            j.meta = 0;
+        }
+    });
+    for (auto &j : jobs) {
+        st.zstd_in += j.data.size();
+        st.zstd_out += j.out.size();
+        ar.add_part_buffered(j.stream_id, std::move(j.out), j.meta);
+    }
+    st.t_zstd += now() - t0;
+}
+
+// the tail of the registration token handling, agc_compressor.cpp:1136-1180
+void CAGCCompressor::Impl::after_registration()
+{
+    if (!concatenated)
+        ++processed_samples;
+    else {
+        processed_samples = processed_samples / pack_cardinality * pack_cardinality + pack_cardinality;
+        uint32_t max_ps = (uint32_t)coll.no_samples();
+        if (max_ps < processed_samples)
+            processed_samples = max_ps;
+    }
+    if (processed_samples % pack_cardinality == 0)
+        coll.store_contig_batch(processed_samples - pack_cardinality, processed_samples);
+    ar.flush_out_buffers();
+}
+
+// ---------------------------------------------------------------------------
+bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base)
+{
+    const uint32_t n_ctg = (uint32_t)ctgs.size();
+    double t0 = now();
+
+    // ---- stage 1a: splitter scan on the GPU (compress_contig's loop) ----
+    std::vector<uint64_t> ctg_off(n_ctg + 1, 0);
+    for (uint32_t i = 0; i < n_ctg; ++i) {
+        ctg_off[i] = ctgs[i].off;
+        st.bases += ctgs[i].len;
+    }
+    if (n_ctg)
+        ctg_off[n_ctg] = ctgs.back().off + ctgs.back().len;
+    for (uint32_t i = 0; i + 1 < n_ctg; ++i)
+        if (ctgs[i].off + ctgs[i].len != ctgs[i + 1].off) {
+            err("internal: contigs of a batch must be contiguous in HBM");
+            return false;
+        }
+    std::vector<uint32_t> h_ctg;
+    std::vector<uint64_t> h_pos, h_dir, h_rc;
+    uint64_t n_hits = 0;
+    if (n_ctg) {
+        uint64_t cap = std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000);
+        for (;;) {
+            h_ctg.resize(cap);
+            h_pos.resize(cap);
+            h_dir.resize(cap);
+            h_rc.resize(cap);
+            int rc = agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
+                                              h_rc.data());
+            if (rc == AGC_HIP_ECAP) {
+                cap = n_hits;
+                continue;
+            }
+            if (!hip_ok(rc, "scan_contigs"))
+                return false;
+            break;
+        }
+    }
+    st.t_scan += now() - t0;
+    t0 = now();
+
+    // ---- stage 1b: cut into segments (agc_compressor.cpp:2018-2048) ----
+    std::vector<Seg> segs;
+    segs.reserve(n_hits + n_ctg);
+    {
+        uint64_t h = 0;
+        for (uint32_t c = 0; c < n_ctg; ++c) {
+            uint64_t split_pos = 0;
+            Kmer split_kmer;
+            while (h < n_hits && h_ctg[h] == c) {
+                Seg s;
+                s.ctg = c;
+                s.start = split_pos;
+                s.len = (uint32_t)(h_pos[h] + 1 - split_pos);
+                s.front = split_kmer;
+                s.back.dir = h_dir[h];
+                s.back.rc = h_rc[h];
+                s.back.full = true;
+                segs.push_back(s);
+                split_pos = h_pos[h] + 1 - k;
+                split_kmer = s.back;
+                ++h;
+            }
+            if (split_pos < ctgs[c].len) {
+                Seg s;
+                s.ctg = c;
+                s.start = split_pos;
+                s.len = (uint32_t)(ctgs[c].len - split_pos);
+                s.front = split_kmer;
+                segs.push_back(s);
+            }
+        }
+    }
+
+    // ---- stage 1c: add_segment, part 1: keys and one-splitter candidates ----
+    std::vector<Cand> cands;
+    for (Seg &s : segs) {
+        const bool ff = s.front.full, bf = s.back.full;
+        if (!ff && !bf) {
+            s.pk = {NO_KMER, NO_KMER}; // agc_compressor.cpp:1286-1301 (fallback filter off)
+        } else if (ff && bf) {
+            if (s.front.data() < s.back.data())
+                s.pk = {s.front.data(), s.back.data()};
+            else {
+                s.pk = {s.back.data(), s.front.data()};
+                s.store_rc = true;
+            }
+        } else {
+            s.back_only = !ff;
+            s.one_kmer = ff ? s.front : s.back;
+            if (s.back_only)
+                s.one_kmer.swap_dir_rc(); // :1339-1340
+            s.cand_begin = (uint32_t)cands.size();
+            auto t = terminators.find(s.one_kmer.data());
+            if (t != terminators.end()) {
+                for (uint64_t ck : t->second) {
+                    Cand c;
+                    if (ck < s.one_kmer.data()) {
+                        c.pk = {ck, s.one_kmer.data()};
+                        c.use_rc = true;
+                    } else {
+                        c.pk = {s.one_kmer.data(), ck};
+                        c.use_rc = false;
+                    }
+                    auto m = map_segments.find(c.pk);
+                    if (m == map_segments.end()) {
+                        err("internal: terminator without group");
+                        return false;
+                    }
+                    c.gid = (uint32_t)m->second;
+                    c.ref_size = groups[c.gid].ref_size;
+                    cands.push_back(c);
+                }
+                // stable_sort by |segment_size - ref_size|, then ref_size (:1681-1690)
+                const int64_t ssz = (int64_t)s.len;
+                std::stable_sort(cands.begin() + s.cand_begin, cands.end(), [ssz](const Cand &x, const Cand &y) {
+                    int64_t xs = (int64_t)x.ref_size, ys = (int64_t)y.ref_size;
+                    int64_t ax = std::llabs(ssz - xs), ay = std::llabs(ssz - ys);
+                    if (ax != ay)
+                        return ax < ay;
+                    return xs < ys;
+                });
+            }
+            s.cand_end = (uint32_t)cands.size();
+            ++st.one_splitter;
+        }
+    }
+    st.t_classify += now() - t0;
+    t0 = now();
+
+    // ---- GPU: estimates for every (one-splitter segment, candidate) pair ----
+    std::vector<uint32_t> est_cost(cands.size()), est_peak(cands.size());
+    if (!cands.empty()) {
+        std::vector<uint32_t> gid(cands.size()), len(cands.size());
+        std::vector<uint64_t> off(cands.size());
+        std::vector<uint8_t> rc(cands.size());
+        for (Seg &s : segs)
+            for (uint32_t c = s.cand_begin; c < s.cand_end; ++c) {
+                gid[c] = cands[c].gid;
+                off[c] = ctgs[s.ctg].off + s.start;
+                len[c] = s.len;
+                // front-only: segment_dir = the segment itself; back-only: segment_dir = its reverse complement (:1317-1345)
+                rc[c] = (uint8_t)(s.back_only ? !cands[c].use_rc : cands[c].use_rc);
+            }
+        if (!hip_ok(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)cands.size(), gid.data(), d_base, off.data(), len.data(), rc.data(),
+                                                  est_cost.data(), est_peak.data()),
+                    "lz_estimate_batch"))
+            return false;
+    }
+    st.t_gpu_aux += now() - t0;
+    t0 = now();
+
+    // ---- add_segment, part 2: resolve one-splitter keys (:1630-1808) ----
+    for (Seg &s : segs) {
+        if (s.front.full == s.back.full)
+            continue;
+        const Kmer &kmer = s.one_kmer;
+        pk_t best_pk{NO_KMER, NO_KMER};
+        bool is_best_rc = false;
+        uint64_t best_estim = s.len < 16 ? s.len : s.len - 16u;
+        const uint32_t nc = s.cand_end - s.cand_begin;
+        std::vector<uint64_t> v_est(nc);
+        for (uint32_t i = 0; i < nc; ++i) {
+            const uint32_t c = s.cand_begin + i;
+            // CSegment::estimate returns 0 for a group without reference (segment.cpp:85-86)
+            uint64_t e;
+            if (groups[cands[c].gid].ref_size == 0)
+                e = 0;
+            else if ((uint64_t)est_peak[c] > (uint32_t)best_estim)
+                e = ~0ULL; // the bounded call returned early with a value > bound: never selected
+            else
+                e = est_cost[c];
+            v_est[i] = e;
+            if (e < best_estim)
+                best_estim = e;
+        }
+        for (uint32_t i = 0; i < nc; ++i) {
+            const Cand &c = cands[s.cand_begin + i];
+            if (v_est[i] < best_estim || (v_est[i] == best_estim && c.pk < best_pk) ||
+                (v_est[i] == best_estim && c.pk == best_pk && !c.use_rc)) {
+                best_estim = v_est[i];
+                best_pk = c.pk;
+                is_best_rc = c.use_rc;
+            }
+        }
+        if (best_pk == pk_t{NO_KMER, NO_KMER}) {
+            if (kmer.is_dir_oriented())
+                best_pk = {kmer.data(), NO_KMER};
+            else {
+                best_pk = {NO_KMER, kmer.data()};
+                is_best_rc = true;
+            }
+        }
+        s.pk = best_pk;
+        s.store_rc = s.back_only ? !is_best_rc : is_best_rc;
+    }
+
+    // ---- add_segment, part 3: missing-middle-splitter candidates (:1366-1459, 1502-1627) ----
+    struct MidJob {
+        uint32_t seg, gid1, gid2;
+        uint8_t rc1, pf1, rc2, pf2;
+    };
+    std::vector<MidJob> mids;
+    for (uint32_t si = 0; si < segs.size(); ++si) {
+        Seg &s = segs[si];
+        if (concatenated || s.pk.first == NO_KMER || s.pk.second == NO_KMER || map_segments.count(s.pk))
+            continue;
+        auto tf = terminators.find(s.pk.first), tb = terminators.find(s.pk.second);
+        if (tf == terminators.end() || tb == terminators.end())
+            continue;
+        if (s.front.data() == s.back.data()) {
+            if (!s.front.is_dir_oriented())
+                s.store_rc = true;
+            continue;
+        }
+        s.kmer1 = s.front;
+        s.kmer2 = s.back;
+        s.use_rc = false;
+        if (s.kmer1.data() > s.kmer2.data()) {
+            std::swap(s.kmer1, s.kmer2);
+            s.use_rc = true;
+            s.kmer1.swap_dir_rc();
+            s.kmer2.swap_dir_rc();
+        }
+        auto p_front = terminators.find(s.kmer1.data()), p_back = terminators.find(s.kmer2.data());
+        std::vector<uint64_t> shared;
+        std::set_intersection(p_front->second.begin(), p_front->second.end(), p_back->second.begin(), p_back->second.end(),
+                              std::back_inserter(shared));
+        shared.erase(std::remove(shared.begin(), shared.end(), NO_KMER), shared.end());
+        ++st.middle_tried;
+        if (shared.empty())
+            continue;
+        s.middle = shared.front();
+        auto m1 = map_segments.find(std::minmax(s.kmer1.data(), s.middle)), m2 = map_segments.find(std::minmax(s.middle, s.kmer2.data()));
+        if (m1 == map_segments.end() || m2 == map_segments.end()) {
+            err("internal: shared terminator without group");
+            return false;
+        }
+        MidJob j;
+        j.seg = si;
+        j.gid1 = (uint32_t)m1->second;
+        j.gid2 = (uint32_t)m2->second;
+        // segment_dir here = use_rc ? rc(segment) : segment (:1394)
+        const bool f_lt_m = s.kmer1.data() < s.middle, m_lt_b = s.middle < s.kmer2.data();
+        j.rc1 = (uint8_t)(f_lt_m ? s.use_rc : !s.use_rc);
+        j.pf1 = f_lt_m ? 1 : 0;
+        j.rc2 = (uint8_t)(m_lt_b ? s.use_rc : !s.use_rc);
+        j.pf2 = m_lt_b ? 0 : 1;
+        s.mid_job = (int32_t)mids.size();
+        mids.push_back(j);
+    }
+    st.t_classify += now() - t0;
+    t0 = now();
+    std::vector<uint32_t> best_pos(mids.size());
+    if (!mids.empty()) {
+        size_t n = mids.size();
+        std::vector<uint32_t> g1(n), g2(n), len(n);
+        std::vector<uint64_t> off(n);
+        std::vector<uint8_t> r1(n), p1(n), r2(n), p2(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Seg &s = segs[mids[i].seg];
+            g1[i] = mids[i].gid1;
+            g2[i] = mids[i].gid2;
+            off[i] = ctgs[s.ctg].off + s.start;
+            len[i] = s.len;
+            r1[i] = mids[i].rc1;
+            p1[i] = mids[i].pf1;
+            r2[i] = mids[i].rc2;
+            p2[i] = mids[i].pf2;
+        }
+        if (!hip_ok(agc_hip_lz_split_point_batch_dev(hip, (uint32_t)n, g1.data(), g2.data(), d_base, off.data(), len.data(), r1.data(),
+                                                     p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr),
+                    "lz_split_point_batch"))
+            return false;
+    }
+    st.t_gpu_aux += now() - t0;
+    t0 = now();
+
+    // ---- add_segment, part 4: final placement + part numbers ----
+    std::vector<Placed> placed;
+    placed.reserve(segs.size() + mids.size());
+    {
+        uint32_t cur_ctg = ~0u, part_no = 0;
+        for (Seg &s : segs) {
+            if (s.ctg != cur_ctg) {
+                cur_ctg = s.ctg;
+                part_no = 0;
+            }
+            const uint64_t abs_off = ctgs[s.ctg].off + s.start;
+            bool two = false;
+            Placed a, b;
+            a.ctg = b.ctg = s.ctg;
+            if (s.mid_job >= 0) {
+                uint32_t bp = best_pos[s.mid_job];
+                if (bp < k + 1u)
+                    bp = 0;
+                if ((size_t)bp + k + 1u > s.len)
+                    bp = s.len;
+                uint32_t left = bp, right = s.len - bp;
+                if (left == 0) {
+                    s.store_rc = (s.middle < s.kmer2.data()) ? s.use_rc : !s.use_rc;
+                    s.pk = std::minmax(s.middle, s.kmer2.data());
+                } else if (right == 0) {
+                    s.store_rc = (s.kmer1.data() < s.middle) ? s.use_rc : !s.use_rc;
+                    s.pk = std::minmax(s.kmer1.data(), s.middle);
+                } else {
+                    if (s.use_rc)
+                        std::swap(left, right);
+                    const uint32_t seg2_start = left - k / 2;
+                    two = true;
+                    ++st.middle_split;
+                    // first part: [0, seg2_start + k)
+                    a.off = abs_off;
+                    a.len = seg2_start + k;
+                    if (s.front.data() < s.middle) {
+                        a.rc = false;
+                        a.pk = {s.front.data(), s.middle};
+                    } else {
+                        a.rc = true;
+                        a.pk = {s.middle, s.front.data()};
+                    }
+                    // second part: [seg2_start, len)
+                    b.off = abs_off + seg2_start;
+                    b.len = s.len - seg2_start;
+                    if (s.middle < s.back.data()) {
+                        b.rc = false;
+                        b.pk = {s.middle, s.back.data()};
+                    } else {
+                        b.rc = true;
+                        b.pk = {s.back.data(), s.middle};
+                    }
+                    auto ma = map_segments.find(a.pk), mb = map_segments.find(b.pk);
+                    if (ma == map_segments.end() || mb == map_segments.end()) {
+                        err("internal: split target group missing");
+                        return false;
+                    }
+                    a.gid = ma->second;
+                    b.gid = mb->second;
+                }
+            }
+            if (two) {
+                a.part_no = part_no;
+                b.part_no = part_no + 1;
+                placed.push_back(a);
+                placed.push_back(b);
+                part_no += 2;
+            } else {
+                a.off = abs_off;
+                a.len = s.len;
+                a.rc = s.store_rc;
+                a.pk = s.pk;
+                auto m = map_segments.find(s.pk);
+                a.gid = m == map_segments.end() ? -1 : m->second;
+                a.part_no = part_no++;
+                placed.push_back(a);
+            }
+        }
+    }
+    st.segments += placed.size();
+
+    // ---- register_segments (agc_compressor.cpp:954-971; agc_compressor.h:384-435) ----
+    auto key_less = [&](uint32_t x, uint32_t y) {
+        const Placed &a = placed[x], &b = placed[y];
+        const Contig &ca = ctgs[a.ctg], &cb = ctgs[b.ctg];
+        if (ca.sample != cb.sample)
+            return ca.sample < cb.sample;
+        if (ca.name != cb.name)
+            return ca.name < cb.name;
+        return a.part_no < b.part_no;
+    };
+    std::vector<uint32_t> order(placed.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), key_less);
+    const uint32_t first_new_gid = no_segments;
+    {
+        std::map<pk_t, uint32_t> m_kmers;
+        uint32_t gid = no_segments;
+        for (uint32_t idx : order)
+            if (placed[idx].gid < 0) {
+                auto it = m_kmers.find(placed[idx].pk);
+                if (it == m_kmers.end())
+                    it = m_kmers.emplace(placed[idx].pk, gid++).first;
+                placed[idx].gid = (int32_t)it->second;
+            }
+        const uint32_t no_new = gid - no_segments;
+        for (uint32_t i = 0; i < no_new; ++i) {
+            groups.emplace_back();
+            Group &g = groups.back();
+            g.stream_ref = ar.register_stream(ss_ref_name(no_segments + i));
+            g.stream_delta = ar.register_stream(ss_delta_name(no_segments + i));
+        }
+        no_segments += no_new;
+        st.new_groups += no_new;
+    }
+    // per-group lists in sorted order
+    std::vector<std::vector<uint32_t>> lists; // index by a dense id of the groups touched
+    std::unordered_map<uint32_t, uint32_t> dense;
+    std::vector<uint32_t> dense_gid;
+    auto list_of = [&](uint32_t gid) -> std::vector<uint32_t> & {
+        auto it = dense.find(gid);
+        if (it == dense.end()) {
+            it = dense.emplace(gid, (uint32_t)lists.size()).first;
+            lists.emplace_back();
+            dense_gid.push_back(gid);
+        }
+        return lists[it->second];
+    };
+    {
+        // distribute_segments(0, 0, 16) on the sorted list of group 0 (agc_compressor.h:417-435)
+        std::vector<uint32_t> raw0;
+        for (uint32_t idx : order)
+            if (placed[idx].gid == 0)
+                raw0.push_back(idx);
+        const size_t n0 = raw0.size();
+        const size_t n_moved = n0 - (n0 + 15) / 16;
+        for (size_t j = 0; j < n0; ++j)
+            placed[raw0[j]].gid = j < n_moved ? (int32_t)(1 + (j % 15)) : 0;
+        for (uint32_t idx : order)
+            list_of((uint32_t)placed[idx].gid).push_back(idx);
+    }
+    st.t_register += now() - t0;
+    t0 = now();
+
+    // ---- store_segments (agc_compressor.cpp:974-1050) ----
+    // (a) new groups: their first item becomes the reference (segment.cpp:39-48)
+    std::vector<uint32_t> new_ref_items; // placed indices, one per new group with items
+    std::vector<uint32_t> raw_items;
+    std::vector<uint32_t> enc_items;
+    for (size_t li = 0; li < lists.size(); ++li) {
+        const uint32_t gid = dense_gid[li];
+        Group &g = groups[gid];
+        bool first = true;
+        for (uint32_t idx : lists[li]) {
+            if (gid < NO_RAW_GROUPS)
+                raw_items.push_back(idx);
+            else if (!g.exists && first)
+                new_ref_items.push_back(idx);
+            else
+                enc_items.push_back(idx);
+            first = false;
+        }
+    }
+    // map_segments / terminators updates happen when a group is first stored (:1003-1028)
+    for (uint32_t idx : new_ref_items) {
+        const Placed &pl = placed[idx];
+        const uint32_t gid = (uint32_t)pl.gid;
+        auto it = map_segments.find(pl.pk);
+        if (it == map_segments.end())
+            map_segments[pl.pk] = (int32_t)gid;
+        else if (it->second > (int32_t)gid)
+            it->second = (int32_t)gid;
+        if (pl.pk.first != NO_KMER && pl.pk.second != NO_KMER) {
+            auto &v1 = terminators[pl.pk.first];
+            v1.push_back(pl.pk.second);
+            std::sort(v1.begin(), v1.end());
+            if (pl.pk.first != pl.pk.second) {
+                auto &v2 = terminators[pl.pk.second];
+                v2.push_back(pl.pk.first);
+                std::sort(v2.begin(), v2.end());
+            }
+        }
+    }
+    // GPU: register the new references (index build) and pull back what the host must pack
+    std::vector<uint32_t> lag_cnt, lag_cur;
+    bytes_t fetched;
+    std::vector<uint64_t> fetched_off;
+    {
+        const size_t nr = new_ref_items.size();
+        if (nr) {
+            std::vector<uint32_t> gid(nr), len(nr);
+            std::vector<uint64_t> off(nr);
+            std::vector<uint8_t> rc(nr);
+            for (size_t i = 0; i < nr; ++i) {
+                const Placed &pl = placed[new_ref_items[i]];
+                gid[i] = (uint32_t)pl.gid;
+                off[i] = pl.off;
+                len[i] = pl.len;
+                rc[i] = pl.rc;
+                st.ref_bytes += pl.len;
+            }
+            if (!hip_ok(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml), "ref_register_batch"))
+                return false;
+            lag_cnt.resize(nr * 28);
+            lag_cur.resize(nr * 28);
+            if (!hip_ok(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data()), "ref_lag_counts"))
+                return false;
+        }
+        const size_t nf = nr + raw_items.size();
+        if (nf) {
+            std::vector<uint32_t> len(nf);
+            std::vector<uint64_t> off(nf);
+            std::vector<uint8_t> rc(nf);
+            uint64_t tot = 0;
+            for (size_t i = 0; i < nf; ++i) {
+                const Placed &pl = placed[i < nr ? new_ref_items[i] : raw_items[i - nr]];
+                off[i] = pl.off;
+                len[i] = pl.len;
+                rc[i] = pl.rc;
+                tot += pl.len;
+            }
+            fetched.resize(tot);
+            fetched_off.resize(nf + 1);
+            if (!hip_ok(agc_hip_fetch_slices_dev(hip, (uint32_t)nf, d_base, off.data(), len.data(), rc.data(), fetched.data(), tot, fetched_off.data()), "fetch_slices"))
+                return false;
+        }
+    }
+    st.t_register += now() - t0;
+    t0 = now();
+    // GPU: LZ-encode every other item against its group's reference (segment.cpp:50-58)
+    bytes_t enc;
+    std::vector<uint64_t> enc_off(enc_items.size() + 1, 0);
+    if (!enc_items.empty()) {
+        const size_t ne = enc_items.size();
+        std::vector<uint32_t> gid(ne), len(ne);
+        std::vector<uint64_t> off(ne);
+        std::vector<uint8_t> rc(ne);
+        uint64_t tot = 0;
+        for (size_t i = 0; i < ne; ++i) {
+            const Placed &pl = placed[enc_items[i]];
+            gid[i] = (uint32_t)pl.gid;
+            off[i] = pl.off;
+            len[i] = pl.len;
+            rc[i] = pl.rc;
+            tot += pl.len;
+        }
+        uint64_t cap = tot / 8 + 65536;
+        for (;;) {
+            enc.resize(cap);
+            int r = agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap, enc_off.data());
+            if (r == AGC_HIP_ECAP) {
+                cap = enc_off[ne] + 64;
+                continue;
+            }
+            if (!hip_ok(r, "lz_encode_batch"))
+                return false;
+            break;
+        }
+        st.lz_encoded += ne;
+        st.delta_bytes += enc_off[ne];
+    }
+    st.t_encode += now() - t0;
+    t0 = now();
+
+    // (b) per-group bookkeeping in list order: CSegment::add / add_raw (segment.cpp:14-80)
+    std::unordered_map<uint32_t, uint32_t> pos_newref, pos_raw, pos_enc;
+    for (uint32_t i = 0; i < new_ref_items.size(); ++i)
+        pos_newref[new_ref_items[i]] = i;
+    for (uint32_t i = 0; i < raw_items.size(); ++i)
+        pos_raw[raw_items[i]] = i;
+    for (uint32_t i = 0; i < enc_items.size(); ++i)
+        pos_enc[enc_items[i]] = i;
+    std::vector<ZJob> jobs;
+    std::vector<uint32_t> in_group_id(placed.size(), 0);
+    for (size_t li = 0; li < lists.size(); ++li) {
+        const uint32_t gid = dense_gid[li];
+        Group &g = groups[gid];
+        for (uint32_t idx : lists[li]) {
+            const Placed &pl = placed[idx];
+            uint32_t igid;
+            if (gid < NO_RAW_GROUPS) {
+                if (g.v_raw.size() == pack_cardinality) {
+                    make_pack_job(jobs, g, g.v_raw);
+                    g.v_raw.clear();
+                }
+                const uint32_t fi = (uint32_t)new_ref_items.size() + pos_raw[idx];
+                ++g.no_seqs;
+                g.v_raw.emplace_back(fetched.begin() + fetched_off[fi], fetched.begin() + fetched_off[fi + 1]);
+                igid = g.no_seqs - 1;
+            } else if (!g.exists) {
+                g.exists = true;
+                const uint32_t fi = pos_newref[idx];
+                ZJob j;
+                j.stream_id = g.stream_ref;
+                j.kind = 0;
+                j.data.assign(fetched.begin() + fetched_off[fi], fetched.begin() + fetched_off[fi + 1]);
+                // repetitiveness probe with the reference's double arithmetic (segment.h:224-247)
+                double best_frac = 0.0;
+                for (uint32_t l = 0; l < 28; ++l) {
+                    const uint32_t cnt = lag_cnt[fi * 28 + l], cur = lag_cur[fi * 28 + l];
+                    double frac = 0.0;
+                    if (cur)
+                        frac = (double)cnt / cur;
+                    if (frac > best_frac) {
+                        best_frac = frac;
+                        if (best_frac >= 0.5)
+                            break;
+                    }
+                }
+                j.repetitive = !(best_frac < 0.5);
+                jobs.emplace_back(std::move(j));
+                g.ref_size = (uint64_t)pl.len + 1;
+                g.no_seqs = 1;
+                igid = 0;
+            } else {
+                if (g.v_lzp.size() == pack_cardinality) {
+                    make_pack_job(jobs, g, g.v_lzp);
+                    g.v_lzp.clear();
+                }
+                const uint32_t ei = pos_enc[idx];
+                bytes_t delta(enc.begin() + enc_off[ei], enc.begin() + enc_off[ei + 1]);
+                if (delta.empty())
+                    igid = 0; // same sequence as the reference (segment.cpp:60-63)
+                else {
+                    auto f = std::find(g.v_lzp.begin(), g.v_lzp.end(), delta);
+                    if (f != g.v_lzp.end())
+                        igid = g.no_seqs - (uint32_t)std::distance(f, g.v_lzp.end());
+                    else {
+                        g.v_lzp.emplace_back(std::move(delta));
+                        ++g.no_seqs;
+                        igid = g.no_seqs - 1;
+                    }
+                }
+            }
+            in_group_id[idx] = igid;
+        }
+    }
+    // collection records (agc_compressor.cpp:1038-1049)
+    {
+        std::string cur_sample;
+        CollectionV3::SampleDesc *sd = nullptr;
+        std::vector<CollectionV3::ContigDesc *> cd(n_ctg, nullptr);
+        for (uint32_t c = 0; c < n_ctg; ++c) {
+            std::string stored = ctgs[c].sample.empty() ? CollectionV3::extract_contig_name(ctgs[c].name) : ctgs[c].sample;
+            sd = &coll.sample_by_name(stored);
+            for (auto &x : sd->contigs)
+                if (x.name == ctgs[c].name) {
+                    cd[c] = &x;
+                    break;
+                }
+        }
+        for (uint32_t idx = 0; idx < placed.size(); ++idx) {
+            const Placed &pl = placed[idx];
+            auto *c = cd[pl.ctg];
+            if (!c)
+                continue;
+            if (pl.part_no >= c->segments.size())
+                c->segments.resize((size_t)pl.part_no + 1);
+            c->segments[pl.part_no] = {(uint32_t)pl.gid, in_group_id[idx], pl.len, pl.rc};
+        }
+    }
+    st.t_store += now() - t0;
+    run_jobs(jobs);
+    return true;
+}
+
+// CSegment::finish for every group (agc_compressor.cpp:880-904, segment.cpp:125-133)
+void CAGCCompressor::Impl::finish_groups()
+{
+    std::vector<ZJob> jobs;
+    for (uint32_t gid = 0; gid < groups.size(); ++gid) {
+        Group &g = groups[gid];
+        if (!g.v_lzp.empty()) {
+            make_pack_job(jobs, g, g.v_lzp);
+            g.v_lzp.clear();
+        }
+        if (!g.v_raw.empty()) {
+            make_pack_job(jobs, g, g.v_raw);
+            g.v_raw.clear();
+        }
+    }
+    run_jobs(jobs);
+}
+
+// ---------------------------------------------------------------------------
+bool CAGCCompressor::AddSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
+                                     const uint64_t *ctg_off)
+{
+    Impl &I = *p;
+    if (!I.created || I.concatenated)
+        return false;
+    I.coll.reset_prev_sample_name();
+    std::vector<Contig> ctgs;
+    for (size_t c = 0; c < contig_names.size(); ++c) {
+        if (!I.coll.register_sample_contig(sample_name, contig_names[c])) {
+            I.err("Error: Pair sample_name:contig_name " + sample_name + ":" + contig_names[c] + " is already in the archive!");
+            continue;
+        }
+        Contig ct;
+        ct.sample = sample_name;
+        ct.name = contig_names[c];
+        ct.off = ctg_off[c];
+        ct.len = ctg_off[c + 1] - ctg_off[c];
+        ctgs.push_back(ct);
+    }
+    if (ctgs.empty())
+        return true;
+    // contigs skipped above would break contiguity: only accept the all-or-nothing case
+    if (ctgs.size() != contig_names.size()) {
+        I.err("duplicate contigs inside a device-resident sample are not supported");
+        return false;
+    }
+    if (!I.process_batch(ctgs, d_codes))
+        return false;
+    I.after_registration();
+    return true;
+}
+
+bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std::string>> &files, uint32_t no_threads)
+{
+    Impl &I = *p;
+    (void)no_threads;
+    if (!I.created)
+        return false;
+    if (files.empty())
+        return true;
+    I.processed_samples = 0;
+    if (I.concatenated)
+        I.cnt_contigs_in_sample = I.processed_samples % I.pack_cardinality;
+
+    std::vector<Contig> batch;
+    std::vector<bytes_t> batch_data;
+    auto flush_batch = [&]() -> bool {
+        // upload the batch's contigs back to back and run the registration cycle
+        uint64_t tot = 0;
+        for (auto &d : batch_data)
+            tot += d.size();
+        uint8_t *d_base = nullptr;
+        double t0 = now();
+        if (!I.hip_ok(agc_hip_sample_buffer(I.hip, tot, &d_base), "sample_buffer"))
+            return false;
+        uint64_t o = 0;
+        for (size_t c = 0; c < batch.size(); ++c) {
+            batch[c].off = o;
+            batch[c].len = batch_data[c].size();
+            if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_base + o, batch_data[c].data(), batch_data[c].size()), "copy_to_device"))
+                return false;
+            o += batch_data[c].size();
+        }
+        I.st.t_io += now() - t0;
+        bool ok = I.process_batch(batch, d_base);
+        batch.clear();
+        batch_data.clear();
+        if (ok)
+            I.after_registration();
+        return ok;
+    };
+
+    for (auto &sf : files) {
+        I.coll.reset_prev_sample_name();
+        FastaReader fr;
+        if (!fr.open(sf.second)) {
+            I.err("Cannot open file: " + sf.second);
+            continue;
+        }
+        std::string id;
+        bytes_t contig;
+        bool any_read = false, any_added = false;
+        double t0 = now();
+        while (fr.read_contig_raw(id, contig)) {
+            const std::string sname = I.concatenated ? std::string() : sf.first;
+            if (!I.coll.register_sample_contig(sname, id))
+                I.err("Error: Pair sample_name:contig_name " + (I.concatenated ? id : sf.first) + ":" + id + " is already in the archive!");
+            else {
+                preprocess_raw_contig(contig);
+                Contig ct;
+                ct.sample = sname;
+                ct.name = id;
+                batch.push_back(ct);
+                batch_data.emplace_back(std::move(contig));
+                contig.clear();
+                any_added = true;
+                if (I.concatenated && ++I.cnt_contigs_in_sample >= I.pack_cardinality) {
+                    I.st.t_io += now() - t0;
+                    if (!flush_batch())
+                        return false;
+                    t0 = now();
+                    I.cnt_contigs_in_sample = 0;
+                }
+            }
+            any_read = true;
+        }
+        I.st.t_io += now() - t0;
+        if (!any_read)
+            I.err("Warning: Pair sample_name:file_path " + sf.first + ":" + sf.second + " contains no contigs and will not be included in the archive!");
+        if (!any_added)
+            I.err("Warning: Pair sample_name:file_path " + sf.first + ":" + sf.second + " contains only contigs already present in the archive!");
+        if (!I.concatenated && any_added)
+            if (!flush_batch())
+                return false;
+    }
+    if (I.concatenated) {
+        // the reference always sends one more registration token at the end (:2231-2238)
+        if (!flush_batch())
+            return false;
+        I.cnt_contigs_in_sample = 0;
+        I.processed_samples = (uint32_t)I.coll.no_samples();
+    }
+    if (I.processed_samples % I.pack_cardinality != 0)
+        I.coll.store_contig_batch((I.processed_samples / I.pack_cardinality) * I.pack_cardinality, I.processed_samples);
+    I.ar.flush_out_buffers();
+    return true;
+}
+
+// close_compression (agc_compressor.cpp:2094-2115), store_metadata (:175-284), store_file_type_info (:287-300)
+bool CAGCCompressor::Close(uint32_t no_threads)
+{
+    Impl &I = *p;
+    (void)no_threads;
+    if (!I.created)
+        return false;
+    I.finish_groups();
+    I.ar.flush_out_buffers();
+
+    auto app32 = [](bytes_t &d, uint32_t x) {
+        for (int i = 0; i < 4; ++i, x >>= 8)
+            d.push_back((uint8_t)(x & 0xff));
+    };
+    auto app64 = [](bytes_t &d, uint64_t x) {
+        for (int i = 0; i < 8; ++i, x >>= 8)
+            d.push_back((uint8_t)(x & 0xff));
+    };
+    auto appstr = [](bytes_t &d, const std::string &s) {
+        d.insert(d.end(), s.begin(), s.end());
+        d.push_back(0);
+    };
+    bytes_t v;
+    app32(v, I.k);
+    app32(v, I.mml);
+    app32(v, I.pack_cardinality);
+    app32(v, I.segment_size);
+    I.ar.add_part(I.ar.register_stream("params"), v, 0);
+
+    v.clear();
+    for (uint64_t x : I.splitters) // sorted
+        app64(v, x);
+    I.ar.add_part(I.ar.register_stream("splitters"), v, I.splitters.size());
+
+    std::vector<std::pair<pk_t, int32_t>> ms(I.map_segments.begin(), I.map_segments.end());
+    std::sort(ms.begin(), ms.end());
+    v.clear();
+    for (auto &x : ms) {
+        app64(v, x.first.first);
+        app64(v, x.first.second);
+        app32(v, (uint32_t)x.second);
+    }
+    I.ar.add_part(I.ar.register_stream("segment-splitters"), v, ms.size());
+
+    I.coll.complete_serialization();
+
+    // m_file_type_info (agc_compressor.cpp:53-59, std::map order).  The reference's own values are
+    // written so that archives stay byte-identical to its output; AGC_AMD_PRODUCER_TAG=1 tags the
+    // producer honestly instead (archives then differ in this one stream).
+    std::map<std::string, std::string> info;
+    const bool tag = getenv("AGC_AMD_PRODUCER_TAG") != nullptr;
+    info["producer"] = tag ? "agc_amd" : "agc";
+    info["producer_version_major"] = "3";
+    info["producer_version_minor"] = "2";
+    info["producer_version_build"] = "20260326.1";
+    info["file_version_major"] = "3";
+    info["file_version_minor"] = "0";
+    info["comment"] = tag ? "agc_amd (MI355X-native create path), archive format of AGC v. 3.2"
+                          : "AGC (Assembled Genomes Compressor) v. 3.2.2 [build 20260326.1]";
+    v.clear();
+    for (auto &x : info) {
+        appstr(v, x.first);
+        appstr(v, x.second);
+    }
+    I.ar.add_part(I.ar.register_stream("file_type_info"), v, info.size());
+    I.ar.close();
+    I.st.archive_bytes = I.ar.bytes_written();
+    I.created = false;
+    return true;
+}
+
+} // namespace agc

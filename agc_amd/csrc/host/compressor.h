@@ -1,0 +1,78 @@
+// compressor.h -- host side of `agc create` above the HIP C ABI (include/agc_hip.h).
+//
+// Mirrors the reference's operator interface for this path,
+//   CAGCCompressor::Create / AddSampleFiles / Close        src/core/agc_compressor.h:754-763
+// (same argument meaning, bool results, messages on stderr, no exceptions across the API),
+// plus AddSampleDevice for callers whose contigs already live in HBM (bench.py).
+//
+// All symbol-level work (scan, index, LZ encode / estimate / cost vectors, reverse
+// complement, repetitiveness counters) runs in the HIP kernels; this file keeps the
+// reference's ORDERING CONTRACT -- which group a segment goes to, group ids, in-group ids,
+// pack boundaries, stream/part order -- and feeds libzstd on the host cores.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct agc_hip_ctx;
+
+namespace agc {
+
+struct CompressorStats {
+    uint64_t bases = 0;            // symbols after preprocess_raw_contig, all samples incl. the reference
+    uint64_t segments = 0;         // placed segments
+    uint64_t new_groups = 0;
+    uint64_t one_splitter = 0;     // segments resolved by find_cand_segment_with_one_splitter
+    uint64_t middle_tried = 0;     // missing-middle searches
+    uint64_t middle_split = 0;     // ... that cut a segment in two
+    uint64_t lz_encoded = 0;       // segments LZ-encoded on the GPU
+    uint64_t delta_bytes = 0;
+    uint64_t ref_bytes = 0;        // symbols stored as group references
+    uint64_t zstd_in = 0, zstd_out = 0;
+    uint64_t archive_bytes = 0;
+    double t_scan = 0, t_classify = 0, t_gpu_aux = 0, t_register = 0, t_encode = 0, t_store = 0, t_zstd = 0, t_io = 0;
+};
+
+class CAGCCompressor {
+    struct Impl;
+    std::unique_ptr<Impl> p;
+
+public:
+    CAGCCompressor();
+    ~CAGCCompressor();
+
+    // device: HIP device ordinal (one process per GPU).  Must be called before Create.
+    bool SetDevice(int device);
+
+    // src/core/agc_compressor.cpp:2273-2327.  file_name "" = discard the archive bytes (bench),
+    // "-" = stdout.  reference_file_name "" = splitters are supplied with SetSplitters.
+    bool Create(const std::string &file_name, uint32_t pack_cardinality, uint32_t kmer_length, const std::string &reference_file_name,
+                uint32_t segment_size, uint32_t min_match_len, bool concatenated_genomes, bool adaptive_compression,
+                uint32_t verbosity, uint32_t no_threads, double fallback_frac);
+
+    // replaces determine_splitters' result (agc_compressor.cpp:543-555) when no reference file is given
+    bool SetSplitters(const uint64_t *kmers, uint64_t n);
+
+    // src/core/agc_compressor.cpp:2118-2270
+    bool AddSampleFiles(const std::vector<std::pair<std::string, std::string>> &sample_file_names, uint32_t no_threads);
+
+    // one sample whose contigs (symbol codes, one byte each) are resident in HBM:
+    // contig c = d_codes[ctg_off[c] .. ctg_off[c+1])
+    bool AddSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
+                         const uint64_t *ctg_off);
+
+    // src/core/agc_compressor.cpp:2094-2115 (close_compression) + ~CArchive
+    bool Close(uint32_t no_threads);
+
+    const CompressorStats &Stats() const;
+    const char *ZstdVersion() const;
+    agc_hip_ctx *HipContext();
+};
+
+// reference preprocessing on the host (agc_compressor.cpp:428-563); contigs = symbol codes
+std::vector<uint64_t> determine_splitters_host(const std::vector<std::vector<uint8_t>> &ref_contigs, uint32_t k, uint32_t segment_size,
+                                               unsigned n_threads);
+
+} // namespace agc

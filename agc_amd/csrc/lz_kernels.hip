@@ -668,4 +668,125 @@ __global__ void __launch_bounds__(256) lag_counts_kernel(const SliceDesc *__rest
     }
 }
 
+// ---------------------------------------------------------------------------
+// Missing-middle-splitter split point (find_cand_segment_with_missing_middle_splitter,
+// src/core/agc_compressor.cpp:1540-1625): given the two cost vectors of one segment,
+//   v1[i] = sum_{j<=i} c1[j]           (c1 read reversed when rev1)
+//   v2[i] = sum_{j>=i} c2[j]           (c2 read reversed when rev2)
+// return the first i minimising v1[i] + v2[i] (u32 arithmetic as std::partial_sum on
+// vector<uint32_t>).  One block per segment.
+// ---------------------------------------------------------------------------
+struct SplitJob {
+    uint64_t off1, off2;   // u32 offsets of the two cost vectors in the scratch buffer
+    uint32_t n;
+    uint32_t rev1, rev2;
+    uint32_t pad;
+};
+
+__global__ void __launch_bounds__(256) split_point_kernel(const SplitJob *__restrict__ jobs, const uint32_t *__restrict__ costs,
+                                                          uint32_t *__restrict__ best_pos, uint32_t *__restrict__ best_sum)
+{
+    const SplitJob jb = jobs[blockIdx.x];
+    const uint32_t n = jb.n;
+    const uint32_t *c1 = costs + jb.off1, *c2 = costs + jb.off2;
+    __shared__ uint32_t s_a[256], s_b[256];
+    __shared__ uint32_t s_carry1, s_carry2, s_total2;
+    const uint32_t tid = threadIdx.x;
+
+    // total of c2
+    uint32_t t2 = 0;
+    for (uint32_t i = tid; i < n; i += 256)
+        t2 += c2[i];
+    s_a[tid] = t2;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+            s_a[tid] += s_a[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        s_total2 = s_a[0];
+        s_carry1 = 0;
+        s_carry2 = 0;
+    }
+    __syncthreads();
+    const uint32_t total2 = s_total2;
+
+    uint32_t my_best = 0xFFFFFFFFu, my_pos = 0xFFFFFFFFu;
+    constexpr uint32_t PER = 8;
+    for (uint32_t base = 0; base < n; base += 256 * PER) {
+        const uint32_t b = base + tid * PER;
+        uint32_t a1[PER], a2[PER];
+        uint32_t sum1 = 0, sum2 = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t i = b + j;
+            uint32_t x1 = 0, x2 = 0;
+            if (i < n) {
+                x1 = jb.rev1 ? c1[n - 1 - i] : c1[i];
+                x2 = jb.rev2 ? c2[n - 1 - i] : c2[i];
+            }
+            a1[j] = x1;
+            a2[j] = x2;
+            sum1 += x1;
+            sum2 += x2;
+        }
+        s_a[tid] = sum1;
+        s_b[tid] = sum2;
+        __syncthreads();
+        // inclusive Hillis-Steele scan over the 256 thread sums
+        for (uint32_t o = 1; o < 256; o <<= 1) {
+            uint32_t va = 0, vb = 0;
+            if (tid >= o) {
+                va = s_a[tid - o];
+                vb = s_b[tid - o];
+            }
+            __syncthreads();
+            s_a[tid] += va;
+            s_b[tid] += vb;
+            __syncthreads();
+        }
+        uint32_t p1 = s_carry1 + s_a[tid] - sum1; // exclusive prefix of c1 before this thread's chunk
+        uint32_t p2 = s_carry2 + s_b[tid] - sum2; // exclusive prefix of c2
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t i = b + j;
+            p1 += a1[j];                          // inclusive prefix of c1 at i
+            const uint32_t v2 = total2 - p2;      // suffix sum of c2 at i
+            p2 += a2[j];
+            if (i < n) {
+                const uint32_t cs = p1 + v2;
+                if (cs < my_best) {
+                    my_best = cs;
+                    my_pos = i;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 255) {
+            s_carry1 += s_a[255];
+            s_carry2 += s_b[255];
+        }
+        __syncthreads();
+    }
+    // arg-min, first position on ties
+    s_a[tid] = my_best;
+    s_b[tid] = my_pos;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const uint32_t ob = s_a[tid + o], op = s_b[tid + o];
+            if (ob < s_a[tid] || (ob == s_a[tid] && op < s_b[tid])) {
+                s_a[tid] = ob;
+                s_b[tid] = op;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        best_pos[blockIdx.x] = n ? s_b[0] : 0;
+        best_sum[blockIdx.x] = s_a[0];
+    }
+}
+
 } // namespace agc

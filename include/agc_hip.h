@@ -59,6 +59,14 @@ int agc_hip_timing_enable(agc_hip_ctx *ctx, int on);
 int agc_hip_timing_reset(agc_hip_ctx *ctx);
 int agc_hip_timing_get(agc_hip_ctx *ctx, int which, double *ms, uint64_t *launches);
 
+/* ---- sample staging (host-resident inputs) ----------------------------- */
+/* A context-owned HBM buffer of at least `bytes` bytes (grown on demand, reused between
+ * calls; valid until the next agc_hip_sample_buffer call) and a synchronous host->HBM copy.
+ * Used by hosts that read FASTA files (the contig_t vectors the reference workers own,
+ * src/core/agc_compressor.cpp:1239-1246). */
+int agc_hip_sample_buffer(agc_hip_ctx *ctx, uint64_t bytes, uint8_t **d_ptr);
+int agc_hip_copy_to_device(agc_hip_ctx *ctx, uint8_t *d_dst, const uint8_t *h_src, uint64_t n);
+
 /* ---- a1: raw FASTA body -> symbol codes ------------------------------- */
 /* Replaces CAGCCompressor::preprocess_raw_contig (src/core/agc_compressor.cpp:907-951):
  * drops every byte < 64, maps the rest through cnv_num (agc_basic.h:40-50).
@@ -155,6 +163,25 @@ int agc_hip_lz_cost_vector_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h
                                  const uint8_t *h_text, const uint64_t *h_off,
                                  const uint32_t *h_len, const uint8_t *h_rc,
                                  const uint8_t *h_prefix_costs, uint32_t *h_costs);
+
+/* Replaces the arithmetic of find_cand_segment_with_missing_middle_splitter
+ * (src/core/agc_compressor.cpp:1540-1625) for a batch of segments: two cost vectors per
+ * segment (GetCodingCostVector against gid1 with text orientation rc1 / prefix1, against gid2
+ * with rc2 / prefix2), the first reversed when prefix1 == 0 and prefix-summed, the second
+ * reversed when prefix2 != 0 and suffix-summed; h_best_pos[s] = first position minimising their
+ * sum (before the caller's k+1 clamps, agc_compressor.cpp:1621-1624), h_best_sum[s] its value. */
+int agc_hip_lz_split_point_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid1, const uint32_t *h_gid2,
+                                     const uint8_t *d_base, const uint64_t *h_off, const uint32_t *h_len,
+                                     const uint8_t *h_rc1, const uint8_t *h_prefix1,
+                                     const uint8_t *h_rc2, const uint8_t *h_prefix2,
+                                     uint32_t *h_best_pos, uint32_t *h_best_sum);
+
+/* Copies slices (optionally reverse-complemented) from HBM into one host buffer, back to back:
+ * slice s = h_out[h_out_off[s] .. h_out_off[s+1]).  Used for the sequences the host must pack
+ * itself (new group references, raw contigs; src/common/segment.cpp:14-48). */
+int agc_hip_fetch_slices_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_base, const uint64_t *h_off,
+                             const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_out, uint64_t out_cap,
+                             uint64_t *h_out_off);
 
 /* ---- a13: reference storage helpers ----------------------------------- */
 /* Repetitiveness probe of CSegment::store_in_archive (src/common/segment.h:224-247):

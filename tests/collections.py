@@ -1,0 +1,83 @@
+"""Seeded FASTA collections for whole-archive parity (reference CLI vs agc_amd)."""
+import os
+
+import numpy as np
+
+from agc_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOY = os.path.join(HERE, "golden", "toy_ex")
+
+# name -> (cli args, builder)
+CONFIGS = {
+    "toy_c1": (["-k", "25", "-l", "17"], "toy"),
+    "toy_default": ([], "toy"),
+    # 4 contigs x 250 kb, 6 samples, SNPs only: both-splitter path + missing-middle splits
+    "syn_snp": (["-k", "31", "-l", "20", "-s", "5000", "-b", "4"], "snp"),
+    # SNPs + indels + N-runs + IUPAC, short min match, odd k
+    "syn_mixed": (["-k", "25", "-l", "15", "-s", "3000", "-b", "3"], "mixed"),
+    # many small genomes (BASELINE configs[1] shape, scaled): 40 x 30 kb, 1 % SNP, default segment size
+    "syn_viral": (["-k", "31", "-l", "20", "-b", "7"], "viral"),
+    # the same, concatenated mode
+    "syn_viral_c": (["-k", "31", "-l", "20", "-b", "7", "-c"], "viral_c"),
+    # contigs in a different order / missing / extra in the samples, lower-case and soft-masked input
+    "syn_shuffled": (["-k", "21", "-l", "17", "-s", "2000", "-b", "50"], "shuffled"),
+}
+
+
+def build(name, outdir):
+    """writes the FASTA files, returns their paths (reference first)"""
+    kind = CONFIGS[name][1]
+    os.makedirs(outdir, exist_ok=True)
+    if kind == "toy":
+        return [os.path.join(TOY, f) for f in ("ref.fa", "a.fa", "b.fa", "c.fa")]
+    rng = np.random.default_rng({"snp": 11, "mixed": 12, "viral": 13, "viral_c": 13, "shuffled": 14}[kind])
+    files = []
+
+    def write(fn, contigs, names):
+        p = os.path.join(outdir, fn)
+        synth.to_fasta(p, contigs, names)
+        files.append(p)
+
+    if kind == "snp":
+        ref = [synth.random_seq(rng, 250_000) for _ in range(4)]
+        names = [f"chr{i+1} len=250000" for i in range(4)]
+        write("ref.fa", ref, names)
+        for s in range(6):
+            write(f"s{s}.fa", [synth.mutate(rng, c, 0.002) for c in ref], names)
+    elif kind == "mixed":
+        ref = [synth.random_seq(rng, int(n)) for n in (180_000, 90_000, 20_000, 40)]
+        names = ["ctgA", "ctgB extra words here", "ctgC", "tiny"]
+        write("ref.fa", ref, names)
+        for s in range(5):
+            write(f"m{s}.fa", [synth.mutate(rng, c, 0.004, n_runs=2, iupac=3, indels=2) if c.size > 100 else c.copy() for c in ref], names)
+    elif kind in ("viral", "viral_c"):
+        ref = synth.random_seq(rng, 30_000)
+        genomes = [ref] + [synth.mutate(rng, ref, 0.01) for _ in range(39)]
+        if kind == "viral":
+            for i, g in enumerate(genomes):
+                write(f"g{i:03d}.fa", [g], [f"MN{i:05d}.1 genome {i}"])
+        else:
+            write("ref.fa", [genomes[0]], ["MN00000.1 genome 0"])
+            write("all.fa", genomes[1:], [f"MN{i:05d}.1 genome {i}" for i in range(1, 40)])
+    elif kind == "shuffled":
+        ref = [synth.random_seq(rng, int(n)) for n in (60_000, 50_000, 45_000, 30_000, 10_000)]
+        names = [f"c{i}" for i in range(5)]
+        write("ref.fa", ref, names)
+        for s in range(4):
+            order = rng.permutation(5)
+            keep = order[: 3 + s % 3]
+            ctg = [synth.mutate(rng, ref[i], 0.003, n_runs=1) for i in keep]
+            nm = [names[i] for i in keep]
+            ctg.append(synth.random_seq(rng, 25_000))  # a contig unrelated to the reference
+            nm.append(f"novel{s}")
+            write(f"x{s}.fa", ctg, nm)
+        # a soft-masked copy of a sample: lower-case bases compress identically
+        p = os.path.join(outdir, "x0.fa")
+        q = os.path.join(outdir, "x0lower.fa")
+        with open(p, "rb") as f:
+            lines = f.read().split(b"\n")
+        with open(q, "wb") as f:
+            f.write(b"\n".join(l if l.startswith(b">") else l.lower() for l in lines))
+        files.append(q)
+    return files

@@ -68,19 +68,23 @@ def scan_golden():
 
 
 def archives():
+    """sha256 of the archives the reference CLI writes for tests/collections.py (t=1 and t=8 must agree)"""
+    from tests import collections as C
     out = {}
-    toy = "/root/reference/toy_ex"
     with tempfile.TemporaryDirectory() as td:
-        def create(name, args, files):
-            fn = os.path.join(td, name + ".agc")
-            subprocess.run([O.REF_AGC, "create"] + args + ["-o", fn] + files, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            b = open(fn, "rb").read()
-            out[name] = {"args": args, "sha256": hashlib.sha256(b).hexdigest(), "size": len(b)}
-        create("toy_c1", ["-k", "25", "-l", "17", "-t", "1"], [f"{toy}/ref.fa", f"{toy}/a.fa", f"{toy}/b.fa", f"{toy}/c.fa"])
-        create("toy_default", ["-t", "1"], [f"{toy}/ref.fa", f"{toy}/a.fa", f"{toy}/b.fa", f"{toy}/c.fa"])
+        for name, (args, _kind) in C.CONFIGS.items():
+            files = C.build(name, os.path.join(td, name))
+            shas = []
+            for t in ("1", "8"):
+                fn = os.path.join(td, f"{name}_{t}.agc")
+                subprocess.run([O.REF_AGC, "create"] + args + ["-t", t, "-o", fn] + files, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                b = open(fn, "rb").read()
+                shas.append(hashlib.sha256(b).hexdigest())
+            assert shas[0] == shas[1], f"{name}: reference output depends on the thread count"
+            out[name] = {"args": args, "sha256": shas[0], "size": len(b)}
     out["zstd"] = "libzstd 1.4.9 (image's conda copy) on both sides"
     json.dump(out, open(os.path.join(HERE, "archives.json"), "w"), indent=1)
-    print("archives.json:", list(out))
+    print("archives.json:", {k_: v["size"] for k_, v in out.items() if isinstance(v, dict)})
 
 
 if __name__ == "__main__":
