@@ -235,13 +235,98 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
     uint32_t est = 0, peak = 0;
 
     AGC_TRACE(3, n);
+    const uint64_t keybits = (1ULL << key_len) - 1ULL;
+    bool stale_out = false;   // bytes at/after `o` were stored by lane 0 earlier (rolled-back literals)
+    bool coop_out = false;    // bytes before `o` were stored by lanes other than 0 since the last drain
+    bool try_wide = false;    // the last exact step produced a literal: look at 64 positions at once next
     while (i + key_len < n) {
         AGC_TRACE(4, i);
+        // ---- wide literal probe: lanes look at positions i .. i+63 at once.  A position is a
+        // certain literal when its key is valid and no slot of its probe chain (up to the first
+        // empty slot / 64 tries) carries the key's fingerprint, or when its key is invalid and no
+        // N-run starts there.  The leading run of certain literals is emitted in one step; the
+        // first other position is handled by the exact (reference-order) step below.
+        // Only entered after an exact step found no match (long matches never pay for it).
+        if (try_wide) {
+            const uint32_t q = i + lane;
+            const uint32_t sa = q < n ? (uint32_t)text[q] : 0xFFu;
+            const uint32_t sb = (lane < key_len + 2 && q + 64 < n) ? (uint32_t)text[q + 64] : 0xFFu;
+            const uint64_t a0 = __ballot((sa & 1u) != 0), a1 = __ballot((sa & 2u) != 0), ai = __ballot(sa > 3), an = __ballot(sa == N_CODE);
+            const uint64_t b0 = __ballot((sb & 1u) != 0), b1 = __ballot((sb & 2u) != 0), bi = __ballot(sb > 3), bn = __ballot(sb == N_CODE);
+            const uint32_t sh = lane, rs = (64 - lane) & 63;
+            const uint64_t hi_on = lane ? ~0ULL : 0ULL; // (x << 64) is undefined: lane 0 takes nothing from the second plane
+            const uint64_t w0 = (a0 >> sh) | ((b0 << rs) & hi_on), w1 = (a1 >> sh) | ((b1 << rs) & hi_on);
+            const uint64_t wi = (ai >> sh) | ((bi << rs) & hi_on), wn = (an >> sh) | ((bn << rs) & hi_on);
+            bool stop;
+            if (!(q + key_len < n))
+                stop = true;
+            else if (wi & keybits)
+                stop = (wn & 7ULL) == 7ULL;
+            else {
+                const uint64_t r0 = __brevll(w0 & keybits) >> (64 - key_len), r1 = __brevll(w1 & keybits) >> (64 - key_len);
+                const uint64_t hx = murmur64(spread_bits(r0) | (spread_bits(r1) << 1));
+                uint32_t sl = (uint32_t)hx & ht_mask;
+                stop = false;
+                if (rd.is_short) {
+                    const uint32_t fp = (uint32_t)(hx >> 48);
+                    for (uint32_t t = 0; t < MAX_NO_TRIES; ++t) {
+                        const uint32_t e = ((const uint32_t *)rd.table)[sl];
+                        if (e == 0xFFFFFFFFu)
+                            break;
+                        if ((e & 0xFFFFu) == fp) {
+                            stop = true;
+                            break;
+                        }
+                        sl = (sl + 1) & ht_mask;
+                    }
+                } else {
+                    const uint32_t fp = (uint32_t)(hx >> 32);
+                    for (uint32_t t = 0; t < MAX_NO_TRIES; ++t) {
+                        const uint64_t e = ((const uint64_t *)rd.table)[sl];
+                        if (e == ~0ULL)
+                            break;
+                        if ((uint32_t)e == fp) {
+                            stop = true;
+                            break;
+                        }
+                        sl = (sl + 1) & ht_mask;
+                    }
+                }
+            }
+            const uint64_t sm = __ballot(stop);
+            const uint32_t f = sm ? ctz64(sm) : WAVE;
+            if (f) {
+                if (MODE == MODE_ENCODE) {
+                    if (stale_out) {
+                        __builtin_amdgcn_s_waitcnt(0); // lane 0's rolled-back bytes land before other lanes overwrite them
+                        stale_out = false;
+                    }
+                    if (lane < f)
+                        out[o + lane] = (uint8_t)('A' + sa);
+                    coop_out = true;
+                } else if (MODE == MODE_ESTIMATE) {
+                    if (est + f - 1 > peak)
+                        peak = est + f - 1; // loop-top checks of these f literal steps
+                    est += f;
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    if (lane < f)
+                        costs[o + lane] = 1;
+                }
+                o += f;
+                i += f;
+                pred_pos += f;
+                npl += f;
+                try_wide = f == WAVE; // a stop position was seen: go straight to its exact step
+                continue;
+            }
+            try_wide = false;
+        }
         if (MODE == MODE_ESTIMATE) {
             if (est > peak)
-                peak = est;
+                peak = est; // the reference's loop-top check sees this value (lz_diff.cpp:868-869)
         }
-        // ---- key at text[i .. i+key_len)  (get_code, lz_diff.h:58-106) ----
+        // ---- exact step at position i.  key at text[i .. i+key_len)  (get_code, lz_diff.h:58-106) ----
         const uint8_t *tp = text + i;
         const uint32_t s = lane < key_len ? (uint32_t)tp[lane] : 0u;
         const uint64_t bad = __ballot(s > 3);
@@ -286,6 +371,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 }
                 i += nrun;
                 npl = 0;
+                try_wide = false;
             } else {
                 if (MODE == MODE_ENCODE) {
                     if (writer)
@@ -298,6 +384,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 ++i;
                 ++pred_pos;
                 ++npl;
+                try_wide = true;
             }
             continue;
         }
@@ -361,9 +448,11 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             ++i;
             ++pred_pos;
             ++npl;
+            try_wide = true;
             continue;
         }
 
+        try_wide = false;
         const uint32_t len = len_bck + len_fwd;
         if (MODE == MODE_ESTIMATE) {
             // no roll-back of the back extension here (lz_diff.cpp:926-936)
@@ -384,6 +473,11 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
         i -= len_bck;
 
         if (MODE == MODE_ENCODE) {
+            if (coop_out) {
+                __builtin_amdgcn_s_waitcnt(0); // literals stored by other lanes are visible to lane 0's reads below
+                coop_out = false;
+            }
+            stale_out = stale_out || len_bck != 0;
             if (match_pos == pred_pos && writer) {
                 // literals equal to the reference become '!' (lz_diff.cpp:769-779)
                 for (uint32_t t = 1; t < o && t < match_pos; ++t) {

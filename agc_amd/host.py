@@ -1,0 +1,114 @@
+"""ctypes binding of the host-side compressor (libagc_host.so, agc_amd/csrc/host/): the
+reference's CAGCCompressor::Create / AddSampleFiles / Close interface for the create path
+(src/core/agc_compressor.h:754-763) plus AddSampleDevice for HBM-resident samples."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libagc_host.so")
+STAT_NAMES = ["bases", "segments", "new_groups", "one_splitter", "middle_tried", "middle_split", "lz_encoded", "delta_bytes",
+              "ref_bytes", "zstd_in", "zstd_out", "archive_bytes",
+              "t_scan", "t_classify", "t_gpu_aux", "t_register", "t_encode", "t_store", "t_zstd", "t_io"]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    capi.load()  # torch first, then libagc_hip.so (one HIP runtime per process)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m agc_amd.build`")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.agc_cmp_new.restype = vp
+    L.agc_cmp_new.argtypes = [C.c_int]
+    L.agc_cmp_delete.argtypes = [vp]
+    L.agc_cmp_delete.restype = None
+    L.agc_cmp_create.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                 C.c_uint32, C.c_uint32, C.c_double]
+    L.agc_cmp_set_splitters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64]
+    L.agc_cmp_add_sample_files.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32]
+    L.agc_cmp_add_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
+    L.agc_cmp_close.argtypes = [vp, C.c_uint32]
+    L.agc_cmp_zstd_version.argtypes = [vp]
+    L.agc_cmp_zstd_version.restype = C.c_char_p
+    L.agc_cmp_hip_ctx.argtypes = [vp]
+    L.agc_cmp_hip_ctx.restype = vp
+    L.agc_cmp_stats.argtypes = [vp, C.POINTER(C.c_double), C.c_uint32]
+    _lib = L
+    return L
+
+
+class Compressor:
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = self.L.agc_cmp_new(device)
+
+    def close_handle(self):
+        if getattr(self, "h", None):
+            self.L.agc_cmp_delete(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close_handle()
+
+    def create(self, out_path, pack_cardinality=50, k=31, ref_file=None, segment_size=60000, min_match_len=20,
+               concatenated=False, adaptive=False, verbosity=0, n_threads=8, fallback_frac=0.0):
+        ok = self.L.agc_cmp_create(self.h, (out_path or "").encode(), pack_cardinality, k, (ref_file or "").encode(), segment_size,
+                                   min_match_len, int(concatenated), int(adaptive), verbosity, n_threads, fallback_frac)
+        if not ok:
+            raise RuntimeError("CAGCCompressor::Create failed (see stderr)")
+
+    def set_splitters(self, kmers):
+        k = np.ascontiguousarray(kmers, dtype=np.uint64)
+        if not self.L.agc_cmp_set_splitters(self.h, k.ctypes.data_as(C.POINTER(C.c_uint64)), k.size):
+            raise RuntimeError("SetSplitters failed")
+
+    def add_sample_files(self, pairs, n_threads=8):
+        n = len(pairs)
+        names = (C.c_char_p * n)(*[p[0].encode() for p in pairs])
+        paths = (C.c_char_p * n)(*[p[1].encode() for p in pairs])
+        if not self.L.agc_cmp_add_sample_files(self.h, n, names, paths, n_threads):
+            raise RuntimeError("AddSampleFiles failed (see stderr)")
+
+    def add_sample_dev(self, sample_name, contig_names, d_codes, ctg_off):
+        n = len(contig_names)
+        names = (C.c_char_p * n)(*[c.encode() for c in contig_names])
+        off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+        if not self.L.agc_cmp_add_sample_dev(self.h, sample_name.encode(), n, names, d_codes, off.ctypes.data_as(C.POINTER(C.c_uint64))):
+            raise RuntimeError("AddSampleDevice failed (see stderr)")
+
+    def close(self, n_threads=8):
+        if not self.L.agc_cmp_close(self.h, n_threads):
+            raise RuntimeError("Close failed")
+
+    def zstd_version(self):
+        return self.L.agc_cmp_zstd_version(self.h).decode()
+
+    def stats(self):
+        v = (C.c_double * len(STAT_NAMES))()
+        self.L.agc_cmp_stats(self.h, v, len(STAT_NAMES))
+        return {n: v[i] for i, n in enumerate(STAT_NAMES)}
+
+    def hip_timing(self, on=True):
+        L = capi.load()
+        ctx = self.L.agc_cmp_hip_ctx(self.h)
+        L.agc_hip_timing_enable(ctx, int(on))
+        L.agc_hip_timing_reset(ctx)
+
+    def hip_timing_get(self):
+        L = capi.load()
+        ctx = self.L.agc_cmp_hip_ctx(self.h)
+        out = {}
+        for i, n in enumerate(capi.K_NAMES):
+            ms = C.c_double()
+            ln = C.c_uint64()
+            L.agc_hip_timing_get(ctx, i, C.byref(ms), C.byref(ln))
+            out[n] = (ms.value, ln.value)
+        return out
