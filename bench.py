@@ -47,6 +47,19 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpus():
+    """CPUs this container may actually use: the cgroup quota when there is one (the GPU box reports
+    256 logical CPUs but grants 16), else the logical CPU count."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, mbp):
     """reference CPU implementation on a bounded twin of the workload (same generator, smaller):
     wall(create ref + 2 samples) - wall(create ref only), all host cores."""
@@ -57,7 +70,7 @@ def cpu_baseline(args, mbp):
     ctg_len = [n // 4] * 4
     refc = [synth.random_seq(rng, l) for l in ctg_len]
     n_samples = 4
-    cores = os.cpu_count() or 1
+    cores = host_cpus()
     if os.path.exists(ref_bin):
         with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
             names = [f"chr{i+1}" for i in range(4)]
@@ -68,7 +81,7 @@ def cpu_baseline(args, mbp):
                 fn = os.path.join(td, f"s{s}.fa")
                 synth.to_fasta(fn, smp, names)
                 files.append(fn)
-            t_threads = str(min(cores, 128))
+            t_threads = str(max(1, min(cores, 128)))
             common = [ref_bin, "create", "-k", str(K), "-l", str(MML), "-b", str(PACK), "-s", str(SEG), "-t", t_threads, "-o"]
 
             def run(extra):
@@ -109,14 +122,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    from agc_amd import host, synth_dev
+    from agc_amd import host, shard, synth_dev
 
     total = int(args.gbp * 1e9)
     ref, off = synth_dev.make_reference(total, 12345, dev)
     tot = int(off[-1])
     spl = synth_dev.positional_splitters(ref, off, K, SEG)
     names = [f"chr{i + 1}" for i in range(len(off) - 1)]
-    threads = max(1, (os.cpu_count() or 8) // world)
+    threads = max(1, host_cpus() // world)
     if args.threads:
         threads = args.threads
     cmp_ = host.Compressor(local)
@@ -131,7 +144,7 @@ def main():
 
     n_steps = args.steps + args.warmup
     # weak scaling: samples are partitioned round-robin over ranks (one archive shard per rank), no data-path collective
-    samples = [synth_dev.make_sample(ref, tot, args.div, 1000 + s * world + rank, dev) for s in range(n_steps)]
+    samples = [synth_dev.make_sample(ref, tot, args.div, shard.sample_seed(1000, s, rank, world), dev) for s in range(n_steps)]
     torch.cuda.synchronize()
 
     def barrier():
