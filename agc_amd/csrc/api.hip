@@ -38,7 +38,7 @@ struct agc_hip_ctx {
 
     // splitter set
     std::vector<uint64_t> spl;       // host copy (unique)
-    DevBuf d_table, d_bloom;
+    DevBuf d_table, d_bloom, d_bloom2;
     uint64_t table_mask = 0;
 
     // references
@@ -181,7 +181,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
+    DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample};
     for (DevBuf *b : bufs)
@@ -301,7 +301,7 @@ static int splitters_upload(agc_hip_ctx *c)
     while (cap < 2 * (uint64_t)c->spl.size())
         cap <<= 1;
     std::vector<uint64_t> tab(cap, ~0ULL);
-    std::vector<uint32_t> bloom(BLOOM_WORDS, 0);
+    std::vector<uint32_t> bloom(BLOOM_WORDS, 0), bloom2(BLOOM2_WORDS, 0);
     for (uint64_t x : c->spl) {
         const uint64_t h = splitter_hash(x);
         uint64_t s = h & (cap - 1);
@@ -309,11 +309,15 @@ static int splitters_upload(agc_hip_ctx *c)
             s = (s + 1) & (cap - 1);
         tab[s] = x;
         uint32_t w, m;
-        bloom_slot(h, w, m);
+        bloom_slot((uint32_t)(x >> 32), (uint32_t)x, w, m);
         bloom[w] |= m;
+        bloom2_slot(h, w, m);
+        bloom2[w] |= m;
     }
     CHK(ensure(c, c->d_table, cap * 8));
     CHK(ensure(c, c->d_bloom, BLOOM_WORDS * 4));
+    CHK(ensure(c, c->d_bloom2, BLOOM2_WORDS * 4));
+    HIPCHK(c, hipMemcpyAsync(c->d_bloom2.p, bloom2.data(), BLOOM2_WORDS * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_table.p, tab.data(), cap * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_bloom.p, bloom.data(), BLOOM_WORDS * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -399,6 +403,7 @@ int agc_hip_scan_contigs_dev(agc_hip_ctx *c, const uint8_t *d_codes, const uint6
         a.table = (const uint64_t *)c->d_table.p;
         a.table_mask = c->table_mask;
         a.bloom = (const uint32_t *)c->d_bloom.p;
+        a.bloom2 = (const uint32_t *)c->d_bloom2.p;
         a.hits = (ScanHit *)c->d_hits.p;
         a.n_hits = (uint32_t *)c->d_counter.p;
         a.cap = dev_cap;
@@ -690,9 +695,16 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream)); // sl is a local
     }
+    // longest first (stable): sort keys (~len << 32 | index)
     std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_len[x] > h_len[y]; });
+    {
+        std::vector<uint64_t> keys(n);
+        for (uint32_t i = 0; i < n; ++i)
+            keys[i] = ((uint64_t)(~h_len[i]) << 32) | i;
+        std::sort(keys.begin(), keys.end());
+        for (uint32_t i = 0; i < n; ++i)
+            order[i] = (uint32_t)keys[i];
+    }
     std::vector<uint64_t> ooff(n);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < n; ++i) {

@@ -86,9 +86,28 @@ struct Group { // CSegment, write side (src/common/segment.{h,cpp})
     bool exists = false;
     uint64_t ref_size = 0; // s.size() + 1 once the reference is set (segment.cpp:46)
     uint32_t no_seqs = 0;
-    std::vector<bytes_t> v_lzp;
-    std::vector<bytes_t> v_raw;
+    // current pack, already in stored form: every sequence followed by the 0xFF separator
+    // (store_in_archive(pack), segment.h:258-280); *_off[i] = start of sequence i
+    bytes_t lzp_data, raw_data;
+    std::vector<uint32_t> lzp_off, raw_off;
     int stream_ref = -1, stream_delta = -1;
+
+    static void push(bytes_t &data, std::vector<uint32_t> &off, const uint8_t *b, size_t n)
+    {
+        off.push_back((uint32_t)data.size());
+        data.insert(data.end(), b, b + n);
+        data.push_back(0xff);
+    }
+    // index of an equal sequence in the current pack or -1 (std::find over v_lzp, segment.cpp:66)
+    static int find(const bytes_t &data, const std::vector<uint32_t> &off, const uint8_t *b, size_t n)
+    {
+        for (size_t i = 0; i < off.size(); ++i) {
+            const size_t e = (i + 1 < off.size() ? off[i + 1] : data.size()) - 1; // without the separator
+            if (e - off[i] == n && memcmp(data.data() + off[i], b, n) == 0)
+                return (int)i;
+        }
+        return -1;
+    }
 };
 
 struct ZJob { // one archive part to produce
@@ -401,7 +420,8 @@ struct CAGCCompressor::Impl {
     bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base);
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs);
-    void make_pack_job(std::vector<ZJob> &jobs, Group &g, std::vector<bytes_t> &v);
+    void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
+    bytes_t enc_buf, fetch_buf; // grown, never shrunk
     void after_registration();
 };
 
@@ -510,7 +530,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         g.exists = true;
         g.stream_delta = I.ar.register_stream(ss_delta_name(I.no_segments));
         g.no_seqs = 1;                  // add_raw({0x7f}), agc_compressor.cpp:2313-2321
-        g.v_raw.push_back(bytes_t{0x7f});
+        const uint8_t dummy = 0x7f;
+        Group::push(g.raw_data, g.raw_off, &dummy, 1);
     }
     I.coll.reset_prev_sample_name();
     return true;
@@ -518,19 +539,14 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
 
 // ---------------------------------------------------------------------------
 // store_in_archive(pack), segment.h:258-280: sequences + 0xFF separators -> zstd 17
-void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, std::vector<bytes_t> &v)
+void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off)
 {
     ZJob j;
     j.stream_id = g.stream_delta;
     j.kind = 1;
-    size_t n = 0;
-    for (auto &x : v)
-        n += x.size() + 1;
-    j.data.reserve(n);
-    for (auto &x : v) {
-        j.data.insert(j.data.end(), x.begin(), x.end());
-        j.data.push_back(0xff);
-    }
+    j.data.swap(data);
+    data.clear();
+    off.clear();
     jobs.emplace_back(std::move(j));
 }
 
@@ -954,18 +970,35 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     st.segments += placed.size();
 
     // ---- register_segments (agc_compressor.cpp:954-971; agc_compressor.h:384-435) ----
-    auto key_less = [&](uint32_t x, uint32_t y) {
-        const Placed &a = placed[x], &b = placed[y];
-        const Contig &ca = ctgs[a.ctg], &cb = ctgs[b.ctg];
-        if (ca.sample != cb.sample)
-            return ca.sample < cb.sample;
-        if (ca.name != cb.name)
-            return ca.name < cb.name;
-        return a.part_no < b.part_no;
-    };
+    // order of CBufferedSegPart's lists and of the std::set of new parts: (sample name, contig name,
+    // part no) (agc_compressor.h:112-120, 157-164).  Contigs are ranked once, items sort on integers.
+    std::vector<uint32_t> ctg_rank(n_ctg);
+    {
+        std::vector<uint32_t> co(n_ctg);
+        std::iota(co.begin(), co.end(), 0u);
+        auto cless = [&](uint32_t x, uint32_t y) {
+            if (ctgs[x].sample != ctgs[y].sample)
+                return ctgs[x].sample < ctgs[y].sample;
+            return ctgs[x].name < ctgs[y].name;
+        };
+        std::stable_sort(co.begin(), co.end(), cless);
+        uint32_t r = 0;
+        for (uint32_t i = 0; i < n_ctg; ++i) {
+            if (i && cless(co[i - 1], co[i]))
+                ++r;
+            ctg_rank[co[i]] = r;
+        }
+    }
     std::vector<uint32_t> order(placed.size());
-    std::iota(order.begin(), order.end(), 0u);
-    std::sort(order.begin(), order.end(), key_less);
+    {
+        std::vector<std::pair<uint64_t, uint32_t>> keyed(placed.size());
+        for (uint32_t i = 0; i < placed.size(); ++i)
+            keyed[i] = {((uint64_t)ctg_rank[placed[i].ctg] << 32) | placed[i].part_no, i};
+        if (!std::is_sorted(keyed.begin(), keyed.end()))
+            std::sort(keyed.begin(), keyed.end());
+        for (uint32_t i = 0; i < placed.size(); ++i)
+            order[i] = keyed[i].second;
+    }
     const uint32_t first_new_gid = no_segments;
     {
         std::map<pk_t, uint32_t> m_kmers;
@@ -1057,7 +1090,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     }
     // GPU: register the new references (index build) and pull back what the host must pack
     std::vector<uint32_t> lag_cnt, lag_cur;
-    bytes_t fetched;
+    bytes_t &fetched = fetch_buf;
     std::vector<uint64_t> fetched_off;
     {
         const size_t nr = new_ref_items.size();
@@ -1093,7 +1126,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 rc[i] = pl.rc;
                 tot += pl.len;
             }
-            fetched.resize(tot);
+            if (fetched.size() < tot)
+                fetched.resize(tot);
             fetched_off.resize(nf + 1);
             if (!hip_ok(agc_hip_fetch_slices_dev(hip, (uint32_t)nf, d_base, off.data(), len.data(), rc.data(), fetched.data(), tot, fetched_off.data()), "fetch_slices"))
                 return false;
@@ -1102,7 +1136,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     st.t_register += now() - t0;
     t0 = now();
     // GPU: LZ-encode every other item against its group's reference (segment.cpp:50-58)
-    bytes_t enc;
+    bytes_t &enc = enc_buf;
     std::vector<uint64_t> enc_off(enc_items.size() + 1, 0);
     if (!enc_items.empty()) {
         const size_t ne = enc_items.size();
@@ -1118,9 +1152,10 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             rc[i] = pl.rc;
             tot += pl.len;
         }
-        uint64_t cap = tot / 8 + 65536;
+        uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 20));
         for (;;) {
-            enc.resize(cap);
+            if (enc.size() < cap)
+                enc.resize(cap);
             int r = agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap, enc_off.data());
             if (r == AGC_HIP_ECAP) {
                 cap = enc_off[ne] + 64;
@@ -1137,7 +1172,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     t0 = now();
 
     // (b) per-group bookkeeping in list order: CSegment::add / add_raw (segment.cpp:14-80)
-    std::unordered_map<uint32_t, uint32_t> pos_newref, pos_raw, pos_enc;
+    std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size()), pos_enc(placed.size());
     for (uint32_t i = 0; i < new_ref_items.size(); ++i)
         pos_newref[new_ref_items[i]] = i;
     for (uint32_t i = 0; i < raw_items.size(); ++i)
@@ -1153,13 +1188,11 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             const Placed &pl = placed[idx];
             uint32_t igid;
             if (gid < NO_RAW_GROUPS) {
-                if (g.v_raw.size() == pack_cardinality) {
-                    make_pack_job(jobs, g, g.v_raw);
-                    g.v_raw.clear();
-                }
+                if (g.raw_off.size() == pack_cardinality)
+                    make_pack_job(jobs, g, g.raw_data, g.raw_off);
                 const uint32_t fi = (uint32_t)new_ref_items.size() + pos_raw[idx];
                 ++g.no_seqs;
-                g.v_raw.emplace_back(fetched.begin() + fetched_off[fi], fetched.begin() + fetched_off[fi + 1]);
+                Group::push(g.raw_data, g.raw_off, fetched.data() + fetched_off[fi], fetched_off[fi + 1] - fetched_off[fi]);
                 igid = g.no_seqs - 1;
             } else if (!g.exists) {
                 g.exists = true;
@@ -1187,20 +1220,19 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 g.no_seqs = 1;
                 igid = 0;
             } else {
-                if (g.v_lzp.size() == pack_cardinality) {
-                    make_pack_job(jobs, g, g.v_lzp);
-                    g.v_lzp.clear();
-                }
+                if (g.lzp_off.size() == pack_cardinality)
+                    make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
                 const uint32_t ei = pos_enc[idx];
-                bytes_t delta(enc.begin() + enc_off[ei], enc.begin() + enc_off[ei + 1]);
-                if (delta.empty())
+                const uint8_t *dp = enc.data() + enc_off[ei];
+                const size_t dn = enc_off[ei + 1] - enc_off[ei];
+                if (dn == 0)
                     igid = 0; // same sequence as the reference (segment.cpp:60-63)
                 else {
-                    auto f = std::find(g.v_lzp.begin(), g.v_lzp.end(), delta);
-                    if (f != g.v_lzp.end())
-                        igid = g.no_seqs - (uint32_t)std::distance(f, g.v_lzp.end());
+                    const int f = Group::find(g.lzp_data, g.lzp_off, dp, dn);
+                    if (f >= 0)
+                        igid = g.no_seqs - (uint32_t)(g.lzp_off.size() - (size_t)f);
                     else {
-                        g.v_lzp.emplace_back(std::move(delta));
+                        Group::push(g.lzp_data, g.lzp_off, dp, dn);
                         ++g.no_seqs;
                         igid = g.no_seqs - 1;
                     }
@@ -1244,14 +1276,10 @@ void CAGCCompressor::Impl::finish_groups()
     std::vector<ZJob> jobs;
     for (uint32_t gid = 0; gid < groups.size(); ++gid) {
         Group &g = groups[gid];
-        if (!g.v_lzp.empty()) {
-            make_pack_job(jobs, g, g.v_lzp);
-            g.v_lzp.clear();
-        }
-        if (!g.v_raw.empty()) {
-            make_pack_job(jobs, g, g.v_raw);
-            g.v_raw.clear();
-        }
+        if (!g.lzp_off.empty())
+            make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
+        if (!g.raw_off.empty())
+            make_pack_job(jobs, g, g.raw_data, g.raw_off);
     }
     run_jobs(jobs);
 }

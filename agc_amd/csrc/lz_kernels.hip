@@ -133,30 +133,46 @@ __device__ __forceinline__ uint32_t dec_len_u32(uint32_t x)
     return n;
 }
 
-// writes the decimal form of x (with '-' when negative) at out[o..); every lane computes
-// the returned length, only `writer` stores.
-__device__ uint32_t emit_int(uint8_t *out, uint32_t o, int64_t x, bool writer)
+__device__ __forceinline__ uint32_t base_dec_len(uint32_t x)
 {
-    uint32_t len = 0;
-    uint64_t ax;
-    if (x < 0) {
-        ax = (uint64_t)(-x);
-        if (writer)
-            out[o] = '-';
-        len = 1;
-    } else
-        ax = (uint64_t)x;
-    uint32_t nd = 1;
-    for (uint64_t t = ax; t >= 10; t /= 10)
-        ++nd;
+    if (x < 10) return 1;
+    if (x < 100) return 2;
+    if (x < 1000) return 3;
+    if (x < 10000) return 4;
+    if (x < 100000) return 5;
+    if (x < 1000000) return 6;
+    if (x < 10000000) return 7;
+    if (x < 100000000) return 8;
+    if (x < 1000000000) return 9;
+    return 10;
+}
+
+// writes the decimal form of x (with '-' when negative) at out[o..); every lane computes
+// the returned length, only `writer` stores.  32-bit arithmetic only: the values are
+// differences of u32 positions taken as int (lz_diff.cpp:633) and u32 lengths, and a 64-bit
+// integer division costs hundreds of VALU instructions on this hardware.
+__device__ __forceinline__ uint32_t emit_uint(uint8_t *out, uint32_t o, uint32_t ax, bool writer)
+{
+    const uint32_t nd = base_dec_len(ax);
     if (writer) {
-        uint64_t t = ax;
+        uint32_t t = ax;
         for (uint32_t d = 0; d < nd; ++d) {
-            out[o + len + nd - 1 - d] = (uint8_t)('0' + (uint32_t)(t % 10));
-            t /= 10;
+            const uint32_t q = t / 10u; // constant divisor: mul-hi + shift
+            out[o + nd - 1 - d] = (uint8_t)('0' + (t - q * 10u));
+            t = q;
         }
     }
-    return len + nd;
+    return nd;
+}
+
+__device__ __forceinline__ uint32_t emit_int(uint8_t *out, uint32_t o, int32_t x, bool writer)
+{
+    if (x < 0) {
+        if (writer)
+            out[o] = '-';
+        return 1 + emit_uint(out, o + 1, (uint32_t)(-(int64_t)x), writer);
+    }
+    return emit_uint(out, o, (uint32_t)x, writer);
 }
 
 // cost helpers ---------------------------------------------------------------
@@ -267,29 +283,62 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 const uint64_t hx = murmur64(spread_bits(r0) | (spread_bits(r1) << 1));
                 uint32_t sl = (uint32_t)hx & ht_mask;
                 stop = false;
+                // walk the probe chain 16 bytes at a time (4 short / 2 long entries per load); chains
+                // end at the first empty slot, so one or two round trips settle almost every lane
                 if (rd.is_short) {
                     const uint32_t fp = (uint32_t)(hx >> 48);
-                    for (uint32_t t = 0; t < MAX_NO_TRIES; ++t) {
-                        const uint32_t e = ((const uint32_t *)rd.table)[sl];
-                        if (e == 0xFFFFFFFFu)
-                            break;
-                        if ((e & 0xFFFFu) == fp) {
-                            stop = true;
-                            break;
+                    const uint32_t *tab = (const uint32_t *)rd.table;
+                    bool done = false;
+                    for (uint32_t t = 0; t < MAX_NO_TRIES && !done; t += 4) {
+                        uint32_t e[4];
+                        if (sl + 3 <= ht_mask) {
+                            uint4 v;
+                            __builtin_memcpy(&v, tab + sl, 16);
+                            e[0] = v.x, e[1] = v.y, e[2] = v.z, e[3] = v.w;
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                e[u] = tab[(sl + u) & ht_mask];
                         }
-                        sl = (sl + 1) & ht_mask;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (!done) {
+                                if (e[u] == 0xFFFFFFFFu)
+                                    done = true;
+                                else if ((e[u] & 0xFFFFu) == fp) {
+                                    stop = true;
+                                    done = true;
+                                }
+                            }
+                        }
+                        sl = (sl + 4) & ht_mask;
                     }
                 } else {
                     const uint32_t fp = (uint32_t)(hx >> 32);
-                    for (uint32_t t = 0; t < MAX_NO_TRIES; ++t) {
-                        const uint64_t e = ((const uint64_t *)rd.table)[sl];
-                        if (e == ~0ULL)
-                            break;
-                        if ((uint32_t)e == fp) {
-                            stop = true;
-                            break;
+                    const uint64_t *tab = (const uint64_t *)rd.table;
+                    bool done = false;
+                    for (uint32_t t = 0; t < MAX_NO_TRIES && !done; t += 2) {
+                        uint64_t e[2];
+                        if (sl + 1 <= ht_mask) {
+                            ulonglong2 v;
+                            __builtin_memcpy(&v, tab + sl, 16);
+                            e[0] = v.x, e[1] = v.y;
+                        } else {
+                            e[0] = tab[sl & ht_mask];
+                            e[1] = tab[(sl + 1) & ht_mask];
                         }
-                        sl = (sl + 1) & ht_mask;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (!done) {
+                                if (e[u] == ~0ULL)
+                                    done = true;
+                                else if ((uint32_t)e[u] == fp) {
+                                    stop = true;
+                                    done = true;
+                                }
+                            }
+                        }
+                        sl = (sl + 2) & ht_mask;
                     }
                 }
             }
@@ -354,7 +403,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                     if (writer)
                         out[o] = N_RUN_STARTER;
                     o += 1;
-                    o += emit_int(out, o, (int64_t)nrun - MIN_NRUN_LEN, writer);
+                    o += emit_uint(out, o, nrun - MIN_NRUN_LEN, writer);
                     if (writer)
                         out[o] = N_CODE;
                     o += 1;
@@ -417,20 +466,36 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
 
         uint32_t len_bck = 0, len_fwd = 0, match_pos = 0;
         uint32_t min_to_update = mml;
+        uint32_t best_tb = 0;      // lane b: text symbol at i-1-b for the chosen candidate
+        bool best_eq = false;      // lane b: that symbol equals ref[h_pos-1-b]
         while (cand) {
             const uint32_t j = ctz64(cand);
             cand &= cand - 1;
             const uint32_t h_pos = bcast_u32(epos, j) * HASHING_STEP;
             const uint8_t *p = ref + h_pos;
+            // backward bytes of the first 64 positions (lz_diff.cpp:308-311), issued before the forward
+            // compare so that both arrive in one round trip
+            const uint32_t lim = npl < h_pos ? npl : h_pos;
+            uint32_t tb = 0x100u, rb = 0x200u; // lanes >= lim: never equal
+            if (lane < lim) {
+                tb = *(tp - 1 - (int64_t)lane);
+                rb = *(p - 1 - (int64_t)lane);
+            }
             const uint32_t f_len = wave_common_prefix(tp, p, max_len);
             if (f_len >= key_len) {
-                const uint32_t lim = npl < h_pos ? npl : h_pos;
-                const uint32_t b_len = lim ? wave_common_suffix(tp, p, lim) : 0;
+                const uint64_t mm = __ballot(tb != rb);
+                uint32_t b_len;
+                if (mm)
+                    b_len = ctz64(mm);
+                else
+                    b_len = lim <= WAVE ? lim : WAVE + wave_common_suffix(tp - WAVE, p - WAVE, lim - WAVE);
                 if (b_len + f_len > min_to_update) {
                     len_bck = b_len;
                     len_fwd = f_len;
                     match_pos = h_pos;
                     min_to_update = b_len + f_len;
+                    best_tb = tb;
+                    best_eq = tb == rb;
                 }
             }
         }
@@ -473,28 +538,47 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
         i -= len_bck;
 
         if (MODE == MODE_ENCODE) {
-            if (coop_out) {
-                __builtin_amdgcn_s_waitcnt(0); // literals stored by other lanes are visible to lane 0's reads below
+            const uint32_t n_trail = npl - len_bck; // literal bytes now ending the delta
+            if (coop_out || (match_pos == pred_pos && n_trail)) {
+                // stores of other lanes to bytes that are about to be re-written (rolled-back or patched
+                // literals) must have landed first
+                __builtin_amdgcn_s_waitcnt(0);
                 coop_out = false;
             }
             stale_out = stale_out || len_bck != 0;
-            if (match_pos == pred_pos && writer) {
-                // literals equal to the reference become '!' (lz_diff.cpp:769-779)
-                for (uint32_t t = 1; t < o && t < match_pos; ++t) {
-                    const uint8_t c = out[o - t];
-                    if (c < 'A' || c > 'Z')
-                        break;
-                    if ((uint8_t)(c - 'A') == ref[match_pos - t])
-                        out[o - t] = '!';
+            if (match_pos == pred_pos && n_trail) {
+                // Literals equal to the reference become '!' (lz_diff.cpp:769-779).  The reference walks
+                // back over the delta while the bytes are 'A'..'Z' (t < e_size, t < match_pos); those
+                // bytes are exactly the trailing literals, i.e. text[i-t] -- lane b of the chosen
+                // candidate's backward probe holds text[i'-1-b], i' = i before the roll-back, so
+                // t = b - len_bck + 1 and nothing has to be read back from the delta.
+                const uint32_t b = lane;
+                const uint32_t t = b - len_bck + 1;
+                const bool in_first = b >= len_bck && b < WAVE && t <= n_trail && t < o && t < match_pos;
+                // t <= n_trail implies b <= npl-1 and t < match_pos implies b < h_pos-1: only lanes with real data
+                const uint64_t brk = __ballot(in_first && best_tb >= 26);
+                const uint32_t first_brk = brk ? ctz64(brk) : WAVE;
+                if (in_first && b < first_brk && best_eq)
+                    out[o - t] = '!';
+                // trailing literals beyond the 64 probed ones (rare): serial walk on text/ref
+                if (!brk && len_bck + n_trail > WAVE && writer) {
+                    for (uint32_t tt = len_bck >= WAVE ? 1u : WAVE - len_bck + 1; tt <= n_trail && tt < o && tt < match_pos; ++tt) {
+                        const uint8_t c = text[i - tt];
+                        if (c >= 26)
+                            break;
+                        if (c == ref[match_pos - tt])
+                            out[o - tt] = '!';
+                    }
                 }
+                coop_out = true; // '!' bytes were stored by lanes other than 0
             }
             const bool to_end = (i + len == n) && (match_pos + len == ref_size);
-            o += emit_int(out, o, (int64_t)(int)match_pos - (int64_t)(int)pred_pos, writer);
+            o += emit_int(out, o, (int32_t)((int)match_pos - (int)pred_pos), writer);
             if (!to_end) {
                 if (writer)
                     out[o] = ',';
                 o += 1;
-                o += emit_int(out, o, (int64_t)len - (int64_t)mml, writer);
+                o += emit_uint(out, o, len - mml, writer);
             }
             if (writer)
                 out[o] = '.';

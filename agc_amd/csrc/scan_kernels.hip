@@ -51,7 +51,8 @@ struct ScanArgs {
     uint32_t k;
     const uint64_t *table;     // exact splitter table, ~0 = empty
     uint64_t table_mask;
-    const uint32_t *bloom;     // BLOOM_WORDS words
+    const uint32_t *bloom;     // BLOOM_WORDS words (copied to LDS)
+    const uint32_t *bloom2;    // BLOOM2_WORDS words (global / L2)
     ScanHit *hits;
     uint32_t *n_hits;
     uint32_t cap;
@@ -146,47 +147,85 @@ __global__ void __launch_bounds__(1024) scan_kernel(ScanArgs a)
                 const uint64_t hi = ((uint64_t)P2 << 32) | P1;   // symbols -32..-1
                 // invalid bits: bit (47 - q) <-> symbol q-32, q in 0..47
                 const uint64_t inv = ((uint64_t)I2 << 32) | ((uint64_t)I1 << 16) | I;
-
-                // k-mer ending at own symbol 0: the k symbols -(k-1)..0
-                // value (right aligned) = bits of [hi:P] >> 30, masked
-                uint64_t dir = ((hi << 2) | (P >> 30)) & kmask;
-                // reverse complement, right aligned: complement, reverse groups, align
-                uint64_t rcv = rev2(~dir) >> lshift; // ~dir flips every 2-bit symbol to 3-s; reversing puts the last symbol first
-                rcv &= kmask;
                 const uint64_t wmask = k == 32 ? 0xFFFFFFFFULL : ((1ULL << k) - 1ULL);
 
-                for (uint32_t j = 0; j < nvalid; ++j) {
-                    if (j) {
-                        const uint64_t sym = (P >> (2 * (15 - j))) & 3;
-                        dir = ((dir << 2) | sym) & kmask;
-                        rcv = (rcv >> 2) | ((3 - sym) << (2 * k - 2));
+                // k-mer ending at own symbol 0: the k symbols -(k-1)..0, right aligned
+                const uint64_t dir0 = ((hi << 2) | (P >> 30)) & kmask;
+                // reverse complement: ~dir flips every symbol to 3-s, rev2 puts the last symbol first
+                const uint64_t rc0 = (rev2(~dir0) >> lshift) & kmask;
+
+                // pass 1 (branch-free, unrolled): bloom test of the 16 k-mers.  Both forms are kept
+                // LEFT-aligned in 32-bit halves (as CKmer does, kmer.h:284-301): rolling is then two
+                // funnel shifts, nothing shifts out of the field and no 64-bit VALU op is needed.
+                uint32_t pass = 0;
+                {
+                    const uint64_t dl0 = dir0 << lshift, rl0 = rc0 << lshift;
+                    uint32_t dh = (uint32_t)(dl0 >> 32), dl = (uint32_t)dl0, rh = (uint32_t)(rl0 >> 32), rl = (uint32_t)rl0;
+                    const uint32_t lo_mask = lshift ? (~0u << lshift) : ~0u; // lshift = 64-2k in [0,30]
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        uint32_t bw[8], bm[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int j = g * 8 + t;
+                            if (j) {
+                                const uint32_t sym = (P >> (2 * (15 - j))) & 3u;
+                                dh = __builtin_amdgcn_alignbit(dh, dl, 30);          // (dh << 2) | (dl >> 30)
+                                dl = (dl << 2) | (sym << lshift);
+                                rl = __builtin_amdgcn_alignbit(rh, rl, 2) & lo_mask; // (rl >> 2) | (rh << 30)
+                                rh = (rh >> 2) | ((sym ^ 3u) << 30);
+                            }
+                            const bool d_lt = dh < rh || (dh == rh && dl < rl);
+                            bloom_slot(d_lt ? dh : rh, d_lt ? dl : rl, bw[t], bm[t]);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            pass |= (uint32_t)((s_bloom[bw[t]] & bm[t]) == bm[t]) << (g * 8 + t);
                     }
-                    // window validity: symbols (j-k+1 .. j) of the own chunk <-> inv bits (15-j) .. (15-j+k-1)
-                    const bool valid = ((inv >> (15 - j)) & wmask) == 0;
-                    if (valid) {
+                }
+                // window validity: symbols (j-k+1 .. j) <-> inv bits (15-j) .. (15-j+k-1); j < nvalid
+                uint32_t ok = 0xFFFFu;
+                if (inv) {
+                    ok = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        ok |= (uint32_t)(((inv >> (15 - j)) & wmask) == 0) << j;
+                }
+                pass &= ok & ((1u << nvalid) - 1u);
+
+                // pass 2 (rare): second-level filter + exact table for the bloom survivors
+                if (pass) {
+                    uint64_t dir = dir0, rcv = rc0;
+                    for (uint32_t j = 0; j < 16 && (pass >> j); ++j) {
+                        if (j) {
+                            const uint64_t sym = (P >> (2 * (15 - j))) & 3;
+                            dir = ((dir << 2) | sym) & kmask;
+                            rcv = (rcv >> 2) | ((3 - sym) << (2 * k - 2));
+                        }
+                        if (!((pass >> j) & 1u))
+                            continue;
                         const uint64_t dl = dir << lshift, rl = rcv << lshift;
                         const uint64_t can = dl < rl ? dl : rl;
                         const uint64_t h = splitter_hash(can);
-                        uint32_t bw, bm;
-                        bloom_slot(h, bw, bm);
-                        if ((s_bloom[bw] & bm) == bm) {
-                            // exact check
-                            uint64_t slot = h & a.table_mask;
-                            for (;;) {
-                                const uint64_t e = a.table[slot];
-                                if (e == can) {
-                                    const uint32_t idx = atomicAdd(a.n_hits, 1u);
-                                    if (idx < a.cap) {
-                                        a.hits[idx].pos = off + j;
-                                        a.hits[idx].dir = dl;
-                                        a.hits[idx].rc = rl;
-                                    }
-                                    break;
+                        uint32_t w2, m2;
+                        bloom2_slot(h, w2, m2);
+                        if ((a.bloom2[w2] & m2) != m2)
+                            continue;
+                        uint64_t slot = h & a.table_mask;
+                        for (;;) {
+                            const uint64_t e = a.table[slot];
+                            if (e == can) {
+                                const uint32_t idx = atomicAdd(a.n_hits, 1u);
+                                if (idx < a.cap) {
+                                    a.hits[idx].pos = off + j;
+                                    a.hits[idx].dir = dl;
+                                    a.hits[idx].rc = rl;
                                 }
-                                if (e == ~0ULL)
-                                    break;
-                                slot = (slot + 1) & a.table_mask;
+                                break;
                             }
+                            if (e == ~0ULL)
+                                break;
+                            slot = (slot + 1) & a.table_mask;
                         }
                     }
                 }
