@@ -58,7 +58,7 @@ struct ScanArgs {
     uint32_t cap;
 };
 
-__global__ void __launch_bounds__(1024) scan_kernel(ScanArgs a)
+__global__ void __launch_bounds__(1024, 8) scan_kernel(ScanArgs a)
 {
     __shared__ uint32_t s_bloom[BLOOM_WORDS];
     for (uint32_t t = threadIdx.x; t < BLOOM_WORDS; t += blockDim.x)
