@@ -282,25 +282,89 @@ struct HostKmer {
 // determine_splitters, agc_compressor.cpp:428-563 (+ 630-704, 762-825); fallback minimizers are
 // dead code at -f 0.
 // ---------------------------------------------------------------------------
-std::vector<uint64_t> determine_splitters_host(const std::vector<bytes_t> &ref, uint32_t k, uint32_t segment_size, unsigned n_threads)
+// splitters of one contig given the sorted candidate k-mers (find_splitters_in_contig, :762-825)
+static void find_splitters_in_contig(const bytes_t &c, uint32_t k, uint32_t segment_size, const std::vector<uint64_t> &cand,
+                                     std::vector<uint64_t> &spl)
+{
+    auto is_cand = [&](uint64_t d) { return std::binary_search(cand.begin(), cand.end(), d); };
+    HostKmer h(k);
+    uint64_t current_len = segment_size;
+    size_t recent_from = 0;
+    for (size_t i = 0; i < c.size(); ++i) {
+        uint8_t x = c[i];
+        if (x > 3)
+            h.reset();
+        else {
+            h.insert(x);
+            if (h.full() && current_len >= segment_size && is_cand(h.data())) {
+                spl.push_back(h.data());
+                current_len = 0;
+                h.reset();
+                recent_from = i + 1;
+            }
+        }
+        ++current_len;
+    }
+    HostKmer t(k);
+    bool have = false;
+    uint64_t best = 0;
+    for (size_t i = recent_from; i < c.size(); ++i) {
+        uint8_t x = c[i];
+        if (x > 3) {
+            t.reset();
+            continue;
+        }
+        t.insert(x);
+        if (t.full() && is_cand(t.data())) {
+            best = t.data();
+            have = true;
+        }
+    }
+    if (have)
+        spl.push_back(best);
+}
+
+static void enumerate_kmers(const bytes_t &c, uint32_t k, std::vector<uint64_t> &km)
+{
+    HostKmer h(k);
+    for (uint8_t x : c) {
+        if (x > 3)
+            h.reset();
+        else {
+            h.insert(x);
+            if (h.full())
+                km.push_back(h.data());
+        }
+    }
+}
+
+// sorted input -> singletons in place, duplicated values (once each) appended to dup when given
+static void split_singletons(std::vector<uint64_t> &km, std::vector<uint64_t> *dup)
+{
+    size_t o = 0;
+    for (size_t i = 0; i < km.size();) {
+        size_t j = i + 1;
+        while (j < km.size() && km[j] == km[i])
+            ++j;
+        if (j == i + 1)
+            km[o++] = km[i];
+        else if (dup)
+            dup->push_back(km[i]);
+        i = j;
+    }
+    km.resize(o);
+}
+
+std::vector<uint64_t> determine_splitters_host(const std::vector<bytes_t> &ref, uint32_t k, uint32_t segment_size, unsigned n_threads,
+                                               std::vector<uint64_t> *singletons_out, std::vector<uint64_t> *duplicates_out)
 {
     size_t tot = 0;
     for (auto &c : ref)
         tot += c.size();
     std::vector<uint64_t> km;
     km.reserve(tot);
-    for (auto &c : ref) {
-        HostKmer h(k);
-        for (uint8_t x : c) {
-            if (x > 3)
-                h.reset();
-            else {
-                h.insert(x);
-                if (h.full())
-                    km.push_back(h.data());
-            }
-        }
-    }
+    for (auto &c : ref)
+        enumerate_kmers(c, k, km);
     // parallel sort: chunks + merges
     {
         unsigned nt = std::max(1u, std::min<unsigned>(n_threads, 64));
@@ -326,59 +390,15 @@ std::vector<uint64_t> determine_splitters_host(const std::vector<bytes_t> &ref, 
         } else
             std::sort(km.begin(), km.end());
     }
-    // singletons only (remove_non_singletons, :664-680)
-    size_t o = 0;
-    for (size_t i = 0; i < km.size();) {
-        size_t j = i + 1;
-        while (j < km.size() && km[j] == km[i])
-            ++j;
-        if (j == i + 1)
-            km[o++] = km[i];
-        i = j;
-    }
-    km.resize(o);
-    auto is_sing = [&](uint64_t d) { return std::binary_search(km.begin(), km.end(), d); };
-
+    // singletons only; adaptive mode also keeps the duplicated k-mers (remove_non_singletons, :664-704)
+    split_singletons(km, duplicates_out);
     std::vector<uint64_t> spl;
-    for (auto &c : ref) { // find_splitters_in_contig, :762-825
-        HostKmer h(k);
-        uint64_t current_len = segment_size;
-        size_t recent_from = 0;
-        for (size_t i = 0; i < c.size(); ++i) {
-            uint8_t x = c[i];
-            if (x > 3)
-                h.reset();
-            else {
-                h.insert(x);
-                if (h.full() && current_len >= segment_size && is_sing(h.data())) {
-                    spl.push_back(h.data());
-                    current_len = 0;
-                    h.reset();
-                    recent_from = i + 1;
-                }
-            }
-            ++current_len;
-        }
-        HostKmer t(k);
-        bool have = false;
-        uint64_t best = 0;
-        for (size_t i = recent_from; i < c.size(); ++i) {
-            uint8_t x = c[i];
-            if (x > 3) {
-                t.reset();
-                continue;
-            }
-            t.insert(x);
-            if (t.full() && is_sing(t.data())) {
-                best = t.data();
-                have = true;
-            }
-        }
-        if (have)
-            spl.push_back(best);
-    }
+    for (auto &c : ref)
+        find_splitters_in_contig(c, k, segment_size, km, spl);
     std::sort(spl.begin(), spl.end());
     spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
+    if (singletons_out)
+        singletons_out->swap(km);
     return spl;
 }
 
@@ -417,11 +437,17 @@ struct CAGCCompressor::Impl {
     }
 
     // -----------------------------------------------------------------------
-    bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base);
+    bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data = nullptr);
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
     bytes_t enc_buf, fetch_buf; // grown, never shrunk
+    // adaptive mode (-a): sorted singleton / duplicated k-mers of the reference genome
+    // (v_candidate_kmers / v_duplicated_kmers, agc_compressor.cpp:493-497)
+    std::vector<uint64_t> ref_singletons, ref_duplicates;
+    bool find_new_splitters(const bytes_t &ctg, std::vector<uint64_t> &out);
+    int scan_batch(const std::vector<uint64_t> &ctg_off, uint32_t n_ctg, const uint8_t *d_base, std::vector<uint32_t> &h_ctg,
+                   std::vector<uint64_t> &h_pos, std::vector<uint64_t> &h_dir, std::vector<uint64_t> &h_rc, uint64_t &n_hits);
     void after_registration();
 };
 
@@ -461,8 +487,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     Impl &I = *p;
     if (I.created)
         return false;
-    if (adaptive_compression) {
-        I.err("adaptive mode (-a) is not implemented in this round");
+    if (adaptive_compression && reference_file_name.empty()) {
+        I.err("adaptive mode (-a) needs the reference file (its singleton k-mers are kept)");
         return false;
     }
     if (fallback_frac != 0.0) {
@@ -510,7 +536,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
             ref.emplace_back(std::move(c));
             c.clear();
         }
-        auto spl = determine_splitters_host(ref, I.k, I.segment_size, nt);
+        auto spl = determine_splitters_host(ref, I.k, I.segment_size, nt, I.adaptive ? &I.ref_singletons : nullptr,
+                                            I.adaptive ? &I.ref_duplicates : nullptr);
         if (!SetSplitters(spl.data(), spl.size()))
             return false;
         if (I.verbosity > 1)
@@ -608,7 +635,47 @@ void CAGCCompressor::Impl::after_registration()
 }
 
 // ---------------------------------------------------------------------------
-bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base)
+int CAGCCompressor::Impl::scan_batch(const std::vector<uint64_t> &ctg_off, uint32_t n_ctg, const uint8_t *d_base,
+                                     std::vector<uint32_t> &h_ctg, std::vector<uint64_t> &h_pos, std::vector<uint64_t> &h_dir,
+                                     std::vector<uint64_t> &h_rc, uint64_t &n_hits)
+{
+    uint64_t cap = std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000);
+    for (;;) {
+        h_ctg.resize(cap);
+        h_pos.resize(cap);
+        h_dir.resize(cap);
+        h_rc.resize(cap);
+        int rc = agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
+                                          h_rc.data());
+        if (rc == AGC_HIP_ECAP) {
+            cap = n_hits;
+            continue;
+        }
+        if (!hip_ok(rc, "scan_contigs"))
+            return rc;
+        return AGC_HIP_OK;
+    }
+}
+
+// find_new_splitters, agc_compressor.cpp:2054-2081: singleton k-mers of the contig that occur nowhere
+// in the reference genome are the candidates
+bool CAGCCompressor::Impl::find_new_splitters(const bytes_t &ctg, std::vector<uint64_t> &out)
+{
+    std::vector<uint64_t> km, tmp;
+    enumerate_kmers(ctg, k, km);
+    std::sort(km.begin(), km.end());
+    split_singletons(km, nullptr);
+    tmp.resize(km.size());
+    auto e = std::set_difference(km.begin(), km.end(), ref_singletons.begin(), ref_singletons.end(), tmp.begin());
+    tmp.erase(e, tmp.end());
+    km.resize(tmp.size());
+    e = std::set_difference(tmp.begin(), tmp.end(), ref_duplicates.begin(), ref_duplicates.end(), km.begin());
+    km.erase(e, km.end());
+    find_splitters_in_contig(ctg, k, segment_size, km, out);
+    return true;
+}
+
+bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data)
 {
     const uint32_t n_ctg = (uint32_t)ctgs.size();
     double t0 = now();
@@ -629,22 +696,92 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     std::vector<uint32_t> h_ctg;
     std::vector<uint64_t> h_pos, h_dir, h_rc;
     uint64_t n_hits = 0;
-    if (n_ctg) {
-        uint64_t cap = std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000);
-        for (;;) {
-            h_ctg.resize(cap);
-            h_pos.resize(cap);
-            h_dir.resize(cap);
-            h_rc.resize(cap);
-            int rc = agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
-                                              h_rc.data());
-            if (rc == AGC_HIP_ECAP) {
-                cap = n_hits;
-                continue;
+    if (n_ctg && scan_batch(ctg_off, n_ctg, d_base, h_ctg, h_pos, h_dir, h_rc, n_hits) != AGC_HIP_OK)
+        return false;
+
+    // ---- adaptive mode: contigs without any splitter look for new ones, the set is extended and
+    // those contigs are scanned again (agc_compressor.cpp:2038-2044, 2054-2081, 1187-1237) ----
+    if (adaptive && n_ctg) {
+        std::vector<uint8_t> has_hit(n_ctg, 0);
+        for (uint64_t h = 0; h < n_hits; ++h)
+            has_hit[h_ctg[h]] = 1;
+        std::vector<uint32_t> deferred;
+        for (uint32_t c = 0; c < n_ctg; ++c)
+            if (!has_hit[c])
+                deferred.push_back(c);
+        if (!deferred.empty()) {
+            // contigs long enough to carry a splitter: their symbols are needed on the host
+            std::vector<uint32_t> need;
+            for (uint32_t c : deferred)
+                if (ctgs[c].len >= segment_size)
+                    need.push_back(c);
+            std::vector<bytes_t> fetched_ctg(need.size());
+            if (!need.empty() && !host_data) {
+                std::vector<uint64_t> off(need.size()), ooff(need.size() + 1);
+                std::vector<uint32_t> len(need.size());
+                uint64_t tot = 0;
+                for (size_t i = 0; i < need.size(); ++i) {
+                    off[i] = ctgs[need[i]].off;
+                    len[i] = (uint32_t)ctgs[need[i]].len;
+                    tot += len[i];
+                }
+                bytes_t buf(tot);
+                if (!hip_ok(agc_hip_fetch_slices_dev(hip, (uint32_t)need.size(), d_base, off.data(), len.data(), nullptr, buf.data(), tot, ooff.data()), "fetch_slices"))
+                    return false;
+                for (size_t i = 0; i < need.size(); ++i)
+                    fetched_ctg[i].assign(buf.begin() + ooff[i], buf.begin() + ooff[i + 1]);
             }
-            if (!hip_ok(rc, "scan_contigs"))
-                return false;
-            break;
+            std::vector<std::vector<uint64_t>> found(need.size());
+            pool->parallel_for(need.size(), [&](size_t i, unsigned) {
+                find_new_splitters(host_data ? (*host_data)[need[i]] : fetched_ctg[i], found[i]);
+            });
+            size_t n_new = 0;
+            for (auto &f : found)
+                n_new += f.size();
+            if (n_new) {
+                std::vector<uint64_t> add;
+                for (auto &f : found)
+                    add.insert(add.end(), f.begin(), f.end());
+                splitters.insert(splitters.end(), add.begin(), add.end());
+                std::sort(splitters.begin(), splitters.end());
+                splitters.erase(std::unique(splitters.begin(), splitters.end()), splitters.end());
+                if (!hip_ok(agc_hip_splitters_insert(hip, add.data(), add.size()), "splitters_insert"))
+                    return false;
+                // second scan with the extended set; only the deferred contigs take its hits
+                std::vector<uint32_t> c2;
+                std::vector<uint64_t> p2, d2, r2;
+                uint64_t n2 = 0;
+                if (scan_batch(ctg_off, n_ctg, d_base, c2, p2, d2, r2, n2) != AGC_HIP_OK)
+                    return false;
+                std::vector<uint32_t> mc;
+                std::vector<uint64_t> mp, md, mr;
+                uint64_t a = 0, b = 0;
+                for (uint32_t c = 0; c < n_ctg; ++c) {
+                    while (a < n_hits && h_ctg[a] < c)
+                        ++a;
+                    while (b < n2 && c2[b] < c)
+                        ++b;
+                    if (has_hit[c])
+                        for (; a < n_hits && h_ctg[a] == c; ++a) {
+                            mc.push_back(c);
+                            mp.push_back(h_pos[a]);
+                            md.push_back(h_dir[a]);
+                            mr.push_back(h_rc[a]);
+                        }
+                    else
+                        for (; b < n2 && c2[b] == c; ++b) {
+                            mc.push_back(c);
+                            mp.push_back(p2[b]);
+                            md.push_back(d2[b]);
+                            mr.push_back(r2[b]);
+                        }
+                }
+                h_ctg.swap(mc);
+                h_pos.swap(mp);
+                h_dir.swap(md);
+                h_rc.swap(mr);
+                n_hits = h_ctg.size();
+            }
         }
     }
     st.t_scan += now() - t0;
@@ -1350,7 +1487,7 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
             o += batch_data[c].size();
         }
         I.st.t_io += now() - t0;
-        bool ok = I.process_batch(batch, d_base);
+        bool ok = I.process_batch(batch, d_base, &batch_data);
         batch.clear();
         batch_data.clear();
         if (ok)

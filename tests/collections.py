@@ -22,6 +22,10 @@ CONFIGS = {
     "syn_viral_c": (["-k", "31", "-l", "20", "-b", "7", "-c"], "viral_c"),
     # contigs in a different order / missing / extra in the samples, lower-case and soft-masked input
     "syn_shuffled": (["-k", "21", "-l", "17", "-s", "2000", "-b", "50"], "shuffled"),
+    # adaptive mode: samples carry contigs that have no splitter of the reference -> new splitters are
+    # mined from them and used by later samples (BASELINE configs[4] shape, scaled)
+    "syn_adaptive": (["-a", "-k", "31", "-l", "20", "-s", "2000", "-b", "5"], "adaptive"),
+    "syn_adaptive_c": (["-a", "-c", "-k", "25", "-l", "18", "-s", "1500", "-b", "4"], "adaptive"),
 }
 
 
@@ -31,7 +35,7 @@ def build(name, outdir):
     os.makedirs(outdir, exist_ok=True)
     if kind == "toy":
         return [os.path.join(TOY, f) for f in ("ref.fa", "a.fa", "b.fa", "c.fa")]
-    rng = np.random.default_rng({"snp": 11, "mixed": 12, "viral": 13, "viral_c": 13, "shuffled": 14}[kind])
+    rng = np.random.default_rng({"snp": 11, "mixed": 12, "viral": 13, "viral_c": 13, "shuffled": 14, "adaptive": 15}[kind])
     files = []
 
     def write(fn, contigs, names):
@@ -80,4 +84,13 @@ def build(name, outdir):
         with open(q, "wb") as f:
             f.write(b"\n".join(l if l.startswith(b">") else l.lower() for l in lines))
         files.append(q)
+    elif kind == "adaptive":
+        ref = [synth.random_seq(rng, int(n)) for n in (50_000, 30_000)]
+        write("ref.fa", ref, ["r0", "r1"])
+        novel = [synth.random_seq(rng, int(n)) for n in (40_000, 25_000, 1_200, 60_000)]
+        plan = [([0, 1], [0]), ([0], [0, 1]), ([1], [1, 2]), ([0, 1], [0, 3]), ([], [3, 1]), ([1], [2, 0, 3])]
+        for s_, (rc_, nv_) in enumerate(plan):
+            ctg = [synth.mutate(rng, ref[i], 0.004) for i in rc_] + [synth.mutate(rng, novel[i], 0.004, n_runs=1) for i in nv_]
+            nm = [f"s{s_}_r{i}" for i in rc_] + [f"s{s_}_n{i}" for i in nv_]
+            write(f"a{s_}.fa", ctg, nm)
     return files
