@@ -42,3 +42,72 @@ def test_archive_bit_identical(name, tmp_path):
 def test_cli_without_reference_file_reports_and_exits_zero(tmp_path):
     r = subprocess.run([AGC_AMD, "create", "-o", str(tmp_path / "x.agc"), str(tmp_path / "missing.fa")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "Cannot" in r.stderr
+
+
+def _run_amd(args, files, out, threads="8"):
+    r = subprocess.run([AGC_AMD, "create"] + args + ["-t", threads, "-o", out] + files, capture_output=True, text=True, timeout=600)
+    assert os.path.exists(out), r.stderr[-2000:]
+    return open(out, "rb").read()
+
+
+def test_survey_scale_collection_vs_reference(tmp_path):
+    """SURVEY App. B.3 shape: 20 Mbp reference in 4 contigs + 6 samples at d = 1e-3, default parameters
+    (s = 60000): ~2400 placed segments, missing-middle splits, reference streams ~5 MB.  Needs the
+    reference binary (prebuilt oracle/_ref); byte-for-byte."""
+    if not os.path.exists(REF_AGC):
+        pytest.skip("oracle/_ref/agc not prebuilt")
+    import numpy as np
+    from agc_amd import agc_container, build, synth
+    build.build_host()
+    rng = np.random.default_rng(12345)
+    ref = [synth.random_seq(rng, 5_000_000) for _ in range(4)]
+    names = [f"chr{i + 1}" for i in range(4)]
+    d = tmp_path / "in"
+    d.mkdir()
+    files = [str(d / "ref.fa")]
+    synth.to_fasta(files[0], ref, names)
+    for s in range(6):
+        fn = str(d / f"s{s}.fa")
+        synth.to_fasta(fn, [synth.mutate(rng, c, 1e-3) for c in ref], names)
+        files.append(fn)
+    want_fn = str(tmp_path / "ref.agc")
+    subprocess.run([REF_AGC, "create", "-t", "8", "-o", want_fn] + files, check=True, capture_output=True, timeout=600)
+    want = open(want_fn, "rb").read()
+    got = _run_amd([], files, str(tmp_path / "amd.agc"))
+    if got != want:
+        pytest.fail("\n".join(agc_container.diff(want, got)))
+
+
+def test_archive_is_deterministic_and_thread_independent(tmp_path):
+    from agc_amd import build
+    build.build_host()
+    args, _ = C.CONFIGS["syn_mixed"]
+    files = C.build("syn_mixed", str(tmp_path / "in"))
+    a = _run_amd(args, files, str(tmp_path / "a.agc"), threads="1")
+    b = _run_amd(args, files, str(tmp_path / "b.agc"), threads="16")
+    assert a == b and hashlib.sha256(a).hexdigest() == GOLD["syn_mixed"]["sha256"]
+
+
+def test_gz_input_and_file_list(tmp_path):
+    """.gz inputs (src/core/genome_io.cpp via gz_wrapper) and -i <list> give the same archive"""
+    import gzip
+    import shutil
+    from agc_amd import build
+    build.build_host()
+    args, _ = C.CONFIGS["syn_shuffled"]
+    files = C.build("syn_shuffled", str(tmp_path / "in"))
+    gz = []
+    for f in files:
+        g = f + ".gz"
+        with open(f, "rb") as fi, gzip.open(g, "wb", compresslevel=1) as fo:
+            shutil.copyfileobj(fi, fo)
+        gz.append(g)
+    a = _run_amd(args, gz, str(tmp_path / "gz.agc"))
+    # sample names are the file stems minus .fa/.gz suffixes, so the archive is identical to the plain one
+    assert hashlib.sha256(a).hexdigest() == GOLD["syn_shuffled"]["sha256"]
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(files[1:]) + "\n")
+    out = str(tmp_path / "lst.agc")
+    r = subprocess.run([AGC_AMD, "create"] + args + ["-i", str(lst), "-o", out, files[0]], capture_output=True, text=True, timeout=300)
+    assert os.path.exists(out), r.stderr
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD["syn_shuffled"]["sha256"]
