@@ -51,6 +51,8 @@ struct agc_hip_ctx {
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_stage, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
         d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample;
 
+    std::vector<SliceDesc> h_slices;
+
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -80,7 +82,9 @@ int ensure(agc_hip_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap)
         return AGC_HIP_OK;
-    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    // headroom: batches of one collection differ by a few percent in size; growing in big steps keeps
+    // hipFree/hipMalloc (hundreds of ms for multi-GB buffers) out of the steady state
+    size_t want = std::max(bytes + bytes / 4, b.cap + b.cap / 2);
     want = (want + 255) & ~(size_t)255;
     if (b.p) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -538,10 +542,13 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     // 2. count keys -> table sizes (prepare_index, lz_diff.cpp:81-125: double division by 0.7,
     //    round down to a power of two, double it, at least 8)
     std::vector<uint32_t> counts(n_refs);
+    // few references per batch (steady state): spread each over several blocks to fill the chip
+    const uint32_t split = n_refs >= 2048 ? 1u : std::min<uint32_t>(16u, 2048u / n_refs);
+    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, (size_t)n_refs * 4, c->stream));
     {
         KTimer t(c, AGC_HIP_K_INDEX);
-        hipLaunchKernelGGL(idx_count_kernel, dim3(n_refs), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p,
-                           (uint32_t *)c->d_counts.p);
+        hipLaunchKernelGGL(idx_count_kernel, dim3(n_refs * split), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p,
+                           (uint32_t *)c->d_counts.p, split);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(counts.data(), c->d_counts.p, (size_t)n_refs * 4, hipMemcpyDeviceToHost, c->stream));
@@ -568,7 +575,7 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
     {
         KTimer t(c, AGC_HIP_K_INDEX);
-        hipLaunchKernelGGL(idx_insert_kernel, dim3(n_refs), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p);
+        hipLaunchKernelGGL(idx_insert_kernel, dim3(n_refs * split), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p, split);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -680,7 +687,8 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         }
     if (n_rc) {
         CHK(ensure(c, c->d_stage, stage + 64));
-        std::vector<SliceDesc> sl;
+        std::vector<SliceDesc> &sl = c->h_slices; // outlives the asynchronous upload
+        sl.clear();
         sl.reserve(n_rc);
         for (uint32_t i = 0; i < n; ++i)
             if (h_rc[i])
@@ -693,7 +701,6 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
                                (const SliceDesc *)c->d_slices.p, n_rc);
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // sl is a local
     }
     // longest first (stable): sort keys (~len << 32 | index)
     std::vector<uint32_t> order(n);
@@ -986,9 +993,11 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base
     CHK(ensure(c, c->d_lag, (size_t)n * 28 * 4 * 2));
     HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
     uint32_t *d_cnt = (uint32_t *)c->d_lag.p, *d_cur = d_cnt + (size_t)n * 28;
+    const uint32_t split = n >= 2048 ? 1u : std::min<uint32_t>(32u, 2048u / n);
+    HIPCHK(c, hipMemsetAsync(c->d_lag.p, 0, (size_t)n * 28 * 4 * 2, c->stream));
     {
         KTimer t(c, AGC_HIP_K_REFSTORE);
-        hipLaunchKernelGGL(lag_counts_kernel, dim3(n), dim3(256), 0, c->stream, (const SliceDesc *)c->d_slices.p, d_cnt, d_cur);
+        hipLaunchKernelGGL(lag_counts_kernel, dim3(n * split), dim3(256), 0, c->stream, (const SliceDesc *)c->d_slices.p, d_cnt, d_cur, split);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));

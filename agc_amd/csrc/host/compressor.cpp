@@ -1318,7 +1318,14 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         pos_enc[enc_items[i]] = i;
     std::vector<ZJob> jobs;
     std::vector<uint32_t> in_group_id(placed.size(), 0);
-    for (size_t li = 0; li < lists.size(); ++li) {
+    // groups are independent of each other (the reference runs them on all worker threads,
+    // agc_compressor.cpp:989-1050): chunks of lists go to the pool, their jobs are merged in list order
+    const size_t n_chunks = std::min<size_t>(lists.size(), (size_t)pool->size() * 8);
+    std::vector<std::vector<ZJob>> chunk_jobs(n_chunks);
+    pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
+    std::vector<ZJob> &jobs = chunk_jobs[ci];
+    const size_t li_begin = lists.size() * ci / n_chunks, li_end = lists.size() * (ci + 1) / n_chunks;
+    for (size_t li = li_begin; li < li_end; ++li) {
         const uint32_t gid = dense_gid[li];
         Group &g = groups[gid];
         for (uint32_t idx : lists[li]) {
@@ -1378,6 +1385,10 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             in_group_id[idx] = igid;
         }
     }
+    });
+    for (auto &cj : chunk_jobs)
+        for (auto &j : cj)
+            jobs.emplace_back(std::move(j));
     // collection records (agc_compressor.cpp:1038-1049)
     {
         std::string cur_sample;

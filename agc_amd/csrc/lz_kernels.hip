@@ -703,21 +703,23 @@ __device__ __forceinline__ uint64_t key_at(const uint8_t *__restrict__ r, uint32
 // number of valid keys at positions 0,4,8,... (the count prepare_index sizes the table by,
 // lz_diff.cpp:88-101: a key is counted where the last key_len symbols are all ACGT and the
 // key starts at a multiple of hashing_step)
-__global__ void __launch_bounds__(256) idx_count_kernel(const IdxBuild *__restrict__ jobs, uint32_t *__restrict__ counts)
+// A reference may be spread over `split` blocks (few, long references): counts[] must be zeroed.
+__global__ void __launch_bounds__(256) idx_count_kernel(const IdxBuild *__restrict__ jobs, uint32_t *__restrict__ counts, uint32_t split)
 {
-    const IdxBuild jb = jobs[blockIdx.x];
+    const uint32_t job = blockIdx.x / split, part = blockIdx.x % split;
+    const IdxBuild jb = jobs[job];
     uint32_t c = 0;
-    for (uint32_t t = threadIdx.x; (uint64_t)t * HASHING_STEP + jb.key_len <= jb.ref_size; t += blockDim.x)
-        c += key_at(jb.ref + t * HASHING_STEP, jb.key_len) != ~0ULL;
+    for (uint32_t t = part * blockDim.x + threadIdx.x; (uint64_t)t * HASHING_STEP + jb.key_len <= jb.ref_size; t += blockDim.x * split)
+        c += key_at(jb.ref + (uint64_t)t * HASHING_STEP, jb.key_len) != ~0ULL;
     // block reduce
     for (int o = 32; o > 0; o >>= 1)
         c += __shfl_down(c, o);
-    __shared__ uint32_t part[4];
+    __shared__ uint32_t part_sum[4];
     if ((threadIdx.x & 63) == 0)
-        part[threadIdx.x >> 6] = c;
+        part_sum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0)
-        counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+        atomicAdd(&counts[job], part_sum[0] + part_sum[1] + part_sum[2] + part_sum[3]);
 }
 
 // Deterministic parallel linear-probing insertion.  The reference inserts keys in
@@ -759,10 +761,11 @@ __device__ void idx_insert_one(const IdxBuild &jb, uint32_t t)
     }
 }
 
-__global__ void __launch_bounds__(256) idx_insert_kernel(const IdxBuild *__restrict__ jobs)
+__global__ void __launch_bounds__(256) idx_insert_kernel(const IdxBuild *__restrict__ jobs, uint32_t split)
 {
-    const IdxBuild jb = jobs[blockIdx.x];
-    for (uint32_t t = threadIdx.x; (uint64_t)t * HASHING_STEP < jb.ref_size; t += blockDim.x) {
+    // the atomicMin fixpoint does not depend on which block inserts which key
+    const IdxBuild jb = jobs[blockIdx.x / split];
+    for (uint32_t t = (blockIdx.x % split) * blockDim.x + threadIdx.x; (uint64_t)t * HASHING_STEP < jb.ref_size; t += blockDim.x * split) {
         if (jb.is_short)
             idx_insert_one<uint32_t, 16>(jb, t);
         else
@@ -795,10 +798,12 @@ __global__ void __launch_bounds__(256) slice_copy_kernel(const SliceDesc *__rest
 
 // repetitiveness probe counters (segment.h:224-247): for lag 4..31,
 // cnt = #{j : j+lag < n, d[j]==d[j+lag]}, cur = #{j : j+lag < n, d[j] < 4}
+// cnt_out / cur_out must be zeroed; a slice may be spread over `split` blocks
 __global__ void __launch_bounds__(256) lag_counts_kernel(const SliceDesc *__restrict__ jobs, uint32_t *__restrict__ cnt_out,
-                                                         uint32_t *__restrict__ cur_out)
+                                                         uint32_t *__restrict__ cur_out, uint32_t split)
 {
-    const SliceDesc sd = jobs[blockIdx.x];
+    const uint32_t job = blockIdx.x / split, part = blockIdx.x % split;
+    const SliceDesc sd = jobs[job];
     __shared__ uint32_t s_cnt[28], s_cur[28];
     if (threadIdx.x < 28) {
         s_cnt[threadIdx.x] = 0;
@@ -810,7 +815,7 @@ __global__ void __launch_bounds__(256) lag_counts_kernel(const SliceDesc *__rest
     for (int l = 0; l < 28; ++l)
         cnt[l] = cur[l] = 0;
     const uint32_t n = sd.len;
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+    for (uint32_t j = part * blockDim.x + threadIdx.x; j < n; j += blockDim.x * split) {
         uint8_t c = sd.rc ? sd.src[n - 1 - j] : sd.src[j];
         if (sd.rc && c < 4)
             c = 3 - c;
@@ -841,8 +846,8 @@ __global__ void __launch_bounds__(256) lag_counts_kernel(const SliceDesc *__rest
     }
     __syncthreads();
     if (threadIdx.x < 28) {
-        cnt_out[blockIdx.x * 28 + threadIdx.x] = s_cnt[threadIdx.x];
-        cur_out[blockIdx.x * 28 + threadIdx.x] = s_cur[threadIdx.x];
+        atomicAdd(&cnt_out[job * 28 + threadIdx.x], s_cnt[threadIdx.x]);
+        atomicAdd(&cur_out[job * 28 + threadIdx.x], s_cur[threadIdx.x]);
     }
 }
 
