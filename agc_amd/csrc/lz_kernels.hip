@@ -69,26 +69,66 @@ __device__ __forceinline__ uint4 load16(const uint8_t *p)
     return v;
 }
 
+// Per-wave window of the text in LDS: the symbols the parse is about to look at (keys of the next
+// positions) without another trip to HBM.  It is refilled from global memory when the parse
+// position leaves it and -- for free -- by the last 1 KiB step of every forward compare, whose text
+// chunk contains the position right after the match.
+constexpr uint32_t WIN_BYTES = 1024;
+struct TextWin {
+    uint8_t *lds;   // WIN_BYTES bytes of LDS owned by this wave
+    uint32_t base;  // text position of lds[0]
+    uint32_t len;   // valid bytes
+};
+
+__device__ __forceinline__ bool win_has(const TextWin &w, uint32_t pos, uint32_t cnt)
+{
+    return pos >= w.base && pos + cnt <= w.base + w.len;
+}
+
+__device__ __forceinline__ void win_fill(TextWin &w, const uint8_t *__restrict__ text, uint32_t n, uint32_t pos)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t len = n - pos < WIN_BYTES ? n - pos : WIN_BYTES;
+    const uint32_t off = lane * 16;
+    if (off < len) {
+        if (len - off >= 16) {
+            const uint4 v = load16(text + pos + off);
+            *(uint4 *)(w.lds + off) = v;
+        } else {
+            for (uint32_t t = off; t < len; ++t)
+                w.lds[t] = text[pos + t];
+        }
+    }
+    w.base = pos;
+    w.len = len;
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS stores are done before the wave reads them back
+}
+
 // Length of the common prefix of p[0..max_len) and q[0..max_len), whole wave.
 // Semantics of refresh::matching_length (3rd_party/refresh/string_operations/lib/
 // string_operations.h:18-69) as used by compare_fwd (lz_diff.h:264-266).
-// Reads of p and q stay inside [0, max_len) except that q may be read up to
-// max_len rounded up to the 16-byte chunk that contains a difference -- never: every
-// 16-byte load is issued only when the whole chunk lies below max_len.
-__device__ uint32_t wave_common_prefix(const uint8_t *__restrict__ p, const uint8_t *__restrict__ q, uint32_t max_len)
+// Every 16-byte load is issued only when the whole chunk lies below max_len.
+// When `win` is given, p is the text at position p_pos and the text chunk of the final step is
+// captured into the window.
+__device__ uint32_t wave_common_prefix(const uint8_t *__restrict__ p, const uint8_t *__restrict__ q, uint32_t max_len,
+                                       TextWin *win = nullptr, uint32_t p_pos = 0)
 {
     const uint32_t lane = lane_id();
     for (uint32_t base = 0;; base += WAVE * 16) {
         const uint32_t off = base + lane * 16;
         bool stop;
         uint32_t so;
+        uint4 a = make_uint4(0, 0, 0, 0);
+        bool full = false;
         if (off >= max_len) {
             stop = true;
             so = 0;
         } else if (max_len - off >= 16) {
-            uint4 a = load16(p + off), b = load16(q + off);
+            a = load16(p + off);
+            const uint4 b = load16(q + off);
             so = first_diff_byte16(a, b);
             stop = so < 16;
+            full = true;
         } else {
             const uint32_t rem = max_len - off;
             so = 0;
@@ -98,6 +138,15 @@ __device__ uint32_t wave_common_prefix(const uint8_t *__restrict__ p, const uint
         }
         const uint64_t m = __ballot(stop);
         if (m) {
+            if (win) {
+                // lanes holding a full chunk form a prefix of the wave: capture them
+                const uint64_t fm = __ballot(full);
+                if (full)
+                    *(uint4 *)(win->lds + lane * 16) = a;
+                win->base = p_pos + base;
+                win->len = (uint32_t)__builtin_popcountll(fm) * 16;
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+            }
             const uint32_t l = ctz64(m);
             const uint32_t r = base + l * 16 + bcast_u32(so, l);
             return r < max_len ? r : max_len;
@@ -229,7 +278,7 @@ struct ParseOut {
 
 template <int MODE>
 __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text, const uint32_t n,
-                             uint8_t *__restrict__ out, uint32_t *__restrict__ costs, const bool prefix_costs)
+                             uint8_t *__restrict__ out, uint32_t *__restrict__ costs, const bool prefix_costs, uint8_t *win_lds)
 {
     const uint32_t lane = lane_id();
     const bool writer = lane == 0;
@@ -254,9 +303,22 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
     const uint64_t keybits = (1ULL << key_len) - 1ULL;
     bool stale_out = false;   // bytes at/after `o` were stored by lane 0 earlier (rolled-back literals)
     bool coop_out = false;    // bytes before `o` were stored by lanes other than 0 since the last drain
-    bool try_wide = false;    // the last exact step produced a literal: look at 64 positions at once next
+    // Wide (64-position) probing pays off in long literal runs but costs one table line per position;
+    // in the match / SNP / match rhythm of similar sequences the 1-4 literals after a mismatch are
+    // cheaper as exact steps.  It is therefore armed only after WIDE_AFTER consecutive literal steps.
+    constexpr uint32_t WIDE_AFTER = 4;
+    uint32_t lit_streak = 0;
+    bool try_wide = false;
+    TextWin win{win_lds, 0, 0};
     while (i + key_len < n) {
         AGC_TRACE(4, i);
+        {
+            // symbols i .. i+64+key_len+2 (as far as the text goes) must be in the LDS window
+            const uint32_t need = n - i < WAVE + key_len + 2 ? n - i : WAVE + key_len + 2;
+            if (!win_has(win, i, need))
+                win_fill(win, text, n, i);
+        }
+        const uint8_t *__restrict__ wtext = win.lds - win.base; // wtext[pos] for positions inside the window
         // ---- wide literal probe: lanes look at positions i .. i+63 at once.  A position is a
         // certain literal when its key is valid and no slot of its probe chain (up to the first
         // empty slot / 64 tries) carries the key's fingerprint, or when its key is invalid and no
@@ -265,8 +327,8 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
         // Only entered after an exact step found no match (long matches never pay for it).
         if (try_wide) {
             const uint32_t q = i + lane;
-            const uint32_t sa = q < n ? (uint32_t)text[q] : 0xFFu;
-            const uint32_t sb = (lane < key_len + 2 && q + 64 < n) ? (uint32_t)text[q + 64] : 0xFFu;
+            const uint32_t sa = q < n ? (uint32_t)wtext[q] : 0xFFu;
+            const uint32_t sb = (lane < key_len + 2 && q + 64 < n) ? (uint32_t)wtext[q + 64] : 0xFFu;
             const uint64_t a0 = __ballot((sa & 1u) != 0), a1 = __ballot((sa & 2u) != 0), ai = __ballot(sa > 3), an = __ballot(sa == N_CODE);
             const uint64_t b0 = __ballot((sb & 1u) != 0), b1 = __ballot((sb & 2u) != 0), bi = __ballot(sb > 3), bn = __ballot(sb == N_CODE);
             const uint32_t sh = lane, rs = (64 - lane) & 63;
@@ -377,7 +439,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
         }
         // ---- exact step at position i.  key at text[i .. i+key_len)  (get_code, lz_diff.h:58-106) ----
         const uint8_t *tp = text + i;
-        const uint32_t s = lane < key_len ? (uint32_t)tp[lane] : 0u;
+        const uint32_t s = lane < key_len ? (uint32_t)wtext[i + lane] : 0u;
         const uint64_t bad = __ballot(s > 3);
         const uint32_t s0 = bcast_u32(s, 0);
         const uint32_t max_len = n - i;
@@ -421,6 +483,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 i += nrun;
                 npl = 0;
                 try_wide = false;
+                lit_streak = 0;
             } else {
                 if (MODE == MODE_ENCODE) {
                     if (writer)
@@ -433,7 +496,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 ++i;
                 ++pred_pos;
                 ++npl;
-                try_wide = true;
+                try_wide = ++lit_streak >= WIDE_AFTER;
             }
             continue;
         }
@@ -481,7 +544,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 tb = *(tp - 1 - (int64_t)lane);
                 rb = *(p - 1 - (int64_t)lane);
             }
-            const uint32_t f_len = wave_common_prefix(tp, p, max_len);
+            const uint32_t f_len = wave_common_prefix(tp, p, max_len, &win, i);
             if (f_len >= key_len) {
                 const uint64_t mm = __ballot(tb != rb);
                 uint32_t b_len;
@@ -513,11 +576,12 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             ++i;
             ++pred_pos;
             ++npl;
-            try_wide = true;
+            try_wide = ++lit_streak >= WIDE_AFTER;
             continue;
         }
 
         try_wide = false;
+        lit_streak = 0;
         const uint32_t len = len_bck + len_fwd;
         if (MODE == MODE_ESTIMATE) {
             // no roll-back of the back extension here (lz_diff.cpp:926-936)
@@ -641,13 +705,15 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
     const SegDesc sd = segs[idx];
     const RefDesc rd = refs[sd.ref_slot];
     AGC_TRACE(2, sd.len);
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_BYTES];
+    uint8_t *win_lds = s_win[threadIdx.x >> 6];
     ParseOut r;
     if (MODE == MODE_ENCODE)
-        r = lz_parse<MODE>(rd, sd.text, sd.len, out_bytes + sd.out_off, nullptr, false);
+        r = lz_parse<MODE>(rd, sd.text, sd.len, out_bytes + sd.out_off, nullptr, false, win_lds);
     else if (MODE == MODE_ESTIMATE)
-        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, nullptr, false);
+        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, nullptr, false, win_lds);
     else
-        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, out_u32 + sd.out_off, (sd.flags & 1u) != 0);
+        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, out_u32 + sd.out_off, (sd.flags & 1u) != 0, win_lds);
     AGC_TRACE(9, r.value);
     if (lane_id() == 0) {
         res_value[sd.pad] = r.value; // sd.pad = index in the caller's order

@@ -220,6 +220,7 @@ def main():
             except Exception as e:  # the baseline is informational; never lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+    cmp_.close_handle()  # tear the HIP context down before the interpreter (and any profiler) exits
     if world > 1:
         dist.destroy_process_group()
 
