@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(1024, 8) scan_kernel(ScanArgs a)
                 const uint64_t cb = rg.begin - 16 * (uint64_t)(lane + 1); // may wrap below 0: handled per byte
                 P = 0;
                 I = 0;
+#pragma unroll 1
                 for (uint32_t j = 0; j < 16; ++j) {
                     const uint64_t p = cb + j;
                     uint32_t c = 4;
@@ -99,21 +100,33 @@ __global__ void __launch_bounds__(1024, 8) scan_kernel(ScanArgs a)
             carryI2 = __shfl(I, 1);
         }
 
+        // the 16-byte chunk of the NEXT step is requested before the current one is processed
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        {
+            const uint64_t off0 = rg.begin + (uint64_t)lane * 16;
+            if (off0 + 16 <= rg.end)
+                __builtin_memcpy(&nxt, a.codes + off0, 16);
+        }
         for (uint64_t base = rg.begin; base < rg.end; base += 1024) {
             const uint64_t off = base + (uint64_t)lane * 16;
+            const uint4 v = nxt;
+            {
+                const uint64_t offn = off + 1024;
+                if (offn + 16 <= rg.end)
+                    __builtin_memcpy(&nxt, a.codes + offn, 16);
+            }
             uint32_t P = 0, I = 0xFFFF;
             uint32_t nvalid = 0; // symbols of this chunk inside the range
             if (off < rg.end) {
                 const uint64_t rem = rg.end - off;
                 if (rem >= 16) {
-                    uint4 v;
-                    __builtin_memcpy(&v, a.codes + off, 16);
                     P = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
                     I = (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
                     nvalid = 16;
                 } else {
                     P = 0;
                     I = 0;
+#pragma unroll 1
                     for (uint32_t j = 0; j < 16; ++j) {
                         uint32_t c = 4;
                         if (j < rem)
@@ -187,23 +200,27 @@ __global__ void __launch_bounds__(1024, 8) scan_kernel(ScanArgs a)
                 uint32_t ok = 0xFFFFu;
                 if (inv) {
                     ok = 0;
-#pragma unroll
+#pragma unroll 1
                     for (int j = 0; j < 16; ++j)
                         ok |= (uint32_t)(((inv >> (15 - j)) & wmask) == 0) << j;
                 }
                 pass &= ok & ((1u << nvalid) - 1u);
 
-                // pass 2 (rare): second-level filter + exact table for the bloom survivors
+                // pass 2: second-level filter + exact table for the bloom survivors.  Rare per lane but some
+                // lane of the wave almost always has one, so it must be cheap: each survivor's k-mer is cut
+                // straight out of the packed window (no re-rolling), and the loop runs over set bits only.
                 if (pass) {
-                    uint64_t dir = dir0, rcv = rc0;
-                    for (uint32_t j = 0; j < 16 && (pass >> j); ++j) {
-                        if (j) {
-                            const uint64_t sym = (P >> (2 * (15 - j))) & 3;
-                            dir = ((dir << 2) | sym) & kmask;
-                            rcv = (rcv >> 2) | ((3 - sym) << (2 * k - 2));
-                        }
-                        if (!((pass >> j) & 1u))
-                            continue;
+                    const uint64_t w_lo = (hi << 32) | P;   // symbols -16..15
+                    const uint64_t w_hi = hi >> 32;          // symbols -32..-17
+                    while (pass) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(pass);
+                        pass &= pass - 1;
+                        const uint32_t sft = 2 * (15 - j);
+                        uint64_t dir = w_lo >> sft;
+                        if (sft)
+                            dir |= w_hi << (64 - sft);
+                        dir &= kmask;
+                        const uint64_t rcv = (rev2(~dir) >> lshift) & kmask;
                         const uint64_t dl = dir << lshift, rl = rcv << lshift;
                         const uint64_t can = dl < rl ? dl : rl;
                         const uint64_t h = splitter_hash(can);

@@ -60,6 +60,27 @@ def host_cpus():
     return n
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this workload
+    (profiles/r1_final/pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes; values in KB;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None when the summary is absent."""
+    fn = os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.csv")
+    try:
+        fetch = write = None
+        for line in open(fn):
+            f = line.strip().split(",")
+            if len(f) >= 5 and f[0].endswith(kernel.replace("lz_parse_kernel<ENCODE>", "lz_parse_kernel<0>")):
+                if f[1] == "FETCH_SIZE":
+                    fetch = float(f[4])   # max over dispatches = the full-size launches
+                elif f[1] == "WRITE_SIZE":
+                    write = float(f[4])
+        if fetch is None:
+            return None, None
+        return int((2.0 * fetch + (write or 0.0)) * 1024), "profiles/r1_final/pmc_summary.csv (2 x FETCH_SIZE + WRITE_SIZE, per launch)"
+    except OSError:
+        return None, None
+
+
 def cpu_baseline(args, mbp):
     """reference CPU implementation on a bounded twin of the workload (same generator, smaller):
     wall(create ref + 2 samples) - wall(create ref only), all host cores."""
@@ -182,11 +203,21 @@ def main():
 
     if rank == 0:
         value = stats["bases"] / elapsed / 1e9
-        enc_ms, enc_n = tm["encode"]
-        # algorithmic bytes of the encode kernel (SURVEY 8d, 1 B/symbol layout): text once + matched reference once.
-        # bases LZ-encoded per launch ~ all bases of the sample (every placed segment except new references)
+        # Roofline (HBM-bound byte work; SURVEY 8d algorithmic bytes, 1 B/symbol layout):
+        #   scan   : every symbol of the sample read once                      -> 1.0 B/bp
+        #   encode : text read once + matched reference read once              -> 2.0 B/bp
+        # kernel time = HIP events on the library's own stream, averaged over the launches of the timed region.
         bases_per_launch = stats["bases"] / world / max(args.steps, 1)
-        achieved = 2.0 * bases_per_launch / (enc_ms / max(enc_n, 1) * 1e-3) / 1e9 if enc_n else 0.0
+        kern = {}
+        for name, bpb in (("scan", 1.0), ("encode", 2.0)):
+            ms_, n_ = tm[name]
+            if n_:
+                avg = ms_ / n_
+                kern[name] = {"avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_bp": bpb,
+                              "achieved": round(bpb * bases_per_launch / (avg * 1e-3) / 1e9, 2)}
+        dominant = max(kern, key=lambda k_: kern[k_]["avg_launch_ms"]) if kern else "encode"
+        kname = {"scan": "scan_kernel", "encode": "lz_parse_kernel<ENCODE>"}[dominant]
+        traffic, traffic_src = pmc_traffic(kname)
         per = lambda x: x / max(args.steps * world, 1)
         out = {
             "metric": "input Gbp/s compressed (create), hot path scan + match + encode + zstd packing",
@@ -209,9 +240,13 @@ def main():
                        "zstd": {"version": cmp_.zstd_version(), "host_threads": threads, "in_bytes": int(stats["zstd_in"]), "out_bytes": int(stats["zstd_out"])},
                        "host_stage_seconds_rank0": {k_: round(stats[k_], 4) for k_ in stats if k_.startswith("t_")},
                        "parallelism": f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "lz_parse_kernel<ENCODE>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "algorithmic_bytes_per_bp": 2.0, "avg_launch_ms": round(enc_ms / max(enc_n, 1), 4),
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": kern.get(dominant, {}).get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(kern.get(dominant, {}).get("achieved", 0.0) / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": int(kern.get(dominant, {}).get("algorithmic_bytes_per_bp", 0) * bases_per_launch),
+                         "avg_launch_ms": kern.get(dominant, {}).get("avg_launch_ms"),
+                         "dominant_by": "largest average launch time among the path's streaming kernels",
+                         "kernels": {k_: dict(v, frac=round(v["achieved"] / HBM_PEAK_GBS, 5)) for k_, v in kern.items()},
                          "kernel_ms_per_step_rank0": {n: round(v[0] / max(args.steps, 1), 4) for n, v in tm.items() if v[1]}},
         }
         if not args.no_cpu_baseline:
