@@ -307,6 +307,9 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
     // in the match / SNP / match rhythm of similar sequences the 1-4 literals after a mismatch are
     // cheaper as exact steps.  It is therefore armed only after WIDE_AFTER consecutive literal steps.
     constexpr uint32_t WIDE_AFTER = 4;
+    // slots a lane may inspect in the wide probe (two 16-byte loads); a longer chain makes the
+    // position a conservative "stop" that the exact step resolves -- the result is unchanged
+    constexpr uint32_t WIDE_MAX_SLOTS = MAX_NO_TRIES; // (a budget of 8 made literal runs slower: more exact steps)
     uint32_t lit_streak = 0;
     bool try_wide = false;
     TextWin win{win_lds, 0, 0};
@@ -351,7 +354,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                     const uint32_t fp = (uint32_t)(hx >> 48);
                     const uint32_t *tab = (const uint32_t *)rd.table;
                     bool done = false;
-                    for (uint32_t t = 0; t < MAX_NO_TRIES && !done; t += 4) {
+                    for (uint32_t t = 0; t < WIDE_MAX_SLOTS && !done; t += 4) {
                         uint32_t e[4];
                         if (sl + 3 <= ht_mask) {
                             uint4 v;
@@ -375,11 +378,12 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                         }
                         sl = (sl + 4) & ht_mask;
                     }
+                    stop = stop || !done; // chain longer than the probe budget: let the exact step decide
                 } else {
                     const uint32_t fp = (uint32_t)(hx >> 32);
                     const uint64_t *tab = (const uint64_t *)rd.table;
                     bool done = false;
-                    for (uint32_t t = 0; t < MAX_NO_TRIES && !done; t += 2) {
+                    for (uint32_t t = 0; t < WIDE_MAX_SLOTS && !done; t += 2) {
                         uint64_t e[2];
                         if (sl + 1 <= ht_mask) {
                             ulonglong2 v;
@@ -402,6 +406,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                         }
                         sl = (sl + 2) & ht_mask;
                     }
+                    stop = stop || !done;
                 }
             }
             const uint64_t sm = __ballot(stop);
