@@ -249,7 +249,7 @@ def main():
                          "kernels": {k_: dict(v, frac=round(v["achieved"] / HBM_PEAK_GBS, 5)) for k_, v in kern.items()},
                          "kernel_ms_per_step_rank0": {n: round(v[0] / max(args.steps, 1), 4) for n, v in tm.items() if v[1]}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_mbp)
             except Exception as e:  # the baseline is informational; never lose the GPU line

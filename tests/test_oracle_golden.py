@@ -93,3 +93,24 @@ def test_oracle_vs_reference_live(oracle):
         assert a.estimate(text, 25) == b.estimate(text, 25), i
         for pc in (0, 1):
             assert np.array_equal(a.cost_vector(text, pc), b.cost_vector(text, pc)), i
+
+
+def test_container_reader_on_reference_archive():
+    """the .agc container reader used by the parity tests, on the archive the reference wrote for
+    BASELINE configs[0] (toy_ex, -k 25 -l 17): stream order and part framing of SURVEY App. A.8 / B.2"""
+    import hashlib
+    import json
+    from agc_amd import agc_container
+    data = open(os.path.join(G, "toy_c1_reference.agc"), "rb").read()
+    gold = json.load(open(os.path.join(G, "archives.json")))["toy_c1"]
+    assert hashlib.sha256(data).hexdigest() == gold["sha256"] == "81502256be60722f89f07622e55a222bce43f558f8a0d760d73313acdb977d62"
+    streams, order = agc_container.parse(data)
+    assert order[:3] == ["collection-samples", "collection-contigs", "collection-details"]
+    assert order[3:19] == ["x%sd" % c for c in "0123456789ABCDEF"]
+    assert order[-4:] == ["params", "splitters", "segment-splitters", "file_type_info"]
+    # contigs shorter than k: no splitters, every contig is a raw segment; 16 raw groups pre-seeded with 0x7f
+    assert streams["splitters"][0][1] == b""
+    import struct
+    assert struct.unpack("<4I", streams["params"][0][1]) == (25, 17, 50, 60000)
+    assert sum(len(p) for n, p in streams.items() if n.startswith("x") and n.endswith("d")) >= 16
+    assert agc_container.diff(data, data) == []
