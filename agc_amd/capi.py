@@ -23,6 +23,7 @@ SYMBOLS = [
     "agc_hip_sample_buffer", "agc_hip_copy_to_device",
     "agc_hip_preprocess_dev",
     "agc_hip_splitters_set", "agc_hip_splitters_insert", "agc_hip_splitters_count",
+    "agc_hip_determine_splitters_dev",
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
     "agc_hip_ref_register", "agc_hip_ref_register_batch_dev", "agc_hip_ref_get", "agc_hip_ref_index_get",
     "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch",
@@ -79,6 +80,8 @@ def load():
     L.agc_hip_splitters_insert.argtypes = [vp, u64p, C.c_uint64]
     L.agc_hip_splitters_count.argtypes = [vp]
     L.agc_hip_splitters_count.restype = C.c_uint64
+    L.agc_hip_determine_splitters_dev.argtypes = [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u64p,
+                                                  C.c_uint64, u64p, u64p]
     scan_tail = [u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     L.agc_hip_scan_contigs_dev.argtypes = [vp, vp] + scan_tail
     L.agc_hip_scan_contigs.argtypes = [vp, u8p] + scan_tail
@@ -165,6 +168,25 @@ class Context:
 
     def splitters_count(self):
         return int(self.L.agc_hip_splitters_count(self.h))
+
+    def determine_splitters_dev(self, d_codes, ctg_off, k, segment_size, want_sorted=False):
+        """-> sorted unique splitters (and, if asked, all canonical k-mers of the reference, sorted)"""
+        off = _a(ctg_off, np.uint64)
+        cap = 1 << 16
+        total = int(off[-1] - off[0])
+        srt = np.zeros(total if want_sorted else 0, np.uint64)
+        while True:
+            out = np.zeros(cap, np.uint64)
+            n = C.c_uint64()
+            ns = C.c_uint64()
+            rc = self.L.agc_hip_determine_splitters_dev(self.h, d_codes, _p(off, u64p), off.size - 1, k, segment_size, cap, _p(out, u64p),
+                                                        C.byref(n), srt.size, _p(srt, u64p) if want_sorted else None,
+                                                        C.byref(ns) if want_sorted else None)
+            if rc == ECAP and n.value > cap:
+                cap = int(n.value)
+                continue
+            self._chk(rc)
+            return (out[:n.value], srt[:ns.value]) if want_sorted else out[:n.value]
 
     def _scan(self, fn, codes_arg, ctg_off, k, cap):
         off = _a(ctg_off, np.uint64)

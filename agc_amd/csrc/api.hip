@@ -1007,3 +1007,5 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base
 }
 
 } // extern "C"
+
+#include "splitters.hip"

@@ -279,8 +279,8 @@ struct HostKmer {
 } // namespace
 
 // ---------------------------------------------------------------------------
-// determine_splitters, agc_compressor.cpp:428-563 (+ 630-704, 762-825); fallback minimizers are
-// dead code at -f 0.
+// Host pieces of the adaptive mode's find_new_splitters (agc_compressor.cpp:2054-2081, 630-704,
+// 762-825); the reference genome itself is preprocessed on the GPU (agc_hip_determine_splitters_dev).
 // ---------------------------------------------------------------------------
 // splitters of one contig given the sorted candidate k-mers (find_splitters_in_contig, :762-825)
 static void find_splitters_in_contig(const bytes_t &c, uint32_t k, uint32_t segment_size, const std::vector<uint64_t> &cand,
@@ -353,53 +353,6 @@ static void split_singletons(std::vector<uint64_t> &km, std::vector<uint64_t> *d
         i = j;
     }
     km.resize(o);
-}
-
-std::vector<uint64_t> determine_splitters_host(const std::vector<bytes_t> &ref, uint32_t k, uint32_t segment_size, unsigned n_threads,
-                                               std::vector<uint64_t> *singletons_out, std::vector<uint64_t> *duplicates_out)
-{
-    size_t tot = 0;
-    for (auto &c : ref)
-        tot += c.size();
-    std::vector<uint64_t> km;
-    km.reserve(tot);
-    for (auto &c : ref)
-        enumerate_kmers(c, k, km);
-    // parallel sort: chunks + merges
-    {
-        unsigned nt = std::max(1u, std::min<unsigned>(n_threads, 64));
-        size_t n = km.size();
-        if (nt > 1 && n > (1u << 20)) {
-            std::vector<size_t> cut(nt + 1);
-            for (unsigned i = 0; i <= nt; ++i)
-                cut[i] = n * i / nt;
-            std::vector<std::thread> th;
-            for (unsigned i = 0; i < nt; ++i)
-                th.emplace_back([&, i] { std::sort(km.begin() + cut[i], km.begin() + cut[i + 1]); });
-            for (auto &t : th)
-                t.join();
-            for (unsigned step = 1; step < nt; step *= 2) {
-                std::vector<std::thread> mt;
-                for (unsigned i = 0; i + step < nt; i += 2 * step)
-                    mt.emplace_back([&, i, step] {
-                        std::inplace_merge(km.begin() + cut[i], km.begin() + cut[i + step], km.begin() + cut[std::min(nt, i + 2 * step)]);
-                    });
-                for (auto &t : mt)
-                    t.join();
-            }
-        } else
-            std::sort(km.begin(), km.end());
-    }
-    // singletons only; adaptive mode also keeps the duplicated k-mers (remove_non_singletons, :664-704)
-    split_singletons(km, duplicates_out);
-    std::vector<uint64_t> spl;
-    for (auto &c : ref)
-        find_splitters_in_contig(c, k, segment_size, km, spl);
-    std::sort(spl.begin(), spl.end());
-    spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
-    if (singletons_out)
-        singletons_out->swap(km);
-    return spl;
 }
 
 // ===========================================================================
@@ -531,13 +484,46 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         std::vector<bytes_t> ref;
         std::string id;
         bytes_t c;
+        uint64_t tot = 0;
         while (fr.read_contig_raw(id, c)) {
             preprocess_raw_contig(c);
+            tot += c.size();
             ref.emplace_back(std::move(c));
             c.clear();
         }
-        auto spl = determine_splitters_host(ref, I.k, I.segment_size, nt, I.adaptive ? &I.ref_singletons : nullptr,
-                                            I.adaptive ? &I.ref_duplicates : nullptr);
+        // determine_splitters on the GPU: contigs go to HBM back to back, k-mers are enumerated, radix
+        // sorted and reduced to singletons there (include/agc_hip.h: agc_hip_determine_splitters_dev)
+        uint8_t *d_ref = nullptr;
+        if (!I.hip_ok(agc_hip_sample_buffer(I.hip, tot, &d_ref), "sample_buffer"))
+            return false;
+        std::vector<uint64_t> off(ref.size() + 1, 0);
+        for (size_t i = 0; i < ref.size(); ++i) {
+            if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size()), "copy_to_device"))
+                return false;
+            off[i + 1] = off[i] + ref[i].size();
+        }
+        std::vector<uint64_t> spl(std::max<uint64_t>(1024, tot / std::max(1u, I.segment_size) * 2 + 2 * ref.size() + 16));
+        std::vector<uint64_t> sorted_kmers(I.adaptive ? tot : 0);
+        uint64_t n_spl = 0, n_sorted = 0;
+        for (;;) {
+            int rc = agc_hip_determine_splitters_dev(I.hip, d_ref, off.data(), (uint32_t)ref.size(), I.k, I.segment_size, spl.size(), spl.data(),
+                                                     &n_spl, sorted_kmers.size(), I.adaptive ? sorted_kmers.data() : nullptr,
+                                                     I.adaptive ? &n_sorted : nullptr);
+            if (rc == AGC_HIP_ECAP && n_spl > spl.size()) {
+                spl.resize(n_spl);
+                continue;
+            }
+            if (!I.hip_ok(rc, "determine_splitters"))
+                return false;
+            break;
+        }
+        spl.resize(n_spl);
+        if (I.adaptive) {
+            // v_candidate_kmers (singletons) and v_duplicated_kmers (agc_compressor.cpp:493-497)
+            sorted_kmers.resize(n_sorted);
+            split_singletons(sorted_kmers, &I.ref_duplicates);
+            I.ref_singletons.swap(sorted_kmers);
+        }
         if (!SetSplitters(spl.data(), spl.size()))
             return false;
         if (I.verbosity > 1)

@@ -71,9 +71,4 @@ public:
     agc_hip_ctx *HipContext();
 };
 
-// reference preprocessing on the host (agc_compressor.cpp:428-563); contigs = symbol codes
-std::vector<uint64_t> determine_splitters_host(const std::vector<std::vector<uint8_t>> &ref_contigs, uint32_t k, uint32_t segment_size,
-                                               unsigned n_threads, std::vector<uint64_t> *singletons_out = nullptr,
-                                               std::vector<uint64_t> *duplicates_out = nullptr);
-
 } // namespace agc

@@ -82,6 +82,19 @@ int agc_hip_splitters_set(agc_hip_ctx *ctx, const uint64_t *h_kmers, uint64_t n)
 int agc_hip_splitters_insert(agc_hip_ctx *ctx, const uint64_t *h_kmers, uint64_t n);
 uint64_t agc_hip_splitters_count(const agc_hip_ctx *ctx);
 
+/* Replaces CAGCCompressor::determine_splitters (src/core/agc_compressor.cpp:428-563; enumerate_kmers
+ * :630-660, remove_non_singletons :664-704, find_splitters_in_contig :762-825) for reference contigs
+ * resident in HBM (absolute offsets < 2^32): canonical k-mers -> radix sort -> singletons -> in every
+ * contig the first singleton once >= segment_size symbols have passed since the previous splitter, and
+ * the right-most singleton of the tail.  h_splitters receives the sorted, unique splitters
+ * (AGC_HIP_ECAP + needed count if cap is too small).  When h_sorted_kmers is given (adaptive mode keeps
+ * v_candidate_kmers / v_duplicated_kmers, :493-497) it receives ALL canonical k-mers of the reference,
+ * sorted, duplicates included; the caller splits them into singletons and duplicated values. */
+int agc_hip_determine_splitters_dev(agc_hip_ctx *ctx, const uint8_t *d_codes, const uint64_t *h_ctg_off,
+                                    uint32_t n_ctg, uint32_t k, uint32_t segment_size,
+                                    uint64_t cap, uint64_t *h_splitters, uint64_t *h_n_splitters,
+                                    uint64_t sorted_cap, uint64_t *h_sorted_kmers, uint64_t *h_n_sorted);
+
 /* Replaces the loop body of CAGCCompressor::compress_contig
  * (src/core/agc_compressor.cpp:2007-2036) for a batch of contigs:
  * d_codes holds the contigs back to back, contig c = [h_ctg_off[c], h_ctg_off[c+1]).

@@ -92,3 +92,35 @@ def test_preprocess(hip_ctx, oracle):
     want = oracle.preprocess(body)
     assert n == want.size
     assert np.array_equal(d_out[:n].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("k,seg", [(31, 1000), (21, 500), (17, 3000), (32, 700)])
+def test_determine_splitters_matches_oracle(hip_ctx, oracle, k, seg):
+    """reference preprocessing on the GPU (agc_hip_determine_splitters_dev) vs the oracle's restatement of
+    determine_splitters: duplicated regions (non-singleton k-mers), N-runs, contigs shorter than k, a contig
+    that is one long repeat (no singleton at all)"""
+    import torch
+    rng = np.random.default_rng(200 + k)
+    a = synth.random_seq(rng, 40_000)
+    b = synth.random_seq(rng, 25_000)
+    b[5_000:9_000] = a[10_000:14_000]                       # shared region: those k-mers are not singletons
+    c = synth.mutate(rng, synth.random_seq(rng, 12_000), 0, n_runs=4, iupac=3)
+    d = np.tile(synth.random_seq(rng, 50), 100)             # pure repeat
+    e = synth.random_seq(rng, k - 1)                        # shorter than k
+    f = oracle.rev_comp(a[20_000:26_000])                   # reverse-complement copy: same canonical k-mers
+    contigs = [a, b, c, d, e, f]
+    off = np.zeros(len(contigs) + 1, np.uint64)
+    off[1:] = np.cumsum([x.size for x in contigs])
+    dev = torch.from_numpy(np.concatenate(contigs)).cuda()
+    got, srt = hip_ctx.determine_splitters_dev(dev.data_ptr(), off, k, seg, want_sorted=True)
+    want = oracle.determine_splitters(contigs, k, seg)
+    assert np.array_equal(got, want), (got.size, want.size)
+    assert want.size > 20
+    # the sorted k-mer list (adaptive mode) = all canonical k-mers of the reference
+    import ctypes as C
+    allk = []
+    for x in contigs:
+        buf = np.zeros(max(x.size, 1), np.uint64)
+        n = oracle.lib().agco_enumerate_kmers(x.ctypes.data_as(C.POINTER(C.c_uint8)), x.size, k, buf.ctypes.data_as(C.POINTER(C.c_uint64)))
+        allk.append(buf[:n])
+    assert np.array_equal(srt, np.sort(np.concatenate(allk)))
