@@ -27,6 +27,11 @@ int agc_cmp_create(void *h, const char *out_path, uint32_t pack_cardinality, uin
 
 int agc_cmp_set_splitters(void *h, const uint64_t *kmers, uint64_t n) { return ((CAGCCompressor *)h)->SetSplitters(kmers, n) ? 1 : 0; }
 
+int agc_cmp_set_reference_dev(void *h, const uint8_t *d_codes, const uint64_t *ctg_off, uint32_t n_ctg)
+{
+    return ((CAGCCompressor *)h)->SetReferenceDevice(d_codes, ctg_off, n_ctg) ? 1 : 0;
+}
+
 int agc_cmp_add_sample_files(void *h, uint32_t n, const char **sample_names, const char **paths, uint32_t n_threads)
 {
     std::vector<std::pair<std::string, std::string>> v;

@@ -423,6 +423,28 @@ const CompressorStats &CAGCCompressor::Stats() const { return p->st; }
 const char *CAGCCompressor::ZstdVersion() const { return p->zstd.h ? p->zstd.versionString() : ""; }
 agc_hip_ctx *CAGCCompressor::HipContext() { return p->hip; }
 
+// determine_splitters for a reference genome that already lives in HBM (bench.py)
+bool CAGCCompressor::SetReferenceDevice(const uint8_t *d_codes, const uint64_t *ctg_off, uint32_t n_ctg)
+{
+    Impl &I = *p;
+    if (!I.created || I.adaptive)
+        return false;
+    const uint64_t tot = n_ctg ? ctg_off[n_ctg] - ctg_off[0] : 0;
+    std::vector<uint64_t> spl(std::max<uint64_t>(1024, tot / std::max(1u, I.segment_size) * 2 + 2ull * n_ctg + 16));
+    uint64_t n_spl = 0;
+    for (;;) {
+        int rc = agc_hip_determine_splitters_dev(I.hip, d_codes, ctg_off, n_ctg, I.k, I.segment_size, spl.size(), spl.data(), &n_spl, 0, nullptr, nullptr);
+        if (rc == AGC_HIP_ECAP && n_spl > spl.size()) {
+            spl.resize(n_spl);
+            continue;
+        }
+        if (!I.hip_ok(rc, "determine_splitters"))
+            return false;
+        break;
+    }
+    return SetSplitters(spl.data(), n_spl);
+}
+
 bool CAGCCompressor::SetSplitters(const uint64_t *kmers, uint64_t n)
 {
     if (!p->created)

@@ -54,6 +54,8 @@ public:
 
     // replaces determine_splitters' result (agc_compressor.cpp:543-555) when no reference file is given
     bool SetSplitters(const uint64_t *kmers, uint64_t n);
+    // the same from a reference genome resident in HBM: runs determine_splitters on the GPU
+    bool SetReferenceDevice(const uint8_t *d_codes, const uint64_t *ctg_off, uint32_t n_ctg);
 
     // src/core/agc_compressor.cpp:2118-2270
     bool AddSampleFiles(const std::vector<std::pair<std::string, std::string>> &sample_file_names, uint32_t no_threads);

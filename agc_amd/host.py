@@ -33,6 +33,7 @@ def load():
     L.agc_cmp_create.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                  C.c_uint32, C.c_uint32, C.c_double]
     L.agc_cmp_set_splitters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64]
+    L.agc_cmp_set_reference_dev.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32]
     L.agc_cmp_add_sample_files.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32]
     L.agc_cmp_add_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_close.argtypes = [vp, C.c_uint32]
@@ -69,6 +70,12 @@ class Compressor:
         k = np.ascontiguousarray(kmers, dtype=np.uint64)
         if not self.L.agc_cmp_set_splitters(self.h, k.ctypes.data_as(C.POINTER(C.c_uint64)), k.size):
             raise RuntimeError("SetSplitters failed")
+
+    def set_reference_dev(self, d_codes, ctg_off):
+        """determine_splitters on the GPU for a reference genome resident in HBM"""
+        off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+        if not self.L.agc_cmp_set_reference_dev(self.h, d_codes, off.ctypes.data_as(C.POINTER(C.c_uint64)), off.size - 1):
+            raise RuntimeError("SetReferenceDevice failed (see stderr)")
 
     def add_sample_files(self, pairs, n_threads=8):
         n = len(pairs)

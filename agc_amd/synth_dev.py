@@ -4,7 +4,8 @@ A collection = one reference (contig lengths proportional to GRCh38 chr1-22,X,Y,
 i.i.d. ACGT) and samples = reference with independent per-base substitutions at rate d.
 Everything is generated directly in HBM as one byte per symbol (codes 0..3).
 
-Splitters: the reference picks, in every reference contig, the first SINGLETON k-mer seen
+Splitters: bench.py runs the real determine_splitters on the GPU (agc_hip_determine_splitters_dev);
+positional_splitters() below is the optional shortcut (--positional-splitters).  The reference picks, in every reference contig, the first SINGLETON k-mer seen
 once >= segment_size symbols have passed since the previous splitter, plus the right-most
 singleton of the tail (src/core/agc_compressor.cpp:762-825).  For an i.i.d. random
 reference of <= a few Gbp and k >= 25 essentially every k-mer is a singleton
