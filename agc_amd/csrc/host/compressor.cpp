@@ -4,6 +4,7 @@
 #include "../../../include/agc_hip.h"
 
 #include <chrono>
+#include <deque>
 #include <cmath>
 #include <iostream>
 #include <numeric>
@@ -44,6 +45,7 @@ struct Kmer {
 struct Contig {
     std::string sample, name;
     uint64_t off = 0, len = 0; // inside the batch's device buffer
+    uint32_t sample_idx = 0;   // position of its sample inside the speculation window (0 for single-sample batches)
 };
 
 struct Seg { // one segment as compress_contig cuts it (agc_compressor.cpp:2007-2048)
@@ -390,9 +392,12 @@ struct CAGCCompressor::Impl {
     }
 
     // -----------------------------------------------------------------------
-    bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data = nullptr);
+    // classifies all contigs (one or several consecutive samples) against the current state and commits the
+    // leading samples whose classification is certainly valid; n_committed = number of samples done
+    bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, uint32_t &n_committed);
     void finish_groups();
-    void run_jobs(std::vector<ZJob> &jobs);
+    void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
+    void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
     bytes_t enc_buf, fetch_buf; // grown, never shrunk
     // adaptive mode (-a): sorted singleton / duplicated k-mers of the reference genome
@@ -586,7 +591,7 @@ void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, byte
 }
 
 // add_to_archive / add_to_archive_tuples, segment.h:172-215; store_in_archive(ref) :218-255
-void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs)
+void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
 {
     double t0 = now();
     pool->parallel_for(jobs.size(), [&](size_t i, unsigned tid) {
@@ -618,12 +623,20 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs)
             j.meta = 0;
         }
     });
-    for (auto &j : jobs) {
+    st.t_zstd += now() - t0;
+    if (add_parts)
+        add_job_parts(jobs, 0, jobs.size());
+}
+
+// hands finished parts to the archive buffer, in job order (= insertion order inside every stream)
+void CAGCCompressor::Impl::add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to)
+{
+    for (size_t i = from; i < to; ++i) {
+        ZJob &j = jobs[i];
         st.zstd_in += j.data.size();
         st.zstd_out += j.out.size();
         ar.add_part_buffered(j.stream_id, std::move(j.out), j.meta);
     }
-    st.t_zstd += now() - t0;
 }
 
 // the tail of the registration token handling, agc_compressor.cpp:1136-1180
@@ -683,8 +696,10 @@ bool CAGCCompressor::Impl::find_new_splitters(const bytes_t &ctg, std::vector<ui
     return true;
 }
 
-bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data)
+bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data,
+                                         uint32_t &n_committed)
 {
+    n_committed = 0;
     const uint32_t n_ctg = (uint32_t)ctgs.size();
     double t0 = now();
 
@@ -1112,16 +1127,29 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             }
         }
     }
-    st.segments += placed.size();
 
-    // ---- register_segments (agc_compressor.cpp:954-971; agc_compressor.h:384-435) ----
+    // ---- speculation window: the contigs may belong to several consecutive samples that were
+    // all classified against the SAME state.  State changes only when a sample mints a new group, so the
+    // classification is valid for every sample up to and including the first one with a new item; later
+    // samples of the window are handed back to the caller (n_committed) and classified again.
+    const uint32_t n_samples = ctgs.empty() ? 1u : ctgs.back().sample_idx + 1;
+    uint32_t commit_upto = n_samples; // exclusive
+    for (const Placed &pl : placed)
+        if (pl.gid < 0 && ctgs[pl.ctg].sample_idx + 1 < commit_upto)
+            commit_upto = ctgs[pl.ctg].sample_idx + 1;
+    n_committed = commit_upto;
+
+    // ---- register_segments per sample (agc_compressor.cpp:954-971; agc_compressor.h:384-435) ----
     // order of CBufferedSegPart's lists and of the std::set of new parts: (sample name, contig name,
-    // part no) (agc_compressor.h:112-120, 157-164).  Contigs are ranked once, items sort on integers.
+    // part no) (agc_compressor.h:112-120, 157-164).  Contigs are ranked once, items sort on integers;
+    // samples keep their processing order (each one is a registration of its own).
     std::vector<uint32_t> ctg_rank(n_ctg);
     {
         std::vector<uint32_t> co(n_ctg);
         std::iota(co.begin(), co.end(), 0u);
         auto cless = [&](uint32_t x, uint32_t y) {
+            if (ctgs[x].sample_idx != ctgs[y].sample_idx)
+                return ctgs[x].sample_idx < ctgs[y].sample_idx;
             if (ctgs[x].sample != ctgs[y].sample)
                 return ctgs[x].sample < ctgs[y].sample;
             return ctgs[x].name < ctgs[y].name;
@@ -1134,18 +1162,22 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             ctg_rank[co[i]] = r;
         }
     }
-    std::vector<uint32_t> order(placed.size());
+    std::vector<uint32_t> order; // committed items only, in (sample, contig name, part) order
     {
-        std::vector<std::pair<uint64_t, uint32_t>> keyed(placed.size());
+        std::vector<std::pair<uint64_t, uint32_t>> keyed;
+        keyed.reserve(placed.size());
         for (uint32_t i = 0; i < placed.size(); ++i)
-            keyed[i] = {((uint64_t)ctg_rank[placed[i].ctg] << 32) | placed[i].part_no, i};
+            if (ctgs[placed[i].ctg].sample_idx < commit_upto)
+                keyed.push_back({((uint64_t)ctg_rank[placed[i].ctg] << 32) | placed[i].part_no, i});
         if (!std::is_sorted(keyed.begin(), keyed.end()))
             std::sort(keyed.begin(), keyed.end());
-        for (uint32_t i = 0; i < placed.size(); ++i)
+        order.resize(keyed.size());
+        for (size_t i = 0; i < keyed.size(); ++i)
             order[i] = keyed[i].second;
+        st.segments += order.size();
     }
-    const uint32_t first_new_gid = no_segments;
     {
+        // new group ids in that order (only the last committed sample can have new items)
         std::map<pk_t, uint32_t> m_kmers;
         uint32_t gid = no_segments;
         for (uint32_t idx : order)
@@ -1165,53 +1197,66 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         no_segments += no_new;
         st.new_groups += no_new;
     }
-    // per-group lists in sorted order
-    std::vector<std::vector<uint32_t>> lists; // index by a dense id of the groups touched
-    std::unordered_map<uint32_t, uint32_t> dense;
-    std::vector<uint32_t> dense_gid;
-    auto list_of = [&](uint32_t gid) -> std::vector<uint32_t> & {
-        auto it = dense.find(gid);
-        if (it == dense.end()) {
-            it = dense.emplace(gid, (uint32_t)lists.size()).first;
-            lists.emplace_back();
-            dense_gid.push_back(gid);
-        }
-        return lists[it->second];
+    // per sample: lists of items per group, raw groups by distribute_segments(0, 0, 16) on the sorted
+    // list of group 0 (agc_compressor.h:417-435)
+    struct SampleLists {
+        std::vector<uint32_t> gids;               // groups touched, in order of first appearance
+        std::vector<std::vector<uint32_t>> lists; // items per group, sorted
     };
+    std::vector<SampleLists> per_sample(commit_upto);
     {
-        // distribute_segments(0, 0, 16) on the sorted list of group 0 (agc_compressor.h:417-435)
-        std::vector<uint32_t> raw0;
-        for (uint32_t idx : order)
-            if (placed[idx].gid == 0)
-                raw0.push_back(idx);
-        const size_t n0 = raw0.size();
-        const size_t n_moved = n0 - (n0 + 15) / 16;
-        for (size_t j = 0; j < n0; ++j)
-            placed[raw0[j]].gid = j < n_moved ? (int32_t)(1 + (j % 15)) : 0;
-        for (uint32_t idx : order)
-            list_of((uint32_t)placed[idx].gid).push_back(idx);
+        size_t pos = 0;
+        for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
+            size_t end = pos;
+            while (end < order.size() && ctgs[placed[order[end]].ctg].sample_idx == sidx)
+                ++end;
+            std::vector<uint32_t> raw0;
+            for (size_t i = pos; i < end; ++i)
+                if (placed[order[i]].gid == 0)
+                    raw0.push_back(order[i]);
+            const size_t n0 = raw0.size();
+            const size_t n_moved = n0 - (n0 + 15) / 16;
+            for (size_t j = 0; j < n0; ++j)
+                placed[raw0[j]].gid = j < n_moved ? (int32_t)(1 + (j % 15)) : 0;
+            SampleLists &sl = per_sample[sidx];
+            std::unordered_map<uint32_t, uint32_t> dense;
+            for (size_t i = pos; i < end; ++i) {
+                const uint32_t gid = (uint32_t)placed[order[i]].gid;
+                auto it = dense.find(gid);
+                if (it == dense.end()) {
+                    it = dense.emplace(gid, (uint32_t)sl.lists.size()).first;
+                    sl.lists.emplace_back();
+                    sl.gids.push_back(gid);
+                }
+                sl.lists[it->second].push_back(order[i]);
+            }
+            pos = end;
+        }
     }
     st.t_register += now() - t0;
     t0 = now();
 
     // ---- store_segments (agc_compressor.cpp:974-1050) ----
-    // (a) new groups: their first item becomes the reference (segment.cpp:39-48)
+    // (a) what each item needs: new groups' first item becomes the reference (segment.cpp:39-48), raw
+    // groups keep the symbols, everything else is LZ-encoded -- decided per group across the committed samples
     std::vector<uint32_t> new_ref_items; // placed indices, one per new group with items
     std::vector<uint32_t> raw_items;
     std::vector<uint32_t> enc_items;
-    for (size_t li = 0; li < lists.size(); ++li) {
-        const uint32_t gid = dense_gid[li];
-        Group &g = groups[gid];
-        bool first = true;
-        for (uint32_t idx : lists[li]) {
-            if (gid < NO_RAW_GROUPS)
-                raw_items.push_back(idx);
-            else if (!g.exists && first)
-                new_ref_items.push_back(idx);
-            else
-                enc_items.push_back(idx);
-            first = false;
-        }
+    {
+        std::vector<uint8_t> will_exist(groups.size(), 0);
+        for (uint32_t sidx = 0; sidx < commit_upto; ++sidx)
+            for (size_t li = 0; li < per_sample[sidx].lists.size(); ++li) {
+                const uint32_t gid = per_sample[sidx].gids[li];
+                for (uint32_t idx : per_sample[sidx].lists[li]) {
+                    if (gid < NO_RAW_GROUPS)
+                        raw_items.push_back(idx);
+                    else if (!groups[gid].exists && !will_exist[gid]) {
+                        new_ref_items.push_back(idx);
+                        will_exist[gid] = 1;
+                    } else
+                        enc_items.push_back(idx);
+                }
+            }
     }
     // map_segments / terminators updates happen when a group is first stored (:1003-1028)
     for (uint32_t idx : new_ref_items) {
@@ -1280,7 +1325,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     }
     st.t_register += now() - t0;
     t0 = now();
-    // GPU: LZ-encode every other item against its group's reference (segment.cpp:50-58)
+    // GPU: LZ-encode every other item against its group's reference (segment.cpp:50-58) -- one batch for
+    // all committed samples
     bytes_t &enc = enc_buf;
     std::vector<uint64_t> enc_off(enc_items.size() + 1, 0);
     if (!enc_items.empty()) {
@@ -1316,7 +1362,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     st.t_encode += now() - t0;
     t0 = now();
 
-    // (b) per-group bookkeeping in list order: CSegment::add / add_raw (segment.cpp:14-80)
+    // (b) per sample, per group, in list order: CSegment::add / add_raw (segment.cpp:14-80); then the sample's
+    // zstd jobs, collection records and the end-of-registration steps
     std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size()), pos_enc(placed.size());
     for (uint32_t i = 0; i < new_ref_items.size(); ++i)
         pos_newref[new_ref_items[i]] = i;
@@ -1324,105 +1371,123 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         pos_raw[raw_items[i]] = i;
     for (uint32_t i = 0; i < enc_items.size(); ++i)
         pos_enc[enc_items[i]] = i;
-    std::vector<ZJob> jobs;
     std::vector<uint32_t> in_group_id(placed.size(), 0);
-    // groups are independent of each other (the reference runs them on all worker threads,
-    // agc_compressor.cpp:989-1050): chunks of lists go to the pool, their jobs are merged in list order
-    const size_t n_chunks = std::min<size_t>(lists.size(), (size_t)pool->size() * 8);
-    std::vector<std::vector<ZJob>> chunk_jobs(n_chunks);
-    pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
-    std::vector<ZJob> &jobs = chunk_jobs[ci];
-    const size_t li_begin = lists.size() * ci / n_chunks, li_end = lists.size() * (ci + 1) / n_chunks;
-    for (size_t li = li_begin; li < li_end; ++li) {
-        const uint32_t gid = dense_gid[li];
-        Group &g = groups[gid];
-        for (uint32_t idx : lists[li]) {
-            const Placed &pl = placed[idx];
-            uint32_t igid;
-            if (gid < NO_RAW_GROUPS) {
-                if (g.raw_off.size() == pack_cardinality)
-                    make_pack_job(jobs, g, g.raw_data, g.raw_off);
-                const uint32_t fi = (uint32_t)new_ref_items.size() + pos_raw[idx];
-                ++g.no_seqs;
-                Group::push(g.raw_data, g.raw_off, fetched.data() + fetched_off[fi], fetched_off[fi + 1] - fetched_off[fi]);
-                igid = g.no_seqs - 1;
-            } else if (!g.exists) {
-                g.exists = true;
-                const uint32_t fi = pos_newref[idx];
-                ZJob j;
-                j.stream_id = g.stream_ref;
-                j.kind = 0;
-                j.data.assign(fetched.begin() + fetched_off[fi], fetched.begin() + fetched_off[fi + 1]);
-                // repetitiveness probe with the reference's double arithmetic (segment.h:224-247)
-                double best_frac = 0.0;
-                for (uint32_t l = 0; l < 28; ++l) {
-                    const uint32_t cnt = lag_cnt[fi * 28 + l], cur = lag_cur[fi * 28 + l];
-                    double frac = 0.0;
-                    if (cur)
-                        frac = (double)cnt / cur;
-                    if (frac > best_frac) {
-                        best_frac = frac;
-                        if (best_frac >= 0.5)
-                            break;
-                    }
-                }
-                j.repetitive = !(best_frac < 0.5);
-                jobs.emplace_back(std::move(j));
-                g.ref_size = (uint64_t)pl.len + 1;
-                g.no_seqs = 1;
-                igid = 0;
-            } else {
-                if (g.lzp_off.size() == pack_cardinality)
-                    make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
-                const uint32_t ei = pos_enc[idx];
-                const uint8_t *dp = enc.data() + enc_off[ei];
-                const size_t dn = enc_off[ei + 1] - enc_off[ei];
-                if (dn == 0)
-                    igid = 0; // same sequence as the reference (segment.cpp:60-63)
-                else {
-                    const int f = Group::find(g.lzp_data, g.lzp_off, dp, dn);
-                    if (f >= 0)
-                        igid = g.no_seqs - (uint32_t)(g.lzp_off.size() - (size_t)f);
-                    else {
-                        Group::push(g.lzp_data, g.lzp_off, dp, dn);
+    // contig descriptors of the collection (agc_compressor.cpp:1038-1049)
+    std::vector<CollectionV3::ContigDesc *> cd(n_ctg, nullptr);
+    for (uint32_t c = 0; c < n_ctg; ++c) {
+        if (ctgs[c].sample_idx >= commit_upto)
+            continue;
+        std::string stored = ctgs[c].sample.empty() ? CollectionV3::extract_contig_name(ctgs[c].name) : ctgs[c].sample;
+        CollectionV3::SampleDesc &sd = coll.sample_by_name(stored);
+        for (auto &x : sd.contigs)
+            if (x.name == ctgs[c].name) {
+                cd[c] = &x;
+                break;
+            }
+    }
+    // zstd jobs of all committed samples are compressed together (they are independent); their parts and
+    // the end-of-registration steps are then replayed sample by sample, so the archive is laid out exactly
+    // as if every sample had been finished before the next one started
+    std::vector<ZJob> all_jobs;
+    std::vector<size_t> jobs_end(commit_upto, 0);
+    for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
+        SampleLists &sl = per_sample[sidx];
+        std::vector<ZJob> jobs;
+        auto book = [&](size_t li_begin, size_t li_end, std::vector<ZJob> &jobs) {
+            for (size_t li = li_begin; li < li_end; ++li) {
+                const uint32_t gid = sl.gids[li];
+                Group &g = groups[gid];
+                for (uint32_t idx : sl.lists[li]) {
+                    const Placed &pl = placed[idx];
+                    uint32_t igid;
+                    if (gid < NO_RAW_GROUPS) {
+                        if (g.raw_off.size() == pack_cardinality)
+                            make_pack_job(jobs, g, g.raw_data, g.raw_off);
+                        const uint32_t fi = (uint32_t)new_ref_items.size() + pos_raw[idx];
                         ++g.no_seqs;
+                        Group::push(g.raw_data, g.raw_off, fetched.data() + fetched_off[fi], fetched_off[fi + 1] - fetched_off[fi]);
                         igid = g.no_seqs - 1;
+                    } else if (!g.exists) {
+                        g.exists = true;
+                        const uint32_t fi = pos_newref[idx];
+                        ZJob j;
+                        j.stream_id = g.stream_ref;
+                        j.kind = 0;
+                        j.data.assign(fetched.begin() + fetched_off[fi], fetched.begin() + fetched_off[fi + 1]);
+                        // repetitiveness probe with the reference's double arithmetic (segment.h:224-247)
+                        double best_frac = 0.0;
+                        for (uint32_t l = 0; l < 28; ++l) {
+                            const uint32_t cnt = lag_cnt[fi * 28 + l], cur = lag_cur[fi * 28 + l];
+                            double frac = 0.0;
+                            if (cur)
+                                frac = (double)cnt / cur;
+                            if (frac > best_frac) {
+                                best_frac = frac;
+                                if (best_frac >= 0.5)
+                                    break;
+                            }
+                        }
+                        j.repetitive = !(best_frac < 0.5);
+                        jobs.emplace_back(std::move(j));
+                        g.ref_size = (uint64_t)pl.len + 1;
+                        g.no_seqs = 1;
+                        igid = 0;
+                    } else {
+                        if (g.lzp_off.size() == pack_cardinality)
+                            make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
+                        const uint32_t ei = pos_enc[idx];
+                        const uint8_t *dp = enc.data() + enc_off[ei];
+                        const size_t dn = enc_off[ei + 1] - enc_off[ei];
+                        if (dn == 0)
+                            igid = 0; // same sequence as the reference (segment.cpp:60-63)
+                        else {
+                            const int f = Group::find(g.lzp_data, g.lzp_off, dp, dn);
+                            if (f >= 0)
+                                igid = g.no_seqs - (uint32_t)(g.lzp_off.size() - (size_t)f);
+                            else {
+                                Group::push(g.lzp_data, g.lzp_off, dp, dn);
+                                ++g.no_seqs;
+                                igid = g.no_seqs - 1;
+                            }
+                        }
                     }
+                    in_group_id[idx] = igid;
                 }
             }
-            in_group_id[idx] = igid;
-        }
-    }
-    });
-    for (auto &cj : chunk_jobs)
-        for (auto &j : cj)
-            jobs.emplace_back(std::move(j));
-    // collection records (agc_compressor.cpp:1038-1049)
-    {
-        std::string cur_sample;
-        CollectionV3::SampleDesc *sd = nullptr;
-        std::vector<CollectionV3::ContigDesc *> cd(n_ctg, nullptr);
-        for (uint32_t c = 0; c < n_ctg; ++c) {
-            std::string stored = ctgs[c].sample.empty() ? CollectionV3::extract_contig_name(ctgs[c].name) : ctgs[c].sample;
-            sd = &coll.sample_by_name(stored);
-            for (auto &x : sd->contigs)
-                if (x.name == ctgs[c].name) {
-                    cd[c] = &x;
-                    break;
-                }
-        }
-        for (uint32_t idx = 0; idx < placed.size(); ++idx) {
-            const Placed &pl = placed[idx];
-            auto *c = cd[pl.ctg];
-            if (!c)
-                continue;
-            if (pl.part_no >= c->segments.size())
-                c->segments.resize((size_t)pl.part_no + 1);
-            c->segments[pl.part_no] = {(uint32_t)pl.gid, in_group_id[idx], pl.len, pl.rc};
-        }
+        };
+        // groups are independent of each other (the reference runs them on all worker threads,
+        // agc_compressor.cpp:989-1050): big samples go to the pool in chunks, jobs merged in list order
+        if (sl.lists.size() >= 4096) {
+            const size_t n_chunks = std::min<size_t>(sl.lists.size(), (size_t)pool->size() * 8);
+            std::vector<std::vector<ZJob>> chunk_jobs(n_chunks);
+            pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
+                book(sl.lists.size() * ci / n_chunks, sl.lists.size() * (ci + 1) / n_chunks, chunk_jobs[ci]);
+            });
+            for (auto &cj : chunk_jobs)
+                for (auto &j : cj)
+                    jobs.emplace_back(std::move(j));
+        } else
+            book(0, sl.lists.size(), jobs);
+        for (size_t li = 0; li < sl.lists.size(); ++li)
+            for (uint32_t idx : sl.lists[li]) {
+                const Placed &pl = placed[idx];
+                auto *c = cd[pl.ctg];
+                if (!c)
+                    continue;
+                if (pl.part_no >= c->segments.size())
+                    c->segments.resize((size_t)pl.part_no + 1);
+                c->segments[pl.part_no] = {(uint32_t)pl.gid, in_group_id[idx], pl.len, pl.rc};
+            }
+        for (auto &j : jobs)
+            all_jobs.emplace_back(std::move(j));
+        jobs_end[sidx] = all_jobs.size();
     }
     st.t_store += now() - t0;
-    run_jobs(jobs);
+    run_jobs(all_jobs, false);
+    for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
+        add_job_parts(all_jobs, sidx ? jobs_end[sidx - 1] : 0, jobs_end[sidx]);
+        after_registration();
+    }
     return true;
 }
 
@@ -1468,10 +1533,8 @@ bool CAGCCompressor::AddSampleDevice(const std::string &sample_name, const std::
         I.err("duplicate contigs inside a device-resident sample are not supported");
         return false;
     }
-    if (!I.process_batch(ctgs, d_codes))
-        return false;
-    I.after_registration();
-    return true;
+    uint32_t n_done = 0;
+    return I.process_batch(ctgs, d_codes, nullptr, n_done);
 }
 
 bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std::string>> &files, uint32_t no_threads)
@@ -1486,34 +1549,79 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     if (I.concatenated)
         I.cnt_contigs_in_sample = I.processed_samples % I.pack_cardinality;
 
-    std::vector<Contig> batch;
-    std::vector<bytes_t> batch_data;
-    auto flush_batch = [&]() -> bool {
-        // upload the batch's contigs back to back and run the registration cycle
+    // Registration batches read from the files but not committed yet.  In the plain mode one batch = one
+    // sample file and several consecutive batches may be classified together (speculation window, see
+    // process_batch); in -c mode a batch = pack_cardinality contigs (windows work the same way), in -a mode the window is one batch.
+    struct Pending {
+        std::vector<Contig> ctgs;
+        std::vector<bytes_t> data;
+        uint64_t bytes = 0;
+    };
+    std::deque<Pending> pending;
+    uint64_t pending_bytes = 0;
+    const uint64_t WINDOW_BYTES = 64ull << 20;
+    const uint32_t WINDOW_MAX = I.adaptive ? 1u : 256u; // new splitters change later scans: no speculation in -a mode
+    uint32_t window = 1; // grows while whole windows commit, shrinks to what did commit otherwise
+
+    auto run_window = [&]() -> bool {
+        // batch = the first `window` pending registrations (at least one)
+        const uint32_t nb = (uint32_t)std::min<size_t>(pending.size(), window);
+        std::vector<Contig> batch;
+        std::vector<bytes_t> batch_data;
         uint64_t tot = 0;
-        for (auto &d : batch_data)
-            tot += d.size();
+        for (uint32_t b = 0; b < nb; ++b)
+            tot += pending[b].bytes;
         uint8_t *d_base = nullptr;
         double t0 = now();
         if (!I.hip_ok(agc_hip_sample_buffer(I.hip, tot, &d_base), "sample_buffer"))
             return false;
         uint64_t o = 0;
-        for (size_t c = 0; c < batch.size(); ++c) {
-            batch[c].off = o;
-            batch[c].len = batch_data[c].size();
-            if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_base + o, batch_data[c].data(), batch_data[c].size()), "copy_to_device"))
-                return false;
-            o += batch_data[c].size();
-        }
+        for (uint32_t b = 0; b < nb; ++b)
+            for (size_t c = 0; c < pending[b].ctgs.size(); ++c) {
+                Contig ct = pending[b].ctgs[c];
+                ct.sample_idx = b;
+                ct.off = o;
+                ct.len = pending[b].data[c].size();
+                if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_base + o, pending[b].data[c].data(), ct.len), "copy_to_device"))
+                    return false;
+                o += ct.len;
+                batch.push_back(ct);
+                if (I.adaptive)
+                    batch_data.push_back(pending[b].data[c]); // new splitters are mined from the host copy
+            }
         I.st.t_io += now() - t0;
-        bool ok = I.process_batch(batch, d_base, &batch_data);
-        batch.clear();
-        batch_data.clear();
-        if (ok)
-            I.after_registration();
-        return ok;
+        uint32_t n_done = 0;
+        if (!I.process_batch(batch, d_base, I.adaptive ? &batch_data : nullptr, n_done))
+            return false;
+        if (nb == 0) // an empty registration (the reference's trailing token in -c mode)
+            return true;
+        if (n_done == nb)
+            window = std::min(WINDOW_MAX, window * 2);
+        else
+            window = std::max(1u, n_done);
+        for (uint32_t b = 0; b < n_done; ++b) {
+            pending_bytes -= pending.front().bytes;
+            pending.pop_front();
+        }
+        return true;
+    };
+    auto push_batch = [&](Pending &&pb) -> bool {
+        pending_bytes += pb.bytes;
+        pending.emplace_back(std::move(pb));
+        // run as soon as a full window is available (or the read-ahead budget is used up)
+        while (!pending.empty() && (pending.size() >= window || pending_bytes >= WINDOW_BYTES))
+            if (!run_window())
+                return false;
+        return true;
+    };
+    auto drain = [&]() -> bool {
+        while (!pending.empty())
+            if (!run_window())
+                return false;
+        return true;
     };
 
+    Pending cur;
     for (auto &sf : files) {
         I.coll.reset_prev_sample_name();
         FastaReader fr;
@@ -1534,14 +1642,16 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
                 Contig ct;
                 ct.sample = sname;
                 ct.name = id;
-                batch.push_back(ct);
-                batch_data.emplace_back(std::move(contig));
+                cur.ctgs.push_back(ct);
+                cur.bytes += contig.size();
+                cur.data.emplace_back(std::move(contig));
                 contig.clear();
                 any_added = true;
                 if (I.concatenated && ++I.cnt_contigs_in_sample >= I.pack_cardinality) {
                     I.st.t_io += now() - t0;
-                    if (!flush_batch())
+                    if (!push_batch(std::move(cur)))
                         return false;
+                    cur = Pending();
                     t0 = now();
                     I.cnt_contigs_in_sample = 0;
                 }
@@ -1553,17 +1663,22 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
             I.err("Warning: Pair sample_name:file_path " + sf.first + ":" + sf.second + " contains no contigs and will not be included in the archive!");
         if (!any_added)
             I.err("Warning: Pair sample_name:file_path " + sf.first + ":" + sf.second + " contains only contigs already present in the archive!");
-        if (!I.concatenated && any_added)
-            if (!flush_batch())
+        if (!I.concatenated && any_added) {
+            if (!push_batch(std::move(cur)))
                 return false;
+            cur = Pending();
+        }
     }
     if (I.concatenated) {
         // the reference always sends one more registration token at the end (:2231-2238)
-        if (!flush_batch())
+        if (!push_batch(std::move(cur)))
+            return false;
+        if (!drain())
             return false;
         I.cnt_contigs_in_sample = 0;
         I.processed_samples = (uint32_t)I.coll.no_samples();
-    }
+    } else if (!drain())
+        return false;
     if (I.processed_samples % I.pack_cardinality != 0)
         I.coll.store_contig_batch((I.processed_samples / I.pack_cardinality) * I.pack_cardinality, I.processed_samples);
     I.ar.flush_out_buffers();
