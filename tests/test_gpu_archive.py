@@ -111,3 +111,38 @@ def test_gz_input_and_file_list(tmp_path):
     r = subprocess.run([AGC_AMD, "create"] + args + ["-i", str(lst), "-o", out, files[0]], capture_output=True, text=True, timeout=300)
     assert os.path.exists(out), r.stderr
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD["syn_shuffled"]["sha256"]
+
+
+@pytest.mark.parametrize("concat", [False, True])
+def test_baseline_config1_full_size(tmp_path, concat):
+    """BASELINE.json configs[1] at its full size: 1000 genomes x 30 kb, 1 % SNPs from one reference, default
+    parameters -- one file per genome, and the same collection as one concatenated file (-c).  Exercises the
+    speculation window (hundreds of registrations classified per GPU pass).  Byte-for-byte against the
+    reference CLI (needs the prebuilt oracle/_ref/agc)."""
+    if not os.path.exists(REF_AGC):
+        pytest.skip("oracle/_ref/agc not prebuilt")
+    import numpy as np
+    from agc_amd import agc_container, build, synth
+    build.build_host()
+    rng = np.random.default_rng(2)
+    ref = synth.random_seq(rng, 30_000)
+    genomes = [ref] + [synth.mutate(rng, ref, 0.01) for _ in range(999)]
+    d = tmp_path / "in"
+    d.mkdir()
+    if concat:
+        files = [str(d / "ref.fa"), str(d / "all.fa")]
+        synth.to_fasta(files[0], [genomes[0]], ["MN000000.1 synthetic genome 0"])
+        synth.to_fasta(files[1], genomes[1:], [f"MN{i:06d}.1 synthetic genome {i}" for i in range(1, 1000)])
+    else:
+        files = []
+        for i, g in enumerate(genomes):
+            fn = str(d / f"g{i:04d}.fa")
+            synth.to_fasta(fn, [g], [f"MN{i:06d}.1 synthetic genome {i}"])
+            files.append(fn)
+    args = ["-c"] if concat else []
+    want_fn = str(tmp_path / "ref.agc")
+    subprocess.run([REF_AGC, "create", "-t", "8"] + args + ["-o", want_fn] + files, check=True, capture_output=True, timeout=600)
+    want = open(want_fn, "rb").read()
+    got = _run_amd(args, files, str(tmp_path / "amd.agc"))
+    if got != want:
+        pytest.fail("\n".join(agc_container.diff(want, got)))
