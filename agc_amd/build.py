@@ -33,13 +33,29 @@ def build(force=False, verbose=False):
 HOST = os.path.join(CSRC, "host")
 HOST_LIB = os.path.join(HERE, "libagc_host.so")
 HOST_BIN = os.path.join(HERE, "bin", "agc_amd")
-HOST_SOURCES = ["compressor.cpp", "compressor.h", "host_support.h", "capi_host.cpp", "main.cpp"]
+HOST_SOURCES = ["compressor.cpp", "compressor.h", "host_support.h", "capi_host.cpp", "main.cpp", "reader.cpp", "reader.h",
+                "capi_read.cpp"]
+READ_LIB = os.path.join(HERE, "libagc_read.so")
+
+
+def build_read(force=False, verbose=False):
+    """g++ for the read side (include/agc_read.h): libagc_read.so -- host only, no HIP dependency."""
+    srcs = [os.path.join(HOST, s) for s in ("reader.cpp", "capi_read.cpp")]
+    deps = srcs + [os.path.join(HOST, "reader.h"), os.path.join(HERE, "..", "include", "agc_read.h")]
+    if not force and os.path.exists(READ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(READ_LIB) for d in deps):
+        return READ_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return READ_LIB
 
 
 def build_host(force=False, verbose=False):
     """g++ for the host-side compressor (C++17): libagc_host.so (links libagc_hip.so by $ORIGIN rpath)
     and the agc-compatible CLI agc_amd/bin/agc_amd.  zstd is dlopen'ed at run time."""
     build()
+    build_read(force, verbose)
     deps = [os.path.join(HOST, s) for s in HOST_SOURCES] + [LIB]
     stale = force or not os.path.exists(HOST_LIB) or not os.path.exists(HOST_BIN) or \
         any(os.path.getmtime(d) > min(os.path.getmtime(HOST_LIB), os.path.getmtime(HOST_BIN)) for d in deps)
@@ -50,7 +66,7 @@ def build_host(force=False, verbose=False):
     common = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
     cmd1 = common + ["-shared", os.path.join(HOST, "compressor.cpp"), os.path.join(HOST, "capi_host.cpp"), "-o", HOST_LIB,
                      "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"]
-    cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
+    cmd2 = common + [os.path.join(HOST, "main.cpp"), os.path.join(HOST, "reader.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
                      "-Wl,-rpath,$ORIGIN/..", "-lz", "-ldl"]
     for cmd in (cmd1, cmd2):
         if verbose:

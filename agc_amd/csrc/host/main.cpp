@@ -1,7 +1,9 @@
 // main.cpp -- `agc_amd create`: command-line compatible with `agc create`
-// (src/app/main.cpp:76-122, src/app/application.cpp:125-187, application.h:63-71).
+// (src/app/main.cpp:76-122, src/app/application.cpp:125-187, application.h:63-71), plus the read-side
+// commands getcol / getset / getctg / listref / listset / listctg (src/app/main.cpp:171-368) on the host decoder.
 // Exit code 0 always, messages on stderr, as the reference.
 #include "compressor.h"
+#include "reader.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +34,128 @@ void usage()
                  "   -s <int>       - expected segment size (default: 60000; min: 100; max: 1000000)\n"
                  "   -t <int>       - no of threads\n"
                  "   -v <int>       - verbosity level (default: 0; min: 0; max: 2)\n"
-                 "   -g <int>       - HIP device ordinal (default: 0)\n";
+                 "   -g <int>       - HIP device ordinal (default: 0)\n"
+                 "       agc_amd getcol  [-l <line>] [-o <dir>] [-n] <in.agc>\n"
+                 "       agc_amd getset  [-l <line>] [-o <file>] <in.agc> <sample> [<sample> ...]\n"
+                 "       agc_amd getctg  [-l <line>] [-o <file>] <in.agc> <contig[@sample][:from-to]> ...\n"
+                 "       agc_amd listref|listset [-o <file>] <in.agc>\n"
+                 "       agc_amd listctg [-o <file>] <in.agc> <sample> [<sample> ...]\n";
+}
+
+bool write_out(const std::string &name, const std::string &data, bool append = false)
+{
+    if (name.empty()) {
+        fwrite(data.data(), 1, data.size(), stdout);
+        return true;
+    }
+    FILE *f = fopen(name.c_str(), append ? "ab" : "wb");
+    if (!f) {
+        std::cerr << "Cannot open output file " << name << std::endl;
+        return false;
+    }
+    fwrite(data.data(), 1, data.size(), f);
+    fclose(f);
+    return true;
+}
+
+// read-side commands; option letters as in application.cpp:190-583 (-g gzip, -p, -s, -t, -v are accepted and ignored)
+int read_command(const std::string &mode, int argc, char **argv)
+{
+    uint32_t line_length = 80;
+    std::string out;
+    bool no_ref = false;
+    int i = 2;
+    for (; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a.size() < 2 || a[0] != '-')
+            break;
+        auto val = [&]() -> const char * {
+            if (a.size() > 2)
+                return argv[i] + 2;
+            return i + 1 < argc ? argv[++i] : "";
+        };
+        switch (a[1]) {
+        case 'l': line_length = clampv<uint32_t>((uint32_t)atoi(val()), 40, 2000000000u); break;
+        case 'o': out = val(); break;
+        case 'g':
+        case 't':
+        case 'v': (void)val(); break;
+        case 'n': no_ref = true; break;
+        default: break;
+        }
+    }
+    if (i >= argc) {
+        std::cerr << "No archive name\n";
+        return 0;
+    }
+    agc::CAGCFile f;
+    if (!f.Open(argv[i])) {
+        std::cerr << "Cannot open archive " << argv[i] << std::endl;
+        return 0;
+    }
+    std::vector<std::string> args(argv + i + 1, argv + argc);
+    std::string txt;
+    if (mode == "listref") {
+        f.GetReferenceSample(txt);
+        write_out(out, txt);
+    } else if (mode == "listset") {
+        std::vector<std::string> v;
+        f.ListSample(v);
+        for (auto &s : v)
+            txt += s + "\n";
+        write_out(out, txt);
+    } else if (mode == "listctg") {
+        if (args.empty())
+            std::cerr << "No sample name\n";
+        for (auto &sn : args) {
+            txt += sn + "\n";
+            std::vector<std::string> v;
+            f.ListCtg(sn, v);
+            for (auto &c : v)
+                txt += "   " + c + "\n";
+        }
+        write_out(out, txt);
+    } else if (mode == "getset") {
+        if (args.empty())
+            std::cerr << "No sample name\n";
+        for (auto &sn : args) {
+            std::string one;
+            if (!f.GetSampleFasta(sn, one, line_length)) {
+                std::cerr << "There is no sample " << sn << std::endl;
+                return 0;
+            }
+            txt += one;
+        }
+        write_out(out, txt);
+    } else if (mode == "getctg") {
+        if (args.empty())
+            std::cerr << "No contig name\n";
+        for (auto &q : args) {
+            std::string err;
+            if (!f.GetContigFasta(q, txt, line_length, err)) {
+                std::cerr << err << std::endl;
+                return 0;
+            }
+        }
+        write_out(out, txt);
+    } else if (mode == "getcol") {
+        if (!out.empty() && !std::filesystem::is_directory(out)) {
+            std::cerr << "Path must point to an existing directory\n";
+            return 0;
+        }
+        std::string ref;
+        f.GetReferenceSample(ref);
+        std::vector<std::string> v;
+        f.ListSampleStored(v);
+        for (size_t j = no_ref ? 1 : 0; j < v.size(); ++j) {
+            std::string one;
+            if (!f.GetSampleFasta(v[j], one, line_length))
+                return 0;
+            write_out(out.empty() ? out : (std::filesystem::path(out) / (v[j] + ".fa")).string(), one);
+        }
+    }
+    f.Close();
+    return 0;
 }
 
 // application.cpp:604-630
@@ -60,6 +183,12 @@ void remove_common_suffixes(std::string &s)
 
 int main(int argc, char **argv)
 {
+    if (argc >= 2) {
+        const std::string mode = argv[1];
+        for (const char *m : {"getcol", "getset", "getctg", "listref", "listset", "listctg"})
+            if (mode == m)
+                return read_command(mode, argc, argv);
+    }
     if (argc < 2 || std::string(argv[1]) != "create") {
         usage();
         return 0;
