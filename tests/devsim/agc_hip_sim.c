@@ -1,0 +1,394 @@
+/*
+ * agc_hip_sim.c -- a CPU stand-in for the device behind include/agc_hip.h.
+ *
+ * TEST INFRASTRUCTURE ONLY (tests/devsim/).  It implements the C ABI of the HIP library on top of the
+ * CPU oracle (oracle/agc_oracle.c) so that the HOST side of the create path -- agc_amd/csrc/host/:
+ * registration order, group bookkeeping, pack/zstd streams, collection metadata, container -- can be
+ * exercised by the `-m "not gpu"` tests on a machine without a GPU: the host sources are compiled
+ * unchanged and linked against this file instead of libagc_hip.so, into tests/devsim/_build/.
+ * Nothing under agc_amd/ builds, links or loads it; agc_amd.build never produces it; the product
+ * libraries keep failing with AGC_HIP_ENODEV without a HIP device.  "Device" pointers here are plain
+ * host pointers.  It is also not a performance statement of any kind.
+ *
+ * The ABI contracts restated here are the ones written in include/agc_hip.h; the algorithms are the
+ * oracle's (each cites the reference file:line there).  The split-point arithmetic follows
+ * src/core/agc_compressor.cpp:1538-1617 directly.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/agc_hip.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+/* oracle entry points (oracle/agc_oracle.c) */
+void agco_rev_comp(const u8 *src, size_t n, u8 *dst);
+size_t agco_scan_contig(const u8 *ctg, size_t n, u32 k, const u64 *spl, size_t n_spl, size_t cap, u64 *seg_start, u64 *seg_len,
+                        u64 *front_dir, u64 *front_rc, u8 *front_full, u64 *back_dir, u64 *back_rc, u8 *back_full);
+size_t agco_enumerate_kmers(const u8 *ctg, size_t n, u32 k, u64 *out);
+size_t agco_find_splitters_in_contig(const u8 *ctg, size_t n, u32 k, u64 segment_size, const u64 *sing, size_t n_sing, u64 *out);
+void *agco_lz_create(const u8 *ref, u32 n, u32 min_match_len);
+void agco_lz_free(void *h);
+size_t agco_lz_encode(void *h, const u8 *text, u32 n, u8 *out);
+u32 agco_lz_estimate(void *h, const u8 *text, u32 n, u32 bound, u32 *peak);
+void agco_lz_cost_vector(void *h, const u8 *text, u32 n, int prefix_costs, u32 *costs);
+void agco_ref_lag_counts(const u8 *data, size_t n, u32 *cnt28, u32 *cur28);
+
+struct agc_hip_ctx {
+    char err[256];
+    u8 *sample;
+    u64 sample_cap;
+    u64 *spl; /* sorted */
+    u64 n_spl;
+    void **lz; /* by gid */
+    u32 n_lz;
+};
+
+static int cmp_u64(const void *a, const void *b)
+{
+    u64 x = *(const u64 *)a, y = *(const u64 *)b;
+    return x < y ? -1 : x > y;
+}
+
+static size_t sort_unique(u64 *v, size_t n)
+{
+    qsort(v, n, sizeof(u64), cmp_u64);
+    size_t o = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (!o || v[o - 1] != v[i])
+            v[o++] = v[i];
+    return o;
+}
+
+static int fail(agc_hip_ctx *c, int code, const char *msg)
+{
+    if (c)
+        snprintf(c->err, sizeof c->err, "devsim: %s", msg);
+    return code;
+}
+
+/* slice as the kernels read it: reverse-complemented when rc */
+static u8 *slice(const u8 *base, u64 off, u32 len, int rc)
+{
+    u8 *t = (u8 *)malloc((size_t)len + 64);
+    if (rc)
+        agco_rev_comp(base + off, len, t);
+    else
+        memcpy(t, base + off, len);
+    return t;
+}
+
+int agc_hip_create(agc_hip_ctx **out, int device)
+{
+    (void)device;
+    if (!out)
+        return AGC_HIP_EINVAL;
+    *out = (agc_hip_ctx *)calloc(1, sizeof(agc_hip_ctx));
+    return *out ? AGC_HIP_OK : AGC_HIP_ENOMEM;
+}
+
+void agc_hip_destroy(agc_hip_ctx *c)
+{
+    if (!c)
+        return;
+    for (u32 i = 0; i < c->n_lz; ++i)
+        agco_lz_free(c->lz[i]);
+    free(c->lz);
+    free(c->spl);
+    free(c->sample);
+    free(c);
+}
+
+const char *agc_hip_last_error(const agc_hip_ctx *c) { return c ? c->err : "no context"; }
+uint32_t agc_hip_abi_version(void) { return 0x5157u; /* not the product's */ }
+int agc_hip_sync(agc_hip_ctx *c) { return c ? AGC_HIP_OK : AGC_HIP_EINVAL; }
+int agc_hip_timing_enable(agc_hip_ctx *c, int on) { (void)c; (void)on; return AGC_HIP_OK; }
+int agc_hip_timing_reset(agc_hip_ctx *c) { (void)c; return AGC_HIP_OK; }
+int agc_hip_timing_get(agc_hip_ctx *c, int which, double *ms, uint64_t *launches)
+{
+    (void)c; (void)which;
+    if (ms) *ms = 0;
+    if (launches) *launches = 0;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_sample_buffer(agc_hip_ctx *c, uint64_t bytes, uint8_t **d_ptr)
+{
+    if (!c || !d_ptr)
+        return AGC_HIP_EINVAL;
+    if (bytes + 4096 > c->sample_cap) {
+        free(c->sample);
+        c->sample_cap = bytes + bytes / 4 + 4096;
+        c->sample = (u8 *)malloc(c->sample_cap);
+        if (!c->sample)
+            return fail(c, AGC_HIP_ENOMEM, "sample buffer");
+    }
+    *d_ptr = c->sample;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_copy_to_device(agc_hip_ctx *c, uint8_t *d_dst, const uint8_t *h_src, uint64_t n)
+{
+    if (!c || (n && (!d_dst || !h_src)))
+        return AGC_HIP_EINVAL;
+    memcpy(d_dst, h_src, n);
+    return AGC_HIP_OK;
+}
+
+int agc_hip_splitters_set(agc_hip_ctx *c, const uint64_t *h, uint64_t n)
+{
+    if (!c || (n && !h))
+        return AGC_HIP_EINVAL;
+    free(c->spl);
+    c->spl = (u64 *)malloc((n + 1) * sizeof(u64));
+    memcpy(c->spl, h, n * sizeof(u64));
+    c->n_spl = sort_unique(c->spl, n);
+    return AGC_HIP_OK;
+}
+
+int agc_hip_splitters_insert(agc_hip_ctx *c, const uint64_t *h, uint64_t n)
+{
+    if (!c || (n && !h))
+        return AGC_HIP_EINVAL;
+    c->spl = (u64 *)realloc(c->spl, (c->n_spl + n + 1) * sizeof(u64));
+    memcpy(c->spl + c->n_spl, h, n * sizeof(u64));
+    c->n_spl = sort_unique(c->spl, c->n_spl + n);
+    return AGC_HIP_OK;
+}
+
+uint64_t agc_hip_splitters_count(const agc_hip_ctx *c) { return c ? c->n_spl : 0; }
+
+int agc_hip_determine_splitters_dev(agc_hip_ctx *c, const uint8_t *d, const uint64_t *off, uint32_t n_ctg, uint32_t k, uint32_t segment_size,
+                                    uint64_t cap, uint64_t *h_spl, uint64_t *h_n_spl, uint64_t sorted_cap, uint64_t *h_sorted,
+                                    uint64_t *h_n_sorted)
+{
+    if (!c || !h_n_spl || (n_ctg && (!d || !off)))
+        return AGC_HIP_EINVAL;
+    const u64 tot = n_ctg ? off[n_ctg] - off[0] : 0;
+    u64 *all = (u64 *)malloc((tot + 1) * sizeof(u64));
+    size_t n_all = 0;
+    for (u32 i = 0; i < n_ctg; ++i)
+        n_all += agco_enumerate_kmers(d + off[i], off[i + 1] - off[i], k, all + n_all);
+    qsort(all, n_all, sizeof(u64), cmp_u64);
+    if (h_sorted) {
+        if (h_n_sorted)
+            *h_n_sorted = n_all;
+        if (n_all > sorted_cap) {
+            free(all);
+            return fail(c, AGC_HIP_ECAP, "sorted k-mer buffer");
+        }
+        memcpy(h_sorted, all, n_all * sizeof(u64));
+    }
+    u64 *sing = (u64 *)malloc((n_all + 1) * sizeof(u64));
+    size_t n_sing = 0;
+    for (size_t i = 0; i < n_all;) {
+        size_t j = i + 1;
+        while (j < n_all && all[j] == all[i])
+            ++j;
+        if (j == i + 1)
+            sing[n_sing++] = all[i];
+        i = j;
+    }
+    size_t n_out = 0;
+    for (u32 i = 0; i < n_ctg; ++i) /* `all` is reused as the output list */
+        n_out += agco_find_splitters_in_contig(d + off[i], off[i + 1] - off[i], k, segment_size, sing, n_sing, all + n_out);
+    n_out = sort_unique(all, n_out);
+    *h_n_spl = n_out;
+    int rc = AGC_HIP_OK;
+    if (n_out > cap)
+        rc = fail(c, AGC_HIP_ECAP, "splitter buffer");
+    else if (n_out)
+        memcpy(h_spl, all, n_out * sizeof(u64));
+    free(all);
+    free(sing);
+    return rc;
+}
+
+int agc_hip_scan_contigs_dev(agc_hip_ctx *c, const uint8_t *d, const uint64_t *off, uint32_t n_ctg, uint32_t k, uint64_t cap,
+                             uint64_t *h_n_hits, uint32_t *h_ctg, uint64_t *h_pos, uint64_t *h_dir, uint64_t *h_rc)
+{
+    if (!c || !h_n_hits || (n_ctg && (!d || !off)))
+        return AGC_HIP_EINVAL;
+    u64 n_hits = 0;
+    for (u32 i = 0; i < n_ctg; ++i) {
+        const u64 n = off[i + 1] - off[i];
+        size_t scap = n / (k ? k : 1) + 4;
+        u64 *buf = (u64 *)malloc(scap * 6 * sizeof(u64));
+        u8 *fl = (u8 *)malloc(scap * 2);
+        u64 *ss = buf, *sl = buf + scap, *fd = buf + 2 * scap, *fr = buf + 3 * scap, *bd = buf + 4 * scap, *br = buf + 5 * scap;
+        const size_t ns = agco_scan_contig(d + off[i], n, k, c->spl, c->n_spl, scap, ss, sl, fd, fr, fl, bd, br, fl + scap);
+        for (size_t s = 0; s < ns && s < scap; ++s)
+            if (fl[scap + s]) { /* the segment ends with a splitter: one accepted hit at its last symbol */
+                if (n_hits < cap) {
+                    h_ctg[n_hits] = i;
+                    h_pos[n_hits] = ss[s] + sl[s] - 1;
+                    h_dir[n_hits] = bd[s];
+                    h_rc[n_hits] = br[s];
+                }
+                ++n_hits;
+            }
+        free(buf);
+        free(fl);
+    }
+    *h_n_hits = n_hits;
+    return n_hits > cap ? fail(c, AGC_HIP_ECAP, "hit buffer") : AGC_HIP_OK;
+}
+
+static void *find_ref(agc_hip_ctx *c, u32 gid) { return gid < c->n_lz ? c->lz[gid] : NULL; }
+
+int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,
+                                   const uint32_t *len, const uint8_t *rc, uint32_t mml)
+{
+    if (!c || (n && (!gid || !d || !off || !len)))
+        return AGC_HIP_EINVAL;
+    for (u32 i = 0; i < n; ++i) {
+        if (gid[i] >= c->n_lz) {
+            u32 m = gid[i] + gid[i] / 2 + 64;
+            c->lz = (void **)realloc(c->lz, m * sizeof(void *));
+            memset(c->lz + c->n_lz, 0, (m - c->n_lz) * sizeof(void *));
+            c->n_lz = m;
+        }
+        if (c->lz[gid[i]])
+            return fail(c, AGC_HIP_EINVAL, "group registered twice");
+        u8 *t = slice(d, off[i], len[i], rc && rc[i]);
+        c->lz[gid[i]] = agco_lz_create(t, len[i], mml);
+        free(t);
+    }
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,
+                                const uint32_t *len, const uint8_t *rc, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off || (n && (!gid || !d || !off || !len)))
+        return AGC_HIP_EINVAL;
+    h_enc_off[0] = 0;
+    int over = 0;
+    for (u32 i = 0; i < n; ++i) {
+        void *z = find_ref(c, gid[i]);
+        if (!z)
+            return fail(c, AGC_HIP_ENOREF, "encode: unknown group");
+        u8 *t = slice(d, off[i], len[i], rc && rc[i]);
+        u8 *o = (u8 *)malloc((size_t)len[i] * 2 + 128);
+        const size_t m = agco_lz_encode(z, t, len[i], o);
+        if (!over && h_enc_off[i] + m <= cap)
+            memcpy(h_enc + h_enc_off[i], o, m);
+        else
+            over = 1;
+        h_enc_off[i + 1] = h_enc_off[i] + m;
+        free(o);
+        free(t);
+    }
+    return over ? fail(c, AGC_HIP_ECAP, "encode buffer") : AGC_HIP_OK;
+}
+
+int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,
+                                  const uint32_t *len, const uint8_t *rc, uint32_t *h_cost, uint32_t *h_peak)
+{
+    if (!c || (n && (!gid || !d || !off || !len || !h_cost)))
+        return AGC_HIP_EINVAL;
+    for (u32 i = 0; i < n; ++i) {
+        void *z = find_ref(c, gid[i]);
+        if (!z)
+            return fail(c, AGC_HIP_ENOREF, "estimate: unknown group");
+        u8 *t = slice(d, off[i], len[i], rc && rc[i]);
+        u32 peak = 0;
+        h_cost[i] = agco_lz_estimate(z, t, len[i], 0xFFFFFFFFu, &peak);
+        if (h_peak)
+            h_peak[i] = peak;
+        free(t);
+    }
+    return AGC_HIP_OK;
+}
+
+/* src/core/agc_compressor.cpp:1538-1617 */
+int agc_hip_lz_split_point_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *g1, const uint32_t *g2, const uint8_t *d,
+                                     const uint64_t *off, const uint32_t *len, const uint8_t *rc1, const uint8_t *pf1, const uint8_t *rc2,
+                                     const uint8_t *pf2, uint32_t *best_pos, uint32_t *best_sum)
+{
+    if (!c || (n && (!g1 || !g2 || !d || !off || !len || !rc1 || !pf1 || !rc2 || !pf2 || !best_pos)))
+        return AGC_HIP_EINVAL;
+    for (u32 s = 0; s < n; ++s) {
+        void *z1 = find_ref(c, g1[s]), *z2 = find_ref(c, g2[s]);
+        if (!z1 || !z2)
+            return fail(c, AGC_HIP_ENOREF, "split point: unknown group");
+        const u32 m = len[s];
+        u32 *v1 = (u32 *)calloc((size_t)m + 1, 4), *v2 = (u32 *)calloc((size_t)m + 1, 4);
+        u8 *t = slice(d, off[s], m, rc1[s]);
+        agco_lz_cost_vector(z1, t, m, pf1[s], v1);
+        free(t);
+        if (!pf1[s])
+            for (u32 i = 0; i < m / 2; ++i) {
+                u32 x = v1[i];
+                v1[i] = v1[m - 1 - i];
+                v1[m - 1 - i] = x;
+            }
+        for (u32 i = 1; i < m; ++i)
+            v1[i] += v1[i - 1];
+        t = slice(d, off[s], m, rc2[s]);
+        agco_lz_cost_vector(z2, t, m, pf2[s], v2);
+        free(t);
+        if (!pf2[s]) { /* suffix sums in place */
+            for (u32 i = m; i-- > 1;)
+                v2[i - 1] += v2[i];
+        } else { /* prefix sums, then reversed */
+            for (u32 i = 1; i < m; ++i)
+                v2[i] += v2[i - 1];
+            for (u32 i = 0; i < m / 2; ++i) {
+                u32 x = v2[i];
+                v2[i] = v2[m - 1 - i];
+                v2[m - 1 - i] = x;
+            }
+        }
+        u32 bs = ~0u, bp = 0;
+        for (u32 i = 0; i < m; ++i) {
+            const u32 cs = v1[i] + v2[i];
+            if (cs < bs) {
+                bs = cs;
+                bp = i;
+            }
+        }
+        best_pos[s] = bp;
+        if (best_sum)
+            best_sum[s] = bs;
+        free(v1);
+        free(v2);
+    }
+    return AGC_HIP_OK;
+}
+
+int agc_hip_fetch_slices_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d, const uint64_t *off, const uint32_t *len, const uint8_t *rc,
+                             uint8_t *h_out, uint64_t cap, uint64_t *h_out_off)
+{
+    if (!c || !h_out_off || (n && (!d || !off || !len)))
+        return AGC_HIP_EINVAL;
+    h_out_off[0] = 0;
+    for (u32 i = 0; i < n; ++i)
+        h_out_off[i + 1] = h_out_off[i] + len[i];
+    if (h_out_off[n] > cap)
+        return fail(c, AGC_HIP_ECAP, "fetch buffer");
+    for (u32 i = 0; i < n; ++i) {
+        if (rc && rc[i])
+            agco_rev_comp(d + off[i], len[i], h_out + h_out_off[i]);
+        else
+            memcpy(h_out + h_out_off[i], d + off[i], len[i]);
+    }
+    return AGC_HIP_OK;
+}
+
+int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d, const uint64_t *off, const uint32_t *len, const uint8_t *rc,
+                               uint32_t *h_cnt, uint32_t *h_cur)
+{
+    if (!c || (n && (!d || !off || !len || !h_cnt || !h_cur)))
+        return AGC_HIP_EINVAL;
+    for (u32 i = 0; i < n; ++i) {
+        u8 *t = slice(d, off[i], len[i], rc && rc[i]);
+        agco_ref_lag_counts(t, len[i], h_cnt + 28 * i, h_cur + 28 * i);
+        free(t);
+    }
+    return AGC_HIP_OK;
+}

@@ -1,0 +1,38 @@
+"""Builds the host pipeline against the CPU device stand-in (tests/devsim/agc_hip_sim.c) into tests/devsim/_build/.
+TEST INFRASTRUCTURE ONLY: the same host sources as agc_amd/build.py:build_host(), linked with the simulator instead of
+libagc_hip.so, so host logic is testable without a GPU.  The product build never touches this directory."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_build")
+HOST = os.path.join(ROOT, "agc_amd", "csrc", "host")
+SIM_HIP = os.path.join(OUT, "libagc_hip.so")
+SIM_HOST = os.path.join(OUT, "libagc_host.so")
+SIM_CLI = os.path.join(OUT, "agc_amd_sim")
+
+
+def _newer(target, deps):
+    return os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps)
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    sim_src = [os.path.join(HERE, "agc_hip_sim.c"), os.path.join(ROOT, "oracle", "agc_oracle.c")]
+    hdr = os.path.join(ROOT, "include", "agc_hip.h")
+    if force or not _newer(SIM_HIP, sim_src + [hdr]):
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall"] + sim_src + ["-o", SIM_HIP])
+    host_src = [os.path.join(HOST, s) for s in ("compressor.cpp", "capi_host.cpp")]
+    host_dep = host_src + [os.path.join(HOST, s) for s in ("compressor.h", "host_support.h")] + [SIM_HIP]
+    common = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
+    if force or not _newer(SIM_HOST, host_dep):
+        subprocess.check_call(common + ["-shared"] + host_src + ["-o", SIM_HOST, "-L" + OUT, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"])
+    cli_src = [os.path.join(HOST, s) for s in ("main.cpp", "reader.cpp")]
+    if force or not _newer(SIM_CLI, cli_src + [os.path.join(HOST, "reader.h"), SIM_HOST]):
+        subprocess.check_call(common + cli_src + ["-o", SIM_CLI, "-L" + OUT, "-lagc_host", "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"])
+    return SIM_CLI
+
+
+if __name__ == "__main__":
+    print(build(force=True))
