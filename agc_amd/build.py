@@ -34,14 +34,14 @@ HOST = os.path.join(CSRC, "host")
 HOST_LIB = os.path.join(HERE, "libagc_host.so")
 HOST_BIN = os.path.join(HERE, "bin", "agc_amd")
 HOST_SOURCES = ["compressor.cpp", "compressor.h", "host_support.h", "capi_host.cpp", "main.cpp", "reader.cpp", "reader.h",
-                "capi_read.cpp"]
+                "capi_read.cpp", "archive_read.h"]
 READ_LIB = os.path.join(HERE, "libagc_read.so")
 
 
 def build_read(force=False, verbose=False):
     """g++ for the read side (include/agc_read.h): libagc_read.so -- host only, no HIP dependency."""
     srcs = [os.path.join(HOST, s) for s in ("reader.cpp", "capi_read.cpp")]
-    deps = srcs + [os.path.join(HOST, "reader.h"), os.path.join(HERE, "..", "include", "agc_read.h")]
+    deps = srcs + [os.path.join(HOST, "reader.h"), os.path.join(HOST, "archive_read.h"), os.path.join(HERE, "..", "include", "agc_read.h")]
     if not force and os.path.exists(READ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(READ_LIB) for d in deps):
         return READ_LIB
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB, "-ldl"]
@@ -64,9 +64,10 @@ def build_host(force=False, verbose=False):
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
     common = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
-    cmd1 = common + ["-shared", os.path.join(HOST, "compressor.cpp"), os.path.join(HOST, "capi_host.cpp"), "-o", HOST_LIB,
+    cmd1 = common + ["-shared", os.path.join(HOST, "compressor.cpp"), os.path.join(HOST, "capi_host.cpp"), os.path.join(HOST, "reader.cpp"),
+                     "-o", HOST_LIB,
                      "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"]
-    cmd2 = common + [os.path.join(HOST, "main.cpp"), os.path.join(HOST, "reader.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
+    cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
                      "-Wl,-rpath,$ORIGIN/..", "-lz", "-ldl"]
     for cmd in (cmd1, cmd2):
         if verbose:

@@ -1,6 +1,8 @@
 // compressor.cpp -- see compressor.h.  Citations: file:line under the reference tree.
 #include "compressor.h"
 #include "host_support.h"
+#include "archive_read.h"
+#include "reader.h"
 #include "../../../include/agc_hip.h"
 
 #include <chrono>
@@ -93,6 +95,12 @@ struct Group { // CSegment, write side (src/common/segment.{h,cpp})
     bytes_t lzp_data, raw_data;
     std::vector<uint32_t> lzp_off, raw_off;
     int stream_ref = -1, stream_delta = -1;
+    // append mode: a group taken over from the input archive stays "packed" until its first add in this session
+    // (CSegment::appending_init / unpack, segment.cpp:418-471, 496-577).  While packed it behaves as the
+    // reference's does: ref_size == 0, so Estimate answers 0 and the cost vector is empty (segment.cpp:85-86, 103-104).
+    bool packed = false;
+    const uint8_t *pk_ref = nullptr, *pk_delta = nullptr; // parts inside the mapped input archive
+    uint64_t pk_ref_size = 0, pk_ref_meta = 0, pk_delta_size = 0, pk_delta_meta = 0;
 
     static void push(bytes_t &data, std::vector<uint32_t> &off, const uint8_t *b, size_t n)
     {
@@ -382,6 +390,13 @@ struct CAGCCompressor::Impl {
 
     CompressorStats st;
 
+    // append mode
+    bool appending = false;
+    rd::Archive in_ar;
+    rd::ZstdD zd;
+    std::map<std::string, std::string> in_file_type_info;
+    bool unpack_group(uint32_t gid);
+
     void err(const std::string &m) { std::cerr << m << std::endl; }
     bool hip_ok(int rc, const char *what)
     {
@@ -578,10 +593,280 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
 }
 
 // ---------------------------------------------------------------------------
+// Append (agc_compressor.cpp:2330-2374): load_file_type_info + load_metadata (agc_basic.cpp:53-236),
+// CCollection_V3::prepare_for_appending_copy / _load_last_batch (collection_v3.cpp:47-108), appending_init (:303-380)
+bool CAGCCompressor::Append(const std::string &in_archive_name, const std::string &out_archive_name, uint32_t verbosity, bool prefetch_archive,
+                            bool concatenated_genomes, bool adaptive_compression, uint32_t no_threads, double fallback_frac)
+{
+    Impl &I = *p;
+    (void)prefetch_archive;
+    if (I.created)
+        return false;
+    if (fallback_frac != 0.0) {
+        I.err("fallback minimizers (-f) are not implemented");
+        return false;
+    }
+    std::string e;
+    if (!I.zstd.load(e)) {
+        I.err(e);
+        return false;
+    }
+    if (!I.zd.load()) {
+        I.err("cannot dlopen libzstd (set AGC_ZSTD_LIB)");
+        return false;
+    }
+    if (!I.in_ar.open(in_archive_name)) {
+        I.err("Cannot open archive " + in_archive_name);
+        return false;
+    }
+    const uint8_t *ptr;
+    uint64_t size, meta;
+    if (!I.in_ar.get_part("file_type_info", 0, ptr, size, meta))
+        return false;
+    {
+        const uint8_t *q = ptr, *qe = ptr + size;
+        std::string key, val;
+        I.in_file_type_info.clear();
+        for (uint64_t i = 0; i < meta && rd::rd_str(q, qe, key) && rd::rd_str(q, qe, val); ++i)
+            I.in_file_type_info[key] = val;
+        if (I.in_file_type_info["file_version_major"] != "3") {
+            I.err("Unsupported archive version (only the v3 format is handled)");
+            return false;
+        }
+    }
+    if (!I.in_ar.get_part("params", 0, ptr, size, meta) || size < 16) {
+        I.err("Archive does not contain parameters section");
+        return false;
+    }
+    auto le32 = [&](const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); };
+    auto le64 = [&](const uint8_t *b) { return (uint64_t)le32(b) | ((uint64_t)le32(b + 4) << 32); };
+    I.k = le32(ptr);
+    I.mml = le32(ptr + 4);
+    I.pack_cardinality = le32(ptr + 8);
+    I.segment_size = le32(ptr + 12);
+    if (!I.pack_cardinality)
+        return false;
+    I.concatenated = concatenated_genomes;
+    I.adaptive = adaptive_compression;
+    I.verbosity = verbosity;
+    I.appending = true;
+
+    if (!I.hip) {
+        int rc = agc_hip_create(&I.hip, I.device);
+        if (rc != AGC_HIP_OK) {
+            I.err("no HIP device: the MI355X path has no CPU fallback (agc_hip_create = " + std::to_string(rc) + ")");
+            return false;
+        }
+    }
+    unsigned nt = std::max(1u, no_threads);
+    I.pool.reset(new ThreadPool(nt));
+    for (unsigned i = 0; i < nt; ++i)
+        I.zctx.emplace_back(new ZstdCtx(&I.zstd));
+
+    if (!I.ar.open(out_archive_name)) {
+        I.err("Cannot create archive " + out_archive_name);
+        return false;
+    }
+    I.created = true;
+    // ---- collection: all batches but the last are copied now (direct parts), sample names are loaded
+    I.coll.set_archive(&I.ar, &I.zstd, I.segment_size, I.k);
+    std::vector<rd::SampleDesc> in_samples;
+    if (!rd::parse_sample_names(I.in_ar, I.zd, in_samples))
+        return false;
+    {
+        std::vector<std::string> names;
+        for (auto &sd : in_samples)
+            names.push_back(sd.name);
+        I.coll.load_sample_names(names);
+    }
+    const size_t n_batches = I.in_ar.n_parts("collection-contigs");
+    auto copy_batch = [&](size_t b) -> bool {
+        if (!I.in_ar.get_part("collection-contigs", b, ptr, size, meta))
+            return false;
+        I.ar.add_part(I.coll.stream_contigs(), ptr, size, meta);
+        if (!I.in_ar.get_part("collection-details", b, ptr, size, meta))
+            return false;
+        I.ar.add_part(I.coll.stream_details(), ptr, size, meta);
+        return true;
+    };
+    for (size_t b = 0; b + 1 < n_batches; ++b)
+        if (!copy_batch(b))
+            return false;
+
+    // ---- adaptive mode: singleton / duplicated k-mers of the reference sample, decoded from the input archive
+    // (build_candidate_kmers_from_archive, agc_compressor.cpp:828-847) and counted on the GPU
+    if (I.adaptive && !in_samples.empty()) {
+        CAGCFile rdr;
+        std::vector<std::string> names;
+        std::vector<bytes_t> ref;
+        if (!rdr.Open(in_archive_name) || !rdr.GetSampleCodes(in_samples.front().name, names, ref)) {
+            I.err("Cannot decode the reference sample of " + in_archive_name);
+            return false;
+        }
+        uint64_t tot = 0;
+        for (auto &c : ref)
+            tot += c.size();
+        uint8_t *d_ref = nullptr;
+        if (!I.hip_ok(agc_hip_sample_buffer(I.hip, tot, &d_ref), "sample_buffer"))
+            return false;
+        std::vector<uint64_t> off(ref.size() + 1, 0);
+        for (size_t i = 0; i < ref.size(); ++i) {
+            if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size()), "copy_to_device"))
+                return false;
+            off[i + 1] = off[i] + ref[i].size();
+        }
+        std::vector<uint64_t> spl(std::max<uint64_t>(1024, tot / std::max(1u, I.segment_size) * 2 + 2 * ref.size() + 16));
+        std::vector<uint64_t> sorted_kmers(tot);
+        uint64_t n_spl = 0, n_sorted = 0;
+        for (;;) {
+            int rc = agc_hip_determine_splitters_dev(I.hip, d_ref, off.data(), (uint32_t)ref.size(), I.k, I.segment_size, spl.size(), spl.data(),
+                                                     &n_spl, sorted_kmers.size(), sorted_kmers.data(), &n_sorted);
+            if (rc == AGC_HIP_ECAP && n_spl > spl.size()) {
+                spl.resize(n_spl);
+                continue;
+            }
+            if (!I.hip_ok(rc, "determine_splitters"))
+                return false;
+            break;
+        }
+        sorted_kmers.resize(n_sorted);
+        split_singletons(sorted_kmers, &I.ref_duplicates);
+        I.ref_singletons.swap(sorted_kmers);
+    }
+
+    // ---- appending_init: the last collection batch is loaded (and copied as well when it is full)
+    if (n_batches) {
+        const size_t first = (n_batches - 1) * (size_t)I.pack_cardinality;
+        if (!rd::parse_contig_batch(I.in_ar, I.zd, (uint32_t)(n_batches - 1), I.pack_cardinality, I.segment_size, I.k, in_samples))
+            return false;
+        const size_t n_last = in_samples.size() > first ? in_samples.size() - first : 0;
+        if (n_last == I.pack_cardinality) {
+            if (!copy_batch(n_batches - 1))
+                return false;
+        } else
+            for (size_t i = first; i < in_samples.size(); ++i) {
+                auto &dst = I.coll.sample_at(i);
+                for (auto &c : in_samples[i].ctgs) {
+                    dst.contigs.emplace_back();
+                    dst.contigs.back().name = c.name;
+                    for (auto &sg : c.segs)
+                        dst.contigs.back().segments.push_back({sg.group_id, sg.in_group_id, sg.raw_length, sg.rc});
+                }
+            }
+    }
+    // ---- groups: reference part and all delta parts but the last are copied, the last one stays packed
+    I.groups.clear();
+    for (I.no_segments = 0;; ++I.no_segments) {
+        const std::string rn = ss_ref_name(I.no_segments), dn = ss_delta_name(I.no_segments);
+        const bool has_r = I.in_ar.ids.count(rn) != 0, has_d = I.in_ar.ids.count(dn) != 0;
+        if (!has_r && !has_d)
+            break;
+        I.groups.emplace_back();
+        Group &g = I.groups.back();
+        g.exists = true;
+        g.packed = true;
+        if (has_r)
+            g.stream_ref = I.ar.register_stream(rn);
+        if (has_d)
+            g.stream_delta = I.ar.register_stream(dn);
+        if (has_r && I.in_ar.get_part(rn, 0, g.pk_ref, g.pk_ref_size, g.pk_ref_meta)) {
+            I.ar.add_part(g.stream_ref, g.pk_ref, g.pk_ref_size, g.pk_ref_meta);
+            g.no_seqs = 1;
+        } else
+            g.pk_ref = nullptr;
+        if (has_d) {
+            const size_t np = I.in_ar.n_parts(dn);
+            for (size_t i = 0; i + 1 < np; ++i) {
+                if (!I.in_ar.get_part(dn, i, ptr, size, meta))
+                    return false;
+                I.ar.add_part(g.stream_delta, ptr, size, meta);
+                g.no_seqs += I.pack_cardinality;
+            }
+            if (np && !I.in_ar.get_part(dn, np - 1, g.pk_delta, g.pk_delta_size, g.pk_delta_meta))
+                return false;
+        }
+    }
+    // ---- splitters and the (kmer1, kmer2) -> group map
+    if (!I.in_ar.get_part("splitters", 0, ptr, size, meta) || size < meta * 8)
+        return false;
+    {
+        std::vector<uint64_t> spl(meta);
+        for (uint64_t i = 0; i < meta; ++i)
+            spl[i] = le64(ptr + 8 * i);
+        if (!SetSplitters(spl.data(), spl.size()))
+            return false;
+    }
+    if (!I.in_ar.get_part("segment-splitters", 0, ptr, size, meta) || size < meta * 20)
+        return false;
+    I.map_segments.clear();
+    I.terminators.clear();
+    I.map_segments[{NO_KMER, NO_KMER}] = 0;
+    for (uint64_t i = 0; i < meta; ++i) {
+        const uint64_t x1 = le64(ptr + 20 * i), x2 = le64(ptr + 20 * i + 8);
+        I.map_segments[{x1, x2}] = (int32_t)le32(ptr + 20 * i + 16);
+        if (x1 != NO_KMER && x2 != NO_KMER) {
+            I.terminators[x1].push_back(x2);
+            if (x1 != x2)
+                I.terminators[x2].push_back(x1);
+        }
+    }
+    for (auto &t : I.terminators)
+        std::sort(t.second.begin(), t.second.end());
+    I.coll.reset_prev_sample_name();
+    return true;
+}
+
+// CSegment::unpack (segment.cpp:496-577): the reference goes to HBM (index built on first use there), the last pack of the
+// input archive becomes the group's current pack again
+bool CAGCCompressor::Impl::unpack_group(uint32_t gid)
+{
+    Group &g = groups[gid];
+    if (g.pk_ref) {
+        bytes_t ref;
+        if (!rd::decode_ref_part(zd, g.pk_ref, g.pk_ref_size, g.pk_ref_meta, ref)) {
+            err("cannot decode the reference of group " + std::to_string(gid));
+            return false;
+        }
+        if (!hip_ok(agc_hip_ref_register(hip, gid, ref.data(), (uint32_t)ref.size(), mml), "ref_register"))
+            return false;
+        g.ref_size = ref.size() + 1;
+        g.pk_ref = nullptr;
+    }
+    if (g.pk_delta) {
+        bytes_t pack;
+        if (!rd::decode_pack_part(zd, g.pk_delta, g.pk_delta_size, g.pk_delta_meta, pack)) {
+            err("cannot decode the last pack of group " + std::to_string(gid));
+            return false;
+        }
+        std::vector<uint32_t> off;
+        uint32_t b = 0;
+        for (uint32_t i = 0; i < pack.size(); ++i)
+            if (pack[i] == 0xff) {
+                off.push_back(b);
+                b = i + 1;
+            }
+        pack.resize(b); // (bytes after the last separator cannot occur)
+        g.no_seqs += (uint32_t)off.size();
+        if (g.ref_size == 0) { // no reference: the "deltas" are raw sequences (segment.cpp:569-570)
+            g.raw_data.swap(pack);
+            g.raw_off.swap(off);
+        } else {
+            g.lzp_data.swap(pack);
+            g.lzp_off.swap(off);
+        }
+        g.pk_delta = nullptr;
+    }
+    g.packed = false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // store_in_archive(pack), segment.h:258-280: sequences + 0xFF separators -> zstd 17
 void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off)
 {
     ZJob j;
+    if (g.stream_delta < 0) // segment.h:262-266
+        g.stream_delta = ar.register_stream(ss_delta_name((uint32_t)(&g - groups.data())));
     j.stream_id = g.stream_delta;
     j.kind = 1;
     j.data.swap(data);
@@ -902,21 +1187,31 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     // ---- GPU: estimates for every (one-splitter segment, candidate) pair ----
     std::vector<uint32_t> est_cost(cands.size()), est_peak(cands.size());
     if (!cands.empty()) {
-        std::vector<uint32_t> gid(cands.size()), len(cands.size());
-        std::vector<uint64_t> off(cands.size());
-        std::vector<uint8_t> rc(cands.size());
+        // candidates without a reference in HBM (append mode: still packed) answer 0 on the host below
+        std::vector<uint32_t> gid, len, which;
+        std::vector<uint64_t> off;
+        std::vector<uint8_t> rc;
         for (Seg &s : segs)
             for (uint32_t c = s.cand_begin; c < s.cand_end; ++c) {
-                gid[c] = cands[c].gid;
-                off[c] = ctgs[s.ctg].off + s.start;
-                len[c] = s.len;
+                if (cands[c].ref_size == 0)
+                    continue;
+                which.push_back(c);
+                gid.push_back(cands[c].gid);
+                off.push_back(ctgs[s.ctg].off + s.start);
+                len.push_back(s.len);
                 // front-only: segment_dir = the segment itself; back-only: segment_dir = its reverse complement (:1317-1345)
-                rc[c] = (uint8_t)(s.back_only ? !cands[c].use_rc : cands[c].use_rc);
+                rc.push_back((uint8_t)(s.back_only ? !cands[c].use_rc : cands[c].use_rc));
             }
-        if (!hip_ok(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)cands.size(), gid.data(), d_base, off.data(), len.data(), rc.data(),
-                                                  est_cost.data(), est_peak.data()),
+        std::vector<uint32_t> cost(which.size()), peak(which.size());
+        if (!which.empty() &&
+            !hip_ok(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)which.size(), gid.data(), d_base, off.data(), len.data(), rc.data(), cost.data(),
+                                                  peak.data()),
                     "lz_estimate_batch"))
             return false;
+        for (size_t i = 0; i < which.size(); ++i) {
+            est_cost[which[i]] = cost[i];
+            est_peak[which[i]] = peak[i];
+        }
     }
     st.t_gpu_aux += now() - t0;
     t0 = now();
@@ -1011,6 +1306,19 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         j.seg = si;
         j.gid1 = (uint32_t)m1->second;
         j.gid2 = (uint32_t)m2->second;
+        {
+            // a group without reference leaves its cost vector empty (segment.cpp:103-104; append mode: still packed):
+            // one empty vector -> sizes differ -> no split (:1604-1607); both empty -> best_pos = 0 -> left part empty
+            const bool e1 = groups[j.gid1].ref_size == 0, e2 = groups[j.gid2].ref_size == 0;
+            if (e1 != e2) {
+                s.middle = NO_KMER;
+                continue;
+            }
+            if (e1) {
+                s.mid_job = -2;
+                continue;
+            }
+        }
         // segment_dir here = use_rc ? rc(segment) : segment (:1394)
         const bool f_lt_m = s.kmer1.data() < s.middle, m_lt_b = s.middle < s.kmer2.data();
         j.rc1 = (uint8_t)(f_lt_m ? s.use_rc : !s.use_rc);
@@ -1061,11 +1369,11 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             bool two = false;
             Placed a, b;
             a.ctg = b.ctg = s.ctg;
-            if (s.mid_job >= 0) {
-                uint32_t bp = best_pos[s.mid_job];
+            if (s.mid_job >= 0 || s.mid_job == -2) {
+                uint32_t bp = s.mid_job >= 0 ? best_pos[s.mid_job] : 0;
                 if (bp < k + 1u)
                     bp = 0;
-                if ((size_t)bp + k + 1u > s.len)
+                if (s.mid_job >= 0 && (size_t)bp + k + 1u > s.len)
                     bp = s.len;
                 uint32_t left = bp, right = s.len - bp;
                 if (left == 0) {
@@ -1135,8 +1443,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     const uint32_t n_samples = ctgs.empty() ? 1u : ctgs.back().sample_idx + 1;
     uint32_t commit_upto = n_samples; // exclusive
     for (const Placed &pl : placed)
-        if (pl.gid < 0 && ctgs[pl.ctg].sample_idx + 1 < commit_upto)
-            commit_upto = ctgs[pl.ctg].sample_idx + 1;
+        if ((pl.gid < 0 || groups[pl.gid].packed) && ctgs[pl.ctg].sample_idx + 1 < commit_upto)
+            commit_upto = ctgs[pl.ctg].sample_idx + 1; // (an unpacked group changes later classifications as a new one does)
     n_committed = commit_upto;
 
     // ---- register_segments per sample (agc_compressor.cpp:954-971; agc_compressor.h:384-435) ----
@@ -1258,6 +1566,12 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 }
             }
     }
+    // append mode: the first add to a group of the input archive unpacks it (segment.cpp:19-20, 39-40)
+    if (appending)
+        for (uint32_t sidx = 0; sidx < commit_upto; ++sidx)
+            for (uint32_t gid : per_sample[sidx].gids)
+                if (groups[gid].packed && !unpack_group(gid))
+                    return false;
     // map_segments / terminators updates happen when a group is first stored (:1003-1028)
     for (uint32_t idx : new_ref_items) {
         const Placed &pl = placed[idx];
@@ -1501,6 +1815,11 @@ void CAGCCompressor::Impl::finish_groups()
             make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
         if (!g.raw_off.empty())
             make_pack_job(jobs, g, g.raw_data, g.raw_off);
+        if (g.packed && g.pk_delta) { // store_compressed_delta_in_archive, segment.h:283-292
+            if (g.stream_delta < 0)
+                g.stream_delta = ar.register_stream(ss_delta_name(gid));
+            ar.add_part_buffered(g.stream_delta, bytes_t(g.pk_delta, g.pk_delta + g.pk_delta_size), g.pk_delta_meta);
+        }
     }
     run_jobs(jobs);
 }
@@ -1545,7 +1864,7 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         return false;
     if (files.empty())
         return true;
-    I.processed_samples = 0;
+    I.processed_samples = I.appending ? (uint32_t)I.coll.no_samples() : 0; // agc_compressor.cpp:2150-2153
     if (I.concatenated)
         I.cnt_contigs_in_sample = I.processed_samples % I.pack_cardinality;
 
@@ -1744,6 +2063,8 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     info["file_version_minor"] = "0";
     info["comment"] = tag ? "agc_amd (MI355X-native create path), archive format of AGC v. 3.2"
                           : "AGC (Assembled Genomes Compressor) v. 3.2.2 [build 20260326.1]";
+    if (I.appending) // load_file_type_info replaced the defaults with the input archive's (agc_basic.cpp:53-90)
+        info = I.in_file_type_info;
     v.clear();
     for (auto &x : info) {
         appstr(v, x.first);

@@ -52,6 +52,11 @@ public:
                 uint32_t segment_size, uint32_t min_match_len, bool concatenated_genomes, bool adaptive_compression,
                 uint32_t verbosity, uint32_t no_threads, double fallback_frac);
 
+    // src/core/agc_compressor.cpp:2330-2374: opens in_archive_name, copies what can be copied to out_archive_name and
+    // restores splitters, groups and the collection so that AddSampleFiles / Close extend the archive
+    bool Append(const std::string &in_archive_name, const std::string &out_archive_name, uint32_t verbosity, bool prefetch_archive,
+                bool concatenated_genomes, bool adaptive_compression, uint32_t no_threads, double fallback_frac);
+
     // replaces determine_splitters' result (agc_compressor.cpp:543-555) when no reference file is given
     bool SetSplitters(const uint64_t *kmers, uint64_t n);
     // the same from a reference genome resident in HBM: runs determine_splitters on the GPU

@@ -267,6 +267,14 @@ public:
         std::lock_guard<std::mutex> lk(mtx);
         add_part_now(id, d, meta);
     }
+    void add_part(int id, const uint8_t *d, size_t n, uint64_t meta)
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        streams[id].parts.push_back({f_offset, n});
+        f_offset += write_num(meta);
+        put(d, n);
+        f_offset += n;
+    }
     void add_part_buffered(int id, bytes_t &&d, uint64_t meta)
     {
         std::lock_guard<std::mutex> lk(mtx);
@@ -476,6 +484,21 @@ public:
     }
     void reset_prev_sample_name() { prev_sample_name.clear(); }
     size_t no_samples() const { return samples.size(); }
+    // append mode (prepare_for_appending_copy / _load_last_batch, collection_v3.cpp:47-108): every sample name of the
+    // input archive; contigs + segments only for the samples of its last, still open batch
+    void load_sample_names(const std::vector<std::string> &names)
+    {
+        samples.clear();
+        sample_ids.clear();
+        for (auto &n : names) {
+            sample_ids[n] = (uint32_t)samples.size();
+            samples.emplace_back();
+            samples.back().name = n;
+        }
+    }
+    SampleDesc &sample_at(size_t i) { return samples[i]; }
+    int stream_contigs() const { return id_contigs; }
+    int stream_details() const { return id_details; }
 
     // collection_v3.cpp:682-708
     bool register_sample_contig(const std::string &sample_name, const std::string &contig_name)

@@ -23,6 +23,7 @@ void usage()
 {
     std::cerr << "agc_amd (MI355X-native create path of AGC v. 3.2)\n"
                  "Usage: agc_amd create [options] <ref.fa> [<in1.fa> ...] > <out.agc>\n"
+                 "       agc_amd append [-a] [-c] [-i <file>] [-o <file>] [-t <int>] [-v <int>] <in.agc> [<in1.fa> ...] > <out.agc>\n"
                  "Options:\n"
                  "   -b <int>       - batch size (default: 50; min: 1; max: 1000000000)\n"
                  "   -c             - concatenated genomes in a single file\n"
@@ -35,7 +36,7 @@ void usage()
                  "   -t <int>       - no of threads\n"
                  "   -v <int>       - verbosity level (default: 0; min: 0; max: 2)\n"
                  "   -g <int>       - HIP device ordinal (default: 0)\n"
-                 "       agc_amd getcol  [-l <line>] [-o <dir>] [-n] <in.agc>\n"
+                 "       agc_amd getcol  [-l <line>] [-o <dir>] [-r] <in.agc>\n"
                  "       agc_amd getset  [-l <line>] [-o <file>] <in.agc> <sample> [<sample> ...]\n"
                  "       agc_amd getctg  [-l <line>] [-o <file>] <in.agc> <contig[@sample][:from-to]> ...\n"
                  "       agc_amd listref|listset [-o <file>] <in.agc>\n"
@@ -80,7 +81,7 @@ int read_command(const std::string &mode, int argc, char **argv)
         case 'g':
         case 't':
         case 'v': (void)val(); break;
-        case 'n': no_ref = true; break;
+        case 'r': no_ref = true; break;
         default: break;
         }
     }
@@ -189,7 +190,8 @@ int main(int argc, char **argv)
             if (mode == m)
                 return read_command(mode, argc, argv);
     }
-    if (argc < 2 || std::string(argv[1]) != "create") {
+    const bool append = argc >= 2 && std::string(argv[1]) == "append";
+    if (argc < 2 || (std::string(argv[1]) != "create" && !append)) {
         usage();
         return 0;
     }
@@ -236,10 +238,12 @@ int main(int argc, char **argv)
         }
     }
     if (i >= argc) {
-        std::cerr << "No reference file name\n";
+        std::cerr << (append ? "No archive name\n" : "No reference file name\n");
         return 0;
     }
-    inputs.insert(inputs.begin(), argv[i]);
+    const std::string in_archive = append ? argv[i] : "";
+    if (!append)
+        inputs.insert(inputs.begin(), argv[i]);
     for (++i; i < argc; ++i)
         inputs.emplace_back(argv[i]);
     { // sanitize_input_file_names, application.cpp:584-601
@@ -252,7 +256,12 @@ int main(int argc, char **argv)
     }
     agc::CAGCCompressor c;
     c.SetDevice(device);
-    if (!c.Create(out, pack, k, inputs.front(), seg, mml, concat, adaptive, verbosity, threads, ff)) {
+    if (append) { // src/app/main.cpp:125-168
+        if (!c.Append(in_archive, out, verbosity, true, concat, adaptive, threads, ff)) {
+            std::cerr << "Cannot open archive " << in_archive << " or create archive " << out << std::endl;
+            return 0;
+        }
+    } else if (!c.Create(out, pack, k, inputs.front(), seg, mml, concat, adaptive, verbosity, threads, ff)) {
         std::cerr << "Cannot create archive " << out << std::endl;
         return 0;
     }

@@ -431,6 +431,24 @@ bool CAGCFile::GetContigFasta(const std::string &query, std::string &out, uint32
     return true;
 }
 
+bool CAGCFile::GetSampleCodes(const std::string &sample, std::vector<std::string> &names, std::vector<std::vector<uint8_t>> &codes) const
+{
+    if (!p->opened)
+        return false;
+    auto it = p->sample_ids.find(sample);
+    if (it == p->sample_ids.end() || !p->ensure_sample(it->second))
+        return false;
+    names.clear();
+    codes.clear();
+    for (auto &c : p->samples[it->second].ctgs) {
+        names.push_back(c.name);
+        codes.emplace_back();
+        if (!p->decode_contig(c, -1, -1, codes.back()))
+            return false;
+    }
+    return true;
+}
+
 bool CAGCFile::GetSampleFasta(const std::string &sample, std::string &out, uint32_t line_length) const
 {
     if (!p->opened)

@@ -34,6 +34,8 @@ public:
     bool GetParams(uint32_t &k, uint32_t &mml, uint32_t &pack, uint32_t &segment_size) const;
     // whole sample as FASTA text (agc getset): ">name\n" + 80-column lines
     bool GetSampleFasta(const std::string &sample, std::string &out, uint32_t line_length = 80) const;
+    // all contigs of a sample as symbol codes (GetSampleSequences, agc_decompressor_lib.cpp; used by append -a)
+    bool GetSampleCodes(const std::string &sample, std::vector<std::string> &names, std::vector<std::vector<uint8_t>> &codes) const;
     // one `agc getctg` query -- contig[@sample][:from-to] (agc_decompressor_lib.h:127-130) -- as FASTA text;
     // the header is the full contig name (+ ":from-to" when a range was given), core/agc_decompressor.cpp:478-567
     bool GetContigFasta(const std::string &query, std::string &out, uint32_t line_length, std::string &err) const;

@@ -28,6 +28,45 @@ CONFIGS = {
     "syn_adaptive_c": (["-a", "-c", "-k", "25", "-l", "18", "-s", "1500", "-b", "4"], "adaptive"),
 }
 
+# append plans: name -> (collection, [number of input files of each step]); step 0 is `create` (reference file
+# first), every later step is one `append` of the next files; the options -a / -c of the collection carry over
+APPEND_PLANS = {
+    "snp_4_3": ("syn_snp", [4, 3]),
+    "snp_1_3_3": ("syn_snp", [1, 3, 3]),           # reference only, then two appends
+    "mixed_3_3": ("syn_mixed", [3, 3]),
+    "viral_25_15": ("syn_viral", [25, 15]),        # 25 = 3 full collection batches (-b 7) + 4
+    "viral_14_20_6": ("syn_viral", [14, 20, 6]),   # 14 = exactly two batches: the last batch is copied, not re-opened
+    "viral_c_1_1": ("syn_viral_c", [1, 1]),
+    "shuffled_2_4": ("syn_shuffled", [2, 4]),
+    "adaptive_3_4": ("syn_adaptive", [3, 4]),
+    "adaptive_1_2_4": ("syn_adaptive", [1, 2, 4]),
+    "adaptive_c_4_3": ("syn_adaptive_c", [4, 3]),
+    "toy_2_2": ("toy_c1", [2, 2]),
+}
+
+
+def run_append_plan(cli, plan, outdir, threads="4", env=None):
+    """runs create + appends with `cli` (reference binary or agc_amd); returns the archive bytes after every step"""
+    import subprocess
+    coll, steps = APPEND_PLANS[plan]
+    args, _ = CONFIGS[coll]
+    files = build(coll, os.path.join(outdir, "in"))
+    assert sum(steps) == len(files), (plan, len(files))
+    carry = [a for a in args if a in ("-a", "-c")]
+    out, pos, prev = [], 0, None
+    for i, n in enumerate(steps):
+        fn = os.path.join(outdir, f"step{i}.agc")
+        if i == 0:
+            cmd = [cli, "create"] + args + ["-t", threads, "-o", fn] + files[:n]
+        else:
+            cmd = [cli, "append"] + carry + ["-t", threads, "-o", fn, prev] + files[pos:pos + n]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert os.path.exists(fn), r.stderr[-2000:]
+        out.append(open(fn, "rb").read())
+        pos += n
+        prev = fn
+    return out
+
 
 def build(name, outdir):
     """writes the FASTA files, returns their paths (reference first)"""

@@ -261,6 +261,12 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *g
     return AGC_HIP_OK;
 }
 
+int agc_hip_ref_register(agc_hip_ctx *c, uint32_t gid, const uint8_t *h_ref, uint32_t n, uint32_t mml)
+{
+    const uint64_t off = 0;
+    return agc_hip_ref_register_batch_dev(c, 1, &gid, h_ref, &off, &n, NULL, mml);
+}
+
 int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,
                                 const uint32_t *len, const uint8_t *rc, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
 {

@@ -67,6 +67,21 @@ def scan_golden():
     print("scan_golden.npz:", n, "cases")
 
 
+def archives_append():
+    """sha256 of the archives the reference CLI writes for create + append sequences (tests/collections.py APPEND_PLANS)"""
+    from tests import collections as C
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "lib"))
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for plan in C.APPEND_PLANS:
+            a = C.run_append_plan(O.REF_AGC, plan, os.path.join(td, plan + "_1"), threads="1", env=env)
+            b = C.run_append_plan(O.REF_AGC, plan, os.path.join(td, plan + "_8"), threads="8", env=env)
+            assert a == b, plan + ": the reference's append output depends on the thread count"
+            out[plan] = [{"sha256": hashlib.sha256(x).hexdigest(), "size": len(x)} for x in a]
+    json.dump(out, open(os.path.join(HERE, "archives_append.json"), "w"), indent=1)
+    print("archives_append.json:", {k_: [x["size"] for x in v] for k_, v in out.items()})
+
+
 def archives():
     """sha256 of the archives the reference CLI writes for tests/collections.py (t=1 and t=8 must agree)"""
     from tests import collections as C
@@ -92,3 +107,4 @@ if __name__ == "__main__":
     lz_golden()
     scan_golden()
     archives()
+    archives_append()

@@ -39,6 +39,20 @@ def test_archive_bit_identical(name, tmp_path):
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+GOLD_APPEND = json.load(open(os.path.join(ROOT, "tests", "golden", "archives_append.json")))
+
+
+@pytest.mark.parametrize("plan", list(C.APPEND_PLANS))
+def test_append_bit_identical(plan, tmp_path):
+    """`agc_amd create` + `agc_amd append` sequences on the GPU: every archive equals the reference CLI's (recorded sha256)"""
+    from agc_amd import build
+    build.build_host()
+    got = C.run_append_plan(AGC_AMD, plan, str(tmp_path), threads="8")
+    want = GOLD_APPEND[plan]
+    assert [len(x) for x in got] == [w["size"] for w in want]
+    assert [hashlib.sha256(x).hexdigest() for x in got] == [w["sha256"] for w in want]
+
+
 def test_cli_without_reference_file_reports_and_exits_zero(tmp_path):
     r = subprocess.run([AGC_AMD, "create", "-o", str(tmp_path / "x.agc"), str(tmp_path / "missing.fa")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "Cannot" in r.stderr

@@ -36,6 +36,52 @@ def test_host_pipeline_writes_the_reference_archive(cli, name, tmp_path):
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+GOLD_APPEND = json.load(open(os.path.join(ROOT, "tests", "golden", "archives_append.json")))
+
+
+@pytest.mark.parametrize("plan", list(C.APPEND_PLANS))
+def test_append_writes_the_reference_archive(cli, plan, tmp_path):
+    """create + append sequences: every intermediate and final archive equals the reference CLI's (recorded sha256),
+    including its append-only behaviour for groups that are still packed (Estimate = 0, empty cost vectors)"""
+    got = C.run_append_plan(cli, plan, str(tmp_path))
+    want = GOLD_APPEND[plan]
+    assert [len(x) for x in got] == [w["size"] for w in want]
+    assert [hashlib.sha256(x).hexdigest() for x in got] == [w["sha256"] for w in want]
+
+
+def test_append_round_trips_through_the_reader(cli, tmp_path):
+    from agc_amd import build, reader
+    from tests.test_read_cpu import fasta_text, parse_fasta
+    build.build_read()
+    C.run_append_plan(cli, "adaptive_1_2_4", str(tmp_path))
+    a = reader.CAGCFile()
+    assert a.Open(str(tmp_path / "step2.agc"))
+    files = C.build("syn_adaptive", str(tmp_path / "in"))
+    assert a.NSample() == len(files)
+    for f in files:
+        sn = os.path.basename(f)[:-3]
+        assert a.GetSampleFasta(sn) == fasta_text(parse_fasta(f)), sn
+
+
+def test_append_rejects_samples_already_present(cli, tmp_path):
+    args, _ = C.CONFIGS["syn_mixed"]
+    files = C.build("syn_mixed", str(tmp_path / "in"))
+    base = str(tmp_path / "base.agc")
+    _create(cli, args, files[:3], base)
+    out = str(tmp_path / "o.agc")
+    r = subprocess.run([cli, "append", "-o", out, base, files[1], files[4]], capture_output=True, text=True, timeout=300)
+    assert "is already in the archive" in r.stderr and r.returncode == 0
+    from agc_amd import build, reader
+    build.build_read()
+    a = reader.CAGCFile()
+    assert a.Open(out) and a.NSample() == 4 and "m3" in a.ListSample()
+
+
+def test_append_to_missing_archive_reports_and_exits_zero(cli, tmp_path):
+    r = subprocess.run([cli, "append", "-o", str(tmp_path / "o.agc"), str(tmp_path / "none.agc"), __file__], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "Cannot open archive" in r.stderr
+
+
 def test_host_pipeline_is_thread_independent(cli, tmp_path):
     args, _ = C.CONFIGS["syn_adaptive"]
     files = C.build("syn_adaptive", str(tmp_path / "in"))
