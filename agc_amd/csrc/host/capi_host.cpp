@@ -49,6 +49,27 @@ int agc_cmp_add_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, con
     return ((CAGCCompressor *)h)->AddSampleDevice(sample_name, names, d_codes, ctg_off) ? 1 : 0;
 }
 
+// multi-GPU single-archive mode (compressor.h: SetDistributed / LastRecord / ApplyRecord)
+int agc_cmp_set_distributed(void *h, uint32_t rank, uint32_t world_size, uint32_t writer_rank)
+{
+    return ((CAGCCompressor *)h)->SetDistributed(rank, world_size, writer_rank) ? 1 : 0;
+}
+int agc_cmp_last_record(void *h, const uint8_t **ptr, uint64_t *n)
+{
+    const std::vector<uint8_t> &r = ((CAGCCompressor *)h)->LastRecord();
+    *ptr = r.data();
+    *n = r.size();
+    return 1;
+}
+int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record)
+{
+    return ((CAGCCompressor *)h)->ApplyRecord(record, n, d_record) ? 1 : 0;
+}
+int agc_cmp_append(void *h, const char *in_archive, const char *out_archive, uint32_t verbosity, int concatenated, int adaptive, uint32_t n_threads)
+{
+    return ((CAGCCompressor *)h)->Append(in_archive, out_archive, verbosity, true, concatenated != 0, adaptive != 0, n_threads, 0.0) ? 1 : 0;
+}
+
 int agc_cmp_close(void *h, uint32_t n_threads) { return ((CAGCCompressor *)h)->Close(n_threads) ? 1 : 0; }
 
 const char *agc_cmp_zstd_version(void *h) { return ((CAGCCompressor *)h)->ZstdVersion(); }

@@ -120,6 +120,26 @@ struct Group { // CSegment, write side (src/common/segment.{h,cpp})
     }
 };
 
+struct SampleLists { // one registration: the items of every group it touches
+    std::vector<uint32_t> gids;               // groups touched, in order of first appearance
+    std::vector<std::vector<uint32_t>> lists; // items per group (indices into placed), in (contig name, part) order
+};
+
+// what store_segments' bookkeeping needs about the committed registrations (filled by process_batch on the rank that
+// classified them, or rebuilt from a commit record on the other ranks of a multi-GPU job)
+struct CommitData {
+    const std::vector<Contig> *ctgs = nullptr;
+    const std::vector<Placed> *placed = nullptr;
+    uint32_t commit_upto = 0;
+    std::vector<SampleLists> per_sample;
+    std::vector<uint32_t> new_ref_items, raw_items, enc_items; // placed indices
+    std::vector<uint8_t> repetitive;                           // per new_ref_items entry (segment.h:224-247)
+    const bytes_t *fetched = nullptr;                          // new references, then raw items
+    std::vector<uint64_t> fetched_off;
+    const bytes_t *enc = nullptr;                              // deltas of enc_items
+    std::vector<uint64_t> enc_off;
+};
+
 struct ZJob { // one archive part to produce
     int stream_id;
     int kind;          // 0 = reference (tuples/zstd13 or zstd19), 1 = pack (zstd17)
@@ -385,7 +405,7 @@ struct CAGCCompressor::Impl {
     std::unordered_map<uint64_t, std::vector<uint64_t>> terminators;          // agc_compressor.h:629
     std::vector<Group> groups;                                                // v_segments
     uint32_t no_segments = 0;
-    uint32_t processed_samples = 0;
+    uint32_t processed_samples = 0, stored_samples = 0;
     size_t cnt_contigs_in_sample = 0;
 
     CompressorStats st;
@@ -410,6 +430,13 @@ struct CAGCCompressor::Impl {
     // classifies all contigs (one or several consecutive samples) against the current state and commits the
     // leading samples whose classification is certainly valid; n_committed = number of samples done
     bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, uint32_t &n_committed);
+    bool book_and_store(CommitData &cd);
+    // multi-GPU single-archive mode: one registration at a time, committed on every rank from the owner's record
+    uint32_t dist_rank = 0, dist_world = 1, dist_writer = 0;
+    bytes_t dist_record;
+    void make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters);
+    bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec);
+    void note_new_group(const pk_t &pk, uint32_t gid);
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
@@ -442,6 +469,23 @@ bool CAGCCompressor::SetDevice(int device)
 const CompressorStats &CAGCCompressor::Stats() const { return p->st; }
 const char *CAGCCompressor::ZstdVersion() const { return p->zstd.h ? p->zstd.versionString() : ""; }
 agc_hip_ctx *CAGCCompressor::HipContext() { return p->hip; }
+
+bool CAGCCompressor::SetDistributed(uint32_t rank, uint32_t world_size, uint32_t writer_rank)
+{
+    if (p->created || !world_size || rank >= world_size || writer_rank >= world_size)
+        return false;
+    p->dist_rank = rank;
+    p->dist_world = world_size;
+    p->dist_writer = writer_rank;
+    return true;
+}
+const std::vector<uint8_t> &CAGCCompressor::LastRecord() const { return p->dist_record; }
+bool CAGCCompressor::ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record)
+{
+    if (!p->created || p->dist_world < 2 || p->appending || p->concatenated)
+        return false;
+    return p->apply_record(record, n, d_record);
+}
 
 // determine_splitters for a reference genome that already lives in HBM (bench.py)
 bool CAGCCompressor::SetReferenceDevice(const uint8_t *d_codes, const uint64_t *ctg_off, uint32_t n_ctg)
@@ -935,8 +979,10 @@ void CAGCCompressor::Impl::after_registration()
         if (max_ps < processed_samples)
             processed_samples = max_ps;
     }
-    if (processed_samples % pack_cardinality == 0)
+    if (processed_samples % pack_cardinality == 0) {
         coll.store_contig_batch(processed_samples - pack_cardinality, processed_samples);
+        stored_samples = processed_samples;
+    }
     ar.flush_out_buffers();
 }
 
@@ -987,6 +1033,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     n_committed = 0;
     const uint32_t n_ctg = (uint32_t)ctgs.size();
     double t0 = now();
+    std::vector<uint64_t> new_splitters_added;
 
     // ---- stage 1a: splitter scan on the GPU (compress_contig's loop) ----
     std::vector<uint64_t> ctg_off(n_ctg + 1, 0);
@@ -1055,6 +1102,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 splitters.erase(std::unique(splitters.begin(), splitters.end()), splitters.end());
                 if (!hip_ok(agc_hip_splitters_insert(hip, add.data(), add.size()), "splitters_insert"))
                     return false;
+                new_splitters_added = add;
                 // second scan with the extended set; only the deferred contigs take its hits
                 std::vector<uint32_t> c2;
                 std::vector<uint64_t> p2, d2, r2;
@@ -1507,10 +1555,6 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     }
     // per sample: lists of items per group, raw groups by distribute_segments(0, 0, 16) on the sorted
     // list of group 0 (agc_compressor.h:417-435)
-    struct SampleLists {
-        std::vector<uint32_t> gids;               // groups touched, in order of first appearance
-        std::vector<std::vector<uint32_t>> lists; // items per group, sorted
-    };
     std::vector<SampleLists> per_sample(commit_upto);
     {
         size_t pos = 0;
@@ -1573,27 +1617,11 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 if (groups[gid].packed && !unpack_group(gid))
                     return false;
     // map_segments / terminators updates happen when a group is first stored (:1003-1028)
-    for (uint32_t idx : new_ref_items) {
-        const Placed &pl = placed[idx];
-        const uint32_t gid = (uint32_t)pl.gid;
-        auto it = map_segments.find(pl.pk);
-        if (it == map_segments.end())
-            map_segments[pl.pk] = (int32_t)gid;
-        else if (it->second > (int32_t)gid)
-            it->second = (int32_t)gid;
-        if (pl.pk.first != NO_KMER && pl.pk.second != NO_KMER) {
-            auto &v1 = terminators[pl.pk.first];
-            v1.push_back(pl.pk.second);
-            std::sort(v1.begin(), v1.end());
-            if (pl.pk.first != pl.pk.second) {
-                auto &v2 = terminators[pl.pk.second];
-                v2.push_back(pl.pk.first);
-                std::sort(v2.begin(), v2.end());
-            }
-        }
-    }
+    for (uint32_t idx : new_ref_items)
+        note_new_group(placed[idx].pk, (uint32_t)placed[idx].gid);
     // GPU: register the new references (index build) and pull back what the host must pack
     std::vector<uint32_t> lag_cnt, lag_cur;
+    std::vector<uint8_t> repetitive;
     bytes_t &fetched = fetch_buf;
     std::vector<uint64_t> fetched_off;
     {
@@ -1616,6 +1644,23 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             lag_cur.resize(nr * 28);
             if (!hip_ok(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data()), "ref_lag_counts"))
                 return false;
+            // repetitiveness probe with the reference's double arithmetic (segment.h:224-247)
+            repetitive.resize(nr);
+            for (size_t fi = 0; fi < nr; ++fi) {
+                double best_frac = 0.0;
+                for (uint32_t l = 0; l < 28; ++l) {
+                    const uint32_t cnt = lag_cnt[fi * 28 + l], cur = lag_cur[fi * 28 + l];
+                    double frac = 0.0;
+                    if (cur)
+                        frac = (double)cnt / cur;
+                    if (frac > best_frac) {
+                        best_frac = frac;
+                        if (best_frac >= 0.5)
+                            break;
+                    }
+                }
+                repetitive[fi] = !(best_frac < 0.5);
+            }
         }
         const size_t nf = nr + raw_items.size();
         if (nf) {
@@ -1676,6 +1721,38 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     st.t_encode += now() - t0;
     t0 = now();
 
+    CommitData cdta;
+    cdta.ctgs = &ctgs;
+    cdta.placed = &placed;
+    cdta.commit_upto = commit_upto;
+    cdta.per_sample = std::move(per_sample);
+    cdta.new_ref_items = std::move(new_ref_items);
+    cdta.raw_items = std::move(raw_items);
+    cdta.enc_items = std::move(enc_items);
+    cdta.repetitive = std::move(repetitive);
+    cdta.fetched = &fetched;
+    cdta.fetched_off = std::move(fetched_off);
+    cdta.enc = &enc;
+    cdta.enc_off = std::move(enc_off);
+    if (dist_world > 1) {
+        make_record(cdta, new_splitters_added);
+        if (dist_rank != dist_writer)
+            return true; // the writer rank does the bookkeeping from the record
+    }
+    return book_and_store(cdta);
+}
+
+// store_segments, second half (agc_compressor.cpp:989-1050): per-group bookkeeping, zstd parts, collection records
+bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
+{
+    double t0 = now();
+    const std::vector<Contig> &ctgs = *cdta.ctgs;
+    const std::vector<Placed> &placed = *cdta.placed;
+    const uint32_t n_ctg = (uint32_t)ctgs.size(), commit_upto = cdta.commit_upto;
+    std::vector<SampleLists> &per_sample = cdta.per_sample;
+    const std::vector<uint32_t> &new_ref_items = cdta.new_ref_items, &raw_items = cdta.raw_items, &enc_items = cdta.enc_items;
+    const bytes_t &fetched = *cdta.fetched, &enc = *cdta.enc;
+    const std::vector<uint64_t> &fetched_off = cdta.fetched_off, &enc_off = cdta.enc_off;
     // (b) per sample, per group, in list order: CSegment::add / add_raw (segment.cpp:14-80); then the sample's
     // zstd jobs, collection records and the end-of-registration steps
     std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size()), pos_enc(placed.size());
@@ -1728,20 +1805,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                         j.stream_id = g.stream_ref;
                         j.kind = 0;
                         j.data.assign(fetched.begin() + fetched_off[fi], fetched.begin() + fetched_off[fi + 1]);
-                        // repetitiveness probe with the reference's double arithmetic (segment.h:224-247)
-                        double best_frac = 0.0;
-                        for (uint32_t l = 0; l < 28; ++l) {
-                            const uint32_t cnt = lag_cnt[fi * 28 + l], cur = lag_cur[fi * 28 + l];
-                            double frac = 0.0;
-                            if (cur)
-                                frac = (double)cnt / cur;
-                            if (frac > best_frac) {
-                                best_frac = frac;
-                                if (best_frac >= 0.5)
-                                    break;
-                            }
-                        }
-                        j.repetitive = !(best_frac < 0.5);
+                        j.repetitive = cdta.repetitive[fi] != 0;
                         jobs.emplace_back(std::move(j));
                         g.ref_size = (uint64_t)pl.len + 1;
                         g.no_seqs = 1;
@@ -1805,6 +1869,311 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     return true;
 }
 
+// store_segments' update of map_segments (keep the smaller id) and of the terminator lists, agc_compressor.cpp:1003-1028
+void CAGCCompressor::Impl::note_new_group(const pk_t &pk, uint32_t gid)
+{
+    auto it = map_segments.find(pk);
+    if (it == map_segments.end())
+        map_segments[pk] = (int32_t)gid;
+    else if (it->second > (int32_t)gid)
+        it->second = (int32_t)gid;
+    if (pk.first != NO_KMER && pk.second != NO_KMER) {
+        auto &v1 = terminators[pk.first];
+        v1.push_back(pk.second);
+        std::sort(v1.begin(), v1.end());
+        if (pk.first != pk.second) {
+            auto &v2 = terminators[pk.second];
+            v2.push_back(pk.first);
+            std::sort(v2.begin(), v2.end());
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU single-archive mode.  Samples are dealt round-robin to the ranks; every rank keeps the
+// whole classification state (splitters, (k1,k2) -> group map, terminators, references in its HBM).  The owner of a
+// sample classifies and encodes it (process_batch), then publishes a COMMIT RECORD: contig names, new splitters and,
+// group by group in registration order, every placed item with its payload (symbols of a new reference -- the
+// "newly-minted reference segments" every GPU needs --, raw symbols, or the delta).  All other ranks apply the
+// record (apply_record): same group ids, same map/terminator updates, references registered in their own HBM;
+// the writer rank also runs the bookkeeping / zstd / archive stage from it.  Samples are committed strictly in
+// order, so the archive equals the single-GPU one byte for byte.
+// Record layout (little endian): "AGCR" | n_ctg | n_lists | n_new_splitters | first_new_gid | n_new_groups |
+//   contigs: sample\0 name\0 ... | splitters u64... | lists: gid, n_items, items: ctg, part_no, len, rc, kind,
+//   [pk1, pk2, repetitive for kind 0], payload_len, payload
+// ---------------------------------------------------------------------------
+namespace {
+void put32(bytes_t &d, uint32_t x)
+{
+    for (int i = 0; i < 4; ++i, x >>= 8)
+        d.push_back((uint8_t)(x & 0xff));
+}
+void put64(bytes_t &d, uint64_t x)
+{
+    for (int i = 0; i < 8; ++i, x >>= 8)
+        d.push_back((uint8_t)(x & 0xff));
+}
+struct RecReader {
+    const uint8_t *p, *e;
+    bool ok = true;
+    bool need(size_t n)
+    {
+        if ((size_t)(e - p) < n)
+            ok = false;
+        return ok;
+    }
+    uint32_t u32()
+    {
+        if (!need(4))
+            return 0;
+        uint32_t x = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        p += 4;
+        return x;
+    }
+    uint64_t u64()
+    {
+        const uint64_t lo = u32(), hi = u32();
+        return lo | (hi << 32);
+    }
+    uint8_t u8() { return need(1) ? *p++ : 0; }
+    std::string str()
+    {
+        const uint8_t *q = p;
+        while (q < e && *q)
+            ++q;
+        if (q >= e) {
+            ok = false;
+            return std::string();
+        }
+        std::string r((const char *)p, (size_t)(q - p));
+        p = q + 1;
+        return r;
+    }
+};
+} // namespace
+
+void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters)
+{
+    const std::vector<Contig> &ctgs = *cd.ctgs;
+    const std::vector<Placed> &placed = *cd.placed;
+    bytes_t &r = dist_record;
+    r.clear();
+    r.insert(r.end(), {'A', 'G', 'C', 'R'});
+    put32(r, (uint32_t)ctgs.size());
+    const SampleLists &sl = cd.per_sample.at(0); // one registration per record
+    put32(r, (uint32_t)sl.lists.size());
+    put32(r, (uint32_t)new_splitters.size());
+    uint32_t first_new = ~0u, n_new = 0;
+    for (uint32_t idx : cd.new_ref_items) {
+        first_new = std::min(first_new, (uint32_t)placed[idx].gid);
+        ++n_new;
+    }
+    put32(r, first_new);
+    put32(r, n_new);
+    for (auto &c : ctgs) {
+        r.insert(r.end(), c.sample.begin(), c.sample.end());
+        r.push_back(0);
+        r.insert(r.end(), c.name.begin(), c.name.end());
+        r.push_back(0);
+    }
+    for (uint64_t x : new_splitters)
+        put64(r, x);
+    std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size()), pos_enc(placed.size());
+    for (uint32_t i = 0; i < cd.new_ref_items.size(); ++i)
+        pos_newref[cd.new_ref_items[i]] = i;
+    for (uint32_t i = 0; i < cd.raw_items.size(); ++i)
+        pos_raw[cd.raw_items[i]] = i;
+    for (uint32_t i = 0; i < cd.enc_items.size(); ++i)
+        pos_enc[cd.enc_items[i]] = i;
+    std::vector<uint8_t> kind(placed.size(), 2);
+    for (uint32_t idx : cd.new_ref_items)
+        kind[idx] = 0;
+    for (uint32_t idx : cd.raw_items)
+        kind[idx] = 1;
+    for (size_t li = 0; li < sl.lists.size(); ++li) {
+        put32(r, sl.gids[li]);
+        put32(r, (uint32_t)sl.lists[li].size());
+        for (uint32_t idx : sl.lists[li]) {
+            const Placed &pl = placed[idx];
+            put32(r, pl.ctg);
+            put32(r, pl.part_no);
+            put32(r, pl.len);
+            r.push_back((uint8_t)pl.rc);
+            r.push_back(kind[idx]);
+            const uint8_t *b;
+            size_t n;
+            if (kind[idx] == 0) {
+                put64(r, pl.pk.first);
+                put64(r, pl.pk.second);
+                const uint32_t fi = pos_newref[idx];
+                r.push_back(cd.repetitive[fi]);
+                b = cd.fetched->data() + cd.fetched_off[fi];
+                n = cd.fetched_off[fi + 1] - cd.fetched_off[fi];
+            } else if (kind[idx] == 1) {
+                const uint32_t fi = (uint32_t)cd.new_ref_items.size() + pos_raw[idx];
+                b = cd.fetched->data() + cd.fetched_off[fi];
+                n = cd.fetched_off[fi + 1] - cd.fetched_off[fi];
+            } else {
+                const uint32_t ei = pos_enc[idx];
+                b = cd.enc->data() + cd.enc_off[ei];
+                n = cd.enc_off[ei + 1] - cd.enc_off[ei];
+            }
+            put32(r, (uint32_t)n);
+            r.insert(r.end(), b, b + n);
+        }
+    }
+    // the owner keeps what later classifications read of its new groups (book_and_store does it on the writer)
+    if (dist_rank != dist_writer)
+        for (uint32_t idx : cd.new_ref_items) {
+            Group &g = groups[(uint32_t)placed[idx].gid];
+            g.exists = true;
+            g.ref_size = (uint64_t)placed[idx].len + 1;
+        }
+}
+
+bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec)
+{
+    RecReader rr{rec, rec + n};
+    if (n < 24 || memcmp(rec, "AGCR", 4) != 0) {
+        err("bad commit record");
+        return false;
+    }
+    rr.p += 4;
+    const uint32_t n_ctg = rr.u32(), n_lists = rr.u32(), n_spl = rr.u32(), first_new = rr.u32(), n_new = rr.u32();
+    std::vector<Contig> ctgs(n_ctg);
+    for (auto &c : ctgs) {
+        c.sample = rr.str();
+        c.name = rr.str();
+        c.sample_idx = 0;
+    }
+    std::vector<uint64_t> add(n_spl);
+    for (auto &x : add)
+        x = rr.u64();
+    if (!rr.ok) {
+        err("truncated commit record");
+        return false;
+    }
+    const bool writer = dist_rank == dist_writer;
+    if (!add.empty()) { // adaptive mode: the owner's new splitters (agc_compressor.cpp:1191-1209)
+        splitters.insert(splitters.end(), add.begin(), add.end());
+        std::sort(splitters.begin(), splitters.end());
+        splitters.erase(std::unique(splitters.begin(), splitters.end()), splitters.end());
+        if (!hip_ok(agc_hip_splitters_insert(hip, add.data(), add.size()), "splitters_insert"))
+            return false;
+    }
+    if (writer) {
+        coll.reset_prev_sample_name();
+        for (auto &c : ctgs)
+            if (!coll.register_sample_contig(c.sample, c.name)) {
+                err("Error: Pair sample_name:contig_name " + c.sample + ":" + c.name + " is already in the archive!");
+                return false;
+            }
+    }
+    if (n_new) {
+        if (first_new != no_segments) {
+            err("commit record out of order: new groups start at " + std::to_string(first_new) + ", expected " + std::to_string(no_segments));
+            return false;
+        }
+        for (uint32_t i = 0; i < n_new; ++i) {
+            groups.emplace_back();
+            Group &g = groups.back();
+            g.stream_ref = ar.register_stream(ss_ref_name(no_segments + i));
+            g.stream_delta = ar.register_stream(ss_delta_name(no_segments + i));
+        }
+        no_segments += n_new;
+        st.new_groups += n_new;
+    }
+    std::vector<Placed> placed;
+    CommitData cd;
+    cd.commit_upto = 1;
+    cd.per_sample.resize(1);
+    SampleLists &sl = cd.per_sample[0];
+    bytes_t refs_raw, raws, enc;
+    std::vector<uint64_t> ref_off{0}, raw_off{0};
+    cd.enc_off.push_back(0);
+    std::vector<uint32_t> reg_gid, reg_len;
+    std::vector<uint64_t> reg_off; // payload offsets inside the record (device copy)
+    for (uint32_t li = 0; li < n_lists && rr.ok; ++li) {
+        const uint32_t gid = rr.u32(), cnt = rr.u32();
+        sl.gids.push_back(gid);
+        sl.lists.emplace_back();
+        for (uint32_t i = 0; i < cnt && rr.ok; ++i) {
+            Placed pl;
+            pl.ctg = rr.u32();
+            pl.part_no = rr.u32();
+            pl.len = rr.u32();
+            pl.rc = rr.u8() != 0;
+            const uint8_t kind = rr.u8();
+            pl.gid = (int32_t)gid;
+            pl.off = 0;
+            uint8_t rep = 0;
+            if (kind == 0) {
+                pl.pk.first = rr.u64();
+                pl.pk.second = rr.u64();
+                rep = rr.u8();
+            }
+            const uint32_t pn = rr.u32();
+            if (!rr.need(pn) || pl.ctg >= n_ctg || gid >= groups.size())
+                break;
+            const uint32_t idx = (uint32_t)placed.size();
+            if (kind == 0) {
+                cd.new_ref_items.push_back(idx);
+                cd.repetitive.push_back(rep);
+                refs_raw.insert(refs_raw.end(), rr.p, rr.p + pn);
+                ref_off.push_back(refs_raw.size());
+                reg_gid.push_back(gid);
+                reg_len.push_back(pn);
+                reg_off.push_back((uint64_t)(rr.p - rec));
+                note_new_group(pl.pk, gid);
+                groups[gid].exists = !writer; // the writer's bookkeeping turns it on (first item = reference)
+                groups[gid].ref_size = (uint64_t)pn + 1;
+            } else if (kind == 1) {
+                cd.raw_items.push_back(idx);
+                raws.insert(raws.end(), rr.p, rr.p + pn);
+                raw_off.push_back(raws.size());
+            } else {
+                cd.enc_items.push_back(idx);
+                enc.insert(enc.end(), rr.p, rr.p + pn);
+                cd.enc_off.push_back(enc.size());
+            }
+            rr.p += pn;
+            sl.lists.back().push_back(idx);
+            placed.push_back(pl);
+        }
+    }
+    if (!rr.ok || rr.p != rr.e) {
+        err("malformed commit record");
+        return false;
+    }
+    st.segments += placed.size();
+    // the newly minted references go to this rank's HBM (from the device copy of the record when there is one)
+    if (!reg_gid.empty()) {
+        if (d_rec) {
+            if (!hip_ok(agc_hip_ref_register_batch_dev(hip, (uint32_t)reg_gid.size(), reg_gid.data(), d_rec, reg_off.data(), reg_len.data(), nullptr, mml),
+                        "ref_register_batch"))
+                return false;
+        } else
+            for (size_t i = 0; i < reg_gid.size(); ++i)
+                if (!hip_ok(agc_hip_ref_register(hip, reg_gid[i], rec + reg_off[i], reg_len[i], mml), "ref_register"))
+                    return false;
+    }
+    if (!writer)
+        return true;
+    // fetched = new references, then raw items (the layout book_and_store indexes)
+    bytes_t fetched;
+    fetched.reserve(refs_raw.size() + raws.size());
+    fetched.insert(fetched.end(), refs_raw.begin(), refs_raw.end());
+    fetched.insert(fetched.end(), raws.begin(), raws.end());
+    cd.fetched_off = ref_off;
+    for (size_t i = 1; i < raw_off.size(); ++i)
+        cd.fetched_off.push_back(refs_raw.size() + raw_off[i]);
+    cd.ctgs = &ctgs;
+    cd.placed = &placed;
+    cd.fetched = &fetched;
+    cd.enc = &enc;
+    return book_and_store(cd);
+}
+
 // CSegment::finish for every group (agc_compressor.cpp:880-904, segment.cpp:125-133)
 void CAGCCompressor::Impl::finish_groups()
 {
@@ -1865,6 +2234,7 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     if (files.empty())
         return true;
     I.processed_samples = I.appending ? (uint32_t)I.coll.no_samples() : 0; // agc_compressor.cpp:2150-2153
+    I.stored_samples = I.processed_samples / I.pack_cardinality * I.pack_cardinality;
     if (I.concatenated)
         I.cnt_contigs_in_sample = I.processed_samples % I.pack_cardinality;
 
@@ -1998,8 +2368,10 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         I.processed_samples = (uint32_t)I.coll.no_samples();
     } else if (!drain())
         return false;
-    if (I.processed_samples % I.pack_cardinality != 0)
+    if (I.processed_samples % I.pack_cardinality != 0) {
         I.coll.store_contig_batch((I.processed_samples / I.pack_cardinality) * I.pack_cardinality, I.processed_samples);
+        I.stored_samples = I.processed_samples;
+    }
     I.ar.flush_out_buffers();
     return true;
 }
@@ -2011,6 +2383,13 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     (void)no_threads;
     if (!I.created)
         return false;
+    // samples that came through AddSampleDevice / ApplyRecord: the open collection batch is stored here, where
+    // AddSampleFiles does it at its end (agc_compressor.cpp:2254-2255)
+    if (I.stored_samples < I.processed_samples && I.processed_samples % I.pack_cardinality != 0) {
+        I.coll.store_contig_batch((I.processed_samples / I.pack_cardinality) * I.pack_cardinality, I.processed_samples);
+        I.stored_samples = I.processed_samples;
+        I.ar.flush_out_buffers();
+    }
     I.finish_groups();
     I.ar.flush_out_buffers();
 

@@ -70,6 +70,15 @@ public:
     bool AddSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
                          const uint64_t *ctg_off);
 
+    // ---- multi-GPU single-archive mode (protocol in compressor.cpp above make_record) ----
+    // Call before Create on every rank; only the writer rank should be given a real archive name.  Afterwards every sample
+    // must reach every rank, in the same order: AddSampleDevice on its owner (then LastRecord is what the other ranks
+    // need), ApplyRecord everywhere else.  d_record = optional copy of the record in this rank's HBM (e.g. the buffer an
+    // RCCL broadcast delivered): the newly minted references are then registered from there without a host round trip.
+    bool SetDistributed(uint32_t rank, uint32_t world_size, uint32_t writer_rank);
+    const std::vector<uint8_t> &LastRecord() const;
+    bool ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record);
+
     // src/core/agc_compressor.cpp:2094-2115 (close_compression) + ~CArchive
     bool Close(uint32_t no_threads);
 

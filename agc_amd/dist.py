@@ -1,0 +1,66 @@
+"""Multi-GPU `create` into ONE archive: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests).
+
+Samples are dealt round-robin (sample i belongs to rank i mod N).  Every rank keeps the complete classification state --
+splitters, the (k1,k2) -> group map, terminator lists and all group references in its own HBM -- so any rank can scan,
+classify and LZ-encode any sample.  What orders the job is the reference's registration contract (group ids are minted
+first-come in sample order, agc_compressor.cpp:954-1050): samples are therefore COMMITTED in order.  Per sample:
+
+    owner:   add_sample_dev()            scan + classification + LZ-encode on its GPU, commit record built
+    all:     broadcast(record)           one collective per sample: length, then the bytes (uint8 tensor on the backend's device)
+    others:  apply_record(record)        same group ids / map / terminator updates; the newly minted reference segments inside the
+                                         record are registered in this rank's HBM straight from the broadcast buffer
+    writer:  (inside add/apply)          bookkeeping, zstd parts, collection metadata, archive
+
+The record carries the symbols of every new reference (the "all-gather of newly-minted reference segments" of the north
+star -- a broadcast from the minting rank, since exactly one rank mints at a time), the raw segments and the deltas
+(~16 B per SNP), i.e. MBs per human-size sample.  The archive is byte-identical to the single-GPU / reference one.
+
+Not covered in this mode: -c (concatenated) and append.
+"""
+import numpy as np
+
+
+class DistCompressor:
+    """wraps an agc_amd.host.Compressor that was given set_distributed(rank, world, writer) before create()"""
+
+    def __init__(self, cmp_, dist, rank, world, device=None, writer=0):
+        import torch
+        self.torch = torch
+        self.cmp = cmp_
+        self.dist = dist
+        self.rank, self.world, self.writer = rank, world, writer
+        self.device = device if device is not None else torch.device("cpu")
+        self.next_sample = 0
+        self.bytes_broadcast = 0
+
+    def owner_of(self, i):
+        return i % self.world
+
+    def add_sample(self, sample_name=None, contig_names=None, d_codes=None, ctg_off=None):
+        """SPMD: every rank calls this once per sample, in the same order; only the owner passes the data."""
+        torch, dist = self.torch, self.dist
+        i = self.next_sample
+        self.next_sample += 1
+        owner = self.owner_of(i)
+        n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        if self.rank == owner:
+            self.cmp.add_sample_dev(sample_name, contig_names, d_codes, ctg_off)
+            rec = self.cmp.last_record()
+            n[0] = rec.size
+        dist.broadcast(n, src=owner)
+        size = int(n.item())
+        if self.rank == owner:
+            buf = torch.from_numpy(rec).to(self.device)
+        else:
+            buf = torch.empty(size, dtype=torch.uint8, device=self.device)
+        dist.broadcast(buf, src=owner)
+        self.bytes_broadcast += size
+        if self.rank != owner:
+            if buf.is_cuda:
+                host = buf.cpu().numpy()      # parsed on the host; the references are registered from the HBM copy
+                self.cmp.apply_record(host.ctypes.data, size, buf.data_ptr())
+            else:
+                host = np.ascontiguousarray(buf.numpy())
+                self.cmp.apply_record(host.ctypes.data, size, None)
+        return owner

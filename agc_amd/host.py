@@ -17,14 +17,8 @@ STAT_NAMES = ["bases", "segments", "new_groups", "one_splitter", "middle_tried",
 _lib = None
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    capi.load()  # torch first, then libagc_hip.so (one HIP runtime per process)
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m agc_amd.build`")
-    L = C.CDLL(LIB_PATH)
+def bind(L):
+    """declares the argument types of the agc_cmp_* entry points (agc_amd/csrc/host/capi_host.cpp) on a loaded library"""
     vp = C.c_void_p
     L.agc_cmp_new.restype = vp
     L.agc_cmp_new.argtypes = [C.c_int]
@@ -42,13 +36,28 @@ def load():
     L.agc_cmp_hip_ctx.argtypes = [vp]
     L.agc_cmp_hip_ctx.restype = vp
     L.agc_cmp_stats.argtypes = [vp, C.POINTER(C.c_double), C.c_uint32]
-    _lib = L
+    L.agc_cmp_set_distributed.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.agc_cmp_last_record.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+    L.agc_cmp_apply_record.argtypes = [vp, vp, C.c_uint64, vp]
+    L.agc_cmp_append.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32]
     return L
 
 
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    capi.load()  # torch first, then libagc_hip.so (one HIP runtime per process)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m agc_amd.build`")
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
 class Compressor:
-    def __init__(self, device=0):
-        self.L = load()
+    def __init__(self, device=0, lib=None):
+        """lib: an already bound library (bind()); default = the in-tree libagc_host.so on top of libagc_hip.so"""
+        self.L = lib if lib is not None else load()
         self.h = self.L.agc_cmp_new(device)
 
     def close_handle(self):
@@ -90,6 +99,26 @@ class Compressor:
         off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
         if not self.L.agc_cmp_add_sample_dev(self.h, sample_name.encode(), n, names, d_codes, off.ctypes.data_as(C.POINTER(C.c_uint64))):
             raise RuntimeError("AddSampleDevice failed (see stderr)")
+
+    def append(self, in_archive, out_path, concatenated=False, adaptive=False, verbosity=0, n_threads=8):
+        if not self.L.agc_cmp_append(self.h, in_archive.encode(), (out_path or "").encode(), verbosity, int(concatenated), int(adaptive), n_threads):
+            raise RuntimeError("CAGCCompressor::Append failed (see stderr)")
+
+    # ---- multi-GPU single-archive mode (agc_amd/dist.py drives these) ----
+    def set_distributed(self, rank, world_size, writer_rank=0):
+        if not self.L.agc_cmp_set_distributed(self.h, rank, world_size, writer_rank):
+            raise RuntimeError("SetDistributed failed (must precede create)")
+
+    def last_record(self):
+        """the commit record of the sample just added (numpy uint8 view copied out of the compressor)"""
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        self.L.agc_cmp_last_record(self.h, C.byref(p), C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+
+    def apply_record(self, h_ptr, n, d_ptr=None):
+        if not self.L.agc_cmp_apply_record(self.h, h_ptr, n, d_ptr):
+            raise RuntimeError("ApplyRecord failed (see stderr)")
 
     def close(self, n_threads=8):
         if not self.L.agc_cmp_close(self.h, n_threads):

@@ -1,0 +1,100 @@
+"""Multi-GPU single-archive protocol (agc_amd/dist.py) on CPU: gloo, world size 2 and 3, every rank driving the
+host pipeline through the CPU device stand-in (tests/devsim).  The one archive the writer rank produces must equal the
+reference CLI's `create` output for the same files (recorded sha256), i.e. the ordered commit of samples classified on
+different ranks -- with the newly minted references travelling inside the broadcast records -- loses nothing."""
+import ctypes as C
+import hashlib
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import collections as COLL
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "archives.json")))
+
+_CNV = np.full(256, 30, np.uint8)
+_CNV[64] = _CNV[96] = 32
+for _i, _c in enumerate("ACGTNRYSWKMBDHVU"):
+    _CNV[ord(_c)] = _CNV[ord(_c) + 32] = _i
+
+
+def fasta_codes(path):
+    """(contig names, symbol codes back to back, offsets) the way the host reads a FASTA file"""
+    names, seqs = [], []
+    for rec in open(path, "rb").read().split(b">")[1:]:
+        head, _, body = rec.partition(b"\n")
+        names.append(head.rstrip(b"\r").decode())
+        b = np.frombuffer(body, np.uint8)
+        seqs.append(_CNV[b[b >= 64]])
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([s.size for s in seqs])
+    return names, np.concatenate(seqs) if seqs else np.zeros(0, np.uint8), off
+
+
+def _worker(rank, world, port, name, files, out_path, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from agc_amd import host
+        from agc_amd.dist import DistCompressor
+        from tests.devsim import build as simbuild
+        lib = host.bind(C.CDLL(simbuild.SIM_HOST))  # host pipeline on the device stand-in (never the product library here)
+        args, _ = COLL.CONFIGS[name]
+        opt = {"-k": 31, "-l": 20, "-s": 60000, "-b": 50}
+        for i in range(0, len(args) - 1):
+            if args[i] in opt:
+                opt[args[i]] = int(args[i + 1])
+        cmp_ = host.Compressor(lib=lib)
+        cmp_.set_distributed(rank, world, 0)
+        cmp_.create(out_path if rank == 0 else "", pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"],
+                    min_match_len=opt["-l"], adaptive="-a" in args, n_threads=2)
+        dc = DistCompressor(cmp_, dist, rank, world)
+        for i, f in enumerate(files):
+            if dc.owner_of(i) == rank:
+                names, codes, off = fasta_codes(f)
+                sn = os.path.basename(f)
+                for suf in (".gz", ".fa", ".fasta", ".fna"):
+                    sn = sn[:-len(suf)] if sn.endswith(suf) else sn
+                dc.add_sample(sn, names, codes.ctypes.data, off)
+            else:
+                dc.add_sample()
+        cmp_.close()
+        st = cmp_.stats()
+        cmp_.close_handle()
+        q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"]))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "error: %r" % (e,), 0, 0))
+
+
+@pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 2), ("syn_viral", 3), ("syn_shuffled", 2), ("syn_adaptive", 2),
+                                        ("syn_adaptive", 3), ("toy_c1", 2)])
+def test_one_archive_from_n_ranks_equals_the_reference(name, world, tmp_path):
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    files = COLL.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "dist.agc")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, name, files, out, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=300) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert all(r[1] == "ok" for r in res), res
+    got = open(out, "rb").read()
+    assert len(got) == GOLD[name]["size"]
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+    # every rank saw every record and minted the same groups
+    assert len({r[2] for r in res}) == 1 and res[0][2] > 0
+    assert len({r[3] for r in res}) == 1
