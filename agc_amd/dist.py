@@ -22,7 +22,9 @@ import numpy as np
 
 
 class DistCompressor:
-    """wraps an agc_amd.host.Compressor that was given set_distributed(rank, world, writer) before create()"""
+    """wraps an agc_amd.host.Compressor that was given set_distributed(rank, world, writer) before create().
+    device: this rank's GPU (torch.device) or None (CPU tests).  The collectives run on the GPU when the backend is nccl
+    (RCCL: the record never leaves HBM on its way between GPUs) and on host tensors otherwise (gloo)."""
 
     def __init__(self, cmp_, dist, rank, world, device=None, writer=0):
         import torch
@@ -30,7 +32,8 @@ class DistCompressor:
         self.cmp = cmp_
         self.dist = dist
         self.rank, self.world, self.writer = rank, world, writer
-        self.device = device if device is not None else torch.device("cpu")
+        self.hbm = device if device is not None and device.type == "cuda" else None
+        self.comm = self.hbm if (self.hbm is not None and dist.get_backend() == "nccl") else torch.device("cpu")
         self.next_sample = 0
         self.bytes_broadcast = 0
 
@@ -43,7 +46,7 @@ class DistCompressor:
         i = self.next_sample
         self.next_sample += 1
         owner = self.owner_of(i)
-        n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        n = torch.zeros(1, dtype=torch.int64, device=self.comm)
         if self.rank == owner:
             self.cmp.add_sample_dev(sample_name, contig_names, d_codes, ctg_off)
             rec = self.cmp.last_record()
@@ -51,16 +54,16 @@ class DistCompressor:
         dist.broadcast(n, src=owner)
         size = int(n.item())
         if self.rank == owner:
-            buf = torch.from_numpy(rec).to(self.device)
+            buf = torch.from_numpy(rec).to(self.comm)
         else:
-            buf = torch.empty(size, dtype=torch.uint8, device=self.device)
+            buf = torch.empty(size, dtype=torch.uint8, device=self.comm)
         dist.broadcast(buf, src=owner)
         self.bytes_broadcast += size
         if self.rank != owner:
-            if buf.is_cuda:
-                host = buf.cpu().numpy()      # parsed on the host; the references are registered from the HBM copy
-                self.cmp.apply_record(host.ctypes.data, size, buf.data_ptr())
-            else:
-                host = np.ascontiguousarray(buf.numpy())
-                self.cmp.apply_record(host.ctypes.data, size, None)
+            # parsed on the host; the new references are registered from the copy in this rank's HBM when there is one
+            host = np.ascontiguousarray(buf.cpu().numpy())
+            d_buf = buf if buf.is_cuda else (buf.to(self.hbm) if self.hbm is not None else None)
+            if d_buf is not None:
+                torch.cuda.synchronize(self.hbm)
+            self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None)
         return owner

@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--positional-splitters", action="store_true",
                     help="skip determine_splitters: take the k-mer at every segment_size-th position (valid for an i.i.d. reference)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for libzstd (default: all cores / n_gpus)")
+    ap.add_argument("--single-archive", action="store_true",
+                    help="N > 1: all ranks feed ONE archive (ordered commit from broadcast commit records, agc_amd/dist.py) instead of "
+                         "one archive shard per rank; rank 0 writes and runs libzstd with all host threads")
     return ap.parse_args()
 
 
@@ -151,10 +154,15 @@ def main():
     ref, off = synth_dev.make_reference(total, 12345, dev)
     tot = int(off[-1])
     names = [f"chr{i + 1}" for i in range(len(off) - 1)]
+    single = args.single_archive and world > 1
     threads = max(1, host_cpus() // world)
+    if single:  # the writer rank does all the zstd work, the others need a few host threads only
+        threads = max(1, host_cpus() - 2 * (world - 1)) if rank == 0 else 2
     if args.threads:
         threads = args.threads
     cmp_ = host.Compressor(local)
+    if single:
+        cmp_.set_distributed(rank, world, 0)
     # archive bytes are produced and discarded (out path ""): file I/O is not the path under test
     cmp_.create("", PACK, K, None, SEG, MML, n_threads=threads)
     # reference preprocessing (once per archive, not timed): the reference's determine_splitters on the GPU
@@ -167,8 +175,23 @@ def main():
     # the reference genome is the first sample of every archive (src/app/main.cpp:106-114): it mints the
     # groups and their references.  Once per archive -> setup, not part of the per-sample hot path.
     t_ref0 = time.perf_counter()
-    cmp_.add_sample_dev("ref", names, ref.data_ptr(), off)
+    dc = None
+    if single:
+        from agc_amd.dist import DistCompressor
+        dc = DistCompressor(cmp_, dist, rank, world, device=dev)
+        dc.add_sample(*(("ref", names, ref.data_ptr(), off) if rank == 0 else ()))  # sample 0: minted on rank 0, broadcast
+    else:
+        cmp_.add_sample_dev("ref", names, ref.data_ptr(), off)
     t_ref = time.perf_counter() - t_ref0
+
+    def add_step(s, tag):
+        """one step = one sample per GPU; in single-archive mode the N samples of a step are committed in rank order"""
+        if not single:
+            cmp_.add_sample_dev(f"{tag}{rank}_{s}", names, samples[s].data_ptr(), off)
+            return
+        for _ in range(world):
+            mine = dc.owner_of(dc.next_sample) == rank
+            dc.add_sample(*((f"{tag}{rank}_{s}", names, samples[s].data_ptr(), off) if mine else ()))
 
     n_steps = args.steps + args.warmup
     # weak scaling: samples are partitioned round-robin over ranks (one archive shard per rank), no data-path collective
@@ -182,13 +205,13 @@ def main():
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        cmp_.add_sample_dev(f"w{rank}_{s}", names, samples[s].data_ptr(), off)
+        add_step(s, "w")
     st0 = cmp_.stats()
     cmp_.hip_timing(True)  # HIP events on the library's stream around every kernel of the timed region
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, n_steps):
-        cmp_.add_sample_dev(f"s{rank}_{s}", names, samples[s].data_ptr(), off)
+        add_step(s, "s")
     t_steps = time.perf_counter() - t0
     # Close(): zstd of every pending delta pack + metadata + footer -- the deferred part of the steps' work
     cmp_.close(threads)
@@ -247,7 +270,10 @@ def main():
                        "new_groups_per_step": int(per(stats["new_groups"])), "delta_bytes_per_step": int(per(stats["delta_bytes"])),
                        "zstd": {"version": cmp_.zstd_version(), "host_threads": threads, "in_bytes": int(stats["zstd_in"]), "out_bytes": int(stats["zstd_out"])},
                        "host_stage_seconds_rank0": {k_: round(stats[k_], 4) for k_ in stats if k_.startswith("t_")},
-                       "parallelism": f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
+                       "parallelism": (f"samples round-robin over {world} GPUs into ONE archive: ordered commit, one RCCL broadcast of the commit "
+                                       f"record (new reference segments + deltas) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each; "
+                                       "rank 0 writes and runs libzstd") if single else
+                                      f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": kern.get(dominant, {}).get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(kern.get(dominant, {}).get("achieved", 0.0) / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -37,15 +37,21 @@ def fasta_codes(path):
     return names, np.concatenate(seqs) if seqs else np.zeros(0, np.uint8), off
 
 
-def _worker(rank, world, port, name, files, out_path, q):
+def _worker(rank, world, port, name, files, out_path, q, on_gpu=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from agc_amd import host
         from agc_amd.dist import DistCompressor
-        from tests.devsim import build as simbuild
-        lib = host.bind(C.CDLL(simbuild.SIM_HOST))  # host pipeline on the device stand-in (never the product library here)
+        device = None
+        if on_gpu:  # the product libraries and the real kernels; samples and records live in HBM
+            import torch
+            lib = host.load()
+            device = torch.device("cuda:0")
+        else:       # host pipeline on the device stand-in (never the product library here)
+            from tests.devsim import build as simbuild
+            lib = host.bind(C.CDLL(simbuild.SIM_HOST))
         args, _ = COLL.CONFIGS[name]
         opt = {"-k": 31, "-l": 20, "-s": 60000, "-b": 50}
         for i in range(0, len(args) - 1):
@@ -55,14 +61,19 @@ def _worker(rank, world, port, name, files, out_path, q):
         cmp_.set_distributed(rank, world, 0)
         cmp_.create(out_path if rank == 0 else "", pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"],
                     min_match_len=opt["-l"], adaptive="-a" in args, n_threads=2)
-        dc = DistCompressor(cmp_, dist, rank, world)
+        dc = DistCompressor(cmp_, dist, rank, world, device=device)
         for i, f in enumerate(files):
             if dc.owner_of(i) == rank:
                 names, codes, off = fasta_codes(f)
                 sn = os.path.basename(f)
                 for suf in (".gz", ".fa", ".fasta", ".fna"):
                     sn = sn[:-len(suf)] if sn.endswith(suf) else sn
-                dc.add_sample(sn, names, codes.ctypes.data, off)
+                if on_gpu:
+                    d_codes = torch.from_numpy(np.concatenate([codes, np.full(4096, 4, np.uint8)])).to(device)
+                    torch.cuda.synchronize()
+                    dc.add_sample(sn, names, d_codes.data_ptr(), off)
+                else:
+                    dc.add_sample(sn, names, codes.ctypes.data, off)
             else:
                 dc.add_sample()
         cmp_.close()
@@ -74,11 +85,7 @@ def _worker(rank, world, port, name, files, out_path, q):
         q.put((rank, "error: %r" % (e,), 0, 0))
 
 
-@pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 2), ("syn_viral", 3), ("syn_shuffled", 2), ("syn_adaptive", 2),
-                                        ("syn_adaptive", 3), ("toy_c1", 2)])
-def test_one_archive_from_n_ranks_equals_the_reference(name, world, tmp_path):
-    from tests.devsim import build as simbuild
-    simbuild.build()
+def _run(name, world, tmp_path, on_gpu):
     files = COLL.build(name, str(tmp_path / "in"))
     out = str(tmp_path / "dist.agc")
     s = socket.socket()
@@ -87,7 +94,7 @@ def test_one_archive_from_n_ranks_equals_the_reference(name, world, tmp_path):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, name, files, out, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, name, files, out, q, on_gpu)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted(q.get(timeout=300) for _ in ps)
     [p.join(timeout=60) for p in ps]
@@ -98,3 +105,22 @@ def test_one_archive_from_n_ranks_equals_the_reference(name, world, tmp_path):
     # every rank saw every record and minted the same groups
     assert len({r[2] for r in res}) == 1 and res[0][2] > 0
     assert len({r[3] for r in res}) == 1
+
+
+@pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 2), ("syn_viral", 3), ("syn_shuffled", 2), ("syn_adaptive", 2),
+                                        ("syn_adaptive", 3), ("toy_c1", 2)])
+def test_one_archive_from_n_ranks_equals_the_reference(name, world, tmp_path):
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    _run(name, world, tmp_path, on_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_adaptive", 2), ("syn_mixed", 3)])
+def test_one_archive_from_n_ranks_on_the_gpu(name, world, tmp_path):
+    """the same protocol with the product libraries: N processes share cuda:0 (gloo moves the HBM-resident records; on a multi-GPU
+    node the backend is nccl = RCCL, see bench.py --single-archive), real kernels on every rank, references registered from the
+    HBM copy of the record"""
+    from agc_amd import build
+    build.build_host()
+    _run(name, world, tmp_path, on_gpu=True)
