@@ -849,19 +849,49 @@ __global__ void __launch_bounds__(256) idx_insert_kernel(const IdxBuild *__restr
 // (reverse_complement_copy, src/common/agc_basic.cpp:282-315; prepare_gen padding,
 // src/common/lz_diff.cpp:48-53)
 // ---------------------------------------------------------------------------
+// complement of four packed symbols: c < 4 ? 3 - c : c  (3 - c == c ^ 3 for c in 0..3)
+__device__ __forceinline__ uint32_t comp4(uint32_t x)
+{
+    const uint32_t m = x & 0xFCFCFCFCu;                                              // non-zero byte <=> symbol >= 4
+    const uint32_t nz = (((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;       // bit 7 of every byte with symbol >= 4
+    const uint32_t lt4 = (nz ^ 0x80808080u) >> 7;                                    // 0x01 in every byte with symbol < 4
+    return x ^ (lt4 * 3u);
+}
+
+__device__ __forceinline__ uint8_t slice_byte(const SliceDesc &sd, uint32_t t)
+{
+    if (sd.rc) {
+        const uint8_t c = sd.src[sd.len - 1 - t];
+        return c < 4 ? (uint8_t)(3 - c) : c;
+    }
+    return sd.src[t];
+}
+
+// 16 bytes per thread: aligned 16-B stores, byte-aligned 16-B loads (mirrored source window for rc)
 __global__ void __launch_bounds__(256) slice_copy_kernel(const SliceDesc *__restrict__ jobs, uint32_t n_jobs)
 {
     for (uint32_t s = blockIdx.x; s < n_jobs; s += gridDim.x) {
         const SliceDesc sd = jobs[s];
-        for (uint32_t t = threadIdx.x; t < sd.len; t += blockDim.x) {
-            uint8_t c;
+        const uint32_t head = min(sd.len, (uint32_t)((16u - (uint32_t)((uintptr_t)sd.dst & 15u)) & 15u));
+        const uint32_t n_vec = (sd.len - head) >> 4;
+        const uint32_t tail = head + (n_vec << 4);
+        if (threadIdx.x < head)
+            sd.dst[threadIdx.x] = slice_byte(sd, threadIdx.x);
+        for (uint32_t v = threadIdx.x; v < n_vec; v += blockDim.x) {
+            const uint32_t t = head + (v << 4);
+            uint4 y;
             if (sd.rc) {
-                c = sd.src[sd.len - 1 - t];
-                c = c < 4 ? (uint8_t)(3 - c) : c;
+                const uint4 x = load16(sd.src + (sd.len - 16u - t)); // dst[t + j] = comp(src[len - 1 - t - j])
+                y.x = comp4(__builtin_bswap32(x.w));
+                y.y = comp4(__builtin_bswap32(x.z));
+                y.z = comp4(__builtin_bswap32(x.y));
+                y.w = comp4(__builtin_bswap32(x.x));
             } else
-                c = sd.src[t];
-            sd.dst[t] = c;
+                y = load16(sd.src + t);
+            *(uint4 *)(sd.dst + t) = y;
         }
+        for (uint32_t t = tail + threadIdx.x; t < sd.len; t += blockDim.x)
+            sd.dst[t] = slice_byte(sd, t);
         for (uint32_t t = threadIdx.x; t < sd.pad_len; t += blockDim.x)
             sd.dst[sd.len + t] = INVALID_SYMBOL;
     }
