@@ -83,7 +83,7 @@ int agc_cmp_stats(void *h, double *out, uint32_t n)
     const double v[] = {(double)s.bases, (double)s.segments, (double)s.new_groups, (double)s.one_splitter, (double)s.middle_tried,
                         (double)s.middle_split, (double)s.lz_encoded, (double)s.delta_bytes, (double)s.ref_bytes, (double)s.zstd_in,
                         (double)s.zstd_out, (double)s.archive_bytes, s.t_scan, s.t_classify, s.t_gpu_aux, s.t_register, s.t_encode,
-                        s.t_store, s.t_zstd, s.t_io};
+                        s.t_store, s.t_zstd, s.t_io, s.t_device, s.h_scan, s.h_classify, s.h_gpu_aux, s.h_register, s.h_encode, s.h_store};
     const uint32_t m = sizeof(v) / sizeof(v[0]);
     for (uint32_t i = 0; i < n && i < m; ++i)
         out[i] = v[i];

@@ -30,6 +30,12 @@ struct PairHash {
     }
 };
 
+// time spent inside the device library (kernels + copies + syncs), for the stage breakdown of -v 1
+#define DEVT_(stats, call) ([&] { const double t_ = now(); const int r_ = (call); (stats).t_device += now() - t_; return r_; }())
+#define DEVT(call) DEVT_(st, call)
+#define DEVTI(call) DEVT_(I.st, call)
+#define DEVTP(call) DEVT_(p->st, call)
+
 double now()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -120,9 +126,11 @@ struct Group { // CSegment, write side (src/common/segment.{h,cpp})
     }
 };
 
-struct SampleLists { // one registration: the items of every group it touches
-    std::vector<uint32_t> gids;               // groups touched, in order of first appearance
-    std::vector<std::vector<uint32_t>> lists; // items per group (indices into placed), in (contig name, part) order
+struct SampleLists { // one registration: the items of every group it touches (CSR)
+    std::vector<uint32_t> gids;  // groups touched, in order of first appearance
+    std::vector<uint32_t> begin; // list li = items[begin[li] .. begin[li + 1])
+    std::vector<uint32_t> items; // indices into placed, per group in (contig name, part) order
+    size_t n_lists() const { return gids.size(); }
 };
 
 // what store_segments' bookkeeping needs about the committed registrations (filled by process_batch on the rank that
@@ -431,6 +439,15 @@ struct CAGCCompressor::Impl {
     // leading samples whose classification is certainly valid; n_committed = number of samples done
     bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, uint32_t &n_committed);
     bool book_and_store(CommitData &cd);
+    // stage accounting: wall time of the stage and its host-only part (wall minus the time inside the device library)
+    void stage_end(double &wall, double &host_only, double &t0, double &dev0)
+    {
+        const double t = now();
+        wall += t - t0;
+        host_only += (t - t0) - (st.t_device - dev0);
+        t0 = t;
+        dev0 = st.t_device;
+    }
     // multi-GPU single-archive mode: one registration at a time, committed on every rank from the owner's record
     uint32_t dist_rank = 0, dist_world = 1, dist_writer = 0;
     bytes_t dist_record;
@@ -442,6 +459,13 @@ struct CAGCCompressor::Impl {
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
     bytes_t enc_buf, fetch_buf; // grown, never shrunk
+    // scratch reused across registrations (no reallocation / page faults / zero fill per sample)
+    std::vector<uint32_t> gid_slot, gid_epoch;
+    uint32_t gid_epoch_ctr = 0;
+    std::vector<uint32_t> scan_ctg;
+    std::vector<uint64_t> scan_pos, scan_dir, scan_rc;
+    std::vector<Seg> seg_buf;
+    std::vector<Placed> placed_buf;
     // adaptive mode (-a): sorted singleton / duplicated k-mers of the reference genome
     // (v_candidate_kmers / v_duplicated_kmers, agc_compressor.cpp:493-497)
     std::vector<uint64_t> ref_singletons, ref_duplicates;
@@ -516,7 +540,7 @@ bool CAGCCompressor::SetSplitters(const uint64_t *kmers, uint64_t n)
     p->splitters.assign(kmers, kmers + n);
     std::sort(p->splitters.begin(), p->splitters.end());
     p->splitters.erase(std::unique(p->splitters.begin(), p->splitters.end()), p->splitters.end());
-    return p->hip_ok(agc_hip_splitters_set(p->hip, p->splitters.data(), p->splitters.size()), "splitters_set");
+    return p->hip_ok(DEVTP(agc_hip_splitters_set(p->hip, p->splitters.data(), p->splitters.size())), "splitters_set");
 }
 
 bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinality, uint32_t kmer_length, const std::string &reference_file_name,
@@ -580,11 +604,11 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         // determine_splitters on the GPU: contigs go to HBM back to back, k-mers are enumerated, radix
         // sorted and reduced to singletons there (include/agc_hip.h: agc_hip_determine_splitters_dev)
         uint8_t *d_ref = nullptr;
-        if (!I.hip_ok(agc_hip_sample_buffer(I.hip, tot, &d_ref), "sample_buffer"))
+        if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, tot, &d_ref)), "sample_buffer"))
             return false;
         std::vector<uint64_t> off(ref.size() + 1, 0);
         for (size_t i = 0; i < ref.size(); ++i) {
-            if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size()), "copy_to_device"))
+            if (!I.hip_ok(DEVTI(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size())), "copy_to_device"))
                 return false;
             off[i + 1] = off[i] + ref[i].size();
         }
@@ -751,11 +775,11 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         for (auto &c : ref)
             tot += c.size();
         uint8_t *d_ref = nullptr;
-        if (!I.hip_ok(agc_hip_sample_buffer(I.hip, tot, &d_ref), "sample_buffer"))
+        if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, tot, &d_ref)), "sample_buffer"))
             return false;
         std::vector<uint64_t> off(ref.size() + 1, 0);
         for (size_t i = 0; i < ref.size(); ++i) {
-            if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size()), "copy_to_device"))
+            if (!I.hip_ok(DEVTI(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size())), "copy_to_device"))
                 return false;
             off[i + 1] = off[i] + ref[i].size();
         }
@@ -871,7 +895,7 @@ bool CAGCCompressor::Impl::unpack_group(uint32_t gid)
             err("cannot decode the reference of group " + std::to_string(gid));
             return false;
         }
-        if (!hip_ok(agc_hip_ref_register(hip, gid, ref.data(), (uint32_t)ref.size(), mml), "ref_register"))
+        if (!hip_ok(DEVT(agc_hip_ref_register(hip, gid, ref.data(), (uint32_t)ref.size(), mml)), "ref_register"))
             return false;
         g.ref_size = ref.size() + 1;
         g.pk_ref = nullptr;
@@ -993,12 +1017,15 @@ int CAGCCompressor::Impl::scan_batch(const std::vector<uint64_t> &ctg_off, uint3
 {
     uint64_t cap = std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000);
     for (;;) {
-        h_ctg.resize(cap);
-        h_pos.resize(cap);
-        h_dir.resize(cap);
-        h_rc.resize(cap);
-        int rc = agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
-                                          h_rc.data());
+        if (h_ctg.size() < cap) { // the buffers only grow (they are reused by every registration)
+            h_ctg.resize(cap);
+            h_pos.resize(cap);
+            h_dir.resize(cap);
+            h_rc.resize(cap);
+        }
+        cap = h_ctg.size();
+        int rc = DEVT(agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
+                                               h_rc.data()));
         if (rc == AGC_HIP_ECAP) {
             cap = n_hits;
             continue;
@@ -1032,7 +1059,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
 {
     n_committed = 0;
     const uint32_t n_ctg = (uint32_t)ctgs.size();
-    double t0 = now();
+    double t0 = now(), dev0 = st.t_device;
     std::vector<uint64_t> new_splitters_added;
 
     // ---- stage 1a: splitter scan on the GPU (compress_contig's loop) ----
@@ -1048,8 +1075,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             err("internal: contigs of a batch must be contiguous in HBM");
             return false;
         }
-    std::vector<uint32_t> h_ctg;
-    std::vector<uint64_t> h_pos, h_dir, h_rc;
+    std::vector<uint32_t> &h_ctg = scan_ctg;
+    std::vector<uint64_t> &h_pos = scan_pos, &h_dir = scan_dir, &h_rc = scan_rc;
     uint64_t n_hits = 0;
     if (n_ctg && scan_batch(ctg_off, n_ctg, d_base, h_ctg, h_pos, h_dir, h_rc, n_hits) != AGC_HIP_OK)
         return false;
@@ -1081,7 +1108,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                     tot += len[i];
                 }
                 bytes_t buf(tot);
-                if (!hip_ok(agc_hip_fetch_slices_dev(hip, (uint32_t)need.size(), d_base, off.data(), len.data(), nullptr, buf.data(), tot, ooff.data()), "fetch_slices"))
+                if (!hip_ok(DEVT(agc_hip_fetch_slices_dev(hip, (uint32_t)need.size(), d_base, off.data(), len.data(), nullptr, buf.data(), tot, ooff.data())), "fetch_slices"))
                     return false;
                 for (size_t i = 0; i < need.size(); ++i)
                     fetched_ctg[i].assign(buf.begin() + ooff[i], buf.begin() + ooff[i + 1]);
@@ -1100,7 +1127,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 splitters.insert(splitters.end(), add.begin(), add.end());
                 std::sort(splitters.begin(), splitters.end());
                 splitters.erase(std::unique(splitters.begin(), splitters.end()), splitters.end());
-                if (!hip_ok(agc_hip_splitters_insert(hip, add.data(), add.size()), "splitters_insert"))
+                if (!hip_ok(DEVT(agc_hip_splitters_insert(hip, add.data(), add.size())), "splitters_insert"))
                     return false;
                 new_splitters_added = add;
                 // second scan with the extended set; only the deferred contigs take its hits
@@ -1140,11 +1167,12 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             }
         }
     }
-    st.t_scan += now() - t0;
+    stage_end(st.t_scan, st.h_scan, t0, dev0);
     t0 = now();
 
     // ---- stage 1b: cut into segments (agc_compressor.cpp:2018-2048) ----
-    std::vector<Seg> segs;
+    std::vector<Seg> &segs = seg_buf;
+    segs.clear();
     segs.reserve(n_hits + n_ctg);
     {
         uint64_t h = 0;
@@ -1229,7 +1257,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             ++st.one_splitter;
         }
     }
-    st.t_classify += now() - t0;
+    stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
 
     // ---- GPU: estimates for every (one-splitter segment, candidate) pair ----
@@ -1252,8 +1280,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             }
         std::vector<uint32_t> cost(which.size()), peak(which.size());
         if (!which.empty() &&
-            !hip_ok(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)which.size(), gid.data(), d_base, off.data(), len.data(), rc.data(), cost.data(),
-                                                  peak.data()),
+            !hip_ok(DEVT(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)which.size(), gid.data(), d_base, off.data(), len.data(), rc.data(), cost.data(),
+                                                  peak.data())),
                     "lz_estimate_batch"))
             return false;
         for (size_t i = 0; i < which.size(); ++i) {
@@ -1261,7 +1289,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             est_peak[which[i]] = peak[i];
         }
     }
-    st.t_gpu_aux += now() - t0;
+    stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
     // ---- add_segment, part 2: resolve one-splitter keys (:1630-1808) ----
@@ -1376,7 +1404,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         s.mid_job = (int32_t)mids.size();
         mids.push_back(j);
     }
-    st.t_classify += now() - t0;
+    stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
     std::vector<uint32_t> best_pos(mids.size());
     if (!mids.empty()) {
@@ -1395,16 +1423,17 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             r2[i] = mids[i].rc2;
             p2[i] = mids[i].pf2;
         }
-        if (!hip_ok(agc_hip_lz_split_point_batch_dev(hip, (uint32_t)n, g1.data(), g2.data(), d_base, off.data(), len.data(), r1.data(),
-                                                     p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr),
+        if (!hip_ok(DEVT(agc_hip_lz_split_point_batch_dev(hip, (uint32_t)n, g1.data(), g2.data(), d_base, off.data(), len.data(), r1.data(),
+                                                     p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr)),
                     "lz_split_point_batch"))
             return false;
     }
-    st.t_gpu_aux += now() - t0;
+    stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
     // ---- add_segment, part 4: final placement + part numbers ----
-    std::vector<Placed> placed;
+    std::vector<Placed> &placed = placed_buf;
+    placed.clear();
     placed.reserve(segs.size() + mids.size());
     {
         uint32_t cur_ctg = ~0u, part_no = 0;
@@ -1571,21 +1600,36 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             for (size_t j = 0; j < n0; ++j)
                 placed[raw0[j]].gid = j < n_moved ? (int32_t)(1 + (j % 15)) : 0;
             SampleLists &sl = per_sample[sidx];
-            std::unordered_map<uint32_t, uint32_t> dense;
+            // slot of every group touched by this registration (epoch-stamped scratch instead of a hash map)
+            if (gid_slot.size() < groups.size()) {
+                gid_slot.resize(groups.size() + groups.size() / 4 + 64, 0);
+                gid_epoch.resize(gid_slot.size(), 0);
+            }
+            ++gid_epoch_ctr;
+            std::vector<uint32_t> cnt;
             for (size_t i = pos; i < end; ++i) {
                 const uint32_t gid = (uint32_t)placed[order[i]].gid;
-                auto it = dense.find(gid);
-                if (it == dense.end()) {
-                    it = dense.emplace(gid, (uint32_t)sl.lists.size()).first;
-                    sl.lists.emplace_back();
+                if (gid_epoch[gid] != gid_epoch_ctr) {
+                    gid_epoch[gid] = gid_epoch_ctr;
+                    gid_slot[gid] = (uint32_t)sl.gids.size();
                     sl.gids.push_back(gid);
+                    cnt.push_back(0);
                 }
-                sl.lists[it->second].push_back(order[i]);
+                ++cnt[gid_slot[gid]];
+            }
+            sl.begin.assign(sl.gids.size() + 1, 0);
+            for (size_t li = 0; li < sl.gids.size(); ++li)
+                sl.begin[li + 1] = sl.begin[li] + cnt[li];
+            sl.items.resize(end - pos);
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (size_t i = pos; i < end; ++i) {
+                const uint32_t li = gid_slot[(uint32_t)placed[order[i]].gid];
+                sl.items[sl.begin[li] + cnt[li]++] = order[i];
             }
             pos = end;
         }
     }
-    st.t_register += now() - t0;
+    stage_end(st.t_register, st.h_register, t0, dev0);
     t0 = now();
 
     // ---- store_segments (agc_compressor.cpp:974-1050) ----
@@ -1597,9 +1641,10 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     {
         std::vector<uint8_t> will_exist(groups.size(), 0);
         for (uint32_t sidx = 0; sidx < commit_upto; ++sidx)
-            for (size_t li = 0; li < per_sample[sidx].lists.size(); ++li) {
+            for (size_t li = 0; li < per_sample[sidx].n_lists(); ++li) {
                 const uint32_t gid = per_sample[sidx].gids[li];
-                for (uint32_t idx : per_sample[sidx].lists[li]) {
+                for (uint32_t ii = per_sample[sidx].begin[li]; ii < per_sample[sidx].begin[li + 1]; ++ii) {
+                    const uint32_t idx = per_sample[sidx].items[ii];
                     if (gid < NO_RAW_GROUPS)
                         raw_items.push_back(idx);
                     else if (!groups[gid].exists && !will_exist[gid]) {
@@ -1638,11 +1683,11 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 rc[i] = pl.rc;
                 st.ref_bytes += pl.len;
             }
-            if (!hip_ok(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml), "ref_register_batch"))
+            if (!hip_ok(DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml)), "ref_register_batch"))
                 return false;
             lag_cnt.resize(nr * 28);
             lag_cur.resize(nr * 28);
-            if (!hip_ok(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data()), "ref_lag_counts"))
+            if (!hip_ok(DEVT(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data())), "ref_lag_counts"))
                 return false;
             // repetitiveness probe with the reference's double arithmetic (segment.h:224-247)
             repetitive.resize(nr);
@@ -1678,11 +1723,11 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             if (fetched.size() < tot)
                 fetched.resize(tot);
             fetched_off.resize(nf + 1);
-            if (!hip_ok(agc_hip_fetch_slices_dev(hip, (uint32_t)nf, d_base, off.data(), len.data(), rc.data(), fetched.data(), tot, fetched_off.data()), "fetch_slices"))
+            if (!hip_ok(DEVT(agc_hip_fetch_slices_dev(hip, (uint32_t)nf, d_base, off.data(), len.data(), rc.data(), fetched.data(), tot, fetched_off.data())), "fetch_slices"))
                 return false;
         }
     }
-    st.t_register += now() - t0;
+    stage_end(st.t_register, st.h_register, t0, dev0);
     t0 = now();
     // GPU: LZ-encode every other item against its group's reference (segment.cpp:50-58) -- one batch for
     // all committed samples
@@ -1706,7 +1751,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         for (;;) {
             if (enc.size() < cap)
                 enc.resize(cap);
-            int r = agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap, enc_off.data());
+            int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap,
+                                                     enc_off.data()));
             if (r == AGC_HIP_ECAP) {
                 cap = enc_off[ne] + 64;
                 continue;
@@ -1718,7 +1764,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         st.lz_encoded += ne;
         st.delta_bytes += enc_off[ne];
     }
-    st.t_encode += now() - t0;
+    stage_end(st.t_encode, st.h_encode, t0, dev0);
     t0 = now();
 
     CommitData cdta;
@@ -1745,7 +1791,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
 // store_segments, second half (agc_compressor.cpp:989-1050): per-group bookkeeping, zstd parts, collection records
 bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
 {
-    double t0 = now();
+    double t0 = now(), dev0 = st.t_device;
     const std::vector<Contig> &ctgs = *cdta.ctgs;
     const std::vector<Placed> &placed = *cdta.placed;
     const uint32_t n_ctg = (uint32_t)ctgs.size(), commit_upto = cdta.commit_upto;
@@ -1788,7 +1834,8 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
             for (size_t li = li_begin; li < li_end; ++li) {
                 const uint32_t gid = sl.gids[li];
                 Group &g = groups[gid];
-                for (uint32_t idx : sl.lists[li]) {
+                for (uint32_t ii = sl.begin[li]; ii < sl.begin[li + 1]; ++ii) {
+                    const uint32_t idx = sl.items[ii];
                     const Placed &pl = placed[idx];
                     uint32_t igid;
                     if (gid < NO_RAW_GROUPS) {
@@ -1835,32 +1882,34 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
         };
         // groups are independent of each other (the reference runs them on all worker threads,
         // agc_compressor.cpp:989-1050): big samples go to the pool in chunks, jobs merged in list order
-        if (sl.lists.size() >= 4096) {
-            const size_t n_chunks = std::min<size_t>(sl.lists.size(), (size_t)pool->size() * 8);
+        if (sl.n_lists() >= 4096) {
+            const size_t n_chunks = std::min<size_t>(sl.n_lists(), (size_t)pool->size() * 8);
             std::vector<std::vector<ZJob>> chunk_jobs(n_chunks);
             pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
-                book(sl.lists.size() * ci / n_chunks, sl.lists.size() * (ci + 1) / n_chunks, chunk_jobs[ci]);
+                book(sl.n_lists() * ci / n_chunks, sl.n_lists() * (ci + 1) / n_chunks, chunk_jobs[ci]);
             });
             for (auto &cj : chunk_jobs)
                 for (auto &j : cj)
                     jobs.emplace_back(std::move(j));
         } else
-            book(0, sl.lists.size(), jobs);
-        for (size_t li = 0; li < sl.lists.size(); ++li)
-            for (uint32_t idx : sl.lists[li]) {
-                const Placed &pl = placed[idx];
-                auto *c = cd[pl.ctg];
-                if (!c)
-                    continue;
-                if (pl.part_no >= c->segments.size())
-                    c->segments.resize((size_t)pl.part_no + 1);
-                c->segments[pl.part_no] = {(uint32_t)pl.gid, in_group_id[idx], pl.len, pl.rc};
-            }
+            book(0, sl.n_lists(), jobs);
+        for (uint32_t idx : sl.items) {
+            const Placed &pl = placed[idx];
+            auto *c = cd[pl.ctg];
+            if (!c)
+                continue;
+            if (pl.part_no >= c->segments.size())
+                c->segments.resize((size_t)pl.part_no + 1);
+            c->segments[pl.part_no] = {(uint32_t)pl.gid, in_group_id[idx], pl.len, pl.rc};
+        }
         for (auto &j : jobs)
             all_jobs.emplace_back(std::move(j));
         jobs_end[sidx] = all_jobs.size();
     }
-    st.t_store += now() - t0;
+    stage_end(st.t_store, st.h_store, t0, dev0);
+    if (verbosity > 1)
+        std::cerr << "registration: " << placed.size() << " items; host-only seconds so far: scan " << st.h_scan << " classify " << st.h_classify
+                  << " register " << st.h_register << " encode " << st.h_encode << " store " << st.h_store << std::endl;
     run_jobs(all_jobs, false);
     for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
         add_job_parts(all_jobs, sidx ? jobs_end[sidx - 1] : 0, jobs_end[sidx]);
@@ -1961,7 +2010,7 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
     r.insert(r.end(), {'A', 'G', 'C', 'R'});
     put32(r, (uint32_t)ctgs.size());
     const SampleLists &sl = cd.per_sample.at(0); // one registration per record
-    put32(r, (uint32_t)sl.lists.size());
+    put32(r, (uint32_t)sl.n_lists());
     put32(r, (uint32_t)new_splitters.size());
     uint32_t first_new = ~0u, n_new = 0;
     for (uint32_t idx : cd.new_ref_items) {
@@ -1990,10 +2039,11 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
         kind[idx] = 0;
     for (uint32_t idx : cd.raw_items)
         kind[idx] = 1;
-    for (size_t li = 0; li < sl.lists.size(); ++li) {
+    for (size_t li = 0; li < sl.n_lists(); ++li) {
         put32(r, sl.gids[li]);
-        put32(r, (uint32_t)sl.lists[li].size());
-        for (uint32_t idx : sl.lists[li]) {
+        put32(r, sl.begin[li + 1] - sl.begin[li]);
+        for (uint32_t ii = sl.begin[li]; ii < sl.begin[li + 1]; ++ii) {
+            const uint32_t idx = sl.items[ii];
             const Placed &pl = placed[idx];
             put32(r, pl.ctg);
             put32(r, pl.part_no);
@@ -2058,7 +2108,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
         splitters.insert(splitters.end(), add.begin(), add.end());
         std::sort(splitters.begin(), splitters.end());
         splitters.erase(std::unique(splitters.begin(), splitters.end()), splitters.end());
-        if (!hip_ok(agc_hip_splitters_insert(hip, add.data(), add.size()), "splitters_insert"))
+        if (!hip_ok(DEVT(agc_hip_splitters_insert(hip, add.data(), add.size())), "splitters_insert"))
             return false;
     }
     if (writer) {
@@ -2096,7 +2146,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     for (uint32_t li = 0; li < n_lists && rr.ok; ++li) {
         const uint32_t gid = rr.u32(), cnt = rr.u32();
         sl.gids.push_back(gid);
-        sl.lists.emplace_back();
+        sl.begin.push_back((uint32_t)sl.items.size());
         for (uint32_t i = 0; i < cnt && rr.ok; ++i) {
             Placed pl;
             pl.ctg = rr.u32();
@@ -2137,10 +2187,11 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
                 cd.enc_off.push_back(enc.size());
             }
             rr.p += pn;
-            sl.lists.back().push_back(idx);
+            sl.items.push_back(idx);
             placed.push_back(pl);
         }
     }
+    sl.begin.push_back((uint32_t)sl.items.size());
     if (!rr.ok || rr.p != rr.e) {
         err("malformed commit record");
         return false;
@@ -2149,12 +2200,12 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     // the newly minted references go to this rank's HBM (from the device copy of the record when there is one)
     if (!reg_gid.empty()) {
         if (d_rec) {
-            if (!hip_ok(agc_hip_ref_register_batch_dev(hip, (uint32_t)reg_gid.size(), reg_gid.data(), d_rec, reg_off.data(), reg_len.data(), nullptr, mml),
+            if (!hip_ok(DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)reg_gid.size(), reg_gid.data(), d_rec, reg_off.data(), reg_len.data(), nullptr, mml)),
                         "ref_register_batch"))
                 return false;
         } else
             for (size_t i = 0; i < reg_gid.size(); ++i)
-                if (!hip_ok(agc_hip_ref_register(hip, reg_gid[i], rec + reg_off[i], reg_len[i], mml), "ref_register"))
+                if (!hip_ok(DEVT(agc_hip_ref_register(hip, reg_gid[i], rec + reg_off[i], reg_len[i], mml)), "ref_register"))
                     return false;
     }
     if (!writer)
@@ -2262,7 +2313,7 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
             tot += pending[b].bytes;
         uint8_t *d_base = nullptr;
         double t0 = now();
-        if (!I.hip_ok(agc_hip_sample_buffer(I.hip, tot, &d_base), "sample_buffer"))
+        if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, tot, &d_base)), "sample_buffer"))
             return false;
         uint64_t o = 0;
         for (uint32_t b = 0; b < nb; ++b)
@@ -2271,7 +2322,7 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
                 ct.sample_idx = b;
                 ct.off = o;
                 ct.len = pending[b].data[c].size();
-                if (!I.hip_ok(agc_hip_copy_to_device(I.hip, d_base + o, pending[b].data[c].data(), ct.len), "copy_to_device"))
+                if (!I.hip_ok(DEVTI(agc_hip_copy_to_device(I.hip, d_base + o, pending[b].data[c].data(), ct.len)), "copy_to_device"))
                     return false;
                 o += ct.len;
                 batch.push_back(ct);
