@@ -36,6 +36,70 @@ struct PairHash {
 #define DEVTI(call) DEVT_(I.st, call)
 #define DEVTP(call) DEVT_(p->st, call)
 
+// (kmer1, kmer2) -> group id: flat open-addressing table (one cache line per lookup instead of a node chase)
+class PkMap {
+    struct Slot {
+        uint64_t a, b;
+        int32_t v;
+        uint32_t used;
+    };
+    std::vector<Slot> t;
+    size_t n = 0, mask = 0;
+    void grow()
+    {
+        std::vector<Slot> old;
+        old.swap(t);
+        t.assign(old.empty() ? 1024 : old.size() * 2, Slot{0, 0, 0, 0});
+        mask = t.size() - 1;
+        for (const Slot &s : old)
+            if (s.used) {
+                size_t i = PairHash()(pk_t{s.a, s.b}) & mask;
+                while (t[i].used)
+                    i = (i + 1) & mask;
+                t[i] = s;
+            }
+    }
+
+public:
+    size_t size() const { return n; }
+    void clear()
+    {
+        t.clear();
+        n = mask = 0;
+    }
+    int32_t *find(const pk_t &k)
+    {
+        if (t.empty())
+            return nullptr;
+        for (size_t i = PairHash()(k) & mask;; i = (i + 1) & mask) {
+            Slot &s = t[i];
+            if (!s.used)
+                return nullptr;
+            if (s.a == k.first && s.b == k.second)
+                return &s.v;
+        }
+    }
+    int32_t &operator[](const pk_t &k)
+    {
+        if (int32_t *p = find(k))
+            return *p;
+        if ((n + 1) * 2 > t.size())
+            grow();
+        size_t i = PairHash()(k) & mask;
+        while (t[i].used)
+            i = (i + 1) & mask;
+        t[i] = Slot{k.first, k.second, 0, 1};
+        ++n;
+        return t[i].v;
+    }
+    template <typename F> void for_each(F f) const
+    {
+        for (const Slot &s : t)
+            if (s.used)
+                f(pk_t{s.a, s.b}, s.v);
+    }
+};
+
 double now()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -70,6 +134,7 @@ struct Seg { // one segment as compress_contig cuts it (agc_compressor.cpp:2007-
     Kmer one_kmer;
     // missing-middle search
     int32_t mid_job = -1;
+    int32_t known_gid = -2; // group of pk when classification looked it up (-1: not there, -2: not looked up)
     Kmer kmer1, kmer2;
     bool use_rc = false;
     uint64_t middle = NO_KMER;
@@ -409,7 +474,7 @@ struct CAGCCompressor::Impl {
     CollectionV3 coll;
     std::vector<uint64_t> splitters;
 
-    std::unordered_map<pk_t, int32_t, PairHash> map_segments;                 // agc_compressor.h:628
+    PkMap map_segments;                                                       // agc_compressor.h:628
     std::unordered_map<uint64_t, std::vector<uint64_t>> terminators;          // agc_compressor.h:629
     std::vector<Group> groups;                                                // v_segments
     uint32_t no_segments = 0;
@@ -1060,6 +1125,15 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     n_committed = 0;
     const uint32_t n_ctg = (uint32_t)ctgs.size();
     double t0 = now(), dev0 = st.t_device;
+    // AGC_AMD_LAPS=1: wall time of every host sub-stage of this registration on stderr (profiling aid)
+    static const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
+    double lap_t = laps ? now() : 0.0;
+    auto LAP = [&](const char *what) {
+        if (!laps)
+            return;
+        std::cerr << "  lap " << what << " " << (now() - lap_t) * 1e3 << " ms\n";
+        lap_t = now();
+    };
     std::vector<uint64_t> new_splitters_added;
 
     // ---- stage 1a: splitter scan on the GPU (compress_contig's loop) ----
@@ -1170,6 +1244,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_scan, st.h_scan, t0, dev0);
     t0 = now();
 
+    LAP("scan");
     // ---- stage 1b: cut into segments (agc_compressor.cpp:2018-2048) ----
     std::vector<Seg> &segs = seg_buf;
     segs.clear();
@@ -1204,6 +1279,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         }
     }
 
+    LAP("cut");
     // ---- stage 1c: add_segment, part 1: keys and one-splitter candidates ----
     std::vector<Cand> cands;
     for (Seg &s : segs) {
@@ -1234,12 +1310,12 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                         c.pk = {s.one_kmer.data(), ck};
                         c.use_rc = false;
                     }
-                    auto m = map_segments.find(c.pk);
-                    if (m == map_segments.end()) {
+                    const int32_t *m = map_segments.find(c.pk);
+                    if (!m) {
                         err("internal: terminator without group");
                         return false;
                     }
-                    c.gid = (uint32_t)m->second;
+                    c.gid = (uint32_t)*m;
                     c.ref_size = groups[c.gid].ref_size;
                     cands.push_back(c);
                 }
@@ -1260,6 +1336,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
 
+    LAP("keys");
     // ---- GPU: estimates for every (one-splitter segment, candidate) pair ----
     std::vector<uint32_t> est_cost(cands.size()), est_peak(cands.size());
     if (!cands.empty()) {
@@ -1292,6 +1369,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
+    LAP("estimates");
     // ---- add_segment, part 2: resolve one-splitter keys (:1630-1808) ----
     for (Seg &s : segs) {
         if (s.front.full == s.back.full)
@@ -1337,6 +1415,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         s.store_rc = s.back_only ? !is_best_rc : is_best_rc;
     }
 
+    LAP("resolve");
     // ---- add_segment, part 3: missing-middle-splitter candidates (:1366-1459, 1502-1627) ----
     struct MidJob {
         uint32_t seg, gid1, gid2;
@@ -1345,8 +1424,13 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     std::vector<MidJob> mids;
     for (uint32_t si = 0; si < segs.size(); ++si) {
         Seg &s = segs[si];
-        if (concatenated || s.pk.first == NO_KMER || s.pk.second == NO_KMER || map_segments.count(s.pk))
+        if (concatenated || s.pk.first == NO_KMER || s.pk.second == NO_KMER)
             continue;
+        if (const int32_t *m = map_segments.find(s.pk)) { // known group: remembered for the placement below
+            s.known_gid = *m;
+            continue;
+        }
+        s.known_gid = -1;
         auto tf = terminators.find(s.pk.first), tb = terminators.find(s.pk.second);
         if (tf == terminators.end() || tb == terminators.end())
             continue;
@@ -1373,15 +1457,15 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         if (shared.empty())
             continue;
         s.middle = shared.front();
-        auto m1 = map_segments.find(std::minmax(s.kmer1.data(), s.middle)), m2 = map_segments.find(std::minmax(s.middle, s.kmer2.data()));
-        if (m1 == map_segments.end() || m2 == map_segments.end()) {
+        const int32_t *m1 = map_segments.find(std::minmax(s.kmer1.data(), s.middle)), *m2 = map_segments.find(std::minmax(s.middle, s.kmer2.data()));
+        if (!m1 || !m2) {
             err("internal: shared terminator without group");
             return false;
         }
         MidJob j;
         j.seg = si;
-        j.gid1 = (uint32_t)m1->second;
-        j.gid2 = (uint32_t)m2->second;
+        j.gid1 = (uint32_t)*m1;
+        j.gid2 = (uint32_t)*m2;
         {
             // a group without reference leaves its cost vector empty (segment.cpp:103-104; append mode: still packed):
             // one empty vector -> sizes differ -> no split (:1604-1607); both empty -> best_pos = 0 -> left part empty
@@ -1406,6 +1490,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     }
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
+    LAP("mids");
     std::vector<uint32_t> best_pos(mids.size());
     if (!mids.empty()) {
         size_t n = mids.size();
@@ -1431,6 +1516,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
+    LAP("splitpoints");
     // ---- add_segment, part 4: final placement + part numbers ----
     std::vector<Placed> &placed = placed_buf;
     placed.clear();
@@ -1485,13 +1571,13 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                         b.rc = true;
                         b.pk = {s.back.data(), s.middle};
                     }
-                    auto ma = map_segments.find(a.pk), mb = map_segments.find(b.pk);
-                    if (ma == map_segments.end() || mb == map_segments.end()) {
+                    const int32_t *ma = map_segments.find(a.pk), *mb = map_segments.find(b.pk);
+                    if (!ma || !mb) {
                         err("internal: split target group missing");
                         return false;
                     }
-                    a.gid = ma->second;
-                    b.gid = mb->second;
+                    a.gid = *ma;
+                    b.gid = *mb;
                 }
             }
             if (two) {
@@ -1505,14 +1591,19 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 a.len = s.len;
                 a.rc = s.store_rc;
                 a.pk = s.pk;
-                auto m = map_segments.find(s.pk);
-                a.gid = m == map_segments.end() ? -1 : m->second;
+                if (s.known_gid != -2 && s.mid_job == -1)
+                    a.gid = s.known_gid; // looked up during classification, key unchanged since
+                else {
+                    const int32_t *m = map_segments.find(s.pk);
+                    a.gid = m ? *m : -1;
+                }
                 a.part_no = part_no++;
                 placed.push_back(a);
             }
         }
     }
 
+    LAP("placement");
     // ---- speculation window: the contigs may belong to several consecutive samples that were
     // all classified against the SAME state.  State changes only when a sample mints a new group, so the
     // classification is valid for every sample up to and including the first one with a new item; later
@@ -1547,6 +1638,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
             ctg_rank[co[i]] = r;
         }
     }
+    LAP("ctg_rank");
     std::vector<uint32_t> order; // committed items only, in (sample, contig name, part) order
     {
         std::vector<std::pair<uint64_t, uint32_t>> keyed;
@@ -1562,6 +1654,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         st.segments += order.size();
     }
     {
+    LAP("order");
         // new group ids in that order (only the last committed sample can have new items)
         std::map<pk_t, uint32_t> m_kmers;
         uint32_t gid = no_segments;
@@ -1582,6 +1675,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         no_segments += no_new;
         st.new_groups += no_new;
     }
+    LAP("newgids");
     // per sample: lists of items per group, raw groups by distribute_segments(0, 0, 16) on the sorted
     // list of group 0 (agc_compressor.h:417-435)
     std::vector<SampleLists> per_sample(commit_upto);
@@ -1632,6 +1726,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_register, st.h_register, t0, dev0);
     t0 = now();
 
+    LAP("per_sample");
     // ---- store_segments (agc_compressor.cpp:974-1050) ----
     // (a) what each item needs: new groups' first item becomes the reference (segment.cpp:39-48), raw
     // groups keep the symbols, everything else is LZ-encoded -- decided per group across the committed samples
@@ -1655,6 +1750,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
                 }
             }
     }
+    LAP("classes");
     // append mode: the first add to a group of the input archive unpacks it (segment.cpp:19-20, 39-40)
     if (appending)
         for (uint32_t sidx = 0; sidx < commit_upto; ++sidx)
@@ -1921,11 +2017,11 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
 // store_segments' update of map_segments (keep the smaller id) and of the terminator lists, agc_compressor.cpp:1003-1028
 void CAGCCompressor::Impl::note_new_group(const pk_t &pk, uint32_t gid)
 {
-    auto it = map_segments.find(pk);
-    if (it == map_segments.end())
+    int32_t *it = map_segments.find(pk);
+    if (!it)
         map_segments[pk] = (int32_t)gid;
-    else if (it->second > (int32_t)gid)
-        it->second = (int32_t)gid;
+    else if (*it > (int32_t)gid)
+        *it = (int32_t)gid;
     if (pk.first != NO_KMER && pk.second != NO_KMER) {
         auto &v1 = terminators[pk.first];
         v1.push_back(pk.second);
@@ -2468,7 +2564,9 @@ bool CAGCCompressor::Close(uint32_t no_threads)
         app64(v, x);
     I.ar.add_part(I.ar.register_stream("splitters"), v, I.splitters.size());
 
-    std::vector<std::pair<pk_t, int32_t>> ms(I.map_segments.begin(), I.map_segments.end());
+    std::vector<std::pair<pk_t, int32_t>> ms;
+    ms.reserve(I.map_segments.size());
+    I.map_segments.for_each([&](const pk_t &k, int32_t v) { ms.emplace_back(k, v); });
     std::sort(ms.begin(), ms.end());
     v.clear();
     for (auto &x : ms) {
