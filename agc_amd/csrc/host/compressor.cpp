@@ -1907,16 +1907,22 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
     std::vector<uint32_t> in_group_id(placed.size(), 0);
     // contig descriptors of the collection (agc_compressor.cpp:1038-1049)
     std::vector<CollectionV3::ContigDesc *> cd(n_ctg, nullptr);
-    for (uint32_t c = 0; c < n_ctg; ++c) {
-        if (ctgs[c].sample_idx >= commit_upto)
-            continue;
-        std::string stored = ctgs[c].sample.empty() ? CollectionV3::extract_contig_name(ctgs[c].name) : ctgs[c].sample;
-        CollectionV3::SampleDesc &sd = coll.sample_by_name(stored);
-        for (auto &x : sd.contigs)
-            if (x.name == ctgs[c].name) {
-                cd[c] = &x;
-                break;
-            }
+    bool dup_names_in_batch = false;
+    {
+        std::set<CollectionV3::ContigDesc *> seen;
+        for (uint32_t c = 0; c < n_ctg; ++c) {
+            if (ctgs[c].sample_idx >= commit_upto)
+                continue;
+            std::string stored = ctgs[c].sample.empty() ? CollectionV3::extract_contig_name(ctgs[c].name) : ctgs[c].sample;
+            CollectionV3::SampleDesc &sd = coll.sample_by_name(stored);
+            for (auto &x : sd.contigs)
+                if (x.name == ctgs[c].name) {
+                    cd[c] = &x;
+                    break;
+                }
+            if (cd[c] && !seen.insert(cd[c]).second)
+                dup_names_in_batch = true;
+        }
     }
     // zstd jobs of all committed samples are compressed together (they are independent); their parts and
     // the end-of-registration steps are then replayed sample by sample, so the archive is laid out exactly
@@ -1989,14 +1995,29 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                     jobs.emplace_back(std::move(j));
         } else
             book(0, sl.n_lists(), jobs);
-        for (uint32_t idx : sl.items) {
+        // collection records.  Two contigs of one sample with the same name share the first one's descriptor
+        // (add_segments_placed looks contigs up by name, collection_v3.cpp:806-817), so where their part numbers collide
+        // the LAST write wins: the reference walks the groups from the highest id down (agc_compressor.cpp:990-996,
+        // agc_compressor.h:509-520) -- done the same way here so that even such inputs come out identical
+        auto place = [&](uint32_t idx) {
             const Placed &pl = placed[idx];
             auto *c = cd[pl.ctg];
             if (!c)
-                continue;
+                return;
             if (pl.part_no >= c->segments.size())
                 c->segments.resize((size_t)pl.part_no + 1);
             c->segments[pl.part_no] = {(uint32_t)pl.gid, in_group_id[idx], pl.len, pl.rc};
+        };
+        if (!dup_names_in_batch)
+            for (uint32_t idx : sl.items)
+                place(idx);
+        else {
+            std::vector<uint32_t> lo(sl.n_lists());
+            std::iota(lo.begin(), lo.end(), 0u);
+            std::sort(lo.begin(), lo.end(), [&](uint32_t a, uint32_t b) { return sl.gids[a] > sl.gids[b]; });
+            for (uint32_t li : lo)
+                for (uint32_t ii = sl.begin[li]; ii < sl.begin[li + 1]; ++ii)
+                    place(sl.items[ii]);
         }
         for (auto &j : jobs)
             all_jobs.emplace_back(std::move(j));

@@ -23,8 +23,11 @@ def mutate(rng, seq, d, n_runs=0, iupac=0, indels=0):
         ln = int(rng.integers(1, 40))
         s[p:p + ln] = 4
     for _ in range(iupac):
-        s[int(rng.integers(0, s.size))] = rng.integers(5, 16)
+        if s.size:
+            s[int(rng.integers(0, s.size))] = rng.integers(5, 16)
     for _ in range(indels):
+        if not s.size:
+            break
         p = int(rng.integers(0, s.size))
         if rng.random() < 0.5:
             s = np.concatenate([s[:p], random_seq(rng, int(rng.integers(1, 30))), s[p:]])

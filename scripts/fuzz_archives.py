@@ -1,0 +1,56 @@
+"""Whole-archive parity fuzzer: random small collections (tests/fuzz.py) through the reference CLI (oracle/_ref/agc) and through
+agc_amd -- the product CLI on a GPU box, or the host pipeline on the CPU device stand-in with --sim -- comparing every archive
+byte for byte.  usage: python scripts/fuzz_archives.py [--sim] [--from N] [--count M] [--keep DIR]"""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import fuzz  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sim", action="store_true")
+    ap.add_argument("--from", dest="first", type=int, default=0)
+    ap.add_argument("--count", type=int, default=50)
+    ap.add_argument("--keep", default=None, help="directory that receives the inputs of failing cases")
+    a = ap.parse_args()
+    ref = os.path.join(ROOT, "oracle", "_ref", "agc")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    if a.sim:
+        from tests.devsim import build as simbuild
+        cli = simbuild.build()
+    else:
+        from agc_amd import build
+        build.build_host()
+        cli = build.HOST_BIN
+    bad = 0
+    for seed in range(a.first, a.first + a.count):
+        d = tempfile.mkdtemp(prefix=f"fuzz{seed}_")
+        case = fuzz.make_case(seed, os.path.join(d, "in"))
+        want, e1 = fuzz.run_case(ref, case, d, "ref", threads="1", env=env)
+        got, e2 = fuzz.run_case(cli, case, d, "amd")
+        # the reference itself dies on some inputs (e.g. `append -c` onto a partly filled batch): compare up to there
+        n_cmp = len(want) - 1 if want and want[-1] is None else len(want)
+        crashed = n_cmp != len(want)
+        ok = want[:n_cmp] == got[:n_cmp] and all(x for x in want[:n_cmp]) and None not in got
+        sz = lambda v: [None if x is None else len(x) for x in v]
+        print(seed, ("ok" if ok else "MISMATCH") + (" (reference crashed at step %d)" % n_cmp if crashed else ""),
+              " ".join(case["args"] + case["carry"]), case["steps"], sz(want), sz(got), flush=True)
+        if not ok:
+            bad += 1
+            if e2[-1].strip():
+                print("   stderr:", e2[-1][-400:])
+            if a.keep:
+                shutil.copytree(d, os.path.join(a.keep, f"case{seed}"), dirs_exist_ok=True)
+        shutil.rmtree(d, ignore_errors=True)
+    print("mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
