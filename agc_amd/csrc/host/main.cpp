@@ -40,6 +40,7 @@ void usage()
                  "       agc_amd getset  [-l <line>] [-o <file>] <in.agc> <sample> [<sample> ...]\n"
                  "       agc_amd getctg  [-l <line>] [-o <file>] <in.agc> <contig[@sample][:from-to]> ...\n"
                  "       agc_amd listref|listset [-o <file>] <in.agc>\n"
+                 "       agc_amd info [-v 1] <in.agc>\n"
                  "       agc_amd listctg [-o <file>] <in.agc> <sample> [<sample> ...]\n";
 }
 
@@ -64,7 +65,7 @@ int read_command(const std::string &mode, int argc, char **argv)
 {
     uint32_t line_length = 80;
     std::string out;
-    bool no_ref = false;
+    bool no_ref = false, verbose = false;
     int i = 2;
     for (; i < argc; ++i) {
         std::string a = argv[i];
@@ -79,8 +80,8 @@ int read_command(const std::string &mode, int argc, char **argv)
         case 'l': line_length = clampv<uint32_t>((uint32_t)atoi(val()), 40, 2000000000u); break;
         case 'o': out = val(); break;
         case 'g':
-        case 't':
-        case 'v': (void)val(); break;
+        case 't': (void)val(); break;
+        case 'v': verbose = atoi(val()) > 0; break;
         case 'r': no_ref = true; break;
         default: break;
         }
@@ -139,6 +140,28 @@ int read_command(const std::string &mode, int argc, char **argv)
             }
         }
         write_out(out, txt);
+    } else if (mode == "info") { // src/app/main.cpp:373-420: everything goes to stderr; v3 archives store no command lines
+        std::vector<std::string> v;
+        f.ListSample(v);
+        uint32_t k, mml, pack, seg;
+        f.GetParams(k, mml, pack, seg);
+        std::string ref;
+        f.GetReferenceSample(ref);
+        std::cerr << "No. samples      : " << v.size() << std::endl;
+        std::cerr << "k-mer length     : " << k << std::endl;
+        std::cerr << "Min. match length: " << mml << std::endl;
+        if (seg)
+            std::cerr << "Segment size     : " << seg << std::endl;
+        std::cerr << "Batch size       : " << pack << std::endl;
+        std::cerr << "Reference name   : " << ref << std::endl;
+        std::cerr << "Command lines:" << std::endl;
+        if (verbose) {
+            std::vector<std::pair<std::string, std::string>> info;
+            f.GetFileTypeInfo(info);
+            std::cerr << "File type info:\n";
+            for (auto &x : info)
+                std::cerr << "  " << x.first << " : " << x.second << std::endl;
+        }
     } else if (mode == "getcol") {
         if (!out.empty() && !std::filesystem::is_directory(out)) {
             std::cerr << "Path must point to an existing directory\n";
@@ -186,7 +209,7 @@ int main(int argc, char **argv)
 {
     if (argc >= 2) {
         const std::string mode = argv[1];
-        for (const char *m : {"getcol", "getset", "getctg", "listref", "listset", "listctg"})
+        for (const char *m : {"getcol", "getset", "getctg", "listref", "listset", "listctg", "info"})
             if (mode == m)
                 return read_command(mode, argc, argv);
     }

@@ -23,6 +23,7 @@ struct CAGCFile::Impl {
     uint32_t k = 0, mml = 0, pack = 0, segment_size = 0;
     mutable std::vector<SampleDesc> samples;
     std::unordered_map<std::string, uint32_t> sample_ids;
+    std::map<std::string, std::string> file_type_info;
     // decoded group references and delta / raw packs (prefetch-style caches)
     mutable std::unordered_map<uint32_t, bytes_t> ref_cache;
     mutable std::map<std::pair<uint32_t, uint32_t>, bytes_t> pack_cache;
@@ -226,7 +227,7 @@ bool CAGCFile::Open(const std::string &file_name, bool)
     if (!I.ar.get_part("file_type_info", 0, ptr, size, meta))
         return false;
     {
-        std::map<std::string, std::string> info;
+        std::map<std::string, std::string> &info = I.file_type_info;
         const uint8_t *q = ptr, *e = ptr + size;
         std::string key, val;
         while (q < e && rd_str(q, e, key) && rd_str(q, e, val))
@@ -428,6 +429,14 @@ bool CAGCFile::GetContigFasta(const std::string &query, std::string &out, uint32
     if (from >= 0 && to >= 0)
         hdr += ":" + std::to_string(from) + "-" + std::to_string(to);
     append_fasta(out, hdr, codes, line_length);
+    return true;
+}
+
+bool CAGCFile::GetFileTypeInfo(std::vector<std::pair<std::string, std::string>> &info) const
+{
+    if (!p->opened)
+        return false;
+    info.assign(p->file_type_info.begin(), p->file_type_info.end());
     return true;
 }
 

@@ -32,6 +32,8 @@ public:
     int ListCtg(const std::string &sample, std::vector<std::string> &names) const;
     // compression parameters stored in the archive: k, min_match_len, pack_cardinality, segment_size
     bool GetParams(uint32_t &k, uint32_t &mml, uint32_t &pack, uint32_t &segment_size) const;
+    // key -> value pairs of the file_type_info stream (agc info -v 1)
+    bool GetFileTypeInfo(std::vector<std::pair<std::string, std::string>> &info) const;
     // whole sample as FASTA text (agc getset): ">name\n" + 80-column lines
     bool GetSampleFasta(const std::string &sample, std::string &out, uint32_t line_length = 80) const;
     // all contigs of a sample as symbol codes (GetSampleSequences, agc_decompressor_lib.cpp; used by append -a)

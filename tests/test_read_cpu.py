@@ -139,6 +139,16 @@ def test_cli_list_and_get_on_toy():
     assert r.returncode == 0 and r.stdout == b"" and b"no sample:contig" in r.stderr
 
 
+def test_cli_info_prints_what_the_reference_prints():
+    got = _cli(["info", "-v", "1", TOY_AGC]).stderr.decode()
+    assert got.startswith("No. samples      : 4\nk-mer length     : 25\nMin. match length: 17\nSegment size     : 60000\n"
+                          "Batch size       : 50\nReference name   : ref\nCommand lines:\nFile type info:\n")
+    assert "  file_version_major : 3\n" in got and "  producer : agc\n" in got
+    if os.path.exists(REF_AGC):
+        want = subprocess.run([REF_AGC, "info", "-v", "1", TOY_AGC], capture_output=True, env=REF_ENV).stderr.decode()
+        assert want.startswith(got)  # the reference adds its "Completed in" footer
+
+
 @pytest.mark.parametrize("name", list(COLL.CONFIGS))
 def test_reference_archives_round_trip_and_match_reference_getset(rd, name, tmp_path):
     if not os.path.exists(REF_AGC):
