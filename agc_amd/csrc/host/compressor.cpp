@@ -503,6 +503,24 @@ struct CAGCCompressor::Impl {
     // classifies all contigs (one or several consecutive samples) against the current state and commits the
     // leading samples whose classification is certainly valid; n_committed = number of samples done
     bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, uint32_t &n_committed);
+    struct BatchState { // working set of one process_batch call
+        std::vector<Contig> *ctgs = nullptr;
+        const uint8_t *d_base = nullptr;
+        const std::vector<bytes_t> *host_data = nullptr;
+        uint32_t n_ctg = 0;
+        double t0 = 0, dev0 = 0, lap_t = 0;
+        std::vector<uint64_t> new_splitters_added; // adaptive mode
+        std::vector<uint32_t> best_pos;            // per missing-middle job
+        uint32_t commit_upto = 0;                  // registrations of the window that are committed now
+        std::vector<uint32_t> order;               // committed items in registration order
+        std::vector<SampleLists> per_sample;
+    };
+    bool stage_scan(BatchState &b);
+    bool stage_classify(BatchState &b);
+    bool stage_place(BatchState &b);
+    bool stage_register(BatchState &b);
+    bool stage_store(BatchState &b);
+    void lap(BatchState &b, const char *what);
     bool book_and_store(CommitData &cd);
     // stage accounting: wall time of the stage and its host-only part (wall minus the time inside the device library)
     void stage_end(double &wall, double &host_only, double &t0, double &dev0)
@@ -1119,23 +1137,47 @@ bool CAGCCompressor::Impl::find_new_splitters(const bytes_t &ctg, std::vector<ui
     return true;
 }
 
+// One call = one pass over a window of registrations: scan -> classification -> placement -> registration -> store.
+// The stages share their working set through BatchState (and the reusable seg_buf / placed_buf scratch of Impl).
 bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data,
                                          uint32_t &n_committed)
 {
     n_committed = 0;
-    const uint32_t n_ctg = (uint32_t)ctgs.size();
-    double t0 = now(), dev0 = st.t_device;
-    // AGC_AMD_LAPS=1: wall time of every host sub-stage of this registration on stderr (profiling aid)
-    static const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
-    double lap_t = laps ? now() : 0.0;
-    auto LAP = [&](const char *what) {
-        if (!laps)
-            return;
-        std::cerr << "  lap " << what << " " << (now() - lap_t) * 1e3 << " ms\n";
-        lap_t = now();
-    };
-    std::vector<uint64_t> new_splitters_added;
+    BatchState b;
+    b.ctgs = &ctgs;
+    b.d_base = d_base;
+    b.host_data = host_data;
+    b.n_ctg = (uint32_t)ctgs.size();
+    b.t0 = now();
+    b.dev0 = st.t_device;
+    b.lap_t = b.t0;
+    if (!stage_scan(b) || !stage_classify(b) || !stage_place(b) || !stage_register(b))
+        return false;
+    n_committed = b.commit_upto;
+    return stage_store(b);
+}
 
+// AGC_AMD_LAPS=1: wall time of every host sub-stage of a registration on stderr (profiling aid)
+void CAGCCompressor::Impl::lap(BatchState &b, const char *what)
+{
+    static const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
+    if (!laps)
+        return;
+    std::cerr << "  lap " << what << " " << (now() - b.lap_t) * 1e3 << " ms\n";
+    b.lap_t = now();
+}
+
+// compress_contig for every contig of the window: splitter hits from the GPU, adaptive-mode re-scan, segments
+bool CAGCCompressor::Impl::stage_scan(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const uint8_t *d_base = b.d_base;
+    const uint32_t n_ctg = b.n_ctg;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    auto LAP = [&](const char *what) { lap(b, what); };
+    (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
+    const std::vector<bytes_t> *host_data = b.host_data;
+    std::vector<uint64_t> &new_splitters_added = b.new_splitters_added;
     // ---- stage 1a: splitter scan on the GPU (compress_contig's loop) ----
     std::vector<uint64_t> ctg_off(n_ctg + 1, 0);
     for (uint32_t i = 0; i < n_ctg; ++i) {
@@ -1279,6 +1321,19 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         }
     }
 
+    return true;
+}
+
+// add_segment for all segments at once: keys, one-splitter candidates (estimates on the GPU), missing-middle split points
+bool CAGCCompressor::Impl::stage_classify(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const uint8_t *d_base = b.d_base;
+    const uint32_t n_ctg = b.n_ctg;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    auto LAP = [&](const char *what) { lap(b, what); };
+    (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
+    std::vector<Seg> &segs = seg_buf;
     LAP("cut");
     // ---- stage 1c: add_segment, part 1: keys and one-splitter candidates ----
     std::vector<Cand> cands;
@@ -1491,7 +1546,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
     LAP("mids");
-    std::vector<uint32_t> best_pos(mids.size());
+    std::vector<uint32_t> &best_pos = b.best_pos;
+    best_pos.assign(mids.size(), 0);
     if (!mids.empty()) {
         size_t n = mids.size();
         std::vector<uint32_t> g1(n), g2(n), len(n);
@@ -1516,11 +1572,25 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
+    return true;
+}
+
+// add_segment, last part: the placed items (one or two per segment) with their part numbers
+bool CAGCCompressor::Impl::stage_place(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const uint8_t *d_base = b.d_base;
+    const uint32_t n_ctg = b.n_ctg;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    auto LAP = [&](const char *what) { lap(b, what); };
+    (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
+    std::vector<Seg> &segs = seg_buf;
+    const std::vector<uint32_t> &best_pos = b.best_pos;
     LAP("splitpoints");
     // ---- add_segment, part 4: final placement + part numbers ----
     std::vector<Placed> &placed = placed_buf;
     placed.clear();
-    placed.reserve(segs.size() + mids.size());
+    placed.reserve(segs.size() + best_pos.size());
     {
         uint32_t cur_ctg = ~0u, part_no = 0;
         for (Seg &s : segs) {
@@ -1603,17 +1673,30 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         }
     }
 
+    return true;
+}
+
+// register_segments: what is committed, in which order, with which (new) group ids
+bool CAGCCompressor::Impl::stage_register(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const uint8_t *d_base = b.d_base;
+    const uint32_t n_ctg = b.n_ctg;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    auto LAP = [&](const char *what) { lap(b, what); };
+    (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
+    std::vector<Placed> &placed = placed_buf;
     LAP("placement");
     // ---- speculation window: the contigs may belong to several consecutive samples that were
     // all classified against the SAME state.  State changes only when a sample mints a new group, so the
     // classification is valid for every sample up to and including the first one with a new item; later
     // samples of the window are handed back to the caller (n_committed) and classified again.
     const uint32_t n_samples = ctgs.empty() ? 1u : ctgs.back().sample_idx + 1;
-    uint32_t commit_upto = n_samples; // exclusive
+    uint32_t &commit_upto = b.commit_upto;
+    commit_upto = n_samples; // exclusive
     for (const Placed &pl : placed)
         if ((pl.gid < 0 || groups[pl.gid].packed) && ctgs[pl.ctg].sample_idx + 1 < commit_upto)
             commit_upto = ctgs[pl.ctg].sample_idx + 1; // (an unpacked group changes later classifications as a new one does)
-    n_committed = commit_upto;
 
     // ---- register_segments per sample (agc_compressor.cpp:954-971; agc_compressor.h:384-435) ----
     // order of CBufferedSegPart's lists and of the std::set of new parts: (sample name, contig name,
@@ -1639,7 +1722,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
         }
     }
     LAP("ctg_rank");
-    std::vector<uint32_t> order; // committed items only, in (sample, contig name, part) order
+    std::vector<uint32_t> &order = b.order; // committed items only, in (sample, contig name, part) order
     {
         std::vector<std::pair<uint64_t, uint32_t>> keyed;
         keyed.reserve(placed.size());
@@ -1678,7 +1761,8 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     LAP("newgids");
     // per sample: lists of items per group, raw groups by distribute_segments(0, 0, 16) on the sorted
     // list of group 0 (agc_compressor.h:417-435)
-    std::vector<SampleLists> per_sample(commit_upto);
+    std::vector<SampleLists> &per_sample = b.per_sample;
+    per_sample.assign(commit_upto, SampleLists());
     {
         size_t pos = 0;
         for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
@@ -1726,6 +1810,22 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     stage_end(st.t_register, st.h_register, t0, dev0);
     t0 = now();
 
+    return true;
+}
+
+// store_segments, first half: new references into HBM, LZ-encode of everything else, then the bookkeeping stage
+bool CAGCCompressor::Impl::stage_store(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const uint8_t *d_base = b.d_base;
+    const uint32_t n_ctg = b.n_ctg;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    auto LAP = [&](const char *what) { lap(b, what); };
+    (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
+    std::vector<Placed> &placed = placed_buf;
+    const uint32_t commit_upto = b.commit_upto;
+    std::vector<SampleLists> &per_sample = b.per_sample;
+    std::vector<uint64_t> &new_splitters_added = b.new_splitters_added;
     LAP("per_sample");
     // ---- store_segments (agc_compressor.cpp:974-1050) ----
     // (a) what each item needs: new groups' first item becomes the reference (segment.cpp:39-48), raw
@@ -1864,7 +1964,7 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     t0 = now();
 
     CommitData cdta;
-    cdta.ctgs = &ctgs;
+    cdta.ctgs = b.ctgs;
     cdta.placed = &placed;
     cdta.commit_upto = commit_upto;
     cdta.per_sample = std::move(per_sample);
