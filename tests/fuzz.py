@@ -133,3 +133,37 @@ def run_case(cli, case, outdir, tag, threads="3", env=None):
         pos += n
         prev = fn
     return out, errs
+
+
+def archive_round_trips(archive_path, files):
+    """True when every contig stored in the archive decodes to an input contig of that name (uses libagc_read.so).  Tells a
+    reference archive that lost data (it happens in `append -c` onto a completely filled batch) from a genuine difference."""
+    from agc_amd import build, reader
+    build.build_read()
+    inputs = {}
+    for f in files:
+        name, seq = None, []
+        for line in open(f, "rb").read().split(b"\n"):
+            if line.startswith(b">"):
+                if name is not None:
+                    inputs.setdefault(name, set()).add(b"".join(seq).upper())
+                name, seq = line[1:].rstrip(b"\r").decode(), []
+            else:
+                seq.append(line.strip())
+        if name is not None:
+            inputs.setdefault(name, set()).add(b"".join(seq).upper())
+    a = reader.CAGCFile()
+    if not a.Open(archive_path):
+        return False
+    try:
+        for sn in a.ListSample():
+            ctgs = a.ListCtg(sn)
+            if not ctgs:  # a sample without contigs cannot have been written on purpose
+                return False
+            for cn in ctgs:
+                n = a.GetCtgLen(sn, cn)
+                if n <= 0 or a.GetCtgSeq(sn, cn, -1, -1).encode() not in inputs.get(cn, ()):
+                    return False
+        return True
+    finally:
+        a.Close()
