@@ -135,6 +135,7 @@ struct Seg { // one segment as compress_contig cuts it (agc_compressor.cpp:2007-
     // missing-middle search
     int32_t mid_job = -1;
     int32_t known_gid = -2; // group of pk when classification looked it up (-1: not there, -2: not looked up)
+    uint32_t bp = 0;        // split position of a missing-middle job (before the k+1 clamps)
     Kmer kmer1, kmer2;
     bool use_rc = false;
     uint64_t middle = NO_KMER;
@@ -148,6 +149,7 @@ struct Cand { // find_cand_segment_with_one_splitter, agc_compressor.cpp:1660-16
 };
 
 struct Placed { // one entry of CBufferedSegPart (agc_compressor.h:27-536)
+    uint32_t key = 0; // 2 * segment index + part: stable across re-placements of the same window
     uint32_t ctg;
     uint64_t off; // absolute offset in the device buffer
     uint32_t len;
@@ -510,7 +512,7 @@ struct CAGCCompressor::Impl {
         uint32_t n_ctg = 0;
         double t0 = 0, dev0 = 0, lap_t = 0;
         std::vector<uint64_t> new_splitters_added; // adaptive mode
-        std::vector<uint32_t> best_pos;            // per missing-middle job
+        std::vector<uint32_t> subset;              // segments stage_classify works on
         uint32_t commit_upto = 0;                  // registrations of the window that are committed now
         std::vector<uint32_t> order;               // committed items in registration order
         std::vector<SampleLists> per_sample;
@@ -1151,7 +1153,11 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     b.t0 = now();
     b.dev0 = st.t_device;
     b.lap_t = b.t0;
-    if (!stage_scan(b) || !stage_classify(b) || !stage_place(b) || !stage_register(b))
+    if (!stage_scan(b))
+        return false;
+    b.subset.resize(seg_buf.size());
+    std::iota(b.subset.begin(), b.subset.end(), 0u);
+    if (!stage_classify(b) || !stage_place(b) || !stage_register(b))
         return false;
     n_committed = b.commit_upto;
     return stage_store(b);
@@ -1335,9 +1341,21 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
     std::vector<Seg> &segs = seg_buf;
     LAP("cut");
+    // the segments to classify: all of the window, or the ones whose decision read state that changed since (revalidate)
+    const std::vector<uint32_t> &L = b.subset;
     // ---- stage 1c: add_segment, part 1: keys and one-splitter candidates ----
     std::vector<Cand> cands;
-    for (Seg &s : segs) {
+    for (uint32_t si : L) {
+        Seg &s = segs[si];
+        s.pk = {NO_KMER, NO_KMER};
+        s.store_rc = false;
+        s.cand_begin = s.cand_end = 0;
+        s.back_only = false;
+        s.mid_job = -1;
+        s.known_gid = -2;
+        s.use_rc = false;
+        s.middle = NO_KMER;
+        s.bp = 0;
         const bool ff = s.front.full, bf = s.back.full;
         if (!ff && !bf) {
             s.pk = {NO_KMER, NO_KMER}; // agc_compressor.cpp:1286-1301 (fallback filter off)
@@ -1399,7 +1417,8 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         std::vector<uint32_t> gid, len, which;
         std::vector<uint64_t> off;
         std::vector<uint8_t> rc;
-        for (Seg &s : segs)
+        for (uint32_t si : L) {
+            const Seg &s = segs[si];
             for (uint32_t c = s.cand_begin; c < s.cand_end; ++c) {
                 if (cands[c].ref_size == 0)
                     continue;
@@ -1410,6 +1429,7 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
                 // front-only: segment_dir = the segment itself; back-only: segment_dir = its reverse complement (:1317-1345)
                 rc.push_back((uint8_t)(s.back_only ? !cands[c].use_rc : cands[c].use_rc));
             }
+        }
         std::vector<uint32_t> cost(which.size()), peak(which.size());
         if (!which.empty() &&
             !hip_ok(DEVT(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)which.size(), gid.data(), d_base, off.data(), len.data(), rc.data(), cost.data(),
@@ -1426,7 +1446,8 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
 
     LAP("estimates");
     // ---- add_segment, part 2: resolve one-splitter keys (:1630-1808) ----
-    for (Seg &s : segs) {
+    for (uint32_t si : L) {
+        Seg &s = segs[si];
         if (s.front.full == s.back.full)
             continue;
         const Kmer &kmer = s.one_kmer;
@@ -1477,7 +1498,7 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         uint8_t rc1, pf1, rc2, pf2;
     };
     std::vector<MidJob> mids;
-    for (uint32_t si = 0; si < segs.size(); ++si) {
+    for (uint32_t si : L) {
         Seg &s = segs[si];
         if (concatenated || s.pk.first == NO_KMER || s.pk.second == NO_KMER)
             continue;
@@ -1546,8 +1567,7 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
     LAP("mids");
-    std::vector<uint32_t> &best_pos = b.best_pos;
-    best_pos.assign(mids.size(), 0);
+    std::vector<uint32_t> best_pos(mids.size(), 0);
     if (!mids.empty()) {
         size_t n = mids.size();
         std::vector<uint32_t> g1(n), g2(n), len(n);
@@ -1569,6 +1589,8 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
                     "lz_split_point_batch"))
             return false;
     }
+    for (size_t i = 0; i < mids.size(); ++i)
+        segs[mids[i].seg].bp = best_pos[i];
     stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
@@ -1585,15 +1607,17 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
     auto LAP = [&](const char *what) { lap(b, what); };
     (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
     std::vector<Seg> &segs = seg_buf;
-    const std::vector<uint32_t> &best_pos = b.best_pos;
     LAP("splitpoints");
     // ---- add_segment, part 4: final placement + part numbers ----
     std::vector<Placed> &placed = placed_buf;
     placed.clear();
-    placed.reserve(segs.size() + best_pos.size());
+    placed.reserve(segs.size() + segs.size() / 8 + 16);
     {
         uint32_t cur_ctg = ~0u, part_no = 0;
-        for (Seg &s : segs) {
+        for (uint32_t si = 0; si < segs.size(); ++si) {
+            const Seg &s = segs[si];
+            pk_t pk = s.pk;            // (placement never writes to the segment: it is repeated after a revalidation)
+            bool store_rc = s.store_rc;
             if (s.ctg != cur_ctg) {
                 cur_ctg = s.ctg;
                 part_no = 0;
@@ -1602,19 +1626,21 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
             bool two = false;
             Placed a, b;
             a.ctg = b.ctg = s.ctg;
+            a.key = 2 * si;
+            b.key = 2 * si + 1;
             if (s.mid_job >= 0 || s.mid_job == -2) {
-                uint32_t bp = s.mid_job >= 0 ? best_pos[s.mid_job] : 0;
+                uint32_t bp = s.mid_job >= 0 ? s.bp : 0;
                 if (bp < k + 1u)
                     bp = 0;
                 if (s.mid_job >= 0 && (size_t)bp + k + 1u > s.len)
                     bp = s.len;
                 uint32_t left = bp, right = s.len - bp;
                 if (left == 0) {
-                    s.store_rc = (s.middle < s.kmer2.data()) ? s.use_rc : !s.use_rc;
-                    s.pk = std::minmax(s.middle, s.kmer2.data());
+                    store_rc = (s.middle < s.kmer2.data()) ? s.use_rc : !s.use_rc;
+                    pk = std::minmax(s.middle, s.kmer2.data());
                 } else if (right == 0) {
-                    s.store_rc = (s.kmer1.data() < s.middle) ? s.use_rc : !s.use_rc;
-                    s.pk = std::minmax(s.kmer1.data(), s.middle);
+                    store_rc = (s.kmer1.data() < s.middle) ? s.use_rc : !s.use_rc;
+                    pk = std::minmax(s.kmer1.data(), s.middle);
                 } else {
                     if (s.use_rc)
                         std::swap(left, right);
@@ -1659,12 +1685,12 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
             } else {
                 a.off = abs_off;
                 a.len = s.len;
-                a.rc = s.store_rc;
-                a.pk = s.pk;
-                if (s.known_gid != -2 && s.mid_job == -1)
+                a.rc = store_rc;
+                a.pk = pk;
+                if (s.known_gid >= 0 && s.mid_job == -1)
                     a.gid = s.known_gid; // looked up during classification, key unchanged since
                 else {
-                    const int32_t *m = map_segments.find(s.pk);
+                    const int32_t *m = map_segments.find(pk);
                     a.gid = m ? *m : -1;
                 }
                 a.part_no = part_no++;
