@@ -211,8 +211,9 @@ struct CommitData {
     std::vector<uint8_t> repetitive;                           // per new_ref_items entry (segment.h:224-247)
     const bytes_t *fetched = nullptr;                          // new references, then raw items
     std::vector<uint64_t> fetched_off;
-    const bytes_t *enc = nullptr;                              // deltas of enc_items
-    std::vector<uint64_t> enc_off;
+    std::vector<const uint8_t *> enc_ptr;                      // delta of every enc_items entry
+    std::vector<uint32_t> enc_len;
+    uint32_t sample_from = 0;                                  // the registrations [sample_from, commit_upto) of the window
 };
 
 struct ZJob { // one archive part to produce
@@ -513,6 +514,14 @@ struct CAGCCompressor::Impl {
         double t0 = 0, dev0 = 0, lap_t = 0;
         std::vector<uint64_t> new_splitters_added; // adaptive mode
         std::vector<uint32_t> subset;              // segments stage_classify works on
+        uint32_t n_samples = 1, s_from = 0;        // registrations of the window; first one not committed yet
+        struct Spec {                              // speculative delta of a placed item (by Placed::key)
+            uint64_t off = 0, enc_off = 0;
+            uint32_t gid = 0, len = 0, enc_len = 0;
+            bool rc = false, valid = false;
+        };
+        std::vector<Spec> spec;
+        std::vector<uint64_t> changed;             // k-mers whose terminator list changed in the last commit run
         uint32_t commit_upto = 0;                  // registrations of the window that are committed now
         std::vector<uint32_t> order;               // committed items in registration order
         std::vector<SampleLists> per_sample;
@@ -522,6 +531,8 @@ struct CAGCCompressor::Impl {
     bool stage_place(BatchState &b);
     bool stage_register(BatchState &b);
     bool stage_store(BatchState &b);
+    bool spec_encode(BatchState &b);
+    bool revalidate(BatchState &b);
     void lap(BatchState &b, const char *what);
     bool book_and_store(CommitData &cd);
     // stage accounting: wall time of the stage and its host-only part (wall minus the time inside the device library)
@@ -543,7 +554,7 @@ struct CAGCCompressor::Impl {
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
-    bytes_t enc_buf, fetch_buf; // grown, never shrunk
+    bytes_t enc_buf, enc_buf2, fetch_buf; // grown, never shrunk (enc_buf: the window's speculative deltas, enc_buf2: per commit run)
     // scratch reused across registrations (no reallocation / page faults / zero fill per sample)
     std::vector<uint32_t> gid_slot, gid_epoch;
     uint32_t gid_epoch_ctr = 0;
@@ -1155,12 +1166,121 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     b.lap_t = b.t0;
     if (!stage_scan(b))
         return false;
+    b.n_samples = ctgs.empty() ? 1u : ctgs.back().sample_idx + 1;
     b.subset.resize(seg_buf.size());
     std::iota(b.subset.begin(), b.subset.end(), 0u);
-    if (!stage_classify(b) || !stage_place(b) || !stage_register(b))
+    if (!stage_classify(b) || !stage_place(b))
         return false;
-    n_committed = b.commit_upto;
-    return stage_store(b);
+    // several registrations in the window: everything that can be encoded already (group known and stored) is, in one batch
+    if (b.n_samples > 1 && !spec_encode(b))
+        return false;
+    ++st.windows;
+    for (b.s_from = 0;;) {
+        ++st.commit_runs;
+        if (!stage_register(b) || !stage_store(b))
+            return false;
+        n_committed = b.commit_upto;
+        // append / adaptive mode: the caller classifies the rest again (unpacked groups and new splitters change more than
+        // the dependencies revalidate() follows; their windows hold one registration anyway)
+        if (b.commit_upto >= b.n_samples || appending || adaptive)
+            break;
+        b.s_from = b.commit_upto;
+        if (!revalidate(b))
+            return false;
+    }
+    return true;
+}
+
+// Up-front LZ encode of the window's items whose group already has its reference: group references never change
+// (segment.cpp:41-48), so these deltas stay valid whatever earlier registrations of the window mint.
+bool CAGCCompressor::Impl::spec_encode(BatchState &b)
+{
+    const std::vector<Placed> &placed = placed_buf;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    b.spec.assign(2 * seg_buf.size(), BatchState::Spec());
+    std::vector<uint32_t> items;
+    for (uint32_t i = 0; i < placed.size(); ++i)
+        if (placed[i].gid >= (int32_t)NO_RAW_GROUPS && groups[placed[i].gid].exists && !groups[placed[i].gid].packed)
+            items.push_back(i);
+    if (items.empty())
+        return true;
+    const size_t ne = items.size();
+    std::vector<uint32_t> gid(ne), len(ne);
+    std::vector<uint64_t> off(ne), eoff(ne + 1, 0);
+    std::vector<uint8_t> rc(ne);
+    uint64_t tot = 0;
+    for (size_t i = 0; i < ne; ++i) {
+        const Placed &pl = placed[items[i]];
+        gid[i] = (uint32_t)pl.gid;
+        off[i] = pl.off;
+        len[i] = pl.len;
+        rc[i] = pl.rc;
+        tot += pl.len;
+    }
+    bytes_t &enc = enc_buf;
+    uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 20));
+    for (;;) {
+        if (enc.size() < cap)
+            enc.resize(cap);
+        int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), b.d_base, off.data(), len.data(), rc.data(), enc.data(), cap, eoff.data()));
+        if (r == AGC_HIP_ECAP) {
+            cap = eoff[ne] + 64;
+            continue;
+        }
+        if (!hip_ok(r, "lz_encode_batch"))
+            return false;
+        break;
+    }
+    for (size_t i = 0; i < ne; ++i) {
+        const Placed &pl = placed[items[i]];
+        BatchState::Spec &sp = b.spec[pl.key];
+        sp.valid = true;
+        sp.gid = gid[i];
+        sp.off = pl.off;
+        sp.len = pl.len;
+        sp.rc = pl.rc;
+        sp.enc_off = eoff[i];
+        sp.enc_len = (uint32_t)(eoff[i + 1] - eoff[i]);
+    }
+    st.lz_encoded += ne;
+    st.delta_bytes += eoff[ne];
+    stage_end(st.t_encode, st.h_encode, t0, dev0);
+    return true;
+}
+
+// After a commit run that minted groups: the not yet committed segments whose decision read what has changed are
+// classified again against the current state -- exactly what processing the registrations one after the other would
+// have seen.  Dependencies of a decision (add_segment, agc_compressor.cpp:1275-1499):
+//   both splitters, key known          -> none (a key never leaves the map, its group never changes)
+//   both splitters, key unknown        -> the key itself (minted meanwhile?) and the terminator lists of its two k-mers
+//                                         (missing-middle search, :1502-1535)
+//   one splitter                       -> the terminator list of that k-mer (candidate groups, :1640-1690)
+//   no splitter                        -> none
+bool CAGCCompressor::Impl::revalidate(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    std::vector<Seg> &segs = seg_buf;
+    std::sort(b.changed.begin(), b.changed.end());
+    b.changed.erase(std::unique(b.changed.begin(), b.changed.end()), b.changed.end());
+    auto changed = [&](uint64_t kmer) { return std::binary_search(b.changed.begin(), b.changed.end(), kmer); };
+    b.subset.clear();
+    for (uint32_t si = 0; si < segs.size(); ++si) {
+        const Seg &s = segs[si];
+        if (ctgs[s.ctg].sample_idx < b.s_from)
+            continue;
+        const bool ff = s.front.full, bf = s.back.full;
+        if (ff != bf) {
+            if (changed(s.one_kmer.data()))
+                b.subset.push_back(si);
+        } else if (ff && bf && !concatenated && s.known_gid == -1) {
+            if (changed(s.front.data()) || changed(s.back.data()) || map_segments.find(std::minmax(s.front.data(), s.back.data())))
+                b.subset.push_back(si);
+        }
+    }
+    st.revalidated += b.subset.size();
+    if (!b.subset.empty() && !stage_classify(b))
+        return false;
+    return stage_place(b); // cheap, and picks up keys that are in the map by now (known_gid < 0 is looked up again)
 }
 
 // AGC_AMD_LAPS=1: wall time of every host sub-stage of a registration on stderr (profiling aid)
@@ -1714,15 +1834,17 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
     std::vector<Placed> &placed = placed_buf;
     LAP("placement");
     // ---- speculation window: the contigs may belong to several consecutive samples that were
-    // all classified against the SAME state.  State changes only when a sample mints a new group, so the
-    // classification is valid for every sample up to and including the first one with a new item; later
-    // samples of the window are handed back to the caller (n_committed) and classified again.
-    const uint32_t n_samples = ctgs.empty() ? 1u : ctgs.back().sample_idx + 1;
+    // all classified against the SAME state.  State changes only when a sample mints a new group (or, in append mode,
+    // unpacks one), so the classification is valid for every sample up to and including the first one that does; this
+    // COMMIT RUN takes the registrations [s_from, commit_upto).  What comes after it is revalidated (process_batch).
+    const uint32_t n_samples = b.n_samples, s_from = b.s_from;
     uint32_t &commit_upto = b.commit_upto;
     commit_upto = n_samples; // exclusive
-    for (const Placed &pl : placed)
-        if ((pl.gid < 0 || groups[pl.gid].packed) && ctgs[pl.ctg].sample_idx + 1 < commit_upto)
-            commit_upto = ctgs[pl.ctg].sample_idx + 1; // (an unpacked group changes later classifications as a new one does)
+    for (const Placed &pl : placed) {
+        const uint32_t sx = ctgs[pl.ctg].sample_idx;
+        if (sx >= s_from && (pl.gid < 0 || groups[pl.gid].packed) && sx + 1 < commit_upto)
+            commit_upto = sx + 1;
+    }
 
     // ---- register_segments per sample (agc_compressor.cpp:954-971; agc_compressor.h:384-435) ----
     // order of CBufferedSegPart's lists and of the std::set of new parts: (sample name, contig name,
@@ -1753,7 +1875,7 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
         std::vector<std::pair<uint64_t, uint32_t>> keyed;
         keyed.reserve(placed.size());
         for (uint32_t i = 0; i < placed.size(); ++i)
-            if (ctgs[placed[i].ctg].sample_idx < commit_upto)
+            if (ctgs[placed[i].ctg].sample_idx >= s_from && ctgs[placed[i].ctg].sample_idx < commit_upto)
                 keyed.push_back({((uint64_t)ctg_rank[placed[i].ctg] << 32) | placed[i].part_no, i});
         if (!std::is_sorted(keyed.begin(), keyed.end()))
             std::sort(keyed.begin(), keyed.end());
@@ -1788,10 +1910,10 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
     // per sample: lists of items per group, raw groups by distribute_segments(0, 0, 16) on the sorted
     // list of group 0 (agc_compressor.h:417-435)
     std::vector<SampleLists> &per_sample = b.per_sample;
-    per_sample.assign(commit_upto, SampleLists());
+    per_sample.assign(commit_upto - s_from, SampleLists());
     {
         size_t pos = 0;
-        for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
+        for (uint32_t sidx = s_from; sidx < commit_upto; ++sidx) {
             size_t end = pos;
             while (end < order.size() && ctgs[placed[order[end]].ctg].sample_idx == sidx)
                 ++end;
@@ -1803,7 +1925,7 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
             const size_t n_moved = n0 - (n0 + 15) / 16;
             for (size_t j = 0; j < n0; ++j)
                 placed[raw0[j]].gid = j < n_moved ? (int32_t)(1 + (j % 15)) : 0;
-            SampleLists &sl = per_sample[sidx];
+            SampleLists &sl = per_sample[sidx - s_from];
             // slot of every group touched by this registration (epoch-stamped scratch instead of a hash map)
             if (gid_slot.size() < groups.size()) {
                 gid_slot.resize(groups.size() + groups.size() / 4 + 64, 0);
@@ -1861,7 +1983,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     std::vector<uint32_t> enc_items;
     {
         std::vector<uint8_t> will_exist(groups.size(), 0);
-        for (uint32_t sidx = 0; sidx < commit_upto; ++sidx)
+        for (uint32_t sidx = 0; sidx < per_sample.size(); ++sidx)
             for (size_t li = 0; li < per_sample[sidx].n_lists(); ++li) {
                 const uint32_t gid = per_sample[sidx].gids[li];
                 for (uint32_t ii = per_sample[sidx].begin[li]; ii < per_sample[sidx].begin[li + 1]; ++ii) {
@@ -1879,13 +2001,19 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     LAP("classes");
     // append mode: the first add to a group of the input archive unpacks it (segment.cpp:19-20, 39-40)
     if (appending)
-        for (uint32_t sidx = 0; sidx < commit_upto; ++sidx)
+        for (uint32_t sidx = 0; sidx < per_sample.size(); ++sidx)
             for (uint32_t gid : per_sample[sidx].gids)
                 if (groups[gid].packed && !unpack_group(gid))
                     return false;
     // map_segments / terminators updates happen when a group is first stored (:1003-1028)
-    for (uint32_t idx : new_ref_items)
+    b.changed.clear();
+    for (uint32_t idx : new_ref_items) {
         note_new_group(placed[idx].pk, (uint32_t)placed[idx].gid);
+        if (placed[idx].pk.first != NO_KMER && placed[idx].pk.second != NO_KMER) { // terminator lists that gained an entry
+            b.changed.push_back(placed[idx].pk.first);
+            b.changed.push_back(placed[idx].pk.second);
+        }
+    }
     // GPU: register the new references (index build) and pull back what the host must pack
     std::vector<uint32_t> lag_cnt, lag_cur;
     std::vector<uint8_t> repetitive;
@@ -1951,40 +2079,58 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     }
     stage_end(st.t_register, st.h_register, t0, dev0);
     t0 = now();
-    // GPU: LZ-encode every other item against its group's reference (segment.cpp:50-58) -- one batch for
-    // all committed samples
-    bytes_t &enc = enc_buf;
-    std::vector<uint64_t> enc_off(enc_items.size() + 1, 0);
-    if (!enc_items.empty()) {
-        const size_t ne = enc_items.size();
-        std::vector<uint32_t> gid(ne), len(ne);
-        std::vector<uint64_t> off(ne);
-        std::vector<uint8_t> rc(ne);
-        uint64_t tot = 0;
-        for (size_t i = 0; i < ne; ++i) {
+    // LZ deltas (segment.cpp:50-58): items whose group already had its reference when the window was classified were encoded
+    // up front in one batch (spec_encode); only the others -- followers of a group minted in this window, segments that a
+    // revalidation placed differently -- are encoded now
+    std::vector<const uint8_t *> enc_ptr(enc_items.size(), nullptr);
+    std::vector<uint32_t> enc_len(enc_items.size(), 0);
+    {
+        std::vector<uint32_t> todo; // positions in enc_items
+        for (uint32_t i = 0; i < enc_items.size(); ++i) {
             const Placed &pl = placed[enc_items[i]];
-            gid[i] = (uint32_t)pl.gid;
-            off[i] = pl.off;
-            len[i] = pl.len;
-            rc[i] = pl.rc;
-            tot += pl.len;
+            const BatchState::Spec *sp = pl.key < b.spec.size() ? &b.spec[pl.key] : nullptr;
+            if (sp && sp->valid && sp->gid == (uint32_t)pl.gid && sp->off == pl.off && sp->len == pl.len && sp->rc == pl.rc) {
+                enc_ptr[i] = enc_buf.data() + sp->enc_off;
+                enc_len[i] = sp->enc_len;
+            } else
+                todo.push_back(i);
         }
-        uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 20));
-        for (;;) {
-            if (enc.size() < cap)
-                enc.resize(cap);
-            int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap,
-                                                     enc_off.data()));
-            if (r == AGC_HIP_ECAP) {
-                cap = enc_off[ne] + 64;
-                continue;
+        if (!todo.empty()) {
+            const size_t ne = todo.size();
+            std::vector<uint32_t> gid(ne), len(ne);
+            std::vector<uint64_t> off(ne), eoff(ne + 1, 0);
+            std::vector<uint8_t> rc(ne);
+            uint64_t tot = 0;
+            for (size_t i = 0; i < ne; ++i) {
+                const Placed &pl = placed[enc_items[todo[i]]];
+                gid[i] = (uint32_t)pl.gid;
+                off[i] = pl.off;
+                len[i] = pl.len;
+                rc[i] = pl.rc;
+                tot += pl.len;
             }
-            if (!hip_ok(r, "lz_encode_batch"))
-                return false;
-            break;
+            bytes_t &enc = enc_buf2;
+            uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 16));
+            for (;;) {
+                if (enc.size() < cap)
+                    enc.resize(cap);
+                int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap,
+                                                         eoff.data()));
+                if (r == AGC_HIP_ECAP) {
+                    cap = eoff[ne] + 64;
+                    continue;
+                }
+                if (!hip_ok(r, "lz_encode_batch"))
+                    return false;
+                break;
+            }
+            for (size_t i = 0; i < ne; ++i) {
+                enc_ptr[todo[i]] = enc.data() + eoff[i];
+                enc_len[todo[i]] = (uint32_t)(eoff[i + 1] - eoff[i]);
+            }
+            st.lz_encoded += ne;
+            st.delta_bytes += eoff[ne];
         }
-        st.lz_encoded += ne;
-        st.delta_bytes += enc_off[ne];
     }
     stage_end(st.t_encode, st.h_encode, t0, dev0);
     t0 = now();
@@ -1993,6 +2139,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     cdta.ctgs = b.ctgs;
     cdta.placed = &placed;
     cdta.commit_upto = commit_upto;
+    cdta.sample_from = b.s_from;
     cdta.per_sample = std::move(per_sample);
     cdta.new_ref_items = std::move(new_ref_items);
     cdta.raw_items = std::move(raw_items);
@@ -2000,8 +2147,8 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     cdta.repetitive = std::move(repetitive);
     cdta.fetched = &fetched;
     cdta.fetched_off = std::move(fetched_off);
-    cdta.enc = &enc;
-    cdta.enc_off = std::move(enc_off);
+    cdta.enc_ptr = std::move(enc_ptr);
+    cdta.enc_len = std::move(enc_len);
     if (dist_world > 1) {
         make_record(cdta, new_splitters_added);
         if (dist_rank != dist_writer)
@@ -2019,8 +2166,9 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
     const uint32_t n_ctg = (uint32_t)ctgs.size(), commit_upto = cdta.commit_upto;
     std::vector<SampleLists> &per_sample = cdta.per_sample;
     const std::vector<uint32_t> &new_ref_items = cdta.new_ref_items, &raw_items = cdta.raw_items, &enc_items = cdta.enc_items;
-    const bytes_t &fetched = *cdta.fetched, &enc = *cdta.enc;
-    const std::vector<uint64_t> &fetched_off = cdta.fetched_off, &enc_off = cdta.enc_off;
+    const bytes_t &fetched = *cdta.fetched;
+    const std::vector<uint64_t> &fetched_off = cdta.fetched_off;
+    const uint32_t sample_from = cdta.sample_from;
     // (b) per sample, per group, in list order: CSegment::add / add_raw (segment.cpp:14-80); then the sample's
     // zstd jobs, collection records and the end-of-registration steps
     std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size()), pos_enc(placed.size());
@@ -2037,7 +2185,7 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
     {
         std::set<CollectionV3::ContigDesc *> seen;
         for (uint32_t c = 0; c < n_ctg; ++c) {
-            if (ctgs[c].sample_idx >= commit_upto)
+            if (ctgs[c].sample_idx < sample_from || ctgs[c].sample_idx >= commit_upto)
                 continue;
             std::string stored = ctgs[c].sample.empty() ? CollectionV3::extract_contig_name(ctgs[c].name) : ctgs[c].sample;
             CollectionV3::SampleDesc &sd = coll.sample_by_name(stored);
@@ -2054,8 +2202,9 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
     // the end-of-registration steps are then replayed sample by sample, so the archive is laid out exactly
     // as if every sample had been finished before the next one started
     std::vector<ZJob> all_jobs;
-    std::vector<size_t> jobs_end(commit_upto, 0);
-    for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
+    const uint32_t n_regs = (uint32_t)per_sample.size();
+    std::vector<size_t> jobs_end(n_regs, 0);
+    for (uint32_t sidx = 0; sidx < n_regs; ++sidx) {
         SampleLists &sl = per_sample[sidx];
         std::vector<ZJob> jobs;
         auto book = [&](size_t li_begin, size_t li_end, std::vector<ZJob> &jobs) {
@@ -2089,8 +2238,8 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                         if (g.lzp_off.size() == pack_cardinality)
                             make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
                         const uint32_t ei = pos_enc[idx];
-                        const uint8_t *dp = enc.data() + enc_off[ei];
-                        const size_t dn = enc_off[ei + 1] - enc_off[ei];
+                        const uint8_t *dp = cdta.enc_ptr[ei];
+                        const size_t dn = cdta.enc_len[ei];
                         if (dn == 0)
                             igid = 0; // same sequence as the reference (segment.cpp:60-63)
                         else {
@@ -2154,7 +2303,7 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
         std::cerr << "registration: " << placed.size() << " items; host-only seconds so far: scan " << st.h_scan << " classify " << st.h_classify
                   << " register " << st.h_register << " encode " << st.h_encode << " store " << st.h_store << std::endl;
     run_jobs(all_jobs, false);
-    for (uint32_t sidx = 0; sidx < commit_upto; ++sidx) {
+    for (uint32_t sidx = 0; sidx < n_regs; ++sidx) {
         add_job_parts(all_jobs, sidx ? jobs_end[sidx - 1] : 0, jobs_end[sidx]);
         after_registration();
     }
@@ -2308,8 +2457,8 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
                 n = cd.fetched_off[fi + 1] - cd.fetched_off[fi];
             } else {
                 const uint32_t ei = pos_enc[idx];
-                b = cd.enc->data() + cd.enc_off[ei];
-                n = cd.enc_off[ei + 1] - cd.enc_off[ei];
+                b = cd.enc_ptr[ei];
+                n = cd.enc_len[ei];
             }
             put32(r, (uint32_t)n);
             r.insert(r.end(), b, b + n);
@@ -2382,8 +2531,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     cd.per_sample.resize(1);
     SampleLists &sl = cd.per_sample[0];
     bytes_t refs_raw, raws, enc;
-    std::vector<uint64_t> ref_off{0}, raw_off{0};
-    cd.enc_off.push_back(0);
+    std::vector<uint64_t> ref_off{0}, raw_off{0}, enc_off{0};
     std::vector<uint32_t> reg_gid, reg_len;
     std::vector<uint64_t> reg_off; // payload offsets inside the record (device copy)
     for (uint32_t li = 0; li < n_lists && rr.ok; ++li) {
@@ -2427,7 +2575,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
             } else {
                 cd.enc_items.push_back(idx);
                 enc.insert(enc.end(), rr.p, rr.p + pn);
-                cd.enc_off.push_back(enc.size());
+                enc_off.push_back(enc.size());
             }
             rr.p += pn;
             sl.items.push_back(idx);
@@ -2464,7 +2612,10 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     cd.ctgs = &ctgs;
     cd.placed = &placed;
     cd.fetched = &fetched;
-    cd.enc = &enc;
+    for (size_t i = 0; i + 1 < enc_off.size(); ++i) {
+        cd.enc_ptr.push_back(enc.data() + enc_off[i]);
+        cd.enc_len.push_back((uint32_t)(enc_off[i + 1] - enc_off[i]));
+    }
     return book_and_store(cd);
 }
 
