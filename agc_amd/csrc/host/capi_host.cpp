@@ -70,6 +70,16 @@ int agc_cmp_append(void *h, const char *in_archive, const char *out_archive, uin
     return ((CAGCCompressor *)h)->Append(in_archive, out_archive, verbosity, true, concatenated != 0, adaptive != 0, n_threads, 0.0) ? 1 : 0;
 }
 
+int agc_cmp_prepare_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const uint8_t *d_codes,
+                               const uint64_t *ctg_off)
+{
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < n_ctg; ++i)
+        names.emplace_back(contig_names[i]);
+    return ((CAGCCompressor *)h)->PrepareSampleDevice(sample_name, names, d_codes, ctg_off) ? 1 : 0;
+}
+int agc_cmp_commit_prepared(void *h) { return ((CAGCCompressor *)h)->CommitPrepared() ? 1 : 0; }
+
 int agc_cmp_close(void *h, uint32_t n_threads) { return ((CAGCCompressor *)h)->Close(n_threads) ? 1 : 0; }
 
 const char *agc_cmp_zstd_version(void *h) { return ((CAGCCompressor *)h)->ZstdVersion(); }
@@ -83,7 +93,8 @@ int agc_cmp_stats(void *h, double *out, uint32_t n)
     const double v[] = {(double)s.bases, (double)s.segments, (double)s.new_groups, (double)s.one_splitter, (double)s.middle_tried,
                         (double)s.middle_split, (double)s.lz_encoded, (double)s.delta_bytes, (double)s.ref_bytes, (double)s.zstd_in,
                         (double)s.zstd_out, (double)s.archive_bytes, s.t_scan, s.t_classify, s.t_gpu_aux, s.t_register, s.t_encode,
-                        s.t_store, s.t_zstd, s.t_io, s.t_device, s.h_scan, s.h_classify, s.h_gpu_aux, s.h_register, s.h_encode, s.h_store};
+                        s.t_store, s.t_zstd, s.t_io, s.t_device, s.h_scan, s.h_classify, s.h_gpu_aux, s.h_register, s.h_encode, s.h_store,
+                        (double)s.windows, (double)s.commit_runs, (double)s.revalidated};
     const uint32_t m = sizeof(v) / sizeof(v[0]);
     for (uint32_t i = 0; i < n && i < m; ++i)
         out[i] = v[i];

@@ -533,6 +533,13 @@ struct CAGCCompressor::Impl {
     bool stage_store(BatchState &b);
     bool spec_encode(BatchState &b);
     bool revalidate(BatchState &b);
+    bool batch_prepare(BatchState &b, std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, bool always_speculate);
+    bool batch_commit(BatchState &b, uint32_t &n_committed);
+    // a sample classified ahead of its turn (multi-GPU mode, PrepareSampleDevice): its working set, and the k-mers whose
+    // terminator lists changed since (through other ranks' records)
+    std::unique_ptr<BatchState> prepared;
+    std::vector<Contig> prepared_ctgs;
+    std::vector<uint64_t> changed_log;
     void lap(BatchState &b, const char *what);
     bool book_and_store(CommitData &cd);
     // stage accounting: wall time of the stage and its host-only part (wall minus the time inside the device library)
@@ -1150,13 +1157,23 @@ bool CAGCCompressor::Impl::find_new_splitters(const bytes_t &ctg, std::vector<ui
     return true;
 }
 
-// One call = one pass over a window of registrations: scan -> classification -> placement -> registration -> store.
+// One call = one pass over a window of registrations: scan -> classification -> placement -> [speculative encode] ->
+// commit runs (registration + store, revalidation in between).
 // The stages share their working set through BatchState (and the reusable seg_buf / placed_buf scratch of Impl).
 bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data,
                                          uint32_t &n_committed)
 {
     n_committed = 0;
     BatchState b;
+    if (!batch_prepare(b, ctgs, d_base, host_data, false))
+        return false;
+    return batch_commit(b, n_committed);
+}
+
+// first half: everything that only reads the classification state
+bool CAGCCompressor::Impl::batch_prepare(BatchState &b, std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data,
+                                         bool always_speculate)
+{
     b.ctgs = &ctgs;
     b.d_base = d_base;
     b.host_data = host_data;
@@ -1171,10 +1188,17 @@ bool CAGCCompressor::Impl::process_batch(std::vector<Contig> &ctgs, const uint8_
     std::iota(b.subset.begin(), b.subset.end(), 0u);
     if (!stage_classify(b) || !stage_place(b))
         return false;
-    // several registrations in the window: everything that can be encoded already (group known and stored) is, in one batch
-    if (b.n_samples > 1 && !spec_encode(b))
+    // several registrations in the window (or a sample prepared ahead of its turn): everything that can be encoded already
+    // (group known and stored) is, in one batch
+    if ((b.n_samples > 1 || always_speculate) && !spec_encode(b))
         return false;
     ++st.windows;
+    return true;
+}
+
+// second half: the commit runs
+bool CAGCCompressor::Impl::batch_commit(BatchState &b, uint32_t &n_committed)
+{
     for (b.s_from = 0;;) {
         ++st.commit_runs;
         if (!stage_register(b) || !stage_store(b))
@@ -2318,6 +2342,10 @@ void CAGCCompressor::Impl::note_new_group(const pk_t &pk, uint32_t gid)
         map_segments[pk] = (int32_t)gid;
     else if (*it > (int32_t)gid)
         *it = (int32_t)gid;
+    if (prepared && pk.first != NO_KMER && pk.second != NO_KMER) {
+        changed_log.push_back(pk.first);
+        changed_log.push_back(pk.second);
+    }
     if (pk.first != NO_KMER && pk.second != NO_KMER) {
         auto &v1 = terminators[pk.first];
         v1.push_back(pk.second);
@@ -2642,32 +2670,60 @@ void CAGCCompressor::Impl::finish_groups()
 bool CAGCCompressor::AddSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
                                      const uint64_t *ctg_off)
 {
+    return PrepareSampleDevice(sample_name, contig_names, d_codes, ctg_off) && CommitPrepared();
+}
+
+// scan + classification + speculative encode of a sample, against the state this process has NOW; nothing is registered
+// yet.  d_codes must stay untouched until CommitPrepared.  In the multi-GPU mode a rank calls this for its next sample
+// while earlier samples are still being committed elsewhere (agc_amd/dist.py).
+bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
+                                         const uint64_t *ctg_off)
+{
     Impl &I = *p;
-    if (!I.created || I.concatenated)
+    if (!I.created || I.concatenated || I.prepared)
         return false;
-    I.coll.reset_prev_sample_name();
-    std::vector<Contig> ctgs;
+    I.prepared_ctgs.clear();
     for (size_t c = 0; c < contig_names.size(); ++c) {
-        if (!I.coll.register_sample_contig(sample_name, contig_names[c])) {
-            I.err("Error: Pair sample_name:contig_name " + sample_name + ":" + contig_names[c] + " is already in the archive!");
-            continue;
-        }
         Contig ct;
         ct.sample = sample_name;
         ct.name = contig_names[c];
         ct.off = ctg_off[c];
         ct.len = ctg_off[c + 1] - ctg_off[c];
-        ctgs.push_back(ct);
+        I.prepared_ctgs.push_back(ct);
     }
-    if (ctgs.empty())
-        return true;
-    // contigs skipped above would break contiguity: only accept the all-or-nothing case
-    if (ctgs.size() != contig_names.size()) {
-        I.err("duplicate contigs inside a device-resident sample are not supported");
+    I.changed_log.clear();
+    I.prepared.reset(new Impl::BatchState());
+    if (!I.batch_prepare(*I.prepared, I.prepared_ctgs, d_codes, nullptr, I.dist_world > 1 && !I.adaptive && !I.appending)) {
+        I.prepared.reset();
         return false;
     }
+    return true;
+}
+
+// the order-dependent half: collection registration, revalidation against what changed since PrepareSampleDevice, commit
+bool CAGCCompressor::CommitPrepared()
+{
+    Impl &I = *p;
+    if (!I.prepared)
+        return false;
+    std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
+    I.coll.reset_prev_sample_name();
+    for (auto &ct : I.prepared_ctgs)
+        if (!I.coll.register_sample_contig(ct.sample, ct.name)) {
+            I.err("Error: Pair sample_name:contig_name " + ct.sample + ":" + ct.name + " is already in the archive!");
+            return false; // (AddSampleFiles skips such contigs; a device-resident sample is all or nothing)
+        }
+    if (I.prepared_ctgs.empty())
+        return true;
+    if (!I.changed_log.empty()) {
+        b->changed.swap(I.changed_log);
+        I.changed_log.clear();
+        b->s_from = 0;
+        if (!I.revalidate(*b))
+            return false;
+    }
     uint32_t n_done = 0;
-    return I.process_batch(ctgs, d_codes, nullptr, n_done);
+    return I.batch_commit(*b, n_done);
 }
 
 bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std::string>> &files, uint32_t no_threads)

@@ -82,6 +82,13 @@ public:
     const std::vector<uint8_t> &LastRecord() const;
     bool ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record);
 
+    // AddSampleDevice in two halves: everything that only reads the classification state (scan, classification, LZ encode of
+    // the segments whose group is known), and the order-dependent commit.  Between the two other samples may be committed
+    // (ApplyRecord); the commit revalidates exactly the decisions that read what changed.
+    bool PrepareSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
+                             const uint64_t *ctg_off);
+    bool CommitPrepared();
+
     // src/core/agc_compressor.cpp:2094-2115 (close_compression) + ~CArchive
     bool Close(uint32_t no_threads);
 

@@ -67,3 +67,54 @@ class DistCompressor:
                 torch.cuda.synchronize(self.hbm)
             self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None)
         return owner
+
+    def compress(self, n_total, get_sample, prefetch=True):
+        """All `n_total` samples, in order.  get_sample(i) -> (sample_name, contig_names, d_codes_ptr, ctg_off) is called for the samples
+        this rank owns only; whatever backs d_codes_ptr must stay alive and unchanged until that sample is committed.
+        prefetch: a rank classifies and speculatively encodes its NEXT sample (PrepareSampleDevice) before it joins the broadcasts of
+        the samples in front of it, so the GPUs work in parallel and only the short commit (revalidation of the decisions that read
+        state changed meanwhile + registration + record) is serial.  Not in adaptive mode: new splitters change later scans."""
+        nxt = self.rank if self.rank < n_total else None
+        prepared = None
+        for i in range(n_total):
+            owner = self.owner_of(i)
+            if prefetch and prepared is None and nxt is not None:
+                self.cmp.prepare_sample_dev(*get_sample(nxt))
+                prepared = nxt
+            if self.rank == owner:
+                if prepared is None:
+                    self.cmp.prepare_sample_dev(*get_sample(i))
+                    prepared = i
+                assert prepared == i
+                self._commit_and_publish(i)
+                prepared = None
+                nxt = i + self.world if i + self.world < n_total else None
+            else:
+                self._receive(owner)
+
+    def _broadcast(self, owner, rec):
+        torch, dist = self.torch, self.dist
+        n = torch.zeros(1, dtype=torch.int64, device=self.comm)
+        if rec is not None:
+            n[0] = rec.size
+        dist.broadcast(n, src=owner)
+        size = int(n.item())
+        buf = torch.from_numpy(rec).to(self.comm) if rec is not None else torch.empty(size, dtype=torch.uint8, device=self.comm)
+        dist.broadcast(buf, src=owner)
+        self.bytes_broadcast += size
+        return buf, size
+
+    def _commit_and_publish(self, i):
+        self.cmp.commit_prepared()
+        self._broadcast(self.rank, self.cmp.last_record())
+        self.next_sample = i + 1
+
+    def _receive(self, owner):
+        torch = self.torch
+        buf, size = self._broadcast(owner, None)
+        host = np.ascontiguousarray(buf.cpu().numpy())
+        d_buf = buf if buf.is_cuda else (buf.to(self.hbm) if self.hbm is not None else None)
+        if d_buf is not None:
+            torch.cuda.synchronize(self.hbm)
+        self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None)
+        self.next_sample += 1

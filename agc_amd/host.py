@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libagc_host.so")
 STAT_NAMES = ["bases", "segments", "new_groups", "one_splitter", "middle_tried", "middle_split", "lz_encoded", "delta_bytes",
               "ref_bytes", "zstd_in", "zstd_out", "archive_bytes",
               "t_scan", "t_classify", "t_gpu_aux", "t_register", "t_encode", "t_store", "t_zstd", "t_io", "t_device",
-              "h_scan", "h_classify", "h_gpu_aux", "h_register", "h_encode", "h_store"]
+              "h_scan", "h_classify", "h_gpu_aux", "h_register", "h_encode", "h_store", "windows", "commit_runs", "revalidated"]
 
 _lib = None
 
@@ -40,6 +40,8 @@ def bind(L):
     L.agc_cmp_set_distributed.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.agc_cmp_last_record.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
     L.agc_cmp_apply_record.argtypes = [vp, vp, C.c_uint64, vp]
+    L.agc_cmp_prepare_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
+    L.agc_cmp_commit_prepared.argtypes = [vp]
     L.agc_cmp_append.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32]
     return L
 
@@ -109,6 +111,18 @@ class Compressor:
     def set_distributed(self, rank, world_size, writer_rank=0):
         if not self.L.agc_cmp_set_distributed(self.h, rank, world_size, writer_rank):
             raise RuntimeError("SetDistributed failed (must precede create)")
+
+    def prepare_sample_dev(self, sample_name, contig_names, d_codes, ctg_off):
+        """scan + classification + speculative encode against the current state; d_codes must stay valid until commit_prepared()"""
+        n = len(contig_names)
+        names = (C.c_char_p * n)(*[c.encode() for c in contig_names])
+        off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+        if not self.L.agc_cmp_prepare_sample_dev(self.h, sample_name.encode(), n, names, d_codes, off.ctypes.data_as(C.POINTER(C.c_uint64))):
+            raise RuntimeError("PrepareSampleDevice failed (see stderr)")
+
+    def commit_prepared(self):
+        if not self.L.agc_cmp_commit_prepared(self.h):
+            raise RuntimeError("CommitPrepared failed (see stderr)")
 
     def last_record(self):
         """the commit record of the sample just added (numpy uint8 view copied out of the compressor)"""

@@ -37,7 +37,7 @@ def fasta_codes(path):
     return names, np.concatenate(seqs) if seqs else np.zeros(0, np.uint8), off
 
 
-def _worker(rank, world, port, name, files, out_path, q, on_gpu=False):
+def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -62,7 +62,23 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False):
         cmp_.create(out_path if rank == 0 else "", pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"],
                     min_match_len=opt["-l"], adaptive="-a" in args, n_threads=2)
         dc = DistCompressor(cmp_, dist, rank, world, device=device)
-        for i, f in enumerate(files):
+        keep = {}
+
+        def get_sample(i):
+            names, codes, off = fasta_codes(files[i])
+            sn = os.path.basename(files[i])
+            for suf in (".gz", ".fa", ".fasta", ".fna"):
+                sn = sn[:-len(suf)] if sn.endswith(suf) else sn
+            if on_gpu:
+                keep[i] = torch.from_numpy(np.concatenate([codes, np.full(4096, 4, np.uint8)])).to(device)
+                torch.cuda.synchronize()
+                return sn, names, keep[i].data_ptr(), off
+            keep[i] = codes
+            return sn, names, codes.ctypes.data, off
+
+        if prefetch:
+            dc.compress(len(files), get_sample, prefetch="-a" not in args)
+        for i, f in enumerate(files if not prefetch else []):
             if dc.owner_of(i) == rank:
                 names, codes, off = fasta_codes(f)
                 sn = os.path.basename(f)
@@ -79,13 +95,13 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False):
         cmp_.close()
         st = cmp_.stats()
         cmp_.close_handle()
-        q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"]))
+        q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"], st["revalidated"]))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
-        q.put((rank, "error: %r" % (e,), 0, 0))
+        q.put((rank, "error: %r" % (e,), 0, 0, 0))
 
 
-def _run(name, world, tmp_path, on_gpu):
+def _run(name, world, tmp_path, on_gpu, prefetch=False):
     files = COLL.build(name, str(tmp_path / "in"))
     out = str(tmp_path / "dist.agc")
     s = socket.socket()
@@ -94,7 +110,7 @@ def _run(name, world, tmp_path, on_gpu):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, name, files, out, q, on_gpu)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, name, files, out, q, on_gpu, prefetch)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted(q.get(timeout=300) for _ in ps)
     [p.join(timeout=60) for p in ps]
@@ -105,6 +121,7 @@ def _run(name, world, tmp_path, on_gpu):
     # every rank saw every record and minted the same groups
     assert len({r[2] for r in res}) == 1 and res[0][2] > 0
     assert len({r[3] for r in res}) == 1
+    return res
 
 
 @pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 2), ("syn_viral", 3), ("syn_shuffled", 2), ("syn_adaptive", 2),
@@ -113,6 +130,26 @@ def test_one_archive_from_n_ranks_equals_the_reference(name, world, tmp_path):
     from tests.devsim import build as simbuild
     simbuild.build()
     _run(name, world, tmp_path, on_gpu=False)
+
+
+@pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_snp", 3), ("syn_mixed", 2), ("syn_mixed", 3), ("syn_shuffled", 3), ("syn_viral", 2),
+                                        ("syn_adaptive", 2)])
+def test_prefetching_ranks_still_write_the_reference_archive(name, world, tmp_path):
+    """every rank classifies and speculatively encodes its next sample BEFORE the samples in front of it are committed; at its
+    turn only the decisions that read changed state are revalidated -- the archive must not notice"""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    res = _run(name, world, tmp_path, on_gpu=False, prefetch=True)
+    if name == "syn_snp":  # groups are minted by every sample here: some prepared decisions must have been taken again
+        assert sum(r[4] for r in res) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 3)])
+def test_prefetching_ranks_on_the_gpu(name, world, tmp_path):
+    from agc_amd import build
+    build.build_host()
+    _run(name, world, tmp_path, on_gpu=True, prefetch=True)
 
 
 @pytest.mark.gpu
