@@ -68,15 +68,17 @@ class DistCompressor:
             self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None)
         return owner
 
-    def compress(self, n_total, get_sample, prefetch=True):
-        """All `n_total` samples, in order.  get_sample(i) -> (sample_name, contig_names, d_codes_ptr, ctg_off) is called for the samples
+    def compress(self, n_total, get_sample, prefetch=True, start=0):
+        """The samples start .. n_total-1, in order (sample indices are global: i belongs to rank i mod N).
+        get_sample(i) -> (sample_name, contig_names, d_codes_ptr, ctg_off) is called for the samples
         this rank owns only; whatever backs d_codes_ptr must stay alive and unchanged until that sample is committed.
         prefetch: a rank classifies and speculatively encodes its NEXT sample (PrepareSampleDevice) before it joins the broadcasts of
         the samples in front of it, so the GPUs work in parallel and only the short commit (revalidation of the decisions that read
         state changed meanwhile + registration + record) is serial.  Not in adaptive mode: new splitters change later scans."""
-        nxt = self.rank if self.rank < n_total else None
+        nxt = start + (self.rank - start) % self.world
+        nxt = nxt if nxt < n_total else None
         prepared = None
-        for i in range(n_total):
+        for i in range(start, n_total):
             owner = self.owner_of(i)
             if prefetch and prepared is None and nxt is not None:
                 self.cmp.prepare_sample_dev(*get_sample(nxt))

@@ -179,7 +179,15 @@ def main():
     if single:
         from agc_amd.dist import DistCompressor
         dc = DistCompressor(cmp_, dist, rank, world, device=dev)
-        dc.add_sample(*(("ref", names, ref.data_ptr(), off) if rank == 0 else ()))  # sample 0: minted on rank 0, broadcast
+
+        def get_sample(i):
+            """global sample i: 0 = the reference genome (rank 0), then one sample per rank and step, committed in rank order"""
+            if i == 0:
+                return "ref", names, ref.data_ptr(), off
+            s_ = (i - rank) // world - (1 if rank == 0 else 0)
+            return f"s{rank}_{s_}", names, samples[s_].data_ptr(), off
+
+        dc.compress(1, get_sample)  # sample 0: minted on rank 0, its record (the whole reference set) broadcast
     else:
         cmp_.add_sample_dev("ref", names, ref.data_ptr(), off)
     t_ref = time.perf_counter() - t_ref0
@@ -189,9 +197,7 @@ def main():
         if not single:
             cmp_.add_sample_dev(f"{tag}{rank}_{s}", names, samples[s].data_ptr(), off)
             return
-        for _ in range(world):
-            mine = dc.owner_of(dc.next_sample) == rank
-            dc.add_sample(*((f"{tag}{rank}_{s}", names, samples[s].data_ptr(), off) if mine else ()))
+        dc.compress(1 + (s + 1) * world, get_sample, start=1 + s * world)  # (each step: the N samples prepared in parallel)
 
     n_steps = args.steps + args.warmup
     # weak scaling: samples are partitioned round-robin over ranks (one archive shard per rank), no data-path collective
