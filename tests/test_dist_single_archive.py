@@ -18,23 +18,7 @@ from tests import collections as COLL
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "archives.json")))
 
-_CNV = np.full(256, 30, np.uint8)
-_CNV[64] = _CNV[96] = 32
-for _i, _c in enumerate("ACGTNRYSWKMBDHVU"):
-    _CNV[ord(_c)] = _CNV[ord(_c) + 32] = _i
-
-
-def fasta_codes(path):
-    """(contig names, symbol codes back to back, offsets) the way the host reads a FASTA file"""
-    names, seqs = [], []
-    for rec in open(path, "rb").read().split(b">")[1:]:
-        head, _, body = rec.partition(b"\n")
-        names.append(head.rstrip(b"\r").decode())
-        b = np.frombuffer(body, np.uint8)
-        seqs.append(_CNV[b[b >= 64]])
-    off = np.zeros(len(seqs) + 1, np.uint64)
-    off[1:] = np.cumsum([s.size for s in seqs])
-    return names, np.concatenate(seqs) if seqs else np.zeros(0, np.uint8), off
+from agc_amd.fasta import read_codes as fasta_codes  # noqa: E402
 
 
 def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=False):
@@ -161,3 +145,26 @@ def test_one_archive_from_n_ranks_on_the_gpu(name, world, tmp_path):
     from agc_amd import build
     build.build_host()
     _run(name, world, tmp_path, on_gpu=True)
+
+
+@pytest.mark.gpu
+def test_dist_create_front_end_on_the_gpu(tmp_path):
+    """python -m agc_amd.dist_create under torch.distributed.run, two ranks sharing cuda:0 (gloo): the user-facing multi-GPU create"""
+    import subprocess
+    import sys
+    from agc_amd import build
+    build.build_host()
+    name = "syn_mixed"
+    args, _ = COLL.CONFIGS[name]
+    files = COLL.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "d.agc")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "agc_amd.dist_create", "--backend", "gloo"] + args + ["-t", "4", "-o", out] + files
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert os.path.exists(out), r.stderr[-3000:]
+    got = open(out, "rb").read()
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"], r.stderr[-2000:]
