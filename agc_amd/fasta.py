@@ -1,5 +1,5 @@
 """FASTA -> symbol codes on the host, the way the compressor's own reader does it (genome_io.cpp:208-252 framing,
-preprocess_raw_contig agc_compressor.cpp:907-951): used by the multi-GPU front end and by tests."""
+preprocess_raw_contig agc_compressor.cpp:907-951): used by the multi-GPU front end."""
 import gzip
 
 import numpy as np

@@ -1,0 +1,62 @@
+/* agc_cmp.h -- C ABI of the host-side compressor (libagc_host.so on top of libagc_hip.so): the reference's
+ * CAGCCompressor surface for `create` / `append` (src/core/agc_compressor.h:754-763, called from src/app/main.cpp:76-168)
+ * as plain C entry points, plus the additions for HBM-resident inputs and multi-GPU jobs.
+ * Every function returns 1 for success and 0 for failure (the reference's bool; the message goes to stderr), unless noted.
+ * There is no CPU fallback: agc_cmp_create / agc_cmp_append fail when no HIP device can be opened.
+ */
+#ifndef AGC_CMP_H
+#define AGC_CMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one compressor per archive and GPU; device = HIP device ordinal */
+void *agc_cmp_new(int device);
+void agc_cmp_delete(void *h);
+
+/* CAGCCompressor::Create (agc_compressor.cpp:2273-2327).  out_path "" = produce and discard the archive bytes, "-" = stdout;
+ * ref_file "" = splitters come from agc_cmp_set_splitters / agc_cmp_set_reference_dev. */
+int agc_cmp_create(void *h, const char *out_path, uint32_t pack_cardinality, uint32_t k, const char *ref_file, uint32_t segment_size,
+                   uint32_t min_match_len, int concatenated, int adaptive, uint32_t verbosity, uint32_t n_threads, double fallback_frac);
+/* CAGCCompressor::Append (agc_compressor.cpp:2330-2374) */
+int agc_cmp_append(void *h, const char *in_archive, const char *out_archive, uint32_t verbosity, int concatenated, int adaptive,
+                   uint32_t n_threads);
+/* determine_splitters' result supplied by the caller (sorted or not, duplicates allowed) */
+int agc_cmp_set_splitters(void *h, const uint64_t *kmers, uint64_t n);
+/* determine_splitters (agc_compressor.cpp:428-563) on the GPU for a reference genome resident in HBM:
+ * contig c = d_codes[ctg_off[c] .. ctg_off[c+1]), one symbol code per byte */
+int agc_cmp_set_reference_dev(void *h, const uint8_t *d_codes, const uint64_t *ctg_off, uint32_t n_ctg);
+/* CAGCCompressor::AddSampleFiles (agc_compressor.cpp:2118-2270): n (sample name, FASTA path) pairs */
+int agc_cmp_add_sample_files(void *h, uint32_t n, const char **sample_names, const char **paths, uint32_t n_threads);
+/* one sample whose contigs are resident in HBM = agc_cmp_prepare_sample_dev + agc_cmp_commit_prepared */
+int agc_cmp_add_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const uint8_t *d_codes,
+                           const uint64_t *ctg_off);
+/* first half: scan, classification and LZ encode of the segments whose group is known, against the present state (d_codes must
+ * stay untouched until the commit); second half: registration and store, after revalidating what changed in between */
+int agc_cmp_prepare_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const uint8_t *d_codes,
+                               const uint64_t *ctg_off);
+int agc_cmp_commit_prepared(void *h);
+/* CAGCCompressor::Close (agc_compressor.cpp:2094-2115, 2386-2400) */
+int agc_cmp_close(void *h, uint32_t n_threads);
+
+/* one archive from N ranks (before agc_cmp_create on every rank; protocol: agc_amd/dist.py, compressor.cpp above make_record).
+ * After agc_cmp_add_sample_dev / agc_cmp_commit_prepared on the owner, agc_cmp_last_record gives the bytes every other rank
+ * must pass to agc_cmp_apply_record (d_record: optional copy in that rank's HBM, or NULL). */
+int agc_cmp_set_distributed(void *h, uint32_t rank, uint32_t world_size, uint32_t writer_rank);
+int agc_cmp_last_record(void *h, const uint8_t **ptr, uint64_t *n);
+int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record);
+
+/* version string of the libzstd in use (archives are byte-identical to the reference's only with the same libzstd) */
+const char *agc_cmp_zstd_version(void *h);
+/* the agc_hip_ctx (include/agc_hip.h) behind this compressor, e.g. for agc_hip_timing_* */
+void *agc_cmp_hip_ctx(void *h);
+/* counters and stage times in the order of agc::CompressorStats (agc_amd/host.py: STAT_NAMES); returns how many exist */
+int agc_cmp_stats(void *h, double *out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -46,3 +46,32 @@ def test_product_does_not_import_oracle():
                 if re.search(r"(from|import)\s+oracle|agc_oracle|libagc_oracle|oracle/_ref", t):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_compressor_header_matches_the_library_and_the_binding():
+    """include/agc_cmp.h declares exactly the agc_cmp_* entry points libagc_host.so exports and agc_amd/host.py binds"""
+    from agc_amd import build, host
+    build.build_host()
+    h = open(os.path.join(ROOT, "include", "agc_cmp.h")).read()
+    decl = sorted(set(re.findall(r"\b(agc_cmp_[a-z0-9_]+)\s*\(", h)))
+    src = open(os.path.join(ROOT, "agc_amd", "csrc", "host", "capi_host.cpp")).read()
+    defined = sorted(set(re.findall(r"^(?:int|void|void \*|const char \*)\s*\*?(agc_cmp_[a-z0-9_]+)\(", src, re.M)))
+    assert decl == defined
+    bound = sorted(set(re.findall(r"L\.(agc_cmp_[a-z0-9_]+)\.", open(host.__file__).read())))
+    assert bound == decl
+    L = ctypes.CDLL(os.path.join(ROOT, "agc_amd", "libagc_hip.so"), mode=ctypes.RTLD_GLOBAL)  # its DT_NEEDED, found by $ORIGIN anyway
+    L = ctypes.CDLL(host.LIB_PATH)
+    for s in decl:
+        assert hasattr(L, s), s
+
+
+def test_product_does_not_reach_into_tests():
+    """the device stand-in (tests/devsim) and the fuzzer are test infrastructure: nothing under agc_amd/ may name them"""
+    bad = []
+    for dp, _dn, fn in os.walk(os.path.join(ROOT, "agc_amd")):
+        for f in fn:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                t = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"devsim|agc_hip_sim|tests\.", t):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
