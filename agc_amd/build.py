@@ -33,8 +33,9 @@ def build(force=False, verbose=False):
 HOST = os.path.join(CSRC, "host")
 HOST_LIB = os.path.join(HERE, "libagc_host.so")
 HOST_BIN = os.path.join(HERE, "bin", "agc_amd")
-HOST_SOURCES = ["compressor.cpp", "compressor.h", "host_support.h", "capi_host.cpp", "main.cpp", "reader.cpp", "reader.h",
-                "capi_read.cpp", "archive_read.h"]
+HOST_SOURCES = ["compressor.cpp", "compressor_batch.cpp", "compressor_dist.cpp", "compressor_impl.h", "compressor.h", "host_support.h",
+                "capi_host.cpp", "main.cpp", "reader.cpp", "reader.h", "capi_read.cpp", "archive_read.h"]
+HOST_LIB_SOURCES = ["compressor.cpp", "compressor_batch.cpp", "compressor_dist.cpp", "capi_host.cpp", "reader.cpp"]
 READ_LIB = os.path.join(HERE, "libagc_read.so")
 
 
@@ -64,8 +65,7 @@ def build_host(force=False, verbose=False):
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
     common = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
-    cmd1 = common + ["-shared", os.path.join(HOST, "compressor.cpp"), os.path.join(HOST, "capi_host.cpp"), os.path.join(HOST, "reader.cpp"),
-                     "-o", HOST_LIB,
+    cmd1 = common + ["-shared"] + [os.path.join(HOST, s) for s in HOST_LIB_SOURCES] + ["-o", HOST_LIB,
                      "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"]
     cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
                      "-Wl,-rpath,$ORIGIN/..", "-lz", "-ldl"]

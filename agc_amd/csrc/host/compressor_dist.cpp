@@ -1,0 +1,295 @@
+// compressor_dist.cpp -- commit records of the multi-GPU single-archive mode (see compressor.h, agc_amd/dist.py).
+#include "compressor_impl.h"
+
+namespace agc {
+
+// ---------------------------------------------------------------------------
+// Multi-GPU single-archive mode.  Samples are dealt round-robin to the ranks; every rank keeps the
+// whole classification state (splitters, (k1,k2) -> group map, terminators, references in its HBM).  The owner of a
+// sample classifies and encodes it (process_batch), then publishes a COMMIT RECORD: contig names, new splitters and,
+// group by group in registration order, every placed item with its payload (symbols of a new reference -- the
+// "newly-minted reference segments" every GPU needs --, raw symbols, or the delta).  All other ranks apply the
+// record (apply_record): same group ids, same map/terminator updates, references registered in their own HBM;
+// the writer rank also runs the bookkeeping / zstd / archive stage from it.  Samples are committed strictly in
+// order, so the archive equals the single-GPU one byte for byte.
+// Record layout (little endian): "AGCR" | n_ctg | n_lists | n_new_splitters | first_new_gid | n_new_groups |
+//   contigs: sample\0 name\0 ... | splitters u64... | lists: gid, n_items, items: ctg, part_no, len, rc, kind,
+//   [pk1, pk2, repetitive for kind 0], payload_len, payload
+// ---------------------------------------------------------------------------
+namespace {
+void put32(bytes_t &d, uint32_t x)
+{
+    for (int i = 0; i < 4; ++i, x >>= 8)
+        d.push_back((uint8_t)(x & 0xff));
+}
+void put64(bytes_t &d, uint64_t x)
+{
+    for (int i = 0; i < 8; ++i, x >>= 8)
+        d.push_back((uint8_t)(x & 0xff));
+}
+struct RecReader {
+    const uint8_t *p, *e;
+    bool ok = true;
+    bool need(size_t n)
+    {
+        if ((size_t)(e - p) < n)
+            ok = false;
+        return ok;
+    }
+    uint32_t u32()
+    {
+        if (!need(4))
+            return 0;
+        uint32_t x = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        p += 4;
+        return x;
+    }
+    uint64_t u64()
+    {
+        const uint64_t lo = u32(), hi = u32();
+        return lo | (hi << 32);
+    }
+    uint8_t u8() { return need(1) ? *p++ : 0; }
+    std::string str()
+    {
+        const uint8_t *q = p;
+        while (q < e && *q)
+            ++q;
+        if (q >= e) {
+            ok = false;
+            return std::string();
+        }
+        std::string r((const char *)p, (size_t)(q - p));
+        p = q + 1;
+        return r;
+    }
+};
+} // namespace
+
+void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters)
+{
+    const std::vector<Contig> &ctgs = *cd.ctgs;
+    const std::vector<Placed> &placed = *cd.placed;
+    bytes_t &r = dist_record;
+    r.clear();
+    r.insert(r.end(), {'A', 'G', 'C', 'R'});
+    put32(r, (uint32_t)ctgs.size());
+    const SampleLists &sl = cd.per_sample.at(0); // one registration per record
+    put32(r, (uint32_t)sl.n_lists());
+    put32(r, (uint32_t)new_splitters.size());
+    uint32_t first_new = ~0u, n_new = 0;
+    for (uint32_t idx : cd.new_ref_items) {
+        first_new = std::min(first_new, (uint32_t)placed[idx].gid);
+        ++n_new;
+    }
+    put32(r, first_new);
+    put32(r, n_new);
+    for (auto &c : ctgs) {
+        r.insert(r.end(), c.sample.begin(), c.sample.end());
+        r.push_back(0);
+        r.insert(r.end(), c.name.begin(), c.name.end());
+        r.push_back(0);
+    }
+    for (uint64_t x : new_splitters)
+        put64(r, x);
+    std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size()), pos_enc(placed.size());
+    for (uint32_t i = 0; i < cd.new_ref_items.size(); ++i)
+        pos_newref[cd.new_ref_items[i]] = i;
+    for (uint32_t i = 0; i < cd.raw_items.size(); ++i)
+        pos_raw[cd.raw_items[i]] = i;
+    for (uint32_t i = 0; i < cd.enc_items.size(); ++i)
+        pos_enc[cd.enc_items[i]] = i;
+    std::vector<uint8_t> kind(placed.size(), 2);
+    for (uint32_t idx : cd.new_ref_items)
+        kind[idx] = 0;
+    for (uint32_t idx : cd.raw_items)
+        kind[idx] = 1;
+    for (size_t li = 0; li < sl.n_lists(); ++li) {
+        put32(r, sl.gids[li]);
+        put32(r, sl.begin[li + 1] - sl.begin[li]);
+        for (uint32_t ii = sl.begin[li]; ii < sl.begin[li + 1]; ++ii) {
+            const uint32_t idx = sl.items[ii];
+            const Placed &pl = placed[idx];
+            put32(r, pl.ctg);
+            put32(r, pl.part_no);
+            put32(r, pl.len);
+            r.push_back((uint8_t)pl.rc);
+            r.push_back(kind[idx]);
+            const uint8_t *b;
+            size_t n;
+            if (kind[idx] == 0) {
+                put64(r, pl.pk.first);
+                put64(r, pl.pk.second);
+                const uint32_t fi = pos_newref[idx];
+                r.push_back(cd.repetitive[fi]);
+                b = cd.fetched->data() + cd.fetched_off[fi];
+                n = cd.fetched_off[fi + 1] - cd.fetched_off[fi];
+            } else if (kind[idx] == 1) {
+                const uint32_t fi = (uint32_t)cd.new_ref_items.size() + pos_raw[idx];
+                b = cd.fetched->data() + cd.fetched_off[fi];
+                n = cd.fetched_off[fi + 1] - cd.fetched_off[fi];
+            } else {
+                const uint32_t ei = pos_enc[idx];
+                b = cd.enc_ptr[ei];
+                n = cd.enc_len[ei];
+            }
+            put32(r, (uint32_t)n);
+            r.insert(r.end(), b, b + n);
+        }
+    }
+    // the owner keeps what later classifications read of its new groups (book_and_store does it on the writer)
+    if (dist_rank != dist_writer)
+        for (uint32_t idx : cd.new_ref_items) {
+            Group &g = groups[(uint32_t)placed[idx].gid];
+            g.exists = true;
+            g.ref_size = (uint64_t)placed[idx].len + 1;
+        }
+}
+
+bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec)
+{
+    RecReader rr{rec, rec + n};
+    if (n < 24 || memcmp(rec, "AGCR", 4) != 0) {
+        err("bad commit record");
+        return false;
+    }
+    rr.p += 4;
+    const uint32_t n_ctg = rr.u32(), n_lists = rr.u32(), n_spl = rr.u32(), first_new = rr.u32(), n_new = rr.u32();
+    std::vector<Contig> ctgs(n_ctg);
+    for (auto &c : ctgs) {
+        c.sample = rr.str();
+        c.name = rr.str();
+        c.sample_idx = 0;
+    }
+    std::vector<uint64_t> add(n_spl);
+    for (auto &x : add)
+        x = rr.u64();
+    if (!rr.ok) {
+        err("truncated commit record");
+        return false;
+    }
+    const bool writer = dist_rank == dist_writer;
+    if (!add.empty()) { // adaptive mode: the owner's new splitters (agc_compressor.cpp:1191-1209)
+        splitters.insert(splitters.end(), add.begin(), add.end());
+        std::sort(splitters.begin(), splitters.end());
+        splitters.erase(std::unique(splitters.begin(), splitters.end()), splitters.end());
+        if (!hip_ok(DEVT(agc_hip_splitters_insert(hip, add.data(), add.size())), "splitters_insert"))
+            return false;
+    }
+    if (writer) {
+        coll.reset_prev_sample_name();
+        for (auto &c : ctgs)
+            if (!coll.register_sample_contig(c.sample, c.name)) {
+                err("Error: Pair sample_name:contig_name " + c.sample + ":" + c.name + " is already in the archive!");
+                return false;
+            }
+    }
+    if (n_new) {
+        if (first_new != no_segments) {
+            err("commit record out of order: new groups start at " + std::to_string(first_new) + ", expected " + std::to_string(no_segments));
+            return false;
+        }
+        for (uint32_t i = 0; i < n_new; ++i) {
+            groups.emplace_back();
+            Group &g = groups.back();
+            g.stream_ref = ar.register_stream(ss_ref_name(no_segments + i));
+            g.stream_delta = ar.register_stream(ss_delta_name(no_segments + i));
+        }
+        no_segments += n_new;
+        st.new_groups += n_new;
+    }
+    std::vector<Placed> placed;
+    CommitData cd;
+    cd.commit_upto = 1;
+    cd.per_sample.resize(1);
+    SampleLists &sl = cd.per_sample[0];
+    bytes_t refs_raw, raws, enc;
+    std::vector<uint64_t> ref_off{0}, raw_off{0}, enc_off{0};
+    std::vector<uint32_t> reg_gid, reg_len;
+    std::vector<uint64_t> reg_off; // payload offsets inside the record (device copy)
+    for (uint32_t li = 0; li < n_lists && rr.ok; ++li) {
+        const uint32_t gid = rr.u32(), cnt = rr.u32();
+        sl.gids.push_back(gid);
+        sl.begin.push_back((uint32_t)sl.items.size());
+        for (uint32_t i = 0; i < cnt && rr.ok; ++i) {
+            Placed pl;
+            pl.ctg = rr.u32();
+            pl.part_no = rr.u32();
+            pl.len = rr.u32();
+            pl.rc = rr.u8() != 0;
+            const uint8_t kind = rr.u8();
+            pl.gid = (int32_t)gid;
+            pl.off = 0;
+            uint8_t rep = 0;
+            if (kind == 0) {
+                pl.pk.first = rr.u64();
+                pl.pk.second = rr.u64();
+                rep = rr.u8();
+            }
+            const uint32_t pn = rr.u32();
+            if (!rr.need(pn) || pl.ctg >= n_ctg || gid >= groups.size())
+                break;
+            const uint32_t idx = (uint32_t)placed.size();
+            if (kind == 0) {
+                cd.new_ref_items.push_back(idx);
+                cd.repetitive.push_back(rep);
+                refs_raw.insert(refs_raw.end(), rr.p, rr.p + pn);
+                ref_off.push_back(refs_raw.size());
+                reg_gid.push_back(gid);
+                reg_len.push_back(pn);
+                reg_off.push_back((uint64_t)(rr.p - rec));
+                note_new_group(pl.pk, gid);
+                groups[gid].exists = !writer; // the writer's bookkeeping turns it on (first item = reference)
+                groups[gid].ref_size = (uint64_t)pn + 1;
+            } else if (kind == 1) {
+                cd.raw_items.push_back(idx);
+                raws.insert(raws.end(), rr.p, rr.p + pn);
+                raw_off.push_back(raws.size());
+            } else {
+                cd.enc_items.push_back(idx);
+                enc.insert(enc.end(), rr.p, rr.p + pn);
+                enc_off.push_back(enc.size());
+            }
+            rr.p += pn;
+            sl.items.push_back(idx);
+            placed.push_back(pl);
+        }
+    }
+    sl.begin.push_back((uint32_t)sl.items.size());
+    if (!rr.ok || rr.p != rr.e) {
+        err("malformed commit record");
+        return false;
+    }
+    st.segments += placed.size();
+    // the newly minted references go to this rank's HBM (from the device copy of the record when there is one)
+    if (!reg_gid.empty()) {
+        if (d_rec) {
+            if (!hip_ok(DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)reg_gid.size(), reg_gid.data(), d_rec, reg_off.data(), reg_len.data(), nullptr, mml)),
+                        "ref_register_batch"))
+                return false;
+        } else
+            for (size_t i = 0; i < reg_gid.size(); ++i)
+                if (!hip_ok(DEVT(agc_hip_ref_register(hip, reg_gid[i], rec + reg_off[i], reg_len[i], mml)), "ref_register"))
+                    return false;
+    }
+    if (!writer)
+        return true;
+    // fetched = new references, then raw items (the layout book_and_store indexes)
+    bytes_t fetched;
+    fetched.reserve(refs_raw.size() + raws.size());
+    fetched.insert(fetched.end(), refs_raw.begin(), refs_raw.end());
+    fetched.insert(fetched.end(), raws.begin(), raws.end());
+    cd.fetched_off = ref_off;
+    for (size_t i = 1; i < raw_off.size(); ++i)
+        cd.fetched_off.push_back(refs_raw.size() + raw_off[i]);
+    cd.ctgs = &ctgs;
+    cd.placed = &placed;
+    cd.fetched = &fetched;
+    for (size_t i = 0; i + 1 < enc_off.size(); ++i) {
+        cd.enc_ptr.push_back(enc.data() + enc_off[i]);
+        cd.enc_len.push_back((uint32_t)(enc_off[i + 1] - enc_off[i]));
+    }
+    return book_and_store(cd);
+}
+
+} // namespace agc

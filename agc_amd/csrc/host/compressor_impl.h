@@ -1,0 +1,588 @@
+// compressor_impl.h -- internals of agc::CAGCCompressor shared by compressor.cpp (API, create / append / close),
+// compressor_batch.cpp (the per-window pipeline: scan -> classification -> placement -> commit runs) and
+// compressor_dist.cpp (commit records of the multi-GPU mode).  Citations: file:line under the reference tree.
+#pragma once
+#include "compressor.h"
+#include "host_support.h"
+#include "archive_read.h"
+#include "reader.h"
+#include "../../../include/agc_hip.h"
+
+#include <chrono>
+#include <deque>
+#include <cmath>
+#include <iostream>
+#include <numeric>
+#include <set>
+#include <zlib.h>
+
+namespace agc {
+
+namespace detail {
+
+using pk_t = std::pair<uint64_t, uint64_t>;
+constexpr uint64_t NO_KMER = ~0ULL;
+constexpr uint32_t NO_RAW_GROUPS = 16; // agc_basic.h:81
+
+struct PairHash {
+    size_t operator()(const pk_t &x) const noexcept
+    {
+        uint64_t h = x.first * 0x9E3779B97F4A7C15ULL;
+        h ^= (h >> 32) ^ (x.second * 0xC2B2AE3D27D4EB4FULL);
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+
+// time spent inside the device library (kernels + copies + syncs), for the stage breakdown of -v 1
+#define DEVT_(stats, call) ([&] { const double t_ = now(); const int r_ = (call); (stats).t_device += now() - t_; return r_; }())
+#define DEVT(call) DEVT_(st, call)
+#define DEVTI(call) DEVT_(I.st, call)
+#define DEVTP(call) DEVT_(p->st, call)
+
+// (kmer1, kmer2) -> group id: flat open-addressing table (one cache line per lookup instead of a node chase)
+class PkMap {
+    struct Slot {
+        uint64_t a, b;
+        int32_t v;
+        uint32_t used;
+    };
+    std::vector<Slot> t;
+    size_t n = 0, mask = 0;
+    void grow()
+    {
+        std::vector<Slot> old;
+        old.swap(t);
+        t.assign(old.empty() ? 1024 : old.size() * 2, Slot{0, 0, 0, 0});
+        mask = t.size() - 1;
+        for (const Slot &s : old)
+            if (s.used) {
+                size_t i = PairHash()(pk_t{s.a, s.b}) & mask;
+                while (t[i].used)
+                    i = (i + 1) & mask;
+                t[i] = s;
+            }
+    }
+
+public:
+    size_t size() const { return n; }
+    void clear()
+    {
+        t.clear();
+        n = mask = 0;
+    }
+    int32_t *find(const pk_t &k)
+    {
+        if (t.empty())
+            return nullptr;
+        for (size_t i = PairHash()(k) & mask;; i = (i + 1) & mask) {
+            Slot &s = t[i];
+            if (!s.used)
+                return nullptr;
+            if (s.a == k.first && s.b == k.second)
+                return &s.v;
+        }
+    }
+    int32_t &operator[](const pk_t &k)
+    {
+        if (int32_t *p = find(k))
+            return *p;
+        if ((n + 1) * 2 > t.size())
+            grow();
+        size_t i = PairHash()(k) & mask;
+        while (t[i].used)
+            i = (i + 1) & mask;
+        t[i] = Slot{k.first, k.second, 0, 1};
+        ++n;
+        return t[i].v;
+    }
+    template <typename F> void for_each(F f) const
+    {
+        for (const Slot &s : t)
+            if (s.used)
+                f(pk_t{s.a, s.b}, s.v);
+    }
+};
+
+inline double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// CKmer in canonical mode (src/core/kmer.h): both forms left-aligned
+struct Kmer {
+    uint64_t dir = 0, rc = 0;
+    bool full = false;
+    uint64_t data() const { return dir < rc ? dir : rc; }   // kmer.h:350-357
+    bool is_dir_oriented() const { return dir <= rc; }      // kmer.h:545-551
+    void swap_dir_rc() { std::swap(dir, rc); }              // kmer.h:554-562
+};
+
+struct Contig {
+    std::string sample, name;
+    uint64_t off = 0, len = 0; // inside the batch's device buffer
+    uint32_t sample_idx = 0;   // position of its sample inside the speculation window (0 for single-sample batches)
+};
+
+struct Seg { // one segment as compress_contig cuts it (agc_compressor.cpp:2007-2048)
+    uint32_t ctg;
+    uint64_t start; // relative to the contig
+    uint32_t len;
+    Kmer front, back;
+    // classification (add_segment, agc_compressor.cpp:1275-1499)
+    pk_t pk{NO_KMER, NO_KMER};
+    bool store_rc = false;
+    // one-splitter search
+    uint32_t cand_begin = 0, cand_end = 0;
+    bool back_only = false;
+    Kmer one_kmer;
+    // missing-middle search
+    int32_t mid_job = -1;
+    int32_t known_gid = -2; // group of pk when classification looked it up (-1: not there, -2: not looked up)
+    uint32_t bp = 0;        // split position of a missing-middle job (before the k+1 clamps)
+    Kmer kmer1, kmer2;
+    bool use_rc = false;
+    uint64_t middle = NO_KMER;
+};
+
+struct Cand { // find_cand_segment_with_one_splitter, agc_compressor.cpp:1660-1690
+    pk_t pk;
+    bool use_rc;
+    uint32_t gid;
+    uint64_t ref_size;
+};
+
+struct Placed { // one entry of CBufferedSegPart (agc_compressor.h:27-536)
+    uint32_t key = 0; // 2 * segment index + part: stable across re-placements of the same window
+    uint32_t ctg;
+    uint64_t off; // absolute offset in the device buffer
+    uint32_t len;
+    uint32_t part_no;
+    bool rc;
+    int32_t gid; // -1: new group
+    pk_t pk;
+};
+
+struct Group { // CSegment, write side (src/common/segment.{h,cpp})
+    bool exists = false;
+    uint64_t ref_size = 0; // s.size() + 1 once the reference is set (segment.cpp:46)
+    uint32_t no_seqs = 0;
+    // current pack, already in stored form: every sequence followed by the 0xFF separator
+    // (store_in_archive(pack), segment.h:258-280); *_off[i] = start of sequence i
+    bytes_t lzp_data, raw_data;
+    std::vector<uint32_t> lzp_off, raw_off;
+    int stream_ref = -1, stream_delta = -1;
+    // append mode: a group taken over from the input archive stays "packed" until its first add in this session
+    // (CSegment::appending_init / unpack, segment.cpp:418-471, 496-577).  While packed it behaves as the
+    // reference's does: ref_size == 0, so Estimate answers 0 and the cost vector is empty (segment.cpp:85-86, 103-104).
+    bool packed = false;
+    const uint8_t *pk_ref = nullptr, *pk_delta = nullptr; // parts inside the mapped input archive
+    uint64_t pk_ref_size = 0, pk_ref_meta = 0, pk_delta_size = 0, pk_delta_meta = 0;
+
+    static void push(bytes_t &data, std::vector<uint32_t> &off, const uint8_t *b, size_t n)
+    {
+        off.push_back((uint32_t)data.size());
+        data.insert(data.end(), b, b + n);
+        data.push_back(0xff);
+    }
+    // index of an equal sequence in the current pack or -1 (std::find over v_lzp, segment.cpp:66)
+    static int find(const bytes_t &data, const std::vector<uint32_t> &off, const uint8_t *b, size_t n)
+    {
+        for (size_t i = 0; i < off.size(); ++i) {
+            const size_t e = (i + 1 < off.size() ? off[i + 1] : data.size()) - 1; // without the separator
+            if (e - off[i] == n && memcmp(data.data() + off[i], b, n) == 0)
+                return (int)i;
+        }
+        return -1;
+    }
+};
+
+struct SampleLists { // one registration: the items of every group it touches (CSR)
+    std::vector<uint32_t> gids;  // groups touched, in order of first appearance
+    std::vector<uint32_t> begin; // list li = items[begin[li] .. begin[li + 1])
+    std::vector<uint32_t> items; // indices into placed, per group in (contig name, part) order
+    size_t n_lists() const { return gids.size(); }
+};
+
+// what store_segments' bookkeeping needs about the committed registrations (filled by process_batch on the rank that
+// classified them, or rebuilt from a commit record on the other ranks of a multi-GPU job)
+struct CommitData {
+    const std::vector<Contig> *ctgs = nullptr;
+    const std::vector<Placed> *placed = nullptr;
+    uint32_t commit_upto = 0;
+    std::vector<SampleLists> per_sample;
+    std::vector<uint32_t> new_ref_items, raw_items, enc_items; // placed indices
+    std::vector<uint8_t> repetitive;                           // per new_ref_items entry (segment.h:224-247)
+    const bytes_t *fetched = nullptr;                          // new references, then raw items
+    std::vector<uint64_t> fetched_off;
+    std::vector<const uint8_t *> enc_ptr;                      // delta of every enc_items entry
+    std::vector<uint32_t> enc_len;
+    uint32_t sample_from = 0;                                  // the registrations [sample_from, commit_upto) of the window
+};
+
+struct ZJob { // one archive part to produce
+    int stream_id;
+    int kind;          // 0 = reference (tuples/zstd13 or zstd19), 1 = pack (zstd17)
+    bytes_t data;      // raw bytes (reference symbols or concatenated pack)
+    bool repetitive = false;
+    bytes_t out;
+    uint64_t meta = 0;
+};
+
+// bytes2tuples, src/common/segment.h:73-138
+inline void bytes2tuples(const bytes_t &v, bytes_t &out)
+{
+    uint8_t me = 0;
+    for (uint8_t c : v)
+        me = std::max(me, c);
+    uint32_t nb, mult;
+    if (me < 4) {
+        nb = 4;
+        mult = 4;
+    } else if (me < 6) {
+        nb = 3;
+        mult = 6;
+    } else if (me < 16) {
+        nb = 2;
+        mult = 16;
+    } else {
+        out = v;
+        out.push_back(0x10u);
+        return;
+    }
+    out.clear();
+    out.reserve(v.size() / nb + 2);
+    size_t i = 0;
+    for (; i + nb <= v.size(); i += nb) {
+        uint8_t c = 0;
+        for (uint32_t j = 0; j < nb; ++j)
+            c = (uint8_t)(c * mult + v[i + j]);
+        out.push_back(c);
+    }
+    uint8_t c = 0;
+    for (; i < v.size(); ++i)
+        c = (uint8_t)(c * mult + v[i]);
+    out.push_back(c);
+    out.push_back((uint8_t)((nb << 4) + (v.size() % nb)));
+}
+
+// cnv_num, src/common/agc_basic.h:40-50; preprocess_raw_contig, agc_compressor.cpp:907-951
+struct CnvTable {
+    uint8_t t[256];
+    CnvTable()
+    {
+        for (int c = 0; c < 256; ++c)
+            t[c] = 30;
+        t[64] = t[96] = 32;
+        const char *named = "ACGTNRYSWKMBDHVU";
+        for (int i = 0; named[i]; ++i) {
+            t[(int)named[i]] = (uint8_t)i;
+            t[(int)named[i] + 32] = (uint8_t)i;
+        }
+        for (int c = 128; c < 256; ++c)
+            t[c] = t[c & 127];
+    }
+};
+inline const CnvTable g_cnv;
+
+inline void preprocess_raw_contig(bytes_t &ctg)
+{
+    size_t o = 0;
+    for (size_t i = 0; i < ctg.size(); ++i) {
+        uint8_t c = ctg[i];
+        if (c >> 6)
+            ctg[o++] = g_cnv.t[c];
+    }
+    ctg.resize(o);
+}
+
+// FASTA(.gz) reader with the reference's framing (src/core/genome_io.cpp:208-252): id = first
+// line minus its first character, body = every byte up to the next '>'.
+class FastaReader {
+    gzFile f = nullptr;
+    std::vector<uint8_t> buf;
+    size_t pos = 0, filled = 0;
+    bool fill()
+    {
+        pos = 0;
+        int r = gzread(f, buf.data(), (unsigned)buf.size());
+        filled = r > 0 ? (size_t)r : 0;
+        return filled != 0;
+    }
+
+public:
+    bool open(const std::string &fn)
+    {
+        f = gzopen(fn.c_str(), "rb");
+        if (!f)
+            return false;
+        gzbuffer(f, 1 << 20);
+        buf.resize(16 << 20);
+        pos = filled = 0;
+        return true;
+    }
+    void close()
+    {
+        if (f)
+            gzclose(f);
+        f = nullptr;
+    }
+    ~FastaReader() { close(); }
+    bool read_contig_raw(std::string &id, bytes_t &ctg)
+    {
+        id.clear();
+        ctg.clear();
+        if (!f)
+            return false;
+        for (;;) {
+            if (pos >= filled && !fill())
+                return false;
+            uint8_t c = buf[pos++];
+            if (c == '\n' || c == '\r')
+                break;
+            id.push_back((char)c);
+        }
+        if (!id.empty())
+            id.erase(id.begin());
+        for (;;) {
+            if (pos >= filled && !fill())
+                break;
+            const uint8_t *b = buf.data() + pos, *e = buf.data() + filled;
+            const uint8_t *q = (const uint8_t *)memchr(b, '>', (size_t)(e - b));
+            if (q) {
+                ctg.insert(ctg.end(), b, q);
+                pos = (size_t)(q - buf.data());
+                break;
+            }
+            ctg.insert(ctg.end(), b, e);
+            pos = filled;
+        }
+        return !id.empty() && !ctg.empty();
+    }
+};
+
+// rolling canonical k-mer on the host (reference preprocessing only)
+struct HostKmer {
+    uint64_t dir = 0, rc = 0;
+    uint32_t cur = 0, k;
+    explicit HostKmer(uint32_t k_) : k(k_) {}
+    void reset() { dir = rc = 0, cur = 0; }
+    void insert(uint64_t s)
+    {
+        const uint32_t shift = 64 - 2 * k;
+        const uint64_t mask = (~0ULL) << shift;
+        rc >>= 2;
+        rc += (3 - s) << 62;
+        rc &= mask;
+        if (cur == k) {
+            dir <<= 2;
+            dir += s << shift;
+        } else {
+            ++cur;
+            dir += s << (64 - 2 * cur);
+        }
+    }
+    bool full() const { return cur == k; }
+    uint64_t data() const { return dir < rc ? dir : rc; }
+};
+
+
+// ---------------------------------------------------------------------------
+// Host pieces of the adaptive mode's find_new_splitters (agc_compressor.cpp:2054-2081, 630-704,
+// 762-825); the reference genome itself is preprocessed on the GPU (agc_hip_determine_splitters_dev).
+// ---------------------------------------------------------------------------
+// splitters of one contig given the sorted candidate k-mers (find_splitters_in_contig, :762-825)
+inline void find_splitters_in_contig(const bytes_t &c, uint32_t k, uint32_t segment_size, const std::vector<uint64_t> &cand,
+                                     std::vector<uint64_t> &spl)
+{
+    auto is_cand = [&](uint64_t d) { return std::binary_search(cand.begin(), cand.end(), d); };
+    HostKmer h(k);
+    uint64_t current_len = segment_size;
+    size_t recent_from = 0;
+    for (size_t i = 0; i < c.size(); ++i) {
+        uint8_t x = c[i];
+        if (x > 3)
+            h.reset();
+        else {
+            h.insert(x);
+            if (h.full() && current_len >= segment_size && is_cand(h.data())) {
+                spl.push_back(h.data());
+                current_len = 0;
+                h.reset();
+                recent_from = i + 1;
+            }
+        }
+        ++current_len;
+    }
+    HostKmer t(k);
+    bool have = false;
+    uint64_t best = 0;
+    for (size_t i = recent_from; i < c.size(); ++i) {
+        uint8_t x = c[i];
+        if (x > 3) {
+            t.reset();
+            continue;
+        }
+        t.insert(x);
+        if (t.full() && is_cand(t.data())) {
+            best = t.data();
+            have = true;
+        }
+    }
+    if (have)
+        spl.push_back(best);
+}
+
+inline void enumerate_kmers(const bytes_t &c, uint32_t k, std::vector<uint64_t> &km)
+{
+    HostKmer h(k);
+    for (uint8_t x : c) {
+        if (x > 3)
+            h.reset();
+        else {
+            h.insert(x);
+            if (h.full())
+                km.push_back(h.data());
+        }
+    }
+}
+
+// sorted input -> singletons in place, duplicated values (once each) appended to dup when given
+inline void split_singletons(std::vector<uint64_t> &km, std::vector<uint64_t> *dup)
+{
+    size_t o = 0;
+    for (size_t i = 0; i < km.size();) {
+        size_t j = i + 1;
+        while (j < km.size() && km[j] == km[i])
+            ++j;
+        if (j == i + 1)
+            km[o++] = km[i];
+        else if (dup)
+            dup->push_back(km[i]);
+        i = j;
+    }
+    km.resize(o);
+}
+
+// ===========================================================================
+} // namespace detail
+
+using namespace detail;
+
+// ===========================================================================
+struct CAGCCompressor::Impl {
+    int device = 0;
+    agc_hip_ctx *hip = nullptr;
+    ZstdApi zstd;
+    std::unique_ptr<ThreadPool> pool;
+    std::vector<std::unique_ptr<ZstdCtx>> zctx;
+
+    bool created = false;
+    uint32_t pack_cardinality = 50, k = 31, segment_size = 60000, mml = 20, verbosity = 0;
+    bool concatenated = false, adaptive = false;
+
+    ArchiveWriter ar;
+    CollectionV3 coll;
+    std::vector<uint64_t> splitters;
+
+    PkMap map_segments;                                                       // agc_compressor.h:628
+    std::unordered_map<uint64_t, std::vector<uint64_t>> terminators;          // agc_compressor.h:629
+    std::vector<Group> groups;                                                // v_segments
+    uint32_t no_segments = 0;
+    uint32_t processed_samples = 0, stored_samples = 0;
+    size_t cnt_contigs_in_sample = 0;
+
+    CompressorStats st;
+
+    // append mode
+    bool appending = false;
+    rd::Archive in_ar;
+    rd::ZstdD zd;
+    std::map<std::string, std::string> in_file_type_info;
+    bool unpack_group(uint32_t gid);
+
+    void err(const std::string &m) { std::cerr << m << std::endl; }
+    bool hip_ok(int rc, const char *what)
+    {
+        if (rc == AGC_HIP_OK)
+            return true;
+        err(std::string(what) + ": " + agc_hip_last_error(hip) + " (code " + std::to_string(rc) + ")");
+        return false;
+    }
+
+    // -----------------------------------------------------------------------
+    // classifies all contigs (one or several consecutive samples) against the current state and commits the
+    // leading samples whose classification is certainly valid; n_committed = number of samples done
+    bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, uint32_t &n_committed);
+    struct BatchState { // working set of one process_batch call
+        std::vector<Contig> *ctgs = nullptr;
+        const uint8_t *d_base = nullptr;
+        const std::vector<bytes_t> *host_data = nullptr;
+        uint32_t n_ctg = 0;
+        double t0 = 0, dev0 = 0, lap_t = 0;
+        std::vector<uint64_t> new_splitters_added; // adaptive mode
+        std::vector<uint32_t> subset;              // segments stage_classify works on
+        uint32_t n_samples = 1, s_from = 0;        // registrations of the window; first one not committed yet
+        struct Spec {                              // speculative delta of a placed item (by Placed::key)
+            uint64_t off = 0, enc_off = 0;
+            uint32_t gid = 0, len = 0, enc_len = 0;
+            bool rc = false, valid = false;
+        };
+        std::vector<Spec> spec;
+        std::vector<uint64_t> changed;             // k-mers whose terminator list changed in the last commit run
+        uint32_t commit_upto = 0;                  // registrations of the window that are committed now
+        std::vector<uint32_t> order;               // committed items in registration order
+        std::vector<SampleLists> per_sample;
+    };
+    bool stage_scan(BatchState &b);
+    bool stage_classify(BatchState &b);
+    bool stage_place(BatchState &b);
+    bool stage_register(BatchState &b);
+    bool stage_store(BatchState &b);
+    bool spec_encode(BatchState &b);
+    bool revalidate(BatchState &b);
+    bool batch_prepare(BatchState &b, std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, bool always_speculate);
+    bool batch_commit(BatchState &b, uint32_t &n_committed);
+    // a sample classified ahead of its turn (multi-GPU mode, PrepareSampleDevice): its working set, and the k-mers whose
+    // terminator lists changed since (through other ranks' records)
+    std::unique_ptr<BatchState> prepared;
+    std::vector<Contig> prepared_ctgs;
+    std::vector<uint64_t> changed_log;
+    void lap(BatchState &b, const char *what);
+    bool book_and_store(CommitData &cd);
+    // stage accounting: wall time of the stage and its host-only part (wall minus the time inside the device library)
+    void stage_end(double &wall, double &host_only, double &t0, double &dev0)
+    {
+        const double t = now();
+        wall += t - t0;
+        host_only += (t - t0) - (st.t_device - dev0);
+        t0 = t;
+        dev0 = st.t_device;
+    }
+    // multi-GPU single-archive mode: one registration at a time, committed on every rank from the owner's record
+    uint32_t dist_rank = 0, dist_world = 1, dist_writer = 0;
+    bytes_t dist_record;
+    void make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters);
+    bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec);
+    void note_new_group(const pk_t &pk, uint32_t gid);
+    void finish_groups();
+    void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
+    void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
+    void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
+    bytes_t enc_buf, enc_buf2, fetch_buf; // grown, never shrunk (enc_buf: the window's speculative deltas, enc_buf2: per commit run)
+    // scratch reused across registrations (no reallocation / page faults / zero fill per sample)
+    std::vector<uint32_t> gid_slot, gid_epoch;
+    uint32_t gid_epoch_ctr = 0;
+    std::vector<uint32_t> scan_ctg;
+    std::vector<uint64_t> scan_pos, scan_dir, scan_rc;
+    std::vector<Seg> seg_buf;
+    std::vector<Placed> placed_buf;
+    // adaptive mode (-a): sorted singleton / duplicated k-mers of the reference genome
+    // (v_candidate_kmers / v_duplicated_kmers, agc_compressor.cpp:493-497)
+    std::vector<uint64_t> ref_singletons, ref_duplicates;
+    bool find_new_splitters(const bytes_t &ctg, std::vector<uint64_t> &out);
+    int scan_batch(const std::vector<uint64_t> &ctg_off, uint32_t n_ctg, const uint8_t *d_base, std::vector<uint32_t> &h_ctg,
+                   std::vector<uint64_t> &h_pos, std::vector<uint64_t> &h_dir, std::vector<uint64_t> &h_rc, uint64_t &n_hits);
+    void after_registration();
+};
+
+} // namespace agc

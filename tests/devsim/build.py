@@ -23,8 +23,8 @@ def build(force=False):
     hdr = os.path.join(ROOT, "include", "agc_hip.h")
     if force or not _newer(SIM_HIP, sim_src + [hdr]):
         subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall"] + sim_src + ["-o", SIM_HIP])
-    host_src = [os.path.join(HOST, s) for s in ("compressor.cpp", "capi_host.cpp", "reader.cpp")]
-    host_dep = host_src + [os.path.join(HOST, s) for s in ("compressor.h", "host_support.h", "reader.h", "archive_read.h")] + [SIM_HIP]
+    host_src = [os.path.join(HOST, s) for s in ("compressor.cpp", "compressor_batch.cpp", "compressor_dist.cpp", "capi_host.cpp", "reader.cpp")]
+    host_dep = host_src + [os.path.join(HOST, s) for s in ("compressor.h", "compressor_impl.h", "host_support.h", "reader.h", "archive_read.h")] + [SIM_HIP]
     common = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
     if force or not _newer(SIM_HOST, host_dep):
         subprocess.check_call(common + ["-shared"] + host_src + ["-o", SIM_HOST, "-L" + OUT, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"])
