@@ -73,7 +73,7 @@ public:
     bool AddSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
                          const uint64_t *ctg_off);
 
-    // ---- multi-GPU single-archive mode (protocol in compressor.cpp above make_record) ----
+    // ---- multi-GPU single-archive mode (protocol in compressor_dist.cpp) ----
     // Call before Create on every rank; only the writer rank should be given a real archive name.  Afterwards every sample
     // must reach every rank, in the same order: AddSampleDevice on its owner (then LastRecord is what the other ranks
     // need), ApplyRecord everywhere else.  d_record = optional copy of the record in this rank's HBM (e.g. the buffer an

@@ -42,7 +42,7 @@ int agc_cmp_commit_prepared(void *h);
 /* CAGCCompressor::Close (agc_compressor.cpp:2094-2115, 2386-2400) */
 int agc_cmp_close(void *h, uint32_t n_threads);
 
-/* one archive from N ranks (before agc_cmp_create on every rank; protocol: agc_amd/dist.py, compressor.cpp above make_record).
+/* one archive from N ranks (before agc_cmp_create on every rank; protocol: agc_amd/dist.py, compressor_dist.cpp).
  * After agc_cmp_add_sample_dev / agc_cmp_commit_prepared on the owner, agc_cmp_last_record gives the bytes every other rank
  * must pass to agc_cmp_apply_record (d_record: optional copy in that rank's HBM, or NULL). */
 int agc_cmp_set_distributed(void *h, uint32_t rank, uint32_t world_size, uint32_t writer_rank);
