@@ -18,14 +18,17 @@ def _rc(s):
     return r
 
 
-def make_case(seed, outdir):
-    """-> dict(args=[...], carry=[...], files=[...], steps=[n0, n1, ...])"""
+def make_case(seed, outdir, big=False):
+    """-> dict(args=[...], carry=[...], files=[...], steps=[n0, n1, ...]).
+    big: Mbp-size contigs and segment sizes up to 1 M (references past 262 k symbols use the 32-bit LZ index, lz_diff.cpp:144-149)"""
     rng = np.random.default_rng(seed)
     os.makedirs(outdir, exist_ok=True)
     k = int(rng.choice([17, 19, 21, 25, 31, 32]))
     l = int(rng.integers(15, min(k, 32) + 1)) if rng.random() < 0.7 else 20
     l = max(15, min(l, 32))
     s = int(rng.choice([100, 300, 1000, 2500, 60000]))
+    if big:
+        s = int(rng.choice([20000, 60000, 300000, 1000000]))
     b = int(rng.choice([1, 2, 3, 5, 50]))
     concat = rng.random() < 0.25
     adaptive = rng.random() < 0.3
@@ -33,6 +36,9 @@ def make_case(seed, outdir):
     carry = (["-c"] if concat else []) + (["-a"] if adaptive else [])
     n_ctg = int(rng.integers(1, 6))
     scale = int(rng.choice([200, 2000, 20000]))
+    if big:
+        scale = int(rng.choice([100000, 400000]))
+        n_ctg = int(rng.integers(1, 4))
     ref = [synth.random_seq(rng, int(rng.integers(1, 8)) * scale + int(rng.integers(0, 50))) for _ in range(n_ctg)]
     if rng.random() < 0.3:  # a contig shorter than k, and a repetitive one
         ref.append(synth.random_seq(rng, int(rng.integers(1, k))))
@@ -52,7 +58,7 @@ def make_case(seed, outdir):
         files.append(p)
 
     write("ref.fa", ref, names)
-    n_samples = int(rng.integers(1, 9))
+    n_samples = int(rng.integers(1, 5 if big else 9))
     uniq = 0
     for si in range(n_samples):
         ctgs, nm = [], []
