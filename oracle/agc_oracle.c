@@ -6,10 +6,13 @@
  * and bench.py's cpu_baseline leg can check / time the HIP path against a
  * plain, scalar statement of the reference algorithm.
  *
- * Parity pin: every function below is compared (tests/test_oracle_vs_ref.py)
- * with the reference's own code compiled in place from /root/reference into
- * oracle/_ref/ (see oracle/Makefile), and with the golden vectors committed
- * under tests/golden/ that were generated from that build.
+ * Parity pin: every function below is compared with the reference's own code
+ * compiled in place from /root/reference into oracle/_ref/ (oracle/Makefile;
+ * tests/test_oracle_golden.py::test_oracle_vs_reference_live), and with the
+ * golden vectors committed under tests/golden/ that were generated from that
+ * build (same file).  The whole-archive tests and the fuzzer
+ * (tests/test_host_devsim.py, tests/test_fuzz_archives.py) exercise it further
+ * through the device stand-in against the reference CLI.
  *
  * All citations are file:line under /root/reference/.
  * Written from the algorithm description; no reference
