@@ -6,7 +6,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(HERE, "_build")
+OUT = os.environ.get("AGC_DEVSIM_OUT") or os.path.join(HERE, "_build")  # (override: a scratch build next to a running fuzz campaign)
 HOST = os.path.join(ROOT, "agc_amd", "csrc", "host")
 SIM_HIP = os.path.join(OUT, "libagc_hip.so")
 SIM_HOST = os.path.join(OUT, "libagc_host.so")
