@@ -519,7 +519,6 @@ bool CAGCCompressor::CommitPrepared()
 bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std::string>> &files, uint32_t no_threads)
 {
     Impl &I = *p;
-    (void)no_threads;
     if (!I.created)
         return false;
     if (files.empty())
@@ -601,31 +600,81 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         return true;
     };
 
+    // Files are read, split into contigs and converted to symbol codes by background tasks, a few files ahead of the one
+    // being registered (the reference reads on its main thread and converts on the workers, agc_compressor.cpp:2160-2228);
+    // registration itself stays strictly in file order on this thread.
+    struct FileData {
+        bool opened = false;
+        std::vector<std::string> ids;
+        std::vector<bytes_t> contigs;
+    };
+    auto read_file = [](std::string path) {
+        FileData fd;
+        FastaReader fr;
+        if (!fr.open(path))
+            return fd;
+        fd.opened = true;
+        std::string id;
+        bytes_t contig;
+        while (fr.read_contig_raw(id, contig)) {
+            preprocess_raw_contig(contig);
+            fd.ids.emplace_back(id);
+            fd.contigs.emplace_back(std::move(contig));
+            contig.clear();
+        }
+        return fd;
+    };
+    auto file_bytes = [](const std::string &path) -> uint64_t {
+        std::error_code ec;
+        const auto n = std::filesystem::file_size(path, ec);
+        return ec ? 0 : (uint64_t)n;
+    };
+    const size_t READ_AHEAD = std::max<size_t>(1, std::min<size_t>(8, no_threads)); // files in flight
+    const uint64_t READ_AHEAD_BYTES = 8ull << 30;                                    // on-disk bytes in flight
+    std::deque<std::future<FileData>> inflight;
+    std::deque<uint64_t> inflight_sz;
+    uint64_t inflight_bytes = 0;
+    size_t next_launch = 0;
+    auto launch = [&]() {
+        while (next_launch < files.size()) {
+            const uint64_t sz = file_bytes(files[next_launch].second);
+            if (!inflight.empty() && (inflight.size() >= READ_AHEAD || inflight_bytes + sz > READ_AHEAD_BYTES))
+                break;
+            inflight.emplace_back(std::async(std::launch::async, read_file, files[next_launch].second));
+            inflight_sz.push_back(sz);
+            inflight_bytes += sz;
+            ++next_launch;
+        }
+    };
+
     Pending cur;
     for (auto &sf : files) {
         I.coll.reset_prev_sample_name();
-        FastaReader fr;
-        if (!fr.open(sf.second)) {
+        double t0 = now();
+        launch();
+        FileData fd = inflight.front().get();
+        inflight.pop_front();
+        inflight_bytes -= inflight_sz.front();
+        inflight_sz.pop_front();
+        launch();
+        if (!fd.opened) {
             I.err("Cannot open file: " + sf.second);
             continue;
         }
-        std::string id;
-        bytes_t contig;
         bool any_read = false, any_added = false;
-        double t0 = now();
-        while (fr.read_contig_raw(id, contig)) {
+        for (size_t ci = 0; ci < fd.ids.size(); ++ci) {
+            const std::string &id = fd.ids[ci];
+            bytes_t &contig = fd.contigs[ci];
             const std::string sname = I.concatenated ? std::string() : sf.first;
             if (!I.coll.register_sample_contig(sname, id))
                 I.err("Error: Pair sample_name:contig_name " + (I.concatenated ? id : sf.first) + ":" + id + " is already in the archive!");
             else {
-                preprocess_raw_contig(contig);
                 Contig ct;
                 ct.sample = sname;
                 ct.name = id;
                 cur.ctgs.push_back(ct);
                 cur.bytes += contig.size();
                 cur.data.emplace_back(std::move(contig));
-                contig.clear();
                 any_added = true;
                 if (I.concatenated && ++I.cnt_contigs_in_sample >= I.pack_cardinality) {
                     I.st.t_io += now() - t0;

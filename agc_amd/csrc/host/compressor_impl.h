@@ -10,6 +10,8 @@
 
 #include <chrono>
 #include <deque>
+#include <filesystem>
+#include <future>
 #include <cmath>
 #include <iostream>
 #include <numeric>
