@@ -173,3 +173,43 @@ def archive_round_trips(archive_path, files):
         return True
     finally:
         a.Close()
+
+
+def read_side_matches(ref_cli, amd_cli, archive_path, seed, env=None, n_queries=6):
+    """random getset / getctg (with and without ranges, by short name) / listctg queries: agc_amd's read side against the reference's
+    on the same archive; returns the first differing query or None"""
+    import subprocess
+    from agc_amd import build, reader
+    build.build_read()
+    rng = np.random.default_rng(seed + 77)
+    a = reader.CAGCFile()
+    if not a.Open(archive_path):
+        return "open"
+    samples = a.ListSample()
+    queries = [["listset", archive_path], ["listref", archive_path]]
+    for _ in range(n_queries):
+        sn = samples[int(rng.integers(0, len(samples)))]
+        ctgs = a.ListCtg(sn)
+        if not ctgs:
+            continue
+        cn = ctgs[int(rng.integers(0, len(ctgs)))]
+        short = cn.split()[0]
+        n = a.GetCtgLen(sn, cn)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            queries.append(["getset", "-l", str(int(rng.choice([40, 80, 1000]))), archive_path, sn])
+        elif kind == 1:
+            queries.append(["getctg", archive_path, f"{short}@{sn}"])
+        elif kind == 2 and n > 2:
+            lo = int(rng.integers(0, n - 1))
+            hi = int(rng.integers(lo, min(n + 5, lo + 5000)))
+            queries.append(["getctg", archive_path, f"{short}@{sn}:{lo}-{hi}"])
+        else:
+            queries.append(["listctg", archive_path, sn])
+    a.Close()
+    for q in queries:
+        want = subprocess.run([ref_cli] + q, capture_output=True, timeout=120, env=env)
+        got = subprocess.run([amd_cli] + q, capture_output=True, timeout=120)
+        if want.returncode == 0 and want.stdout != got.stdout:
+            return " ".join(q[:1] + q[2:])
+    return None

@@ -38,6 +38,20 @@ def _check(cli, seed, tmp_path):
             break
 
 
+@pytest.mark.parametrize("seed", [0, 1, 3, 5, 13, 100, 101, 104, 107, 110])
+def test_fuzz_read_side(seed, tmp_path):
+    """random getset / getctg / listctg queries on a reference-built archive: agc_amd's read side prints what the reference prints"""
+    if not os.path.exists(REF_AGC):
+        pytest.skip("oracle/_ref/agc not prebuilt")
+    from agc_amd import build
+    build.build_host()
+    case = fuzz.make_case(seed, str(tmp_path / "in"))
+    want, _ = fuzz.run_case(REF_AGC, case, str(tmp_path), "ref", threads="1", env=REF_ENV)
+    last = max(i for i, x in enumerate(want) if x)
+    bad = fuzz.read_side_matches(REF_AGC, build.HOST_BIN, str(tmp_path / f"ref_{last}.agc"), seed, env=REF_ENV)
+    assert bad is None, bad
+
+
 @pytest.mark.parametrize("seed", CPU_SEEDS)
 def test_fuzz_host_pipeline(seed, tmp_path):
     if not os.path.exists(REF_AGC):
