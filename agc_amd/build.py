@@ -45,7 +45,7 @@ def build_read(force=False, verbose=False):
     deps = srcs + [os.path.join(HOST, "reader.h"), os.path.join(HOST, "archive_read.h"), os.path.join(HERE, "..", "include", "agc_read.h")]
     if not force and os.path.exists(READ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(READ_LIB) for d in deps):
         return READ_LIB
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB, "-ldl"]
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB, "-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -269,7 +269,7 @@ struct SampleDesc {
     bool loaded = false;
 };
 
-// tuples2bytes, src/common/segment.h:92-138
+// tuples2bytes, src/common/segment.h:92-138 (one table look-up per packed byte instead of a division per symbol)
 inline bool tuples2bytes(const bytes_t &t, bytes_t &out)
 {
     if (t.size() < 2)
@@ -282,21 +282,27 @@ inline bool tuples2bytes(const bytes_t &t, bytes_t &out)
     }
     const uint32_t mult = nb == 4 ? 4 : nb == 3 ? 6 : 16;
     const size_t n = (t.size() - 2) * nb + trailing;
-    out.resize(n);
-    size_t i = 0, j = 0;
-    for (; j + nb <= n; ++i, j += nb) {
-        uint8_t c = t[i];
+    out.resize(n + 4); // room for whole-word stores; trimmed below
+    uint32_t lut[256]; // the nb symbols of a packed byte, first symbol in the low byte
+    for (uint32_t v = 0; v < 256; ++v) {
+        uint32_t c = v, w = 0;
         for (int k = (int)nb - 1; k >= 0; --k) {
-            out[j + k] = c % mult;
+            w |= (c % mult) << (8 * k);
             c /= mult;
         }
+        lut[v] = w;
     }
+    size_t i = 0, j = 0;
+    uint8_t *o = out.data();
+    for (; j + nb <= n; ++i, j += nb)
+        memcpy(o + j, &lut[t[i]], 4); // (little endian; the bytes past nb are overwritten by the next store)
     uint8_t c = t[i];
     const uint32_t r = (uint32_t)(n % nb);
     for (int k = (int)r - 1; k >= 0; --k) {
-        out[j + k] = c % mult;
+        o[j + k] = c % mult;
         c /= mult;
     }
+    out.resize(n);
     return true;
 }
 

@@ -120,15 +120,20 @@ int read_command(const std::string &mode, int argc, char **argv)
     } else if (mode == "getset") {
         if (args.empty())
             std::cerr << "No sample name\n";
-        for (auto &sn : args) {
-            std::string one;
-            if (!f.GetSampleFasta(sn, one, line_length)) {
-                std::cerr << "There is no sample " << sn << std::endl;
-                return 0;
-            }
-            txt += one;
+        FILE *fo = out.empty() ? stdout : fopen(out.c_str(), "wb");
+        if (!fo) {
+            std::cerr << "Cannot open output file " << out << std::endl;
+            return 0;
         }
-        write_out(out, txt);
+        for (auto &sn : args)
+            if (!f.WriteSampleFasta(sn, fo, line_length)) {
+                std::cerr << "There is no sample " << sn << std::endl;
+                break;
+            }
+        if (fo != stdout)
+            fclose(fo);
+        else
+            fflush(stdout);
     } else if (mode == "getctg") {
         if (args.empty())
             std::cerr << "No contig name\n";
@@ -172,11 +177,13 @@ int read_command(const std::string &mode, int argc, char **argv)
         std::vector<std::string> v;
         f.ListSampleStored(v);
         for (size_t j = no_ref ? 1 : 0; j < v.size(); ++j) {
-            std::string one;
-            if (!f.GetSampleFasta(v[j], one, line_length))
+            FILE *fo = out.empty() ? stdout : fopen((std::filesystem::path(out) / (v[j] + ".fa")).string().c_str(), "wb");
+            if (!fo || !f.WriteSampleFasta(v[j], fo, line_length))
                 return 0;
-            write_out(out.empty() ? out : (std::filesystem::path(out) / (v[j] + ".fa")).string(), one);
+            if (fo != stdout)
+                fclose(fo);
         }
+        fflush(stdout);
     }
     f.Close();
     return 0;

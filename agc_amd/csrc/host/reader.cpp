@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <iostream>
 #include <map>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 
 #include "archive_read.h"
@@ -37,6 +39,7 @@ struct CAGCFile::Impl {
             return false;
         return samples[sid].loaded;
     }
+    void warm_refs(const SampleDesc &s) const;
     bool get_pack(uint32_t gid, uint32_t part, const bytes_t *&out) const;
     bool get_ref(uint32_t gid, const bytes_t *&out) const;
     bool get_segment(uint32_t gid, uint32_t igid, bytes_t &out) const;
@@ -82,6 +85,41 @@ bool CAGCFile::Impl::get_ref(uint32_t gid, const bytes_t *&out) const
     }
     out = &it->second;
     return true;
+}
+
+// whole-sample extraction: the group references the sample needs are decoded (zstd + tuples) by a few threads up front;
+// the sequential assembly below then finds them in the cache
+void CAGCFile::Impl::warm_refs(const SampleDesc &s) const
+{
+    std::vector<uint32_t> need;
+    for (auto &c : s.ctgs)
+        for (auto &sg : c.segs)
+            if (sg.group_id >= NO_RAW_GROUPS && !ref_cache.count(sg.group_id))
+                need.push_back(sg.group_id);
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    if (need.size() < 64 || need.size() + ref_cache.size() > 65536)
+        return;
+    const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    std::vector<bytes_t> dec(need.size());
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < need.size();) {
+            const uint8_t *ptr;
+            uint64_t size, meta;
+            if (ar.get_part("x" + int_to_base64(need[i]) + "r", 0, ptr, size, meta))
+                decode_ref_part(z, ptr, size, meta, dec[i]);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t)
+        th.emplace_back(work);
+    work();
+    for (auto &t : th)
+        t.join();
+    for (size_t i = 0; i < need.size(); ++i)
+        if (!dec[i].empty())
+            ref_cache.emplace(need[i], std::move(dec[i]));
 }
 
 static bool nth_in_pack(const bytes_t &pack, uint32_t idx, const uint8_t *&b, size_t &n)
@@ -362,18 +400,28 @@ int CAGCFile::GetCtgSeq(const std::string &sample, const std::string &name, int6
 
 static void append_fasta(std::string &out, const std::string &name, const bytes_t &codes, uint32_t line_length)
 {
+    static const struct Lut {
+        char t[256];
+        Lut()
+        {
+            for (int i = 0; i < 256; ++i)
+                t[i] = i < 16 ? ALPHA[i] : ' ';
+        }
+    } lut;
     out.push_back('>');
     out.append(name);
     out.push_back('\n');
     const size_t ll = line_length ? line_length : codes.size();
     size_t o = out.size();
     out.resize(o + codes.size() + (ll ? (codes.size() + ll - 1) / ll : 0));
+    char *dst = &out[0];
+    const uint8_t *src = codes.data();
     for (size_t i = 0; i < codes.size(); i += ll) {
         const size_t n = std::min<size_t>(ll, codes.size() - i);
         for (size_t j = 0; j < n; ++j)
-            out[o + j] = codes[i + j] < 16 ? ALPHA[codes[i + j]] : ' ';
+            dst[o + j] = lut.t[src[i + j]];
         o += n;
-        out[o++] = '\n';
+        dst[o++] = '\n';
     }
 }
 
@@ -440,6 +488,27 @@ bool CAGCFile::GetFileTypeInfo(std::vector<std::pair<std::string, std::string>> 
     return true;
 }
 
+bool CAGCFile::WriteSampleFasta(const std::string &sample, FILE *f, uint32_t line_length) const
+{
+    if (!p->opened || !f)
+        return false;
+    auto it = p->sample_ids.find(sample);
+    if (it == p->sample_ids.end() || !p->ensure_sample(it->second))
+        return false;
+    p->warm_refs(p->samples[it->second]);
+    bytes_t codes;
+    std::string text;
+    for (auto &c : p->samples[it->second].ctgs) {
+        if (!p->decode_contig(c, -1, -1, codes))
+            return false;
+        text.clear();
+        append_fasta(text, c.name, codes, line_length);
+        if (fwrite(text.data(), 1, text.size(), f) != text.size())
+            return false;
+    }
+    return true;
+}
+
 bool CAGCFile::GetSampleCodes(const std::string &sample, std::vector<std::string> &names, std::vector<std::vector<uint8_t>> &codes) const
 {
     if (!p->opened)
@@ -466,6 +535,7 @@ bool CAGCFile::GetSampleFasta(const std::string &sample, std::string &out, uint3
     if (it == p->sample_ids.end() || !p->ensure_sample(it->second))
         return false;
     out.clear();
+    p->warm_refs(p->samples[it->second]);
     bytes_t codes;
     for (auto &c : p->samples[it->second].ctgs) {
         if (!p->decode_contig(c, -1, -1, codes))

@@ -5,6 +5,7 @@
 // src/common/agc_decompressor_lib.cpp:172-286, src/common/segment.cpp:136-400, src/common/lz_diff.cpp:801-836).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <memory>
 #include <string>
 #include <vector>
@@ -38,6 +39,8 @@ public:
     bool GetSampleFasta(const std::string &sample, std::string &out, uint32_t line_length = 80) const;
     // all contigs of a sample as symbol codes (GetSampleSequences, agc_decompressor_lib.cpp; used by append -a)
     bool GetSampleCodes(const std::string &sample, std::vector<std::string> &names, std::vector<std::vector<uint8_t>> &codes) const;
+    // the same, written contig by contig to an open stream (what the CLI uses: no sample-size string is built)
+    bool WriteSampleFasta(const std::string &sample, FILE *f, uint32_t line_length = 80) const;
     // one `agc getctg` query -- contig[@sample][:from-to] (agc_decompressor_lib.h:127-130) -- as FASTA text;
     // the header is the full contig name (+ ":from-to" when a range was given), core/agc_decompressor.cpp:478-567
     bool GetContigFasta(const std::string &query, std::string &out, uint32_t line_length, std::string &err) const;
