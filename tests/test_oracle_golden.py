@@ -114,3 +114,37 @@ def test_container_reader_on_reference_archive():
     assert struct.unpack("<4I", streams["params"][0][1]) == (25, 17, 50, 60000)
     assert sum(len(p) for n, p in streams.items() if n.startswith("x") and n.endswith("d")) >= 16
     assert agc_container.diff(data, data) == []
+
+
+def test_lz_properties_on_random_edits(oracle):
+    """size-independent properties of the LZ-diff restatement, on random references and edit mixes (hypothesis):
+    decode(encode(t)) == t; the identical sequence encodes to nothing; the unbounded estimate (value, peak) is reproducible;
+    both cost vectors cover every position with a positive total."""
+    from hypothesis import given, settings, strategies as hs
+
+    @settings(max_examples=60, deadline=None)
+    @given(seed=hs.integers(0, 2**31 - 1), n=hs.integers(1, 4000), mml=hs.integers(15, 32),
+           d=hs.sampled_from([0.0, 0.001, 0.02, 0.2]), n_runs=hs.integers(0, 3), iupac=hs.integers(0, 3), indels=hs.integers(0, 3))
+    def prop(seed, n, mml, d, n_runs, iupac, indels):
+        rng = np.random.default_rng(seed)
+        ref = synth.random_seq(rng, n)
+        if rng.random() < 0.2:
+            ref[int(rng.integers(0, n))] = 4
+        text = synth.mutate(rng, ref, d, n_runs=n_runs, iupac=iupac, indels=indels)
+        if text.size == 0:
+            return
+        z = oracle.LZ(ref, mml)
+        enc = z.encode(text)
+        if np.array_equal(text, ref):
+            assert enc.size == 0
+        else:
+            dec, m = z.decode(enc, text.size + 8)
+            assert m == text.size and np.array_equal(dec, text)
+        c1, p1 = z.estimate(text, want_peak=True)
+        c2, p2 = z.estimate(text, want_peak=True)
+        assert (c1, p1) == (c2, p2) and p1 <= 0xFFFFFFFF
+        for pf in (0, 1):
+            cv = z.cost_vector(text, pf)
+            assert cv.size == text.size and int(cv.sum()) > 0
+
+    prop()
