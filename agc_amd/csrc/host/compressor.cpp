@@ -627,10 +627,13 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     auto file_bytes = [](const std::string &path) -> uint64_t {
         std::error_code ec;
         const auto n = std::filesystem::file_size(path, ec);
-        return ec ? 0 : (uint64_t)n;
+        if (ec)
+            return 0;
+        const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+        return (uint64_t)n * (gz ? 4 : 1); // what it will occupy once read
     };
     const size_t READ_AHEAD = std::max<size_t>(1, std::min<size_t>(8, no_threads)); // files in flight
-    const uint64_t READ_AHEAD_BYTES = 8ull << 30;                                    // on-disk bytes in flight
+    const uint64_t READ_AHEAD_BYTES = 8ull << 30;                                    // (estimated) bytes of sequence in flight
     std::deque<std::future<FileData>> inflight;
     std::deque<uint64_t> inflight_sz;
     uint64_t inflight_bytes = 0;
