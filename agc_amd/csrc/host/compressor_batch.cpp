@@ -195,10 +195,14 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
 {
     const std::vector<Placed> &placed = placed_buf;
     double &t0 = b.t0, &dev0 = b.dev0;
-    b.spec.assign(2 * seg_buf.size(), BatchState::Spec());
+    if (b.spec.size() != 2 * seg_buf.size()) {
+        b.spec.assign(2 * seg_buf.size(), BatchState::Spec());
+        b.spec_bytes = 0;
+    }
     std::vector<uint32_t> items;
     for (uint32_t i = 0; i < placed.size(); ++i)
-        if (placed[i].gid >= (int32_t)NO_RAW_GROUPS && groups[placed[i].gid].exists && !groups[placed[i].gid].packed)
+        if (placed[i].gid >= (int32_t)NO_RAW_GROUPS && groups[placed[i].gid].exists && !groups[placed[i].gid].packed &&
+            !b.spec[placed[i].key].valid) // (not delivered by the asynchronous encode already)
             items.push_back(i);
     if (items.empty())
         return true;
@@ -216,11 +220,13 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
         tot += pl.len;
     }
     bytes_t &enc = enc_buf;
-    uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 20));
+    const uint64_t base = b.spec_bytes; // the deltas are appended to what the window already holds
+    uint64_t cap = std::max<uint64_t>(enc.size() > base ? enc.size() - base : 0, tot / 64 + (1u << 20));
     for (;;) {
-        if (enc.size() < cap)
-            enc.resize(cap);
-        int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), b.d_base, off.data(), len.data(), rc.data(), enc.data(), cap, eoff.data()));
+        if (enc.size() < base + cap)
+            enc.resize(base + cap);
+        int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), b.d_base, off.data(), len.data(), rc.data(), enc.data() + base, cap,
+                                                 eoff.data()));
         if (r == AGC_HIP_ECAP) {
             cap = eoff[ne] + 64;
             continue;
@@ -237,9 +243,10 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
         sp.off = pl.off;
         sp.len = pl.len;
         sp.rc = pl.rc;
-        sp.enc_off = eoff[i];
+        sp.enc_off = base + eoff[i];
         sp.enc_len = (uint32_t)(eoff[i + 1] - eoff[i]);
     }
+    b.spec_bytes = base + eoff[ne];
     st.lz_encoded += ne;
     st.delta_bytes += eoff[ne];
     stage_end(st.t_encode, st.h_encode, t0, dev0);
@@ -527,6 +534,35 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
 
+    // AGC_AMD_ASYNC_ENCODE=1: the both-splitter segments whose key is already in the map are placed whatever the rest of the
+    // classification decides, and their group's reference cannot change -- their LZ encode is launched now on the device
+    // library's second stream and collected after the split points, so the estimate / cost-vector kernels (few, long waves)
+    // run beside it instead of in front of it
+    static const bool async_encode = getenv("AGC_AMD_ASYNC_ENCODE") != nullptr;
+    std::vector<uint32_t> a_seg, a_gid, a_len;
+    std::vector<uint64_t> a_off;
+    std::vector<uint8_t> a_rc;
+    if (async_encode && !b.async_done && L.size() == segs.size()) {
+        for (uint32_t si : L) {
+            const Seg &s = segs[si];
+            if (!s.front.full || !s.back.full)
+                continue;
+            const int32_t *m = map_segments.find(s.pk);
+            if (!m || *m < (int32_t)NO_RAW_GROUPS || !groups[*m].exists || groups[*m].packed)
+                continue;
+            a_seg.push_back(si);
+            a_gid.push_back((uint32_t)*m);
+            a_off.push_back(ctgs[s.ctg].off + s.start);
+            a_len.push_back(s.len);
+            a_rc.push_back((uint8_t)s.store_rc);
+        }
+        if (!a_seg.empty() &&
+            !hip_ok(DEVT(agc_hip_lz_encode_begin_dev(hip, (uint32_t)a_seg.size(), a_gid.data(), d_base, a_off.data(), a_len.data(), a_rc.data())),
+                    "lz_encode_begin"))
+            return false;
+        b.async_done = true;
+    }
+
     LAP("keys");
     // ---- GPU: estimates for every (one-splitter segment, candidate) pair ----
     std::vector<uint32_t> est_cost(cands.size()), est_peak(cands.size());
@@ -712,6 +748,42 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
+    if (!a_seg.empty()) { // collect the asynchronous encode: speculative deltas of the whole segments (item key = 2 * segment)
+        const size_t ne = a_seg.size();
+        std::vector<uint64_t> eoff(ne + 1, 0);
+        uint64_t tot = 0;
+        for (uint32_t l : a_len)
+            tot += l;
+        bytes_t &enc = enc_buf;
+        uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 20));
+        for (;;) {
+            if (enc.size() < cap)
+                enc.resize(cap);
+            int r = DEVT(agc_hip_lz_encode_end(hip, enc.data(), cap, eoff.data()));
+            if (r == AGC_HIP_ECAP) {
+                cap = eoff[ne] + 64;
+                continue;
+            }
+            if (!hip_ok(r, "lz_encode_end"))
+                return false;
+            break;
+        }
+        b.spec.assign(2 * segs.size(), BatchState::Spec());
+        for (size_t i = 0; i < ne; ++i) {
+            BatchState::Spec &sp = b.spec[2 * (size_t)a_seg[i]];
+            sp.valid = true;
+            sp.gid = a_gid[i];
+            sp.off = a_off[i];
+            sp.len = a_len[i];
+            sp.rc = a_rc[i] != 0;
+            sp.enc_off = eoff[i];
+            sp.enc_len = (uint32_t)(eoff[i + 1] - eoff[i]);
+        }
+        b.spec_bytes = eoff[ne];
+        st.lz_encoded += ne;
+        st.delta_bytes += eoff[ne];
+        stage_end(st.t_encode, st.h_encode, t0, dev0);
+    }
     return true;
 }
 

@@ -530,6 +530,8 @@ struct CAGCCompressor::Impl {
             bool rc = false, valid = false;
         };
         std::vector<Spec> spec;
+        uint64_t spec_bytes = 0;                   // bytes of enc_buf the speculative deltas occupy
+        bool async_done = false;                   // the asynchronous encode of the window has been launched
         std::vector<uint64_t> changed;             // k-mers whose terminator list changed in the last commit run
         uint32_t commit_upto = 0;                  // registrations of the window that are committed now
         std::vector<uint32_t> order;               // committed items in registration order

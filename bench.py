@@ -270,6 +270,7 @@ def main():
                        "setup_not_timed": f"determine_splitters ({'positional shortcut' if args.positional_splitters else 'GPU: enumerate + radix sort + singletons'}): "
                                           f"{t_spl:.2f} s; reference genome as first sample (mints ~{int(st0['new_groups'])} groups): {t_ref:.2f} s",
                        "steps_only_ms": round(t_steps / max(args.steps, 1) * 1e3, 3),
+                       "async_encode": bool(os.environ.get("AGC_AMD_ASYNC_ENCODE")),
                        "close_ms": round((elapsed - t_steps) * 1e3, 1),
                        "segments_per_step": int(per(stats["segments"])), "lz_encoded_per_step": int(per(stats["lz_encoded"])),
                        "missing_middle_per_step": int(per(stats["middle_tried"])), "one_splitter_per_step": int(per(stats["one_splitter"])),

@@ -131,3 +131,18 @@ def test_lag_counts(hip_ctx, oracle):
         for i, s in enumerate(seqs):
             wc, wu = oracle.ref_lag_counts(oracle.rev_comp(s) if rc else s)
             assert np.array_equal(cnt[i], wc) and np.array_equal(cur[i], wu)
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("AGC_TEST_ASYNC"),
+                    reason="asynchronous encode (second stream) is opt-in until it has been measured on the GPU: set AGC_TEST_ASYNC=1")
+def test_async_encode_equals_sync(hip_ctx, oracle, registered):
+    """agc_hip_lz_encode_begin_dev / _end deliver the bytes of agc_hip_lz_encode_batch_dev, with estimates running in between"""
+    import torch
+    buf, off, ln = _concat(registered)
+    gids = 1000 + np.arange(len(registered))
+    d = torch.from_numpy(buf).cuda()
+    want, woff = hip_ctx.lz_encode_batch_dev(d.data_ptr(), gids, off, ln)
+    hip_ctx.lz_encode_begin_dev(d.data_ptr(), gids, off, ln)
+    hip_ctx.lz_estimate_batch_dev(d.data_ptr(), gids, off, ln)  # first stream, first buffer set, concurrently
+    got, goff = hip_ctx.lz_encode_end()
+    assert np.array_equal(woff, goff) and np.array_equal(want, got)
