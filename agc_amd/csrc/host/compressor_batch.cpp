@@ -949,9 +949,24 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
                 keyed.push_back({((uint64_t)ctg_rank[placed[i].ctg] << 32) | placed[i].part_no, i});
         if (!std::is_sorted(keyed.begin(), keyed.end()))
             std::sort(keyed.begin(), keyed.end());
-        order.resize(keyed.size());
-        for (size_t i = 0; i < keyed.size(); ++i)
-            order[i] = keyed[i].second;
+        // items for NEW groups wait in a std::set keyed by (sample, contig name, part no) in the reference
+        // (agc_compressor.h:111-118, 326-331): a second new item with the same key -- two contigs of one sample carrying the
+        // same name -- never gets in.  Dropped here the same way (the first one, in contig order, stays).
+        order.clear();
+        uint64_t cur_key = ~0ULL;
+        bool have_new = false;
+        for (size_t i = 0; i < keyed.size(); ++i) {
+            if (keyed[i].first != cur_key) {
+                cur_key = keyed[i].first;
+                have_new = false;
+            }
+            if (placed[keyed[i].second].gid < 0) {
+                if (have_new)
+                    continue;
+                have_new = true;
+            }
+            order.push_back(keyed[i].second);
+        }
         st.segments += order.size();
     }
     {
