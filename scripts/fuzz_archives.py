@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--from", dest="first", type=int, default=0)
     ap.add_argument("--count", type=int, default=50)
     ap.add_argument("--keep", default=None, help="directory that receives the inputs of failing cases")
+    ap.add_argument("--many", action="store_true", help="20-70 samples per case (long speculation windows, many commit runs)")
     ap.add_argument("--big", action="store_true", help="Mbp-size contigs, segment sizes up to 1 M (32-bit LZ index regime)")
     a = ap.parse_args()
     ref = os.path.join(ROOT, "oracle", "_ref", "agc")
@@ -32,7 +33,7 @@ def main():
     bad = 0
     for seed in range(a.first, a.first + a.count):
         d = tempfile.mkdtemp(prefix=f"fuzz{seed}_")
-        case = fuzz.make_case(seed, os.path.join(d, "in"), big=a.big)
+        case = fuzz.make_case(seed, os.path.join(d, "in"), big=a.big, many=a.many)
         want, e1 = fuzz.run_case(ref, case, d, "ref", threads="1", env=env)
         got, e2 = fuzz.run_case(cli, case, d, "amd")
         # the reference itself dies on some inputs (e.g. `append -c` onto a partly filled batch): compare up to there

@@ -18,9 +18,10 @@ def _rc(s):
     return r
 
 
-def make_case(seed, outdir, big=False):
+def make_case(seed, outdir, big=False, many=False):
     """-> dict(args=[...], carry=[...], files=[...], steps=[n0, n1, ...]).
-    big: Mbp-size contigs and segment sizes up to 1 M (references past 262 k symbols use the 32-bit LZ index, lz_diff.cpp:144-149)"""
+    big: Mbp-size contigs and segment sizes up to 1 M (references past 262 k symbols use the 32-bit LZ index, lz_diff.cpp:144-149);
+    many: 20-70 samples per case"""
     rng = np.random.default_rng(seed)
     os.makedirs(outdir, exist_ok=True)
     k = int(rng.choice([17, 19, 21, 25, 31, 32]))
@@ -59,6 +60,8 @@ def make_case(seed, outdir, big=False):
 
     write("ref.fa", ref, names)
     n_samples = int(rng.integers(1, 5 if big else 9))
+    if many:  # long runs of small samples: speculation windows of 16-64 registrations, many commit runs and revalidations
+        n_samples = int(rng.integers(20, 70))
     uniq = 0
     for si in range(n_samples):
         ctgs, nm = [], []
