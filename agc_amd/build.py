@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagc_hip.so")
-SOURCES = ["api.hip", "scan_kernels.hip", "lz_kernels.hip", "splitters.hip", "async_encode.hip", "dev_common.h"]
+SOURCES = ["api.hip", "scan_kernels.hip", "lz_kernels.hip", "splitters.hip", "dev_common.h"]
 
 
 def _stale():

@@ -26,7 +26,7 @@ SYMBOLS = [
     "agc_hip_determine_splitters_dev",
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
     "agc_hip_ref_register", "agc_hip_ref_register_batch_dev", "agc_hip_ref_get", "agc_hip_ref_index_get",
-    "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch", "agc_hip_lz_encode_begin_dev", "agc_hip_lz_encode_end",
+    "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch",
     "agc_hip_lz_estimate_batch_dev", "agc_hip_lz_estimate_batch",
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
@@ -90,8 +90,6 @@ def load():
     L.agc_hip_ref_get.argtypes = [vp, C.c_uint32, u8p, C.c_uint32, u32p]
     L.agc_hip_ref_index_get.argtypes = [vp, C.c_uint32, u32p, C.c_uint64, u64p, C.POINTER(C.c_int)]
     L.agc_hip_lz_encode_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
-    L.agc_hip_lz_encode_begin_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p]
-    L.agc_hip_lz_encode_end.argtypes = [vp, u8p, C.c_uint64, u64p]
     L.agc_hip_lz_encode_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_lz_estimate_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_lz_estimate_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u32p, u32p]
@@ -264,21 +262,6 @@ class Context:
     def lz_encode_batch_dev(self, d_base, gids, off, length, rc=None, enc_cap=None):
         """-> (enc bytes, enc_off[n+1])"""
         return self._encode(self.L.agc_hip_lz_encode_batch_dev, d_base, gids, off, length, rc, enc_cap)
-
-    def lz_encode_begin_dev(self, d_base, gids, off, length, rc=None):
-        """asynchronous encode: launches on the second stream and returns; lz_encode_end() delivers (enc bytes, enc_off[n+1])"""
-        g, o, l, r = self._batch(gids, off, length, rc)
-        self._async = (g, o, l, r)  # keep the descriptor arrays alive
-        self._chk(self.L.agc_hip_lz_encode_begin_dev(self.h, g.size, _p(g, u32p), d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p)))
-
-    def lz_encode_end(self, enc_cap=None):
-        g, _o, l, _r = self._async
-        if enc_cap is None:
-            enc_cap = int(l.astype(np.uint64).sum()) * 21 // 16 + 64 * g.size + 64
-        enc = np.empty(enc_cap, np.uint8)
-        eoff = np.zeros(g.size + 1, np.uint64)
-        self._chk(self.L.agc_hip_lz_encode_end(self.h, _p(enc, u8p), enc_cap, _p(eoff, u64p)))
-        return enc[:int(eoff[-1])], eoff
 
     def lz_encode_batch(self, text, gids, off, length, rc=None, enc_cap=None):
         text = _a(text, np.uint8)

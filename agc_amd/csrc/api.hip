@@ -52,7 +52,6 @@ struct agc_hip_ctx {
         d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample;
 
     std::vector<SliceDesc> h_slices;
-    void *async_enc = nullptr; // second stream + buffer set of the asynchronous encode (async_encode.hip), created on first use
 
     // timing
     bool timing = false;
@@ -146,8 +145,6 @@ int upload_refs(agc_hip_ctx *c)
     return AGC_HIP_OK;
 }
 
-void async_enc_destroy(agc_hip_ctx *c); // async_encode.hip
-
 uint32_t grid_for(uint32_t n_items, uint32_t per_block, uint32_t max_blocks)
 {
     uint64_t b = ((uint64_t)n_items + per_block - 1) / per_block;
@@ -188,7 +185,6 @@ void agc_hip_destroy(agc_hip_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    async_enc_destroy(c);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample};
@@ -1013,4 +1009,3 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base
 } // extern "C"
 
 #include "splitters.hip"
-#include "async_encode.hip"

@@ -127,7 +127,7 @@ struct Archive {
             return false;
         const Part &pt = streams[it->second].parts[idx];
         uint64_t p = pt.offset;
-        if (!num(data, p, meta) || p + pt.size > data.size())
+        if (!num(data, p, meta) || pt.size > data.size() - p) // (no wrap-around on a corrupt footer)
             return false;
         ptr = data.data() + p;
         size = pt.size;

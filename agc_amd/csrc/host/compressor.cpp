@@ -482,6 +482,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
         I.prepared_ctgs.push_back(ct);
     }
     I.changed_log.clear();
+    I.minted_since_prepare = false;
     I.prepared.reset(new Impl::BatchState());
     if (!I.batch_prepare(*I.prepared, I.prepared_ctgs, d_codes, nullptr, I.dist_world > 1 && !I.adaptive && !I.appending)) {
         I.prepared.reset();
@@ -497,17 +498,27 @@ bool CAGCCompressor::CommitPrepared()
     if (!I.prepared)
         return false;
     std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
+    I.dist_record.clear();
     I.coll.reset_prev_sample_name();
     for (auto &ct : I.prepared_ctgs)
         if (!I.coll.register_sample_contig(ct.sample, ct.name)) {
             I.err("Error: Pair sample_name:contig_name " + ct.sample + ":" + ct.name + " is already in the archive!");
             return false; // (AddSampleFiles skips such contigs; a device-resident sample is all or nothing)
         }
-    if (I.prepared_ctgs.empty())
+    if (I.prepared_ctgs.empty()) {
+        // a sample without contigs registers nothing (the reference warns and skips such a file, agc_compressor.cpp:2187-2195);
+        // the other ranks still expect one record per sample: an empty one
+        if (I.dist_world > 1)
+            I.make_empty_record();
         return true;
-    if (!I.changed_log.empty()) {
+    }
+    // Any group minted since PrepareSampleDevice -- also one keyed (k-mer, NO_KMER), which has no terminator entry and is
+    // therefore not in changed_log -- may be the group of a prepared segment whose key was unknown then: the placement is
+    // repeated (revalidate ends with stage_place), the classification only for what the changed terminator lists touch.
+    if (I.minted_since_prepare || !I.changed_log.empty()) {
         b->changed.swap(I.changed_log);
         I.changed_log.clear();
+        I.minted_since_prepare = false;
         b->s_from = 0;
         if (!I.revalidate(*b))
             return false;
@@ -798,6 +809,10 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     I.ar.close();
     I.st.archive_bytes = I.ar.bytes_written();
     I.created = false;
+    if (I.ar.failed()) {
+        I.err("Error: writing the archive failed (disk full or I/O error): the output is incomplete");
+        return false;
+    }
     return true;
 }
 

@@ -10,9 +10,10 @@ namespace agc {
 void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off)
 {
     ZJob j;
-    if (g.stream_delta < 0) // segment.h:262-266
-        g.stream_delta = ar.register_stream(ss_delta_name((uint32_t)(&g - groups.data())));
-    j.stream_id = g.stream_delta;
+    j.gid = (uint32_t)(&g - groups.data());
+    if (g.stream_delta < 0 && !defer_stream_reg) // segment.h:262-266
+        g.stream_delta = ar.register_stream(ss_delta_name(j.gid));
+    j.stream_id = g.stream_delta; // (< 0: registered by the caller, in list order)
     j.kind = 1;
     j.data.swap(data);
     data.clear();
@@ -202,7 +203,7 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
     std::vector<uint32_t> items;
     for (uint32_t i = 0; i < placed.size(); ++i)
         if (placed[i].gid >= (int32_t)NO_RAW_GROUPS && groups[placed[i].gid].exists && !groups[placed[i].gid].packed &&
-            !b.spec[placed[i].key].valid) // (not delivered by the asynchronous encode already)
+            !b.spec[placed[i].key].valid)
             items.push_back(i);
     if (items.empty())
         return true;
@@ -218,6 +219,8 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
         len[i] = pl.len;
         rc[i] = pl.rc;
         tot += pl.len;
+        st.enc_text += pl.len;
+        st.enc_ref += groups[pl.gid].ref_size ? groups[pl.gid].ref_size - 1 : 0;
     }
     bytes_t &enc = enc_buf;
     const uint64_t base = b.spec_bytes; // the deltas are appended to what the window already holds
@@ -534,35 +537,6 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
 
-    // AGC_AMD_ASYNC_ENCODE=1: the both-splitter segments whose key is already in the map are placed whatever the rest of the
-    // classification decides, and their group's reference cannot change -- their LZ encode is launched now on the device
-    // library's second stream and collected after the split points, so the estimate / cost-vector kernels (few, long waves)
-    // run beside it instead of in front of it
-    static const bool async_encode = getenv("AGC_AMD_ASYNC_ENCODE") != nullptr;
-    std::vector<uint32_t> a_seg, a_gid, a_len;
-    std::vector<uint64_t> a_off;
-    std::vector<uint8_t> a_rc;
-    if (async_encode && !b.async_done && L.size() == segs.size()) {
-        for (uint32_t si : L) {
-            const Seg &s = segs[si];
-            if (!s.front.full || !s.back.full)
-                continue;
-            const int32_t *m = map_segments.find(s.pk);
-            if (!m || *m < (int32_t)NO_RAW_GROUPS || !groups[*m].exists || groups[*m].packed)
-                continue;
-            a_seg.push_back(si);
-            a_gid.push_back((uint32_t)*m);
-            a_off.push_back(ctgs[s.ctg].off + s.start);
-            a_len.push_back(s.len);
-            a_rc.push_back((uint8_t)s.store_rc);
-        }
-        if (!a_seg.empty() &&
-            !hip_ok(DEVT(agc_hip_lz_encode_begin_dev(hip, (uint32_t)a_seg.size(), a_gid.data(), d_base, a_off.data(), a_len.data(), a_rc.data())),
-                    "lz_encode_begin"))
-            return false;
-        b.async_done = true;
-    }
-
     LAP("keys");
     // ---- GPU: estimates for every (one-splitter segment, candidate) pair ----
     std::vector<uint32_t> est_cost(cands.size()), est_peak(cands.size());
@@ -582,6 +556,8 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
                 len.push_back(s.len);
                 // front-only: segment_dir = the segment itself; back-only: segment_dir = its reverse complement (:1317-1345)
                 rc.push_back((uint8_t)(s.back_only ? !cands[c].use_rc : cands[c].use_rc));
+                st.est_text += s.len;
+                st.est_ref += cands[c].ref_size - 1;
             }
         }
         std::vector<uint32_t> cost(which.size()), peak(which.size());
@@ -737,6 +713,8 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
             p1[i] = mids[i].pf1;
             r2[i] = mids[i].rc2;
             p2[i] = mids[i].pf2;
+            st.cv_text += 2ull * s.len;
+            st.cv_ref += groups[g1[i]].ref_size + groups[g2[i]].ref_size - 2;
         }
         if (!hip_ok(DEVT(agc_hip_lz_split_point_batch_dev(hip, (uint32_t)n, g1.data(), g2.data(), d_base, off.data(), len.data(), r1.data(),
                                                      p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr)),
@@ -748,42 +726,6 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
 
-    if (!a_seg.empty()) { // collect the asynchronous encode: speculative deltas of the whole segments (item key = 2 * segment)
-        const size_t ne = a_seg.size();
-        std::vector<uint64_t> eoff(ne + 1, 0);
-        uint64_t tot = 0;
-        for (uint32_t l : a_len)
-            tot += l;
-        bytes_t &enc = enc_buf;
-        uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 20));
-        for (;;) {
-            if (enc.size() < cap)
-                enc.resize(cap);
-            int r = DEVT(agc_hip_lz_encode_end(hip, enc.data(), cap, eoff.data()));
-            if (r == AGC_HIP_ECAP) {
-                cap = eoff[ne] + 64;
-                continue;
-            }
-            if (!hip_ok(r, "lz_encode_end"))
-                return false;
-            break;
-        }
-        b.spec.assign(2 * segs.size(), BatchState::Spec());
-        for (size_t i = 0; i < ne; ++i) {
-            BatchState::Spec &sp = b.spec[2 * (size_t)a_seg[i]];
-            sp.valid = true;
-            sp.gid = a_gid[i];
-            sp.off = a_off[i];
-            sp.len = a_len[i];
-            sp.rc = a_rc[i] != 0;
-            sp.enc_off = eoff[i];
-            sp.enc_len = (uint32_t)(eoff[i + 1] - eoff[i]);
-        }
-        b.spec_bytes = eoff[ne];
-        st.lz_encoded += ne;
-        st.delta_bytes += eoff[ne];
-        stage_end(st.t_encode, st.h_encode, t0, dev0);
-    }
     return true;
 }
 
@@ -1193,6 +1135,8 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
                 len[i] = pl.len;
                 rc[i] = pl.rc;
                 tot += pl.len;
+                st.enc_text += pl.len;
+                st.enc_ref += groups[pl.gid].ref_size ? groups[pl.gid].ref_size - 1 : 0;
             }
             bytes_t &enc = enc_buf2;
             uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 16));
@@ -1347,12 +1291,23 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
         if (sl.n_lists() >= 4096) {
             const size_t n_chunks = std::min<size_t>(sl.n_lists(), (size_t)pool->size() * 8);
             std::vector<std::vector<ZJob>> chunk_jobs(n_chunks);
+            defer_stream_reg = true;
             pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
                 book(sl.n_lists() * ci / n_chunks, sl.n_lists() * (ci + 1) / n_chunks, chunk_jobs[ci]);
             });
+            // a group taken over from an input archive without a delta stream (append mode) registers it with its first pack
+            // (segment.h:262-266): here, in list order, as the serial path does -- never in thread-timing order
+            defer_stream_reg = false;
             for (auto &cj : chunk_jobs)
-                for (auto &j : cj)
+                for (auto &j : cj) {
+                    if (j.stream_id < 0) {
+                        Group &g = groups[j.gid];
+                        if (g.stream_delta < 0)
+                            g.stream_delta = ar.register_stream(ss_delta_name(j.gid));
+                        j.stream_id = g.stream_delta;
+                    }
                     jobs.emplace_back(std::move(j));
+                }
         } else
             book(0, sl.n_lists(), jobs);
         // collection records.  Two contigs of one sample with the same name share the first one's descriptor
@@ -1403,6 +1358,8 @@ void CAGCCompressor::Impl::note_new_group(const pk_t &pk, uint32_t gid)
         map_segments[pk] = (int32_t)gid;
     else if (*it > (int32_t)gid)
         *it = (int32_t)gid;
+    if (prepared)
+        minted_since_prepare = true;
     if (prepared && pk.first != NO_KMER && pk.second != NO_KMER) {
         changed_log.push_back(pk.first);
         changed_log.push_back(pk.second);

@@ -146,6 +146,19 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
         }
 }
 
+// the record of a sample without contigs: nothing to register anywhere
+void CAGCCompressor::Impl::make_empty_record()
+{
+    bytes_t &r = dist_record;
+    r.clear();
+    r.insert(r.end(), {'A', 'G', 'C', 'R'});
+    put32(r, 0);
+    put32(r, 0);
+    put32(r, 0);
+    put32(r, ~0u);
+    put32(r, 0);
+}
+
 bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec)
 {
     RecReader rr{rec, rec + n};
@@ -168,6 +181,8 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
         err("truncated commit record");
         return false;
     }
+    if (n_ctg == 0 && n_lists == 0 && n_spl == 0 && n_new == 0)
+        return rr.p == rr.e; // empty sample: skipped on every rank
     const bool writer = dist_rank == dist_writer;
     if (!add.empty()) { // adaptive mode: the owner's new splitters (agc_compressor.cpp:1191-1209)
         splitters.insert(splitters.end(), add.begin(), add.end());

@@ -223,6 +223,7 @@ struct CommitData {
 
 struct ZJob { // one archive part to produce
     int stream_id;
+    uint32_t gid = 0;  // pack jobs: the group (for a deferred stream registration)
     int kind;          // 0 = reference (tuples/zstd13 or zstd19), 1 = pack (zstd17)
     bytes_t data;      // raw bytes (reference symbols or concatenated pack)
     bool repetitive = false;
@@ -531,7 +532,6 @@ struct CAGCCompressor::Impl {
         };
         std::vector<Spec> spec;
         uint64_t spec_bytes = 0;                   // bytes of enc_buf the speculative deltas occupy
-        bool async_done = false;                   // the asynchronous encode of the window has been launched
         std::vector<uint64_t> changed;             // k-mers whose terminator list changed in the last commit run
         uint32_t commit_upto = 0;                  // registrations of the window that are committed now
         std::vector<uint32_t> order;               // committed items in registration order
@@ -551,6 +551,8 @@ struct CAGCCompressor::Impl {
     std::unique_ptr<BatchState> prepared;
     std::vector<Contig> prepared_ctgs;
     std::vector<uint64_t> changed_log;
+    bool defer_stream_reg = false;     // parallel bookkeeping: pack jobs leave a missing delta stream to the merging thread
+    bool minted_since_prepare = false; // a group of any key (also one-sided) was minted while a sample was prepared
     void lap(BatchState &b, const char *what);
     bool book_and_store(CommitData &cd);
     // stage accounting: wall time of the stage and its host-only part (wall minus the time inside the device library)
@@ -566,6 +568,7 @@ struct CAGCCompressor::Impl {
     uint32_t dist_rank = 0, dist_world = 1, dist_writer = 0;
     bytes_t dist_record;
     void make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters);
+    void make_empty_record();
     bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec);
     void note_new_group(const pk_t &pk, uint32_t gid);
     void finish_groups();

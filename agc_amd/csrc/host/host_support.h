@@ -183,6 +183,10 @@ class ArchiveWriter {
     FILE *f = nullptr;
     bool own = false;
     bytes_t wbuf;
+    bool io_error = false; // a write or the final close failed
+public:
+    bool failed() const { return io_error; }
+private:
     uint64_t f_offset = 0;
     std::mutex mtx;
 
@@ -195,8 +199,8 @@ class ArchiveWriter {
     }
     void flush_file()
     {
-        if (f && !wbuf.empty())
-            fwrite(wbuf.data(), 1, wbuf.size(), f);
+        if (f && !wbuf.empty() && fwrite(wbuf.data(), 1, wbuf.size(), f) != wbuf.size())
+            io_error = true; // latched: close() reports it (ENOSPC, I/O error)
         wbuf.clear();
     }
     size_t write_num(uint64_t x)
@@ -309,10 +313,11 @@ public:
         put(le, 8);
         f_offset += fs + 8;
         flush_file();
-        if (f && own)
-            fclose(f);
-        else if (f)
-            fflush(f);
+        if (f && own) {
+            if (fclose(f) != 0)
+                io_error = true;
+        } else if (f && fflush(f) != 0)
+            io_error = true;
         f = nullptr;
     }
 };

@@ -55,8 +55,11 @@ bool write_out(const std::string &name, const std::string &data, bool append = f
         std::cerr << "Cannot open output file " << name << std::endl;
         return false;
     }
-    fwrite(data.data(), 1, data.size(), f);
-    fclose(f);
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    if (fclose(f) != 0 || !ok) {
+        std::cerr << "Cannot write output file " << name << std::endl;
+        return false;
+    }
     return true;
 }
 

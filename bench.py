@@ -13,8 +13,8 @@ archives are byte-identical to the reference's (tests/test_gpu_archive.py).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `value` = bases of all ranks / max-over-ranks time.
-roofline.* is for the dominant kernel (LZ encode), timed with HIP events on the library's
-own stream; cpu_baseline is the reference CPU implementation (oracle/_ref/agc, when it was
+roofline.* is for the kernel with the largest time per step (every kernel of the path competes), timed with HIP
+events on the library's own stream, on the layout as built and on SURVEY 8d's 2-bit figures; cpu_baseline is the reference CPU implementation (oracle/_ref/agc, when it was
 prebuilt) or the oracle port, timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 K, MML, SEG, PACK = 31, 15, 60000, 100
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_SYMBOL = 1.0  # device layout of sample and reference symbols
 
 
 def parse():
@@ -65,25 +66,33 @@ def host_cpus():
     return n
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this workload
-    (profiles/r1_final/pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes; values in KB;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None when the summary is absent."""
-    fn = os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r2", "pmc_summary.csv")
+KERNEL_SYMBOL = {"scan": "agc::scan_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
+                 "costvec": "agc::lz_parse_kernel<2>"}
+
+
+def pmc_table():
+    """{kernel symbol: {counter: max KB per dispatch}} from the committed rocprofv3 PMC summary of this workload
+    (scripts/pmc_summary.py over separate --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1`; max over
+    dispatches = the full-size launches).  Empty when the summary is absent."""
+    tab = {}
     try:
-        fetch = write = None
-        for line in open(fn):
+        for line in open(os.path.join(ROOT, PMC_SUMMARY)):
             f = line.strip().split(",")
-            if len(f) >= 5 and f[0].endswith(kernel.replace("lz_parse_kernel<ENCODE>", "lz_parse_kernel<0>")):
-                if f[1] == "FETCH_SIZE":
-                    fetch = float(f[4])   # max over dispatches = the full-size launches
-                elif f[1] == "WRITE_SIZE":
-                    write = float(f[4])
-        if fetch is None:
-            return None, None
-        return int((2.0 * fetch + (write or 0.0)) * 1024), "profiles/r1_final/pmc_summary.csv (2 x FETCH_SIZE + WRITE_SIZE, per launch)"
+            if len(f) >= 5 and f[0] != "kernel":
+                tab.setdefault(f[0], {})[f[1]] = float(f[4])
     except OSError:
-        return None, None
+        pass
+    return tab
+
+
+def pmc_traffic(tab, name):
+    """HBM bytes per launch: FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies the 128-B requests of wide coalesced
+    loads as 64 B; profiles/r2/fetch_calibration.txt holds this repo's own calibration incl. the 16-B table probes) + WRITE_SIZE."""
+    c = tab.get(KERNEL_SYMBOL[name])
+    if not c or "FETCH_SIZE" not in c:
+        return None
+    return int((2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
 
 
 def cpu_baseline(args, mbp):
@@ -239,21 +248,35 @@ def main():
 
     if rank == 0:
         value = stats["bases"] / elapsed / 1e9
-        # Roofline (HBM-bound byte work; SURVEY 8d algorithmic bytes, 1 B/symbol layout):
-        #   scan   : every symbol of the sample read once                      -> 1.0 B/bp
-        #   encode : text read once + matched reference read once              -> 2.0 B/bp
-        # kernel time = HIP events on the library's own stream, averaged over the launches of the timed region.
-        bases_per_launch = stats["bases"] / world / max(args.steps, 1)
+        # Roofline (HBM-bound byte work).  Algorithmic bytes per kernel and step = the symbols the kernel was asked to look at
+        # (host counters): scan = every symbol of the sample once; encode / estimate / cost vectors = every text once + its
+        # reference once.  Two columns: the layout as built (`bytes_per_symbol` B per symbol) and SURVEY 8d's 2-bit figure
+        # (0.25 B per symbol), which is what north_star's roofline target is quoted on.
+        # Kernel time = HIP events on the library's own stream around every launch of the timed region, summed per step
+        # (scan and encode are one launch per step; "costvec" = the cost-vector parse + the split-point reduction).
+        n_rank_steps = max(args.steps * world, 1)
+        sym = {"scan": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"], "estimate": stats["est_text"] + stats["est_ref"],
+               "costvec": stats["cv_text"] + stats["cv_ref"]}
+        tab = pmc_table()
         kern = {}
-        for name, bpb in (("scan", 1.0), ("encode", 2.0)):
+        for name in ("scan", "encode", "estimate", "costvec"):
             ms_, n_ = tm[name]
-            if n_:
-                avg = ms_ / n_
-                kern[name] = {"avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_bp": bpb,
-                              "achieved": round(bpb * bases_per_launch / (avg * 1e-3) / 1e9, 2)}
-        dominant = max(kern, key=lambda k_: kern[k_]["avg_launch_ms"]) if kern else "encode"
-        kname = {"scan": "scan_kernel", "encode": "lz_parse_kernel<ENCODE>"}[dominant]
-        traffic, traffic_src = pmc_traffic(kname)
+            if not n_:
+                continue
+            ms_step = ms_ / max(args.steps, 1)
+            sym_step = sym[name] / n_rank_steps
+            row = {"ms_per_step": round(ms_step, 4), "launches_per_step": round(n_ / max(args.steps, 1), 2),
+                   "symbols_per_step": int(sym_step)}
+            for col, bps in (("as_built", BYTES_PER_SYMBOL), ("packed_2bit", 0.25)):
+                ach = bps * sym_step / (ms_step * 1e-3) / 1e9
+                row[col] = {"bytes_per_symbol": bps, "algorithmic_bytes": int(bps * sym_step), "achieved": round(ach, 2),
+                            "frac": round(ach / HBM_PEAK_GBS, 5)}
+            tr = pmc_traffic(tab, name)
+            row["traffic"] = tr
+            row["waste"] = round(tr / row["as_built"]["algorithmic_bytes"], 2) if tr and row["as_built"]["algorithmic_bytes"] else None
+            kern[name] = row
+        dominant = max(kern, key=lambda k_: kern[k_]["ms_per_step"]) if kern else None
+        dom = kern.get(dominant, {})
         per = lambda x: x / max(args.steps * world, 1)
         out = {
             "metric": "input Gbp/s compressed (create), hot path scan + match + encode + zstd packing",
@@ -270,7 +293,6 @@ def main():
                        "setup_not_timed": f"determine_splitters ({'positional shortcut' if args.positional_splitters else 'GPU: enumerate + radix sort + singletons'}): "
                                           f"{t_spl:.2f} s; reference genome as first sample (mints ~{int(st0['new_groups'])} groups): {t_ref:.2f} s",
                        "steps_only_ms": round(t_steps / max(args.steps, 1) * 1e3, 3),
-                       "async_encode": bool(os.environ.get("AGC_AMD_ASYNC_ENCODE")),
                        "close_ms": round((elapsed - t_steps) * 1e3, 1),
                        "segments_per_step": int(per(stats["segments"])), "lz_encoded_per_step": int(per(stats["lz_encoded"])),
                        "missing_middle_per_step": int(per(stats["middle_tried"])), "one_splitter_per_step": int(per(stats["one_splitter"])),
@@ -281,13 +303,16 @@ def main():
                                        f"record (new reference segments + deltas) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each; "
                                        "rank 0 writes and runs libzstd") if single else
                                       f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": kern.get(dominant, {}).get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(kern.get(dominant, {}).get("achieved", 0.0) / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(kern.get(dominant, {}).get("algorithmic_bytes_per_bp", 0) * bases_per_launch),
-                         "avg_launch_ms": kern.get(dominant, {}).get("avg_launch_ms"),
-                         "dominant_by": "largest average launch time among the path's streaming kernels",
-                         "kernels": {k_: dict(v, frac=round(v["achieved"] / HBM_PEAK_GBS, 5)) for k_, v in kern.items()},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dominant), "achieved": dom.get("as_built", {}).get("achieved"),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("as_built", {}).get("frac"),
+                         "frac_packed_2bit": dom.get("packed_2bit", {}).get("frac"),
+                         "traffic": dom.get("traffic"), "waste": dom.get("waste"),
+                         "traffic_source": PMC_SUMMARY + " (2 x FETCH_SIZE + WRITE_SIZE, max over dispatches, per launch)" if dom.get("traffic") else None,
+                         "algorithmic_bytes_per_launch": dom.get("as_built", {}).get("algorithmic_bytes"),
+                         "avg_launch_ms": dom.get("ms_per_step"),
+                         "dominant_by": "largest kernel time per step among ALL kernels of the path (scan, encode, estimate, cost vectors)",
+                         "layout": f"{BYTES_PER_SYMBOL} B per symbol in HBM",
+                         "kernels": kern,
                          "kernel_ms_per_step_rank0": {n: round(v[0] / max(args.steps, 1), 4) for n, v in tm.items() if v[1]}},
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only

@@ -146,14 +146,6 @@ int agc_hip_lz_encode_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_
                                 const uint8_t *d_base, const uint64_t *h_off,
                                 const uint32_t *h_len, const uint8_t *h_rc,
                                 uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
-/* The same in two halves: begin launches the batch on a second stream with its own buffers and returns; end waits and
- * delivers the deltas (AGC_HIP_ECAP: call end again with h_enc_off[n] bytes).  In between, the other entry points of the
- * context run concurrently on the first stream -- except reference registration, which must wait for end.  One batch at a
- * time. */
-int agc_hip_lz_encode_begin_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
-                                const uint8_t *d_base, const uint64_t *h_off,
-                                const uint32_t *h_len, const uint8_t *h_rc);
-int agc_hip_lz_encode_end(agc_hip_ctx *ctx, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
 /* Host-resident texts: text s = h_text[h_off[s] .. h_off[s]+h_len[s]). */
 int agc_hip_lz_encode_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
                             const uint8_t *h_text, const uint64_t *h_off,

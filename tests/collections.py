@@ -26,6 +26,15 @@ CONFIGS = {
     # mined from them and used by later samples (BASELINE configs[4] shape, scaled)
     "syn_adaptive": (["-a", "-k", "31", "-l", "20", "-s", "2000", "-b", "5"], "adaptive"),
     "syn_adaptive_c": (["-a", "-c", "-k", "25", "-l", "18", "-s", "1500", "-b", "4"], "adaptive"),
+    # --- twins of the BASELINE.json configs that are otherwise only benchmarked (exact CLI parameters, scaled sizes) ---
+    # configs[2]: 24 contigs proportioned like GRCh38 (30 Mbp, 1/100 size), 10 samples, d = 1e-3, -k 31 -l 15 -b 100
+    "syn_c3_twin": (["-k", "31", "-l", "15", "-b", "100"], "c3"),
+    # configs[3] (HPP-shaped, non-adaptive, default parameters): haplotype assemblies of 300+ contigs each -- pieces of the
+    # reference chromosomes in either orientation, scaffold gaps (N-runs of 1-5 kb), a few indels, unplaced short contigs
+    "syn_c4_twin": ([], "c4"),
+    # configs[4] (bacterial, adaptive): 64 genomes at ~5 % pairwise divergence, accessory contigs (plasmid families) that have
+    # no splitter of the reference genome -> new splitters are mined and reused by later genomes
+    "syn_c5_twin": (["-a", "-s", "1500"], "c5"),
 }
 
 # append plans: name -> (collection, [number of input files of each step]); step 0 is `create` (reference file
@@ -74,7 +83,8 @@ def build(name, outdir):
     os.makedirs(outdir, exist_ok=True)
     if kind == "toy":
         return [os.path.join(TOY, f) for f in ("ref.fa", "a.fa", "b.fa", "c.fa")]
-    rng = np.random.default_rng({"snp": 11, "mixed": 12, "viral": 13, "viral_c": 13, "shuffled": 14, "adaptive": 15}[kind])
+    rng = np.random.default_rng({"snp": 11, "mixed": 12, "viral": 13, "viral_c": 13, "shuffled": 14, "adaptive": 15,
+                                 "c3": 16, "c4": 17, "c5": 18}[kind])
     files = []
 
     def write(fn, contigs, names):
@@ -132,4 +142,54 @@ def build(name, outdir):
             ctg = [synth.mutate(rng, ref[i], 0.004) for i in rc_] + [synth.mutate(rng, novel[i], 0.004, n_runs=1) for i in nv_]
             nm = [f"s{s_}_r{i}" for i in rc_] + [f"s{s_}_n{i}" for i in nv_]
             write(f"a{s_}.fa", ctg, nm)
+    elif kind == "c3":
+        from agc_amd import synth_dev
+        ln = synth_dev.contig_lengths(30_000_000)
+        ref = [synth.random_seq(rng, int(n)) for n in ln]
+        names = [f"chr{i + 1}" for i in range(len(ln))]
+        write("GRCh38_twin.fa", ref, names)
+        for s_ in range(10):
+            write(f"asm{s_:02d}.fa", [synth.mutate(rng, c, 1e-3) for c in ref], names)
+    elif kind == "c4":
+        from agc_amd import synth_dev
+        ln = synth_dev.contig_lengths(20_000_000)
+        ref = [synth.random_seq(rng, int(n)) for n in ln]
+        write("CHM13_twin.fa", ref, [f"chr{i + 1}" for i in range(len(ln))])
+        for s_ in range(6):
+            ctg, nm = [], []
+            for ci, c in enumerate(ref):
+                hap = synth.mutate(rng, c, 1e-3, indels=3)
+                # assembly contigs: the haplotype cut at random breakpoints (about 13 pieces per chromosome)
+                cuts = np.sort(rng.integers(0, hap.size, size=int(rng.integers(10, 16))))
+                b = 0
+                for e in list(cuts) + [hap.size]:
+                    piece = hap[b:int(e)].copy()
+                    b = int(e)
+                    if piece.size == 0:
+                        continue
+                    if rng.random() < 0.5:  # assemblers report either strand
+                        piece = piece[::-1].copy()
+                        m = piece < 4
+                        piece[m] = 3 - piece[m]
+                    if piece.size > 200_000 and rng.random() < 0.3:  # scaffold gap
+                        p = int(rng.integers(10_000, piece.size - 10_000))
+                        piece[p:p + int(rng.integers(1_000, 5_000))] = 4
+                    ctg.append(piece)
+                    nm.append(f"HG{s_:05d}#1#JAHBC{len(ctg):07d}.1")
+            for _ in range(20):  # unplaced short contigs, unrelated to the reference
+                ctg.append(synth.random_seq(rng, int(rng.integers(500, 20_000))))
+                nm.append(f"HG{s_:05d}#1#JAHBD{len(ctg):07d}.1")
+            order = rng.permutation(len(ctg))
+            write(f"HG{s_:05d}.1.fa", [ctg[i] for i in order], [nm[i] for i in order])
+    elif kind == "c5":
+        anc = [synth.random_seq(rng, 120_000)]
+        plasmids = [synth.random_seq(rng, int(rng.integers(2_000, 9_000))) for _ in range(12)]
+        write("K12_twin.fa", [synth.mutate(rng, anc[0], 0.025)], ["NC_000913.3 chromosome"])
+        for s_ in range(63):
+            ctg = [synth.mutate(rng, anc[0], 0.025, indels=2)]
+            nm = [f"NZ_CP{s_:06d}.1 strain {s_} chromosome"]
+            for pi in rng.permutation(12)[: int(rng.integers(0, 3))]:
+                ctg.append(synth.mutate(rng, plasmids[int(pi)], 0.025))
+                nm.append(f"NZ_CP{s_:06d}p{int(pi)}.1 strain {s_} plasmid p{int(pi)}")
+            write(f"GCF_{s_:09d}.fa", ctg, nm)
     return files

@@ -40,11 +40,6 @@ void agco_ref_lag_counts(const u8 *data, size_t n, u32 *cnt28, u32 *cur28);
 
 struct agc_hip_ctx {
     char err[256];
-    /* asynchronous encode: computed at begin, handed over at end */
-    u8 *a_enc;
-    u64 *a_off;
-    u32 a_n;
-    int a_in_flight;
     u8 *sample;
     u64 sample_cap;
     u64 *spl; /* sorted */
@@ -103,8 +98,6 @@ void agc_hip_destroy(agc_hip_ctx *c)
     for (u32 i = 0; i < c->n_lz; ++i)
         agco_lz_free(c->lz[i]);
     free(c->lz);
-    free(c->a_enc);
-    free(c->a_off);
     free(c->spl);
     free(c->sample);
     free(c);
@@ -297,38 +290,6 @@ int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid,
         free(t);
     }
     return over ? fail(c, AGC_HIP_ECAP, "encode buffer") : AGC_HIP_OK;
-}
-
-int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,
-                                const uint32_t *len, const uint8_t *rc)
-{
-    if (!c || c->a_in_flight)
-        return AGC_HIP_EINVAL;
-    u64 tot = 0;
-    for (u32 i = 0; i < n; ++i)
-        tot += (u64)len[i] * 2 + 128;
-    free(c->a_enc);
-    free(c->a_off);
-    c->a_enc = (u8 *)malloc(tot + 64);
-    c->a_off = (u64 *)calloc((size_t)n + 1, sizeof(u64));
-    c->a_n = n;
-    const int r = agc_hip_lz_encode_batch_dev(c, n, gid, d, off, len, rc, c->a_enc, tot + 64, c->a_off);
-    if (r == AGC_HIP_OK)
-        c->a_in_flight = 1;
-    return r;
-}
-
-int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
-{
-    if (!c || !c->a_in_flight || !h_enc_off)
-        return AGC_HIP_EINVAL;
-    memcpy(h_enc_off, c->a_off, ((size_t)c->a_n + 1) * sizeof(u64));
-    if (c->a_off[c->a_n] > cap)
-        return fail(c, AGC_HIP_ECAP, "encode buffer");
-    if (c->a_off[c->a_n])
-        memcpy(h_enc, c->a_enc, c->a_off[c->a_n]);
-    c->a_in_flight = 0;
-    return AGC_HIP_OK;
 }
 
 int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,

@@ -168,3 +168,106 @@ def test_dist_create_front_end_on_the_gpu(tmp_path):
     assert os.path.exists(out), r.stderr[-3000:]
     got = open(out, "rb").read()
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"], r.stderr[-2000:]
+
+
+# ---- edge cases of the prepare / commit split ------------------------------------------------------------
+def _edge_samples():
+    """splitters chosen by hand (SetSplitters): three inside a genome G, one in the middle of an unrelated sequence Z.
+    sample 1 mints only ONE-SIDED groups -- (kZ, none) and (none, kZ): its contig Z holds a single splitter that has no
+    terminator yet -- while sample 2, prepared on the other rank before sample 1 is committed, carries a mutated Z whose
+    segments must join exactly those groups.  Sample 3 has no contigs at all."""
+    from agc_amd import synth
+    from oracle import agc_oracle as O
+    rng = np.random.default_rng(99)
+    k = 21
+    G = synth.random_seq(rng, 12_000)
+    Z = synth.random_seq(rng, 5_000)
+
+    def can(seq, end):  # canonical k-mer ending at `end`, left-aligned as CKmer keeps it
+        s = seq[end - k + 1:end + 1].astype(np.uint64)
+        d = np.uint64(0)
+        r = np.uint64(0)
+        for j in range(k):
+            d = (d << np.uint64(2)) | s[j]
+            r = (r << np.uint64(2)) | (np.uint64(3) - s[k - 1 - j])
+        sh = np.uint64(64 - 2 * k)
+        return min(int(d << sh), int(r << sh))
+
+    spl = np.array(sorted({can(G, 3000), can(G, 6000), can(G, 9000), can(Z, 2500)}), np.uint64)
+    samples = [
+        ("s0", ["g"], [G]),
+        ("s1", ["g", "z"], [synth.mutate(rng, G, 0.003), Z]),
+        ("s2", ["g", "z"], [synth.mutate(rng, G, 0.003), synth.mutate(rng, Z, 0.003)]),
+        ("s3", [], []),
+        ("s4", ["z", "g"], [synth.mutate(rng, Z, 0.003), synth.mutate(rng, G, 0.003)]),
+    ]
+    return k, spl, samples
+
+
+def _edge_worker(rank, world, port, out_path, q, prefetch):
+    try:
+        from agc_amd import host
+        from tests.devsim import build as simbuild
+        lib = host.bind(C.CDLL(simbuild.SIM_HOST))
+        k, spl, samples = _edge_samples()
+        cmp_ = host.Compressor(lib=lib)
+        if world > 1:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            cmp_.set_distributed(rank, world, 0)
+        cmp_.create(out_path if rank == 0 else "", pack_cardinality=3, k=k, ref_file=None, segment_size=1000, min_match_len=18, n_threads=2)
+        cmp_.set_splitters(spl)
+        keep = {}
+
+        def get_sample(i):
+            name, names, ctgs = samples[i]
+            off = np.zeros(len(ctgs) + 1, np.uint64)
+            off[1:] = np.cumsum([c.size for c in ctgs])
+            keep[i] = np.concatenate(ctgs + [np.full(64, 4, np.uint8)])
+            return name, names, keep[i].ctypes.data, off
+
+        if world > 1:
+            from agc_amd.dist import DistCompressor
+            dc = DistCompressor(cmp_, dist, rank, world, device=None)
+            dc.compress(len(samples), get_sample, prefetch=prefetch)
+        else:
+            for i in range(len(samples)):
+                cmp_.add_sample_dev(*get_sample(i))
+        cmp_.close()
+        st = cmp_.stats()
+        cmp_.close_handle()
+        q.put((rank, "ok", st["new_groups"]))
+        if world > 1:
+            dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "error: %r" % (e,), 0))
+
+
+def _edge_run(world, tmp_path, prefetch, tag):
+    out = str(tmp_path / f"edge_{tag}.agc")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_edge_worker, args=(r, world, port, out, q, prefetch)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=300) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert all(r[1] == "ok" for r in res), res
+    assert len({r[2] for r in res}) == 1, res  # every rank minted the same number of groups
+    return open(out, "rb").read(), res[0][2]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_sided_groups_minted_between_prepare_and_commit_and_an_empty_sample(world, tmp_path):
+    """a group keyed (k-mer, none) minted by a sample committed between another rank's PrepareSampleDevice and CommitPrepared
+    must be joined, not minted twice; a sample without contigs must not derail the record stream"""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    want, n_groups = _edge_run(1, tmp_path, False, "single")
+    got, n2 = _edge_run(world, tmp_path, True, f"w{world}")
+    assert n2 == n_groups
+    assert got == want

@@ -20,7 +20,8 @@ GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "archives.json")))
 
 @pytest.mark.parametrize("name", list(C.CONFIGS))
 def test_archive_bit_identical(name, tmp_path):
-    from agc_amd import agc_container, build
+    from agc_amd import build
+    from tests import agc_container
     build.build_host()
     args, _ = C.CONFIGS[name]
     files = C.build(name, str(tmp_path / "in"))
@@ -71,7 +72,8 @@ def test_survey_scale_collection_vs_reference(tmp_path):
     if not os.path.exists(REF_AGC):
         pytest.skip("oracle/_ref/agc not prebuilt")
     import numpy as np
-    from agc_amd import agc_container, build, synth
+    from agc_amd import build, synth
+    from tests import agc_container
     build.build_host()
     rng = np.random.default_rng(12345)
     ref = [synth.random_seq(rng, 5_000_000) for _ in range(4)]
@@ -136,7 +138,8 @@ def test_baseline_config1_full_size(tmp_path, concat):
     if not os.path.exists(REF_AGC):
         pytest.skip("oracle/_ref/agc not prebuilt")
     import numpy as np
-    from agc_amd import agc_container, build, synth
+    from agc_amd import build, synth
+    from tests import agc_container
     build.build_host()
     rng = np.random.default_rng(2)
     ref = synth.random_seq(rng, 30_000)

@@ -133,16 +133,68 @@ def test_lag_counts(hip_ctx, oracle):
             assert np.array_equal(cnt[i], wc) and np.array_equal(cur[i], wu)
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("AGC_TEST_ASYNC"),
-                    reason="asynchronous encode (second stream) is opt-in until it has been measured on the GPU: set AGC_TEST_ASYNC=1")
-def test_async_encode_equals_sync(hip_ctx, oracle, registered):
-    """agc_hip_lz_encode_begin_dev / _end deliver the bytes of agc_hip_lz_encode_batch_dev, with estimates running in between"""
+def _split_point_oracle(oracle, ref1, ref2, mml, seg, rc1, pf1, rc2, pf2):
+    """find_cand_segment_with_missing_middle_splitter, src/core/agc_compressor.cpp:1540-1625 (before the k+1 clamps):
+    v1 = prefix sums of the first cost vector (reversed first when it was taken with prefix_costs = false),
+    v2 = suffix sums of the second one (taken on the reversed vector when prefix_costs = true); first arg-min of v1 + v2,
+    all in u32 as std::partial_sum on vector<uint32_t>."""
+    t1 = oracle.rev_comp(seg) if rc1 else seg
+    t2 = oracle.rev_comp(seg) if rc2 else seg
+    c1 = oracle.LZ(ref1, mml).cost_vector(t1, int(pf1)).astype(np.uint32)
+    c2 = oracle.LZ(ref2, mml).cost_vector(t2, int(pf2)).astype(np.uint32)
+    if not pf1:
+        c1 = c1[::-1]
+    v1 = np.cumsum(c1, dtype=np.uint32)
+    if pf2:
+        v2 = np.cumsum(c2, dtype=np.uint32)[::-1]
+    else:
+        v2 = np.cumsum(c2[::-1], dtype=np.uint32)[::-1]
+    s = (v1 + v2).astype(np.uint32)
+    p = int(np.argmin(s))  # first minimum
+    return p, int(s[p])
+
+
+def test_split_point_matches_oracle(hip_ctx, oracle):
+    """agc_hip_lz_split_point_batch_dev against the oracle's two cost vectors + the reference's sums / arg-min, for every
+    orientation combination; segments = left part of one reference + right part of another (the destroyed-middle-splitter
+    shape), plus unrelated and tiny segments."""
     import torch
-    buf, off, ln = _concat(registered)
-    gids = 1000 + np.arange(len(registered))
+    from agc_amd import synth
+    rng = np.random.default_rng(4242)
+    mml = 18
+    k = 21
+    gid0 = 5000
+    refs, segs, jobs = [], [], []
+    for case in range(12):
+        n1, n2 = int(rng.integers(300, 6000)), int(rng.integers(300, 6000))
+        a, b = synth.random_seq(rng, n1), synth.random_seq(rng, n2)
+        b[:k] = a[-k:]  # the two references overlap by the middle splitter
+        if case == 9:
+            seg = synth.random_seq(rng, 500)  # nothing matches: all literals, arg-min at the first position
+        elif case == 10:
+            seg = a[:30].copy()
+        else:
+            seg = np.concatenate([a, b[k:]])
+            seg = synth.mutate(rng, seg, 0.01, n_runs=1 if case % 3 == 0 else 0, indels=case % 2)
+        refs += [a, b]
+        segs.append(seg)
+    for i, r in enumerate(refs):
+        hip_ctx.ref_register(gid0 + i, r, mml)
+    off = np.zeros(len(segs), np.uint64)
+    ln = np.array([s.size for s in segs], np.uint32)
+    off[1:] = np.cumsum(ln[:-1].astype(np.uint64) + 5)
+    buf = np.full(int(off[-1] + ln[-1]) + 64, 4, np.uint8)
+    for o, s in zip(off, segs):
+        buf[int(o):int(o) + s.size] = s
     d = torch.from_numpy(buf).cuda()
-    want, woff = hip_ctx.lz_encode_batch_dev(d.data_ptr(), gids, off, ln)
-    hip_ctx.lz_encode_begin_dev(d.data_ptr(), gids, off, ln)
-    hip_ctx.lz_estimate_batch_dev(d.data_ptr(), gids, off, ln)  # first stream, first buffer set, concurrently
-    got, goff = hip_ctx.lz_encode_end()
-    assert np.array_equal(woff, goff) and np.array_equal(want, got)
+    g1, g2, oo, ll, r1, p1, r2, p2, want = [], [], [], [], [], [], [], [], []
+    for i, seg in enumerate(segs):
+        for combo in range(16):
+            rc1, pf1, rc2, pf2 = combo & 1, (combo >> 1) & 1, (combo >> 2) & 1, (combo >> 3) & 1
+            # the reference only uses (rc1 == !pf1) xor use_rc combinations, but the ABI takes any
+            g1.append(gid0 + 2 * i), g2.append(gid0 + 2 * i + 1), oo.append(off[i]), ll.append(ln[i])
+            r1.append(rc1), p1.append(pf1), r2.append(rc2), p2.append(pf2)
+            want.append(_split_point_oracle(oracle, refs[2 * i], refs[2 * i + 1], mml, seg, rc1, pf1, rc2, pf2))
+    pos, sm = hip_ctx.lz_split_point_batch_dev(d.data_ptr(), g1, g2, oo, ll, r1, p1, r2, p2)
+    for j, (wp, ws) in enumerate(want):
+        assert (int(pos[j]), int(sm[j])) == (wp, ws), f"job {j} (segment {j // 16}, combo {j % 16}): got {(int(pos[j]), int(sm[j]))} want {(wp, ws)}"

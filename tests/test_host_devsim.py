@@ -82,17 +82,6 @@ def test_append_to_missing_archive_reports_and_exits_zero(cli, tmp_path):
     assert r.returncode == 0 and "Cannot open archive" in r.stderr
 
 
-@pytest.mark.parametrize("name", ["syn_snp", "syn_mixed", "syn_viral_c", "syn_adaptive"])
-def test_host_pipeline_with_asynchronous_encode(cli, name, tmp_path, monkeypatch):
-    """AGC_AMD_ASYNC_ENCODE=1: known-group segments are encoded through agc_hip_lz_encode_begin_dev / _end around the
-    estimate and split-point calls; the archive must not change"""
-    monkeypatch.setenv("AGC_AMD_ASYNC_ENCODE", "1")
-    args, _ = C.CONFIGS[name]
-    files = C.build(name, str(tmp_path / "in"))
-    got = _create(cli, args, files, str(tmp_path / "o.agc"))
-    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
-
-
 def test_host_pipeline_is_thread_independent(cli, tmp_path):
     args, _ = C.CONFIGS["syn_adaptive"]
     files = C.build("syn_adaptive", str(tmp_path / "in"))

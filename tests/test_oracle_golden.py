@@ -100,7 +100,7 @@ def test_container_reader_on_reference_archive():
     BASELINE configs[0] (toy_ex, -k 25 -l 17): stream order and part framing of SURVEY App. A.8 / B.2"""
     import hashlib
     import json
-    from agc_amd import agc_container
+    from tests import agc_container
     data = open(os.path.join(G, "toy_c1_reference.agc"), "rb").read()
     gold = json.load(open(os.path.join(G, "archives.json")))["toy_c1"]
     assert hashlib.sha256(data).hexdigest() == gold["sha256"] == "81502256be60722f89f07622e55a222bce43f558f8a0d760d73313acdb977d62"
