@@ -494,8 +494,10 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     uint32_t max_gid = 0;
     for (uint32_t i = 0; i < n_refs; ++i) {
         max_gid = std::max(max_gid, h_gid[i]);
-        if (h_gid[i] < c->refs.size() && c->refs[h_gid[i]].valid)
+        if (h_gid[i] < c->refs.size() && c->refs[h_gid[i]].valid) {
+            c->err = "group " + std::to_string(h_gid[i]) + " already has a reference";
             return AGC_HIP_EINVAL;
+        }
     }
     {
         std::vector<uint32_t> g(h_gid, h_gid + n_refs);

@@ -32,7 +32,7 @@ struct ZstdD {
         for (const char *c : cands) {
             if (!c)
                 continue;
-            h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+            h = dlopen(c, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
             if (h)
                 break;
         }

@@ -49,7 +49,9 @@ struct ZstdApi {
         cands.push_back("libzstd.so.1");
         cands.push_back("libzstd.so");
         for (auto &p : cands) {
-            h = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
+            // DEEPBIND: this libzstd's calls to its own (exported) internals must not be interposed by another libzstd
+            // already in the process (rocprofv3's tool library brings the system's 1.4.8: mixed versions crashed in free())
+            h = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
             if (h) {
                 path = p;
                 break;

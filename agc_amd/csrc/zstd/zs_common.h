@@ -1,0 +1,107 @@
+// zs_common.h -- shared definitions of the level-17 zstd frame encoder (S3, SURVEY 8b: ZSTD_compressCCtx at
+// src/common/segment.h:176,201) written for gfx950: one frame per lane, every table in a per-frame workspace in HBM.
+//
+// The code under agc_amd/csrc/zstd/ restates what libzstd 1.4.9 does for ZSTD_compressCCtx(level 17) on inputs of at most
+// one block (<= 128 KiB): zstd's format is public (RFC 8878) but the BYTES depend on the encoder's match finder, price
+// model and table heuristics, so those are followed decision by decision (zstd v1.4.9: lib/compress/zstd_opt.c,
+// zstd_compress.c, zstd_compress_sequences.c, zstd_compress_literals.c, huf_compress.c, fse_compress.c, hist.c).  The
+// reference tree has no copy of zstd (empty submodule): parity is pinned against the image's libzstd 1.4.9 itself --
+// tests/test_zstd_frames.py compares every frame byte for byte, and the parser's sequences with ZSTD_generateSequences.
+//
+// The same headers compile for the host (gcc, tests only: tests/zstd_host) and for the device (hipcc, the product).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#ifdef __HIPCC__
+#define ZFN __device__ static inline
+#define ZCONST __device__ static const
+#else
+#define ZFN static inline
+#define ZCONST static const
+#endif
+
+namespace zs {
+
+typedef uint8_t BYTE;
+typedef uint16_t U16;
+typedef uint32_t U32;
+typedef uint64_t U64;
+
+constexpr U32 OPT_NUM = 1u << 12;      // ZSTD_OPT_NUM
+constexpr U32 REP_NUM = 3;             // ZSTD_REP_NUM
+constexpr U32 REP_MOVE = 2;            // ZSTD_REP_MOVE
+constexpr U32 MINMATCH = 3;
+constexpr U32 MaxLit = 255, MaxLL = 35, MaxML = 52, MaxOff = 31;
+constexpr U32 BLOCKSIZE_MAX = 1u << 17;
+constexpr U32 HASHLOG3_MAX = 17;
+
+enum { STRAT_BTOPT = 7, STRAT_BTULTRA = 8, STRAT_BTULTRA2 = 9 };
+
+struct CParams {
+    U32 windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy;
+};
+
+struct Match {
+    U32 off, len;
+};
+
+struct Optimal { // ZSTD_optimal_t
+    int price;
+    U32 off, mlen, litlen;
+    U32 rep[3];
+};
+
+struct Seq { // one stored sequence (full lengths; offCode = repcode 0..2 or distance + 2)
+    U32 offCode, litLength, matchLength;
+};
+
+ZFN U32 highbit32(U32 v) { return 31u - (U32)__builtin_clz(v); }
+
+ZFN U32 read32(const BYTE *p)
+{
+    U32 v;
+    memcpy(&v, p, 4);
+    return v;
+}
+ZFN U64 read64(const BYTE *p)
+{
+    U64 v;
+    memcpy(&v, p, 8);
+    return v;
+}
+
+// ZSTD_count: common length of ip / match, ip bounded by iend
+ZFN U32 count(const BYTE *ip, const BYTE *match, const BYTE *iend)
+{
+    const BYTE *const start = ip;
+    while (ip + 8 <= iend) {
+        const U64 d = read64(ip) ^ read64(match);
+        if (d)
+            return (U32)(ip - start) + ((U32)__builtin_ctzll(d) >> 3);
+        ip += 8;
+        match += 8;
+    }
+    while (ip < iend && *ip == *match) {
+        ++ip;
+        ++match;
+    }
+    return (U32)(ip - start);
+}
+
+ZCONST U32 LL_bits[MaxLL + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+ZCONST U32 ML_bits[MaxML + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+ZCONST BYTE LL_Code[64] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 18,
+                           19, 19, 20, 20, 20, 20, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23,
+                           23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
+ZCONST BYTE ML_Code[128] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25,
+                            26, 27, 28, 29, 30, 31, 32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38, 38, 38,
+                            38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40,
+                            40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 42, 42, 42, 42, 42, 42, 42, 42,
+                            42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
+
+ZFN U32 LLcode(U32 litLength) { return litLength > 63 ? highbit32(litLength) + 19 : LL_Code[litLength]; }
+ZFN U32 MLcode(U32 mlBase) { return mlBase > 127 ? highbit32(mlBase) + 36 : ML_Code[mlBase]; }
+
+} // namespace zs

@@ -163,8 +163,8 @@ def test_split_point_matches_oracle(hip_ctx, oracle):
     rng = np.random.default_rng(4242)
     mml = 18
     k = 21
-    gid0 = 5000
-    refs, segs, jobs = [], [], []
+    gid0 = 7000
+    refs, segs = [], []
     for case in range(12):
         n1, n2 = int(rng.integers(300, 6000)), int(rng.integers(300, 6000))
         a, b = synth.random_seq(rng, n1), synth.random_seq(rng, n2)

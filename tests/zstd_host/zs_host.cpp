@@ -1,0 +1,47 @@
+// zs_host.cpp -- TEST INFRASTRUCTURE: the zstd level-17 encoder headers of agc_amd/csrc/zstd/ compiled for the HOST, so that
+// the -m "not gpu" tests can compare them with the image's libzstd 1.4.9 (sequences: ZSTD_generateSequences, frames:
+// ZSTD_compressCCtx) without a GPU.  The product compiles the same headers with hipcc into libagc_hip.so and never loads this.
+#include "../../agc_amd/csrc/zstd/zs_opt.h"
+#include <stdlib.h>
+#include <vector>
+
+using namespace zs;
+
+extern "C" {
+
+// parser only: sequences as (offCode, litLength, matchLength) triples; returns the number of sequences, *last_lits = trailing literals
+int zs_host_parse(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint32_t *out_seq3, uint32_t cap, uint32_t *last_lits)
+{
+    OptWs w;
+    memset(&w, 0, sizeof(w));
+    w.cp = {cparams7[0], cparams7[1], cparams7[2], cparams7[3], cparams7[4], cparams7[5], cparams7[6]};
+    const U32 hl3 = w.cp.minMatch == 3 ? (HASHLOG3_MAX < w.cp.windowLog ? HASHLOG3_MAX : w.cp.windowLog) : 0;
+    std::vector<U32> ht((size_t)1 << w.cp.hashLog, 0), ht3((size_t)1 << hl3, 0), ct((size_t)1 << w.cp.chainLog, 0);
+    std::vector<Optimal> opt(OPT_NUM + 2);
+    std::vector<Match> mt(OPT_NUM + 2);
+    std::vector<U32> freq(256 + 36 + 53 + 32, 0);
+    std::vector<Seq> seqs(n / 3 + 16);
+    std::vector<BYTE> lits(n + 16);
+    w.hashTable = ht.data();
+    w.hashTable3 = ht3.data();
+    w.chainTable = ct.data();
+    w.opt = opt.data();
+    w.matches = mt.data();
+    w.litFreq = freq.data();
+    w.litLengthFreq = w.litFreq + 256;
+    w.matchLengthFreq = w.litLengthFreq + 36;
+    w.offCodeFreq = w.matchLengthFreq + 53;
+    w.seqs = seqs.data();
+    w.lits = lits.data();
+    U32 rep[3] = {1, 4, 8};
+    U32 ll = 0;
+    compressBlockBt(w, rep, src, n, &ll);
+    *last_lits = ll;
+    for (U32 i = 0; i < w.nSeq && i < cap; ++i) {
+        out_seq3[3 * i] = w.seqs[i].offCode;
+        out_seq3[3 * i + 1] = w.seqs[i].litLength;
+        out_seq3[3 * i + 2] = w.seqs[i].matchLength;
+    }
+    return (int)w.nSeq;
+}
+}
