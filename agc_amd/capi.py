@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libagc_hip.so")
 
 OK, ENODEV, EINVAL, ENOMEM, ECAP, ENOREF = 0, -1, -2, -3, -4, -5
 K_SCAN, K_INDEX, K_ENCODE, K_ESTIMATE, K_COSTVEC, K_REVCOMP, K_PREPROCESS, K_REFSTORE = range(8)
-K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore"]
+K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd"]
 
 # every symbol include/agc_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -31,6 +31,7 @@ SYMBOLS = [
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
     "agc_hip_ref_lag_counts_dev",
+    "agc_hip_zstd17_max_input", "agc_hip_zstd17_batch", "agc_hip_zstd17_cparams",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -98,9 +99,12 @@ def load():
     L.agc_hip_lz_split_point_batch_dev.argtypes = [vp, C.c_uint32, u32p, u32p, vp, u64p, u32p, u8p, u8p, u8p, u8p, u32p, u32p]
     L.agc_hip_fetch_slices_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_ref_lag_counts_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u32p, u32p]
+    L.agc_hip_zstd17_batch.argtypes = [vp, C.c_uint32, u8p, u64p, u8p, C.c_uint64, u64p]
+    L.agc_hip_zstd17_cparams.argtypes = [C.c_uint64, u32p]
+    L.agc_hip_zstd17_max_input.restype = C.c_uint32
     for s in SYMBOLS:
         f = getattr(L, s)
-        if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count"):
+        if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count", "agc_hip_zstd17_max_input"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -303,6 +307,18 @@ class Context:
         self._chk(self.L.agc_hip_lz_split_point_batch_dev(self.h, g1.size, _p(g1, u32p), _p(g2, u32p), d_base, _p(o, u64p), _p(l, u32p),
                                                           _p(r1, u8p), _p(p1, u8p), _p(r2, u8p), _p(p2, u8p), _p(pos, u32p), _p(sm, u32p)))
         return pos, sm
+
+    def zstd17_batch(self, inputs):
+        """inputs: list of bytes-like; returns the list of level-17 zstd frames (S3 on the GPU)"""
+        n = len(inputs)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in inputs])
+        src = np.frombuffer(b"".join(bytes(x) for x in inputs), np.uint8) if off[-1] else np.zeros(1, np.uint8)
+        cap = int(off[-1]) + 32 * n + 64
+        dst = np.zeros(cap, np.uint8)
+        doff = np.zeros(n + 1, np.uint64)
+        self._chk(self.L.agc_hip_zstd17_batch(self.h, n, _p(src, u8p), _p(off, u64p), _p(dst, u8p), cap, _p(doff, u64p)))
+        return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)]
 
     def fetch_slices_dev(self, d_base, off, length, rc=None):
         o, l = _a(off, np.uint64), _a(length, np.uint32)

@@ -14,6 +14,7 @@
 
 #include "scan_kernels.hip"
 #include "lz_kernels.hip"
+#include "zstd_kernels.hip"
 
 using namespace agc;
 
@@ -49,7 +50,7 @@ struct agc_hip_ctx {
 
     // scratch
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_stage, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
-        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample;
+        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout;
 
     std::vector<SliceDesc> h_slices;
 
@@ -187,7 +188,8 @@ void agc_hip_destroy(agc_hip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
-                      &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample};
+                      &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
+                      &c->d_zjobs, &c->d_zsize, &c->d_zout};
     for (DevBuf *b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -1004,6 +1006,160 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_cur, d_cur, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// S3: zstd level-17 frames
+// ---------------------------------------------------------------------------
+uint32_t agc_hip_zstd17_max_input(void) { return zs::BLOCKSIZE_MAX; }
+
+// ZSTD_getCParams(17, srcSize, 0) of libzstd 1.4.9: the level-17 rows of ZSTD_defaultCParameters (one per source-size
+// class) followed by ZSTD_adjustCParams_internal (zstd_compress.c)
+int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
+{
+    if (!out7)
+        return AGC_HIP_EINVAL;
+    //                     W   C   H   S  mml  TL  strategy
+    uint32_t p[7];
+    const uint64_t rSize = src_size ? src_size : ~0ULL; // 0 = unknown in the library; a known empty input has its own path
+    if (src_size == 0) {
+        const uint32_t r[7] = {14, 15, 15, 6, 3, 128, zs::STRAT_BTULTRA2};
+        memcpy(p, r, sizeof(p));
+    } else if (rSize <= 16 * 1024) {
+        const uint32_t r[7] = {14, 15, 15, 6, 3, 128, zs::STRAT_BTULTRA2};
+        memcpy(p, r, sizeof(p));
+    } else if (rSize <= 128 * 1024) {
+        const uint32_t r[7] = {17, 18, 17, 8, 3, 256, zs::STRAT_BTULTRA};
+        memcpy(p, r, sizeof(p));
+    } else if (rSize <= 256 * 1024) {
+        const uint32_t r[7] = {18, 19, 19, 8, 3, 256, zs::STRAT_BTULTRA};
+        memcpy(p, r, sizeof(p));
+    } else {
+        const uint32_t r[7] = {23, 23, 22, 5, 4, 64, zs::STRAT_BTOPT};
+        memcpy(p, r, sizeof(p));
+    }
+    if (src_size < (1ULL << 30)) { // resize windowLog if the input is small enough
+        const uint32_t tSize = (uint32_t)src_size;
+        const uint32_t srcLog = (tSize < (1u << 6)) ? 6 : zs::highbit32(tSize - 1) + 1;
+        if (p[0] > srcLog)
+            p[0] = srcLog;
+    }
+    {
+        const uint32_t cycleLog = p[1] - 1; // bt strategies
+        if (p[2] > p[0] + 1)
+            p[2] = p[0] + 1;
+        if (cycleLog > p[0])
+            p[1] -= cycleLog - p[0];
+    }
+    if (p[0] < 10)
+        p[0] = 10; // ZSTD_WINDOWLOG_ABSOLUTEMIN
+    memcpy(out7, p, sizeof(p));
+    return AGC_HIP_OK;
+}
+
+int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
+                         uint64_t *h_dst_off)
+{
+    if (!c || !h_dst_off || (n && (!h_src_off)))
+        return AGC_HIP_EINVAL;
+    h_dst_off[0] = 0;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t src_total = h_src_off[n] - h_src_off[0];
+    if (src_total && !h_src)
+        return AGC_HIP_EINVAL;
+    // per frame: parameters, workspace size; longest first so that the lanes of a wave finish together
+    std::vector<ZFrameJob> jobs(n);
+    std::vector<uint64_t> ws_need(n), dst_o(n);
+    uint64_t dst_total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t len = h_src_off[i + 1] - h_src_off[i];
+        if (h_src_off[i + 1] < h_src_off[i] || len > zs::BLOCKSIZE_MAX) {
+            c->err = "zstd17_batch: input " + std::to_string(i) + " is larger than one block";
+            return AGC_HIP_EINVAL;
+        }
+        uint32_t p[7];
+        agc_hip_zstd17_cparams(len, p);
+        const zs::CParams cp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6]};
+        ws_need[i] = zs::wsLayout(cp, (uint32_t)len).total;
+        dst_o[i] = dst_total;
+        dst_total += (zs::frameBound((uint32_t)len) + 15) & ~15u;
+        jobs[i].src = nullptr;
+        jobs[i].dst = nullptr;
+        jobs[i].ws = nullptr;
+        jobs[i].src_size = (uint32_t)len;
+        jobs[i].idx = i;
+        jobs[i].cp = cp;
+        jobs[i].pad = 0;
+    }
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].src_size > jobs[b].src_size; });
+
+    CHK(ensure(c, c->d_zsrc, src_total + 64));
+    CHK(ensure(c, c->d_zdst, dst_total + 64));
+    CHK(ensure(c, c->d_zsize, (size_t)n * 4));
+    CHK(ensure(c, c->d_zjobs, (size_t)n * sizeof(ZFrameJob)));
+    if (src_total)
+        HIPCHK(c, hipMemcpyAsync(c->d_zsrc.p, h_src + h_src_off[0], src_total, hipMemcpyHostToDevice, c->stream));
+    // workspace arena: as many frames per launch as the budget allows (a frame's tables must be zero at its start)
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = std::min<uint64_t>(48ull << 30, (uint64_t)((free_b + c->d_zws.cap) * 0.6));
+    if (const char *e = getenv("AGC_HIP_ZSTD_ARENA_MB"))
+        budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
+    budget = std::max<uint64_t>(budget, ws_need[order[0]]);
+    std::vector<ZFrameJob> sorted(n);
+    for (uint32_t done = 0; done < n;) {
+        uint64_t used = 0;
+        uint32_t m = 0;
+        while (done + m < n && used + ws_need[order[done + m]] <= budget) {
+            used += ws_need[order[done + m]];
+            ++m;
+        }
+        CHK(ensure(c, c->d_zws, used));
+        used = 0;
+        for (uint32_t t = 0; t < m; ++t) {
+            const uint32_t i = order[done + t];
+            ZFrameJob jb = jobs[i];
+            jb.src = (const uint8_t *)c->d_zsrc.p + (h_src_off[i] - h_src_off[0]);
+            jb.dst = (uint8_t *)c->d_zdst.p + dst_o[i];
+            jb.ws = (uint8_t *)c->d_zws.p + used;
+            used += ws_need[i];
+            sorted[done + t] = jb;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_zws.p, 0, used, c->stream));
+        HIPCHK(c, hipMemcpyAsync((ZFrameJob *)c->d_zjobs.p + done, sorted.data() + done, (size_t)m * sizeof(ZFrameJob), hipMemcpyHostToDevice,
+                                 c->stream));
+        {
+            KTimer t(c, AGC_HIP_K_ZSTD);
+            hipLaunchKernelGGL(zstd_frames_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p + done, m,
+                               (uint32_t *)c->d_zsize.p);
+        }
+        HIPCHK(c, hipGetLastError());
+        done += m;
+    }
+    std::vector<uint32_t> sizes(n);
+    HIPCHK(c, hipMemcpyAsync(sizes.data(), c->d_zsize.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i)
+        h_dst_off[i + 1] = h_dst_off[i] + sizes[i];
+    const uint64_t tot = h_dst_off[n];
+    if (tot > dst_cap)
+        return AGC_HIP_ECAP;
+    if (!h_dst)
+        return AGC_HIP_EINVAL;
+    // compact the frames and bring them back in one copy
+    CHK(ensure(c, c->d_zout, tot + 64));
+    CHK(ensure(c, c->d_dstoff, (size_t)(n + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(c->d_dstoff.p, h_dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(zstd_gather_kernel, dim3(grid_for(n, 1, 16384)), dim3(256), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p, n,
+                       (const uint64_t *)c->d_dstoff.p, (uint8_t *)c->d_zout.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_dst, c->d_zout.p, tot, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AGC_HIP_OK;
 }

@@ -15,9 +15,11 @@
 
 #ifdef __HIPCC__
 #define ZFN __device__ static inline
+#define ZHD __host__ __device__ static inline   // also needed by the host side of the C ABI (sizes, parameters)
 #define ZCONST __device__ static const
 #else
 #define ZFN static inline
+#define ZHD static inline
 #define ZCONST static const
 #endif
 
@@ -56,7 +58,7 @@ struct Seq { // one stored sequence (full lengths; offCode = repcode 0..2 or dis
     U32 offCode, litLength, matchLength;
 };
 
-ZFN U32 highbit32(U32 v) { return 31u - (U32)__builtin_clz(v); }
+ZHD U32 highbit32(U32 v) { return 31u - (U32)__builtin_clz(v); }
 
 ZFN U32 read32(const BYTE *p)
 {

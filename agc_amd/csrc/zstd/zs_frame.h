@@ -1,0 +1,136 @@
+// zs_frame.h -- one zstd frame as ZSTD_compressCCtx(level) of libzstd 1.4.9 writes it for an input of at most one block
+// (<= 128 KiB) with the bt* strategies: frame header (zstd_compress.c: ZSTD_writeFrameHeader), the block
+// (ZSTD_compressBlock_internal) and its header (ZSTD_compress_frameChunk).  Everything works inside a caller-provided
+// workspace; nothing is allocated.
+#pragma once
+#include "zs_opt.h"
+#include "zs_entropy.h"
+
+namespace zs {
+
+// bytes of workspace one frame needs (all tables of OptWs + EntWs + the sequence store), 16-byte aligned pieces
+ZHD size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+struct WsLayout {
+    size_t hashTable, hashTable3, chainTable, opt, matches, freqs, seqs, lits, codes, ent, total;
+};
+
+ZHD WsLayout wsLayout(const CParams &cp, U32 srcSize)
+{
+    WsLayout L;
+    const U32 hl3 = cp.minMatch == 3 ? (HASHLOG3_MAX < cp.windowLog ? HASHLOG3_MAX : cp.windowLog) : 0;
+    size_t o = 0;
+    L.hashTable = o;
+    o += align16(((size_t)4) << cp.hashLog);
+    L.hashTable3 = o;
+    o += align16(((size_t)4) << hl3);
+    L.chainTable = o;
+    o += align16(((size_t)4) << cp.chainLog);
+    L.opt = o;
+    o += align16(sizeof(Optimal) * (OPT_NUM + 2));
+    L.matches = o;
+    o += align16(sizeof(Match) * (OPT_NUM + 2));
+    L.freqs = o;
+    o += align16(4 * (256 + 36 + 53 + 32));
+    L.seqs = o;
+    o += align16(sizeof(Seq) * ((size_t)srcSize / 3 + 16));
+    L.lits = o;
+    o += align16((size_t)srcSize + 32);
+    L.codes = o;
+    o += align16(3 * ((size_t)srcSize / 3 + 16));
+    L.ent = o;
+    o += align16(sizeof(EntWs));
+    L.total = o;
+    return L;
+}
+
+// upper bound of a frame: header (<= 9) + block header (3) + raw block
+ZHD U32 frameBound(U32 srcSize) { return srcSize + 16; }
+
+// the level's frame for src[0..srcSize), 7 <= ... any srcSize <= BLOCKSIZE_MAX, written to dst (frameBound bytes).
+// ws: wsLayout(cp, srcSize).total bytes, hashTable / hashTable3 / chainTable regions ZEROED by the caller.
+ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst)
+{
+    BYTE *op = dst;
+    // ---- frame header: magic, descriptor, [window], content size (contentSizeFlag = 1, no checksum, no dictID) ----
+    {
+        const U32 windowSize = 1u << cp.windowLog;
+        const U32 singleSegment = windowSize >= srcSize;
+        const U32 fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
+        op[0] = 0x28;
+        op[1] = 0xB5;
+        op[2] = 0x2F;
+        op[3] = 0xFD;
+        op[4] = (BYTE)((singleSegment << 5) + (fcsCode << 6));
+        op += 5;
+        if (!singleSegment)
+            *op++ = (BYTE)((cp.windowLog - 10) << 3);
+        switch (fcsCode) {
+        case 0:
+            if (singleSegment)
+                *op++ = (BYTE)srcSize;
+            break;
+        case 1:
+            op[0] = (BYTE)(srcSize - 256);
+            op[1] = (BYTE)((srcSize - 256) >> 8);
+            op += 2;
+            break;
+        default:
+            op[0] = (BYTE)srcSize;
+            op[1] = (BYTE)(srcSize >> 8);
+            op[2] = (BYTE)(srcSize >> 16);
+            op[3] = (BYTE)(srcSize >> 24);
+            op += 4;
+            break;
+        }
+    }
+    if (srcSize == 0) { // ZSTD_writeEpilogue: one empty raw block marked last
+        op[0] = 1;
+        op[1] = 0;
+        op[2] = 0;
+        return (U32)(op + 3 - dst);
+    }
+    U32 cSize = 0;
+    if (srcSize >= 7) { // MIN_CBLOCK_SIZE + ZSTD_blockHeaderSize + 1: smaller blocks are not even tried
+        const WsLayout L = wsLayout(cp, srcSize);
+        OptWs w;
+        w.hashTable = (U32 *)(ws + L.hashTable);
+        w.hashTable3 = (U32 *)(ws + L.hashTable3);
+        w.chainTable = (U32 *)(ws + L.chainTable);
+        w.opt = (Optimal *)(ws + L.opt);
+        w.matches = (Match *)(ws + L.matches);
+        w.litFreq = (U32 *)(ws + L.freqs);
+        w.litLengthFreq = w.litFreq + 256;
+        w.matchLengthFreq = w.litLengthFreq + 36;
+        w.offCodeFreq = w.matchLengthFreq + 53;
+        w.seqs = (Seq *)(ws + L.seqs);
+        w.lits = ws + L.lits;
+        w.cp = cp;
+        U32 rep[3] = {1, 4, 8};
+        U32 lastLits = 0;
+        compressBlockBt(w, rep, src, srcSize, &lastLits);
+        for (U32 i = 0; i < lastLits; ++i) // ZSTD_storeLastLiterals
+            w.lits[w.nLits + i] = src[srcSize - lastLits + i];
+        w.nLits += lastLits;
+        EntWs &e = *(EntWs *)(ws + L.ent);
+        cSize = entropyCompressBlock(e, cp, w.seqs, w.nSeq, w.lits, w.nLits, ws + L.codes, op + 3, srcSize);
+    }
+    if (cSize == 0) { // ZSTD_noCompressBlock
+        const U32 h = 1 + (0u << 1) + (srcSize << 3);
+        op[0] = (BYTE)h;
+        op[1] = (BYTE)(h >> 8);
+        op[2] = (BYTE)(h >> 16);
+        for (U32 i = 0; i < srcSize; ++i)
+            op[3 + i] = src[i];
+        return (U32)(op + 3 + srcSize - dst);
+    }
+    {
+        const U32 h = 1 + (2u << 1) + (cSize << 3);
+        op[0] = (BYTE)h;
+        op[1] = (BYTE)(h >> 8);
+        op[2] = (BYTE)(h >> 16);
+    }
+    return (U32)(op + 3 + cSize - dst);
+}
+
+} // namespace zs

@@ -1,0 +1,46 @@
+// zstd_kernels.hip -- S3 on the GPU: ZSTD_compressCCtx(level 17) frames for delta packs (src/common/segment.h:258-280 ->
+// :199-201), byte-identical to libzstd 1.4.9 (restated in agc_amd/csrc/zstd/*.h; parity: tests/test_zstd_frames.py on the
+// host build of the same headers, tests/test_gpu_zstd.py through this kernel).
+//
+// Mapping: the greedy/optimal parse of one frame is a serial dependency chain (binary-tree insertions, price table), but a
+// collection closes tens of thousands of INDEPENDENT packs at once (one per group): one frame per LANE, every table of a
+// frame in its own slice of an HBM arena.  No MFMA, no LDS: integer/byte work bound by dependent memory latency; the
+// parallelism is the number of frames in flight.
+#include "dev_common.h"
+#include "zstd/zs_frame.h"
+
+namespace agc {
+
+struct ZFrameJob {
+    const uint8_t *src;
+    uint8_t *dst;       // zs::frameBound(src_size) bytes
+    uint8_t *ws;        // zs::wsLayout(cp, src_size).total bytes, hash / chain tables zeroed
+    uint32_t src_size;
+    uint32_t idx;       // index in the caller's order
+    zs::CParams cp;
+    uint32_t pad;
+};
+
+__global__ void __launch_bounds__(64) zstd_frames_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_jobs)
+        return;
+    const ZFrameJob jb = jobs[j];
+    out_size[jb.idx] = zs::compressFrame(jb.ws, jb.cp, jb.src, jb.src_size, jb.dst);
+}
+
+// frames (scattered, padded slots) -> one contiguous buffer in the caller's order
+__global__ void __launch_bounds__(256) zstd_gather_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, const uint64_t *__restrict__ dst_off,
+                                                          uint8_t *__restrict__ out)
+{
+    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
+        const ZFrameJob jb = jobs[j];
+        const uint64_t o = dst_off[jb.idx];
+        const uint32_t len = (uint32_t)(dst_off[jb.idx + 1] - o);
+        for (uint32_t t = threadIdx.x; t < len; t += blockDim.x)
+            out[o + t] = jb.dst[t];
+    }
+}
+
+} // namespace agc

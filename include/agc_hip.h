@@ -53,7 +53,8 @@ enum {
     AGC_HIP_K_REVCOMP = 5,
     AGC_HIP_K_PREPROCESS = 6,
     AGC_HIP_K_REFSTORE = 7,
-    AGC_HIP_K_COUNT = 8
+    AGC_HIP_K_ZSTD = 8,
+    AGC_HIP_K_COUNT = 9
 };
 int agc_hip_timing_enable(agc_hip_ctx *ctx, int on);
 int agc_hip_timing_reset(agc_hip_ctx *ctx);
@@ -203,6 +204,20 @@ int agc_hip_fetch_slices_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_base
 int agc_hip_ref_lag_counts_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_base,
                                const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
                                uint32_t *h_cnt /* n*28 */, uint32_t *h_cur /* n*28 */);
+
+/* ---- S3: entropy coding of delta packs (a14) -------------------------- */
+/* Replaces ZSTD_compressCCtx(cctx, dst, bound, src, n, 17) as CSegment::add_to_archive calls it for delta packs
+ * (src/common/segment.h:199-201, store_in_archive(pack) :258-280), for a batch of independent inputs: frame i =
+ * h_dst[h_dst_off[i] .. h_dst_off[i+1]), byte for byte what libzstd 1.4.9 writes (the library the reference is pinned
+ * against here; zstd frames depend on the encoder version).  Inputs: h_src[h_src_off[i] .. h_src_off[i+1]), each at
+ * most agc_hip_zstd17_max_input() bytes (one zstd block); longer ones are the caller's to hand to libzstd itself.
+ * AGC_HIP_ECAP (+ the needed size in h_dst_off[n]) when dst_cap is too small. */
+uint32_t agc_hip_zstd17_max_input(void);
+int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off,
+                         uint8_t *h_dst, uint64_t dst_cap, uint64_t *h_dst_off);
+/* The compression parameters libzstd 1.4.9 derives for level 17 and a known source size (ZSTD_getCParams(17, n, 0)):
+ * windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy.  Exposed so that tests can pin them. */
+int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7]);
 
 #ifdef __cplusplus
 }

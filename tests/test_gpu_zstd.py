@@ -1,0 +1,36 @@
+"""GPU parity of S3: agc_hip_zstd17_batch (one zstd frame per lane) must return, byte for byte, the frames
+ZSTD_compressCCtx(level 17) of libzstd 1.4.9 writes for the same inputs."""
+import numpy as np
+import pytest
+
+from tests import zstd_cases as ZC
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_frames_equal_libzstd(hip_ctx, oracle):
+    if ZC.libzstd().ZSTD_versionNumber() != 10409:
+        pytest.skip("parity is pinned against libzstd 1.4.9")
+    inputs = ZC.corpus(oracle, 31337, 400)
+    got = hip_ctx.zstd17_batch(inputs)
+    bad = [(i, len(p)) for i, p in enumerate(inputs) if got[i] != ZC.ref_frame(p)]
+    assert not bad, bad
+
+
+def test_gpu_many_equal_size_packs(hip_ctx, oracle):
+    """the shape Close() produces: thousands of packs of similar size in one call (several workspace-arena rounds when the
+    arena is small)"""
+    import os
+    rng = np.random.default_rng(5)
+    base = [ZC.delta_pack(oracle, rng, 20, 60000, 1e-3) for _ in range(40)]
+    inputs = [base[i % 40][: len(base[i % 40]) - (i % 7)] for i in range(3000)]
+    os.environ["AGC_HIP_ZSTD_ARENA_MB"] = "600"  # forces several rounds
+    try:
+        got = hip_ctx.zstd17_batch(inputs)
+    finally:
+        del os.environ["AGC_HIP_ZSTD_ARENA_MB"]
+    want = {}
+    for i, p in enumerate(inputs):
+        if p not in want:
+            want[p] = ZC.ref_frame(p)
+        assert got[i] == want[p], i

@@ -1,0 +1,81 @@
+"""CPU parity of the zstd level-17 encoder (agc_amd/csrc/zstd/*.h, compiled for the host by tests/zstd_host) with the image's
+libzstd 1.4.9: the parser's sequences against ZSTD_generateSequences, whole frames against ZSTD_compressCCtx(level 17), the
+restated parameter selection against ZSTD_getCParams.  The GPU build of the same headers is checked by tests/test_gpu_zstd.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import zstd_cases as ZC
+from tests.zstd_host import build as zbuild
+
+
+@pytest.fixture(scope="module")
+def zs():
+    if ZC.libzstd().ZSTD_versionNumber() != 10409:
+        pytest.skip("parity is pinned against libzstd 1.4.9")
+    H = C.CDLL(zbuild.build())
+    H.zs_host_parse.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    H.zs_host_compress.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    H.zs_host_compress.restype = C.c_uint32
+    return H
+
+
+def _my_frame(H, data):
+    n = len(data)
+    cp = np.array(ZC.ref_cparams(n), np.uint32)
+    out = np.zeros(n + 64, np.uint8)
+    k = H.zs_host_compress(bytes(data), n, cp.ctypes.data, out.ctypes.data)
+    return out[:k].tobytes()
+
+
+def _my_sequences(H, data):
+    """the parser's (offCode, litLength, matchLength) resolved to libzstd's (offset, litLength, matchLength, rep) form"""
+    n = len(data)
+    cp = np.array(ZC.ref_cparams(n), np.uint32)
+    out = np.zeros(3 * (n // 3 + 16), np.uint32)
+    ll = np.zeros(1, np.uint32)
+    k = H.zs_host_parse(bytes(data), n, cp.ctypes.data, out.ctypes.data, n // 3 + 16, ll.ctypes.data)
+    rep, res = [1, 4, 8], []
+    for off_code, l, m in out[:3 * k].reshape(-1, 3).tolist():
+        if off_code >= 3:
+            raw, r = off_code - 2, 0
+            rep = [raw, rep[0], rep[1]]
+        else:
+            r = off_code + 1
+            rc = off_code + (1 if l == 0 else 0)
+            if rc == 0:
+                raw = rep[0]
+            else:
+                raw = rep[0] - 1 if rc == 3 else rep[rc]
+                rep = [raw, rep[0], rep[1]] if rc >= 2 else [raw, rep[0], rep[2]]
+        res.append((raw, l, m, r))
+    res.append((0, int(ll[0]), 0, 0))
+    return res
+
+
+def test_frames_equal_libzstd(zs, oracle):
+    bad = []
+    for i, p in enumerate(ZC.corpus(oracle, 2024, 160)):
+        if _my_frame(zs, p) != ZC.ref_frame(p):
+            bad.append((i, len(p)))
+    assert not bad, bad
+
+
+def test_parser_sequences_equal_generate_sequences(zs, oracle):
+    rng = np.random.default_rng(7)
+    for n_samp, seg in ((1, 60000), (20, 60000), (100, 60000), (100, 30000), (7, 5000)):
+        p = ZC.delta_pack(oracle, rng, n_samp, seg, 1e-3)
+        assert _my_sequences(zs, p) == ZC.ref_sequences(p), (n_samp, seg, len(p))
+
+
+def test_level17_parameters_equal_getcparams():
+    from agc_amd import capi
+    L = capi.load()
+    out = (C.c_uint32 * 7)()
+    # (0 means "unknown" to the public ZSTD_getCParams; the one-shot path of an empty input is covered by the frame test)
+    sizes = list(range(1, 3000)) + list(range(3000, 140000, 97)) + [16383, 16384, 16385, 131071, 131072, 131073, 262144, 262145, 1 << 20]
+    for n in sizes:
+        assert L.agc_hip_zstd17_cparams(n, out) == 0
+        assert list(out) == ZC.ref_cparams(n), n
+    assert L.agc_hip_zstd17_max_input() == 131072

@@ -45,3 +45,16 @@ int zs_host_parse(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint
     return (int)w.nSeq;
 }
 }
+
+#include "../../agc_amd/csrc/zstd/zs_frame.h"
+
+extern "C" {
+// whole frame; dst must hold n + 16 bytes; returns the frame size
+uint32_t zs_host_compress(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint8_t *dst)
+{
+    CParams cp = {cparams7[0], cparams7[1], cparams7[2], cparams7[3], cparams7[4], cparams7[5], cparams7[6]};
+    const WsLayout L = wsLayout(cp, n);
+    std::vector<BYTE> ws(L.total, 0);
+    return compressFrame(ws.data(), cp, src, n, dst);
+}
+}
