@@ -1015,47 +1015,11 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base
 // ---------------------------------------------------------------------------
 uint32_t agc_hip_zstd17_max_input(void) { return zs::BLOCKSIZE_MAX; }
 
-// ZSTD_getCParams(17, srcSize, 0) of libzstd 1.4.9: the level-17 rows of ZSTD_defaultCParameters (one per source-size
-// class) followed by ZSTD_adjustCParams_internal (zstd_compress.c)
 int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
 {
     if (!out7)
         return AGC_HIP_EINVAL;
-    //                     W   C   H   S  mml  TL  strategy
-    uint32_t p[7];
-    const uint64_t rSize = src_size ? src_size : ~0ULL; // 0 = unknown in the library; a known empty input has its own path
-    if (src_size == 0) {
-        const uint32_t r[7] = {14, 15, 15, 6, 3, 128, zs::STRAT_BTULTRA2};
-        memcpy(p, r, sizeof(p));
-    } else if (rSize <= 16 * 1024) {
-        const uint32_t r[7] = {14, 15, 15, 6, 3, 128, zs::STRAT_BTULTRA2};
-        memcpy(p, r, sizeof(p));
-    } else if (rSize <= 128 * 1024) {
-        const uint32_t r[7] = {17, 18, 17, 8, 3, 256, zs::STRAT_BTULTRA};
-        memcpy(p, r, sizeof(p));
-    } else if (rSize <= 256 * 1024) {
-        const uint32_t r[7] = {18, 19, 19, 8, 3, 256, zs::STRAT_BTULTRA};
-        memcpy(p, r, sizeof(p));
-    } else {
-        const uint32_t r[7] = {23, 23, 22, 5, 4, 64, zs::STRAT_BTOPT};
-        memcpy(p, r, sizeof(p));
-    }
-    if (src_size < (1ULL << 30)) { // resize windowLog if the input is small enough
-        const uint32_t tSize = (uint32_t)src_size;
-        const uint32_t srcLog = (tSize < (1u << 6)) ? 6 : zs::highbit32(tSize - 1) + 1;
-        if (p[0] > srcLog)
-            p[0] = srcLog;
-    }
-    {
-        const uint32_t cycleLog = p[1] - 1; // bt strategies
-        if (p[2] > p[0] + 1)
-            p[2] = p[0] + 1;
-        if (cycleLog > p[0])
-            p[1] -= cycleLog - p[0];
-    }
-    if (p[0] < 10)
-        p[0] = 10; // ZSTD_WINDOWLOG_ABSOLUTEMIN
-    memcpy(out7, p, sizeof(p));
+    zs::level17Params(src_size, out7);
     return AGC_HIP_OK;
 }
 
@@ -1082,7 +1046,7 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             return AGC_HIP_EINVAL;
         }
         uint32_t p[7];
-        agc_hip_zstd17_cparams(len, p);
+        zs::level17Params(len, p);
         const zs::CParams cp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6]};
         ws_need[i] = zs::wsLayout(cp, (uint32_t)len).total;
         dst_o[i] = dst_total;

@@ -111,6 +111,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     I.pool.reset(new ThreadPool(nt));
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
+    I.choose_entropy_stage();
     I.created = true;
 
     if (!reference_file_name.empty()) {
@@ -259,6 +260,7 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     I.pool.reset(new ThreadPool(nt));
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
+    I.choose_entropy_stage();
 
     if (!I.ar.open(out_archive_name)) {
         I.err("Cannot create archive " + out_archive_name);
@@ -455,6 +457,24 @@ bool CAGCCompressor::Impl::unpack_group(uint32_t gid)
     }
     g.packed = false;
     return true;
+}
+
+// Delta packs go to the GPU entropy stage when its frames are the ones the host's libzstd would write (the device encoder
+// restates libzstd 1.4.9; 1.4.8 writes the same level-17 frames): references and metadata stay on libzstd, and one archive
+// must not mix encoder versions.  AGC_AMD_HOST_ZSTD=1 keeps everything on the host, AGC_AMD_GPU_ZSTD=force overrides the check.
+void CAGCCompressor::Impl::choose_entropy_stage()
+{
+    const std::string v = zstd.versionString ? zstd.versionString() : "";
+    gpu_zstd = (v == "1.4.9" || v == "1.4.8");
+    if (const char *e = getenv("AGC_AMD_GPU_ZSTD"))
+        if (std::string(e) == "force")
+            gpu_zstd = true;
+    if (getenv("AGC_AMD_HOST_ZSTD"))
+        gpu_zstd = false;
+    if (const char *e = getenv("AGC_AMD_GPU_ZSTD_MIN"))
+        gpu_zstd_min = (uint32_t)std::max(1, atoi(e));
+    if (verbosity > 0)
+        std::cerr << "entropy stage: delta packs on " << (gpu_zstd ? "the GPU (zstd 1.4.9 frames)" : "host libzstd") << ", libzstd " << v << std::endl;
 }
 
 bool CAGCCompressor::AddSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,

@@ -22,11 +22,57 @@ void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, byte
 }
 
 // add_to_archive / add_to_archive_tuples, segment.h:172-215; store_in_archive(ref) :218-255
+// Delta packs (zstd level 17, the bulk of the bytes) are compressed on the GPU, one frame per lane
+// (agc_hip_zstd17_batch: byte-identical to ZSTD_compressCCtx of libzstd 1.4.x); references (tuples + level 13, or level
+// 19), packs beyond one zstd block and everything when the library in use is not 1.4.x go to libzstd on the host pool,
+// at the same time.
 void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
 {
     double t0 = now();
-    pool->parallel_for(jobs.size(), [&](size_t i, unsigned tid) {
-        ZJob &j = jobs[i];
+    auto finish = [](ZJob &j, bytes_t &packed, uint32_t ps, uint8_t marker) {
+        packed[ps] = marker;
+        if (ps + 1u < (uint32_t)j.data.size()) {
+            packed.resize((size_t)ps + 1);
+            j.out = std::move(packed);
+            j.meta = j.data.size();
+        } else {
+            j.out = j.data;
+            j.meta = 0;
+        }
+    };
+    // which jobs the device takes
+    std::vector<uint32_t> dev_jobs, host_jobs;
+    const uint32_t dev_max = gpu_zstd ? agc_hip_zstd17_max_input() : 0;
+    for (uint32_t i = 0; i < jobs.size(); ++i)
+        if (gpu_zstd && jobs[i].kind == 1 && !jobs[i].data.empty() && jobs[i].data.size() <= dev_max)
+            dev_jobs.push_back(i);
+        else
+            host_jobs.push_back(i);
+    if (dev_jobs.size() < gpu_zstd_min) { // not worth a launch
+        host_jobs.insert(host_jobs.end(), dev_jobs.begin(), dev_jobs.end());
+        std::sort(host_jobs.begin(), host_jobs.end());
+        dev_jobs.clear();
+    }
+    std::future<bool> dev_done;
+    std::vector<uint64_t> src_off, dst_off;
+    if (!dev_jobs.empty()) {
+        const size_t nd = dev_jobs.size();
+        src_off.assign(nd + 1, 0);
+        for (size_t t = 0; t < nd; ++t)
+            src_off[t + 1] = src_off[t] + jobs[dev_jobs[t]].data.size();
+        if (zsrc_buf.size() < src_off[nd])
+            zsrc_buf.resize(src_off[nd]);
+        pool->parallel_for(nd, [&](size_t t, unsigned) { memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size()); });
+        const uint64_t cap = src_off[nd] + 32 * nd + 64; // a frame never exceeds its input by more than the headers
+        if (zdst_buf.size() < cap)
+            zdst_buf.resize(cap);
+        dst_off.assign(nd + 1, 0);
+        dev_done = std::async(std::launch::async, [&, nd, cap] {
+            return hip_ok(agc_hip_zstd17_batch(hip, (uint32_t)nd, zsrc_buf.data(), src_off.data(), zdst_buf.data(), cap, dst_off.data()), "zstd17_batch");
+        });
+    }
+    pool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
+        ZJob &j = jobs[host_jobs[hi]];
         ZstdCtx &z = *zctx[tid];
         const bytes_t *src = &j.data;
         bytes_t tuples;
@@ -44,16 +90,31 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
         size_t bound = zstd.compressBound(src->size());
         bytes_t packed(bound + 1);
         uint32_t ps = (uint32_t)z.compress(packed.data(), bound, src->data(), src->size(), level);
-        packed[ps] = marker;
-        if (ps + 1u < (uint32_t)j.data.size()) {
-            packed.resize((size_t)ps + 1);
-            j.out = std::move(packed);
-            j.meta = j.data.size();
-        } else {
-            j.out = j.data;
-            j.meta = 0;
-        }
+        finish(j, packed, ps, marker);
     });
+    if (!dev_jobs.empty()) {
+        const double t1 = now();
+        const bool ok = dev_done.get();
+        st.t_device += now() - t1;
+        if (!ok) { // the device refused: libzstd does them after all (same bytes)
+            pool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
+                ZJob &j = jobs[dev_jobs[t]];
+                size_t bound = zstd.compressBound(j.data.size());
+                bytes_t packed(bound + 1);
+                uint32_t ps = (uint32_t)zctx[tid]->compress(packed.data(), bound, j.data.data(), j.data.size(), 17);
+                finish(j, packed, ps, 0);
+            });
+        } else {
+            pool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned) {
+                ZJob &j = jobs[dev_jobs[t]];
+                const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);
+                bytes_t packed(zdst_buf.begin() + dst_off[t], zdst_buf.begin() + dst_off[t + 1]);
+                packed.push_back(0);
+                finish(j, packed, ps, 0);
+            });
+            st.zstd_dev_in += src_off[dev_jobs.size()];
+        }
+    }
     st.t_zstd += now() - t0;
     if (add_parts)
         add_job_parts(jobs, 0, jobs.size());

@@ -551,6 +551,9 @@ struct CAGCCompressor::Impl {
     std::unique_ptr<BatchState> prepared;
     std::vector<Contig> prepared_ctgs;
     std::vector<uint64_t> changed_log;
+    bool gpu_zstd = false;             // delta packs are entropy-coded on the GPU (libzstd 1.4.x frames; AGC_AMD_HOST_ZSTD=1 turns it off)
+    uint32_t gpu_zstd_min = 64;        // fewer packs than this in one call stay on the host (AGC_AMD_GPU_ZSTD_MIN)
+    bytes_t zsrc_buf, zdst_buf;        // staging of the device entropy stage
     bool defer_stream_reg = false;     // parallel bookkeeping: pack jobs leave a missing delta stream to the merging thread
     bool minted_since_prepare = false; // a group of any key (also one-sided) was minted while a sample was prepared
     void lap(BatchState &b, const char *what);
@@ -573,6 +576,7 @@ struct CAGCCompressor::Impl {
     void note_new_group(const pk_t &pk, uint32_t gid);
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
+    void choose_entropy_stage();
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
     bytes_t enc_buf, enc_buf2, fetch_buf; // grown, never shrunk (enc_buf: the window's speculative deltas, enc_buf2: per commit run)

@@ -8,6 +8,7 @@
 // parallelism is the number of frames in flight.
 #include "dev_common.h"
 #include "zstd/zs_frame.h"
+#include "zstd/zs_params.h"
 
 namespace agc {
 

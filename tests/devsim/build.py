@@ -21,8 +21,17 @@ def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     sim_src = [os.path.join(HERE, "agc_hip_sim.c"), os.path.join(ROOT, "oracle", "agc_oracle.c")]
     hdr = os.path.join(ROOT, "include", "agc_hip.h")
-    if force or not _newer(SIM_HIP, sim_src + [hdr]):
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall"] + sim_src + ["-o", SIM_HIP])
+    zsim = os.path.join(HERE, "zstd_sim.cpp")
+    zdeps = [zsim] + [os.path.join(ROOT, "agc_amd", "csrc", "zstd", h) for h in ("zs_common.h", "zs_opt.h", "zs_entropy.h", "zs_frame.h", "zs_params.h")]
+    if force or not _newer(SIM_HIP, sim_src + [hdr] + zdeps):
+        objs = []
+        for s_ in sim_src:
+            o = os.path.join(OUT, os.path.basename(s_) + ".o")
+            subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-Wall", "-c", s_, "-o", o])
+            objs.append(o)
+        zo = os.path.join(OUT, "zstd_sim.o")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", zsim, "-o", zo])
+        subprocess.check_call(["g++", "-shared"] + objs + [zo, "-o", SIM_HIP])
     host_src = [os.path.join(HOST, s) for s in ("compressor.cpp", "compressor_batch.cpp", "compressor_dist.cpp", "capi_host.cpp", "reader.cpp")]
     host_dep = host_src + [os.path.join(HOST, s) for s in ("compressor.h", "compressor_impl.h", "host_support.h", "reader.h", "archive_read.h")] + [SIM_HIP]
     common = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]

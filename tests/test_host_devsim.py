@@ -82,6 +82,25 @@ def test_append_to_missing_archive_reports_and_exits_zero(cli, tmp_path):
     assert r.returncode == 0 and "Cannot open archive" in r.stderr
 
 
+@pytest.mark.parametrize("name", ["toy_c1", "syn_snp", "syn_mixed", "syn_viral", "syn_viral_c", "syn_adaptive_c", "syn_c5_twin"])
+def test_host_pipeline_with_every_pack_on_the_device_entropy_stage(cli, name, tmp_path, monkeypatch):
+    """AGC_AMD_GPU_ZSTD_MIN=1: even a single delta pack goes through agc_hip_zstd17_batch (here: the host build of the encoder
+    the HIP kernel runs) instead of libzstd -- the archives must still be the reference's"""
+    monkeypatch.setenv("AGC_AMD_GPU_ZSTD_MIN", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
+def test_host_zstd_switch_gives_the_same_archive(cli, tmp_path, monkeypatch):
+    monkeypatch.setenv("AGC_AMD_HOST_ZSTD", "1")
+    args, _ = C.CONFIGS["syn_c3_twin"]
+    files = C.build("syn_c3_twin", str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD["syn_c3_twin"]["sha256"]
+
+
 def test_host_pipeline_is_thread_independent(cli, tmp_path):
     args, _ = C.CONFIGS["syn_adaptive"]
     files = C.build("syn_adaptive", str(tmp_path / "in"))
