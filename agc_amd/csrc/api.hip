@@ -1100,8 +1100,11 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                                  c->stream));
         {
             KTimer t(c, AGC_HIP_K_ZSTD);
-            hipLaunchKernelGGL(zstd_frames_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p + done, m,
-                               (uint32_t *)c->d_zsize.p);
+            uint32_t lanes = 64;
+            if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
+                lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
+            hipLaunchKernelGGL(zstd_frames_kernel, dim3((m + lanes - 1) / lanes), dim3(64), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p + done, m,
+                               (uint32_t *)c->d_zsize.p, lanes);
         }
         HIPCHK(c, hipGetLastError());
         done += m;

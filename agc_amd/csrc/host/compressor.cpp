@@ -471,6 +471,8 @@ void CAGCCompressor::Impl::choose_entropy_stage()
             gpu_zstd = true;
     if (getenv("AGC_AMD_HOST_ZSTD"))
         gpu_zstd = false;
+    if (const char *e = getenv("AGC_AMD_GPU_ZSTD_SHARE"))
+        gpu_zstd_share = std::min(1.0, std::max(0.0, atof(e)));
     if (const char *e = getenv("AGC_AMD_GPU_ZSTD_MIN"))
         gpu_zstd_min = (uint32_t)std::max(1, atoi(e));
     if (verbosity > 0)

@@ -28,6 +28,28 @@ void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, byte
 // at the same time.
 void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
 {
+    // a very large call (Close() of a big collection) is cut into a few rounds so that the device / host split can follow
+    // the rates it measures (the first round starts from the previous call's share)
+    uint64_t pack_bytes = 0;
+    for (const ZJob &j : jobs)
+        if (j.kind == 1)
+            pack_bytes += j.data.size();
+    const size_t rounds = gpu_zstd ? std::min<size_t>(4, std::max<size_t>(1, pack_bytes / (64u << 20))) : 1;
+    if (rounds > 1) {
+        for (size_t r = 0; r < rounds; ++r) {
+            const size_t b = jobs.size() * r / rounds, e = jobs.size() * (r + 1) / rounds;
+            std::vector<ZJob> part(std::make_move_iterator(jobs.begin() + b), std::make_move_iterator(jobs.begin() + e));
+            run_jobs_round(part);
+            std::move(part.begin(), part.end(), jobs.begin() + b);
+        }
+    } else
+        run_jobs_round(jobs);
+    if (add_parts)
+        add_job_parts(jobs, 0, jobs.size());
+}
+
+void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
+{
     double t0 = now();
     auto finish = [](ZJob &j, bytes_t &packed, uint32_t ps, uint8_t marker) {
         packed[ps] = marker;
@@ -52,7 +74,31 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
         host_jobs.insert(host_jobs.end(), dev_jobs.begin(), dev_jobs.end());
         std::sort(host_jobs.begin(), host_jobs.end());
         dev_jobs.clear();
+    } else if (gpu_zstd_share < 1.0 && pool->size() > 1) {
+        // both engines work at the same time: the device keeps the share of the pack bytes that makes them finish together
+        // (its measured rate against the host pool's, updated after every call); the rest joins the host jobs
+        uint64_t tot = 0, acc = 0;
+        for (uint32_t i : dev_jobs)
+            tot += jobs[i].data.size();
+        std::vector<uint32_t> keep;
+        for (uint32_t i : dev_jobs) {
+            // spread evenly over the job list (neighbouring groups have similar packs)
+            const uint64_t before = (uint64_t)(acc * gpu_zstd_share), after = (uint64_t)((acc + jobs[i].data.size()) * gpu_zstd_share);
+            acc += jobs[i].data.size();
+            if (after != before || gpu_zstd_share >= 1.0)
+                keep.push_back(i);
+            else
+                host_jobs.push_back(i);
+        }
+        (void)tot;
+        std::sort(host_jobs.begin(), host_jobs.end());
+        dev_jobs.swap(keep);
     }
+    uint64_t host_bytes = 0;
+    for (uint32_t i : host_jobs)
+        if (jobs[i].kind == 1)
+            host_bytes += jobs[i].data.size();
+    double t_dev = 0, t_host = 0;
     std::future<bool> dev_done;
     std::vector<uint64_t> src_off, dst_off;
     if (!dev_jobs.empty()) {
@@ -63,14 +109,30 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
         if (zsrc_buf.size() < src_off[nd])
             zsrc_buf.resize(src_off[nd]);
         pool->parallel_for(nd, [&](size_t t, unsigned) { memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size()); });
+        if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
+            static int dump_no = 0;
+            const std::string base = std::string(dump) + "/packs_" + std::to_string(dump_no++);
+            if (FILE *f = fopen((base + ".bin").c_str(), "wb")) {
+                fwrite(zsrc_buf.data(), 1, src_off[nd], f);
+                fclose(f);
+            }
+            if (FILE *f = fopen((base + ".off").c_str(), "wb")) {
+                fwrite(src_off.data(), 8, nd + 1, f);
+                fclose(f);
+            }
+        }
         const uint64_t cap = src_off[nd] + 32 * nd + 64; // a frame never exceeds its input by more than the headers
         if (zdst_buf.size() < cap)
             zdst_buf.resize(cap);
         dst_off.assign(nd + 1, 0);
         dev_done = std::async(std::launch::async, [&, nd, cap] {
-            return hip_ok(agc_hip_zstd17_batch(hip, (uint32_t)nd, zsrc_buf.data(), src_off.data(), zdst_buf.data(), cap, dst_off.data()), "zstd17_batch");
+            const double td = now();
+            const bool ok = hip_ok(agc_hip_zstd17_batch(hip, (uint32_t)nd, zsrc_buf.data(), src_off.data(), zdst_buf.data(), cap, dst_off.data()), "zstd17_batch");
+            t_dev = now() - td;
+            return ok;
         });
     }
+    const double th0 = now();
     pool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
         ZJob &j = jobs[host_jobs[hi]];
         ZstdCtx &z = *zctx[tid];
@@ -92,6 +154,7 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
         uint32_t ps = (uint32_t)z.compress(packed.data(), bound, src->data(), src->size(), level);
         finish(j, packed, ps, marker);
     });
+    t_host = now() - th0;
     if (!dev_jobs.empty()) {
         const double t1 = now();
         const bool ok = dev_done.get();
@@ -113,11 +176,17 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
                 finish(j, packed, ps, 0);
             });
             st.zstd_dev_in += src_off[dev_jobs.size()];
+            // rates of this call -> share of the next one (only meaningful when both had a real amount of work)
+            if (src_off[dev_jobs.size()] > (8u << 20) && host_bytes > (8u << 20) && t_dev > 0 && t_host > 0 && !getenv("AGC_AMD_GPU_ZSTD_SHARE")) {
+                const double r_dev = src_off[dev_jobs.size()] / t_dev, r_host = host_bytes / t_host;
+                gpu_zstd_share = std::min(0.98, std::max(0.05, r_dev / (r_dev + r_host)));
+            }
+            if (verbosity > 0)
+                std::cerr << "entropy stage: device " << src_off[dev_jobs.size()] / 1e6 << " MB in " << t_dev << " s, host " << host_bytes / 1e6 << " MB in "
+                          << t_host << " s; next device share " << gpu_zstd_share << std::endl;
         }
     }
     st.t_zstd += now() - t0;
-    if (add_parts)
-        add_job_parts(jobs, 0, jobs.size());
 }
 
 // hands finished parts to the archive buffer, in job order (= insertion order inside every stream)

@@ -552,6 +552,7 @@ struct CAGCCompressor::Impl {
     std::vector<Contig> prepared_ctgs;
     std::vector<uint64_t> changed_log;
     bool gpu_zstd = false;             // delta packs are entropy-coded on the GPU (libzstd 1.4.x frames; AGC_AMD_HOST_ZSTD=1 turns it off)
+    double gpu_zstd_share = 0.5;       // share of the pack bytes the device takes when both engines run (AGC_AMD_GPU_ZSTD_SHARE fixes it)
     uint32_t gpu_zstd_min = 64;        // fewer packs than this in one call stay on the host (AGC_AMD_GPU_ZSTD_MIN)
     bytes_t zsrc_buf, zdst_buf;        // staging of the device entropy stage
     bool defer_stream_reg = false;     // parallel bookkeeping: pack jobs leave a missing delta stream to the merging thread
@@ -576,6 +577,7 @@ struct CAGCCompressor::Impl {
     void note_new_group(const pk_t &pk, uint32_t gid);
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
+    void run_jobs_round(std::vector<ZJob> &jobs);
     void choose_entropy_stage();
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);

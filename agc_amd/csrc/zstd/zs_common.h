@@ -91,19 +91,29 @@ ZFN U32 count(const BYTE *ip, const BYTE *match, const BYTE *iend)
     return (U32)(ip - start);
 }
 
-ZCONST U32 LL_bits[MaxLL + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-ZCONST U32 ML_bits[MaxML + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-ZCONST BYTE LL_Code[64] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 18,
-                           19, 19, 20, 20, 20, 20, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23,
-                           23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
-ZCONST BYTE ML_Code[128] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25,
-                            26, 27, 28, 29, 30, 31, 32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38, 38, 38,
-                            38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40,
-                            40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 42, 42, 42, 42, 42, 42, 42, 42,
-                            42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
-
-ZFN U32 LLcode(U32 litLength) { return litLength > 63 ? highbit32(litLength) + 19 : LL_Code[litLength]; }
-ZFN U32 MLcode(U32 mlBase) { return mlBase > 127 ? highbit32(mlBase) + 36 : ML_Code[mlBase]; }
+// Code tables of the zstd format (RFC 8878 3.1.1.3.2.1.1: literal-length and match-length codes and their extra bits) as
+// ARITHMETIC: on the GPU a table lookup is a global-memory round trip per call, a few selects are not.  The tables the
+// library uses (LL_Code / ML_Code / LL_bits / ML_bits, zstd_internal.h) are spelled out in tests/test_zstd_frames.py, which
+// checks these functions against them for every argument.
+ZHD U32 LLbits(U32 code) // LL_bits[code], code <= 35
+{
+    return code < 16 ? 0 : code < 20 ? 1 : code < 22 ? 2 : code < 24 ? 3 : code == 24 ? 4 : code == 25 ? 6 : code - 19;
+}
+ZHD U32 MLbits(U32 code) // ML_bits[code], code <= 52
+{
+    return code < 32 ? 0 : code < 36 ? 1 : code < 38 ? 2 : code < 40 ? 3 : code < 42 ? 4 : code == 42 ? 5 : code == 43 ? 7 : code - 36;
+}
+ZHD U32 LLcode(U32 l) // ZSTD_LLcode
+{
+    if (l > 63)
+        return highbit32(l) + 19;
+    return l < 16 ? l : l < 24 ? 16 + ((l - 16) >> 1) : l < 32 ? 20 + ((l - 24) >> 2) : l < 48 ? 22 + ((l - 32) >> 3) : 24;
+}
+ZHD U32 MLcode(U32 m) // ZSTD_MLcode (m = match length - MINMATCH)
+{
+    if (m > 127)
+        return highbit32(m) + 36;
+    return m < 32 ? m : m < 40 ? 32 + ((m - 32) >> 1) : m < 48 ? 36 + ((m - 40) >> 2) : m < 64 ? 38 + ((m - 48) >> 3) : m < 96 ? 40 + ((m - 64) >> 4) : 42;
+}
 
 } // namespace zs

@@ -1027,8 +1027,8 @@ ZFN U32 entropyCompressBlock(EntWs &e, const CParams &cp, const Seq *seqs, U32 n
             fseInitState2(stML, ctML, mlCodeTable[nbSeq - 1]);
             fseInitState2(stOF, ctOF, ofCodeTable[nbSeq - 1]);
             fseInitState2(stLL, ctLL, llCodeTable[nbSeq - 1]);
-            bitAdd(b, seqs[nbSeq - 1].litLength, LL_bits[llCodeTable[nbSeq - 1]]);
-            bitAdd(b, seqs[nbSeq - 1].matchLength - MINMATCH, ML_bits[mlCodeTable[nbSeq - 1]]);
+            bitAdd(b, seqs[nbSeq - 1].litLength, LLbits(llCodeTable[nbSeq - 1]));
+            bitAdd(b, seqs[nbSeq - 1].matchLength - MINMATCH, MLbits(mlCodeTable[nbSeq - 1]));
             bitAdd(b, seqs[nbSeq - 1].offCode + 1, ofCodeTable[nbSeq - 1]);
             bitFlush(b);
             for (U32 n = nbSeq - 2; n < nbSeq; n--) { // intentional underflow
@@ -1037,8 +1037,8 @@ ZFN U32 entropyCompressBlock(EntWs &e, const CParams &cp, const Seq *seqs, U32 n
                 fseEncodeSymbol(b, stML, ctML, mlCode);
                 fseEncodeSymbol(b, stLL, ctLL, llCode);
                 bitFlush(b);
-                bitAdd(b, seqs[n].litLength, LL_bits[llCode]);
-                bitAdd(b, seqs[n].matchLength - MINMATCH, ML_bits[mlCode]);
+                bitAdd(b, seqs[n].litLength, LLbits(llCode));
+                bitAdd(b, seqs[n].matchLength - MINMATCH, MLbits(mlCode));
                 bitFlush(b);
                 bitAdd(b, seqs[n].offCode + 1, ofCode);
                 bitFlush(b);

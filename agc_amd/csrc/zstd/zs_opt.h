@@ -156,7 +156,7 @@ ZFN U32 litLengthPrice(U32 litLength, const OptWs &w, int optLevel)
     if (w.priceType == zop_predef)
         return weight(litLength, optLevel);
     const U32 llCode = LLcode(litLength);
-    return (LL_bits[llCode] * BITCOST_MULTIPLIER) + w.litLengthSumBasePrice - weight(w.litLengthFreq[llCode], optLevel);
+    return (LLbits(llCode) * BITCOST_MULTIPLIER) + w.litLengthSumBasePrice - weight(w.litLengthFreq[llCode], optLevel);
 }
 
 ZFN U32 getMatchPrice(U32 offset, U32 matchLength, const OptWs &w, int optLevel)
@@ -169,7 +169,7 @@ ZFN U32 getMatchPrice(U32 offset, U32 matchLength, const OptWs &w, int optLevel)
     if ((optLevel < 2) && offCode >= 20)
         price += (offCode - 19) * 2 * BITCOST_MULTIPLIER;
     const U32 mlCode = MLcode(mlBase);
-    price += (ML_bits[mlCode] * BITCOST_MULTIPLIER) + (w.matchLengthSumBasePrice - weight(w.matchLengthFreq[mlCode], optLevel));
+    price += (MLbits(mlCode) * BITCOST_MULTIPLIER) + (w.matchLengthSumBasePrice - weight(w.matchLengthFreq[mlCode], optLevel));
     price += BITCOST_MULTIPLIER / 5;
     return price;
 }

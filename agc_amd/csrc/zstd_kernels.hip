@@ -22,9 +22,14 @@ struct ZFrameJob {
     uint32_t pad;
 };
 
-__global__ void __launch_bounds__(64) zstd_frames_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size)
+// lanes_per_wave < 64 leaves lanes idle on purpose: fewer frames per wave = less control-flow divergence inside a wave and
+// more waves per SIMD to hide memory latency behind each other (the frames of one call rarely fill the chip's wave slots)
+__global__ void __launch_bounds__(64) zstd_frames_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
+                                                         uint32_t lanes_per_wave)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x >= lanes_per_wave)
+        return;
+    const uint32_t j = blockIdx.x * lanes_per_wave + threadIdx.x;
     if (j >= n_jobs)
         return;
     const ZFrameJob jb = jobs[j];

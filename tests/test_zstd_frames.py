@@ -79,3 +79,14 @@ def test_level17_parameters_equal_getcparams():
         assert L.agc_hip_zstd17_cparams(n, out) == 0
         assert list(out) == ZC.ref_cparams(n), n
     assert L.agc_hip_zstd17_max_input() == 131072
+
+
+def test_code_functions_equal_the_format_tables(zs):
+    """LL_bits / ML_bits / LL_Code / ML_Code of zstd_internal.h (RFC 8878 3.1.1.3.2.1.1) against the arithmetic the kernels use"""
+    LL_bits = [0] * 16 + [1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
+    ML_bits = [0] * 32 + [1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
+    LL_Code = list(range(16)) + [16, 16, 17, 17, 18, 18, 19, 19] + [20] * 4 + [21] * 4 + [22] * 8 + [23] * 8 + [24] * 16
+    ML_Code = list(range(32)) + [32, 32, 33, 33, 34, 34, 35, 35] + [36] * 4 + [37] * 4 + [38] * 8 + [39] * 8 + [40] * 16 + [41] * 16 + [42] * 32
+    a, b, c, d = (C.c_uint32 * 36)(), (C.c_uint32 * 53)(), (C.c_uint32 * 64)(), (C.c_uint32 * 128)()
+    zs.zs_host_code_tables(a, b, c, d)
+    assert list(a) == LL_bits and list(b) == ML_bits and list(c) == LL_Code and list(d) == ML_Code

@@ -58,3 +58,14 @@ uint32_t zs_host_compress(const uint8_t *src, uint32_t n, const uint32_t *cparam
     return compressFrame(ws.data(), cp, src, n, dst);
 }
 }
+
+extern "C" {
+// the arithmetic forms of the format's code tables, for every argument the tables cover
+void zs_host_code_tables(uint32_t *ll_bits36, uint32_t *ml_bits53, uint32_t *ll_code64, uint32_t *ml_code128)
+{
+    for (uint32_t c = 0; c < 36; ++c) ll_bits36[c] = LLbits(c);
+    for (uint32_t c = 0; c < 53; ++c) ml_bits53[c] = MLbits(c);
+    for (uint32_t l = 0; l < 64; ++l) ll_code64[l] = LLcode(l);
+    for (uint32_t m = 0; m < 128; ++m) ml_code128[m] = MLcode(m);
+}
+}
