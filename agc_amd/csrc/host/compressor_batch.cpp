@@ -34,7 +34,9 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
     for (const ZJob &j : jobs)
         if (j.kind == 1)
             pack_bytes += j.data.size();
-    const size_t rounds = gpu_zstd ? std::min<size_t>(4, std::max<size_t>(1, pack_bytes / (64u << 20))) : 1;
+    // (one round: the device's time for a launch is the serial time of ONE frame whatever the number of frames -- rounds only add up)
+    const size_t rounds = 1;
+    (void)pack_bytes;
     if (rounds > 1) {
         for (size_t r = 0; r < rounds; ++r) {
             const size_t b = jobs.size() * r / rounds, e = jobs.size() * (r + 1) / rounds;

@@ -4,6 +4,7 @@
 // workspace; nothing is allocated.
 #pragma once
 #include "zs_opt.h"
+#include "zs_opt_sm.h"
 #include "zs_entropy.h"
 
 namespace zs {
@@ -49,7 +50,8 @@ ZHD U32 frameBound(U32 srcSize) { return srcSize + 16; }
 
 // the level's frame for src[0..srcSize), 7 <= ... any srcSize <= BLOCKSIZE_MAX, written to dst (frameBound bytes).
 // ws: wsLayout(cp, srcSize).total bytes, hashTable / hashTable3 / chainTable regions ZEROED by the caller.
-ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst)
+// loop_nest: parse with the plain loop nest (zs_opt.h) instead of the micro-step loop (zs_opt_sm.h); same bytes
+ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, bool loop_nest = false)
 {
     BYTE *op = dst;
     // ---- frame header: magic, descriptor, [window], content size (contentSizeFlag = 1, no checksum, no dictID) ----
@@ -108,7 +110,10 @@ ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize,
         w.cp = cp;
         U32 rep[3] = {1, 4, 8};
         U32 lastLits = 0;
-        compressBlockBt(w, rep, src, srcSize, &lastLits);
+        if (loop_nest)
+            compressBlockBt(w, rep, src, srcSize, &lastLits, [](OptWs &w_, U32 *rep_, const BYTE *s_, U32 n_, int l_) { return compressBlockOpt(w_, rep_, s_, n_, l_); });
+        else
+            compressBlockBt(w, rep, src, srcSize, &lastLits, [](OptWs &w_, U32 *rep_, const BYTE *s_, U32 n_, int l_) { return compressBlockOptSM(w_, rep_, s_, n_, l_); });
         for (U32 i = 0; i < lastLits; ++i) // ZSTD_storeLastLiterals
             w.lits[w.nLits + i] = src[srcSize - lastLits + i];
         w.nLits += lastLits;

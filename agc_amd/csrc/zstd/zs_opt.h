@@ -645,7 +645,8 @@ ZFN U32 compressBlockOpt(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, int
 
 // the block compressor ZSTD_selectBlockCompressor picks for btopt / btultra / btultra2 at the start of a frame;
 // fills w.seqs / w.lits (without the last literals) and returns their count in *lastLits
-ZFN void compressBlockBt(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, U32 *lastLits)
+// (PARSE = compressBlockOpt, the loop nest, or compressBlockOptSM of zs_opt_sm.h, the same parse as one loop of micro-steps)
+template <typename PARSE> ZFN void compressBlockBt(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, U32 *lastLits, PARSE parse)
 {
     w.litSum = w.litLengthSum = w.matchLengthSum = w.offCodeSum = 0;
     w.nSeq = 0;
@@ -657,7 +658,7 @@ ZFN void compressBlockBt(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, U32
     if (w.cp.strategy == STRAT_BTULTRA2 && srcSize > PREDEF_THRESHOLD) {
         // ZSTD_initStats_ultra: a first pass collects statistics, its sequences are dropped
         U32 tmpRep[3] = {rep[0], rep[1], rep[2]};
-        compressBlockOpt(w, tmpRep, src, srcSize, 2);
+        parse(w, tmpRep, src, srcSize, 2);
         w.nSeq = 0;
         w.nLits = 0;
         w.idx0 += srcSize;   // window.base -= srcSize
@@ -665,7 +666,7 @@ ZFN void compressBlockBt(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, U32
         w.nextToUpdate = w.dictLimit;
         upscaleStats(w);
     }
-    *lastLits = compressBlockOpt(w, rep, src, srcSize, w.cp.strategy == STRAT_BTOPT ? 0 : 2);
+    *lastLits = parse(w, rep, src, srcSize, w.cp.strategy == STRAT_BTOPT ? 0 : 2);
 }
 
 } // namespace zs

@@ -22,7 +22,7 @@ def build(force=False):
     sim_src = [os.path.join(HERE, "agc_hip_sim.c"), os.path.join(ROOT, "oracle", "agc_oracle.c")]
     hdr = os.path.join(ROOT, "include", "agc_hip.h")
     zsim = os.path.join(HERE, "zstd_sim.cpp")
-    zdeps = [zsim] + [os.path.join(ROOT, "agc_amd", "csrc", "zstd", h) for h in ("zs_common.h", "zs_opt.h", "zs_entropy.h", "zs_frame.h", "zs_params.h")]
+    zdeps = [zsim] + [os.path.join(ROOT, "agc_amd", "csrc", "zstd", h) for h in ("zs_common.h", "zs_opt.h", "zs_opt_sm.h", "zs_entropy.h", "zs_frame.h", "zs_params.h")]
     if force or not _newer(SIM_HIP, sim_src + [hdr] + zdeps):
         objs = []
         for s_ in sim_src:

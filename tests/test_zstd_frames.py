@@ -18,14 +18,16 @@ def zs():
     H.zs_host_parse.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     H.zs_host_compress.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     H.zs_host_compress.restype = C.c_uint32
+    H.zs_host_compress2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    H.zs_host_compress2.restype = C.c_uint32
     return H
 
 
-def _my_frame(H, data):
+def _my_frame(H, data, loop_nest=0):
     n = len(data)
     cp = np.array(ZC.ref_cparams(n), np.uint32)
     out = np.zeros(n + 64, np.uint8)
-    k = H.zs_host_compress(bytes(data), n, cp.ctypes.data, out.ctypes.data)
+    k = H.zs_host_compress2(bytes(data), n, cp.ctypes.data, out.ctypes.data, loop_nest)
     return out[:k].tobytes()
 
 
@@ -54,10 +56,12 @@ def _my_sequences(H, data):
     return res
 
 
-def test_frames_equal_libzstd(zs, oracle):
+@pytest.mark.parametrize("loop_nest", [0, 1])
+def test_frames_equal_libzstd(zs, oracle, loop_nest):
+    """both forms of the parser: the micro-step loop the kernel runs (0) and the plain loop nest (1)"""
     bad = []
     for i, p in enumerate(ZC.corpus(oracle, 2024, 160)):
-        if _my_frame(zs, p) != ZC.ref_frame(p):
+        if _my_frame(zs, p, loop_nest) != ZC.ref_frame(p):
             bad.append((i, len(p)))
     assert not bad, bad
 

@@ -35,7 +35,7 @@ int zs_host_parse(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint
     w.lits = lits.data();
     U32 rep[3] = {1, 4, 8};
     U32 ll = 0;
-    compressBlockBt(w, rep, src, n, &ll);
+    compressBlockBt(w, rep, src, n, &ll, [](OptWs &w_, U32 *rep_, const BYTE *s_, U32 n_, int l_) { return compressBlockOpt(w_, rep_, s_, n_, l_); });
     *last_lits = ll;
     for (U32 i = 0; i < w.nSeq && i < cap; ++i) {
         out_seq3[3 * i] = w.seqs[i].offCode;
@@ -50,6 +50,13 @@ int zs_host_parse(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint
 
 extern "C" {
 // whole frame; dst must hold n + 16 bytes; returns the frame size
+uint32_t zs_host_compress2(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint8_t *dst, int loop_nest)
+{
+    CParams cp = {cparams7[0], cparams7[1], cparams7[2], cparams7[3], cparams7[4], cparams7[5], cparams7[6]};
+    const WsLayout L = wsLayout(cp, n);
+    std::vector<BYTE> ws(L.total, 0);
+    return compressFrame(ws.data(), cp, src, n, dst, loop_nest != 0);
+}
 uint32_t zs_host_compress(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint8_t *dst)
 {
     CParams cp = {cparams7[0], cparams7[1], cparams7[2], cparams7[3], cparams7[4], cparams7[5], cparams7[6]};
