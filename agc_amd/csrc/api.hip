@@ -1051,9 +1051,9 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
         ws_need[i] = zs::wsLayout(cp, (uint32_t)len).total;
         dst_o[i] = dst_total;
         dst_total += (zs::frameBound((uint32_t)len) + 15) & ~15u;
-        jobs[i].src = nullptr;
-        jobs[i].dst = nullptr;
-        jobs[i].ws = nullptr;
+        jobs[i].src = 0;
+        jobs[i].dst = 0;
+        jobs[i].ws = 0;
         jobs[i].src_size = (uint32_t)len;
         jobs[i].idx = i;
         jobs[i].cp = cp;
@@ -1089,9 +1089,9 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
         for (uint32_t t = 0; t < m; ++t) {
             const uint32_t i = order[done + t];
             ZFrameJob jb = jobs[i];
-            jb.src = (const uint8_t *)c->d_zsrc.p + (h_src_off[i] - h_src_off[0]);
-            jb.dst = (uint8_t *)c->d_zdst.p + dst_o[i];
-            jb.ws = (uint8_t *)c->d_zws.p + used;
+            jb.src = h_src_off[i] - h_src_off[0];
+            jb.dst = dst_o[i];
+            jb.ws = used;
             used += ws_need[i];
             sorted[done + t] = jb;
         }
@@ -1104,7 +1104,7 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
                 lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
             hipLaunchKernelGGL(zstd_frames_kernel, dim3((m + lanes - 1) / lanes), dim3(64), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p + done, m,
-                               (uint32_t *)c->d_zsize.p, lanes);
+                               (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p);
         }
         HIPCHK(c, hipGetLastError());
         done += m;
@@ -1124,7 +1124,7 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     CHK(ensure(c, c->d_dstoff, (size_t)(n + 1) * 8));
     HIPCHK(c, hipMemcpyAsync(c->d_dstoff.p, h_dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(zstd_gather_kernel, dim3(grid_for(n, 1, 16384)), dim3(256), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p, n,
-                       (const uint64_t *)c->d_dstoff.p, (uint8_t *)c->d_zout.p);
+                       (const uint64_t *)c->d_dstoff.p, (const uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zout.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_dst, c->d_zout.p, tot, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

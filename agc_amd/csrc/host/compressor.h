@@ -33,6 +33,7 @@ struct CompressorStats {
     uint64_t zstd_in = 0, zstd_out = 0;
     uint64_t archive_bytes = 0;
     // symbols the LZ kernels were asked to look at (algorithmic bytes of SURVEY 8d: every text once + its reference once)
+    double t_zstd_dev = 0, t_zstd_host = 0, t_zstd_stage = 0; // entropy stage: device call, host pool, staging copies (all inside t_zstd)
     uint64_t zstd_dev_in = 0;      // bytes entropy-coded on the GPU (part of zstd_in)
     uint64_t enc_text = 0, enc_ref = 0, est_text = 0, est_ref = 0, cv_text = 0, cv_ref = 0;
     uint64_t windows = 0, commit_runs = 0, revalidated = 0; // process_batch calls, commit runs inside them, segments classified again

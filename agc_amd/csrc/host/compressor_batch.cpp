@@ -79,20 +79,18 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     } else if (gpu_zstd_share < 1.0 && pool->size() > 1) {
         // both engines work at the same time: the device keeps the share of the pack bytes that makes them finish together
         // (its measured rate against the host pool's, updated after every call); the rest joins the host jobs
-        uint64_t tot = 0, acc = 0;
-        for (uint32_t i : dev_jobs)
-            tot += jobs[i].data.size();
+        uint64_t acc = 0, dev_acc = 0;
         std::vector<uint32_t> keep;
         for (uint32_t i : dev_jobs) {
-            // spread evenly over the job list (neighbouring groups have similar packs)
-            const uint64_t before = (uint64_t)(acc * gpu_zstd_share), after = (uint64_t)((acc + jobs[i].data.size()) * gpu_zstd_share);
-            acc += jobs[i].data.size();
-            if (after != before || gpu_zstd_share >= 1.0)
+            // proportional, spread evenly over the job list (neighbouring groups have similar packs)
+            const uint64_t sz = jobs[i].data.size();
+            acc += sz;
+            if ((double)(dev_acc + sz / 2) <= gpu_zstd_share * (double)acc) {
                 keep.push_back(i);
-            else
+                dev_acc += sz;
+            } else
                 host_jobs.push_back(i);
         }
-        (void)tot;
         std::sort(host_jobs.begin(), host_jobs.end());
         dev_jobs.swap(keep);
     }
@@ -103,6 +101,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     double t_dev = 0, t_host = 0;
     std::future<bool> dev_done;
     std::vector<uint64_t> src_off, dst_off;
+    const double ts0 = now();
     if (!dev_jobs.empty()) {
         const size_t nd = dev_jobs.size();
         src_off.assign(nd + 1, 0);
@@ -135,6 +134,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         });
     }
     const double th0 = now();
+    st.t_zstd_stage += th0 - ts0;
     pool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
         ZJob &j = jobs[host_jobs[hi]];
         ZstdCtx &z = *zctx[tid];
@@ -157,10 +157,13 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         finish(j, packed, ps, marker);
     });
     t_host = now() - th0;
+    st.t_zstd_host += t_host;
     if (!dev_jobs.empty()) {
         const double t1 = now();
         const bool ok = dev_done.get();
         st.t_device += now() - t1;
+        st.t_zstd_dev += t_dev;
+        const double ts1 = now();
         if (!ok) { // the device refused: libzstd does them after all (same bytes)
             pool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
                 ZJob &j = jobs[dev_jobs[t]];
@@ -178,6 +181,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 finish(j, packed, ps, 0);
             });
             st.zstd_dev_in += src_off[dev_jobs.size()];
+            st.t_zstd_stage += now() - ts1;
             // rates of this call -> share of the next one (only meaningful when both had a real amount of work)
             if (src_off[dev_jobs.size()] > (8u << 20) && host_bytes > (8u << 20) && t_dev > 0 && t_host > 0 && !getenv("AGC_AMD_GPU_ZSTD_SHARE")) {
                 const double r_dev = src_off[dev_jobs.size()] / t_dev, r_host = host_bytes / t_host;

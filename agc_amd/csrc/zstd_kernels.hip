@@ -12,10 +12,12 @@
 
 namespace agc {
 
+// (offsets from the three base pointers the kernel receives as ARGUMENTS: pointers loaded from memory would be generic
+// ("flat") to the compiler -- slower instructions and, worse, waits on every outstanding access before each use)
 struct ZFrameJob {
-    const uint8_t *src;
-    uint8_t *dst;       // zs::frameBound(src_size) bytes
-    uint8_t *ws;        // zs::wsLayout(cp, src_size).total bytes, hash / chain tables zeroed
+    uint64_t src;       // offset of the input in the source buffer
+    uint64_t dst;       // offset of the frame slot (zs::frameBound(src_size) bytes) in the output buffer
+    uint64_t ws;        // offset of the workspace (zs::wsLayout(cp, src_size).total bytes, zeroed) in the arena
     uint32_t src_size;
     uint32_t idx;       // index in the caller's order
     zs::CParams cp;
@@ -25,7 +27,8 @@ struct ZFrameJob {
 // lanes_per_wave < 64 leaves lanes idle on purpose: fewer frames per wave = less control-flow divergence inside a wave and
 // more waves per SIMD to hide memory latency behind each other (the frames of one call rarely fill the chip's wave slots)
 __global__ void __launch_bounds__(64) zstd_frames_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
-                                                         uint32_t lanes_per_wave)
+                                                         uint32_t lanes_per_wave, const uint8_t *__restrict__ src_base, uint8_t *__restrict__ dst_base,
+                                                         uint8_t *__restrict__ ws_base)
 {
     if (threadIdx.x >= lanes_per_wave)
         return;
@@ -33,19 +36,19 @@ __global__ void __launch_bounds__(64) zstd_frames_kernel(const ZFrameJob *__rest
     if (j >= n_jobs)
         return;
     const ZFrameJob jb = jobs[j];
-    out_size[jb.idx] = zs::compressFrame(jb.ws, jb.cp, jb.src, jb.src_size, jb.dst);
+    out_size[jb.idx] = zs::compressFrame(ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst);
 }
 
 // frames (scattered, padded slots) -> one contiguous buffer in the caller's order
 __global__ void __launch_bounds__(256) zstd_gather_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, const uint64_t *__restrict__ dst_off,
-                                                          uint8_t *__restrict__ out)
+                                                          const uint8_t *__restrict__ dst_base, uint8_t *__restrict__ out)
 {
     for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
         const ZFrameJob jb = jobs[j];
         const uint64_t o = dst_off[jb.idx];
         const uint32_t len = (uint32_t)(dst_off[jb.idx + 1] - o);
         for (uint32_t t = threadIdx.x; t < len; t += blockDim.x)
-            out[o + t] = jb.dst[t];
+            out[o + t] = dst_base[jb.dst + t];
     }
 }
 

@@ -297,7 +297,9 @@ def main():
                        "segments_per_step": int(per(stats["segments"])), "lz_encoded_per_step": int(per(stats["lz_encoded"])),
                        "missing_middle_per_step": int(per(stats["middle_tried"])), "one_splitter_per_step": int(per(stats["one_splitter"])),
                        "new_groups_per_step": int(per(stats["new_groups"])), "delta_bytes_per_step": int(per(stats["delta_bytes"])),
-                       "zstd": {"version": cmp_.zstd_version(), "host_threads": threads, "in_bytes": int(stats["zstd_in"]), "out_bytes": int(stats["zstd_out"])},
+                       "zstd": {"version": cmp_.zstd_version(), "host_threads": threads, "in_bytes": int(stats["zstd_in"]), "out_bytes": int(stats["zstd_out"]),
+                                "device_in_bytes": int(stats["zstd_dev_in"]), "device_call_s": round(stats["t_zstd_dev"], 3),
+                                "host_pool_s": round(stats["t_zstd_host"], 3), "staging_s": round(stats["t_zstd_stage"], 3)},
                        "host_stage_seconds_rank0": {k_: round(stats[k_], 4) for k_ in stats if k_.startswith("t_")},
                        "parallelism": (f"samples round-robin over {world} GPUs into ONE archive: ordered commit, one RCCL broadcast of the commit "
                                        f"record (new reference segments + deltas) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each; "
