@@ -63,7 +63,7 @@ def load():
         pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -m agc_amd.build` (hipcc, gfx950) first")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("AGC_HIP_LIB", LIB_PATH))  # (AGC_HIP_LIB: a kernel-variant build for scripts/ probes)
     L.agc_hip_create.argtypes = [C.POINTER(vp), C.c_int]
     L.agc_hip_destroy.argtypes = [vp]
     L.agc_hip_destroy.restype = None

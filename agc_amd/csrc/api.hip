@@ -1103,8 +1103,21 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             uint32_t lanes = 32; // measured best on the pack mix of Close(): 64 lanes 2.30 s, 32 lanes 2.11 s per 50 k frames
             if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
                 lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
-            hipLaunchKernelGGL(zstd_frames_kernel, dim3((m + lanes - 1) / lanes), dim3(64), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p + done, m,
-                               (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p);
+            int wps = 2;
+            if (const char *e = getenv("AGC_HIP_ZSTD_WPS"))
+                wps = atoi(e);
+            const uint32_t dbg = (uint32_t)(getenv("AGC_HIP_ZSTD_DEBUG") ? atoi(getenv("AGC_HIP_ZSTD_DEBUG")) : 0);
+            const dim3 grid((m + lanes - 1) / lanes), block(64);
+            const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
+            if (wps >= 4)
+                hipLaunchKernelGGL(zstd_frames_kernel<4>, grid, block, 0, c->stream, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                                   (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+            else if (wps == 3)
+                hipLaunchKernelGGL(zstd_frames_kernel<3>, grid, block, 0, c->stream, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                                   (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+            else
+                hipLaunchKernelGGL(zstd_frames_kernel<2>, grid, block, 0, c->stream, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                                   (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
         }
         HIPCHK(c, hipGetLastError());
         done += m;

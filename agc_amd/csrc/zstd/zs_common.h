@@ -48,10 +48,11 @@ struct Match {
     U32 off, len;
 };
 
-struct Optimal { // ZSTD_optimal_t
+struct alignas(16) Optimal { // ZSTD_optimal_t (padded to 32 bytes: two 16-byte accesses per entry)
     int price;
     U32 off, mlen, litlen;
     U32 rep[3];
+    U32 pad;
 };
 
 struct Seq { // one stored sequence (full lengths; offCode = repcode 0..2 or distance + 2)
@@ -88,6 +89,39 @@ ZFN U32 count(const BYTE *ip, const BYTE *match, const BYTE *iend)
         ++ip;
         ++match;
     }
+    return (U32)(ip - start);
+}
+
+// ZSTD_count that also hands back the two bytes at the first difference (what the tree walk compares next): they are in the
+// words just compared, a second trip to memory for them is wasted.  *diff = false when ip reached iend.
+ZFN U32 countEx(const BYTE *ip, const BYTE *match, const BYTE *iend, U32 *ipByte, U32 *matchByte, bool *diff)
+{
+    const BYTE *const start = ip;
+    while (ip + 8 <= iend) {
+        const U64 a = read64(ip), b = read64(match);
+        const U64 d = a ^ b;
+        if (d) {
+            const U32 sh = (U32)__builtin_ctzll(d) & ~7u;
+            *ipByte = (U32)(a >> sh) & 0xFF;
+            *matchByte = (U32)(b >> sh) & 0xFF;
+            *diff = true;
+            return (U32)(ip - start) + (sh >> 3);
+        }
+        ip += 8;
+        match += 8;
+    }
+    while (ip < iend) {
+        const U32 a = *ip, b = *match;
+        if (a != b) {
+            *ipByte = a;
+            *matchByte = b;
+            *diff = true;
+            return (U32)(ip - start);
+        }
+        ++ip;
+        ++match;
+    }
+    *diff = false;
     return (U32)(ip - start);
 }
 

@@ -51,7 +51,7 @@ ZHD U32 frameBound(U32 srcSize) { return srcSize + 16; }
 // the level's frame for src[0..srcSize), 7 <= ... any srcSize <= BLOCKSIZE_MAX, written to dst (frameBound bytes).
 // ws: wsLayout(cp, srcSize).total bytes, hashTable / hashTable3 / chainTable regions ZEROED by the caller.
 // loop_nest: parse with the plain loop nest (zs_opt.h) instead of the micro-step loop (zs_opt_sm.h); same bytes
-ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, bool loop_nest = false)
+ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, bool loop_nest = false, U32 debug = 0)
 {
     BYTE *op = dst;
     // ---- frame header: magic, descriptor, [window], content size (contentSizeFlag = 1, no checksum, no dictID) ----
@@ -118,6 +118,7 @@ ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize,
             w.lits[w.nLits + i] = src[srcSize - lastLits + i];
         w.nLits += lastLits;
         EntWs &e = *(EntWs *)(ws + L.ent);
+        if (!(debug & 1)) // (debug bit 0: profiling aid -- parse only, emit a raw block)
         cSize = entropyCompressBlock(e, cp, w.seqs, w.nSeq, w.lits, w.nLits, ws + L.codes, op + 3, srcSize);
     }
     if (cSize == 0) { // ZSTD_noCompressBlock

@@ -14,8 +14,14 @@
 
 namespace zs {
 
-constexpr U32 SM_PRICE_STEPS = 6;     // price updates per trip
-constexpr U32 SM_WALK_LEVELS = 3;     // tree levels per trip
+#ifndef ZS_SM_PRICE_STEPS
+#define ZS_SM_PRICE_STEPS 8
+#endif
+#ifndef ZS_SM_WALK_LEVELS
+#define ZS_SM_WALK_LEVELS 4
+#endif
+constexpr U32 SM_PRICE_STEPS = ZS_SM_PRICE_STEPS;     // price updates per trip
+constexpr U32 SM_WALK_LEVELS = ZS_SM_WALK_LEVELS;     // tree levels per trip
 constexpr U32 SM_STORE_SEQS = 3;      // stored sequences per trip
 constexpr U32 SM_NOPTR = 0xFFFFFFFFu; // "dummy32": the tree pointer that is no longer written
 
@@ -35,6 +41,17 @@ enum {
     ST_STORE,          // one sequence of the chunk
     ST_DONE
 };
+
+// price / off / mlen / litlen of an entry in one 16-byte store (the repcodes of the entry are written later)
+ZFN void storeHead(Optimal &dst, const Optimal &o)
+{
+    struct alignas(16) Head {
+        int price;
+        U32 off, mlen, litlen;
+    };
+    Head h = {o.price, o.off, o.mlen, o.litlen};
+    *(Head *)&dst = h;
+}
 
 ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, int optLevel)
 {
@@ -67,8 +84,9 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
     // tree walk
     U32 wk_current = 0, matchIndex = 0, clSmaller = 0, clLarger = 0, smallerPtr = 0, largerPtr = 0, matchEndIdx = 0, bestLength = 0, nbCompares = 0,
         btLow = 0, lowLimit = 0, mnum = 0, upd_idx = 0;
-    // price loops
-    U32 pr_matchNb = 0, pr_pos = 0, pr_literalsPrice = 0;
+    // price loops (the match being priced is cached: pm_*)
+    U32 pr_matchNb = 0, pr_pos = 0, pr_literalsPrice = 0, pm_off = 0, pm_len = 0, pm_start = 0, cur_litlen_back = 0;
+    U32 last_m_off = 0, last_m_len = 0; // the longest match of the current request (matches[nbMatches - 1])
     // store loop
     U32 storePos = 0, storeEnd = 0;
 
@@ -135,46 +153,56 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
         } while (0);
         if (state == ST_CUR_BEGIN) do {
             const U32 inr = ip + cur;
+            // the two entries are read ONCE, worked on in registers and written back once (every further look at opt[cur] in this
+            // block uses the copy: a reload after a store is a round trip to memory on this hardware)
+            const Optimal op = opt[cur - 1];
+            Optimal oc = opt[cur];
             {
-                const U32 litlen = (opt[cur - 1].mlen == 0) ? opt[cur - 1].litlen + 1 : 1;
-                const int price = opt[cur - 1].price + (int)rawLiteralsCost(src + inr - 1, 1, w, optLevel) + (int)litLengthPrice(litlen, w, optLevel) -
+                const U32 litlen = (op.mlen == 0) ? op.litlen + 1 : 1;
+                const int price = op.price + (int)rawLiteralsCost(src + inr - 1, 1, w, optLevel) + (int)litLengthPrice(litlen, w, optLevel) -
                                   (int)litLengthPrice(litlen - 1, w, optLevel);
-                if (price <= opt[cur].price) {
-                    opt[cur].mlen = 0;
-                    opt[cur].off = 0;
-                    opt[cur].litlen = litlen;
-                    opt[cur].price = price;
+                if (price <= oc.price) {
+                    oc.mlen = 0;
+                    oc.off = 0;
+                    oc.litlen = litlen;
+                    oc.price = price;
                 }
             }
-            if (opt[cur].mlen != 0) {
-                const U32 prev = cur - opt[cur].mlen;
-                updateRep(opt[cur].rep, opt[prev].rep, opt[cur].off, opt[cur].litlen == 0);
+            if (oc.mlen != 0) {
+                const U32 prev = cur - oc.mlen;
+                U32 pr[3];
+                pr[0] = opt[prev].rep[0];
+                pr[1] = opt[prev].rep[1];
+                pr[2] = opt[prev].rep[2];
+                updateRep(oc.rep, pr, oc.off, oc.litlen == 0);
             } else {
                 for (U32 i = 0; i < REP_NUM; ++i)
-                    opt[cur].rep[i] = opt[cur - 1].rep[i];
+                    oc.rep[i] = op.rep[i];
             }
+            opt[cur] = oc;
             if (inr > ilimit_off) { // last match must start at a minimum distance of 8 from oend
                 state = ST_CUR_NEXT;
                 break;
             }
             if (cur == last_pos) { // `break` of the forward loop
-                lastSequence = opt[last_pos];
+                lastSequence = oc;
                 const U32 tl = lastSequence.litlen + lastSequence.mlen;
                 cur = last_pos > tl ? last_pos - tl : 0;
                 state = ST_CHUNK_END;
                 break;
             }
-            if ((optLevel == 0) && (opt[cur + 1].price <= opt[cur].price + (int)(BITCOST_MULTIPLIER / 2))) {
+            if ((optLevel == 0) && (opt[cur + 1].price <= oc.price + (int)(BITCOST_MULTIPLIER / 2))) {
                 state = ST_CUR_NEXT; // skip unpromising positions
                 break;
             }
-            q_ll0 = (opt[cur].mlen != 0);
-            q_litlen = (opt[cur].mlen == 0) ? opt[cur].litlen : 0;
-            basePrice = (U32)opt[cur].price + litLengthPrice(0, w, optLevel);
+            q_ll0 = (oc.mlen != 0);
+            q_litlen = (oc.mlen == 0) ? oc.litlen : 0;
+            cur_litlen_back = (oc.mlen == 0) ? oc.litlen : 0; // what `cur -= ...` of the early chunk end needs
+            basePrice = (U32)oc.price + litLengthPrice(0, w, optLevel);
             q_current = inr + w.idx0;
-            q_rep[0] = opt[cur].rep[0];
-            q_rep[1] = opt[cur].rep[1];
-            q_rep[2] = opt[cur].rep[2];
+            q_rep[0] = oc.rep[0];
+            q_rep[1] = oc.rep[1];
+            q_rep[2] = oc.rep[2];
             inChunk = true;
             state = ST_GETM_BEGIN;
         } while (0);
@@ -218,7 +246,16 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     const U32 nextPtr = 2 * (matchIndex & btMask);
                     U32 matchLength = clSmaller < clLarger ? clSmaller : clLarger;
                     const BYTE *const match = src + (matchIndex - w.idx0);
-                    matchLength += count(p + matchLength, match + matchLength, iend);
+                    // both children are read before the stores below (a store to this walk's own pointers never hits the node read here)
+                U32 childSmaller, childLarger;
+                {
+                    const U64 pair = *(const U64 *)(bt + nextPtr);
+                    childLarger = (U32)pair;          // nextPtr[0]
+                    childSmaller = (U32)(pair >> 32); // nextPtr[1]
+                }
+                U32 pByte = 0, mByte = 0;
+                bool differ = false;
+                matchLength += countEx(p + matchLength, match + matchLength, iend, &pByte, &mByte, &differ);
                     if (matchLength > bestLength) {
                         bestLength = matchLength;
                         if (matchLength > matchEndIdx - matchIndex)
@@ -226,7 +263,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     }
                     if (p + matchLength != iend) {
                         ended = false;
-                        if (match[matchLength] < p[matchLength]) {
+                        if (mByte < pByte) { // match[matchLength] < p[matchLength] (differ holds: p + matchLength != iend)
                             if (smallerPtr != SM_NOPTR)
                                 bt[smallerPtr] = matchIndex;
                             clSmaller = matchLength;
@@ -235,7 +272,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                                 ended = true;
                             } else {
                                 smallerPtr = nextPtr + 1;
-                                matchIndex = bt[nextPtr + 1];
+                                matchIndex = childSmaller;
                             }
                         } else {
                             if (largerPtr != SM_NOPTR)
@@ -246,7 +283,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                                 ended = true;
                             } else {
                                 largerPtr = nextPtr;
-                                matchIndex = bt[nextPtr];
+                                matchIndex = childLarger;
                             }
                         }
                     }
@@ -298,6 +335,8 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                         bestLength = repLen;
                         matches[mnum].off = repCode - q_ll0;
                         matches[mnum].len = repLen;
+                        last_m_off = repCode - q_ll0;
+                        last_m_len = repLen;
                         mnum++;
                         if ((repLen > sufficient_len) | (p + repLen == iend)) {
                             done = true; // best possible
@@ -315,6 +354,8 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                         bestLength = mlen;
                         matches[0].off = (wk_current - matchIndex3) + REP_MOVE;
                         matches[0].len = mlen;
+                        last_m_off = (wk_current - matchIndex3) + REP_MOVE;
+                        last_m_len = mlen;
                         mnum = 1;
                         if ((mlen > sufficient_len) | (p + mlen == iend)) {
                             w.nextToUpdate = wk_current + 1; // skip insertion
@@ -339,7 +380,16 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 const U32 nextPtr = 2 * (matchIndex & btMask);
                 U32 matchLength = clSmaller < clLarger ? clSmaller : clLarger;
                 const BYTE *const match = src + (matchIndex - w.idx0);
-                matchLength += count(p + matchLength, match + matchLength, iend);
+                // both children are read before the stores below (a store to this walk's own pointers never hits the node read here)
+                U32 childSmaller, childLarger;
+                {
+                    const U64 pair = *(const U64 *)(bt + nextPtr);
+                    childLarger = (U32)pair;          // nextPtr[0]
+                    childSmaller = (U32)(pair >> 32); // nextPtr[1]
+                }
+                U32 pByte = 0, mByte = 0;
+                bool differ = false;
+                matchLength += countEx(p + matchLength, match + matchLength, iend, &pByte, &mByte, &differ);
                 bool brk = false;
                 if (matchLength > bestLength) {
                     if (matchLength > matchEndIdx - matchIndex)
@@ -347,13 +397,15 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     bestLength = matchLength;
                     matches[mnum].off = (wk_current - matchIndex) + REP_MOVE;
                     matches[mnum].len = matchLength;
+                    last_m_off = (wk_current - matchIndex) + REP_MOVE;
+                    last_m_len = matchLength;
                     mnum++;
                     if ((matchLength > OPT_NUM) | (p + matchLength == iend))
                         brk = true; // drop, to preserve bt consistency
                 }
                 if (!brk) {
                     ended = false;
-                    if (match[matchLength] < p[matchLength]) {
+                    if (mByte < pByte) { // match[matchLength] < p[matchLength] (differ holds: p + matchLength != iend)
                         if (smallerPtr != SM_NOPTR)
                             bt[smallerPtr] = matchIndex;
                         clSmaller = matchLength;
@@ -362,7 +414,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                             ended = true;
                         } else {
                             smallerPtr = nextPtr + 1;
-                            matchIndex = bt[nextPtr + 1];
+                            matchIndex = childSmaller;
                         }
                     } else {
                         if (largerPtr != SM_NOPTR)
@@ -373,7 +425,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                             ended = true;
                         } else {
                             largerPtr = nextPtr;
-                            matchIndex = bt[nextPtr];
+                            matchIndex = childLarger;
                         }
                     }
                 }
@@ -400,8 +452,8 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 opt[0].mlen = 0;
                 opt[0].litlen = q_litlen;
                 opt[0].price = (int)litLengthPrice(q_litlen, w, optLevel);
-                const U32 maxML = matches[nbMatches - 1].len;
-                const U32 maxOffset = matches[nbMatches - 1].off;
+                const U32 maxML = last_m_len;
+                const U32 maxOffset = last_m_off;
                 if (maxML > sufficient_len) { // large match -> immediate encoding
                     lastSequence.litlen = q_litlen;
                     lastSequence.mlen = maxML;
@@ -416,6 +468,8 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     opt[pos].price = MAX_PRICE;
                 pr_pos = minMatch;
                 pr_matchNb = 0;
+                pm_off = matches[0].off;
+                pm_len = matches[0].len;
                 state = ST_PRICE_FIRST;
                 break;
             }
@@ -424,12 +478,12 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 break;
             }
             {
-                const U32 maxML = matches[nbMatches - 1].len;
+                const U32 maxML = last_m_len;
                 if ((maxML > sufficient_len) || (cur + maxML >= OPT_NUM)) {
                     lastSequence.mlen = maxML;
-                    lastSequence.off = matches[nbMatches - 1].off;
+                    lastSequence.off = last_m_off;
                     lastSequence.litlen = q_litlen;
-                    cur -= (opt[cur].mlen == 0) ? opt[cur].litlen : 0; // last sequence is actually only literals (may underflow)
+                    cur -= cur_litlen_back; // last sequence is actually only literals (may underflow)
                     last_pos = cur + lastSequence.litlen + lastSequence.mlen;
                     if (cur > OPT_NUM)
                         cur = 0; // underflow => first match
@@ -438,25 +492,33 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 }
             }
             pr_matchNb = 0;
-            pr_pos = matches[0].len; // mlen cursor of the downward scan
+            pm_off = matches[0].off;
+            pm_len = matches[0].len;
+            pm_start = minMatch;
+            pr_pos = pm_len; // mlen cursor of the downward scan
             state = ST_PRICE_CUR;
         } while (0);
         if (state == ST_PRICE_FIRST) do {
             // for (matchNb...) for ( ; pos <= end ; pos++ ): a few positions per micro-step
             U32 budget = SM_PRICE_STEPS;
             while (budget && pr_matchNb < nbMatches) {
-                const U32 offset = matches[pr_matchNb].off;
-                const U32 end = matches[pr_matchNb].len;
-                if (pr_pos <= end) {
-                    const U32 sequencePrice = pr_literalsPrice + getMatchPrice(offset, pr_pos, w, optLevel);
-                    opt[pr_pos].mlen = pr_pos;
-                    opt[pr_pos].off = offset;
-                    opt[pr_pos].litlen = q_litlen;
-                    opt[pr_pos].price = (int)sequencePrice;
+                if (pr_pos <= pm_len) {
+                    const U32 sequencePrice = pr_literalsPrice + getMatchPrice(pm_off, pr_pos, w, optLevel);
+                    Optimal o; // (rep is set when the forward pass reaches the position)
+                    o.price = (int)sequencePrice;
+                    o.off = pm_off;
+                    o.mlen = pr_pos;
+                    o.litlen = q_litlen;
+                    storeHead(opt[pr_pos], o);
                     pr_pos++;
                     budget--;
-                } else
+                } else {
                     pr_matchNb++;
+                    if (pr_matchNb < nbMatches) {
+                        pm_off = matches[pr_matchNb].off;
+                        pm_len = matches[pr_matchNb].len;
+                    }
+                }
             }
             if (pr_matchNb >= nbMatches) {
                 last_pos = pr_pos - 1;
@@ -468,22 +530,22 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
             // for (matchNb...) for (mlen = lastML; mlen >= startML; mlen--): a few lengths per micro-step
             U32 budget = SM_PRICE_STEPS;
             while (budget && pr_matchNb < nbMatches) {
-                const U32 offset = matches[pr_matchNb].off;
-                const U32 startML = (pr_matchNb > 0) ? matches[pr_matchNb - 1].len + 1 : minMatch;
                 bool next = false;
-                if (pr_pos >= startML) {
+                if (pr_pos >= pm_start) {
                     const U32 mlen = pr_pos;
                     const U32 pos = cur + mlen;
-                    const int price = (int)(basePrice + getMatchPrice(offset, mlen, w, optLevel));
+                    const int price = (int)(basePrice + getMatchPrice(pm_off, mlen, w, optLevel));
                     if ((pos > last_pos) || (price < opt[pos].price)) {
                         while (last_pos < pos) {
                             opt[last_pos + 1].price = MAX_PRICE;
                             last_pos++;
                         }
-                        opt[pos].mlen = mlen;
-                        opt[pos].off = offset;
-                        opt[pos].litlen = q_litlen;
-                        opt[pos].price = price;
+                        Optimal o;
+                        o.price = price;
+                        o.off = pm_off;
+                        o.mlen = mlen;
+                        o.litlen = q_litlen;
+                        storeHead(opt[pos], o);
                     } else if (optLevel == 0)
                         next = true; // early update abort
                     pr_pos--;
@@ -492,8 +554,12 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     next = true;
                 if (next) {
                     pr_matchNb++;
-                    if (pr_matchNb < nbMatches)
-                        pr_pos = matches[pr_matchNb].len;
+                    if (pr_matchNb < nbMatches) {
+                        pm_start = pm_len + 1; // matches[matchNb - 1].len + 1
+                        pm_off = matches[pr_matchNb].off;
+                        pm_len = matches[pr_matchNb].len;
+                        pr_pos = pm_len;
+                    }
                 }
             }
             if (pr_matchNb >= nbMatches)

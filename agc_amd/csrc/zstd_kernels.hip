@@ -26,9 +26,12 @@ struct ZFrameJob {
 
 // lanes_per_wave < 64 leaves lanes idle on purpose: fewer frames per wave = less control-flow divergence inside a wave and
 // more waves per SIMD to hide memory latency behind each other (the frames of one call rarely fill the chip's wave slots)
-__global__ void __launch_bounds__(64) zstd_frames_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
+// WPS = waves per SIMD the register allocation leaves room for: with few lanes per wave a call has several waves per SIMD,
+// and their memory waits overlap only if they are resident together
+template <int WPS>
+__global__ void __launch_bounds__(64, WPS) zstd_frames_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
                                                          uint32_t lanes_per_wave, const uint8_t *__restrict__ src_base, uint8_t *__restrict__ dst_base,
-                                                         uint8_t *__restrict__ ws_base)
+                                                         uint8_t *__restrict__ ws_base, uint32_t debug)
 {
     if (threadIdx.x >= lanes_per_wave)
         return;
@@ -36,8 +39,12 @@ __global__ void __launch_bounds__(64) zstd_frames_kernel(const ZFrameJob *__rest
     if (j >= n_jobs)
         return;
     const ZFrameJob jb = jobs[j];
-    out_size[jb.idx] = zs::compressFrame(ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst);
+    out_size[jb.idx] = zs::compressFrame(ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, false, debug);
 }
+
+template __global__ void zstd_frames_kernel<2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
+template __global__ void zstd_frames_kernel<3>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
+template __global__ void zstd_frames_kernel<4>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
 
 // frames (scattered, padded slots) -> one contiguous buffer in the caller's order
 __global__ void __launch_bounds__(256) zstd_gather_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, const uint64_t *__restrict__ dst_off,
