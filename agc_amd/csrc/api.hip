@@ -50,7 +50,7 @@ struct agc_hip_ctx {
 
     // scratch
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_stage, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
-        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout;
+        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_maybe, d_fjobs;
 
     std::vector<SliceDesc> h_slices;
 
@@ -189,7 +189,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
-                      &c->d_zjobs, &c->d_zsize, &c->d_zout};
+                      &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_maybe, &c->d_fjobs};
     for (DevBuf *b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -528,6 +528,7 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
         sl[i].pad2 = 0;
         jobs[i].ref = rbase + roff[i];
         jobs[i].table = nullptr;
+        jobs[i].bloom = nullptr;
         jobs[i].ref_size = h_len[i];
         jobs[i].key_len = key_len;
         jobs[i].ht_mask = 0;
@@ -574,8 +575,15 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     uint8_t *tbase = nullptr;
     CHK(arena_alloc(c, tab_bytes, &tbase));
     HIPCHK(c, hipMemsetAsync(tbase, 0xFF, tab_bytes, c->stream));
-    for (uint32_t i = 0; i < n_refs; ++i)
+    // key filters (KEY_BLOOM_WORDS x 8 bytes each, zeroed; the insert kernel sets the bits)
+    uint8_t *bbase = nullptr;
+    const size_t bloom_bytes = (size_t)n_refs * KEY_BLOOM_WORDS * 8;
+    CHK(arena_alloc(c, bloom_bytes, &bbase));
+    HIPCHK(c, hipMemsetAsync(bbase, 0, bloom_bytes, c->stream));
+    for (uint32_t i = 0; i < n_refs; ++i) {
         jobs[i].table = tbase + toff[i];
+        jobs[i].bloom = (unsigned long long *)(bbase + (size_t)i * KEY_BLOOM_WORDS * 8);
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
     {
         KTimer t(c, AGC_HIP_K_INDEX);
@@ -585,11 +593,12 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     if (c->refs.size() <= max_gid)
-        c->refs.resize((size_t)max_gid + 1, RefDesc{nullptr, nullptr, 0, 0, 0, 0, 0, 0});
+        c->refs.resize((size_t)max_gid + 1, RefDesc{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0});
     for (uint32_t i = 0; i < n_refs; ++i) {
         RefDesc &r = c->refs[h_gid[i]];
         r.ref = jobs[i].ref;
         r.table = jobs[i].table;
+        r.bloom = jobs[i].bloom;
         r.ref_size = h_len[i];
         r.ht_mask = jobs[i].ht_mask;
         r.key_len = key_len;
@@ -727,15 +736,43 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
     }
     b.out_total = tot;
     b.segs.resize(n);
+    // estimate / cost vector: one "may match" bit per text position (key_filter_kernel) lets the parse skip literal runs
+    std::vector<FilterJob> fjobs;
+    std::vector<uint64_t> moff(n, 0);
+    if (mode != MODE_ENCODE) {
+        uint64_t words = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            moff[i] = words;
+            words += ((uint64_t)h_len[i] + 63) / 64 + 1;
+        }
+        CHK(ensure(c, c->d_maybe, words * 8 + 64));
+    }
     for (uint32_t p = 0; p < n; ++p) {
         const uint32_t i = order[p];
         SegDesc &s = b.segs[p];
+        s.maybe = nullptr;
         s.text = (h_rc && h_rc[i]) ? (const uint8_t *)c->d_stage.p + soff[i] : d_base + h_off[i];
         s.out_off = ooff[i];
         s.len = h_len[i];
         s.ref_slot = h_gid[i];
         s.flags = (h_prefix && h_prefix[i]) ? 1u : 0u;
         s.pad = i;
+        const RefDesc &rd = c->refs[h_gid[i]];
+        if (mode != MODE_ENCODE && rd.bloom && h_len[i] > 4 * WAVE) { // (short texts: not worth a block)
+            s.maybe = (const unsigned long long *)c->d_maybe.p + moff[i];
+            for (uint32_t ch = 0; ch < h_len[i]; ch += FILTER_CHUNK)
+                fjobs.push_back({s.text, rd.bloom, (unsigned long long *)c->d_maybe.p + moff[i], h_len[i], rd.key_len, ch, 0u});
+        }
+    }
+    if (!fjobs.empty()) {
+        CHK(ensure(c, c->d_fjobs, fjobs.size() * sizeof(FilterJob)));
+        HIPCHK(c, hipMemcpyAsync(c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), hipMemcpyHostToDevice, c->stream));
+        {
+            KTimer t(c, mode == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+            hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, c->stream, (const FilterJob *)c->d_fjobs.p);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // (fjobs is a local)
     }
     CHK(ensure(c, c->d_segs, (size_t)n * sizeof(SegDesc)));
     HIPCHK(c, hipMemcpyAsync(c->d_segs.p, b.segs.data(), (size_t)n * sizeof(SegDesc), hipMemcpyHostToDevice, c->stream));

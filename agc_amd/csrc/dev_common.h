@@ -19,9 +19,27 @@ constexpr uint32_t REF_TAIL_PAD = 64;    // bytes of INVALID_SYMBOL kept after e
 // long form: u64 = pos32<<32 | fp32.  pos = ref position / 4 exactly as ht16/ht32
 // hold it; fp = fingerprint of the key's hash (filter only; every candidate is
 // verified against the reference bytes).  All-ones = empty.
+// Key filter of a reference: a blocked Bloom filter over the 2-bit keys in its index (KEY_BLOOM_WORDS x 64 bits; per key one
+// word and three bits of it, from a cheap hash of the key -- its own hash, the index keeps MurMur64).  A text position whose
+// key is not in the filter cannot start a match.  key_filter_kernel turns that into one bit per text position ("may match")
+// for the estimate / cost-vector parses, whose texts are mostly literal runs (the non-matching half of a missing-middle
+// segment, wrong one-splitter candidates): the parse then skips from one candidate position to the next instead of probing
+// the index table in HBM at every position.
+constexpr uint32_t KEY_BLOOM_WORDS = 4096; // 32 KiB: 0.4 % false positives for the 15 k keys of a 60 kb reference
+__host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t &word, uint64_t &mask)
+{
+    const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
+    uint32_t h1 = (a ^ (b * 0x9E3779B1u)) * 0x85EBCA6Bu;
+    h1 ^= h1 >> 15;
+    const uint32_t h2 = h1 * 0xC2B2AE35u;
+    word = h1 >> 20; // 12 bits
+    mask = (1ULL << (h2 >> 26)) | (1ULL << ((h2 >> 20) & 63)) | (1ULL << ((h2 >> 14) & 63));
+}
+
 struct RefDesc {
     const uint8_t *ref;   // ref_size symbols + >= key_len + REF_TAIL_PAD bytes of 31
     const void *table;    // ht_mask+1 entries
+    const unsigned long long *bloom; // KEY_BLOOM_WORDS words (nullptr: none)
     uint32_t ref_size;
     uint32_t ht_mask;
     uint32_t key_len;
@@ -33,6 +51,7 @@ struct RefDesc {
 // One sequence to parse.
 struct SegDesc {
     const uint8_t *text;  // oriented symbols (already reverse-complemented if needed)
+    const unsigned long long *maybe; // estimate / cost vector: one bit per text position, 0 = certainly a literal (nullptr: none)
     uint64_t out_off;     // encode: byte offset in the scratch output; cost vector: u32 offset
     uint32_t len;
     uint32_t ref_slot;    // index into the RefDesc array

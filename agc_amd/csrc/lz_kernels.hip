@@ -276,9 +276,12 @@ struct ParseOut {
     uint32_t peak;  // estimate: largest cost seen at a loop-top check
 };
 
+// maybe: one bit per text position from key_filter_kernel (0 = the key at this position is valid and not in the reference's
+// index: a certain literal); nullptr: literal runs are found by probing the table (wide probe)
 template <int MODE>
 __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text, const uint32_t n,
-                             uint8_t *__restrict__ out, uint32_t *__restrict__ costs, const bool prefix_costs, uint8_t *win_lds)
+                             uint8_t *__restrict__ out, uint32_t *__restrict__ costs, const bool prefix_costs, uint8_t *win_lds,
+                             const unsigned long long *__restrict__ maybe)
 {
     const uint32_t lane = lane_id();
     const bool writer = lane == 0;
@@ -328,7 +331,43 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
         // N-run starts there.  The leading run of certain literals is emitted in one step; the
         // first other position is handled by the exact (reference-order) step below.
         // Only entered after an exact step found no match (long matches never pay for it).
-        if (try_wide) {
+        if (MODE != MODE_ENCODE && try_wide && maybe) {
+            // literal run by the filter bitmap: the next position that may match, up to 4096 positions ahead (one 8-byte load
+            // per lane); everything before it is a certain literal
+            const uint32_t w0i = i >> 6;
+            const uint32_t n_words = (n + 63) >> 6;
+            uint64_t mw = w0i + lane < n_words ? maybe[w0i + lane] : ~0ULL; // past the text: "stop"
+            if (lane == 0)
+                mw &= ~0ULL << (i & 63);
+            const uint64_t any = __ballot(mw != 0);
+            const uint32_t l = ctz64(any);                 // (lane w0i + lane >= n_words always votes)
+            const uint32_t first = (w0i + l) * 64 + (uint32_t)__builtin_ctzll(__shfl(mw, (int)l));
+            uint32_t stop_pos = any ? first : (w0i + WAVE) * 64;
+            // positions must satisfy q + key_len < n (the loop condition of the exact steps)
+            const uint32_t lim = n - key_len; // i + key_len < n holds here, so lim > i
+            if (stop_pos > lim)
+                stop_pos = lim;
+            const uint32_t f = stop_pos - i;
+            if (f) {
+                if (MODE == MODE_ESTIMATE) {
+                    if (est + f - 1 > peak)
+                        peak = est + f - 1; // loop-top checks of these f literal steps
+                    est += f;
+                } else {
+                    for (uint32_t t = lane; t < f; t += WAVE)
+                        costs[o + t] = 1;
+                }
+                o += f;
+                i += f;
+                pred_pos += f;
+                npl += f;
+                try_wide = !any && stop_pos < lim; // nothing found in this stretch: look at the next one
+                if (!try_wide)
+                    lit_streak = WIDE_AFTER; // the stop position gets its exact step; a literal there re-arms the skipping
+                continue;
+            }
+            try_wide = false;
+        } else if (try_wide) {
             const uint32_t q = i + lane;
             const uint32_t sa = q < n ? (uint32_t)wtext[q] : 0xFFu;
             const uint32_t sb = (lane < key_len + 2 && q + 64 < n) ? (uint32_t)wtext[q + 64] : 0xFFu;
@@ -425,7 +464,8 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                         peak = est + f - 1; // loop-top checks of these f literal steps
                     est += f;
                 } else {
-                    __builtin_amdgcn_s_waitcnt(0);
+                    // (no drain: positions at or after `o` hold no pending store -- a roll-back is always followed by a match
+                    // that covers the rolled-back positions and drains around its own stores)
                     if (lane < f)
                         costs[o + lane] = 1;
                 }
@@ -697,6 +737,9 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
 // One wavefront per segment: wave w of block b parses segment 4*b + w of the host's
 // longest-first list (the dispatcher hands blocks out in order, so the long segments start
 // first and the short ones fill the tail).
+// One wavefront per segment: wave w of block b parses segment 4*b + w of the host's
+// longest-first list (the dispatcher hands blocks out in order, so the long segments start
+// first and the short ones fill the tail).
 template <int MODE>
 __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs,
                                                        uint32_t n_segs, uint8_t *__restrict__ out_bytes,
@@ -714,11 +757,11 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
     uint8_t *win_lds = s_win[threadIdx.x >> 6];
     ParseOut r;
     if (MODE == MODE_ENCODE)
-        r = lz_parse<MODE>(rd, sd.text, sd.len, out_bytes + sd.out_off, nullptr, false, win_lds);
+        r = lz_parse<MODE>(rd, sd.text, sd.len, out_bytes + sd.out_off, nullptr, false, win_lds, nullptr);
     else if (MODE == MODE_ESTIMATE)
-        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, nullptr, false, win_lds);
+        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, nullptr, false, win_lds, sd.maybe);
     else
-        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, out_u32 + sd.out_off, (sd.flags & 1u) != 0, win_lds);
+        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, out_u32 + sd.out_off, (sd.flags & 1u) != 0, win_lds, sd.maybe);
     AGC_TRACE(9, r.value);
     if (lane_id() == 0) {
         res_value[sd.pad] = r.value; // sd.pad = index in the caller's order
@@ -747,11 +790,116 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__rest
 }
 
 // ---------------------------------------------------------------------------
+// Key filter: for every position of a text, may the key starting there be in the reference's index?
+// One block per (text, chunk of FILTER_CHUNK positions); the reference's filter (32 KiB) sits in LDS.  Each lane takes 16
+// consecutive positions per step: one 16-byte load, 2-bit packing, the two following lanes' words by shuffles (the last two
+// lanes of a wave load their followers themselves), then per position: key = a funnel shift of the packed window, three
+// multiplies for the filter hash, one LDS read.  Bit = 1 ("may match / let the exact step decide") when the key is in the
+// filter, contains a symbol outside ACGT, or runs past the end of the text.
+// ---------------------------------------------------------------------------
+constexpr uint32_t FILTER_CHUNK = 16384;
+
+struct FilterJob {
+    const uint8_t *text;
+    const unsigned long long *bloom;
+    unsigned long long *out;   // (len + 63) / 64 words
+    uint32_t len;
+    uint32_t key_len;
+    uint32_t chunk;            // first position of this block's chunk
+    uint32_t pad;
+};
+
+__device__ __forceinline__ void pack16(const uint8_t *__restrict__ text, uint32_t len, uint32_t pos, uint32_t &P, uint32_t &I)
+{
+    // 16 symbols at pos: P = 2-bit codes (first symbol most significant), I = mask of symbols > 3 (first symbol = bit 15);
+    // positions at or after len count as invalid
+    P = 0;
+    I = 0xFFFF;
+    if (pos + 16 <= len) {
+        const uint4 v = load16(text + pos);
+        auto pk = [](uint32_t w) { return ((w & 0x03030303u) * 0x40100401u) >> 24; };
+        auto iv = [](uint32_t w) {
+            uint32_t x = w & 0xFCFCFCFCu;
+            uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+            return ((nz >> 7) & 1u) << 3 | ((nz >> 15) & 1u) << 2 | ((nz >> 23) & 1u) << 1 | (nz >> 31);
+        };
+        P = (pk(v.x) << 24) | (pk(v.y) << 16) | (pk(v.z) << 8) | pk(v.w);
+        I = (iv(v.x) << 12) | (iv(v.y) << 8) | (iv(v.z) << 4) | iv(v.w);
+    } else if (pos < len) {
+        I = 0;
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t c = pos + j < len ? text[pos + j] : 4u;
+            P = (P << 2) | (c & 3u);
+            I = (I << 1) | (c > 3u);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__restrict__ jobs)
+{
+    const FilterJob jb = jobs[blockIdx.x];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[KEY_BLOOM_WORDS];
+    {
+        const uint4 *src = (const uint4 *)jb.bloom;
+        uint4 *dst = (uint4 *)s_bloom;
+        for (uint32_t t = threadIdx.x; t < KEY_BLOOM_WORDS / 2; t += blockDim.x)
+            dst[t] = src[t];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t k = jb.key_len;
+    const uint64_t kmask = (1ULL << (2 * k)) - 1ULL;     // key_len <= 29
+    const uint32_t imask = (1u << k) - 1u;
+    const uint32_t end = min(jb.len, jb.chunk + FILTER_CHUNK);
+    for (uint32_t base = jb.chunk + wave * 1024; base < end; base += 4 * 1024) {
+        const uint32_t pos = base + lane * 16;
+        uint32_t P, I;
+        pack16(jb.text, jb.len, pos, P, I);
+        uint32_t P1 = __shfl_down(P, 1), I1 = __shfl_down(I, 1), P2 = __shfl_down(P, 2), I2 = __shfl_down(I, 2);
+        if (lane >= 62) { // the followers of the last two lanes belong to the next step
+            if (lane == 63)
+                pack16(jb.text, jb.len, pos + 16, P1, I1);
+            pack16(jb.text, jb.len, pos + 32, P2, I2);
+            if (lane == 62) {
+                // P1 came from lane 63 by the shuffle; P2 is the chunk after lane 63's
+            }
+        }
+        // 96-bit window: symbols 0..15 (P), 16..31 (P1), 32..47 (P2); symbol s at bits [94 - 2s, 95 - 2s]
+        const uint64_t hi = ((uint64_t)P << 32) | P1;            // symbols 0..31
+        const uint64_t inv = ((uint64_t)I << 32) | ((uint64_t)I1 << 16) | I2; // symbol s <-> bit 47 - s
+        uint32_t bits = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            // key = symbols j .. j+k-1
+            const uint32_t top = 2 * j;                           // bits consumed before the key
+            uint64_t w = hi << top;                               // symbols j.. left aligned
+            if (top)
+                w |= (uint64_t)P2 >> (32 - top);
+            const uint64_t key = (w >> (64 - 2 * k)) & kmask;
+            const bool bad = ((uint32_t)(inv >> (48 - j - k)) & imask) != 0;
+            uint32_t bw;
+            uint64_t bm;
+            key_bloom_slot(key, bw, bm);
+            const bool in_f = (s_bloom[bw] & bm) == bm;
+            const bool past = !(pos + j + k < jb.len);
+            bits |= (uint32_t)(bad || in_f || past) << j;
+        }
+        // 4 lanes make one 64-bit word (positions ascending = bits ascending)
+        const uint64_t mine = (uint64_t)bits << (16 * (lane & 3));
+        uint64_t word = mine | __shfl_xor(mine, 1);
+        word |= __shfl_xor(word, 2);
+        if ((lane & 3) == 0 && pos < jb.len)
+            jb.out[pos >> 6] = word;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Index build.
 // ---------------------------------------------------------------------------
 struct IdxBuild {
     const uint8_t *ref;  // padded reference
     void *table;         // filled by the insert kernel (pre-set to all ones)
+    unsigned long long *bloom; // key filter (zeroed), filled by the insert kernel
     uint32_t ref_size;
     uint32_t key_len;
     uint32_t ht_mask;
@@ -808,6 +956,12 @@ __device__ void idx_insert_one(const IdxBuild &jb, uint32_t t)
         return;
     E *tab = (E *)jb.table;
     const uint64_t h = murmur64(x);
+    if (jb.bloom) {
+        uint32_t bw;
+        uint64_t bm;
+        key_bloom_slot(x, bw, bm);
+        atomicOr(&jb.bloom[bw], (unsigned long long)bm);
+    }
     const E fp = FPBITS == 16 ? (E)(h >> 48) : (E)(h >> 32);
     E cur = ((E)t << FPBITS) | fp;
     uint32_t slot = (uint32_t)h & jb.ht_mask;
