@@ -32,12 +32,18 @@ SYMBOLS = [
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
     "agc_hip_ref_lag_counts_dev",
     "agc_hip_zstd17_max_input", "agc_hip_zstd17_batch", "agc_hip_zstd17_cparams",
+    "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
 ]
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 vp = C.c_void_p
+
+
+class Packed(C.Structure):
+    """agc_hip_packed (include/agc_hip.h): a sample in the 2-bit HBM layout"""
+    _fields_ = [("d_words", C.c_void_p), ("d_esc_index", C.c_void_p), ("d_esc_bytes", C.c_void_p), ("n_symbols", C.c_uint64)]
 
 
 class AgcHipError(RuntimeError):
@@ -102,9 +108,17 @@ def load():
     L.agc_hip_zstd17_batch.argtypes = [vp, C.c_uint32, u8p, u64p, u8p, C.c_uint64, u64p]
     L.agc_hip_zstd17_cparams.argtypes = [C.c_uint64, u32p]
     L.agc_hip_zstd17_max_input.restype = C.c_uint32
+    L.agc_hip_packed_words_bytes.restype = C.c_uint64
+    L.agc_hip_packed_words_bytes.argtypes = [C.c_uint64]
+    L.agc_hip_packed_index_bytes.restype = C.c_uint64
+    L.agc_hip_packed_index_bytes.argtypes = [C.c_uint64]
+    L.agc_hip_pack_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
+    L.agc_hip_expand_dev.argtypes = [vp, C.POINTER(Packed), vp]
+    L.agc_hip_scan_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     for s in SYMBOLS:
         f = getattr(L, s)
-        if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count", "agc_hip_zstd17_max_input"):
+        if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count", "agc_hip_zstd17_max_input",
+                     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -129,10 +143,19 @@ class Context:
             raise AgcHipError(rc, "agc_hip_create failed (no HIP device?)")
         self.h = h
 
+    @classmethod
+    def from_handle(cls, handle):
+        """a view of an agc_hip_ctx that somebody else owns (the host compressor's): close() leaves it alone"""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.h = vp(handle) if not isinstance(handle, vp) else handle
+        self.borrowed = True
+        return self
+
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "borrowed", False):
             self.L.agc_hip_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         self.close()
@@ -212,6 +235,36 @@ class Context:
     def scan_contigs_dev(self, d_codes, ctg_off, k, cap=1 << 16):
         """-> (ctg, pos, dir, rc) of the accepted splitter hits."""
         return self._scan(self.L.agc_hip_scan_contigs_dev, d_codes, ctg_off, k, cap)
+
+    # ---- 2-bit packed samples ------------------------------------------------
+    def pack_dev(self, d_codes_tensor, n_symbols=None):
+        """torch uint8 tensor of codes on the GPU -> (Packed struct, tensors that back it).  The escape buffer is sized by a
+        first attempt and grown if the sample has more escaped blocks."""
+        import torch
+        n = int(d_codes_tensor.numel() if n_symbols is None else n_symbols)
+        dev = d_codes_tensor.device
+        words = torch.empty(int(self.L.agc_hip_packed_words_bytes(n)) // 4 + 1, dtype=torch.int32, device=dev)
+        index = torch.empty(int(self.L.agc_hip_packed_index_bytes(n)) // 4 + 1, dtype=torch.int32, device=dev)
+        cap = 64
+        while True:
+            esc = torch.empty(max(cap, 1) * 1024, dtype=torch.uint8, device=dev)
+            cnt = np.zeros(1, np.uint64)
+            rc = self.L.agc_hip_pack_dev(self.h, d_codes_tensor.data_ptr(), n, words.data_ptr(), index.data_ptr(), esc.data_ptr(), cap, _p(cnt, u64p))
+            if rc == ECAP:
+                cap = int(cnt[0]) + 16
+                continue
+            self._chk(rc)
+            break
+        pk = Packed(words.data_ptr(), index.data_ptr(), esc.data_ptr(), n)
+        return pk, (words, index, esc)
+
+    def expand_dev(self, pk, d_codes_ptr):
+        self._chk(self.L.agc_hip_expand_dev(self.h, C.byref(pk), d_codes_ptr))
+        self._chk(self.L.agc_hip_sync(self.h))
+
+    def scan_packed_dev(self, pk, ctg_off, k, cap=1 << 16):
+        fn = lambda h, arg, *rest: self.L.agc_hip_scan_packed_dev(h, C.byref(arg), *rest)
+        return self._scan(fn, pk, ctg_off, k, cap)
 
     def scan_contigs(self, codes, ctg_off, k, cap=1 << 16):
         codes = _a(codes, np.uint8)

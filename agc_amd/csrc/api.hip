@@ -39,7 +39,9 @@ struct agc_hip_ctx {
 
     // splitter set
     std::vector<uint64_t> spl;       // host copy (unique)
-    DevBuf d_table, d_bloom, d_bloom2;
+    DevBuf d_table, d_bloom, d_bloom2, d_sbloom;
+    uint32_t sbloom_k = 0;          // the packed scan's suffix filter: built for this k ...
+    size_t sbloom_n = ~(size_t)0;   // ... and this many splitters
     uint64_t table_mask = 0;
 
     // references
@@ -186,7 +188,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
+    DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_sbloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
                       &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_maybe, &c->d_fjobs};
@@ -356,6 +358,50 @@ uint64_t agc_hip_splitters_count(const agc_hip_ctx *c) { return c ? c->spl.size(
 // ---------------------------------------------------------------------------
 // scan
 // ---------------------------------------------------------------------------
+} // extern "C"
+
+// sorts the raw hits and applies the reference's "reset the k-mer after a hit" rule (agc_compressor.cpp:2029): the next hit of the
+// same contig must end at least k symbols later
+static int deliver_hits(agc_hip_ctx *c, uint32_t n_found, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap, uint64_t *h_n_hits,
+                        uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+{
+    std::vector<ScanHit> hits(n_found);
+    if (n_found) {
+        HIPCHK(c, hipMemcpyAsync(hits.data(), c->d_hits.p, (size_t)n_found * sizeof(ScanHit), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    std::sort(hits.begin(), hits.end(), [](const ScanHit &x, const ScanHit &y) { return x.pos < y.pos; });
+
+    // accept_hits: after a hit the reference resets the k-mer (agc_compressor.cpp:2029), so the next
+    // hit of the same contig must end at least k symbols later.
+    uint64_t n_acc = 0;
+    uint32_t ci = 0;
+    bool have_last = false;
+    uint64_t last = 0;
+    for (const ScanHit &h : hits) {
+        while (ci + 1 < n_ctg && h.pos >= h_ctg_off[ci + 1]) {
+            ++ci;
+            have_last = false;
+        }
+        if (have_last && h.pos < last + k)
+            continue;
+        have_last = true;
+        last = h.pos;
+        if (n_acc < cap) {
+            h_hit_ctg[n_acc] = ci;
+            h_hit_pos[n_acc] = h.pos - h_ctg_off[ci];
+            h_hit_dir[n_acc] = h.dir;
+            h_hit_rc[n_acc] = h.rc;
+        }
+        ++n_acc;
+    }
+    *h_n_hits = n_acc;
+    return n_acc > cap ? AGC_HIP_ECAP : AGC_HIP_OK;
+}
+
+
+extern "C" {
+
 int agc_hip_scan_contigs_dev(agc_hip_ctx *c, const uint8_t *d_codes, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
                              uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir,
                              uint64_t *h_hit_rc)
@@ -425,38 +471,7 @@ int agc_hip_scan_contigs_dev(agc_hip_ctx *c, const uint8_t *d_codes, const uint6
             break;
         dev_cap = n_found;
     }
-    std::vector<ScanHit> hits(n_found);
-    if (n_found) {
-        HIPCHK(c, hipMemcpyAsync(hits.data(), c->d_hits.p, (size_t)n_found * sizeof(ScanHit), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    std::sort(hits.begin(), hits.end(), [](const ScanHit &x, const ScanHit &y) { return x.pos < y.pos; });
-
-    // accept_hits: after a hit the reference resets the k-mer (agc_compressor.cpp:2029), so the next
-    // hit of the same contig must end at least k symbols later.
-    uint64_t n_acc = 0;
-    uint32_t ci = 0;
-    bool have_last = false;
-    uint64_t last = 0;
-    for (const ScanHit &h : hits) {
-        while (ci + 1 < n_ctg && h.pos >= h_ctg_off[ci + 1]) {
-            ++ci;
-            have_last = false;
-        }
-        if (have_last && h.pos < last + k)
-            continue;
-        have_last = true;
-        last = h.pos;
-        if (n_acc < cap) {
-            h_hit_ctg[n_acc] = ci;
-            h_hit_pos[n_acc] = h.pos - h_ctg_off[ci];
-            h_hit_dir[n_acc] = h.dir;
-            h_hit_rc[n_acc] = h.rc;
-        }
-        ++n_acc;
-    }
-    *h_n_hits = n_acc;
-    return n_acc > cap ? AGC_HIP_ECAP : AGC_HIP_OK;
+    return deliver_hits(c, n_found, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
 }
 
 int agc_hip_scan_contigs(agc_hip_ctx *c, const uint8_t *h_codes, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
@@ -477,6 +492,167 @@ int agc_hip_scan_contigs(agc_hip_ctx *c, const uint8_t *h_codes, const uint64_t 
         off[i] = h_ctg_off[i] - lo;
     return agc_hip_scan_contigs_dev(c, (const uint8_t *)c->d_in.p, off.data(), n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos,
                                     h_hit_dir, h_hit_rc);
+}
+
+
+// ---------------------------------------------------------------------------
+// 2-bit packed samples
+// ---------------------------------------------------------------------------
+uint64_t agc_hip_packed_words_bytes(uint64_t n_symbols) { return ((n_symbols + PACK_BLOCK - 1) / PACK_BLOCK) * (PACK_BLOCK / 4) + 64; }
+uint64_t agc_hip_packed_index_bytes(uint64_t n_symbols) { return ((n_symbols + PACK_BLOCK - 1) / PACK_BLOCK) * 4 + 64; }
+
+int agc_hip_pack_dev(agc_hip_ctx *c, const uint8_t *d_codes, uint64_t n_symbols, uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes,
+                     uint64_t esc_cap_blocks, uint64_t *h_n_esc_blocks)
+{
+    if (!c || !h_n_esc_blocks || (n_symbols && (!d_codes || !d_words || !d_esc_index)) || (esc_cap_blocks && !d_esc_bytes))
+        return AGC_HIP_EINVAL;
+    *h_n_esc_blocks = 0;
+    if (!n_symbols)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure(c, c->d_counter, 64));
+    HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 4, c->stream));
+    const uint64_t n_blocks = (n_symbols + PACK_BLOCK - 1) / PACK_BLOCK;
+    {
+        KTimer t(c, AGC_HIP_K_PREPROCESS);
+        hipLaunchKernelGGL(pack_codes_kernel, dim3((uint32_t)std::min<uint64_t>((n_blocks + 3) / 4, 65536)), dim3(256), 0, c->stream, d_codes, n_symbols,
+                           d_words, d_esc_index, d_esc_bytes, (uint32_t *)c->d_counter.p, (uint32_t)std::min<uint64_t>(esc_cap_blocks, 0x7fffffffu));
+    }
+    HIPCHK(c, hipGetLastError());
+    uint32_t cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_counter.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *h_n_esc_blocks = cnt;
+    return cnt > esc_cap_blocks ? AGC_HIP_ECAP : AGC_HIP_OK;
+}
+
+int agc_hip_expand_dev(agc_hip_ctx *c, const agc_hip_packed *pk, uint8_t *d_codes)
+{
+    if (!c || !pk || (pk->n_symbols && (!pk->d_words || !pk->d_esc_index || !d_codes)))
+        return AGC_HIP_EINVAL;
+    if (!pk->n_symbols)
+        return AGC_HIP_OK;
+    if ((uintptr_t)d_codes & 15)
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const PackedView pv = {pk->d_words, pk->d_esc_index, pk->d_esc_bytes, pk->n_symbols};
+    const uint64_t n_blocks = (pk->n_symbols + PACK_BLOCK - 1) / PACK_BLOCK;
+    {
+        KTimer t(c, AGC_HIP_K_PREPROCESS);
+        hipLaunchKernelGGL(expand_codes_kernel, dim3((uint32_t)std::min<uint64_t>((n_blocks + 3) / 4, 65536)), dim3(256), 0, c->stream, pv, d_codes);
+    }
+    HIPCHK(c, hipGetLastError());
+    return AGC_HIP_OK;
+}
+
+// filter over the last 16 symbols of every splitter and of its reverse complement, for k-mer length k (cached per k)
+static int sbloom_upload(agc_hip_ctx *c, uint32_t k)
+{
+    if (c->sbloom_k == k && c->sbloom_n == c->spl.size() && c->d_sbloom.p)
+        return AGC_HIP_OK;
+    std::vector<uint32_t> bl(SBLOOM_WORDS, 0);
+    const uint32_t lshift = 64 - 2 * k;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    auto rev2h = [](uint64_t x) {
+        x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+        x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+        return __builtin_bswap64(x);
+    };
+    for (uint64_t x : c->spl) {
+        const uint64_t dir = (x >> lshift) & kmask;                 // right-aligned, last symbol in the low bits
+        const uint64_t rc = (rev2h(~dir) >> lshift) & kmask;
+        for (uint64_t v : {dir, rc}) {
+            uint32_t w, m;
+            sbloom_slot((uint32_t)v, w, m);
+            bl[w] |= m;
+        }
+    }
+    CHK(ensure(c, c->d_sbloom, SBLOOM_WORDS * 4));
+    HIPCHK(c, hipMemcpyAsync(c->d_sbloom.p, bl.data(), SBLOOM_WORDS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sbloom_k = k;
+    c->sbloom_n = c->spl.size();
+    return AGC_HIP_OK;
+}
+
+int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap,
+                            uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+{
+    if (!c || !pk || !h_ctg_off || !h_n_hits || k < 16 || k > 32)
+        return AGC_HIP_EINVAL; // (k < 16: the last-16-symbols filter does not apply; expand and use agc_hip_scan_contigs_dev)
+    if (cap && (!h_hit_ctg || !h_hit_pos || !h_hit_dir || !h_hit_rc))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    *h_n_hits = 0;
+    if (!c->d_table.p)
+        CHK(splitters_upload(c));
+    const uint64_t total = n_ctg ? h_ctg_off[n_ctg] - h_ctg_off[0] : 0;
+    if (!total)
+        return AGC_HIP_OK;
+    if (!pk->d_words || !pk->d_esc_index || h_ctg_off[n_ctg] > pk->n_symbols)
+        return AGC_HIP_EINVAL;
+    CHK(sbloom_upload(c, k));
+    // ranges: pieces of about range_len symbols whose inner boundaries are multiples of PACK_BLOCK in the buffer
+    const uint64_t target_waves = 4096ULL * 4;
+    uint64_t range_len = (total / target_waves + PACK_BLOCK - 1) / PACK_BLOCK * PACK_BLOCK;
+    range_len = std::min<uint64_t>(std::max<uint64_t>(range_len, 8 * PACK_BLOCK), 256 * PACK_BLOCK);
+    std::vector<ScanRange> ranges;
+    for (uint32_t ci = 0; ci < n_ctg; ++ci) {
+        const uint64_t b = h_ctg_off[ci], e = h_ctg_off[ci + 1];
+        if (e < b)
+            return AGC_HIP_EINVAL;
+        if (e - b < k)
+            continue;
+        for (uint64_t p = b; p < e;) {
+            uint64_t q = (p + range_len) & ~(uint64_t)(PACK_BLOCK - 1);
+            if (q >= e || e - q < PACK_BLOCK)
+                q = e;
+            ranges.push_back({b, e, p, q});
+            p = q;
+        }
+    }
+    if (ranges.empty())
+        return AGC_HIP_OK;
+    if (ranges.size() > 0x7fffffffULL)
+        return AGC_HIP_EINVAL;
+    CHK(ensure(c, c->d_ranges, ranges.size() * sizeof(ScanRange)));
+    CHK(ensure(c, c->d_counter, 64));
+    HIPCHK(c, hipMemcpyAsync(c->d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), hipMemcpyHostToDevice, c->stream));
+    static bool lds_set = false;
+    if (!lds_set) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)scan_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SBLOOM_WORDS * 4));
+        lds_set = true;
+    }
+    uint32_t dev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(total / 2000 + 4096, c->d_hits.cap / sizeof(ScanHit)), 1u << 30);
+    uint32_t n_found = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        CHK(ensure(c, c->d_hits, (size_t)dev_cap * sizeof(ScanHit)));
+        HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 4, c->stream));
+        ScanPackedArgs a;
+        a.pv = {pk->d_words, pk->d_esc_index, pk->d_esc_bytes, pk->n_symbols};
+        a.ranges = (const ScanRange *)c->d_ranges.p;
+        a.n_ranges = (uint32_t)ranges.size();
+        a.k = k;
+        a.table = (const uint64_t *)c->d_table.p;
+        a.table_mask = c->table_mask;
+        a.sbloom = (const uint32_t *)c->d_sbloom.p;
+        a.bloom2 = (const uint32_t *)c->d_bloom2.p;
+        a.hits = (ScanHit *)c->d_hits.p;
+        a.n_hits = (uint32_t *)c->d_counter.p;
+        a.cap = dev_cap;
+        const uint32_t grid = grid_for((uint32_t)ranges.size(), 16, 256); // one 1024-thread block per CU (128 KiB of LDS each)
+        {
+            KTimer t(c, AGC_HIP_K_SCAN);
+            hipLaunchKernelGGL(scan_packed_kernel, dim3(grid), dim3(1024), SBLOOM_WORDS * 4, c->stream, a);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&n_found, c->d_counter.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_found <= dev_cap)
+            break;
+        dev_cap = n_found;
+    }
+    return deliver_hits(c, n_found, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
 }
 
 // ---------------------------------------------------------------------------

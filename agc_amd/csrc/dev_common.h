@@ -75,6 +75,26 @@ struct ScanRange {
     uint64_t end;         // one past the last
 };
 
+// A sample resident in HBM in the 2-bit layout: symbol i of the buffer (contigs back to back) sits at bits [2*(i & 15),
+// +1] of 32-bit word i >> 4.  Blocks of PACK_BLOCK symbols that contain anything outside ACGT (N runs, IUPAC codes) are
+// "escaped": kept verbatim, one byte per symbol, in esc_bytes; esc_index[block] = slot there or -1.  0.25 B per symbol for
+// clean sequence, 1.25 B for escaped blocks.
+constexpr uint32_t PACK_BLOCK = 1024;
+struct PackedView {
+    const uint32_t *words;
+    const int32_t *esc_index;
+    const uint8_t *esc_bytes;
+    uint64_t n_symbols;
+};
+
+constexpr uint32_t SBLOOM_WORDS = 32768; // 128 KiB of LDS: filter over the last 16 symbols of the splitters (both strands)
+__host__ __device__ inline void sbloom_slot(uint32_t w16, uint32_t &word, uint32_t &mask)
+{
+    const uint32_t m = w16 * 0x9E3779B1u;
+    word = m >> 17; // 15 bits
+    mask = (1u << ((m >> 12) & 31)) | (1u << ((m >> 7) & 31)) | (1u << ((m >> 2) & 31));
+}
+
 struct ScanHit {
     uint64_t pos;         // absolute offset of the LAST symbol of the k-mer
     uint64_t dir;         // left-aligned, as CKmer::kmer_dir (kmer.h:284-301)

@@ -78,6 +78,22 @@ int agc_cmp_prepare_sample_dev(void *h, const char *sample_name, uint32_t n_ctg,
         names.emplace_back(contig_names[i]);
     return ((CAGCCompressor *)h)->PrepareSampleDevice(sample_name, names, d_codes, ctg_off) ? 1 : 0;
 }
+int agc_cmp_prepare_sample_packed_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const void *packed,
+                                      const uint64_t *ctg_off)
+{
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < n_ctg; ++i)
+        names.emplace_back(contig_names[i]);
+    return ((CAGCCompressor *)h)->PrepareSamplePackedDevice(sample_name, names, packed, ctg_off) ? 1 : 0;
+}
+int agc_cmp_add_sample_packed_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const void *packed,
+                                  const uint64_t *ctg_off)
+{
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < n_ctg; ++i)
+        names.emplace_back(contig_names[i]);
+    return ((CAGCCompressor *)h)->AddSamplePackedDevice(sample_name, names, packed, ctg_off) ? 1 : 0;
+}
 int agc_cmp_commit_prepared(void *h) { return ((CAGCCompressor *)h)->CommitPrepared() ? 1 : 0; }
 
 int agc_cmp_close(void *h, uint32_t n_threads) { return ((CAGCCompressor *)h)->Close(n_threads) ? 1 : 0; }

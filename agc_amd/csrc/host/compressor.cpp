@@ -485,6 +485,30 @@ bool CAGCCompressor::AddSampleDevice(const std::string &sample_name, const std::
     return PrepareSampleDevice(sample_name, contig_names, d_codes, ctg_off) && CommitPrepared();
 }
 
+bool CAGCCompressor::AddSamplePackedDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const void *packed,
+                                           const uint64_t *ctg_off)
+{
+    return PrepareSamplePackedDevice(sample_name, contig_names, packed, ctg_off) && CommitPrepared();
+}
+
+bool CAGCCompressor::PrepareSamplePackedDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const void *packed,
+                                               const uint64_t *ctg_off)
+{
+    Impl &I = *p;
+    if (!I.created || !packed)
+        return false;
+    const agc_hip_packed &pk = *(const agc_hip_packed *)packed;
+    // byte staging copy for the LZ kernels (context-owned buffer, valid until the next sample)
+    uint8_t *d_codes = nullptr;
+    if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, pk.n_symbols + 64, &d_codes)), "sample_buffer") ||
+        !I.hip_ok(DEVTI(agc_hip_expand_dev(I.hip, &pk, d_codes)), "expand"))
+        return false;
+    I.packed_sample = pk;
+    const bool ok = PrepareSampleDevice(sample_name, contig_names, d_codes, ctg_off);
+    I.packed_sample.n_symbols = 0; // (scans of the commit phase -- adaptive mode -- run inside PrepareSampleDevice as well)
+    return ok;
+}
+
 // scan + classification + speculative encode of a sample, against the state this process has NOW; nothing is registered
 // yet.  d_codes must stay untouched until CommitPrepared.  In the multi-GPU mode a rank calls this for its next sample
 // while earlier samples are still being committed elsewhere (agc_amd/dist.py).

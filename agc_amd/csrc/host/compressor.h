@@ -92,6 +92,13 @@ public:
     bool PrepareSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
                              const uint64_t *ctg_off);
     bool CommitPrepared();
+    // the same for a sample resident in HBM in the 2-bit layout (include/agc_hip.h: agc_hip_packed; contig c = symbols
+    // [ctg_off[c], ctg_off[c+1]) of the packed buffer): the splitter scan reads the packed words, the LZ kernels a byte staging
+    // copy expanded inside the call
+    bool PrepareSamplePackedDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const void *packed,
+                                   const uint64_t *ctg_off);
+    bool AddSamplePackedDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const void *packed,
+                               const uint64_t *ctg_off);
 
     // src/core/agc_compressor.cpp:2094-2115 (close_compression) + ~CArchive
     bool Close(uint32_t no_threads);

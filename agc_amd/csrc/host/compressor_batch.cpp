@@ -238,8 +238,11 @@ int CAGCCompressor::Impl::scan_batch(const std::vector<uint64_t> &ctg_off, uint3
             h_rc.resize(cap);
         }
         cap = h_ctg.size();
-        int rc = DEVT(agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
-                                               h_rc.data()));
+        int rc = (packed_sample.n_symbols && k >= 16)
+                     ? DEVT(agc_hip_scan_packed_dev(hip, &packed_sample, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(),
+                                                    h_dir.data(), h_rc.data()))
+                     : DEVT(agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
+                                                     h_rc.data()));
         if (rc == AGC_HIP_ECAP) {
             cap = n_hits;
             continue;

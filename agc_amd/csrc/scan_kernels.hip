@@ -252,6 +252,253 @@ __global__ void __launch_bounds__(1024, 8) scan_kernel(ScanArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// 2-bit packed samples: pack / expand / scan
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack4le(uint32_t w)
+{
+    // 4 symbols (low 2 bits of each byte, first symbol in the low byte) -> 8 bits, first symbol in the LOW bits
+    uint32_t x = w & 0x03030303u;
+    x = (x | (x >> 6)) & 0x000F000Fu;
+    return (x | (x >> 12)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t unpack4le(uint32_t b)
+{
+    uint32_t x = b & 0xFFu;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    return (x | (x << 6)) & 0x03030303u;
+}
+// reverse the order of the sixteen 2-bit groups of a word
+__device__ __forceinline__ uint32_t rev2_32(uint32_t x)
+{
+    x = __brev(x);
+    return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+}
+
+// codes (1 B per symbol) -> packed words + escaped blocks; one wave per block of PACK_BLOCK symbols
+__global__ void __launch_bounds__(256) pack_codes_kernel(const uint8_t *__restrict__ codes, uint64_t n, uint32_t *__restrict__ words,
+                                                         int32_t *__restrict__ esc_index, uint8_t *__restrict__ esc_bytes,
+                                                         uint32_t *__restrict__ esc_count, uint32_t esc_cap)
+{
+    const uint64_t n_blocks = (n + PACK_BLOCK - 1) / PACK_BLOCK;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t blk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < n_blocks; blk += (uint64_t)gridDim.x * 4) {
+        const uint64_t g = blk * PACK_BLOCK + (uint64_t)lane * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g + 16 <= n)
+            __builtin_memcpy(&v, codes + g, 16);
+        else if (g < n) {
+            uint8_t tmp[16];
+            for (uint32_t j = 0; j < 16; ++j)
+                tmp[j] = g + j < n ? codes[g + j] : 0;
+            __builtin_memcpy(&v, tmp, 16);
+        }
+        const bool high = ((v.x | v.y | v.z | v.w) & 0xFCFCFCFCu) != 0;
+        const uint64_t any = __ballot(high);
+        int32_t slot = -1;
+        if (any) {
+            uint32_t s = 0;
+            if (lane == 0)
+                s = atomicAdd(esc_count, 1u);
+            s = (uint32_t)__shfl((int)s, 0);
+            if (s < esc_cap) {
+                slot = (int32_t)s;
+                *(uint4 *)(esc_bytes + (uint64_t)s * PACK_BLOCK + lane * 16) = v;
+            } else
+                slot = -2; // over capacity: the caller retries with a larger buffer
+        }
+        if (lane == 0)
+            esc_index[blk] = slot;
+        // (escaped blocks: symbols outside ACGT leave their two low bits, which nobody reads)
+        words[g >> 4] = pack4le(v.x) | (pack4le(v.y) << 8) | (pack4le(v.z) << 16) | (pack4le(v.w) << 24);
+    }
+}
+
+// packed -> codes (1 B per symbol), the staging form the LZ kernels read; one wave per block
+__global__ void __launch_bounds__(256) expand_codes_kernel(PackedView pv, uint8_t *__restrict__ codes)
+{
+    const uint64_t n = pv.n_symbols;
+    const uint64_t n_blocks = (n + PACK_BLOCK - 1) / PACK_BLOCK;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t blk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < n_blocks; blk += (uint64_t)gridDim.x * 4) {
+        const uint64_t g = blk * PACK_BLOCK + (uint64_t)lane * 16;
+        if (g >= n)
+            continue;
+        const int32_t slot = pv.esc_index[blk];
+        uint4 v;
+        if (slot >= 0)
+            v = *(const uint4 *)(pv.esc_bytes + (uint64_t)slot * PACK_BLOCK + lane * 16);
+        else {
+            const uint32_t w = pv.words[g >> 4];
+            v = make_uint4(unpack4le(w), unpack4le(w >> 8), unpack4le(w >> 16), unpack4le(w >> 24));
+        }
+        if (g + 16 <= n)
+            *(uint4 *)(codes + g) = v; // (the output buffer is 16-byte aligned)
+        else {
+            uint8_t tmp[16];
+            __builtin_memcpy(tmp, &v, 16);
+            for (uint32_t j = 0; g + j < n; ++j)
+                codes[g + j] = tmp[j];
+        }
+    }
+}
+
+// ---- splitter scan over a packed sample ----
+// Same contract as scan_kernel (every position whose canonical k-mer is a splitter), different first-level test: a k-mer
+// can only be a splitter if its LAST 16 SYMBOLS are the last 16 symbols of a splitter or of a splitter's reverse
+// complement, and that 32-bit word costs one funnel shift of the packed stream per position -- no rolling of two strands,
+// no canonical select.  A 128 KiB filter over those words lives in LDS (one 1024-thread block per CU); the survivors
+// (~3 %) get the full k-mer, its canonical form, the second-level filter and the exact table as before.
+struct ScanPackedArgs {
+    PackedView pv;
+    const ScanRange *ranges;   // begin / end multiples of 16 symbols relative to the buffer, except at contig ends
+    uint32_t n_ranges;
+    uint32_t k;
+    const uint64_t *table;
+    uint64_t table_mask;
+    const uint32_t *sbloom;    // SBLOOM_WORDS words (copied to LDS)
+    const uint32_t *bloom2;
+    ScanHit *hits;
+    uint32_t *n_hits;
+    uint32_t cap;
+};
+
+// 16 symbols at the 16-aligned buffer position g (may lie before 0): P = 2-bit codes, first symbol most significant;
+// I = invalid mask (first symbol = bit 15): outside ACGT or outside the contig [cb, ce)
+__device__ __forceinline__ void load_chunk(const PackedView &pv, int64_t g, uint64_t cb, uint64_t ce, uint32_t &P, uint32_t &I)
+{
+    P = 0;
+    I = 0xFFFF;
+    if (g + 16 <= (int64_t)cb || g >= (int64_t)ce)
+        return;
+    const int32_t slot = pv.esc_index[(uint64_t)g / PACK_BLOCK];
+    if (slot < 0) {
+        P = rev2_32(pv.words[(uint64_t)g >> 4]);
+        I = 0;
+    } else {
+        const uint4 v = *(const uint4 *)(pv.esc_bytes + (uint64_t)slot * PACK_BLOCK + ((uint64_t)g & (PACK_BLOCK - 1)));
+        P = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
+        I = (inv4(v.x) << 12) | (inv4(v.y) << 8) | (inv4(v.z) << 4) | inv4(v.w);
+    }
+    if ((int64_t)cb > g) // the first cb - g symbols belong to the previous contig
+        I |= ~(0xFFFFu >> (uint32_t)((int64_t)cb - g)) & 0xFFFFu;
+    if ((int64_t)ce < g + 16) // symbols from ce on belong to the next one
+        I |= 0xFFFFu >> (uint32_t)((int64_t)ce - g);
+}
+
+__global__ void __launch_bounds__(1024, 4) scan_packed_kernel(ScanPackedArgs a)
+{
+    extern __shared__ uint32_t s_sbloom[];
+    for (uint32_t t = threadIdx.x; t < SBLOOM_WORDS; t += blockDim.x)
+        s_sbloom[t] = a.sbloom[t];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t k = a.k;
+    const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    const uint32_t lshift = 64 - 2 * k;
+    const uint64_t wmask = k == 32 ? 0xFFFFFFFFULL : ((1ULL << k) - 1ULL);
+
+    for (uint32_t r = blockIdx.x * waves_per_block + wave; r < a.n_ranges; r += gridDim.x * waves_per_block) {
+        const ScanRange rg = a.ranges[r];
+        const int64_t first = (int64_t)(rg.begin & ~(uint64_t)(PACK_BLOCK - 1));
+        uint32_t carryP1, carryP2, carryI1, carryI2; // chunks right before the step (1 = immediately before)
+        {
+            uint32_t P = 0, I = 0xFFFF;
+            if (lane < 2)
+                load_chunk(a.pv, first - 16 * (int64_t)(lane + 1), rg.ctg_begin, rg.ctg_end, P, I);
+            carryP1 = __shfl(P, 0);
+            carryI1 = __shfl(I, 0);
+            carryP2 = __shfl(P, 1);
+            carryI2 = __shfl(I, 1);
+        }
+        for (int64_t base = first; base < (int64_t)rg.end; base += PACK_BLOCK) {
+            const int64_t g = base + (int64_t)lane * 16;
+            uint32_t P, I;
+            load_chunk(a.pv, g, rg.ctg_begin, rg.ctg_end, P, I);
+            uint32_t P1 = __shfl_up(P, 1), I1 = __shfl_up(I, 1);
+            uint32_t P2 = __shfl_up(P, 2), I2 = __shfl_up(I, 2);
+            if (lane == 0) {
+                P1 = carryP1;
+                I1 = carryI1;
+                P2 = carryP2;
+                I2 = carryI2;
+            } else if (lane == 1) {
+                P2 = carryP1;
+                I2 = carryI1;
+            }
+            carryP1 = __shfl(P, 63);
+            carryI1 = __shfl(I, 63);
+            carryP2 = __shfl(P, 62);
+            carryI2 = __shfl(I, 62);
+
+            // positions of this chunk the range reports: begin <= g + j < end
+            uint32_t vmask = 0xFFFFu;
+            if ((int64_t)rg.begin > g)
+                vmask &= (int64_t)rg.begin - g >= 16 ? 0u : (0xFFFFu << (uint32_t)((int64_t)rg.begin - g));
+            if ((int64_t)rg.end < g + 16)
+                vmask &= (int64_t)rg.end <= g ? 0u : (0xFFFFu >> (uint32_t)(g + 16 - (int64_t)rg.end));
+            if (!vmask)
+                continue;
+
+            // pass 1: filter on the last 16 symbols of the k-mer ending at every own position
+            uint32_t pass = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t w16 = j == 15 ? P : __builtin_amdgcn_alignbit(P1, P, 2 * (15 - j)); // symbols j-15 .. j
+                uint32_t bw, bm;
+                sbloom_slot(w16, bw, bm);
+                pass |= (uint32_t)((s_sbloom[bw] & bm) == bm) << j;
+            }
+            pass &= vmask;
+            if (pass) {
+                // window validity: symbols (j-k+1 .. j) <-> inv bits (15-j) .. (15-j+k-1)
+                const uint64_t inv = ((uint64_t)I2 << 32) | ((uint64_t)I1 << 16) | I;
+                const uint64_t hi = ((uint64_t)P2 << 32) | P1; // symbols -32..-1
+                const uint64_t w_lo = (hi << 32) | P;           // symbols -16..15
+                const uint64_t w_hi = hi >> 32;                 // symbols -32..-17
+                while (pass) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(pass);
+                    pass &= pass - 1;
+                    if (((inv >> (15 - j)) & wmask) != 0)
+                        continue;
+                    const uint32_t sft = 2 * (15 - j);
+                    uint64_t dir = w_lo >> sft;
+                    if (sft)
+                        dir |= w_hi << (64 - sft);
+                    dir &= kmask;
+                    const uint64_t rcv = (rev2(~dir) >> lshift) & kmask;
+                    const uint64_t dl = dir << lshift, rl = rcv << lshift;
+                    const uint64_t can = dl < rl ? dl : rl;
+                    const uint64_t h = splitter_hash(can);
+                    uint32_t w2, m2;
+                    bloom2_slot(h, w2, m2);
+                    if ((a.bloom2[w2] & m2) != m2)
+                        continue;
+                    uint64_t slot = h & a.table_mask;
+                    for (;;) {
+                        const uint64_t e = a.table[slot];
+                        if (e == can) {
+                            const uint32_t idx = atomicAdd(a.n_hits, 1u);
+                            if (idx < a.cap) {
+                                a.hits[idx].pos = (uint64_t)g + j;
+                                a.hits[idx].dir = dl;
+                                a.hits[idx].rc = rl;
+                            }
+                            break;
+                        }
+                        if (e == ~0ULL)
+                            break;
+                        slot = (slot + 1) & a.table_mask;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a1: raw FASTA body -> codes.  Three passes: per-block kept counts, scan of the block
 // counts (single block), scatter.
 // ---------------------------------------------------------------------------

@@ -81,11 +81,11 @@ class DistCompressor:
         for i in range(start, n_total):
             owner = self.owner_of(i)
             if prefetch and prepared is None and nxt is not None:
-                self.cmp.prepare_sample_dev(*get_sample(nxt))
+                self._prepare(get_sample(nxt))
                 prepared = nxt
             if self.rank == owner:
                 if prepared is None:
-                    self.cmp.prepare_sample_dev(*get_sample(i))
+                    self._prepare(get_sample(i))
                     prepared = i
                 assert prepared == i
                 self._commit_and_publish(i)
@@ -93,6 +93,14 @@ class DistCompressor:
                 nxt = i + self.world if i + self.world < n_total else None
             else:
                 self._receive(owner)
+
+    def _prepare(self, sample):
+        """sample = (name, contig names, d_codes pointer | agc_amd.capi.Packed, ctg_off)"""
+        name, names, data, off = sample
+        if isinstance(data, int) or data is None:
+            self.cmp.prepare_sample_dev(name, names, data, off)
+        else:
+            self.cmp.prepare_sample_packed_dev(name, names, data, off)
 
     def _broadcast(self, owner, rec):
         torch, dist = self.torch, self.dist

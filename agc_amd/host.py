@@ -42,6 +42,8 @@ def bind(L):
     L.agc_cmp_last_record.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
     L.agc_cmp_apply_record.argtypes = [vp, vp, C.c_uint64, vp]
     L.agc_cmp_prepare_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
+    L.agc_cmp_prepare_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
+    L.agc_cmp_add_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_commit_prepared.argtypes = [vp]
     L.agc_cmp_append.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32]
     return L
@@ -104,6 +106,21 @@ class Compressor:
         if not self.L.agc_cmp_add_sample_dev(self.h, sample_name.encode(), n, names, d_codes, off.ctypes.data_as(C.POINTER(C.c_uint64))):
             raise RuntimeError("AddSampleDevice failed (see stderr)")
 
+    def add_sample_packed_dev(self, sample_name, contig_names, packed, ctg_off):
+        """packed: agc_amd.capi.Packed (the sample in the 2-bit HBM layout); ctg_off: symbol offsets in that buffer"""
+        n = len(contig_names)
+        names = (C.c_char_p * n)(*[c.encode() for c in contig_names])
+        off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+        if not self.L.agc_cmp_add_sample_packed_dev(self.h, sample_name.encode(), n, names, C.byref(packed), off.ctypes.data_as(C.POINTER(C.c_uint64))):
+            raise RuntimeError("AddSamplePackedDevice failed (see stderr)")
+
+    def prepare_sample_packed_dev(self, sample_name, contig_names, packed, ctg_off):
+        n = len(contig_names)
+        names = (C.c_char_p * n)(*[c.encode() for c in contig_names])
+        off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+        if not self.L.agc_cmp_prepare_sample_packed_dev(self.h, sample_name.encode(), n, names, C.byref(packed), off.ctypes.data_as(C.POINTER(C.c_uint64))):
+            raise RuntimeError("PrepareSamplePackedDevice failed (see stderr)")
+
     def append(self, in_archive, out_path, concatenated=False, adaptive=False, verbosity=0, n_threads=8):
         if not self.L.agc_cmp_append(self.h, in_archive.encode(), (out_path or "").encode(), verbosity, int(concatenated), int(adaptive), n_threads):
             raise RuntimeError("CAGCCompressor::Append failed (see stderr)")
@@ -147,6 +164,10 @@ class Compressor:
         v = (C.c_double * len(STAT_NAMES))()
         self.L.agc_cmp_stats(self.h, v, len(STAT_NAMES))
         return {n: v[i] for i, n in enumerate(STAT_NAMES)}
+
+    def hip_ctx(self):
+        """the compressor's agc_hip_ctx (raw handle; agc_amd.capi.Context.from_handle wraps it)"""
+        return self.L.agc_cmp_hip_ctx(self.h)
 
     def hip_timing(self, on=True):
         L = capi.load()

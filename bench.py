@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 K, MML, SEG, PACK = 31, 15, 60000, 100
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-BYTES_PER_SYMBOL = 1.0  # device layout of sample and reference symbols
+BYTES_PER_SYMBOL = 1.0  # layout the LZ kernels read (byte staging copy of the sample, references); the scan reads the 2-bit layout
 
 
 def parse():
@@ -67,8 +67,12 @@ def host_cpus():
 
 
 PMC_SUMMARY = os.path.join("profiles", "r2", "pmc_summary.csv")
-KERNEL_SYMBOL = {"scan": "agc::scan_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
-                 "costvec": "agc::lz_parse_kernel<2>"}
+KERNEL_SYMBOL = {"scan": "agc::scan_packed_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
+                 "costvec": "agc::lz_parse_kernel<2>", "preprocess": "agc::expand_codes_kernel"}
+# bytes per symbol each kernel reads/writes in the layout AS BUILT: the scan reads the 2-bit layout, the expansion reads it and
+# writes the byte staging copy, the LZ kernels read bytes (text + reference)
+AS_BUILT_BPS = {"scan": 0.25, "preprocess": 1.25, "encode": 1.0, "estimate": 1.0, "costvec": 1.0}
+PACKED_BPS = {"scan": 0.25, "preprocess": 0.0, "encode": 0.25, "estimate": 0.25, "costvec": 0.25}
 
 
 def pmc_table():
@@ -194,7 +198,7 @@ def main():
             if i == 0:
                 return "ref", names, ref.data_ptr(), off
             s_ = (i - rank) // world - (1 if rank == 0 else 0)
-            return f"s{rank}_{s_}", names, samples[s_].data_ptr(), off
+            return f"s{rank}_{s_}", names, samples[s_][0], off
 
         dc.compress(1, get_sample)  # sample 0: minted on rank 0, its record (the whole reference set) broadcast
     else:
@@ -204,13 +208,22 @@ def main():
     def add_step(s, tag):
         """one step = one sample per GPU; in single-archive mode the N samples of a step are committed in rank order"""
         if not single:
-            cmp_.add_sample_dev(f"{tag}{rank}_{s}", names, samples[s].data_ptr(), off)
+            cmp_.add_sample_packed_dev(f"{tag}{rank}_{s}", names, samples[s][0], off)
             return
         dc.compress(1 + (s + 1) * world, get_sample, start=1 + s * world)  # (each step: the N samples prepared in parallel)
 
     n_steps = args.steps + args.warmup
     # weak scaling: samples are partitioned round-robin over ranks (one archive shard per rank), no data-path collective
-    samples = [synth_dev.make_sample(ref, tot, args.div, shard.sample_seed(1000, s, rank, world), dev) for s in range(n_steps)]
+    # samples are RESIDENT IN HBM IN THE 2-BIT LAYOUT (0.25 B per base; include/agc_hip.h: agc_hip_packed): generated as codes,
+    # packed, and the codes dropped.  Inside a step the scan reads the packed words; the LZ kernels read a byte staging copy
+    # expanded at the start of the step (timed).
+    from agc_amd import capi
+    hctx = capi.Context.from_handle(cmp_.hip_ctx())
+    samples = []
+    for s in range(n_steps):
+        codes = synth_dev.make_sample(ref, tot, args.div, shard.sample_seed(1000, s, rank, world), dev)
+        samples.append(hctx.pack_dev(codes, tot))
+        del codes
     torch.cuda.synchronize()
 
     def barrier():
@@ -253,13 +266,15 @@ def main():
         # reference once.  Two columns: the layout as built (`bytes_per_symbol` B per symbol) and SURVEY 8d's 2-bit figure
         # (0.25 B per symbol), which is what north_star's roofline target is quoted on.
         # Kernel time = HIP events on the library's own stream around every launch of the timed region, summed per step
-        # (scan and encode are one launch per step; "costvec" = the cost-vector parse + the split-point reduction).
+        # (scan and encode are one launch per step; "costvec" = key filter + cost-vector parse + split-point reduction;
+        # "preprocess" = expansion of the packed sample into the byte staging copy; the algorithmic bytes of a kernel with
+        # nothing to do on a fully packed path (the expansion) are 0 in the packed column).
         n_rank_steps = max(args.steps * world, 1)
-        sym = {"scan": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"], "estimate": stats["est_text"] + stats["est_ref"],
-               "costvec": stats["cv_text"] + stats["cv_ref"]}
+        sym = {"scan": stats["bases"], "preprocess": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"],
+               "estimate": stats["est_text"] + stats["est_ref"], "costvec": stats["cv_text"] + stats["cv_ref"]}
         tab = pmc_table()
         kern = {}
-        for name in ("scan", "encode", "estimate", "costvec"):
+        for name in ("scan", "preprocess", "encode", "estimate", "costvec"):
             ms_, n_ = tm[name]
             if not n_:
                 continue
@@ -267,7 +282,7 @@ def main():
             sym_step = sym[name] / n_rank_steps
             row = {"ms_per_step": round(ms_step, 4), "launches_per_step": round(n_ / max(args.steps, 1), 2),
                    "symbols_per_step": int(sym_step)}
-            for col, bps in (("as_built", BYTES_PER_SYMBOL), ("packed_2bit", 0.25)):
+            for col, bps in (("as_built", AS_BUILT_BPS[name]), ("packed_2bit", PACKED_BPS[name])):
                 ach = bps * sym_step / (ms_step * 1e-3) / 1e9
                 row[col] = {"bytes_per_symbol": bps, "algorithmic_bytes": int(bps * sym_step), "achieved": round(ach, 2),
                             "frac": round(ach / HBM_PEAK_GBS, 5)}
@@ -313,7 +328,9 @@ def main():
                          "algorithmic_bytes_per_launch": dom.get("as_built", {}).get("algorithmic_bytes"),
                          "avg_launch_ms": dom.get("ms_per_step"),
                          "dominant_by": "largest kernel time per step among ALL kernels of the path (scan, encode, estimate, cost vectors)",
-                         "layout": f"{BYTES_PER_SYMBOL} B per symbol in HBM",
+                         "layout": "samples resident in HBM at 0.25 B per symbol (2-bit words + escaped blocks); the scan reads that; the LZ "
+                                   "kernels read a 1 B per symbol staging copy made at the start of the step ('preprocess' = that expansion) "
+                                   "and 1 B per symbol references",
                          "kernels": kern,
                          "kernel_ms_per_step_rank0": {n: round(v[0] / max(args.steps, 1), 4) for n, v in tm.items() if v[1]}},
         }

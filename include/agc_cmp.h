@@ -39,6 +39,12 @@ int agc_cmp_add_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, con
 int agc_cmp_prepare_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const uint8_t *d_codes,
                                const uint64_t *ctg_off);
 int agc_cmp_commit_prepared(void *h);
+/* the same for a sample resident in HBM in the 2-bit layout (packed: const agc_hip_packed *, include/agc_hip.h; contig c =
+ * symbols [ctg_off[c], ctg_off[c+1]) of the packed buffer) */
+int agc_cmp_add_sample_packed_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const void *packed,
+                                  const uint64_t *ctg_off);
+int agc_cmp_prepare_sample_packed_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const void *packed,
+                                      const uint64_t *ctg_off);
 /* CAGCCompressor::Close (agc_compressor.cpp:2094-2115, 2386-2400) */
 int agc_cmp_close(void *h, uint32_t n_threads);
 

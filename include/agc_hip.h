@@ -116,6 +116,32 @@ int agc_hip_scan_contigs(agc_hip_ctx *ctx, const uint8_t *h_codes,
                          uint32_t *h_hit_ctg, uint64_t *h_hit_pos,
                          uint64_t *h_hit_dir, uint64_t *h_hit_rc);
 
+/* ---- 2-bit packed samples (the HBM-resident form of contigs) -------------- */
+/* Symbol i of the buffer (contigs back to back, codes of agc_basic.h:40-50) at bits [2*(i & 15), +1] of 32-bit word i >> 4.
+ * Blocks of 1024 symbols containing anything outside ACGT are kept verbatim (one byte per symbol) in d_esc_bytes;
+ * d_esc_index[block] = their slot (x 1024 bytes) or -1.  CKmer does the same packing symbol by symbol
+ * (src/core/kmer.h:284-301); this is the layout the sample itself has in HBM. */
+typedef struct {
+    const uint32_t *d_words;      /* agc_hip_packed_words_bytes(n_symbols) bytes */
+    const int32_t *d_esc_index;   /* agc_hip_packed_index_bytes(n_symbols) bytes */
+    const uint8_t *d_esc_bytes;   /* 1024 bytes per escaped block */
+    uint64_t n_symbols;
+} agc_hip_packed;
+uint64_t agc_hip_packed_words_bytes(uint64_t n_symbols);
+uint64_t agc_hip_packed_index_bytes(uint64_t n_symbols);
+/* codes (1 B per symbol, device) -> packed.  AGC_HIP_ECAP (+ the needed count in *h_n_esc_blocks) when more than
+ * esc_cap_blocks blocks have to be escaped. */
+int agc_hip_pack_dev(agc_hip_ctx *ctx, const uint8_t *d_codes, uint64_t n_symbols, uint32_t *d_words, int32_t *d_esc_index,
+                     uint8_t *d_esc_bytes, uint64_t esc_cap_blocks, uint64_t *h_n_esc_blocks);
+/* packed -> codes (d_codes: n_symbols bytes, 16-byte aligned): the staging form the LZ kernels read.  Asynchronous on
+ * the context's stream (ordered before every later call). */
+int agc_hip_expand_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, uint8_t *d_codes);
+/* agc_hip_scan_contigs_dev on a packed sample (contig c = symbols [h_ctg_off[c], h_ctg_off[c+1]) of the buffer), 16 <= k <= 32.
+ * Same results; reads 0.25 B per symbol. */
+int agc_hip_scan_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                            uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos,
+                            uint64_t *h_hit_dir, uint64_t *h_hit_rc);
+
 /* ---- S2: LZ-diff against group references (a10, a11, a6, a7) ---------- */
 /* A "slice" names one sequence inside a device buffer: symbols
  * d_base[off .. off+len), read reverse-complemented when rc != 0

@@ -398,3 +398,62 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d, con
     }
     return AGC_HIP_OK;
 }
+
+/* ---- 2-bit packed samples: the layout of include/agc_hip.h on the host ---- */
+uint64_t agc_hip_packed_words_bytes(uint64_t n) { return ((n + 1023) / 1024) * 256 + 64; }
+uint64_t agc_hip_packed_index_bytes(uint64_t n) { return ((n + 1023) / 1024) * 4 + 64; }
+
+int agc_hip_pack_dev(agc_hip_ctx *c, const uint8_t *codes, uint64_t n, uint32_t *words, int32_t *esc_index, uint8_t *esc_bytes, uint64_t cap,
+                     uint64_t *h_n_esc)
+{
+    if (!c || !h_n_esc)
+        return AGC_HIP_EINVAL;
+    uint64_t cnt = 0;
+    for (uint64_t b = 0; b * 1024 < n; ++b) {
+        int high = 0;
+        for (uint64_t i = b * 1024; i < n && i < (b + 1) * 1024; ++i)
+            high |= codes[i] > 3;
+        for (uint32_t w = 0; w < 64; ++w) {
+            uint32_t x = 0;
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint64_t i = b * 1024 + w * 16 + j;
+                x |= (uint32_t)((i < n ? codes[i] : 0) & 3) << (2 * j);
+            }
+            words[b * 64 + w] = x;
+        }
+        esc_index[b] = -1;
+        if (high) {
+            if (cnt < cap) {
+                esc_index[b] = (int32_t)cnt;
+                for (uint32_t j = 0; j < 1024; ++j)
+                    esc_bytes[cnt * 1024 + j] = b * 1024 + j < n ? codes[b * 1024 + j] : 0;
+            }
+            ++cnt;
+        }
+    }
+    *h_n_esc = cnt;
+    return cnt > cap ? AGC_HIP_ECAP : AGC_HIP_OK;
+}
+
+int agc_hip_expand_dev(agc_hip_ctx *c, const agc_hip_packed *pk, uint8_t *codes)
+{
+    if (!c || !pk)
+        return AGC_HIP_EINVAL;
+    for (uint64_t i = 0; i < pk->n_symbols; ++i) {
+        const int32_t s = pk->d_esc_index[i / 1024];
+        codes[i] = s >= 0 ? pk->d_esc_bytes[(uint64_t)s * 1024 + (i & 1023)] : (uint8_t)((pk->d_words[i >> 4] >> (2 * (i & 15))) & 3);
+    }
+    return AGC_HIP_OK;
+}
+
+int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap,
+                            uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+{
+    if (!c || !pk || k < 16)
+        return AGC_HIP_EINVAL;
+    uint8_t *codes = (uint8_t *)malloc(pk->n_symbols + 64);
+    agc_hip_expand_dev(c, pk, codes);
+    const int r = agc_hip_scan_contigs_dev(c, codes, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
+    free(codes);
+    return r;
+}

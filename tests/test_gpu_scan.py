@@ -124,3 +124,62 @@ def test_determine_splitters_matches_oracle(hip_ctx, oracle, k, seg):
         n = oracle.lib().agco_enumerate_kmers(x.ctypes.data_as(C.POINTER(C.c_uint8)), x.size, k, buf.ctypes.data_as(C.POINTER(C.c_uint64)))
         allk.append(buf[:n])
     assert np.array_equal(srt, np.sort(np.concatenate(allk)))
+
+
+# ---- 2-bit packed samples ---------------------------------------------------------------------------------------------
+def _packed_case(oracle, rng, k):
+    refc = [synth.random_seq(rng, int(n)) for n in (70_000, 12_345, 150_001, 40, 5)]
+    spl = oracle.determine_splitters(refc, k, 1000)
+    contigs = [synth.mutate(rng, refc[0], 0.002, n_runs=3, iupac=5),
+               synth.mutate(rng, refc[1], 0.01),
+               synth.mutate(rng, refc[2], 0.001, indels=3),
+               refc[3].copy(), refc[4].copy(),
+               refc[0][:65536].copy(), refc[0][:1024].copy(), refc[2][:4096 + k - 1].copy(),
+               np.full(3000, 4, np.uint8),                                  # a contig of N only
+               synth.mutate(rng, refc[0][10_000:30_000], 0.0, n_runs=1)]
+    return spl, contigs
+
+
+@pytest.mark.parametrize("k", [17, 21, 25, 31, 32])
+def test_packed_scan_matches_oracle(hip_ctx, oracle, k):
+    """pack -> scan on the 2-bit layout (contigs back to back at arbitrary symbol offsets, escaped blocks for N runs / IUPAC)
+    must report what the oracle's scan reports"""
+    import torch
+    rng = np.random.default_rng(300 + k)
+    spl, contigs = _packed_case(oracle, rng, k)
+    off = np.zeros(len(contigs) + 1, np.uint64)
+    off[1:] = np.cumsum([c.size for c in contigs])
+    codes = np.concatenate(contigs)
+    d = torch.from_numpy(codes).cuda()
+    pk, keep = hip_ctx.pack_dev(d)
+    hip_ctx.splitters_set(spl)
+    got = hip_ctx.scan_packed_dev(pk, off, k)
+    want = _oracle_hits(oracle, contigs, k, spl)
+    for g, w, name in zip(got, want, ("ctg", "pos", "dir", "rc")):
+        assert np.array_equal(g, w), name
+    assert want[0].size > 100
+    # and the expansion gives the symbols back, escaped blocks included
+    out = torch.zeros(codes.size + 64, dtype=torch.uint8, device="cuda")
+    hip_ctx.expand_dev(pk, out.data_ptr())
+    assert np.array_equal(out[:codes.size].cpu().numpy(), codes)
+
+
+def test_packed_scan_equals_byte_scan_on_a_big_sample(hip_ctx, oracle):
+    """size-independent property at a larger size: the two scan kernels agree (50 Mbp, 6 contigs, a few escaped blocks)"""
+    import torch
+    rng = np.random.default_rng(77)
+    k = 31
+    ref = synth.random_seq(rng, 2_000_000)
+    spl = oracle.determine_splitters([ref], k, 20_000)
+    parts = [synth.mutate(rng, ref, 0.001, n_runs=2, iupac=2) for _ in range(6)]
+    parts += [np.tile(ref, 20)[: 38_000_000 - 7]]
+    off = np.zeros(len(parts) + 1, np.uint64)
+    off[1:] = np.cumsum([p.size for p in parts])
+    d = torch.from_numpy(np.concatenate(parts)).cuda()
+    pk, keep = hip_ctx.pack_dev(d)
+    hip_ctx.splitters_set(spl)
+    a = hip_ctx.scan_packed_dev(pk, off, k, cap=1 << 18)
+    b = hip_ctx.scan_contigs_dev(d.data_ptr(), off, k, cap=1 << 18)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[0].size > 2000
