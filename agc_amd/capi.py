@@ -243,6 +243,7 @@ class Context:
         import torch
         n = int(d_codes_tensor.numel() if n_symbols is None else n_symbols)
         dev = d_codes_tensor.device
+        torch.cuda.synchronize(dev)  # the codes come from torch's stream, the packing runs on the library's
         words = torch.empty(int(self.L.agc_hip_packed_words_bytes(n)) // 4 + 1, dtype=torch.int32, device=dev)
         index = torch.empty(int(self.L.agc_hip_packed_index_bytes(n)) // 4 + 1, dtype=torch.int32, device=dev)
         cap = 64

@@ -96,6 +96,14 @@ int agc_cmp_add_sample_packed_dev(void *h, const char *sample_name, uint32_t n_c
 }
 int agc_cmp_commit_prepared(void *h) { return ((CAGCCompressor *)h)->CommitPrepared() ? 1 : 0; }
 
+int agc_cmp_close_collect_packs(void *h, const uint8_t **src, const uint64_t **off, uint32_t *n)
+{
+    return ((CAGCCompressor *)h)->CloseCollectPacks(src, off, n) ? 1 : 0;
+}
+int agc_cmp_close_provide_frames(void *h, const uint8_t *frames, const uint64_t *off)
+{
+    return ((CAGCCompressor *)h)->CloseProvideFrames(frames, off) ? 1 : 0;
+}
 int agc_cmp_close(void *h, uint32_t n_threads) { return ((CAGCCompressor *)h)->Close(n_threads) ? 1 : 0; }
 
 const char *agc_cmp_zstd_version(void *h) { return ((CAGCCompressor *)h)->ZstdVersion(); }

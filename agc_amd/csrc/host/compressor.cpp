@@ -777,21 +777,85 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
 }
 
 // close_compression (agc_compressor.cpp:2094-2115), store_metadata (:175-284), store_file_type_info (:287-300)
+bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off, uint32_t *n)
+{
+    Impl &I = *p;
+    if (!I.created || I.close_collected || !src || !off || !n)
+        return false;
+    I.store_open_batch();
+    I.close_jobs.clear();
+    I.build_close_jobs(I.close_jobs);
+    I.close_dev_jobs.clear();
+    const uint32_t dev_max = agc_hip_zstd17_max_input();
+    I.close_src_off.assign(1, 0);
+    for (uint32_t i = 0; i < I.close_jobs.size(); ++i) {
+        const ZJob &j = I.close_jobs[i];
+        if (I.gpu_zstd && j.kind == 1 && !j.data.empty() && j.data.size() <= dev_max) {
+            I.close_dev_jobs.push_back(i);
+            I.close_src_off.push_back(I.close_src_off.back() + j.data.size());
+        }
+    }
+    I.zsrc_buf.resize(I.close_src_off.back());
+    I.pool->parallel_for(I.close_dev_jobs.size(), [&](size_t t, unsigned) {
+        const ZJob &j = I.close_jobs[I.close_dev_jobs[t]];
+        memcpy(I.zsrc_buf.data() + I.close_src_off[t], j.data.data(), j.data.size());
+    });
+    *src = I.zsrc_buf.data();
+    *off = I.close_src_off.data();
+    *n = (uint32_t)I.close_dev_jobs.size();
+    I.close_collected = true;
+    I.close_frames_off.clear();
+    return true;
+}
+
+bool CAGCCompressor::CloseProvideFrames(const uint8_t *frames, const uint64_t *off)
+{
+    Impl &I = *p;
+    if (!I.close_collected || (!I.close_dev_jobs.empty() && (!frames || !off)))
+        return false;
+    const size_t nd = I.close_dev_jobs.size();
+    I.close_frames_off.assign(off, off + nd + 1);
+    I.zdst_buf.assign(frames + off[0], frames + off[nd]);
+    const uint64_t base = off[0];
+    for (auto &x : I.close_frames_off)
+        x -= base;
+    return true;
+}
+
+void CAGCCompressor::Impl::store_open_batch()
+{
+    // samples that came through AddSampleDevice / ApplyRecord: the open collection batch is stored here, where
+    // AddSampleFiles does it at its end (agc_compressor.cpp:2254-2255)
+    if (stored_samples < processed_samples && processed_samples % pack_cardinality != 0) {
+        coll.store_contig_batch((processed_samples / pack_cardinality) * pack_cardinality, processed_samples);
+        stored_samples = processed_samples;
+        ar.flush_out_buffers();
+    }
+}
+
 bool CAGCCompressor::Close(uint32_t no_threads)
 {
     Impl &I = *p;
     (void)no_threads;
     if (!I.created)
         return false;
-    // samples that came through AddSampleDevice / ApplyRecord: the open collection batch is stored here, where
-    // AddSampleFiles does it at its end (agc_compressor.cpp:2254-2255)
-    if (I.stored_samples < I.processed_samples && I.processed_samples % I.pack_cardinality != 0) {
-        I.coll.store_contig_batch((I.processed_samples / I.pack_cardinality) * I.pack_cardinality, I.processed_samples);
-        I.stored_samples = I.processed_samples;
-        I.ar.flush_out_buffers();
+    if (I.close_collected && I.close_frames_off.size() != I.close_dev_jobs.size() + 1) {
+        I.err("Close: CloseCollectPacks was called but the frames were never provided");
+        return false;
     }
+    if (!I.close_collected)
+        I.store_open_batch();
+    const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
+    double lt = now();
+    auto LAP = [&](const char *what) {
+        if (laps)
+            std::cerr << "  close lap " << what << " " << (now() - lt) * 1e3 << " ms\n";
+        lt = now();
+    };
     I.finish_groups();
+    LAP("finish_groups (pack jobs + entropy stage + parts)");
     I.ar.flush_out_buffers();
+    LAP("flush_out_buffers");
 
     auto app32 = [](bytes_t &d, uint32_t x) {
         for (int i = 0; i < 4; ++i, x >>= 8)
@@ -829,7 +893,9 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     }
     I.ar.add_part(I.ar.register_stream("segment-splitters"), v, ms.size());
 
+    LAP("params / splitters / segment-splitters");
     I.coll.complete_serialization();
+    LAP("collection complete_serialization");
 
     // m_file_type_info (agc_compressor.cpp:53-59, std::map order).  The reference's own values are
     // written so that archives stay byte-identical to its output; AGC_AMD_PRODUCER_TAG=1 tags the
@@ -853,6 +919,7 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     }
     I.ar.add_part(I.ar.register_stream("file_type_info"), v, info.size());
     I.ar.close();
+    LAP("archive close");
     I.st.archive_bytes = I.ar.bytes_written();
     I.created = false;
     if (I.ar.failed()) {

@@ -102,6 +102,12 @@ public:
 
     // src/core/agc_compressor.cpp:2094-2115 (close_compression) + ~CArchive
     bool Close(uint32_t no_threads);
+    // Close in steps, for an entropy stage spread over several GPUs (agc_amd/dist.py): CloseCollectPacks builds the pending pack
+    // jobs and hands out the inputs of those a device may compress (back to back, pack i = src[off[i] .. off[i+1])); the caller
+    // has them compressed (agc_hip_zstd17_batch on any GPU) and returns the frames in the same order; Close then finishes with
+    // them.  Without these two calls Close compresses everything itself.
+    bool CloseCollectPacks(const uint8_t **src, const uint64_t **off, uint32_t *n);
+    bool CloseProvideFrames(const uint8_t *frames, const uint64_t *off);
 
     const CompressorStats &Stats() const;
     const char *ZstdVersion() const;

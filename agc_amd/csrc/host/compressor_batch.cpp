@@ -53,6 +53,13 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
 void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
 {
     double t0 = now();
+    static const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
+    double lt = t0;
+    auto LAP = [&](const char *what) {
+        if (laps && jobs.size() > 1000)
+            std::cerr << "    entropy lap " << what << " " << (now() - lt) * 1e3 << " ms\n";
+        lt = now();
+    };
     auto finish = [](ZJob &j, bytes_t &packed, uint32_t ps, uint8_t marker) {
         packed[ps] = marker;
         if (ps + 1u < (uint32_t)j.data.size()) {
@@ -67,12 +74,21 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     // which jobs the device takes
     std::vector<uint32_t> dev_jobs, host_jobs;
     const uint32_t dev_max = gpu_zstd ? agc_hip_zstd17_max_input() : 0;
+    const bool ext = close_collected && &jobs == &close_jobs; // frames of the collected packs came in through CloseProvideFrames
+    if (ext) {
+        std::vector<uint8_t> is_dev(jobs.size(), 0);
+        for (uint32_t i : close_dev_jobs)
+            is_dev[i] = 1;
+        for (uint32_t i = 0; i < jobs.size(); ++i)
+            (is_dev[i] ? dev_jobs : host_jobs).push_back(i);
+    } else
     for (uint32_t i = 0; i < jobs.size(); ++i)
         if (gpu_zstd && jobs[i].kind == 1 && !jobs[i].data.empty() && jobs[i].data.size() <= dev_max)
             dev_jobs.push_back(i);
         else
             host_jobs.push_back(i);
-    if (dev_jobs.size() < gpu_zstd_min) { // not worth a launch
+    if (ext) {
+    } else if (dev_jobs.size() < gpu_zstd_min) { // not worth a launch
         host_jobs.insert(host_jobs.end(), dev_jobs.begin(), dev_jobs.end());
         std::sort(host_jobs.begin(), host_jobs.end());
         dev_jobs.clear();
@@ -99,10 +115,13 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         if (jobs[i].kind == 1)
             host_bytes += jobs[i].data.size();
     double t_dev = 0, t_host = 0;
+    LAP("split");
     std::future<bool> dev_done;
     std::vector<uint64_t> src_off, dst_off;
     const double ts0 = now();
-    if (!dev_jobs.empty()) {
+    if (ext) {
+        dst_off = close_frames_off; // (zdst_buf holds the frames)
+    } else if (!dev_jobs.empty()) {
         const size_t nd = dev_jobs.size();
         src_off.assign(nd + 1, 0);
         for (size_t t = 0; t < nd; ++t)
@@ -135,6 +154,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     }
     const double th0 = now();
     st.t_zstd_stage += th0 - ts0;
+    LAP("gather + launch");
     pool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
         ZJob &j = jobs[host_jobs[hi]];
         ZstdCtx &z = *zctx[tid];
@@ -158,11 +178,13 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     });
     t_host = now() - th0;
     st.t_zstd_host += t_host;
+    LAP("host pool");
     if (!dev_jobs.empty()) {
         const double t1 = now();
-        const bool ok = dev_done.get();
+        const bool ok = ext ? true : dev_done.get();
         st.t_device += now() - t1;
         st.t_zstd_dev += t_dev;
+        LAP("wait for the device");
         const double ts1 = now();
         if (!ok) { // the device refused: libzstd does them after all (same bytes)
             pool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
@@ -180,18 +202,20 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 packed.push_back(0);
                 finish(j, packed, ps, 0);
             });
-            st.zstd_dev_in += src_off[dev_jobs.size()];
+            if (!ext)
+                st.zstd_dev_in += src_off[dev_jobs.size()];
             st.t_zstd_stage += now() - ts1;
             // rates of this call -> share of the next one (only meaningful when both had a real amount of work)
-            if (src_off[dev_jobs.size()] > (8u << 20) && host_bytes > (8u << 20) && t_dev > 0 && t_host > 0 && !getenv("AGC_AMD_GPU_ZSTD_SHARE")) {
+            if (!ext && src_off[dev_jobs.size()] > (8u << 20) && host_bytes > (8u << 20) && t_dev > 0 && t_host > 0 && !getenv("AGC_AMD_GPU_ZSTD_SHARE")) {
                 const double r_dev = src_off[dev_jobs.size()] / t_dev, r_host = host_bytes / t_host;
                 gpu_zstd_share = std::min(0.98, std::max(0.05, r_dev / (r_dev + r_host)));
             }
-            if (verbosity > 0)
+            if (verbosity > 0 && !ext)
                 std::cerr << "entropy stage: device " << src_off[dev_jobs.size()] / 1e6 << " MB in " << t_dev << " s, host " << host_bytes / 1e6 << " MB in "
                           << t_host << " s; next device share " << gpu_zstd_share << std::endl;
         }
     }
+    LAP("results -> jobs");
     st.t_zstd += now() - t0;
 }
 
@@ -1518,7 +1542,20 @@ void CAGCCompressor::Impl::note_new_group(const pk_t &pk, uint32_t gid)
 // CSegment::finish for every group (agc_compressor.cpp:880-904, segment.cpp:125-133)
 void CAGCCompressor::Impl::finish_groups()
 {
+    if (close_collected) { // CloseCollectPacks built the jobs; their device-eligible packs were compressed elsewhere
+        run_jobs(close_jobs);
+        close_jobs.clear();
+        close_collected = false;
+        return;
+    }
     std::vector<ZJob> jobs;
+    build_close_jobs(jobs);
+    run_jobs(jobs);
+}
+
+// the pack jobs of every group's open pack (+ the parts an appended archive's untouched groups keep as they are)
+void CAGCCompressor::Impl::build_close_jobs(std::vector<ZJob> &jobs)
+{
     for (uint32_t gid = 0; gid < groups.size(); ++gid) {
         Group &g = groups[gid];
         if (!g.lzp_off.empty())
@@ -1531,7 +1568,6 @@ void CAGCCompressor::Impl::finish_groups()
             ar.add_part_buffered(g.stream_delta, bytes_t(g.pk_delta, g.pk_delta + g.pk_delta_size), g.pk_delta_meta);
         }
     }
-    run_jobs(jobs);
 }
 
 } // namespace agc

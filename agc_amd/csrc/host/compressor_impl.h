@@ -579,6 +579,13 @@ struct CAGCCompressor::Impl {
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
     void run_jobs_round(std::vector<ZJob> &jobs);
+    void build_close_jobs(std::vector<ZJob> &jobs);
+    void store_open_batch();
+    // Close in steps (multi-GPU entropy stage, compressor.h: CloseCollectPacks / CloseProvideFrames)
+    std::vector<ZJob> close_jobs;
+    std::vector<uint32_t> close_dev_jobs;      // indices in close_jobs of the packs handed out
+    std::vector<uint64_t> close_src_off, close_frames_off;
+    bool close_collected = false;
     void choose_entropy_stage();
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);

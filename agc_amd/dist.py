@@ -102,6 +102,70 @@ class DistCompressor:
         else:
             self.cmp.prepare_sample_packed_dev(name, names, data, off)
 
+    def close(self, zstd_batch=None, n_threads=8):
+        """Close() with the entropy stage of the delta packs spread over all ranks: the writer hands the pending packs out
+        (one broadcast), rank r compresses packs r, r + N, ... on its own GPU (agc_hip_zstd17_batch), the frames go back to the
+        writer (gather), which finishes the archive.  zstd_batch(list of bytes-like) -> list of frames; default: this rank's GPU.
+        Every rank must call this instead of Compressor.close()."""
+        torch, dist = self.torch, self.dist
+        if zstd_batch is None:
+            from agc_amd import capi
+            ctx = capi.Context.from_handle(self.cmp.hip_ctx())
+            zstd_batch = ctx.zstd17_batch
+        writer = self.rank == self.writer
+        if writer:
+            src, off = self.cmp.close_collect_packs()
+            meta = torch.tensor([off.size - 1, int(off[-1])], dtype=torch.int64, device=self.comm)
+        else:
+            meta = torch.zeros(2, dtype=torch.int64, device=self.comm)
+        dist.broadcast(meta, src=self.writer)
+        n, total = int(meta[0]), int(meta[1])
+        if n == 0:
+            if writer:
+                self.cmp.close_provide_frames(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+            self.cmp.close(n_threads)
+            return
+        d_off = torch.from_numpy(off.astype(np.int64)).to(self.comm) if writer else torch.zeros(n + 1, dtype=torch.int64, device=self.comm)
+        d_src = torch.from_numpy(src).to(self.comm) if writer else torch.empty(total, dtype=torch.uint8, device=self.comm)
+        dist.broadcast(d_off, src=self.writer)
+        dist.broadcast(d_src, src=self.writer)   # (nccl: HBM -> HBM over xGMI)
+        h_off = d_off.cpu().numpy()
+        h_src = d_src.cpu().numpy()
+        mine = list(range(self.rank, n, self.world))
+        frames = zstd_batch([h_src[int(h_off[i]):int(h_off[i + 1])] for i in mine]) if mine else []
+        # sizes of every rank's frames (padded to the longest list), then the bytes (padded to the largest total)
+        per = (n + self.world - 1) // self.world
+        sz = torch.zeros(per, dtype=torch.int64, device=self.comm)
+        if frames:
+            sz[:len(frames)] = torch.tensor([len(f) for f in frames], dtype=torch.int64, device=self.comm)
+        all_sz = [torch.zeros(per, dtype=torch.int64, device=self.comm) for _ in range(self.world)]
+        dist.all_gather(all_sz, sz)
+        tot = [int(x.sum()) for x in all_sz]
+        cap = max(tot) if tot else 0
+        buf = torch.zeros(max(cap, 1), dtype=torch.uint8, device=self.comm)
+        if frames:
+            buf[:tot[self.rank]] = torch.from_numpy(np.frombuffer(b"".join(frames), np.uint8).copy()).to(self.comm)
+        gathered = [torch.zeros(max(cap, 1), dtype=torch.uint8, device=self.comm) for _ in range(self.world)] if writer else None
+        dist.gather(buf, gathered, dst=self.writer)
+        if writer:
+            sizes = np.zeros(n, np.uint64)
+            for r in range(self.world):
+                idx = np.arange(r, n, self.world)
+                sizes[idx] = all_sz[r].cpu().numpy()[:idx.size].astype(np.uint64)
+            foff = np.zeros(n + 1, np.uint64)
+            foff[1:] = np.cumsum(sizes)
+            out = np.zeros(int(foff[-1]), np.uint8)
+            for r in range(self.world):
+                idx = np.arange(r, n, self.world)
+                g = gathered[r].cpu().numpy()
+                o = 0
+                for i in idx:
+                    ln = int(sizes[i])
+                    out[int(foff[i]):int(foff[i]) + ln] = g[o:o + ln]
+                    o += ln
+            self.cmp.close_provide_frames(out, foff)
+        self.cmp.close(n_threads)
+
     def _broadcast(self, owner, rec):
         torch, dist = self.torch, self.dist
         n = torch.zeros(1, dtype=torch.int64, device=self.comm)

@@ -58,7 +58,7 @@ def main(argv=None):
         return fasta.sample_name(files[i]), names, keep[i].data_ptr(), off
 
     dc.compress(len(files), get_sample, prefetch=not a.a)
-    cmp_.close(threads if rank == 0 else 2)
+    dc.close(n_threads=threads if rank == 0 else 2)  # the delta packs are entropy-coded on every rank's GPU
     cmp_.close_handle()
     dist.barrier()
     dist.destroy_process_group()

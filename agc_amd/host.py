@@ -33,6 +33,8 @@ def bind(L):
     L.agc_cmp_add_sample_files.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32]
     L.agc_cmp_add_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_close.argtypes = [vp, C.c_uint32]
+    L.agc_cmp_close_collect_packs.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32)]
+    L.agc_cmp_close_provide_frames.argtypes = [vp, vp, vp]
     L.agc_cmp_zstd_version.argtypes = [vp]
     L.agc_cmp_zstd_version.restype = C.c_char_p
     L.agc_cmp_hip_ctx.argtypes = [vp]
@@ -152,6 +154,23 @@ class Compressor:
     def apply_record(self, h_ptr, n, d_ptr=None):
         if not self.L.agc_cmp_apply_record(self.h, h_ptr, n, d_ptr):
             raise RuntimeError("ApplyRecord failed (see stderr)")
+
+    def close_collect_packs(self):
+        """(src bytes as a numpy view, offsets [n + 1]) of the pending packs a device may compress; valid until close()"""
+        p = C.POINTER(C.c_uint8)()
+        o = C.POINTER(C.c_uint64)()
+        n = C.c_uint32()
+        if not self.L.agc_cmp_close_collect_packs(self.h, C.byref(p), C.byref(o), C.byref(n)):
+            raise RuntimeError("CloseCollectPacks failed")
+        off = np.ctypeslib.as_array(o, shape=(n.value + 1,)).copy()
+        src = np.ctypeslib.as_array(p, shape=(int(off[-1]),)) if off[-1] else np.zeros(0, np.uint8)
+        return src, off
+
+    def close_provide_frames(self, frames, off):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        if not self.L.agc_cmp_close_provide_frames(self.h, frames.ctypes.data, off.ctypes.data):
+            raise RuntimeError("CloseProvideFrames failed")
 
     def close(self, n_threads=8):
         if not self.L.agc_cmp_close(self.h, n_threads):

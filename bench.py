@@ -47,9 +47,10 @@ def parse():
     ap.add_argument("--positional-splitters", action="store_true",
                     help="skip determine_splitters: take the k-mer at every segment_size-th position (valid for an i.i.d. reference)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for libzstd (default: all cores / n_gpus)")
-    ap.add_argument("--single-archive", action="store_true",
-                    help="N > 1: all ranks feed ONE archive (ordered commit from broadcast commit records, agc_amd/dist.py) instead of "
-                         "one archive shard per rank; rank 0 writes and runs libzstd with all host threads")
+    ap.add_argument("--shards", action="store_true",
+                    help="N > 1: one independent archive shard per rank (no collective) instead of the default: all ranks feed ONE "
+                         "archive (ordered commit from broadcast commit records, entropy stage spread over the ranks' GPUs; agc_amd/dist.py)")
+    ap.add_argument("--single-archive", action="store_true", help="(the default for N > 1; kept for older command lines)")
     return ap.parse_args()
 
 
@@ -167,7 +168,7 @@ def main():
     ref, off = synth_dev.make_reference(total, 12345, dev)
     tot = int(off[-1])
     names = [f"chr{i + 1}" for i in range(len(off) - 1)]
-    single = args.single_archive and world > 1
+    single = world > 1 and not args.shards
     threads = max(1, host_cpus() // world)
     if single:  # the writer rank does all the zstd work, the others need a few host threads only
         threads = max(1, host_cpus() - 2 * (world - 1)) if rank == 0 else 2
@@ -242,7 +243,10 @@ def main():
         add_step(s, "s")
     t_steps = time.perf_counter() - t0
     # Close(): zstd of every pending delta pack + metadata + footer -- the deferred part of the steps' work
-    cmp_.close(threads)
+    if single:
+        dc.close(n_threads=threads)  # packs handed out to every rank's GPU, frames gathered by the writer
+    else:
+        cmp_.close(threads)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     tm = cmp_.hip_timing_get()
@@ -318,7 +322,7 @@ def main():
                        "host_stage_seconds_rank0": {k_: round(stats[k_], 4) for k_ in stats if k_.startswith("t_")},
                        "parallelism": (f"samples round-robin over {world} GPUs into ONE archive: ordered commit, one RCCL broadcast of the commit "
                                        f"record (new reference segments + deltas) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each; "
-                                       "rank 0 writes and runs libzstd") if single else
+                                       "at Close the pending packs are broadcast, every rank's GPU compresses its share, rank 0 gathers and writes") if single else
                                       f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dominant), "achieved": dom.get("as_built", {}).get("achieved"),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("as_built", {}).get("frac"),

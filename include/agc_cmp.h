@@ -47,6 +47,11 @@ int agc_cmp_prepare_sample_packed_dev(void *h, const char *sample_name, uint32_t
                                       const uint64_t *ctg_off);
 /* CAGCCompressor::Close (agc_compressor.cpp:2094-2115, 2386-2400) */
 int agc_cmp_close(void *h, uint32_t n_threads);
+/* Close in steps (entropy stage spread over several GPUs): the inputs of the pending delta packs a device may compress
+ * (pack i = src[off[i] .. off[i+1]), n packs), then their level-17 zstd frames in the same order (frame i =
+ * frames[off[i] .. off[i+1])), then agc_cmp_close.  The buffers returned by the first call stay valid until agc_cmp_close. */
+int agc_cmp_close_collect_packs(void *h, const uint8_t **src, const uint64_t **off, uint32_t *n);
+int agc_cmp_close_provide_frames(void *h, const uint8_t *frames, const uint64_t *off);
 
 /* one archive from N ranks (before agc_cmp_create on every rank; protocol: agc_amd/dist.py, compressor_dist.cpp).
  * After agc_cmp_add_sample_dev / agc_cmp_commit_prepared on the owner, agc_cmp_last_record gives the bytes every other rank

@@ -21,6 +21,25 @@ GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "archives.json")))
 from agc_amd.fasta import read_codes as fasta_codes  # noqa: E402
 
 
+def _sim_zstd_batch():
+    """list of packs -> list of level-17 frames through the CPU stand-in's agc_hip_zstd17_batch"""
+    from tests.devsim import build as simbuild
+    sim = C.CDLL(simbuild.SIM_HIP)
+    sim.agc_hip_zstd17_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+
+    def run(inputs):
+        n = len(inputs)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in inputs])
+        src = np.frombuffer(b"".join(bytes(x) for x in inputs), np.uint8) if off[-1] else np.zeros(1, np.uint8)
+        cap = int(off[-1]) + 32 * n + 64
+        dst = np.zeros(cap, np.uint8)
+        doff = np.zeros(n + 1, np.uint64)
+        assert sim.agc_hip_zstd17_batch(C.c_void_p(1), n, src.ctypes.data, off.ctypes.data, dst.ctypes.data, cap, doff.ctypes.data) == 0
+        return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)]
+    return run
+
+
 def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -76,7 +95,10 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
                     dc.add_sample(sn, names, codes.ctypes.data, off)
             else:
                 dc.add_sample()
-        cmp_.close()
+        if on_gpu:
+            dc.close()
+        else:
+            dc.close(zstd_batch=_sim_zstd_batch())  # the stand-in's agc_hip_zstd17_batch (same encoder headers as the kernel)
         st = cmp_.stats()
         cmp_.close_handle()
         q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"], st["revalidated"]))
@@ -234,7 +256,10 @@ def _edge_worker(rank, world, port, out_path, q, prefetch):
         else:
             for i in range(len(samples)):
                 cmp_.add_sample_dev(*get_sample(i))
-        cmp_.close()
+        if world > 1:
+            dc.close(zstd_batch=_sim_zstd_batch())
+        else:
+            cmp_.close()
         st = cmp_.stats()
         cmp_.close_handle()
         q.put((rank, "ok", st["new_groups"]))

@@ -151,6 +151,7 @@ def test_packed_scan_matches_oracle(hip_ctx, oracle, k):
     off[1:] = np.cumsum([c.size for c in contigs])
     codes = np.concatenate(contigs)
     d = torch.from_numpy(codes).cuda()
+    torch.cuda.synchronize()
     pk, keep = hip_ctx.pack_dev(d)
     hip_ctx.splitters_set(spl)
     got = hip_ctx.scan_packed_dev(pk, off, k)
@@ -160,6 +161,7 @@ def test_packed_scan_matches_oracle(hip_ctx, oracle, k):
     assert want[0].size > 100
     # and the expansion gives the symbols back, escaped blocks included
     out = torch.zeros(codes.size + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # (torch's fill and the library's kernels run on different streams)
     hip_ctx.expand_dev(pk, out.data_ptr())
     assert np.array_equal(out[:codes.size].cpu().numpy(), codes)
 
@@ -176,6 +178,7 @@ def test_packed_scan_equals_byte_scan_on_a_big_sample(hip_ctx, oracle):
     off = np.zeros(len(parts) + 1, np.uint64)
     off[1:] = np.cumsum([p.size for p in parts])
     d = torch.from_numpy(np.concatenate(parts)).cuda()
+    torch.cuda.synchronize()
     pk, keep = hip_ctx.pack_dev(d)
     hip_ctx.splitters_set(spl)
     a = hip_ctx.scan_packed_dev(pk, off, k, cap=1 << 18)
