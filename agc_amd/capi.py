@@ -21,7 +21,7 @@ SYMBOLS = [
     "agc_hip_create", "agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_sync",
     "agc_hip_timing_enable", "agc_hip_timing_reset", "agc_hip_timing_get",
     "agc_hip_sample_buffer", "agc_hip_copy_to_device",
-    "agc_hip_preprocess_dev",
+    "agc_hip_preprocess_dev", "agc_hip_preprocess",
     "agc_hip_splitters_set", "agc_hip_splitters_insert", "agc_hip_splitters_count",
     "agc_hip_determine_splitters_dev",
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",

@@ -299,6 +299,19 @@ int agc_hip_preprocess_dev(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw,
     return AGC_HIP_OK;
 }
 
+int agc_hip_preprocess(agc_hip_ctx *c, const uint8_t *h_raw, uint64_t n_raw, uint8_t *d_codes, uint64_t *h_n_codes)
+{
+    if (!c || !h_n_codes || (n_raw && (!h_raw || !d_codes)))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    *h_n_codes = 0;
+    if (!n_raw)
+        return AGC_HIP_OK;
+    CHK(ensure(c, c->d_in, n_raw + 64));
+    HIPCHK(c, hipMemcpyAsync(c->d_in.p, h_raw, n_raw, hipMemcpyHostToDevice, c->stream));
+    return agc_hip_preprocess_dev(c, (const uint8_t *)c->d_in.p, n_raw, d_codes, h_n_codes);
+}
+
 // ---------------------------------------------------------------------------
 // splitters
 // ---------------------------------------------------------------------------

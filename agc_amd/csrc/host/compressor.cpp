@@ -591,6 +591,7 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     struct Pending {
         std::vector<Contig> ctgs;
         std::vector<bytes_t> data;
+        std::vector<uint8_t> raw; // data[c] is a raw FASTA body (converted at upload)
         uint64_t bytes = 0;
     };
     std::deque<Pending> pending;
@@ -618,7 +619,12 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
                 ct.sample_idx = b;
                 ct.off = o;
                 ct.len = pending[b].data[c].size();
-                if (!I.hip_ok(DEVTI(agc_hip_copy_to_device(I.hip, d_base + o, pending[b].data[c].data(), ct.len)), "copy_to_device"))
+                if (c < pending[b].raw.size() && pending[b].raw[c]) { // a1 on the GPU; the converted length comes back
+                    uint64_t n_codes = 0;
+                    if (!I.hip_ok(DEVTI(agc_hip_preprocess(I.hip, pending[b].data[c].data(), ct.len, d_base + o, &n_codes)), "preprocess"))
+                        return false;
+                    ct.len = n_codes;
+                } else if (!I.hip_ok(DEVTI(agc_hip_copy_to_device(I.hip, d_base + o, pending[b].data[c].data(), ct.len)), "copy_to_device"))
                     return false;
                 o += ct.len;
                 batch.push_back(ct);
@@ -664,8 +670,13 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         bool opened = false;
         std::vector<std::string> ids;
         std::vector<bytes_t> contigs;
+        std::vector<uint8_t> raw; // contig still holds the FASTA body (line ends and all): converted on the GPU at upload
     };
-    auto read_file = [](std::string path) {
+    // preprocess_raw_contig (agc_compressor.cpp:907-951) of big contigs runs on the GPU (agc_hip_preprocess: the body goes to
+    // HBM as it is, the kernels drop the line ends and map the letters); small ones -- and adaptive mode, which mines new
+    // splitters from host copies -- are converted by the reading thread as before
+    const uint64_t GPU_A1_MIN = I.adaptive ? ~0ull : (1ull << 20);
+    auto read_file = [GPU_A1_MIN](std::string path) {
         FileData fd;
         FastaReader fr;
         if (!fr.open(path))
@@ -674,7 +685,10 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         std::string id;
         bytes_t contig;
         while (fr.read_contig_raw(id, contig)) {
-            preprocess_raw_contig(contig);
+            const bool keep_raw = contig.size() >= GPU_A1_MIN;
+            if (!keep_raw)
+                preprocess_raw_contig(contig);
+            fd.raw.push_back(keep_raw);
             fd.ids.emplace_back(id);
             fd.contigs.emplace_back(std::move(contig));
             contig.clear();
@@ -735,6 +749,7 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
                 cur.ctgs.push_back(ct);
                 cur.bytes += contig.size();
                 cur.data.emplace_back(std::move(contig));
+                cur.raw.push_back(ci < fd.raw.size() ? fd.raw[ci] : 0);
                 any_added = true;
                 if (I.concatenated && ++I.cnt_contigs_in_sample >= I.pack_cardinality) {
                     I.st.t_io += now() - t0;
@@ -822,14 +837,15 @@ bool CAGCCompressor::CloseProvideFrames(const uint8_t *frames, const uint64_t *o
     return true;
 }
 
-void CAGCCompressor::Impl::store_open_batch()
+void CAGCCompressor::Impl::store_open_batch(bool flush)
 {
     // samples that came through AddSampleDevice / ApplyRecord: the open collection batch is stored here, where
     // AddSampleFiles does it at its end (agc_compressor.cpp:2254-2255)
     if (stored_samples < processed_samples && processed_samples % pack_cardinality != 0) {
         coll.store_contig_batch((processed_samples / pack_cardinality) * pack_cardinality, processed_samples);
         stored_samples = processed_samples;
-        ar.flush_out_buffers();
+        if (flush)
+            ar.flush_out_buffers();
     }
 }
 
@@ -843,8 +859,12 @@ bool CAGCCompressor::Close(uint32_t no_threads)
         I.err("Close: CloseCollectPacks was called but the frames were never provided");
         return false;
     }
+    // the open collection batch (contig details of up to pack_cardinality samples: one thread of zstd-19 work, 0.4 s at human
+    // scale) is serialised while the entropy stage of the delta packs runs; both only buffer parts, which are flushed below in
+    // stream-id order whatever their arrival order
+    std::future<void> open_batch;
     if (!I.close_collected)
-        I.store_open_batch();
+        open_batch = std::async(std::launch::async, [&I] { I.store_open_batch(false); });
     const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
     double lt = now();
     auto LAP = [&](const char *what) {
@@ -853,7 +873,9 @@ bool CAGCCompressor::Close(uint32_t no_threads)
         lt = now();
     };
     I.finish_groups();
-    LAP("finish_groups (pack jobs + entropy stage + parts)");
+    if (open_batch.valid())
+        open_batch.get();
+    LAP("finish_groups (pack jobs + entropy stage + parts) || open collection batch");
     I.ar.flush_out_buffers();
     LAP("flush_out_buffers");
 

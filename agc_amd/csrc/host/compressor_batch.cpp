@@ -101,7 +101,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
             // proportional, spread evenly over the job list (neighbouring groups have similar packs)
             const uint64_t sz = jobs[i].data.size();
             acc += sz;
-            if ((double)(dev_acc + sz / 2) <= gpu_zstd_share * (double)acc) {
+            if ((double)dev_acc < gpu_zstd_share * (double)acc) {
                 keep.push_back(i);
                 dev_acc += sz;
             } else
@@ -115,6 +115,16 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         if (jobs[i].kind == 1)
             host_bytes += jobs[i].data.size();
     double t_dev = 0, t_host = 0;
+    if (laps && jobs.size() > 1000) {
+        uint64_t nb[4] = {0, 0, 0, 0}, nc[4] = {0, 0, 0, 0};
+        for (const ZJob &j : jobs) {
+            const int c = j.kind == 0 ? 0 : j.data.size() > dev_max ? 1 : j.data.size() > 16384 ? 2 : 3;
+            nb[c] += j.data.size();
+            ++nc[c];
+        }
+        std::cerr << "    entropy jobs: refs " << nc[0] << " (" << nb[0] / 1e6 << " MB), packs > 128 KiB " << nc[1] << " (" << nb[1] / 1e6 << " MB), packs 16-128 KiB "
+                  << nc[2] << " (" << nb[2] / 1e6 << " MB), packs <= 16 KiB " << nc[3] << " (" << nb[3] / 1e6 << " MB); device gets " << dev_jobs.size() << "\n";
+    }
     LAP("split");
     std::future<bool> dev_done;
     std::vector<uint64_t> src_off, dst_off;

@@ -580,7 +580,7 @@ struct CAGCCompressor::Impl {
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
     void run_jobs_round(std::vector<ZJob> &jobs);
     void build_close_jobs(std::vector<ZJob> &jobs);
-    void store_open_batch();
+    void store_open_batch(bool flush = true);
     // Close in steps (multi-GPU entropy stage, compressor.h: CloseCollectPacks / CloseProvideFrames)
     std::vector<ZJob> close_jobs;
     std::vector<uint32_t> close_dev_jobs;      // indices in close_jobs of the packs handed out

@@ -75,6 +75,9 @@ int agc_hip_copy_to_device(agc_hip_ctx *ctx, uint8_t *d_dst, const uint8_t *h_sr
 int agc_hip_preprocess_dev(agc_hip_ctx *ctx, const uint8_t *d_raw, uint64_t n_raw,
                            uint8_t *d_codes, uint64_t *h_n_codes);
 
+/* The same for a raw body in host memory (copied to HBM first): d_codes receives the codes, *h_n_codes their number. */
+int agc_hip_preprocess(agc_hip_ctx *ctx, const uint8_t *h_raw, uint64_t n_raw, uint8_t *d_codes, uint64_t *h_n_codes);
+
 /* ---- S1: splitter scan (a2-a4) ---------------------------------------- */
 /* Replaces the splitter set hs_splitters + bloom_splitters
  * (src/core/agc_compressor.h:625-626; hs.h:448-497; utils_adv.h:180-282):

@@ -457,3 +457,17 @@ int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     free(codes);
     return r;
 }
+
+/* a1 on the stand-in: the oracle's preprocess_raw_contig */
+size_t agco_preprocess(const u8 *raw, size_t n, u8 *out);
+int agc_hip_preprocess_dev(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw, uint8_t *d_codes, uint64_t *h_n)
+{
+    if (!c || !h_n)
+        return AGC_HIP_EINVAL;
+    *h_n = n_raw ? agco_preprocess(d_raw, n_raw, d_codes) : 0;
+    return AGC_HIP_OK;
+}
+int agc_hip_preprocess(agc_hip_ctx *c, const uint8_t *h_raw, uint64_t n_raw, uint8_t *d_codes, uint64_t *h_n)
+{
+    return agc_hip_preprocess_dev(c, h_raw, n_raw, d_codes, h_n);
+}
