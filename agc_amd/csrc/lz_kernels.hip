@@ -315,6 +315,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
     constexpr uint32_t WIDE_MAX_SLOTS = MAX_NO_TRIES; // (a budget of 8 made literal runs slower: more exact steps)
     uint32_t lit_streak = 0;
     bool try_wide = false;
+    bool force_exact = false; // the grouped probe could not settle position i: the next step is the exact one
     TextWin win{win_lds, 0, 0};
     while (i + key_len < n) {
         AGC_TRACE(4, i);
@@ -478,16 +479,99 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             }
             try_wide = false;
         }
+        // ---- grouped probe: positions i .. i+3, 16 lanes = 16 probe slots each, one round trip.  In the match / SNP / match
+        // rhythm the literal at the SNP and the 0-3 un-indexed positions after it (HASHING_STEP = 4) are settled together with
+        // the probe of the first position that has candidates; what the exact step would have seen for that position (the
+        // fingerprint hits before the first empty slot, in slot order) is handed to the verification below.  A group whose
+        // chain does not end within 16 slots, or whose key holds a non-ACGT symbol, is left to the exact step.
+        uint64_t cand = 0;
+        uint32_t epos = 0;
+        bool have_cands = false;
+        if (!force_exact) {
+            constexpr uint32_t MP_G = 4, MP_S = WAVE / MP_G;
+            const uint32_t g = lane / MP_S;
+            const uint32_t sa = (lane < key_len + MP_G - 1 && i + lane < n) ? (uint32_t)wtext[i + lane] : 0xFFu;
+            const uint64_t a0 = __ballot((sa & 1u) != 0), a1 = __ballot((sa & 2u) != 0), ai = __ballot(sa > 3);
+            const bool q_ok = i + g + key_len < n && ((ai >> g) & keybits) == 0;
+            bool is_empty = false, fp_ok = false;
+            if (q_ok) {
+                const uint64_t r0 = __brevll((a0 >> g) & keybits) >> (64 - key_len), r1 = __brevll((a1 >> g) & keybits) >> (64 - key_len);
+                const uint64_t hx = murmur64(spread_bits(r0) | (spread_bits(r1) << 1));
+                const uint32_t sl = ((uint32_t)hx + (lane % MP_S)) & ht_mask;
+                if (rd.is_short) {
+                    const uint32_t e = ((const uint32_t *)rd.table)[sl];
+                    is_empty = e == 0xFFFFFFFFu;
+                    epos = e >> 16;
+                    fp_ok = (e & 0xFFFFu) == (uint32_t)(hx >> 48);
+                } else {
+                    const uint64_t e = ((const uint64_t *)rd.table)[sl];
+                    is_empty = e == ~0ULL;
+                    epos = (uint32_t)(e >> 32);
+                    fp_ok = (uint32_t)e == (uint32_t)(hx >> 32);
+                }
+            }
+            const uint64_t em = __ballot(is_empty), fm = __ballot(fp_ok && !is_empty);
+            uint32_t f = 0;
+            bool to_exact = false;
+            for (; f < MP_G; ++f) {
+                if (!(i + f + key_len < n))
+                    break; // the loop ends here
+                const uint32_t em16 = (uint32_t)(em >> (f * MP_S)) & 0xFFFFu;
+                if (((ai >> f) & keybits) != 0 || !em16) {
+                    to_exact = true;
+                    break;
+                }
+                const uint32_t c16 = (uint32_t)(fm >> (f * MP_S)) & ((1u << __builtin_ctz(em16)) - 1u);
+                if (c16) {
+                    cand = (uint64_t)c16 << (f * MP_S);
+                    have_cands = true;
+                    break;
+                }
+            }
+            if (f) {
+                if (MODE == MODE_ENCODE) {
+                    if (stale_out) {
+                        __builtin_amdgcn_s_waitcnt(0); // lane 0's rolled-back bytes land before other lanes overwrite them
+                        stale_out = false;
+                    }
+                    if (lane < f)
+                        out[o + lane] = (uint8_t)('A' + sa);
+                    coop_out = true;
+                } else if (MODE == MODE_ESTIMATE) {
+                    if (est + f - 1 > peak)
+                        peak = est + f - 1; // loop-top checks of these f literal steps
+                    est += f;
+                } else if (lane < f)
+                    costs[o + lane] = 1;
+                o += f;
+                i += f;
+                pred_pos += f;
+                npl += f;
+                lit_streak += f;
+            }
+            if (!have_cands) {
+                force_exact = to_exact;
+                if (f) {
+                    try_wide = !to_exact && lit_streak >= WIDE_AFTER;
+                    continue;
+                }
+            }
+        }
         if (MODE == MODE_ESTIMATE) {
             if (est > peak)
                 peak = est; // the reference's loop-top check sees this value (lz_diff.cpp:868-869)
         }
-        // ---- exact step at position i.  key at text[i .. i+key_len)  (get_code, lz_diff.h:58-106) ----
         const uint8_t *tp = text + i;
+        const uint32_t max_len = n - i;
+        uint32_t s0;
+        if (have_cands)
+            s0 = (uint32_t)wtext[i];
+        else {
+        // ---- exact step at position i.  key at text[i .. i+key_len)  (get_code, lz_diff.h:58-106) ----
+        force_exact = false;
         const uint32_t s = lane < key_len ? (uint32_t)wtext[i + lane] : 0u;
         const uint64_t bad = __ballot(s > 3);
-        const uint32_t s0 = bcast_u32(s, 0);
-        const uint32_t max_len = n - i;
+        s0 = bcast_u32(s, 0);
 
         if (bad) {
             // N-run? (get_Nrun_len, lz_diff.h:122-132)
@@ -554,7 +638,6 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
         const uint32_t slot = ((uint32_t)h & ht_mask);
 
         // ---- find_best_match: 64 lanes = 64 probes ----
-        uint32_t epos;
         bool is_empty, fp_ok;
         if (rd.is_short) {
             const uint32_t e = ((const uint32_t *)rd.table)[(slot + lane) & ht_mask];
@@ -568,9 +651,10 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             fp_ok = (uint32_t)e == (uint32_t)(h >> 32);
         }
         const uint64_t em = __ballot(is_empty);
-        uint64_t cand = __ballot(fp_ok && !is_empty);
+        cand = __ballot(fp_ok && !is_empty);
         if (em)
             cand &= (1ULL << ctz64(em)) - 1ULL; // probes stop at the first empty slot
+        }
 
         uint32_t len_bck = 0, len_fwd = 0, match_pos = 0;
         uint32_t min_to_update = mml;
