@@ -35,6 +35,7 @@ struct ArenaChunk {
 struct agc_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t zstream = nullptr; // the entropy stage's own stream: agc_hip_zstd17_batch may run beside every other entry point
     std::string err;
 
     // splitter set
@@ -52,13 +53,13 @@ struct agc_hip_ctx {
 
     // scratch
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_stage, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
-        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_maybe, d_fjobs;
+        d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_zdstoff, d_maybe, d_fjobs;
 
     std::vector<SliceDesc> h_slices;
 
     // timing
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, zev0 = nullptr, zev1 = nullptr;
     double ms[AGC_HIP_K_COUNT] = {0};
     uint64_t launches[AGC_HIP_K_COUNT] = {0};
 };
@@ -81,16 +82,18 @@ struct agc_hip_ctx {
 
 namespace {
 
-int ensure(agc_hip_ctx *c, DevBuf &b, size_t bytes)
+int ensure(agc_hip_ctx *c, DevBuf &b, size_t bytes, hipStream_t stream = nullptr)
 {
     if (bytes <= b.cap)
         return AGC_HIP_OK;
+    if (!stream)
+        stream = c->stream;
     // headroom: batches of one collection differ by a few percent in size; growing in big steps keeps
     // hipFree/hipMalloc (hundreds of ms for multi-GB buffers) out of the steady state
     size_t want = std::max(bytes + bytes / 4, b.cap + b.cap / 2);
     want = (want + 255) & ~(size_t)255;
     if (b.p) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(stream));
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -136,6 +139,29 @@ struct KTimer {
     }
 };
 
+// the entropy stage's kernels: own events, own stream (only that call writes ms[AGC_HIP_K_ZSTD])
+struct ZTimer {
+    agc_hip_ctx *c;
+    explicit ZTimer(agc_hip_ctx *c_) : c(c_)
+    {
+        if (c->timing)
+            (void)hipEventRecord(c->zev0, c->zstream);
+    }
+    ~ZTimer()
+    {
+        if (c->timing) {
+            (void)hipEventRecord(c->zev1, c->zstream);
+            (void)hipEventSynchronize(c->zev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->zev0, c->zev1);
+            c->ms[AGC_HIP_K_ZSTD] += ms;
+            c->launches[AGC_HIP_K_ZSTD] += 1;
+        }
+    }
+};
+
+int ensure_z(agc_hip_ctx *c, DevBuf &b, size_t bytes) { return ensure(c, b, bytes, c->zstream); }
+
 int upload_refs(agc_hip_ctx *c)
 {
     if (!c->refs_dirty)
@@ -174,7 +200,8 @@ int agc_hip_create(agc_hip_ctx **out, int device)
     agc_hip_ctx *c = new agc_hip_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        hipStreamCreateWithFlags(&c->zstream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->zev0) != hipSuccess || hipEventCreate(&c->zev1) != hipSuccess) {
         delete c;
         return AGC_HIP_ENODEV;
     }
@@ -188,10 +215,12 @@ void agc_hip_destroy(agc_hip_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->zstream)
+        (void)hipStreamSynchronize(c->zstream);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_sbloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
-                      &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_maybe, &c->d_fjobs};
+                      &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs};
     for (DevBuf *b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -201,8 +230,14 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
         (void)hipEventDestroy(c->ev1);
+    if (c->zev0)
+        (void)hipEventDestroy(c->zev0);
+    if (c->zev1)
+        (void)hipEventDestroy(c->zev1);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
+    if (c->zstream)
+        (void)hipStreamDestroy(c->zstream);
     delete c;
 }
 
@@ -1258,6 +1293,7 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     if (!n)
         return AGC_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    const hipStream_t zs_ = c->zstream; // (this call shares no buffer, stream or event with the other entry points)
     const uint64_t src_total = h_src_off[n] - h_src_off[0];
     if (src_total && !h_src)
         return AGC_HIP_EINVAL;
@@ -1289,12 +1325,12 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].src_size > jobs[b].src_size; });
 
-    CHK(ensure(c, c->d_zsrc, src_total + 64));
-    CHK(ensure(c, c->d_zdst, dst_total + 64));
-    CHK(ensure(c, c->d_zsize, (size_t)n * 4));
-    CHK(ensure(c, c->d_zjobs, (size_t)n * sizeof(ZFrameJob)));
+    CHK(ensure_z(c, c->d_zsrc, src_total + 64));
+    CHK(ensure_z(c, c->d_zdst, dst_total + 64));
+    CHK(ensure_z(c, c->d_zsize, (size_t)n * 4));
+    CHK(ensure_z(c, c->d_zjobs, (size_t)n * sizeof(ZFrameJob)));
     if (src_total)
-        HIPCHK(c, hipMemcpyAsync(c->d_zsrc.p, h_src + h_src_off[0], src_total, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_zsrc.p, h_src + h_src_off[0], src_total, hipMemcpyHostToDevice, zs_));
     // workspace arena: as many frames per launch as the budget allows (a frame's tables must be zero at its start)
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
@@ -1310,7 +1346,7 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             used += ws_need[order[done + m]];
             ++m;
         }
-        CHK(ensure(c, c->d_zws, used));
+        CHK(ensure_z(c, c->d_zws, used));
         used = 0;
         for (uint32_t t = 0; t < m; ++t) {
             const uint32_t i = order[done + t];
@@ -1321,11 +1357,11 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             used += ws_need[i];
             sorted[done + t] = jb;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_zws.p, 0, used, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_zws.p, 0, used, zs_));
         HIPCHK(c, hipMemcpyAsync((ZFrameJob *)c->d_zjobs.p + done, sorted.data() + done, (size_t)m * sizeof(ZFrameJob), hipMemcpyHostToDevice,
-                                 c->stream));
+                                 zs_));
         {
-            KTimer t(c, AGC_HIP_K_ZSTD);
+            ZTimer t(c);
             uint32_t lanes = 32; // measured best on the pack mix of Close(): 64 lanes 2.30 s, 32 lanes 2.11 s per 50 k frames
             if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
                 lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
@@ -1336,21 +1372,21 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             const dim3 grid((m + lanes - 1) / lanes), block(64);
             const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
             if (wps >= 4)
-                hipLaunchKernelGGL(zstd_frames_kernel<4>, grid, block, 0, c->stream, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                hipLaunchKernelGGL(zstd_frames_kernel<4>, grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             else if (wps == 3)
-                hipLaunchKernelGGL(zstd_frames_kernel<3>, grid, block, 0, c->stream, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                hipLaunchKernelGGL(zstd_frames_kernel<3>, grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             else
-                hipLaunchKernelGGL(zstd_frames_kernel<2>, grid, block, 0, c->stream, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                hipLaunchKernelGGL(zstd_frames_kernel<2>, grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
         }
         HIPCHK(c, hipGetLastError());
         done += m;
     }
     std::vector<uint32_t> sizes(n);
-    HIPCHK(c, hipMemcpyAsync(sizes.data(), c->d_zsize.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(sizes.data(), c->d_zsize.p, (size_t)n * 4, hipMemcpyDeviceToHost, zs_));
+    HIPCHK(c, hipStreamSynchronize(zs_));
     for (uint32_t i = 0; i < n; ++i)
         h_dst_off[i + 1] = h_dst_off[i] + sizes[i];
     const uint64_t tot = h_dst_off[n];
@@ -1359,14 +1395,14 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     if (!h_dst)
         return AGC_HIP_EINVAL;
     // compact the frames and bring them back in one copy
-    CHK(ensure(c, c->d_zout, tot + 64));
-    CHK(ensure(c, c->d_dstoff, (size_t)(n + 1) * 8));
-    HIPCHK(c, hipMemcpyAsync(c->d_dstoff.p, h_dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(zstd_gather_kernel, dim3(grid_for(n, 1, 16384)), dim3(256), 0, c->stream, (const ZFrameJob *)c->d_zjobs.p, n,
-                       (const uint64_t *)c->d_dstoff.p, (const uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zout.p);
+    CHK(ensure_z(c, c->d_zout, tot + 64));
+    CHK(ensure_z(c, c->d_zdstoff, (size_t)(n + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(c->d_zdstoff.p, h_dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, zs_));
+    hipLaunchKernelGGL(zstd_gather_kernel, dim3(grid_for(n, 1, 16384)), dim3(256), 0, zs_, (const ZFrameJob *)c->d_zjobs.p, n,
+                       (const uint64_t *)c->d_zdstoff.p, (const uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zout.p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(h_dst, c->d_zout.p, tot, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_dst, c->d_zout.p, tot, hipMemcpyDeviceToHost, zs_));
+    HIPCHK(c, hipStreamSynchronize(zs_));
     return AGC_HIP_OK;
 }
 

@@ -7,6 +7,7 @@ namespace agc {
 CAGCCompressor::CAGCCompressor() : p(new Impl) {}
 CAGCCompressor::~CAGCCompressor()
 {
+    p->z_shutdown(); // the entropy thread uses the device context
     if (p->hip)
         agc_hip_destroy(p->hip);
 }
@@ -109,8 +110,10 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     }
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
+    I.zpool.reset(new ThreadPool(nt));
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
+    I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
     I.choose_entropy_stage();
     I.created = true;
 
@@ -258,8 +261,10 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     }
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
+    I.zpool.reset(new ThreadPool(nt));
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
+    I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
     I.choose_entropy_stage();
 
     if (!I.ar.open(out_archive_name)) {
@@ -797,6 +802,7 @@ bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off
     Impl &I = *p;
     if (!I.created || I.close_collected || !src || !off || !n)
         return false;
+    I.z_wait_all(); // (the staging buffers below are the entropy thread's)
     I.store_open_batch();
     I.close_jobs.clear();
     I.build_close_jobs(I.close_jobs);
@@ -837,6 +843,14 @@ bool CAGCCompressor::CloseProvideFrames(const uint8_t *frames, const uint64_t *o
     return true;
 }
 
+bool CAGCCompressor::Drain()
+{
+    if (!p->created)
+        return false;
+    p->z_wait_all();
+    return true;
+}
+
 void CAGCCompressor::Impl::store_open_batch(bool flush)
 {
     // samples that came through AddSampleDevice / ApplyRecord: the open collection batch is stored here, where
@@ -873,6 +887,7 @@ bool CAGCCompressor::Close(uint32_t no_threads)
         lt = now();
     };
     I.finish_groups();
+    I.z_wait_all();
     if (open_batch.valid())
         open_batch.get();
     LAP("finish_groups (pack jobs + entropy stage + parts) || open collection batch");

@@ -34,6 +34,7 @@ struct CompressorStats {
     uint64_t archive_bytes = 0;
     // symbols the LZ kernels were asked to look at (algorithmic bytes of SURVEY 8d: every text once + its reference once)
     double t_zstd_dev = 0, t_zstd_host = 0, t_zstd_stage = 0; // entropy stage: device call, host pool, staging copies (all inside t_zstd)
+    double t_zstd_wait = 0;        // time the caller stood still for the entropy stage (t_zstd runs beside the steps; this part was not hidden)
     uint64_t zstd_dev_in = 0;      // bytes entropy-coded on the GPU (part of zstd_in)
     uint64_t enc_text = 0, enc_ref = 0, est_text = 0, est_ref = 0, cv_text = 0, cv_ref = 0;
     uint64_t windows = 0, commit_runs = 0, revalidated = 0; // process_batch calls, commit runs inside them, segments classified again
@@ -107,6 +108,7 @@ public:
     // has them compressed (agc_hip_zstd17_batch on any GPU) and returns the frames in the same order; Close then finishes with
     // them.  Without these two calls Close compresses everything itself.
     bool CloseCollectPacks(const uint8_t **src, const uint64_t **off, uint32_t *n);
+    bool Drain(); // waits for the asynchronous entropy stage (every part handed over so far compressed and written)
     bool CloseProvideFrames(const uint8_t *frames, const uint64_t *off);
 
     const CompressorStats &Stats() const;

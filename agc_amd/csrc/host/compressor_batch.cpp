@@ -28,26 +28,87 @@ void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, byte
 // at the same time.
 void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
 {
-    // a very large call (Close() of a big collection) is cut into a few rounds so that the device / host split can follow
-    // the rates it measures (the first round starts from the previous call's share)
-    uint64_t pack_bytes = 0;
-    for (const ZJob &j : jobs)
-        if (j.kind == 1)
-            pack_bytes += j.data.size();
-    // (one round: the device's time for a launch is the serial time of ONE frame whatever the number of frames -- rounds only add up)
-    const size_t rounds = 1;
-    (void)pack_bytes;
-    if (rounds > 1) {
-        for (size_t r = 0; r < rounds; ++r) {
-            const size_t b = jobs.size() * r / rounds, e = jobs.size() * (r + 1) / rounds;
-            std::vector<ZJob> part(std::make_move_iterator(jobs.begin() + b), std::make_move_iterator(jobs.begin() + e));
-            run_jobs_round(part);
-            std::move(part.begin(), part.end(), jobs.begin() + b);
-        }
-    } else
-        run_jobs_round(jobs);
+    // (one round: the device's time for a launch is close to the serial time of ONE frame whatever the number of frames --
+    // rounds only add up)
+    z_wait_all(); // zpool, the zstd contexts and the staging buffers are the entropy thread's while it works
+    run_jobs_round(jobs);
     if (add_parts)
         add_job_parts(jobs, 0, jobs.size());
+}
+
+// ---- the asynchronous entropy stage ----------------------------------------
+void CAGCCompressor::Impl::z_submit(std::vector<ZJob> &&jobs)
+{
+    if (jobs.empty())
+        return;
+    {
+        std::lock_guard<std::mutex> lk(z_mtx);
+        if (!z_thread.joinable())
+            z_thread = std::thread([this] { z_main(); });
+        z_queue.emplace_back(std::move(jobs));
+    }
+    z_cv.notify_all();
+}
+
+void CAGCCompressor::Impl::z_main()
+{
+    for (;;) {
+        std::vector<ZJob> batch;
+        {
+            std::unique_lock<std::mutex> lk(z_mtx);
+            z_cv.wait(lk, [&] { return z_stop || !z_queue.empty(); });
+            if (z_queue.empty())
+                return; // (z_stop)
+            batch = std::move(z_queue.front());
+            z_queue.pop_front();
+            // small registrations pile up while a big one is in the works: take them together (one device launch)
+            while (!z_queue.empty() && batch.size() < 4096) {
+                for (auto &j : z_queue.front())
+                    batch.emplace_back(std::move(j));
+                z_queue.pop_front();
+            }
+            z_busy = true;
+        }
+        run_jobs_round(batch);
+        for (ZJob &j : batch) {
+            st.zstd_in += j.data.size();
+            st.zstd_out += j.out.size();
+            j.slot->out = std::move(j.out);
+            j.slot->meta = j.meta;
+            j.slot->ready.store(true, std::memory_order_release);
+        }
+        batch.clear();
+        {
+            std::lock_guard<std::mutex> lk(z_mtx);
+            z_busy = false;
+        }
+        z_idle_cv.notify_all();
+    }
+}
+
+void CAGCCompressor::Impl::z_wait_all()
+{
+    if (!z_thread.joinable())
+        return;
+    const double t0 = now();
+    {
+        std::unique_lock<std::mutex> lk(z_mtx);
+        z_idle_cv.wait(lk, [&] { return z_queue.empty() && !z_busy; });
+    }
+    st.t_zstd_wait += now() - t0;
+    ar.try_drain();
+}
+
+void CAGCCompressor::Impl::z_shutdown()
+{
+    if (!z_thread.joinable())
+        return;
+    {
+        std::lock_guard<std::mutex> lk(z_mtx);
+        z_stop = true;
+    }
+    z_cv.notify_all();
+    z_thread.join();
 }
 
 void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
@@ -92,7 +153,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         host_jobs.insert(host_jobs.end(), dev_jobs.begin(), dev_jobs.end());
         std::sort(host_jobs.begin(), host_jobs.end());
         dev_jobs.clear();
-    } else if (gpu_zstd_share < 1.0 && pool->size() > 1) {
+    } else if (gpu_zstd_share < 1.0 && zpool->size() > 1) {
         // both engines work at the same time: the device keeps the share of the pack bytes that makes them finish together
         // (its measured rate against the host pool's, updated after every call); the rest joins the host jobs
         uint64_t acc = 0, dev_acc = 0;
@@ -138,7 +199,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
             src_off[t + 1] = src_off[t] + jobs[dev_jobs[t]].data.size();
         if (zsrc_buf.size() < src_off[nd])
             zsrc_buf.resize(src_off[nd]);
-        pool->parallel_for(nd, [&](size_t t, unsigned) { memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size()); });
+        zpool->parallel_for(nd, [&](size_t t, unsigned) { memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size()); });
         if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
             static int dump_no = 0;
             const std::string base = std::string(dump) + "/packs_" + std::to_string(dump_no++);
@@ -165,7 +226,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     const double th0 = now();
     st.t_zstd_stage += th0 - ts0;
     LAP("gather + launch");
-    pool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
+    zpool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
         ZJob &j = jobs[host_jobs[hi]];
         ZstdCtx &z = *zctx[tid];
         const bytes_t *src = &j.data;
@@ -197,7 +258,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         LAP("wait for the device");
         const double ts1 = now();
         if (!ok) { // the device refused: libzstd does them after all (same bytes)
-            pool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
+            zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
                 ZJob &j = jobs[dev_jobs[t]];
                 size_t bound = zstd.compressBound(j.data.size());
                 bytes_t packed(bound + 1);
@@ -205,7 +266,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 finish(j, packed, ps, 0);
             });
         } else {
-            pool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned) {
+            zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned) {
                 ZJob &j = jobs[dev_jobs[t]];
                 const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);
                 bytes_t packed(zdst_buf.begin() + dst_off[t], zdst_buf.begin() + dst_off[t + 1]);
@@ -1515,11 +1576,18 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
     if (verbosity > 1)
         std::cerr << "registration: " << placed.size() << " items; host-only seconds so far: scan " << st.h_scan << " classify " << st.h_classify
                   << " register " << st.h_register << " encode " << st.h_encode << " store " << st.h_store << std::endl;
-    run_jobs(all_jobs, false);
+    // the parts take their places in the archive now (per registration, then its end-of-registration steps); their payload
+    // follows from the entropy thread
+    for (ZJob &j : all_jobs)
+        j.slot = std::make_shared<PartSlot>();
     for (uint32_t sidx = 0; sidx < n_regs; ++sidx) {
-        add_job_parts(all_jobs, sidx ? jobs_end[sidx - 1] : 0, jobs_end[sidx]);
+        for (size_t i = sidx ? jobs_end[sidx - 1] : 0; i < jobs_end[sidx]; ++i)
+            ar.add_part_deferred(all_jobs[i].stream_id, all_jobs[i].slot);
         after_registration();
     }
+    z_submit(std::move(all_jobs));
+    if (sync_entropy)
+        z_wait_all();
     return true;
 }
 
@@ -1560,7 +1628,11 @@ void CAGCCompressor::Impl::finish_groups()
     }
     std::vector<ZJob> jobs;
     build_close_jobs(jobs);
-    run_jobs(jobs);
+    for (ZJob &j : jobs) {
+        j.slot = std::make_shared<PartSlot>();
+        ar.add_part_deferred(j.stream_id, j.slot);
+    }
+    z_submit(std::move(jobs)); // (Close waits for the entropy thread, then flushes)
 }
 
 // the pack jobs of every group's open pack (+ the parts an appended archive's untouched groups keep as they are)

@@ -229,6 +229,7 @@ struct ZJob { // one archive part to produce
     bool repetitive = false;
     bytes_t out;
     uint64_t meta = 0;
+    std::shared_ptr<PartSlot> slot; // asynchronous entropy stage: where the finished part goes (already queued in the archive)
 };
 
 // bytes2tuples, src/common/segment.h:73-138
@@ -476,8 +477,25 @@ struct CAGCCompressor::Impl {
     int device = 0;
     agc_hip_ctx *hip = nullptr;
     ZstdApi zstd;
-    std::unique_ptr<ThreadPool> pool;
-    std::vector<std::unique_ptr<ZstdCtx>> zctx;
+    std::unique_ptr<ThreadPool> pool;   // the stages of a step
+    std::unique_ptr<ThreadPool> zpool;  // the entropy stage (runs beside the steps)
+    std::vector<std::unique_ptr<ZstdCtx>> zctx; // one per zpool thread
+
+    // Asynchronous entropy stage.  The reference's workers compress a pack the moment it fills (segment.h:172-215) while the
+    // other workers go on; here the zstd jobs of a registration are handed to one background thread that drives the device
+    // (agc_hip_zstd17_batch, own HIP stream) and zpool; their parts take their place in the archive at once (PartSlot) and are
+    // written, in order, when the payload is there.  Close() only drains.  AGC_AMD_SYNC_ENTROPY=1: every registration waits.
+    std::thread z_thread;
+    std::mutex z_mtx;
+    std::condition_variable z_cv, z_idle_cv;
+    std::deque<std::vector<ZJob>> z_queue;
+    bool z_busy = false, z_stop = false;
+    bool sync_entropy = false;
+    void z_submit(std::vector<ZJob> &&jobs);
+    void z_wait_all();
+    void z_main();
+    void z_shutdown();
+    ~Impl() { z_shutdown(); }
 
     bool created = false;
     uint32_t pack_cardinality = 50, k = 31, segment_size = 60000, mml = 20, verbosity = 0;

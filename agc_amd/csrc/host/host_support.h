@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <dlfcn.h>
 #include <functional>
 #include <map>
@@ -170,9 +172,22 @@ public:
 //   footer = #streams, per stream: name\0, #parts, raw_size, (offset,size)*, then 8-byte LE footer size
 //                                                             archive.cpp:142-169, io.h:371-380
 // ---------------------------------------------------------------------------
+// a part whose payload is still being compressed (the asynchronous entropy stage): it takes its place in the archive's
+// part order when it is handed over; the bytes are written when they are there
+struct PartSlot {
+    bytes_t out;
+    uint64_t meta = 0;
+    std::atomic<bool> ready{false};
+};
+
 class ArchiveWriter {
     struct Part {
         uint64_t offset, size;
+    };
+    struct BufPart {
+        bytes_t d;
+        uint64_t meta;
+        std::shared_ptr<PartSlot> slot; // set: d / meta come from the slot once it is ready
     };
     struct Stream {
         std::string name;
@@ -181,7 +196,10 @@ class ArchiveWriter {
     };
     std::vector<Stream> streams;
     std::unordered_map<std::string, int> ids;
-    std::map<int, std::vector<std::pair<bytes_t, uint64_t>>> buffer;
+    typedef std::map<int, std::vector<BufPart>> buffer_t;
+    buffer_t buffer;
+    std::deque<buffer_t> events; // flushes waiting for the payload of one of their parts (written strictly in this order)
+    bool buffer_deferred = false;
     FILE *f = nullptr;
     bool own = false;
     bytes_t wbuf;
@@ -271,11 +289,15 @@ public:
     void add_part(int id, const bytes_t &d, uint64_t meta = 0)
     {
         std::lock_guard<std::mutex> lk(mtx);
+        if (!events.empty())
+            io_error = true; // (never: the callers drain first) an immediate part must not overtake a queued flush
         add_part_now(id, d, meta);
     }
     void add_part(int id, const uint8_t *d, size_t n, uint64_t meta)
     {
         std::lock_guard<std::mutex> lk(mtx);
+        if (!events.empty())
+            io_error = true;
         streams[id].parts.push_back({f_offset, n});
         f_offset += write_num(meta);
         put(d, n);
@@ -284,15 +306,67 @@ public:
     void add_part_buffered(int id, bytes_t &&d, uint64_t meta)
     {
         std::lock_guard<std::mutex> lk(mtx);
-        buffer[id].emplace_back(std::move(d), meta);
+        buffer[id].push_back(BufPart{std::move(d), meta, nullptr});
     }
+    void add_part_deferred(int id, const std::shared_ptr<PartSlot> &slot)
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        buffer[id].push_back(BufPart{bytes_t(), 0, slot});
+        buffer_deferred = true;
+    }
+
+private:
+    void write_event(buffer_t &b)
+    {
+        for (auto &x : b)
+            for (auto &y : x.second) {
+                if (y.slot)
+                    add_part_now(x.first, y.slot->out, y.slot->meta);
+                else
+                    add_part_now(x.first, y.d, y.meta);
+            }
+    }
+    static bool event_ready(const buffer_t &b)
+    {
+        for (auto &x : b)
+            for (auto &y : x.second)
+                if (y.slot && !y.slot->ready.load(std::memory_order_acquire))
+                    return false;
+        return true;
+    }
+    void drain_locked()
+    {
+        while (!events.empty() && event_ready(events.front())) {
+            write_event(events.front());
+            events.pop_front();
+        }
+    }
+
+public:
+    // archive.cpp:332-351.  With deferred parts in flight the flush is queued; queued flushes are written in order as soon as
+    // their payloads are there (try_drain), so the file is laid out exactly as if every part had been ready at once
     void flush_out_buffers()
     {
         std::lock_guard<std::mutex> lk(mtx);
-        for (auto &x : buffer)
-            for (auto &y : x.second)
-                add_part_now(x.first, y.first, y.second);
-        buffer.clear();
+        if (!buffer.empty()) {
+            if (events.empty() && !buffer_deferred)
+                write_event(buffer);
+            else
+                events.emplace_back(std::move(buffer));
+            buffer.clear();
+            buffer_deferred = false;
+        }
+        drain_locked();
+    }
+    void try_drain()
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        drain_locked();
+    }
+    bool pending_events()
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        return !events.empty();
     }
     // ~CArchive -> Close: flush buffered parts, footer, 8-byte footer size (archive.cpp:68-85)
     void close()

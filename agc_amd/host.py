@@ -14,7 +14,7 @@ STAT_NAMES = ["bases", "segments", "new_groups", "one_splitter", "middle_tried",
               "ref_bytes", "zstd_in", "zstd_out", "archive_bytes",
               "t_scan", "t_classify", "t_gpu_aux", "t_register", "t_encode", "t_store", "t_zstd", "t_io", "t_device",
               "h_scan", "h_classify", "h_gpu_aux", "h_register", "h_encode", "h_store", "windows", "commit_runs", "revalidated",
-              "enc_text", "enc_ref", "est_text", "est_ref", "cv_text", "cv_ref", "zstd_dev_in", "t_zstd_dev", "t_zstd_host", "t_zstd_stage"]
+              "enc_text", "enc_ref", "est_text", "est_ref", "cv_text", "cv_ref", "zstd_dev_in", "t_zstd_dev", "t_zstd_host", "t_zstd_stage", "t_zstd_wait"]
 
 _lib = None
 
@@ -33,6 +33,7 @@ def bind(L):
     L.agc_cmp_add_sample_files.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32]
     L.agc_cmp_add_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_close.argtypes = [vp, C.c_uint32]
+    L.agc_cmp_drain.argtypes = [vp]
     L.agc_cmp_close_collect_packs.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32)]
     L.agc_cmp_close_provide_frames.argtypes = [vp, vp, vp]
     L.agc_cmp_zstd_version.argtypes = [vp]
@@ -154,6 +155,11 @@ class Compressor:
     def apply_record(self, h_ptr, n, d_ptr=None):
         if not self.L.agc_cmp_apply_record(self.h, h_ptr, n, d_ptr):
             raise RuntimeError("ApplyRecord failed (see stderr)")
+
+    def drain(self):
+        """waits for the entropy stage that runs beside the add calls (never needed for correctness: close() drains)"""
+        if not self.L.agc_cmp_drain(self.h):
+            raise RuntimeError("Drain failed")
 
     def close_collect_packs(self):
         """(src bytes as a numpy view, offsets [n + 1]) of the pending packs a device may compress; valid until close()"""

@@ -47,6 +47,11 @@ int agc_cmp_prepare_sample_packed_dev(void *h, const char *sample_name, uint32_t
                                       const uint64_t *ctg_off);
 /* CAGCCompressor::Close (agc_compressor.cpp:2094-2115, 2386-2400) */
 int agc_cmp_close(void *h, uint32_t n_threads);
+/* The entropy stage runs beside the add calls (the reference's workers compress a pack when it fills while the others go on,
+ * segment.h:172-215; here one background thread drives the GPU zstd kernel and a host pool).  agc_cmp_drain waits until every
+ * part handed over so far is compressed and written -- never needed for correctness (agc_cmp_close drains), only to put a
+ * clean line between two measured regions. */
+int agc_cmp_drain(void *h);
 /* Close in steps (entropy stage spread over several GPUs): the inputs of the pending delta packs a device may compress
  * (pack i = src[off[i] .. off[i+1]), n packs), then their level-17 zstd frames in the same order (frame i =
  * frames[off[i] .. off[i+1])), then agc_cmp_close.  The buffers returned by the first call stay valid until agc_cmp_close. */

@@ -59,10 +59,13 @@ def test_host_compressor_header_matches_the_library_and_the_binding():
     assert decl == defined
     bound = sorted(set(re.findall(r"L\.(agc_cmp_[a-z0-9_]+)\.", open(host.__file__).read())))
     assert bound == decl
-    L = ctypes.CDLL(os.path.join(ROOT, "agc_amd", "libagc_hip.so"), mode=ctypes.RTLD_GLOBAL)  # its DT_NEEDED, found by $ORIGIN anyway
-    L = ctypes.CDLL(host.LIB_PATH)
-    for s in decl:
-        assert hasattr(L, s), s
+    # loaded in a child process: the product's libagc_hip.so must not stay in this process, where other tests load the host
+    # library linked against the CPU stand-in of the same soname
+    import subprocess
+    import sys
+    code = ("import ctypes,sys\nL = ctypes.CDLL(sys.argv[1])\n"
+            "missing = [s for s in sys.argv[2:] if not hasattr(L, s)]\nassert not missing, missing\n")
+    subprocess.check_call([sys.executable, "-c", code, host.LIB_PATH] + decl)
 
 
 def test_product_does_not_reach_into_tests():

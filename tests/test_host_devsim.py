@@ -118,21 +118,45 @@ def test_product_library_is_not_the_simulator():
     assert b"gfx950" in blob and b"devsim" not in blob
 
 
+_PACKED_CHILD = r"""
+import ctypes as ct, json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from agc_amd import capi, fasta, host
+from tests.devsim import build as simbuild
+opt, files, out = json.loads(sys.argv[2]), json.loads(sys.argv[3]), sys.argv[4]
+lib = host.bind(ct.CDLL(simbuild.SIM_HOST))
+sim = ct.CDLL(simbuild.SIM_HIP)
+sim.agc_hip_packed_words_bytes.restype = ct.c_uint64
+sim.agc_hip_packed_words_bytes.argtypes = [ct.c_uint64]
+sim.agc_hip_packed_index_bytes.restype = ct.c_uint64
+sim.agc_hip_packed_index_bytes.argtypes = [ct.c_uint64]
+sim.agc_hip_pack_dev.argtypes = [ct.c_void_p] * 2 + [ct.c_uint64] + [ct.c_void_p] * 3 + [ct.c_uint64, ct.c_void_p]
+cmp_ = host.Compressor(lib=lib)
+cmp_.create(out, pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"], min_match_len=opt["-l"], n_threads=2)
+ctx = ct.c_void_p(1)  # the stand-in's pack entry point only checks for a context pointer
+for f in files:
+    names, codes, off = fasta.read_codes(f)
+    n = codes.size
+    words = np.zeros(int(sim.agc_hip_packed_words_bytes(n)) // 4, np.uint32)
+    index = np.zeros(int(sim.agc_hip_packed_index_bytes(n)) // 4, np.int32)
+    esc = np.zeros((n // 1024 + 2) * 1024, np.uint8)
+    cnt = np.zeros(1, np.uint64)
+    assert sim.agc_hip_pack_dev(ctx, codes.ctypes.data, n, words.ctypes.data, index.ctypes.data, esc.ctypes.data, n // 1024 + 2, cnt.ctypes.data) == 0
+    pk = capi.Packed(words.ctypes.data, index.ctypes.data, esc.ctypes.data, n)
+    cmp_.add_sample_packed_dev(fasta.sample_name(f), names, pk, off)
+cmp_.close()
+cmp_.close_handle()
+"""
+
+
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_snp", "syn_shuffled"])
 def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, tmp_path):
     """AddSamplePackedDevice: every sample handed over in the 2-bit layout (escaped blocks for N runs / IUPAC codes, contigs at
-    arbitrary symbol offsets); the archive must be the one the reference CLI writes from the FASTA files"""
-    import ctypes as ct
-    import numpy as np
-    from agc_amd import capi, fasta, host
-    from tests.devsim import build as simbuild
-    lib = host.bind(ct.CDLL(simbuild.SIM_HOST))
-    sim = ct.CDLL(simbuild.SIM_HIP)
-    sim.agc_hip_packed_words_bytes.restype = ct.c_uint64
-    sim.agc_hip_packed_words_bytes.argtypes = [ct.c_uint64]
-    sim.agc_hip_packed_index_bytes.restype = ct.c_uint64
-    sim.agc_hip_packed_index_bytes.argtypes = [ct.c_uint64]
-    sim.agc_hip_pack_dev.argtypes = [ct.c_void_p] * 2 + [ct.c_uint64] + [ct.c_void_p] * 3 + [ct.c_uint64, ct.c_void_p]
+    arbitrary symbol offsets); the archive must be the one the reference CLI writes from the FASTA files.  (In a child process:
+    the host library linked with the CPU stand-in must not meet the product's libagc_hip.so of the same name.)"""
+    import json
+    import sys
     args, _ = C.CONFIGS[name]
     opt = {"-k": 31, "-l": 20, "-s": 60000, "-b": 50}
     for i in range(len(args) - 1):
@@ -140,20 +164,7 @@ def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, tmp_
             opt[args[i]] = int(args[i + 1])
     files = C.build(name, str(tmp_path / "in"))
     out = str(tmp_path / "packed.agc")
-    cmp_ = host.Compressor(lib=lib)
-    cmp_.create(out, pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"], min_match_len=opt["-l"], n_threads=2)
-    ctx = ct.c_void_p(1)  # the stand-in's pack entry point only checks for a context pointer
-    for f in files:
-        names, codes, off = fasta.read_codes(f)
-        n = codes.size
-        words = np.zeros(int(sim.agc_hip_packed_words_bytes(n)) // 4, np.uint32)
-        index = np.zeros(int(sim.agc_hip_packed_index_bytes(n)) // 4, np.int32)
-        esc = np.zeros((n // 1024 + 2) * 1024, np.uint8)
-        cnt = np.zeros(1, np.uint64)
-        assert sim.agc_hip_pack_dev(ctx, codes.ctypes.data, n, words.ctypes.data, index.ctypes.data, esc.ctypes.data, n // 1024 + 2, cnt.ctypes.data) == 0
-        pk = capi.Packed(words.ctypes.data, index.ctypes.data, esc.ctypes.data, n)
-        cmp_.add_sample_packed_dev(fasta.sample_name(f), names, pk, off)
-    cmp_.close()
-    cmp_.close_handle()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, "-c", _PACKED_CHILD, root, json.dumps(opt), json.dumps(files), out])
     got = open(out, "rb").read()
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
