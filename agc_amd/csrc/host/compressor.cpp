@@ -110,7 +110,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     }
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
-    I.zpool.reset(new ThreadPool(nt));
+    I.zpool.reset(new ThreadPool(nt, 10));
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
@@ -261,7 +261,7 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     }
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
-    I.zpool.reset(new ThreadPool(nt));
+    I.zpool.reset(new ThreadPool(nt, 10));
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;

@@ -155,22 +155,26 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         dev_jobs.clear();
     } else if (gpu_zstd_share < 1.0 && zpool->size() > 1) {
         // both engines work at the same time: the device keeps the share of the pack bytes that makes them finish together
-        // (its measured rate against the host pool's, updated after every call); the rest joins the host jobs
-        uint64_t acc = 0, dev_acc = 0;
+        // (its measured rate against the host pool's, updated after every call).  It takes the SMALLEST packs: one lane parses
+        // one frame, so a launch lasts as long as its longest frame, while a host thread's time only follows the bytes
+        uint64_t total = 0, dev_acc = 0;
+        for (uint32_t i : dev_jobs)
+            total += jobs[i].data.size();
+        std::vector<uint32_t> by_size(dev_jobs);
+        std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return jobs[a].data.size() < jobs[b].data.size(); });
         std::vector<uint32_t> keep;
-        for (uint32_t i : dev_jobs) {
-            // proportional, spread evenly over the job list (neighbouring groups have similar packs)
-            const uint64_t sz = jobs[i].data.size();
-            acc += sz;
-            if ((double)dev_acc < gpu_zstd_share * (double)acc) {
+        for (uint32_t i : by_size) {
+            if ((double)dev_acc < gpu_zstd_share * (double)total) {
                 keep.push_back(i);
-                dev_acc += sz;
+                dev_acc += jobs[i].data.size();
             } else
                 host_jobs.push_back(i);
         }
-        std::sort(host_jobs.begin(), host_jobs.end());
+        std::sort(keep.begin(), keep.end());
         dev_jobs.swap(keep);
     }
+    // host pool: longest jobs first (the tail of the pool is then made of short ones)
+    std::stable_sort(host_jobs.begin(), host_jobs.end(), [&](uint32_t a, uint32_t b) { return jobs[a].data.size() > jobs[b].data.size(); });
     uint64_t host_bytes = 0;
     for (uint32_t i : host_jobs)
         if (jobs[i].kind == 1)
@@ -197,27 +201,30 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         src_off.assign(nd + 1, 0);
         for (size_t t = 0; t < nd; ++t)
             src_off[t + 1] = src_off[t] + jobs[dev_jobs[t]].data.size();
-        if (zsrc_buf.size() < src_off[nd])
-            zsrc_buf.resize(src_off[nd]);
-        zpool->parallel_for(nd, [&](size_t t, unsigned) { memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size()); });
-        if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
-            static int dump_no = 0;
-            const std::string base = std::string(dump) + "/packs_" + std::to_string(dump_no++);
-            if (FILE *f = fopen((base + ".bin").c_str(), "wb")) {
-                fwrite(zsrc_buf.data(), 1, src_off[nd], f);
-                fclose(f);
-            }
-            if (FILE *f = fopen((base + ".off").c_str(), "wb")) {
-                fwrite(src_off.data(), 8, nd + 1, f);
-                fclose(f);
-            }
-        }
         const uint64_t cap = src_off[nd] + 32 * nd + 64; // a frame never exceeds its input by more than the headers
-        if (zdst_buf.size() < cap)
-            zdst_buf.resize(cap);
         dst_off.assign(nd + 1, 0);
         dev_done = std::async(std::launch::async, [&, nd, cap] {
             const double td = now();
+            // (staging and gather run here, beside the host pool: they are part of the device's side of the split)
+            if (zsrc_buf.size() < src_off[nd])
+                zsrc_buf.resize(src_off[nd]);
+            if (zdst_buf.size() < cap)
+                zdst_buf.resize(cap);
+            for (size_t t = 0; t < nd; ++t)
+                memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size());
+            if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
+                static int dump_no = 0;
+                const std::string base = std::string(dump) + "/packs_" + std::to_string(dump_no++);
+                if (FILE *f = fopen((base + ".bin").c_str(), "wb")) {
+                    fwrite(zsrc_buf.data(), 1, src_off[nd], f);
+                    fclose(f);
+                }
+                if (FILE *f = fopen((base + ".off").c_str(), "wb")) {
+                    fwrite(src_off.data(), 8, nd + 1, f);
+                    fclose(f);
+                }
+            }
+
             const bool ok = hip_ok(agc_hip_zstd17_batch(hip, (uint32_t)nd, zsrc_buf.data(), src_off.data(), zdst_buf.data(), cap, dst_off.data()), "zstd17_batch");
             t_dev = now() - td;
             return ok;

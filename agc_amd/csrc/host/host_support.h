@@ -12,6 +12,9 @@
 #include <deque>
 #include <memory>
 #include <dlfcn.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -131,12 +134,18 @@ class ThreadPool {
     }
 
 public:
-    explicit ThreadPool(unsigned n)
+    // nice_value > 0: the workers yield to the other threads of the process when the cores run out (the entropy stage's pool
+    // beside the thread that drives the steps)
+    explicit ThreadPool(unsigned n, int nice_value = 0)
     {
         if (n < 1)
             n = 1;
         for (unsigned i = 0; i < n; ++i)
-            th.emplace_back([this, i] { run(i); });
+            th.emplace_back([this, i, nice_value] {
+                if (nice_value > 0)
+                    (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_value); // (Linux: per thread)
+                run(i);
+            });
     }
     ~ThreadPool()
     {
