@@ -26,7 +26,8 @@ SYMBOLS = [
     "agc_hip_determine_splitters_dev",
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
     "agc_hip_ref_register", "agc_hip_ref_register_batch_dev", "agc_hip_ref_get", "agc_hip_ref_index_get",
-    "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch",
+    "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch", "agc_hip_lz_encode_begin_dev", "agc_hip_lz_encode_end",
+    "agc_hip_host_alloc", "agc_hip_host_free",
     "agc_hip_lz_estimate_batch_dev", "agc_hip_lz_estimate_batch",
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
@@ -98,6 +99,10 @@ def load():
     L.agc_hip_ref_index_get.argtypes = [vp, C.c_uint32, u32p, C.c_uint64, u64p, C.POINTER(C.c_int)]
     L.agc_hip_lz_encode_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_lz_encode_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
+    L.agc_hip_lz_encode_begin_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p]
+    L.agc_hip_lz_encode_end.argtypes = [vp, u8p, C.c_uint64, u64p]
+    L.agc_hip_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.agc_hip_host_free.argtypes = [vp, vp]
     L.agc_hip_lz_estimate_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_lz_estimate_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_lz_cost_vector_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u8p, u32p]
@@ -320,6 +325,28 @@ class Context:
     def lz_encode_batch_dev(self, d_base, gids, off, length, rc=None, enc_cap=None):
         """-> (enc bytes, enc_off[n+1])"""
         return self._encode(self.L.agc_hip_lz_encode_batch_dev, d_base, gids, off, length, rc, enc_cap)
+
+    def lz_encode_begin_dev(self, d_base, gids, off, length, rc=None):
+        """first half of lz_encode_batch_dev: queues the encode on the context's second stream and returns"""
+        g, o, l, r = self._batch(gids, off, length, rc)
+        self._enc_pending = (g, o, l, r)  # (the arrays stay alive until the end call)
+        self._chk(self.L.agc_hip_lz_encode_begin_dev(self.h, g.size, _p(g, u32p), d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p)))
+
+    def lz_encode_end(self, enc_cap=None):
+        """second half: waits, -> (enc bytes, enc_off[n+1]) exactly as lz_encode_batch_dev"""
+        g, o, l, r = self._enc_pending
+        if enc_cap is None:
+            enc_cap = int(l.astype(np.uint64).sum()) * 21 // 16 + 64 * g.size + 64
+        enc = np.empty(enc_cap, np.uint8)
+        eoff = np.zeros(g.size + 1, np.uint64)
+        rc_ = self.L.agc_hip_lz_encode_end(self.h, _p(enc, u8p), enc_cap, _p(eoff, u64p))
+        if rc_ == ECAP:
+            enc_cap = int(eoff[-1]) + 64
+            enc = np.empty(enc_cap, np.uint8)
+            rc_ = self.L.agc_hip_lz_encode_end(self.h, _p(enc, u8p), enc_cap, _p(eoff, u64p))
+        self._chk(rc_)
+        self._enc_pending = None
+        return enc[:int(eoff[-1])], eoff
 
     def lz_encode_batch(self, text, gids, off, length, rc=None, enc_cap=None):
         text = _a(text, np.uint8)

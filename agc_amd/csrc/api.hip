@@ -57,6 +57,22 @@ struct agc_hip_ctx {
 
     std::vector<SliceDesc> h_slices;
 
+    // second LZ lane: agc_hip_lz_encode_begin_dev / _end run the encode of a whole sample on `stream2` with their own scratch,
+    // beside the estimates / cost vectors / index builds the caller goes on with on `stream`
+    struct Lane2 {
+        DevBuf d_stage, d_slices, d_segs, d_counter, d_resv, d_resp, d_scratch, d_dstoff, d_compact;
+        std::vector<SliceDesc> h_slices;
+        uint32_t *h_lens = nullptr; // pinned (a device-to-host copy into pageable memory would make begin wait for the kernel)
+        size_t h_lens_cap = 0;
+        uint32_t n = 0;          // segments of the encode in flight
+        bool pending = false, timed = false;
+        hipEvent_t e0 = nullptr, e1 = nullptr, ready = nullptr;
+    } l2;
+    hipStream_t stream2 = nullptr;
+
+    // pinned host allocations handed out by agc_hip_host_alloc
+    std::vector<void *> host_allocs;
+
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, zev0 = nullptr, zev1 = nullptr;
@@ -121,14 +137,14 @@ int arena_alloc(agc_hip_ctx *c, size_t bytes, uint8_t **out)
 struct KTimer {
     agc_hip_ctx *c;
     int which;
-    KTimer(agc_hip_ctx *c_, int w) : c(c_), which(w)
+    KTimer(agc_hip_ctx *c_, int w) : c(c_), which(w) // (w < 0: not timed -- a launch on the second lane)
     {
-        if (c->timing)
+        if (c->timing && which >= 0)
             (void)hipEventRecord(c->ev0, c->stream);
     }
     ~KTimer()
     {
-        if (c->timing) {
+        if (c->timing && which >= 0) {
             (void)hipEventRecord(c->ev1, c->stream);
             (void)hipEventSynchronize(c->ev1);
             float ms = 0;
@@ -166,6 +182,8 @@ int upload_refs(agc_hip_ctx *c)
 {
     if (!c->refs_dirty)
         return AGC_HIP_OK;
+    if (c->l2.pending)
+        HIPCHK(c, hipStreamSynchronize(c->stream2)); // the encode in flight reads the table that is about to be replaced
     CHK(ensure(c, c->d_refs, std::max<size_t>(1, c->refs.size()) * sizeof(RefDesc)));
     if (!c->refs.empty())
         HIPCHK(c, hipMemcpyAsync(c->d_refs.p, c->refs.data(), c->refs.size() * sizeof(RefDesc), hipMemcpyHostToDevice, c->stream));
@@ -200,7 +218,10 @@ int agc_hip_create(agc_hip_ctx **out, int device)
     agc_hip_ctx *c = new agc_hip_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->zstream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->zstream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l2.e0) != hipSuccess ||
+        hipEventCreate(&c->l2.e1) != hipSuccess || hipEventCreateWithFlags(&c->l2.ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->zev0) != hipSuccess || hipEventCreate(&c->zev1) != hipSuccess) {
         delete c;
         return AGC_HIP_ENODEV;
@@ -217,10 +238,18 @@ void agc_hip_destroy(agc_hip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->zstream)
         (void)hipStreamSynchronize(c->zstream);
+    if (c->stream2)
+        (void)hipStreamSynchronize(c->stream2);
+    for (void *hp : c->host_allocs)
+        (void)hipHostFree(hp);
+    if (c->l2.h_lens)
+        (void)hipHostFree(c->l2.h_lens);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_sbloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
-                      &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs};
+                      &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs,
+                      &c->l2.d_stage, &c->l2.d_slices, &c->l2.d_segs, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
+                      &c->l2.d_compact};
     for (DevBuf *b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -238,6 +267,11 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipStreamDestroy(c->stream);
     if (c->zstream)
         (void)hipStreamDestroy(c->zstream);
+    for (hipEvent_t e : {c->l2.e0, c->l2.e1, c->l2.ready})
+        if (e)
+            (void)hipEventDestroy(e);
+    if (c->stream2)
+        (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -904,8 +938,14 @@ struct Batch {
 
 // Builds descriptors; reverse-complemented texts are materialised once in the staging buffer.
 int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
-                  const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix, Batch &b)
+                  const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix, Batch &b, bool lane2 = false)
 {
+    // (lane 2: encode only -- no filter bitmaps; its own scratch and stream)
+    DevBuf &L_stage = lane2 ? c->l2.d_stage : c->d_stage, &L_slices = lane2 ? c->l2.d_slices : c->d_slices,
+           &L_segs = lane2 ? c->l2.d_segs : c->d_segs, &L_counter = lane2 ? c->l2.d_counter : c->d_counter,
+           &L_resv = lane2 ? c->l2.d_resv : c->d_resv, &L_resp = lane2 ? c->l2.d_resp : c->d_resp;
+    std::vector<SliceDesc> &L_hslices = lane2 ? c->l2.h_slices : c->h_slices;
+    const hipStream_t L_stream = lane2 ? c->stream2 : c->stream;
     for (uint32_t i = 0; i < n; ++i)
         if (h_gid[i] >= c->refs.size() || !c->refs[h_gid[i]].valid) {
             c->err = "group " + std::to_string(h_gid[i]) + " has no registered reference";
@@ -923,19 +963,19 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
             ++n_rc;
         }
     if (n_rc) {
-        CHK(ensure(c, c->d_stage, stage + 64));
-        std::vector<SliceDesc> &sl = c->h_slices; // outlives the asynchronous upload
+        CHK(ensure(c, L_stage, stage + 64, L_stream));
+        std::vector<SliceDesc> &sl = L_hslices; // outlives the asynchronous upload
         sl.clear();
         sl.reserve(n_rc);
         for (uint32_t i = 0; i < n; ++i)
             if (h_rc[i])
-                sl.push_back({d_base + h_off[i], (uint8_t *)c->d_stage.p + soff[i], h_len[i], 1u, 0u, 0u});
-        CHK(ensure(c, c->d_slices, sl.size() * sizeof(SliceDesc)));
-        HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), sl.size() * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
+                sl.push_back({d_base + h_off[i], (uint8_t *)L_stage.p + soff[i], h_len[i], 1u, 0u, 0u});
+        CHK(ensure(c, L_slices, sl.size() * sizeof(SliceDesc), L_stream));
+        HIPCHK(c, hipMemcpyAsync(L_slices.p, sl.data(), sl.size() * sizeof(SliceDesc), hipMemcpyHostToDevice, L_stream));
         {
-            KTimer t(c, AGC_HIP_K_REVCOMP);
-            hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n_rc, 1, 65536)), dim3(256), 0, c->stream,
-                               (const SliceDesc *)c->d_slices.p, n_rc);
+            KTimer t(c, lane2 ? -1 : AGC_HIP_K_REVCOMP);
+            hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n_rc, 1, 65536)), dim3(256), 0, L_stream,
+                               (const SliceDesc *)L_slices.p, n_rc);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -975,7 +1015,7 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         const uint32_t i = order[p];
         SegDesc &s = b.segs[p];
         s.maybe = nullptr;
-        s.text = (h_rc && h_rc[i]) ? (const uint8_t *)c->d_stage.p + soff[i] : d_base + h_off[i];
+        s.text = (h_rc && h_rc[i]) ? (const uint8_t *)L_stage.p + soff[i] : d_base + h_off[i];
         s.out_off = ooff[i];
         s.len = h_len[i];
         s.ref_slot = h_gid[i];
@@ -990,31 +1030,32 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
     }
     if (!fjobs.empty()) {
         CHK(ensure(c, c->d_fjobs, fjobs.size() * sizeof(FilterJob)));
-        HIPCHK(c, hipMemcpyAsync(c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), hipMemcpyHostToDevice, L_stream));
         {
             KTimer t(c, mode == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
-            hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, c->stream, (const FilterJob *)c->d_fjobs.p);
+            hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // (fjobs is a local)
+        HIPCHK(c, hipStreamSynchronize(L_stream)); // (fjobs is a local)
     }
-    CHK(ensure(c, c->d_segs, (size_t)n * sizeof(SegDesc)));
-    HIPCHK(c, hipMemcpyAsync(c->d_segs.p, b.segs.data(), (size_t)n * sizeof(SegDesc), hipMemcpyHostToDevice, c->stream));
-    CHK(ensure(c, c->d_counter, 64));
-    HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 4, c->stream));
-    CHK(ensure(c, c->d_resv, (size_t)n * 4));
-    CHK(ensure(c, c->d_resp, (size_t)n * 4));
+    CHK(ensure(c, L_segs, (size_t)n * sizeof(SegDesc), L_stream));
+    HIPCHK(c, hipMemcpyAsync(L_segs.p, b.segs.data(), (size_t)n * sizeof(SegDesc), hipMemcpyHostToDevice, L_stream));
+    CHK(ensure(c, L_counter, 64, L_stream));
+    HIPCHK(c, hipMemsetAsync(L_counter.p, 0, 4, L_stream));
+    CHK(ensure(c, L_resv, (size_t)n * 4, L_stream));
+    CHK(ensure(c, L_resp, (size_t)n * 4, L_stream));
     return AGC_HIP_OK;
 }
 
 template <int MODE>
-int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32)
+int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, bool lane2 = false)
 {
     const uint32_t grid = (n + 3) / 4; // one wave per segment, 4 waves per block
     {
-        KTimer t(c, MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
-        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, c->stream, (const RefDesc *)c->d_refs.p,
-                           (const SegDesc *)c->d_segs.p, n, out_bytes, out_u32, (uint32_t *)c->d_resv.p, (uint32_t *)c->d_resp.p);
+        KTimer t(c, lane2 ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, lane2 ? c->stream2 : c->stream, (const RefDesc *)c->d_refs.p,
+                           (const SegDesc *)(lane2 ? c->l2.d_segs.p : c->d_segs.p), n, out_bytes, out_u32,
+                           (uint32_t *)(lane2 ? c->l2.d_resv.p : c->d_resv.p), (uint32_t *)(lane2 ? c->l2.d_resp.p : c->d_resp.p));
     }
     HIPCHK(c, hipGetLastError());
     return AGC_HIP_OK;
@@ -1074,6 +1115,123 @@ int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gi
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_enc, c->d_compact.p, tot, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+// The same encode in two halves (include/agc_hip.h): begin queues the reverse-complement staging, the parse and the copy of
+// the delta lengths on the context's second stream and returns; end waits, lays the deltas out back to back and brings them
+// over.  Between the two the caller may use every other entry point (they run on the first stream with their own scratch).
+int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc)
+{
+    if (!c || (n && (!h_gid || !h_off || !h_len || !d_base)))
+        return AGC_HIP_EINVAL;
+    if (c->l2.pending) { // (an abandoned encode: a caller that failed between the two halves) -- dropped
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        c->l2.pending = false;
+    }
+    c->l2.n = n;
+    if (!n) {
+        c->l2.pending = true;
+        return AGC_HIP_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    // everything queued on the first stream so far (the sample's staging copy, index builds) comes first
+    HIPCHK(c, hipEventRecord(c->l2.ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->l2.ready, 0));
+    static thread_local Batch b; // (its descriptors are read by an asynchronous upload: they outlive this call)
+    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, d_base, h_off, h_len, h_rc, nullptr, b, true));
+    CHK(ensure(c, c->l2.d_scratch, b.out_total + 64, c->stream2));
+    if (c->l2.h_lens_cap < n) {
+        if (c->l2.h_lens)
+            HIPCHK(c, hipHostFree(c->l2.h_lens));
+        c->l2.h_lens = nullptr;
+        c->l2.h_lens_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->l2.h_lens, ((size_t)n + n / 4 + 1024) * 4, hipHostMallocDefault));
+        c->l2.h_lens_cap = (size_t)n + n / 4 + 1024;
+    }
+    c->l2.timed = c->timing;
+    if (c->l2.timed)
+        (void)hipEventRecord(c->l2.e0, c->stream2);
+    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)c->l2.d_scratch.p, nullptr, true));
+    if (c->l2.timed)
+        (void)hipEventRecord(c->l2.e1, c->stream2);
+    HIPCHK(c, hipMemcpyAsync(c->l2.h_lens, c->l2.d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream2));
+    c->l2.pending = true;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off)
+        return AGC_HIP_EINVAL;
+    if (!c->l2.pending) {
+        c->err = "lz_encode_end: no encode in flight";
+        return AGC_HIP_EINVAL;
+    }
+    const uint32_t n = c->l2.n;
+    h_enc_off[0] = 0;
+    if (!n) {
+        c->l2.pending = false;
+        return AGC_HIP_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->l2.timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->l2.e0, c->l2.e1) == hipSuccess) {
+            c->ms[AGC_HIP_K_ENCODE] += ms;
+            c->launches[AGC_HIP_K_ENCODE] += 1;
+        }
+        c->l2.timed = false; // (a second call after AGC_HIP_ECAP must not count the launch twice)
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        h_enc_off[i + 1] = h_enc_off[i] + c->l2.h_lens[i];
+    const uint64_t tot = h_enc_off[n];
+    if (tot > enc_cap)
+        return AGC_HIP_ECAP; // (still in flight: call again with a larger buffer)
+    if (tot) {
+        if (!h_enc)
+            return AGC_HIP_EINVAL;
+        CHK(ensure(c, c->l2.d_dstoff, (size_t)n * 8, c->stream2));
+        CHK(ensure(c, c->l2.d_compact, tot, c->stream2));
+        HIPCHK(c, hipMemcpyAsync(c->l2.d_dstoff.p, h_enc_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream2));
+        hipLaunchKernelGGL(gather_bytes_kernel, dim3(grid_for(n, 1, 8192)), dim3(256), 0, c->stream2, (const uint8_t *)c->l2.d_scratch.p,
+                           (const SegDesc *)c->l2.d_segs.p, (const uint32_t *)c->l2.d_resv.p, (const uint64_t *)c->l2.d_dstoff.p, n,
+                           (uint8_t *)c->l2.d_compact.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h_enc, c->l2.d_compact.p, tot, hipMemcpyDeviceToHost, c->stream2));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+    }
+    c->l2.pending = false;
+    return AGC_HIP_OK;
+}
+
+// pinned host memory for the buffers results are copied into (a copy into pageable memory goes through a bounce buffer)
+int agc_hip_host_alloc(agc_hip_ctx *c, uint64_t bytes, void **out)
+{
+    if (!c || !out)
+        return AGC_HIP_EINVAL;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    c->host_allocs.push_back(p);
+    *out = p;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_host_free(agc_hip_ctx *c, void *p)
+{
+    if (!c)
+        return AGC_HIP_EINVAL;
+    if (!p)
+        return AGC_HIP_OK;
+    auto it = std::find(c->host_allocs.begin(), c->host_allocs.end(), p);
+    if (it == c->host_allocs.end())
+        return AGC_HIP_EINVAL;
+    c->host_allocs.erase(it);
+    HIPCHK(c, hipHostFree(p));
     return AGC_HIP_OK;
 }
 

@@ -8,6 +8,8 @@ CAGCCompressor::CAGCCompressor() : p(new Impl) {}
 CAGCCompressor::~CAGCCompressor()
 {
     p->z_shutdown(); // the entropy thread uses the device context
+    p->enc_buf.release(); // (pinned memory of that context)
+    p->enc_buf2.release();
     if (p->hip)
         agc_hip_destroy(p->hip);
 }
@@ -114,6 +116,9 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
+    I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
+    if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
+        I.overlap_mode = !strcmp(e, "off") || !strcmp(e, "0") ? 0 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 1;
     I.choose_entropy_stage();
     I.created = true;
 
@@ -265,6 +270,9 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
+    I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
+    if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
+        I.overlap_mode = !strcmp(e, "off") || !strcmp(e, "0") ? 0 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 1;
     I.choose_entropy_stage();
 
     if (!I.ar.open(out_archive_name)) {

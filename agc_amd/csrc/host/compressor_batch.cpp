@@ -400,6 +400,7 @@ bool CAGCCompressor::Impl::batch_prepare(BatchState &b, std::vector<Contig> &ctg
     if (!stage_scan(b))
         return false;
     b.n_samples = ctgs.empty() ? 1u : ctgs.back().sample_idx + 1;
+    b.overlap_encode = overlap_mode != 0 && b.n_samples == 1 && !always_speculate;
     b.subset.resize(seg_buf.size());
     std::iota(b.subset.begin(), b.subset.end(), 0u);
     if (!stage_classify(b) || !stage_place(b))
@@ -463,7 +464,7 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
         st.enc_text += pl.len;
         st.enc_ref += groups[pl.gid].ref_size ? groups[pl.gid].ref_size - 1 : 0;
     }
-    bytes_t &enc = enc_buf;
+    PinnedBytes &enc = enc_buf;
     const uint64_t base = b.spec_bytes; // the deltas are appended to what the window already holds
     uint64_t cap = std::max<uint64_t>(enc.size() > base ? enc.size() - base : 0, tot / 64 + (1u << 20));
     for (;;) {
@@ -494,6 +495,93 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
     st.lz_encoded += ne;
     st.delta_bytes += eoff[ne];
     stage_end(st.t_encode, st.h_encode, t0, dev0);
+    return true;
+}
+
+// The same for a window of ONE registration, in two halves around the rest of its classification: segments with both
+// splitters whose key is in the map (97 % of a sample that resembles the collection) are placed where the map says, whatever
+// the other segments turn out to be (a key never leaves the map, its group never changes: revalidate's first rule), so their
+// deltas can be produced while estimates, missing-middle searches and split points are still being worked out.  The deltas are
+// matched to the placed items by (group, offset, length, orientation) at commit time like every speculative delta.
+bool CAGCCompressor::Impl::overlap_encode_begin(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const std::vector<Seg> &segs = seg_buf;
+    if (b.spec.size() != 2 * segs.size()) {
+        b.spec.assign(2 * segs.size(), BatchState::Spec());
+        b.spec_bytes = 0;
+    }
+    b.flight_keys.clear();
+    b.flight_gid.clear();
+    b.flight_len.clear();
+    b.flight_off.clear();
+    b.flight_rc.clear();
+    for (uint32_t si : b.subset) {
+        const Seg &s = segs[si];
+        if (!s.front.full || !s.back.full || s.pk.first == NO_KMER || s.pk.second == NO_KMER)
+            continue;
+        const int32_t *m = map_segments.find(s.pk);
+        if (!m || *m < (int32_t)NO_RAW_GROUPS)
+            continue;
+        const Group &g = groups[*m];
+        if (!g.exists || g.packed)
+            continue;
+        b.flight_keys.push_back(2 * si);
+        b.flight_gid.push_back((uint32_t)*m);
+        b.flight_off.push_back(ctgs[s.ctg].off + s.start);
+        b.flight_len.push_back(s.len);
+        b.flight_rc.push_back((uint8_t)s.store_rc);
+        st.enc_text += s.len;
+        st.enc_ref += g.ref_size ? g.ref_size - 1 : 0;
+    }
+    if (b.flight_keys.empty())
+        return true;
+    if (!hip_ok(DEVT(agc_hip_lz_encode_begin_dev(hip, (uint32_t)b.flight_keys.size(), b.flight_gid.data(), b.d_base, b.flight_off.data(),
+                                                 b.flight_len.data(), b.flight_rc.data())),
+                "lz_encode_begin"))
+        return false;
+    b.enc_in_flight = true;
+    return true;
+}
+
+bool CAGCCompressor::Impl::overlap_encode_end(BatchState &b)
+{
+    const size_t ne = b.flight_keys.size();
+    std::vector<uint64_t> eoff(ne + 1, 0);
+    uint64_t tot = 0;
+    for (uint32_t l : b.flight_len)
+        tot += l;
+    PinnedBytes &enc = enc_buf;
+    const uint64_t base = b.spec_bytes;
+    uint64_t cap = std::max<uint64_t>(enc.size() > base ? enc.size() - base : 0, tot / 64 + (1u << 20));
+    for (;;) {
+        if (!enc.resize(base + cap)) {
+            err("out of memory (delta buffer)");
+            return false;
+        }
+        int r = DEVT(agc_hip_lz_encode_end(hip, enc.data() + base, cap, eoff.data()));
+        if (r == AGC_HIP_ECAP) {
+            cap = eoff[ne] + 64 + eoff[ne] / 8; // (headroom: the next samples' deltas are about as long)
+            continue;
+        }
+        b.enc_in_flight = false;
+        if (!hip_ok(r, "lz_encode_end"))
+            return false;
+        break;
+    }
+    for (size_t i = 0; i < ne; ++i) {
+        BatchState::Spec &sp = b.spec[b.flight_keys[i]];
+        sp.valid = true;
+        sp.gid = b.flight_gid[i];
+        sp.off = b.flight_off[i];
+        sp.len = b.flight_len[i];
+        sp.rc = b.flight_rc[i] != 0;
+        sp.enc_off = base + eoff[i];
+        sp.enc_len = (uint32_t)(eoff[i + 1] - eoff[i]);
+    }
+    b.spec_bytes = base + eoff[ne];
+    st.lz_encoded += ne;
+    st.delta_bytes += eoff[ne];
     return true;
 }
 
@@ -779,6 +867,9 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     t0 = now();
 
     LAP("keys");
+    if (b.overlap_encode && overlap_mode == 1 && !overlap_encode_begin(b))
+        return false;
+    LAP("encode_begin");
     // ---- GPU: estimates for every (one-splitter segment, candidate) pair ----
     std::vector<uint32_t> est_cost(cands.size()), est_peak(cands.size());
     if (!cands.empty()) {
@@ -981,6 +1072,8 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
     (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
     std::vector<Seg> &segs = seg_buf;
     LAP("splitpoints");
+    if (b.overlap_encode && overlap_mode == 2 && !b.enc_in_flight && !overlap_encode_begin(b))
+        return false;
     // ---- add_segment, part 4: final placement + part numbers ----
     std::vector<Placed> &placed = placed_buf;
     placed.clear();
@@ -1301,8 +1394,10 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
                 rc[i] = pl.rc;
                 st.ref_bytes += pl.len;
             }
+            LAP("note_new_groups");
             if (!hip_ok(DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml)), "ref_register_batch"))
                 return false;
+            LAP("ref_register");
             lag_cnt.resize(nr * 28);
             lag_cur.resize(nr * 28);
             if (!hip_ok(DEVT(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data())), "ref_lag_counts"))
@@ -1324,6 +1419,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
                 }
                 repetitive[fi] = !(best_frac < 0.5);
             }
+            LAP("lag_counts");
         }
         const size_t nf = nr + raw_items.size();
         if (nf) {
@@ -1345,6 +1441,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
                 return false;
         }
     }
+    LAP("fetch_slices");
     stage_end(st.t_register, st.h_register, t0, dev0);
     t0 = now();
     // LZ deltas (segment.cpp:50-58): items whose group already had its reference when the window was classified were encoded
@@ -1352,6 +1449,9 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     // revalidation placed differently -- are encoded now
     std::vector<const uint8_t *> enc_ptr(enc_items.size(), nullptr);
     std::vector<uint32_t> enc_len(enc_items.size(), 0);
+    if (b.enc_in_flight && !overlap_encode_end(b))
+        return false;
+    LAP("encode_end");
     {
         std::vector<uint32_t> todo; // positions in enc_items
         for (uint32_t i = 0; i < enc_items.size(); ++i) {
@@ -1379,7 +1479,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
                 st.enc_text += pl.len;
                 st.enc_ref += groups[pl.gid].ref_size ? groups[pl.gid].ref_size - 1 : 0;
             }
-            bytes_t &enc = enc_buf2;
+            PinnedBytes &enc = enc_buf2;
             uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 16));
             for (;;) {
                 if (enc.size() < cap)
@@ -1402,6 +1502,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
             st.delta_bytes += eoff[ne];
         }
     }
+    LAP("encode");
     stage_end(st.t_encode, st.h_encode, t0, dev0);
     t0 = now();
 
@@ -1424,7 +1525,9 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
         if (dist_rank != dist_writer)
             return true; // the writer rank does the bookkeeping from the record
     }
-    return book_and_store(cdta);
+    const bool ok = book_and_store(cdta);
+    LAP("book_and_store");
+    return ok;
 }
 
 // store_segments, second half (agc_compressor.cpp:989-1050): per-group bookkeeping, zstd parts, collection records

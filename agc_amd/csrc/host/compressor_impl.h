@@ -221,6 +221,51 @@ struct CommitData {
     uint32_t sample_from = 0;                                  // the registrations [sample_from, commit_upto) of the window
 };
 
+// result buffer in pinned host memory (agc_hip_host_alloc; plain malloc when that fails): grows, keeps its content, never shrinks
+struct PinnedBytes {
+    agc_hip_ctx *ctx = nullptr;
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    bool pinned = false;
+    size_t size() const { return n; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    bool resize(size_t m)
+    {
+        if (m <= n)
+            return true;
+        void *q = nullptr;
+        const bool pin = ctx && agc_hip_host_alloc(ctx, m, &q) == AGC_HIP_OK && q;
+        if (!pin)
+            q = malloc(m);
+        if (!q)
+            return false;
+        if (p) {
+            memcpy(q, p, n);
+            release();
+        }
+        p = (uint8_t *)q;
+        n = m;
+        pinned = pin;
+        return true;
+    }
+    void release()
+    {
+        if (p) {
+            if (pinned)
+                agc_hip_host_free(ctx, p);
+            else
+                free(p);
+        }
+        p = nullptr;
+        n = 0;
+    }
+    PinnedBytes() = default;
+    PinnedBytes(const PinnedBytes &) = delete;
+    PinnedBytes &operator=(const PinnedBytes &) = delete;
+    ~PinnedBytes() { release(); }
+};
+
 struct ZJob { // one archive part to produce
     int stream_id;
     uint32_t gid = 0;  // pack jobs: the group (for a deferred stream registration)
@@ -550,6 +595,12 @@ struct CAGCCompressor::Impl {
         };
         std::vector<Spec> spec;
         uint64_t spec_bytes = 0;                   // bytes of enc_buf the speculative deltas occupy
+        // single-registration window: the segments whose group is known from their two splitters (nearly all) are encoded
+        // on the device's second stream while the rest of the window is still being classified
+        bool overlap_encode = false, enc_in_flight = false;
+        std::vector<uint32_t> flight_keys, flight_gid, flight_len;
+        std::vector<uint64_t> flight_off;
+        std::vector<uint8_t> flight_rc;
         std::vector<uint64_t> changed;             // k-mers whose terminator list changed in the last commit run
         uint32_t commit_upto = 0;                  // registrations of the window that are committed now
         std::vector<uint32_t> order;               // committed items in registration order
@@ -561,6 +612,9 @@ struct CAGCCompressor::Impl {
     bool stage_register(BatchState &b);
     bool stage_store(BatchState &b);
     bool spec_encode(BatchState &b);
+    bool overlap_encode_begin(BatchState &b);
+    bool overlap_encode_end(BatchState &b);
+    int overlap_mode = 1; // AGC_AMD_ENCODE_OVERLAP: 0 = off, 1 = from the key lookup on (default), 2 = from the placement on
     bool revalidate(BatchState &b);
     bool batch_prepare(BatchState &b, std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, bool always_speculate);
     bool batch_commit(BatchState &b, uint32_t &n_committed);
@@ -607,7 +661,8 @@ struct CAGCCompressor::Impl {
     void choose_entropy_stage();
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
     void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
-    bytes_t enc_buf, enc_buf2, fetch_buf; // grown, never shrunk (enc_buf: the window's speculative deltas, enc_buf2: per commit run)
+    PinnedBytes enc_buf, enc_buf2; // grown, never shrunk (enc_buf: the window's speculative deltas, enc_buf2: per commit run); pinned
+    bytes_t fetch_buf;
     // scratch reused across registrations (no reallocation / page faults / zero fill per sample)
     std::vector<uint32_t> gid_slot, gid_epoch;
     uint32_t gid_epoch_ctr = 0;

@@ -182,6 +182,21 @@ int agc_hip_lz_encode_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
                             const uint32_t *h_len, const uint8_t *h_rc,
                             uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
 
+/* The encode of agc_hip_lz_encode_batch_dev in two halves, for a caller that has other work for the device and for itself
+ * while a whole sample is encoded (the reference's worker threads encode segments while others are still being classified,
+ * agc_compressor.cpp:989-1050).  begin queues the work on the context's second stream and returns at once; between begin and
+ * end every other entry point may be used (own stream, own scratch); end waits and delivers exactly what
+ * agc_hip_lz_encode_batch_dev would have (AGC_HIP_ECAP: h_enc_off[n] holds the size needed, call end again).  One encode in
+ * flight per context (a begin while one is in flight drops the earlier one).  The texts and every reference named must stay unchanged until end returns. */
+int agc_hip_lz_encode_begin_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc);
+int agc_hip_lz_encode_end(agc_hip_ctx *ctx, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
+
+/* Pinned host memory for result buffers (device-to-host copies into pageable memory go through a bounce buffer at a
+ * fraction of the link rate).  Freed by agc_hip_host_free or with the context. */
+int agc_hip_host_alloc(agc_hip_ctx *ctx, uint64_t bytes, void **out);
+int agc_hip_host_free(agc_hip_ctx *ctx, void *p);
+
 /* Replaces CLZDiff_V2::Estimate (src/common/lz_diff.cpp:839-946) evaluated
  * WITHOUT a bound: h_cost[s] is the estimate with bound = ~0, h_peak[s] the
  * largest running cost seen at a loop-top check, so the caller can replay the

@@ -46,6 +46,13 @@ struct agc_hip_ctx {
     u64 n_spl;
     void **lz; /* by gid */
     u32 n_lz;
+    /* encode in two halves: the arguments of begin, replayed by end */
+    int enc_pending;
+    u32 enc_n;
+    u32 *enc_gid, *enc_len;
+    u64 *enc_off;
+    u8 *enc_rc;
+    const u8 *enc_base;
 };
 
 static int cmp_u64(const void *a, const void *b)
@@ -290,6 +297,71 @@ int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid,
         free(t);
     }
     return over ? fail(c, AGC_HIP_ECAP, "encode buffer") : AGC_HIP_OK;
+}
+
+static void *dup_mem(const void *p, size_t n)
+{
+    void *q = malloc(n ? n : 1);
+    if (p && n)
+        memcpy(q, p, n);
+    return q;
+}
+
+static void enc_clear(agc_hip_ctx *c)
+{
+    free(c->enc_gid);
+    free(c->enc_len);
+    free(c->enc_off);
+    free(c->enc_rc);
+    c->enc_gid = c->enc_len = NULL;
+    c->enc_off = NULL;
+    c->enc_rc = NULL;
+    c->enc_pending = 0;
+}
+
+int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off, const uint32_t *len,
+                                const uint8_t *rc)
+{
+    if (!c || (n && (!gid || !d || !off || !len)))
+        return AGC_HIP_EINVAL;
+    if (c->enc_pending)
+        enc_clear(c); /* an abandoned encode is dropped */
+    c->enc_n = n;
+    c->enc_gid = (u32 *)dup_mem(gid, (size_t)n * 4);
+    c->enc_len = (u32 *)dup_mem(len, (size_t)n * 4);
+    c->enc_off = (u64 *)dup_mem(off, (size_t)n * 8);
+    c->enc_rc = rc ? (u8 *)dup_mem(rc, n) : NULL;
+    c->enc_base = d;
+    c->enc_pending = 1;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off)
+        return AGC_HIP_EINVAL;
+    if (!c->enc_pending)
+        return fail(c, AGC_HIP_EINVAL, "encode_end: no encode in flight");
+    const int r = agc_hip_lz_encode_batch_dev(c, c->enc_n, c->enc_gid, c->enc_base, c->enc_off, c->enc_len, c->enc_rc, h_enc, cap, h_enc_off);
+    if (r != AGC_HIP_ECAP)
+        enc_clear(c);
+    return r;
+}
+
+int agc_hip_host_alloc(agc_hip_ctx *c, uint64_t bytes, void **out)
+{
+    if (!c || !out)
+        return AGC_HIP_EINVAL;
+    *out = malloc(bytes ? bytes : 1);
+    return *out ? AGC_HIP_OK : AGC_HIP_ENOMEM;
+}
+
+int agc_hip_host_free(agc_hip_ctx *c, void *p)
+{
+    if (!c)
+        return AGC_HIP_EINVAL;
+    free(p);
+    return AGC_HIP_OK;
 }
 
 int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,

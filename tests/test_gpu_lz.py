@@ -64,6 +64,34 @@ def test_encode_reverse_complement(hip_ctx, oracle, registered):
         assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], want), f"case {i}"
 
 
+def test_encode_in_two_halves_beside_other_calls(hip_ctx, oracle, registered):
+    """agc_hip_lz_encode_begin_dev / _end (second stream, own scratch): estimates and cost vectors issued between the two
+    halves come out right, and the deltas are the ones the one-call encode and the oracle give -- also for reverse-complemented
+    texts and after a too-small buffer (AGC_HIP_ECAP, second end call)"""
+    import torch
+    buf, off, ln = _concat(registered)
+    gids = 1000 + np.arange(len(registered))
+    rc = (np.arange(len(registered)) % 2).astype(np.uint8)
+    d = torch.from_numpy(np.concatenate([buf, np.zeros(64, np.uint8)])).cuda()
+    torch.cuda.synchronize()
+    for round_ in range(3):
+        hip_ctx.lz_encode_begin_dev(d.data_ptr(), gids, off, ln, rc=rc)
+        cost, peak = hip_ctx.lz_estimate_batch_dev(d.data_ptr(), gids, off, ln)
+        pf = np.zeros(len(registered), np.uint8)
+        costs = hip_ctx.lz_cost_vector_batch_dev(d.data_ptr(), gids, off, ln, None, pf)
+        enc, eoff = hip_ctx.lz_encode_end(enc_cap=16 if round_ == 1 else None)
+        p = 0
+        for i, (mml, ref, text) in enumerate(registered):
+            z = oracle.LZ(ref, mml)
+            want = z.encode(oracle.rev_comp(text) if rc[i] else text)
+            assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], want), f"round {round_} case {i}"
+            assert int(cost[i]) == z.estimate(text), f"round {round_} case {i}"
+            assert np.array_equal(costs[p:p + text.size], z.cost_vector(text, 0)), f"round {round_} case {i}"
+            p += text.size
+    one, ooff = hip_ctx.lz_encode_batch_dev(d.data_ptr(), gids, off, ln, rc=rc)
+    assert np.array_equal(one, enc) and np.array_equal(ooff, eoff)
+
+
 def test_estimate_and_peak(hip_ctx, oracle, registered):
     buf, off, ln = _concat(registered)
     gids = 1000 + np.arange(len(registered))
