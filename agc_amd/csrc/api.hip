@@ -6,6 +6,7 @@
 #include "dev_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -452,7 +453,26 @@ static int deliver_hits(agc_hip_ctx *c, uint32_t n_found, const uint64_t *h_ctg_
         HIPCHK(c, hipMemcpyAsync(hits.data(), c->d_hits.p, (size_t)n_found * sizeof(ScanHit), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    std::sort(hits.begin(), hits.end(), [](const ScanHit &x, const ScanHit &y) { return x.pos < y.pos; });
+    // by position (positions are unique): LSD radix sort, 11 bits a pass, as many passes as the largest position needs
+    if (n_found > 1) {
+        uint64_t max_pos = 0;
+        for (const ScanHit &h : hits)
+            max_pos = std::max<uint64_t>(max_pos, h.pos);
+        std::vector<ScanHit> tmp(n_found);
+        ScanHit *src = hits.data(), *dst = tmp.data();
+        for (int sh = 0; sh < 64 && (max_pos >> sh) != 0; sh += 11) {
+            uint32_t cnt[2049] = {0};
+            for (uint32_t i = 0; i < n_found; ++i)
+                ++cnt[(((uint64_t)src[i].pos >> sh) & 2047u) + 1];
+            for (int t = 0; t < 2048; ++t)
+                cnt[t + 1] += cnt[t];
+            for (uint32_t i = 0; i < n_found; ++i)
+                dst[cnt[((uint64_t)src[i].pos >> sh) & 2047u]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != hits.data())
+            std::memcpy(hits.data(), src, (size_t)n_found * sizeof(ScanHit));
+    }
 
     // accept_hits: after a hit the reference resets the k-mer (agc_compressor.cpp:2029), so the next
     // hit of the same contig must end at least k symbols later.
@@ -946,11 +966,22 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
            &L_resv = lane2 ? c->l2.d_resv : c->d_resv, &L_resp = lane2 ? c->l2.d_resp : c->d_resp;
     std::vector<SliceDesc> &L_hslices = lane2 ? c->l2.h_slices : c->h_slices;
     const hipStream_t L_stream = lane2 ? c->stream2 : c->stream;
+    static const bool laps = getenv("AGC_HIP_LAPS") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double lt = laps ? tnow() : 0;
+    auto LAP = [&](const char *what) {
+        if (laps && n > 10000) {
+            const double t = tnow();
+            fprintf(stderr, "    prepare_batch lap %s %.3f ms\n", what, t - lt);
+            lt = t;
+        }
+    };
     for (uint32_t i = 0; i < n; ++i)
         if (h_gid[i] >= c->refs.size() || !c->refs[h_gid[i]].valid) {
             c->err = "group " + std::to_string(h_gid[i]) + " has no registered reference";
             return AGC_HIP_ENOREF;
         }
+    LAP("valid");
     CHK(upload_refs(c));
     // staging for rc texts
     size_t stage = 0;
@@ -979,16 +1010,30 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         }
         HIPCHK(c, hipGetLastError());
     }
-    // longest first (stable): sort keys (~len << 32 | index)
+    LAP("rc_staging");
+    // longest first, stable in the index: LSD radix sort on ~len (3 passes of 11 bits; a comparison sort of the 50 k segments
+    // of a human sample costs milliseconds of host time per call)
     std::vector<uint32_t> order(n);
     {
-        std::vector<uint64_t> keys(n);
+        std::vector<uint32_t> tmp(n);
         for (uint32_t i = 0; i < n; ++i)
-            keys[i] = ((uint64_t)(~h_len[i]) << 32) | i;
-        std::sort(keys.begin(), keys.end());
-        for (uint32_t i = 0; i < n; ++i)
-            order[i] = (uint32_t)keys[i];
+            order[i] = i;
+        uint32_t *src = order.data(), *dst = tmp.data();
+        for (int pass = 0; pass < 3; ++pass) {
+            const int sh = 11 * pass;
+            uint32_t cnt[2049] = {0};
+            for (uint32_t i = 0; i < n; ++i)
+                ++cnt[((~h_len[src[i]] >> sh) & 2047u) + 1];
+            for (int t = 0; t < 2048; ++t)
+                cnt[t + 1] += cnt[t];
+            for (uint32_t i = 0; i < n; ++i)
+                dst[cnt[(~h_len[src[i]] >> sh) & 2047u]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != order.data())
+            std::memcpy(order.data(), src, (size_t)n * 4);
     }
+    LAP("sort");
     std::vector<uint64_t> ooff(n);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -1038,12 +1083,14 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(L_stream)); // (fjobs is a local)
     }
+    LAP("descriptors");
     CHK(ensure(c, L_segs, (size_t)n * sizeof(SegDesc), L_stream));
     HIPCHK(c, hipMemcpyAsync(L_segs.p, b.segs.data(), (size_t)n * sizeof(SegDesc), hipMemcpyHostToDevice, L_stream));
     CHK(ensure(c, L_counter, 64, L_stream));
     HIPCHK(c, hipMemsetAsync(L_counter.p, 0, 4, L_stream));
     CHK(ensure(c, L_resv, (size_t)n * 4, L_stream));
     CHK(ensure(c, L_resp, (size_t)n * 4, L_stream));
+    LAP("upload");
     return AGC_HIP_OK;
 }
 

@@ -118,7 +118,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
     I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
-        I.overlap_mode = !strcmp(e, "off") || !strcmp(e, "0") ? 0 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 1;
+        I.overlap_mode = !strcmp(e, "early") || !strcmp(e, "1") ? 1 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 0;
     I.choose_entropy_stage();
     I.created = true;
 
@@ -272,7 +272,7 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
     I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
-        I.overlap_mode = !strcmp(e, "off") || !strcmp(e, "0") ? 0 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 1;
+        I.overlap_mode = !strcmp(e, "early") || !strcmp(e, "1") ? 1 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 0;
     I.choose_entropy_stage();
 
     if (!I.ar.open(out_archive_name)) {

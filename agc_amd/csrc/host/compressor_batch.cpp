@@ -160,8 +160,15 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         uint64_t total = 0, dev_acc = 0;
         for (uint32_t i : dev_jobs)
             total += jobs[i].data.size();
+        // (length of a frame's serial chain: level 17 parses inputs of up to 16 KB twice -- btultra2 -- and larger ones once,
+        // with a deeper search; AGC_AMD_ZSTD_CHAIN_W: relative cost of a position of the larger class, in percent)
+        static const uint64_t w_big = getenv("AGC_AMD_ZSTD_CHAIN_W") ? strtoull(getenv("AGC_AMD_ZSTD_CHAIN_W"), nullptr, 10) : 150;
+        auto chain = [&](uint32_t i) -> uint64_t {
+            const uint64_t sz = jobs[i].data.size();
+            return sz <= 16384 ? 200 * sz : w_big * sz;
+        };
         std::vector<uint32_t> by_size(dev_jobs);
-        std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return jobs[a].data.size() < jobs[b].data.size(); });
+        std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return chain(a) < chain(b); });
         std::vector<uint32_t> keep;
         for (uint32_t i : by_size) {
             if ((double)dev_acc < gpu_zstd_share * (double)total) {
@@ -233,6 +240,12 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     const double th0 = now();
     st.t_zstd_stage += th0 - ts0;
     LAP("gather + launch");
+    // a small batch (the new references of one registration, while the steps go on): a quarter of the pool keeps up with it
+    // and leaves the cores and the caches to the thread that drives the steps
+    uint64_t all_bytes = 0;
+    for (const ZJob &j : jobs)
+        all_bytes += j.data.size();
+    const unsigned host_workers = all_bytes < (64u << 20) ? std::max(2u, zpool->size() / 4) : zpool->size();
     zpool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
         ZJob &j = jobs[host_jobs[hi]];
         ZstdCtx &z = *zctx[tid];
@@ -253,7 +266,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         bytes_t packed(bound + 1);
         uint32_t ps = (uint32_t)z.compress(packed.data(), bound, src->data(), src->size(), level);
         finish(j, packed, ps, marker);
-    });
+    }, host_workers);
     t_host = now() - th0;
     st.t_zstd_host += t_host;
     LAP("host pool");
@@ -518,11 +531,9 @@ bool CAGCCompressor::Impl::overlap_encode_begin(BatchState &b)
     b.flight_rc.clear();
     for (uint32_t si : b.subset) {
         const Seg &s = segs[si];
-        if (!s.front.full || !s.back.full || s.pk.first == NO_KMER || s.pk.second == NO_KMER)
+        if (!s.front.full || !s.back.full || s.map_gid < (int32_t)NO_RAW_GROUPS)
             continue;
-        const int32_t *m = map_segments.find(s.pk);
-        if (!m || *m < (int32_t)NO_RAW_GROUPS)
-            continue;
+        const int32_t mg = s.map_gid, *m = &mg;
         const Group &g = groups[*m];
         if (!g.exists || g.packed)
             continue;
@@ -754,6 +765,7 @@ bool CAGCCompressor::Impl::stage_scan(BatchState &b)
     std::vector<Seg> &segs = seg_buf;
     segs.clear();
     segs.reserve(n_hits + n_ctg);
+    LAP("cut_reserve");
     {
         uint64_t h = 0;
         for (uint32_t c = 0; c < n_ctg; ++c) {
@@ -783,6 +795,7 @@ bool CAGCCompressor::Impl::stage_scan(BatchState &b)
             }
         }
     }
+    LAP("cut_loop");
 
     return true;
 }
@@ -866,6 +879,19 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
 
+    // the keys of the segments with both splitters, looked up once (the pool: 50 k probes of a table that does not fit the caches)
+    {
+        const size_t nL = L.size(), n_chunks = std::min<size_t>(std::max<size_t>(nL / 2048, 1), (size_t)pool->size() * 4);
+        pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
+            for (size_t t = nL * ci / n_chunks; t < nL * (ci + 1) / n_chunks; ++t) {
+                Seg &s = segs[L[t]];
+                s.map_gid = -1;
+                if (s.front.full && s.back.full)
+                    if (const int32_t *m = map_segments.find(s.pk))
+                        s.map_gid = *m;
+            }
+        });
+    }
     LAP("keys");
     if (b.overlap_encode && overlap_mode == 1 && !overlap_encode_begin(b))
         return false;
@@ -964,9 +990,17 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         Seg &s = segs[si];
         if (concatenated || s.pk.first == NO_KMER || s.pk.second == NO_KMER)
             continue;
-        if (const int32_t *m = map_segments.find(s.pk)) { // known group: remembered for the placement below
-            s.known_gid = *m;
-            continue;
+        {
+            // known group: remembered for the placement below
+            int32_t mg = s.map_gid;
+            if (s.front.full != s.back.full) { // (a one-splitter segment got its key just now)
+                const int32_t *m = map_segments.find(s.pk);
+                mg = m ? *m : -1;
+            }
+            if (mg >= 0) {
+                s.known_gid = mg;
+                continue;
+            }
         }
         s.known_gid = -1;
         auto tf = terminators.find(s.pk.first), tb = terminators.find(s.pk.second);
@@ -1223,8 +1257,21 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
         for (uint32_t i = 0; i < placed.size(); ++i)
             if (ctgs[placed[i].ctg].sample_idx >= s_from && ctgs[placed[i].ctg].sample_idx < commit_upto)
                 keyed.push_back({((uint64_t)ctg_rank[placed[i].ctg] << 32) | placed[i].part_no, i});
-        if (!std::is_sorted(keyed.begin(), keyed.end()))
-            std::sort(keyed.begin(), keyed.end());
+        if (!std::is_sorted(keyed.begin(), keyed.end())) {
+            // the items come contig by contig with rising part numbers: a stable counting sort by contig rank gives the
+            // order at once (two contigs sharing a name, hence a rank: the comparison sort settles it)
+            std::vector<uint32_t> cnt((size_t)n_ctg + 2, 0);
+            for (auto &x : keyed)
+                ++cnt[(x.first >> 32) + 1];
+            for (size_t t = 0; t + 1 < cnt.size(); ++t)
+                cnt[t + 1] += cnt[t];
+            std::vector<std::pair<uint64_t, uint32_t>> sorted(keyed.size());
+            for (auto &x : keyed)
+                sorted[cnt[x.first >> 32]++] = x;
+            keyed.swap(sorted);
+            if (!std::is_sorted(keyed.begin(), keyed.end()))
+                std::sort(keyed.begin(), keyed.end());
+        }
         // items for NEW groups wait in a std::set keyed by (sample, contig name, part no) in the reference
         // (agc_compressor.h:111-118, 326-331): a second new item with the same key -- two contigs of one sample carrying the
         // same name -- never gets in.  Dropped here the same way (the first one, in contig order, stays).

@@ -140,6 +140,7 @@ struct Seg { // one segment as compress_contig cuts it (agc_compressor.cpp:2007-
     // missing-middle search
     int32_t mid_job = -1;
     int32_t known_gid = -2; // group of pk when classification looked it up (-1: not there, -2: not looked up)
+    int32_t map_gid = -1;   // both splitters: what map_segments holds for pk (looked up once, by the pool; -1: not there)
     uint32_t bp = 0;        // split position of a missing-middle job (before the k+1 clamps)
     Kmer kmer1, kmer2;
     bool use_rc = false;
@@ -614,7 +615,10 @@ struct CAGCCompressor::Impl {
     bool spec_encode(BatchState &b);
     bool overlap_encode_begin(BatchState &b);
     bool overlap_encode_end(BatchState &b);
-    int overlap_mode = 1; // AGC_AMD_ENCODE_OVERLAP: 0 = off, 1 = from the key lookup on (default), 2 = from the placement on
+    // AGC_AMD_ENCODE_OVERLAP: off (default) | early (from the key lookup on) | late (from the placement on).  Measured on the
+    // 3 Gbp step: the encode kernel hidden behind estimates / split points costs those kernels what it saves (27.8 ms per step
+    // off, 26.4-29.6 ms early), so the default keeps the kernels one after the other and their timings clean
+    int overlap_mode = 0;
     bool revalidate(BatchState &b);
     bool batch_prepare(BatchState &b, std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, bool always_speculate);
     bool batch_commit(BatchState &b, uint32_t &n_committed);

@@ -104,7 +104,7 @@ class ThreadPool {
     std::function<void(size_t, unsigned)> fn;
     std::atomic<size_t> next{0};
     size_t n_jobs = 0;
-    unsigned active = 0;
+    unsigned active = 0, limit = ~0u;
     uint64_t epoch = 0;
     bool stop = false;
 
@@ -119,7 +119,7 @@ class ThreadPool {
                     return;
                 seen = epoch;
             }
-            for (;;) {
+            for (; tid < limit;) {
                 size_t i = next.fetch_add(1);
                 if (i >= n_jobs)
                     break;
@@ -158,13 +158,15 @@ public:
             t.join();
     }
     unsigned size() const { return (unsigned)th.size(); }
-    // fn(job index, worker id); returns when every job has run
-    void parallel_for(size_t n, std::function<void(size_t, unsigned)> f)
+    // fn(job index, worker id); returns when every job has run.  max_workers: only that many workers take jobs (a small
+    // batch beside other busy threads of the process)
+    void parallel_for(size_t n, std::function<void(size_t, unsigned)> f, unsigned max_workers = ~0u)
     {
         if (!n)
             return;
         std::unique_lock<std::mutex> lk(mtx);
         fn = std::move(f);
+        limit = max_workers ? max_workers : 1;
         n_jobs = n;
         next = 0;
         active = (unsigned)th.size();

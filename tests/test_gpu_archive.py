@@ -40,6 +40,25 @@ def test_archive_bit_identical(name, tmp_path):
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("mode", ["early", "late"])
+@pytest.mark.parametrize("name", ["syn_adaptive", "syn_c5_twin", "syn_c3_twin"])
+def test_archive_with_the_encode_on_the_second_stream(name, mode, tmp_path, monkeypatch):
+    """AGC_AMD_ENCODE_OVERLAP=early|late: windows of one registration encode their key-known segments on the context's second
+    HIP stream (agc_hip_lz_encode_begin_dev / _end) while estimates, cost vectors and index builds run on the first one;
+    with AGC_AMD_SYNC_ENTROPY=1 on top every registration also waits for its zstd parts.  Same bytes as the reference."""
+    from agc_amd import build
+    build.build_host()
+    monkeypatch.setenv("AGC_AMD_ENCODE_OVERLAP", mode)
+    if mode == "late":
+        monkeypatch.setenv("AGC_AMD_SYNC_ENTROPY", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "amd.agc")
+    r = subprocess.run([AGC_AMD, "create"] + args + ["-t", "8", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    assert os.path.exists(out), r.stderr[-2000:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"], r.stderr[-1500:]
+
+
 GOLD_APPEND = json.load(open(os.path.join(ROOT, "tests", "golden", "archives_append.json")))
 
 

@@ -101,6 +101,21 @@ def test_host_zstd_switch_gives_the_same_archive(cli, tmp_path, monkeypatch):
     assert hashlib.sha256(got).hexdigest() == GOLD["syn_c3_twin"]["sha256"]
 
 
+@pytest.mark.parametrize("mode", ["early", "late"])
+@pytest.mark.parametrize("name", ["syn_adaptive", "syn_c5_twin", "syn_mixed"])
+def test_encode_overlapped_with_the_classification_gives_the_same_archive(cli, name, mode, tmp_path, monkeypatch):
+    """AGC_AMD_ENCODE_OVERLAP: windows of one registration (adaptive mode; every sample handed over through the device API)
+    start the encode of the key-known segments before the rest of the window is classified (agc_hip_lz_encode_begin_dev /
+    _end) -- same archive; AGC_AMD_SYNC_ENTROPY=1 on top: every registration waits for its zstd parts"""
+    monkeypatch.setenv("AGC_AMD_ENCODE_OVERLAP", mode)
+    if mode == "late":
+        monkeypatch.setenv("AGC_AMD_SYNC_ENTROPY", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
 def test_host_pipeline_is_thread_independent(cli, tmp_path):
     args, _ = C.CONFIGS["syn_adaptive"]
     files = C.build("syn_adaptive", str(tmp_path / "in"))
@@ -150,8 +165,9 @@ cmp_.close_handle()
 """
 
 
+@pytest.mark.parametrize("overlap", ["off", "early"])
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_snp", "syn_shuffled"])
-def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, tmp_path):
+def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, overlap, tmp_path, monkeypatch):
     """AddSamplePackedDevice: every sample handed over in the 2-bit layout (escaped blocks for N runs / IUPAC codes, contigs at
     arbitrary symbol offsets); the archive must be the one the reference CLI writes from the FASTA files.  (In a child process:
     the host library linked with the CPU stand-in must not meet the product's libagc_hip.so of the same name.)"""
@@ -165,6 +181,7 @@ def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, tmp_
     files = C.build(name, str(tmp_path / "in"))
     out = str(tmp_path / "packed.agc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("AGC_AMD_ENCODE_OVERLAP", overlap)  # (one registration per window here: the overlapped encode runs)
     subprocess.check_call([sys.executable, "-c", _PACKED_CHILD, root, json.dumps(opt), json.dumps(files), out])
     got = open(out, "rb").read()
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
