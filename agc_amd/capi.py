@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libagc_hip.so")
 
 OK, ENODEV, EINVAL, ENOMEM, ECAP, ENOREF = 0, -1, -2, -3, -4, -5
 K_SCAN, K_INDEX, K_ENCODE, K_ESTIMATE, K_COSTVEC, K_REVCOMP, K_PREPROCESS, K_REFSTORE = range(8)
-K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd"]
+K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd", "filter"]
 
 # every symbol include/agc_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -1077,7 +1077,7 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         CHK(ensure(c, c->d_fjobs, fjobs.size() * sizeof(FilterJob)));
         HIPCHK(c, hipMemcpyAsync(c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), hipMemcpyHostToDevice, L_stream));
         {
-            KTimer t(c, mode == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+            KTimer t(c, AGC_HIP_K_FILTER);
             hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
         }
         HIPCHK(c, hipGetLastError());

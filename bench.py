@@ -75,11 +75,11 @@ def host_cpus():
 
 PMC_SUMMARY = os.path.join("profiles", "r2", "pmc_summary.csv")
 KERNEL_SYMBOL = {"scan": "agc::scan_packed_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
-                 "costvec": "agc::lz_parse_kernel<2>", "preprocess": "agc::expand_codes_kernel"}
+                 "costvec": "agc::lz_parse_kernel<2>", "preprocess": "agc::expand_codes_kernel", "filter": "agc::key_filter_kernel"}
 # bytes per symbol each kernel reads/writes in the layout AS BUILT: the scan reads the 2-bit layout, the expansion reads it and
 # writes the byte staging copy, the LZ kernels read bytes (text + reference)
-AS_BUILT_BPS = {"scan": 0.25, "preprocess": 1.25, "encode": 1.0, "estimate": 1.0, "costvec": 1.0}
-PACKED_BPS = {"scan": 0.25, "preprocess": 0.0, "encode": 0.25, "estimate": 0.25, "costvec": 0.25}
+AS_BUILT_BPS = {"scan": 0.25, "preprocess": 1.25, "encode": 1.0, "estimate": 1.0, "costvec": 1.0, "filter": 1.0}
+PACKED_BPS = {"scan": 0.25, "preprocess": 0.0, "encode": 0.25, "estimate": 0.25, "costvec": 0.25, "filter": 0.25}
 
 
 def pmc_table():
@@ -329,15 +329,17 @@ def main():
         # reference once.  Two columns: the layout as built (`bytes_per_symbol` B per symbol) and SURVEY 8d's 2-bit figure
         # (0.25 B per symbol), which is what north_star's roofline target is quoted on.
         # Kernel time = HIP events on the library's own stream around every launch of the timed region, summed per step
-        # (scan and encode are one launch per step; "costvec" = key filter + cost-vector parse + split-point reduction;
+        # (scan and encode are one launch per step; "costvec" = cost-vector parse + split-point reduction; "filter" = the
+        # key-filter kernel that writes the "may match" bitmaps of the estimate / cost-vector parses: it reads every text once;
         # "preprocess" = expansion of the packed sample into the byte staging copy; the algorithmic bytes of a kernel with
         # nothing to do on a fully packed path (the expansion) are 0 in the packed column).
         n_rank_steps = max(args.steps * world, 1)
         sym = {"scan": stats["bases"], "preprocess": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"],
-               "estimate": stats["est_text"] + stats["est_ref"], "costvec": stats["cv_text"] + stats["cv_ref"]}
+               "estimate": stats["est_text"] + stats["est_ref"], "costvec": stats["cv_text"] + stats["cv_ref"],
+               "filter": stats["est_text"] + stats["cv_text"]}
         tab = pmc_table()
         kern = {}
-        for name in ("scan", "preprocess", "encode", "estimate", "costvec"):
+        for name in ("scan", "preprocess", "encode", "estimate", "costvec", "filter"):
             ms_, n_ = tm[name]
             if not n_:
                 continue
@@ -395,7 +397,7 @@ def main():
                          "traffic_source": PMC_SUMMARY + " (2 x FETCH_SIZE + WRITE_SIZE, max over dispatches, per launch)" if dom.get("traffic") else None,
                          "algorithmic_bytes_per_launch": dom.get("as_built", {}).get("algorithmic_bytes"),
                          "avg_launch_ms": dom.get("ms_per_step"),
-                         "dominant_by": "largest kernel time per step among ALL kernels of the path (scan, encode, estimate, cost vectors)",
+                         "dominant_by": "largest kernel time per step among ALL kernels of the path (scan, expansion, encode, estimate, cost vectors, key filter)",
                          "layout": "samples resident in HBM at 0.25 B per symbol (2-bit words + escaped blocks); the scan reads that; the LZ "
                                    "kernels read a 1 B per symbol staging copy made at the start of the step ('preprocess' = that expansion) "
                                    "and 1 B per symbol references",

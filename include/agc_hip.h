@@ -54,7 +54,8 @@ enum {
     AGC_HIP_K_PREPROCESS = 6,
     AGC_HIP_K_REFSTORE = 7,
     AGC_HIP_K_ZSTD = 8,
-    AGC_HIP_K_COUNT = 9
+    AGC_HIP_K_FILTER = 9, /* key_filter_kernel: the "may match" bitmaps of the estimate / cost-vector parses */
+    AGC_HIP_K_COUNT = 10
 };
 int agc_hip_timing_enable(agc_hip_ctx *ctx, int on);
 int agc_hip_timing_reset(agc_hip_ctx *ctx);
