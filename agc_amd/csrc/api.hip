@@ -1575,15 +1575,16 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                 wps = atoi(e);
             const uint32_t dbg = (uint32_t)(getenv("AGC_HIP_ZSTD_DEBUG") ? atoi(getenv("AGC_HIP_ZSTD_DEBUG")) : 0);
             const dim3 grid((m + lanes - 1) / lanes), block(64);
+            const size_t lds_bytes = (size_t)lanes * zs::FAST_FREQ_WORDS * 4;
             const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
             if (wps >= 4)
-                hipLaunchKernelGGL(zstd_frames_kernel<4>, grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                hipLaunchKernelGGL(zstd_frames_kernel<4>, grid, block, lds_bytes, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             else if (wps == 3)
-                hipLaunchKernelGGL(zstd_frames_kernel<3>, grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                hipLaunchKernelGGL(zstd_frames_kernel<3>, grid, block, lds_bytes, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             else
-                hipLaunchKernelGGL(zstd_frames_kernel<2>, grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+                hipLaunchKernelGGL(zstd_frames_kernel<2>, grid, block, lds_bytes, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
         }
         HIPCHK(c, hipGetLastError());

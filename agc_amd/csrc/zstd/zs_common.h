@@ -14,7 +14,8 @@
 #include <string.h>
 
 #ifdef __HIPCC__
-#define ZFN __device__ static inline
+// (always_inline: an outlined function takes generic pointers -- flat_* instead of global_*/ds_* accesses -- and a 128-VGPR budget)
+#define ZFN __device__ static inline __attribute__((always_inline))
 #define ZHD __host__ __device__ static inline   // also needed by the host side of the C ABI (sizes, parameters)
 #define ZCONST __device__ static const
 #else

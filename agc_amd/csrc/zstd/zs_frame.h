@@ -51,7 +51,11 @@ ZHD U32 frameBound(U32 srcSize) { return srcSize + 16; }
 // the level's frame for src[0..srcSize), 7 <= ... any srcSize <= BLOCKSIZE_MAX, written to dst (frameBound bytes).
 // ws: wsLayout(cp, srcSize).total bytes, hashTable / hashTable3 / chainTable regions ZEROED by the caller.
 // loop_nest: parse with the plain loop nest (zs_opt.h) instead of the micro-step loop (zs_opt_sm.h); same bytes
-ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, bool loop_nest = false, U32 debug = 0)
+// fast_freqs: FAST_FREQ_WORDS words of fast memory for the three small statistics tables the price loops read all the time
+// (lit-length, match-length, offset-code frequencies) -- the kernel passes a slice of LDS; nullptr = they live in ws
+constexpr U32 FAST_FREQ_WORDS = 36 + 53 + 32;
+ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, bool loop_nest = false, U32 debug = 0,
+                      U32 *fast_freqs = nullptr)
 {
     BYTE *op = dst;
     // ---- frame header: magic, descriptor, [window], content size (contentSizeFlag = 1, no checksum, no dictID) ----
@@ -102,9 +106,16 @@ ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize,
         w.opt = (Optimal *)(ws + L.opt);
         w.matches = (Match *)(ws + L.matches);
         w.litFreq = (U32 *)(ws + L.freqs);
-        w.litLengthFreq = w.litFreq + 256;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (unconditional on the device so that the compiler sees ONE address space behind each pointer)
+        w.litLengthFreq = fast_freqs;
+        w.matchLengthFreq = fast_freqs + 36;
+        w.offCodeFreq = fast_freqs + 36 + 53;
+#else
+        w.litLengthFreq = fast_freqs ? fast_freqs : w.litFreq + 256;
         w.matchLengthFreq = w.litLengthFreq + 36;
         w.offCodeFreq = w.matchLengthFreq + 53;
+#endif
         w.seqs = (Seq *)(ws + L.seqs);
         w.lits = ws + L.lits;
         w.cp = cp;

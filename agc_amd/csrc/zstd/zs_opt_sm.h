@@ -89,6 +89,10 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
     U32 last_m_off = 0, last_m_len = 0; // the longest match of the current request (matches[nbMatches - 1])
     // store loop
     U32 storePos = 0, storeEnd = 0;
+    // the 8 source bytes at the position being worked on, read at the head of the position (together with the price-table
+    // entries) so that the hashes, the repcode tests and the literal price of the NEXT position need no load of their own
+    U64 p8 = 0;
+    U32 p8_pos = 0xFFFFFFFFu; // offset in src p8 was read at
 
     rescaleFreqs(w, src, srcSize, optLevel);
     ip += (w.idx0 == w.dictLimit);
@@ -142,6 +146,8 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 state = ST_DONE;
                 break;
             }
+            p8 = read64(src + ip); // (ip < srcSize - 8)
+            p8_pos = ip;
             q_litlen = ip - anchor;
             q_ll0 = !q_litlen;
             q_current = ip + w.idx0;
@@ -153,13 +159,23 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
         } while (0);
         if (state == ST_CUR_BEGIN) do {
             const U32 inr = ip + cur;
+            // everything this position reads from memory is asked for up front: the literal before it (usually the first byte
+            // of the previous position's window) and its frequency, the 8 bytes at the position, the two price-table entries
+            const U32 lit_byte = (p8_pos == inr - 1) ? (U32)(p8 & 0xFF) : (U32)src[inr - 1];
+            const U32 lit_freq = (w.priceType == zop_predef) ? 0 : w.litFreq[lit_byte];
+            if (inr <= ilimit_off) {
+                p8 = read64(src + inr);
+                p8_pos = inr;
+            }
             // the two entries are read ONCE, worked on in registers and written back once (every further look at opt[cur] in this
             // block uses the copy: a reload after a store is a round trip to memory on this hardware)
             const Optimal op = opt[cur - 1];
             Optimal oc = opt[cur];
             {
                 const U32 litlen = (op.mlen == 0) ? op.litlen + 1 : 1;
-                const int price = op.price + (int)rawLiteralsCost(src + inr - 1, 1, w, optLevel) + (int)litLengthPrice(litlen, w, optLevel) -
+                // rawLiteralsCost(src + inr - 1, 1)
+                const U32 lit_cost = (w.priceType == zop_predef) ? 6 * BITCOST_MULTIPLIER : w.litSumBasePrice - weight(lit_freq, optLevel);
+                const int price = op.price + (int)lit_cost + (int)litLengthPrice(litlen, w, optLevel) -
                                   (int)litLengthPrice(litlen - 1, w, optLevel);
                 if (price <= oc.price) {
                     oc.mlen = 0;
@@ -306,7 +322,8 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
             // ZSTD_insertBtAndGetAllMatches up to the tree walk
             wk_current = q_current;
             const BYTE *const p = src + (wk_current - w.idx0);
-            const U32 h = hashPtr(p, cp.hashLog, mls);
+            const U64 pv = (p8_pos == wk_current - w.idx0) ? p8 : read64(p); // (p <= iend - 8)
+            const U32 h = mls == 5 ? hash5(pv, cp.hashLog) : mls == 6 ? hash6(pv, cp.hashLog) : hash4((U32)pv, cp.hashLog);
             matchIndex = w.hashTable[h];
             clSmaller = clLarger = 0;
             const U32 dictLimit = w.dictLimit;
@@ -328,7 +345,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     const U32 repIndex = wk_current - repOffset;
                     U32 repLen = 0;
                     if (repOffset - 1 /* intentional overflow, discards 0 and -1 */ < wk_current - dictLimit) {
-                        if ((repIndex >= windowLow) & (readMINMATCH(p, minMatch) == readMINMATCH(p - repOffset, minMatch)))
+                        if ((repIndex >= windowLow) & ((minMatch == 3 ? ((U32)pv << 8) : (U32)pv) == readMINMATCH(p - repOffset, minMatch)))
                             repLen = count(p + minMatch, p + minMatch - repOffset, iend) + minMatch;
                     }
                     if (repLen > bestLength) {
@@ -346,7 +363,15 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 }
             }
             if (!done && (mls == 3) && (bestLength < mls)) { // HC3 match finder
-                const U32 matchIndex3 = insertAndFindFirstIndexHash3(w, src, &nextToUpdate3, wk_current);
+                // ZSTD_insertAndFindFirstIndexHash3 (the hash of the position itself from the window)
+                U32 matchIndex3;
+                {
+                    const U32 h3 = hash3((U32)pv, w.hashLog3);
+                    for (U32 idx = nextToUpdate3; idx < wk_current; ++idx)
+                        w.hashTable3[hash3(read32(src + (idx - w.idx0)), w.hashLog3)] = idx;
+                    nextToUpdate3 = wk_current;
+                    matchIndex3 = w.hashTable3[h3];
+                }
                 if ((matchIndex3 >= lowLimit) & (wk_current - matchIndex3 < (1u << 18))) {
                     const BYTE *const match = src + (matchIndex3 - w.idx0);
                     const U32 mlen = count(p, match, iend);
@@ -527,29 +552,49 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
             }
         } while (0);
         if (state == ST_PRICE_CUR) do {
-            // for (matchNb...) for (mlen = lastML; mlen >= startML; mlen--): a few lengths per micro-step
+            // for (matchNb...) for (mlen = lastML; mlen >= startML; mlen--): a few lengths per micro-step.  The prices the lengths
+            // of one batch compete with are read TOGETHER before the batch (one round trip instead of one per length): every
+            // position is visited once per `cur`, the fills below only touch positions beyond last_pos, so a price read up front
+            // is still the one in memory when its turn comes -- and a position beyond the last_pos of the batch's start holds
+            // MAX_PRICE by then (or is still beyond last_pos, where the comparison is not made at all).
             U32 budget = SM_PRICE_STEPS;
             while (budget && pr_matchNb < nbMatches) {
                 bool next = false;
                 if (pr_pos >= pm_start) {
-                    const U32 mlen = pr_pos;
-                    const U32 pos = cur + mlen;
-                    const int price = (int)(basePrice + getMatchPrice(pm_off, mlen, w, optLevel));
-                    if ((pos > last_pos) || (price < opt[pos].price)) {
-                        while (last_pos < pos) {
-                            opt[last_pos + 1].price = MAX_PRICE;
-                            last_pos++;
+                    const U32 lp0 = last_pos;
+                    const U32 avail = pr_pos - pm_start + 1;
+                    const U32 nb = budget < avail ? budget : avail;
+                    int pp[SM_PRICE_STEPS];
+#pragma unroll
+                    for (U32 t = 0; t < SM_PRICE_STEPS; ++t) {
+                        const U32 pos = cur + pr_pos - t;
+                        pp[t] = (t < nb && pos <= lp0) ? opt[pos].price : MAX_PRICE;
+                    }
+#pragma unroll
+                    for (U32 t = 0; t < SM_PRICE_STEPS; ++t) {
+                        if (t < nb && !next) {
+                            const U32 mlen = pr_pos;
+                            const U32 pos = cur + mlen;
+                            const int price = (int)(basePrice + getMatchPrice(pm_off, mlen, w, optLevel));
+                            if ((pos > last_pos) || (price < pp[t])) {
+                                while (last_pos < pos) {
+                                    opt[last_pos + 1].price = MAX_PRICE;
+                                    last_pos++;
+                                }
+                                Optimal o;
+                                o.price = price;
+                                o.off = pm_off;
+                                o.mlen = mlen;
+                                o.litlen = q_litlen;
+                                storeHead(opt[pos], o);
+                            } else if (optLevel == 0)
+                                next = true; // early update abort
+                            pr_pos--;
+                            budget--;
                         }
-                        Optimal o;
-                        o.price = price;
-                        o.off = pm_off;
-                        o.mlen = mlen;
-                        o.litlen = q_litlen;
-                        storeHead(opt[pos], o);
-                    } else if (optLevel == 0)
-                        next = true; // early update abort
-                    pr_pos--;
-                    budget--;
+                    }
+                    if (pr_pos < pm_start)
+                        next = true;
                 } else
                     next = true;
                 if (next) {

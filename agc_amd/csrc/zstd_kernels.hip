@@ -4,8 +4,8 @@
 //
 // Mapping: the greedy/optimal parse of one frame is a serial dependency chain (binary-tree insertions, price table), but a
 // collection closes tens of thousands of INDEPENDENT packs at once (one per group): one frame per LANE, every table of a
-// frame in its own slice of an HBM arena.  No MFMA, no LDS: integer/byte work bound by dependent memory latency; the
-// parallelism is the number of frames in flight.
+// frame in its own slice of an HBM arena (the three small frequency tables of the price model in LDS).  No MFMA: integer/byte
+// work bound by dependent memory latency; the parallelism is the number of frames in flight.
 #include "dev_common.h"
 #include "zstd/zs_frame.h"
 #include "zstd/zs_params.h"
@@ -39,7 +39,11 @@ __global__ void __launch_bounds__(64, WPS) zstd_frames_kernel(const ZFrameJob *_
     if (j >= n_jobs)
         return;
     const ZFrameJob jb = jobs[j];
-    out_size[jb.idx] = zs::compressFrame(ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, false, debug);
+    // the three small frequency tables of the price model (121 words per frame) live in LDS: the price loops look them up for
+    // every candidate length; an odd stride keeps the lanes of a wave on different banks for equal indices
+    extern __shared__ uint32_t zs_lds[];
+    uint32_t *const fast = zs_lds + threadIdx.x * zs::FAST_FREQ_WORDS;
+    out_size[jb.idx] = zs::compressFrame(ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, false, debug, fast);
 }
 
 template __global__ void zstd_frames_kernel<2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
