@@ -824,7 +824,7 @@ bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off
             I.close_src_off.push_back(I.close_src_off.back() + j.data.size());
         }
     }
-    I.zsrc_buf.resize(I.close_src_off.back());
+    I.zsrc_buf.resize(I.close_src_off.back(), false);
     I.pool->parallel_for(I.close_dev_jobs.size(), [&](size_t t, unsigned) {
         const ZJob &j = I.close_jobs[I.close_dev_jobs[t]];
         memcpy(I.zsrc_buf.data() + I.close_src_off[t], j.data.data(), j.data.size());
@@ -844,7 +844,9 @@ bool CAGCCompressor::CloseProvideFrames(const uint8_t *frames, const uint64_t *o
         return false;
     const size_t nd = I.close_dev_jobs.size();
     I.close_frames_off.assign(off, off + nd + 1);
-    I.zdst_buf.assign(frames + off[0], frames + off[nd]);
+    I.zdst_buf.resize(off[nd] - off[0], false);
+    if (off[nd] > off[0])
+        memcpy(I.zdst_buf.data(), frames + off[0], off[nd] - off[0]);
     const uint64_t base = off[0];
     for (auto &x : I.close_frames_off)
         x -= base;

@@ -213,10 +213,8 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         dev_done = std::async(std::launch::async, [&, nd, cap] {
             const double td = now();
             // (staging and gather run here, beside the host pool: they are part of the device's side of the split)
-            if (zsrc_buf.size() < src_off[nd])
-                zsrc_buf.resize(src_off[nd]);
-            if (zdst_buf.size() < cap)
-                zdst_buf.resize(cap);
+            zsrc_buf.resize(src_off[nd] + src_off[nd] / 8, false); // (headroom: the next call's packs are a little longer)
+            zdst_buf.resize(cap + cap / 8, false);
             for (size_t t = 0; t < nd; ++t)
                 memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size());
             if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
@@ -289,7 +287,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
             zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned) {
                 ZJob &j = jobs[dev_jobs[t]];
                 const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);
-                bytes_t packed(zdst_buf.begin() + dst_off[t], zdst_buf.begin() + dst_off[t + 1]);
+                bytes_t packed(zdst_buf.data() + dst_off[t], zdst_buf.data() + dst_off[t + 1]);
                 packed.push_back(0);
                 finish(j, packed, ps, 0);
             });

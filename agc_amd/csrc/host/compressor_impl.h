@@ -231,10 +231,12 @@ struct PinnedBytes {
     size_t size() const { return n; }
     uint8_t *data() { return p; }
     const uint8_t *data() const { return p; }
-    bool resize(size_t m)
+    bool resize(size_t m, bool keep = true)
     {
         if (m <= n)
             return true;
+        if (!keep)
+            release();
         void *q = nullptr;
         const bool pin = ctx && agc_hip_host_alloc(ctx, m, &q) == AGC_HIP_OK && q;
         if (!pin)
@@ -631,7 +633,7 @@ struct CAGCCompressor::Impl {
     bool gpu_zstd = false;             // delta packs are entropy-coded on the GPU (libzstd 1.4.x frames; AGC_AMD_HOST_ZSTD=1 turns it off)
     double gpu_zstd_share = 0.8;       // share of the pack bytes the device takes when both engines run (AGC_AMD_GPU_ZSTD_SHARE fixes it)
     uint32_t gpu_zstd_min = 64;        // fewer packs than this in one call stay on the host (AGC_AMD_GPU_ZSTD_MIN)
-    bytes_t zsrc_buf, zdst_buf;        // staging of the device entropy stage
+    PinnedBytes zsrc_buf, zdst_buf;    // staging of the device entropy stage (plain malloc: no zero fill of hundreds of MB)
     bool defer_stream_reg = false;     // parallel bookkeeping: pack jobs leave a missing delta stream to the merging thread
     bool minted_since_prepare = false; // a group of any key (also one-sided) was minted while a sample was prepared
     void lap(BatchState &b, const char *what);
