@@ -117,6 +117,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
     I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
+    if (const char *e = getenv("AGC_AMD_PAR_MIN"))
+        I.par_min = (size_t)std::max(1LL, atoll(e));
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
         I.overlap_mode = !strcmp(e, "early") || !strcmp(e, "1") ? 1 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 0;
     I.choose_entropy_stage();
@@ -271,6 +273,8 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
     I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
+    if (const char *e = getenv("AGC_AMD_PAR_MIN"))
+        I.par_min = (size_t)std::max(1LL, atoll(e));
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
         I.overlap_mode = !strcmp(e, "early") || !strcmp(e, "1") ? 1 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 0;
     I.choose_entropy_stage();

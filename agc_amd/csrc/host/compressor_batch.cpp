@@ -760,38 +760,59 @@ bool CAGCCompressor::Impl::stage_scan(BatchState &b)
 
     LAP("scan");
     // ---- stage 1b: cut into segments (agc_compressor.cpp:2018-2048) ----
+    // The segment records are 208 bytes and a human sample has 50 k of them: they are laid out by a prefix sum over the contigs
+    // and filled by the pool; only the fields the cut defines are written here -- classification (stage_classify) sets every
+    // field it reads before it reads it, so records left over from the previous window need no clearing.
     std::vector<Seg> &segs = seg_buf;
-    segs.clear();
-    segs.reserve(n_hits + n_ctg);
-    LAP("cut_reserve");
     {
-        uint64_t h = 0;
-        for (uint32_t c = 0; c < n_ctg; ++c) {
-            uint64_t split_pos = 0;
-            Kmer split_kmer;
-            while (h < n_hits && h_ctg[h] == c) {
-                Seg s;
-                s.ctg = c;
-                s.start = split_pos;
-                s.len = (uint32_t)(h_pos[h] + 1 - split_pos);
-                s.front = split_kmer;
-                s.back.dir = h_dir[h];
-                s.back.rc = h_rc[h];
-                s.back.full = true;
-                segs.push_back(s);
-                split_pos = h_pos[h] + 1 - k;
-                split_kmer = s.back;
-                ++h;
+        std::vector<uint64_t> h_begin((size_t)n_ctg + 1, 0), s_begin((size_t)n_ctg + 1, 0);
+        {
+            uint64_t h = 0;
+            for (uint32_t c = 0; c < n_ctg; ++c) {
+                h_begin[c] = h;
+                while (h < n_hits && h_ctg[h] == c)
+                    ++h;
+                const uint64_t nh = h - h_begin[c];
+                const uint64_t last_split = nh ? h_pos[h - 1] + 1 - k : 0;
+                s_begin[c + 1] = s_begin[c] + nh + (last_split < ctgs[c].len ? 1 : 0);
             }
-            if (split_pos < ctgs[c].len) {
-                Seg s;
-                s.ctg = c;
-                s.start = split_pos;
-                s.len = (uint32_t)(ctgs[c].len - split_pos);
-                s.front = split_kmer;
-                segs.push_back(s);
-            }
+            h_begin[n_ctg] = h;
         }
+        segs.resize(s_begin[n_ctg]); // (grows or shrinks by the difference to the previous window only)
+        LAP("cut_reserve");
+        const size_t n_chunks = std::min<size_t>(n_ctg, std::max<size_t>(1, (size_t)pool->size() * 4));
+        auto fill = [&](size_t ci, unsigned) {
+            for (uint32_t c = (uint32_t)((uint64_t)n_ctg * ci / n_chunks); c < (uint32_t)((uint64_t)n_ctg * (ci + 1) / n_chunks); ++c) {
+                uint64_t split_pos = 0;
+                Kmer split_kmer;
+                Seg *out = segs.data() + s_begin[c];
+                for (uint64_t h = h_begin[c]; h < h_begin[c + 1]; ++h) {
+                    Seg &s = *out++;
+                    s.ctg = c;
+                    s.start = split_pos;
+                    s.len = (uint32_t)(h_pos[h] + 1 - split_pos);
+                    s.front = split_kmer;
+                    s.back.dir = h_dir[h];
+                    s.back.rc = h_rc[h];
+                    s.back.full = true;
+                    split_pos = h_pos[h] + 1 - k;
+                    split_kmer = s.back;
+                }
+                if (split_pos < ctgs[c].len) {
+                    Seg &s = *out++;
+                    s.ctg = c;
+                    s.start = split_pos;
+                    s.len = (uint32_t)(ctgs[c].len - split_pos);
+                    s.front = split_kmer;
+                    s.back = Kmer();
+                }
+            }
+        };
+        if (segs.size() >= par_min)
+            pool->parallel_for(n_chunks, fill);
+        else
+            for (size_t ci = 0; ci < n_chunks; ++ci)
+                fill(ci, 0);
     }
     LAP("cut_loop");
 
@@ -813,28 +834,47 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     const std::vector<uint32_t> &L = b.subset;
     // ---- stage 1c: add_segment, part 1: keys and one-splitter candidates ----
     std::vector<Cand> cands;
+    // (a) per segment, independent of the others: reset of the classification fields, the key of a segment with both splitters
+    // and its look-up in the map -- 50 k records and as many probes of a table that does not fit the caches: the pool
+    {
+        const size_t nL = L.size(), n_chunks = nL >= par_min ? std::min<size_t>(std::max<size_t>(nL / 2048, 2), (size_t)pool->size() * 4) : 1;
+        auto reset_chunk = [&](size_t ci, unsigned) {
+            for (size_t t = nL * ci / n_chunks; t < nL * (ci + 1) / n_chunks; ++t) {
+                Seg &s = segs[L[t]];
+                s.pk = {NO_KMER, NO_KMER};
+                s.store_rc = false;
+                s.cand_begin = s.cand_end = 0;
+                s.back_only = false;
+                s.mid_job = -1;
+                s.known_gid = -2;
+                s.use_rc = false;
+                s.middle = NO_KMER;
+                s.bp = 0;
+                s.map_gid = -1;
+                if (s.front.full && s.back.full) {
+                    if (s.front.data() < s.back.data())
+                        s.pk = {s.front.data(), s.back.data()};
+                    else {
+                        s.pk = {s.back.data(), s.front.data()};
+                        s.store_rc = true;
+                    }
+                    if (const int32_t *m = map_segments.find(s.pk))
+                        s.map_gid = *m;
+                } // (no splitter at all: pk stays {NO_KMER, NO_KMER}, agc_compressor.cpp:1286-1301, fallback filter off)
+            }
+        };
+        if (n_chunks > 1)
+            pool->parallel_for(n_chunks, reset_chunk);
+        else
+            reset_chunk(0, 0);
+    }
+    // (b) the one-splitter segments (contig ends: a few dozen per sample), in list order: their candidate lists
     for (uint32_t si : L) {
         Seg &s = segs[si];
-        s.pk = {NO_KMER, NO_KMER};
-        s.store_rc = false;
-        s.cand_begin = s.cand_end = 0;
-        s.back_only = false;
-        s.mid_job = -1;
-        s.known_gid = -2;
-        s.use_rc = false;
-        s.middle = NO_KMER;
-        s.bp = 0;
         const bool ff = s.front.full, bf = s.back.full;
-        if (!ff && !bf) {
-            s.pk = {NO_KMER, NO_KMER}; // agc_compressor.cpp:1286-1301 (fallback filter off)
-        } else if (ff && bf) {
-            if (s.front.data() < s.back.data())
-                s.pk = {s.front.data(), s.back.data()};
-            else {
-                s.pk = {s.back.data(), s.front.data()};
-                s.store_rc = true;
-            }
-        } else {
+        if (ff == bf)
+            continue;
+        {
             s.back_only = !ff;
             s.one_kmer = ff ? s.front : s.back;
             if (s.back_only)
@@ -877,19 +917,6 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
 
-    // the keys of the segments with both splitters, looked up once (the pool: 50 k probes of a table that does not fit the caches)
-    {
-        const size_t nL = L.size(), n_chunks = std::min<size_t>(std::max<size_t>(nL / 2048, 1), (size_t)pool->size() * 4);
-        pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
-            for (size_t t = nL * ci / n_chunks; t < nL * (ci + 1) / n_chunks; ++t) {
-                Seg &s = segs[L[t]];
-                s.map_gid = -1;
-                if (s.front.full && s.back.full)
-                    if (const int32_t *m = map_segments.find(s.pk))
-                        s.map_gid = *m;
-            }
-        });
-    }
     LAP("keys");
     if (b.overlap_encode && overlap_mode == 1 && !overlap_encode_begin(b))
         return false;
@@ -984,10 +1011,17 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         uint8_t rc1, pf1, rc2, pf2;
     };
     std::vector<MidJob> mids;
-    for (uint32_t si : L) {
+    {
+        // the segments are independent here (the map and the terminator lists are only read): chunks of the list go to the pool,
+        // the jobs they produce are numbered afterwards in segment order
+        const size_t nL = L.size(), n_chunks = nL >= par_min ? std::min<size_t>(std::max<size_t>(nL / 1024, 2), (size_t)pool->size() * 4) : 1;
+        std::vector<std::vector<MidJob>> chunk_jobs(n_chunks);
+        std::vector<uint64_t> chunk_tried(n_chunks, 0);
+        std::vector<uint8_t> chunk_bad(n_chunks, 0);
+        auto one = [&](uint32_t si, std::vector<MidJob> &out, uint64_t &tried, bool &bad) {
         Seg &s = segs[si];
         if (concatenated || s.pk.first == NO_KMER || s.pk.second == NO_KMER)
-            continue;
+            return;
         {
             // known group: remembered for the placement below
             int32_t mg = s.map_gid;
@@ -997,17 +1031,17 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
             }
             if (mg >= 0) {
                 s.known_gid = mg;
-                continue;
+                return;
             }
         }
         s.known_gid = -1;
         auto tf = terminators.find(s.pk.first), tb = terminators.find(s.pk.second);
         if (tf == terminators.end() || tb == terminators.end())
-            continue;
+            return;
         if (s.front.data() == s.back.data()) {
             if (!s.front.is_dir_oriented())
                 s.store_rc = true;
-            continue;
+            return;
         }
         s.kmer1 = s.front;
         s.kmer2 = s.back;
@@ -1023,14 +1057,14 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         std::set_intersection(p_front->second.begin(), p_front->second.end(), p_back->second.begin(), p_back->second.end(),
                               std::back_inserter(shared));
         shared.erase(std::remove(shared.begin(), shared.end(), NO_KMER), shared.end());
-        ++st.middle_tried;
+        ++tried;
         if (shared.empty())
-            continue;
+            return;
         s.middle = shared.front();
         const int32_t *m1 = map_segments.find(std::minmax(s.kmer1.data(), s.middle)), *m2 = map_segments.find(std::minmax(s.middle, s.kmer2.data()));
         if (!m1 || !m2) {
-            err("internal: shared terminator without group");
-            return false;
+            bad = true;
+            return;
         }
         MidJob j;
         j.seg = si;
@@ -1042,11 +1076,11 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
             const bool e1 = groups[j.gid1].ref_size == 0, e2 = groups[j.gid2].ref_size == 0;
             if (e1 != e2) {
                 s.middle = NO_KMER;
-                continue;
+                return;
             }
             if (e1) {
                 s.mid_job = -2;
-                continue;
+                return;
             }
         }
         // segment_dir here = use_rc ? rc(segment) : segment (:1394)
@@ -1055,8 +1089,29 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         j.pf1 = f_lt_m ? 1 : 0;
         j.rc2 = (uint8_t)(m_lt_b ? s.use_rc : !s.use_rc);
         j.pf2 = m_lt_b ? 0 : 1;
-        s.mid_job = (int32_t)mids.size();
-        mids.push_back(j);
+        out.push_back(j); // (its index in the job list is given out below, in segment order)
+            };
+        auto run_chunk = [&](size_t ci, unsigned) {
+            bool bad = false;
+            for (size_t t = nL * ci / n_chunks; t < nL * (ci + 1) / n_chunks && !bad; ++t)
+                one(L[t], chunk_jobs[ci], chunk_tried[ci], bad);
+            chunk_bad[ci] = bad;
+        };
+        if (n_chunks > 1)
+            pool->parallel_for(n_chunks, run_chunk);
+        else
+            run_chunk(0, 0);
+        for (size_t ci = 0; ci < n_chunks; ++ci) {
+            if (chunk_bad[ci]) {
+                err("internal: shared terminator without group");
+                return false;
+            }
+            st.middle_tried += chunk_tried[ci];
+            for (const MidJob &j : chunk_jobs[ci]) {
+                segs[j.seg].mid_job = (int32_t)mids.size();
+                mids.push_back(j);
+            }
+        }
     }
     stage_end(st.t_classify, st.h_classify, t0, dev0);
     t0 = now();
@@ -1677,7 +1732,7 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
         };
         // groups are independent of each other (the reference runs them on all worker threads,
         // agc_compressor.cpp:989-1050): big samples go to the pool in chunks, jobs merged in list order
-        if (sl.n_lists() >= 4096) {
+        if (sl.n_lists() >= par_min) {
             const size_t n_chunks = std::min<size_t>(sl.n_lists(), (size_t)pool->size() * 8);
             std::vector<std::vector<ZJob>> chunk_jobs(n_chunks);
             defer_stream_reg = true;

@@ -539,6 +539,7 @@ struct CAGCCompressor::Impl {
     std::deque<std::vector<ZJob>> z_queue;
     bool z_busy = false, z_stop = false;
     bool sync_entropy = false;
+    size_t par_min = 4096; // lists shorter than this are walked by the calling thread (AGC_AMD_PAR_MIN: tests force the pool paths)
     void z_submit(std::vector<ZJob> &&jobs);
     void z_wait_all();
     void z_main();

@@ -116,6 +116,17 @@ def test_encode_overlapped_with_the_classification_gives_the_same_archive(cli, n
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_shuffled", "syn_adaptive", "syn_c4_twin", "syn_viral_c"])
+def test_pool_paths_of_the_host_stages_give_the_same_archive(cli, name, tmp_path, monkeypatch):
+    """AGC_AMD_PAR_MIN=1: the stages that hand long lists to the worker pool at human scale (segment cut per contig, key
+    lookups, missing-middle candidate search, per-group bookkeeping) take that path for these small collections too"""
+    monkeypatch.setenv("AGC_AMD_PAR_MIN", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"), threads="5")
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
 def test_host_pipeline_is_thread_independent(cli, tmp_path):
     args, _ = C.CONFIGS["syn_adaptive"]
     files = C.build("syn_adaptive", str(tmp_path / "in"))
