@@ -1567,7 +1567,15 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                                  zs_));
         {
             ZTimer t(c);
-            uint32_t lanes = 32; // measured best on the pack mix of Close(): 64 lanes 2.30 s, 32 lanes 2.11 s per 50 k frames
+            // frames per wave: fewer = fewer distinct parser states per trip of the micro-step loop, but every wave of the
+            // launch must be resident at once (2 per SIMD = 2048 on 256 CUs) or the launch takes two rounds.  Measured per
+            // 36 k frames of 13 KB: 24 lanes 1.31 s, 32 lanes 1.35 s, 48 lanes 1.38 s, 64 lanes 1.48 s, 16 lanes (two rounds) 1.82 s
+            uint32_t lanes = 64;
+            for (uint32_t cand : {24u, 32u, 48u})
+                if ((m + cand - 1) / cand <= 1900) {
+                    lanes = cand;
+                    break;
+                }
             if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
                 lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
             int wps = 2;

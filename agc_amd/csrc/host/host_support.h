@@ -223,6 +223,8 @@ private:
 
     void put(const void *p, size_t n)
     {
+        if (!f)
+            return; // no output path (bench mode): the parts exist, nothing is assembled
         const uint8_t *b = (const uint8_t *)p;
         wbuf.insert(wbuf.end(), b, b + n);
         if (wbuf.size() >= (32u << 20))
