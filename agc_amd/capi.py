@@ -32,7 +32,7 @@ SYMBOLS = [
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
     "agc_hip_ref_lag_counts_dev",
-    "agc_hip_zstd17_max_input", "agc_hip_zstd17_batch", "agc_hip_zstd17_cparams",
+    "agc_hip_zstd17_max_input", "agc_hip_zstd17_batch", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams",
     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
 ]
 
@@ -112,6 +112,7 @@ def load():
     L.agc_hip_ref_lag_counts_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_zstd17_batch.argtypes = [vp, C.c_uint32, u8p, u64p, u8p, C.c_uint64, u64p]
     L.agc_hip_zstd17_cparams.argtypes = [C.c_uint64, u32p]
+    L.agc_hip_zstd17_background.argtypes = [vp, C.c_int]
     L.agc_hip_zstd17_max_input.restype = C.c_uint32
     L.agc_hip_packed_words_bytes.restype = C.c_uint64
     L.agc_hip_packed_words_bytes.argtypes = [C.c_uint64]

@@ -37,6 +37,7 @@ struct agc_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t zstream = nullptr; // the entropy stage's own stream: agc_hip_zstd17_batch may run beside every other entry point
+    bool zstd_background = false;  // agc_hip_zstd17_background: launches leave the LDS to the kernels of the other streams
     std::string err;
 
     // splitter set
@@ -179,6 +180,15 @@ struct ZTimer {
 
 int ensure_z(agc_hip_ctx *c, DevBuf &b, size_t bytes) { return ensure(c, b, bytes, c->zstream); }
 
+// the entropy stage's stream yields to the streams of the steps wherever the hardware queues let it
+hipError_t create_low_priority_stream(hipStream_t *s)
+{
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess)
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, lo);
+}
+
 int upload_refs(agc_hip_ctx *c)
 {
     if (!c->refs_dirty)
@@ -219,7 +229,7 @@ int agc_hip_create(agc_hip_ctx **out, int device)
     agc_hip_ctx *c = new agc_hip_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->zstream, hipStreamNonBlocking) != hipSuccess ||
+        create_low_priority_stream(&c->zstream) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l2.e0) != hipSuccess ||
         hipEventCreate(&c->l2.e1) != hipSuccess || hipEventCreateWithFlags(&c->l2.ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess ||
@@ -1489,6 +1499,14 @@ int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
     return AGC_HIP_OK;
 }
 
+int agc_hip_zstd17_background(agc_hip_ctx *c, int on)
+{
+    if (!c)
+        return AGC_HIP_EINVAL;
+    c->zstd_background = on != 0;
+    return AGC_HIP_OK;
+}
+
 int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
                          uint64_t *h_dst_off)
 {
@@ -1570,30 +1588,24 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             // frames per wave: fewer = fewer distinct parser states per trip of the micro-step loop, but every wave of the
             // launch must be resident at once (2 per SIMD = 2048 on 256 CUs) or the launch takes two rounds.  Measured per
             // 36 k frames of 13 KB: 24 lanes 1.31 s, 32 lanes 1.35 s, 48 lanes 1.38 s, 64 lanes 1.48 s, 16 lanes (two rounds) 1.82 s
-            uint32_t lanes = 64;
-            for (uint32_t cand : {24u, 32u, 48u})
-                if ((m + cand - 1) / cand <= 1900) {
-                    lanes = cand;
-                    break;
-                }
+            uint32_t lanes = 64; // (background launches: as few waves as possible, the other streams' kernels need the slots)
+            if (!c->zstd_background)
+                for (uint32_t cand : {24u, 32u, 48u})
+                    if ((m + cand - 1) / cand <= 1900) {
+                        lanes = cand;
+                        break;
+                    }
             if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
                 lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
-            int wps = 2;
-            if (const char *e = getenv("AGC_HIP_ZSTD_WPS"))
-                wps = atoi(e);
             const uint32_t dbg = (uint32_t)(getenv("AGC_HIP_ZSTD_DEBUG") ? atoi(getenv("AGC_HIP_ZSTD_DEBUG")) : 0);
             const dim3 grid((m + lanes - 1) / lanes), block(64);
-            const size_t lds_bytes = (size_t)lanes * zs::FAST_FREQ_WORDS * 4;
             const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
-            if (wps >= 4)
-                hipLaunchKernelGGL(zstd_frames_kernel<4>, grid, block, lds_bytes, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
-                                   (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
-            else if (wps == 3)
-                hipLaunchKernelGGL(zstd_frames_kernel<3>, grid, block, lds_bytes, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
+            if (c->zstd_background)
+                hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             else
-                hipLaunchKernelGGL(zstd_frames_kernel<2>, grid, block, lds_bytes, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
-                                   (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+                hipLaunchKernelGGL((zstd_frames_kernel<2, true>), grid, block, (size_t)lanes * zs::FAST_FREQ_WORDS * 4, zs_, dj, m, (uint32_t *)c->d_zsize.p,
+                                   lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
         }
         HIPCHK(c, hipGetLastError());
         done += m;

@@ -31,6 +31,7 @@ void CAGCCompressor::Impl::run_jobs(std::vector<ZJob> &jobs, bool add_parts)
     // (one round: the device's time for a launch is close to the serial time of ONE frame whatever the number of frames --
     // rounds only add up)
     z_wait_all(); // zpool, the zstd contexts and the staging buffers are the entropy thread's while it works
+    agc_hip_zstd17_background(hip, 0);
     run_jobs_round(jobs);
     if (add_parts)
         add_job_parts(jobs, 0, jobs.size());
@@ -69,6 +70,7 @@ void CAGCCompressor::Impl::z_main()
             }
             z_busy = true;
         }
+        agc_hip_zstd17_background(hip, z_caller_waits.load() ? 0 : 1); // beside the steps: leave the LDS to the scan
         run_jobs_round(batch);
         for (ZJob &j : batch) {
             st.zstd_in += j.data.size();
@@ -91,10 +93,12 @@ void CAGCCompressor::Impl::z_wait_all()
     if (!z_thread.joinable())
         return;
     const double t0 = now();
+    z_caller_waits = true;
     {
         std::unique_lock<std::mutex> lk(z_mtx);
         z_idle_cv.wait(lk, [&] { return z_queue.empty() && !z_busy; });
     }
+    z_caller_waits = false;
     st.t_zstd_wait += now() - t0;
     ar.try_drain();
 }
@@ -1842,7 +1846,8 @@ void CAGCCompressor::Impl::finish_groups()
         j.slot = std::make_shared<PartSlot>();
         ar.add_part_deferred(j.stream_id, j.slot);
     }
-    z_submit(std::move(jobs)); // (Close waits for the entropy thread, then flushes)
+    z_caller_waits = true;     // (Close waits for the entropy thread, then flushes)
+    z_submit(std::move(jobs));
 }
 
 // the pack jobs of every group's open pack (+ the parts an appended archive's untouched groups keep as they are)

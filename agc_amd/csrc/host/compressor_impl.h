@@ -538,6 +538,7 @@ struct CAGCCompressor::Impl {
     std::condition_variable z_cv, z_idle_cv;
     std::deque<std::vector<ZJob>> z_queue;
     bool z_busy = false, z_stop = false;
+    std::atomic<bool> z_caller_waits{false}; // the caller stands still for the stage (Close, Drain): its launches may take the LDS
     bool sync_entropy = false;
     size_t par_min = 4096; // lists shorter than this are walked by the calling thread (AGC_AMD_PAR_MIN: tests force the pool paths)
     void z_submit(std::vector<ZJob> &&jobs);

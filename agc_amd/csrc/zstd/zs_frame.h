@@ -54,6 +54,8 @@ ZHD U32 frameBound(U32 srcSize) { return srcSize + 16; }
 // fast_freqs: FAST_FREQ_WORDS words of fast memory for the three small statistics tables the price loops read all the time
 // (lit-length, match-length, offset-code frequencies) -- the kernel passes a slice of LDS; nullptr = they live in ws
 constexpr U32 FAST_FREQ_WORDS = 36 + 53 + 32;
+// FAST (device only): the tables are at fast_freqs; !FAST: in ws (a launch that must leave the LDS to kernels of other streams)
+template <bool FAST = true>
 ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, bool loop_nest = false, U32 debug = 0,
                       U32 *fast_freqs = nullptr)
 {
@@ -107,10 +109,16 @@ ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize,
         w.matches = (Match *)(ws + L.matches);
         w.litFreq = (U32 *)(ws + L.freqs);
 #if defined(__HIP_DEVICE_COMPILE__)
-        // (unconditional on the device so that the compiler sees ONE address space behind each pointer)
-        w.litLengthFreq = fast_freqs;
-        w.matchLengthFreq = fast_freqs + 36;
-        w.offCodeFreq = fast_freqs + 36 + 53;
+        // (decided at compile time on the device so that the compiler sees ONE address space behind each pointer)
+        if (FAST) {
+            w.litLengthFreq = fast_freqs;
+            w.matchLengthFreq = fast_freqs + 36;
+            w.offCodeFreq = fast_freqs + 36 + 53;
+        } else {
+            w.litLengthFreq = w.litFreq + 256;
+            w.matchLengthFreq = w.litLengthFreq + 36;
+            w.offCodeFreq = w.matchLengthFreq + 53;
+        }
 #else
         w.litLengthFreq = fast_freqs ? fast_freqs : w.litFreq + 256;
         w.matchLengthFreq = w.litLengthFreq + 36;

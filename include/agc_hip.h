@@ -260,6 +260,11 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_ba
 uint32_t agc_hip_zstd17_max_input(void);
 int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off,
                          uint8_t *h_dst, uint64_t dst_cap, uint64_t *h_dst_off);
+/* on != 0: the launches of agc_hip_zstd17_batch keep their tables out of the LDS, so that kernels of the context's other
+ * streams that need most of a CU's LDS (the packed splitter scan: 128 KiB per block) can start beside a launch that runs for
+ * a second.  For a caller that compresses packs in the background while it goes on adding samples; off (the default) is
+ * ~10 % faster when nothing else runs. */
+int agc_hip_zstd17_background(agc_hip_ctx *ctx, int on);
 /* The compression parameters libzstd 1.4.9 derives for level 17 and a known source size (ZSTD_getCParams(17, n, 0)):
  * windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy.  Exposed so that tests can pin them. */
 int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7]);

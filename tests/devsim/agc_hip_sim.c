@@ -348,6 +348,12 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t cap, uint64_t
     return r;
 }
 
+int agc_hip_zstd17_background(agc_hip_ctx *c, int on)
+{
+    (void)on;
+    return c ? AGC_HIP_OK : AGC_HIP_EINVAL;
+}
+
 int agc_hip_host_alloc(agc_hip_ctx *c, uint64_t bytes, void **out)
 {
     if (!c || !out)

@@ -8,11 +8,18 @@ from tests import zstd_cases as ZC
 pytestmark = pytest.mark.gpu
 
 
-def test_gpu_frames_equal_libzstd(hip_ctx, oracle):
+@pytest.mark.parametrize("background", [0, 1])
+def test_gpu_frames_equal_libzstd(hip_ctx, oracle, background):
+    """both builds of the kernel: frequency tables in LDS (default) and in the workspace (agc_hip_zstd17_background: launches that
+    run beside the steps of the next samples)"""
     if ZC.libzstd().ZSTD_versionNumber() != 10409:
         pytest.skip("parity is pinned against libzstd 1.4.9")
-    inputs = ZC.corpus(oracle, 31337, 400)
-    got = hip_ctx.zstd17_batch(inputs)
+    inputs = ZC.corpus(oracle, 31337 + background, 400)
+    assert hip_ctx.L.agc_hip_zstd17_background(hip_ctx.h, background) == 0
+    try:
+        got = hip_ctx.zstd17_batch(inputs)
+    finally:
+        hip_ctx.L.agc_hip_zstd17_background(hip_ctx.h, 0)
     bad = [(i, len(p)) for i, p in enumerate(inputs) if got[i] != ZC.ref_frame(p)]
     assert not bad, bad
 
