@@ -402,6 +402,20 @@ class Context:
         self._chk(self.L.agc_hip_zstd17_batch(self.h, n, _p(src, u8p), _p(off, u64p), _p(dst, u8p), cap, _p(doff, u64p)))
         return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)]
 
+    def zstd17_batch_raw(self, src, off):
+        """packs back to back (pack i = src[off[i]:off[i+1]]) -> (frames back to back, their offsets [n + 1]); no per-pack
+        Python work (the multi-GPU Close hands tens of thousands of packs through here)"""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = off.size - 1
+        cap = int(off[-1] - off[0]) + 32 * n + 64
+        dst = np.empty(cap, np.uint8)
+        doff = np.zeros(n + 1, np.uint64)
+        if src.size == 0:
+            src = np.zeros(1, np.uint8)
+        self._chk(self.L.agc_hip_zstd17_batch(self.h, n, _p(src, u8p), _p(off, u64p), _p(dst, u8p), cap, _p(doff, u64p)))
+        return dst[:int(doff[-1])], doff
+
     def fetch_slices_dev(self, d_base, off, length, rc=None):
         o, l = _a(off, np.uint64), _a(length, np.uint32)
         r = _a(rc, np.uint8) if rc is not None else None

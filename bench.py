@@ -214,10 +214,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # AGC_BENCH_ONE_GPU=1 (testing aid, a box with one GPU): every rank on cuda:0, records over gloo -- the N > 1 code path of
+    # this file end to end on real kernels; the driver's runs use one GPU per rank and RCCL
+    one_gpu = world > 1 and os.environ.get("AGC_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    red_dev = torch.device("cpu") if one_gpu else dev  # where the small reductions of the timings live
     from agc_amd import host, shard, synth_dev
 
     total = int(args.gbp * 1e9)
@@ -312,11 +319,11 @@ def main():
     st1 = cmp_.stats()
     stats = {k_: st1[k_] - st0[k_] for k_ in st1}
     if world > 1:
-        t = torch.tensor([elapsed, t_steps], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, t_steps], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_steps = [float(x) for x in t.tolist()]
         keys = ["bases", "segments", "lz_encoded", "delta_bytes", "middle_tried", "middle_split", "one_splitter", "new_groups", "zstd_in", "zstd_out"]
-        agg = torch.tensor([stats[k_] for k_ in keys], device=dev, dtype=torch.float64)
+        agg = torch.tensor([stats[k_] for k_ in keys], device=red_dev, dtype=torch.float64)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         for k_, v in zip(keys, agg.tolist()):
             stats[k_] = v

@@ -22,21 +22,22 @@ from agc_amd.fasta import read_codes as fasta_codes  # noqa: E402
 
 
 def _sim_zstd_batch():
-    """list of packs -> list of level-17 frames through the CPU stand-in's agc_hip_zstd17_batch"""
+    """(packs back to back, offsets) -> (level-17 frames back to back, offsets) through the CPU stand-in's agc_hip_zstd17_batch"""
     from tests.devsim import build as simbuild
     sim = C.CDLL(simbuild.SIM_HIP)
     sim.agc_hip_zstd17_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 
-    def run(inputs):
-        n = len(inputs)
-        off = np.zeros(n + 1, np.uint64)
-        off[1:] = np.cumsum([len(x) for x in inputs])
-        src = np.frombuffer(b"".join(bytes(x) for x in inputs), np.uint8) if off[-1] else np.zeros(1, np.uint8)
+    def run(src, off):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = off.size - 1
+        if src.size == 0:
+            src = np.zeros(1, np.uint8)
         cap = int(off[-1]) + 32 * n + 64
         dst = np.zeros(cap, np.uint8)
         doff = np.zeros(n + 1, np.uint64)
         assert sim.agc_hip_zstd17_batch(C.c_void_p(1), n, src.ctypes.data, off.ctypes.data, dst.ctypes.data, cap, doff.ctypes.data) == 0
-        return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)]
+        return dst[:int(doff[-1])], doff
     return run
 
 
@@ -98,7 +99,7 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
         if on_gpu:
             dc.close()
         else:
-            dc.close(zstd_batch=_sim_zstd_batch())  # the stand-in's agc_hip_zstd17_batch (same encoder headers as the kernel)
+            dc.close(zstd_raw=_sim_zstd_batch())  # the stand-in's agc_hip_zstd17_batch (same encoder headers as the kernel)
         st = cmp_.stats()
         cmp_.close_handle()
         q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"], st["revalidated"]))
@@ -257,7 +258,7 @@ def _edge_worker(rank, world, port, out_path, q, prefetch):
             for i in range(len(samples)):
                 cmp_.add_sample_dev(*get_sample(i))
         if world > 1:
-            dc.close(zstd_batch=_sim_zstd_batch())
+            dc.close(zstd_raw=_sim_zstd_batch())
         else:
             cmp_.close()
         st = cmp_.stats()
