@@ -18,7 +18,7 @@ namespace zs {
 #define ZS_SM_PRICE_STEPS 8
 #endif
 #ifndef ZS_SM_WALK_LEVELS
-#define ZS_SM_WALK_LEVELS 4
+#define ZS_SM_WALK_LEVELS 6
 #endif
 constexpr U32 SM_PRICE_STEPS = ZS_SM_PRICE_STEPS;     // price updates per trip
 constexpr U32 SM_WALK_LEVELS = ZS_SM_WALK_LEVELS;     // tree levels per trip
