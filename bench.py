@@ -138,9 +138,16 @@ def cpu_baseline(args, mbp):
             t_ref = min(run([]), run([]))
             t_all = min(run(files), run(files))
             dt = max(t_all - t_ref, 1e-6)
+            # SURVEY 8d asks for T in {1, all cores}: the single-thread figure on one sample of the same twin
+            common[common.index("-t") + 1] = "1"
+            t1_ref = run([])
+            t1_one = run(files[:1])
+            dt1 = max(t1_one - t1_ref, 1e-6)
             return {"value": n_samples * n / dt / 1e9, "unit": "Gbp/s", "cores": int(t_threads), "kind": "reference",
                     "sample": f"oracle/_ref/agc create -t {t_threads}: wall(ref + {n_samples} x {mbp:g} Mbp samples, d={args.div:g}) "
-                              f"- wall(ref only) = {dt:.2f} s"}
+                              f"- wall(ref only) = {dt:.2f} s",
+                    "value_1_thread": round(n / dt1 / 1e9, 4),
+                    "sample_1_thread": f"the same with -t 1 and one sample: {dt1:.2f} s"}
     # oracle port, single thread: scan + encode of one sample
     from oracle import agc_oracle as O
     spl = O.determine_splitters(refc, K, SEG)
