@@ -214,13 +214,21 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
             src_off[t + 1] = src_off[t] + jobs[dev_jobs[t]].data.size();
         const uint64_t cap = src_off[nd] + 32 * nd + 64; // a frame never exceeds its input by more than the headers
         dst_off.assign(nd + 1, 0);
-        dev_done = std::async(std::launch::async, [&, nd, cap] {
-            const double td = now();
-            // (staging and gather run here, beside the host pool: they are part of the device's side of the split)
-            zsrc_buf.resize(src_off[nd] + src_off[nd] / 8, false); // (headroom: the next call's packs are a little longer)
+        // the packs are gathered by the whole pool (hundreds of MB into fresh pages: a tenth of a second for one thread, and the
+        // device's side of the split is the longer one), then the device call runs beside the pool's own jobs
+        const double tg = now();
+        zsrc_buf.resize(src_off[nd] + src_off[nd] / 8, false); // (headroom: the next call's packs are a little longer)
+        {
+            const size_t n_chunks = std::min<size_t>(nd, (size_t)zpool->size() * 4);
+            zpool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
+                for (size_t t = nd * ci / n_chunks; t < nd * (ci + 1) / n_chunks; ++t)
+                    memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size());
+            });
+        }
+        const double t_gather = now() - tg;
+        dev_done = std::async(std::launch::async, [&, nd, cap, t_gather] {
+            const double td = now() - t_gather; // (the gather counts as device-side time for the split rule)
             zdst_buf.resize(cap + cap / 8, false);
-            for (size_t t = 0; t < nd; ++t)
-                memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size());
             if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
                 static int dump_no = 0;
                 const std::string base = std::string(dump) + "/packs_" + std::to_string(dump_no++);
