@@ -817,7 +817,13 @@ bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off
     I.z_wait_all(); // (the staging buffers below are the entropy thread's)
     I.store_open_batch();
     I.close_jobs.clear();
+    for (ZJob &j : I.deferred_packs) // the packs that filled during the run come first (their parts are already placed)
+        I.close_jobs.emplace_back(std::move(j));
+    I.deferred_packs.clear();
+    const size_t n_kept = I.close_jobs.size();
     I.build_close_jobs(I.close_jobs);
+    if (getenv("AGC_AMD_LAPS"))
+        std::cerr << "  CloseCollectPacks: " << n_kept << " packs kept from the run + " << I.close_jobs.size() - n_kept << " open ones\n";
     I.close_dev_jobs.clear();
     const uint32_t dev_max = agc_hip_zstd17_max_input();
     I.close_src_off.assign(1, 0);

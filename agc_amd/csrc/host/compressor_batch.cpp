@@ -327,7 +327,12 @@ void CAGCCompressor::Impl::add_job_parts(std::vector<ZJob> &jobs, size_t from, s
         ZJob &j = jobs[i];
         st.zstd_in += j.data.size();
         st.zstd_out += j.out.size();
-        ar.add_part_buffered(j.stream_id, std::move(j.out), j.meta);
+        if (j.slot) { // the part took its place when the pack filled (a pack kept for the distributed Close)
+            j.slot->out = std::move(j.out);
+            j.slot->meta = j.meta;
+            j.slot->ready.store(true, std::memory_order_release);
+        } else
+            ar.add_part_buffered(j.stream_id, std::move(j.out), j.meta);
     }
 }
 
@@ -1807,6 +1812,18 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
             ar.add_part_deferred(all_jobs[i].stream_id, all_jobs[i].slot);
         after_registration();
     }
+    if (dist_world > 1 && gpu_zstd) {
+        // one archive from N ranks: the writer's own entropy stage would be the only one at work during the run -- full packs a
+        // device can code are kept for the distributed Close (CloseCollectPacks), the rest (references) goes on now
+        const uint32_t dev_max = agc_hip_zstd17_max_input();
+        std::vector<ZJob> now_jobs;
+        for (ZJob &j : all_jobs)
+            if (j.kind == 1 && !j.data.empty() && j.data.size() <= dev_max)
+                deferred_packs.emplace_back(std::move(j));
+            else
+                now_jobs.emplace_back(std::move(j));
+        all_jobs.swap(now_jobs);
+    }
     z_submit(std::move(all_jobs));
     if (sync_entropy)
         z_wait_all();
@@ -1854,6 +1871,9 @@ void CAGCCompressor::Impl::finish_groups()
         j.slot = std::make_shared<PartSlot>();
         ar.add_part_deferred(j.stream_id, j.slot);
     }
+    for (ZJob &j : deferred_packs) // (Close without CloseCollectPacks: the kept packs are coded here after all)
+        jobs.emplace_back(std::move(j));
+    deferred_packs.clear();
     z_caller_waits = true;     // (Close waits for the entropy thread, then flushes)
     z_submit(std::move(jobs));
 }

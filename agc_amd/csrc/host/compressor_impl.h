@@ -662,6 +662,9 @@ struct CAGCCompressor::Impl {
     void build_close_jobs(std::vector<ZJob> &jobs);
     void store_open_batch(bool flush = true);
     // Close in steps (multi-GPU entropy stage, compressor.h: CloseCollectPacks / CloseProvideFrames)
+    // single-archive mode, writer rank: delta packs that filled during the run wait here (their parts already hold their place in
+    // the archive) so that Close in steps can spread them over every rank's GPU together with the packs still open
+    std::vector<ZJob> deferred_packs;
     std::vector<ZJob> close_jobs;
     std::vector<uint32_t> close_dev_jobs;      // indices in close_jobs of the packs handed out
     std::vector<uint64_t> close_src_off, close_frames_off;
