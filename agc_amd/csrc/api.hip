@@ -1603,8 +1603,8 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             if (c->zstd_background)
                 hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
                                    (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
-            else
-                hipLaunchKernelGGL((zstd_frames_kernel<2, true>), grid, block, (size_t)lanes * zs::FAST_FREQ_WORDS * 4, zs_, dj, m, (uint32_t *)c->d_zsize.p,
+            else // (frequency tables and the first matches of a request in LDS)
+                hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs_, dj, m, (uint32_t *)c->d_zsize.p,
                                    lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
         }
         HIPCHK(c, hipGetLastError());

@@ -54,10 +54,13 @@ ZHD U32 frameBound(U32 srcSize) { return srcSize + 16; }
 // fast_freqs: FAST_FREQ_WORDS words of fast memory for the three small statistics tables the price loops read all the time
 // (lit-length, match-length, offset-code frequencies) -- the kernel passes a slice of LDS; nullptr = they live in ws
 constexpr U32 FAST_FREQ_WORDS = 36 + 53 + 32;
+constexpr U32 FAST_MATCHES = 16;                                  // matches of a request kept in fast memory (FASTM)
+constexpr U32 FAST_WORDS = FAST_FREQ_WORDS + 2 * FAST_MATCHES;    // per frame, when both are used (odd: lanes on different banks)
 // FAST (device only): the tables are at fast_freqs; !FAST: in ws (a launch that must leave the LDS to kernels of other streams)
-template <bool FAST = true>
+// FASTM: the first FAST_MATCHES matches of a request are kept at fast_freqs + FAST_FREQ_WORDS (host: fast_matches, a test hook)
+template <bool FAST = true, bool FASTM = false>
 ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, bool loop_nest = false, U32 debug = 0,
-                      U32 *fast_freqs = nullptr)
+                      U32 *fast_freqs = nullptr, Match *fast_matches = nullptr)
 {
     BYTE *op = dst;
     // ---- frame header: magic, descriptor, [window], content size (contentSizeFlag = 1, no checksum, no dictID) ----
@@ -123,6 +126,13 @@ ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize,
         w.litLengthFreq = fast_freqs ? fast_freqs : w.litFreq + 256;
         w.matchLengthFreq = w.litLengthFreq + 36;
         w.offCodeFreq = w.matchLengthFreq + 53;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+        w.fastMatches = FASTM ? (Match *)(fast_freqs + FAST_FREQ_WORDS) : nullptr;
+        w.fastMatchCap = FASTM ? FAST_MATCHES : 0;
+#else
+        w.fastMatches = fast_matches;
+        w.fastMatchCap = fast_matches ? FAST_MATCHES : 0;
 #endif
         w.seqs = (Seq *)(ws + L.seqs);
         w.lits = ws + L.lits;

@@ -31,6 +31,8 @@ struct OptWs {
     // optimal parser
     Optimal *opt;      // OPT_NUM + 1 entries
     Match *matches;    // OPT_NUM + 1 entries
+    Match *fastMatches; // the first fastMatchCap matches of a request live here instead (fast memory: LDS on the device)
+    U32 fastMatchCap;
     U32 *litFreq;      // 256
     U32 *litLengthFreq; // 36
     U32 *matchLengthFreq; // 53

@@ -65,6 +65,30 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
     U32 *const bt = w.chainTable;
     Optimal *const opt = w.opt;
     Match *const matches = w.matches;
+    Match *const fm = w.fastMatches; // the first fmCap matches of a request (a position rarely has more than a handful)
+    const U32 fmCap = w.fastMatchCap;
+#define ZS_M_SET(i_, off_, len_)                 \
+    do {                                         \
+        const U32 mi_ = (i_);                    \
+        if (mi_ < fmCap) {                       \
+            fm[mi_].off = (off_);                \
+            fm[mi_].len = (len_);                \
+        } else {                                 \
+            matches[mi_].off = (off_);           \
+            matches[mi_].len = (len_);           \
+        }                                        \
+    } while (0)
+#define ZS_M_GET(i_, off_, len_)                 \
+    do {                                         \
+        const U32 mi_ = (i_);                    \
+        if (mi_ < fmCap) {                       \
+            (off_) = fm[mi_].off;                \
+            (len_) = fm[mi_].len;                \
+        } else {                                 \
+            (off_) = matches[mi_].off;           \
+            (len_) = matches[mi_].len;           \
+        }                                        \
+    } while (0)
     U32 nextToUpdate3 = w.nextToUpdate;
 
     // parser state
@@ -350,8 +374,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     }
                     if (repLen > bestLength) {
                         bestLength = repLen;
-                        matches[mnum].off = repCode - q_ll0;
-                        matches[mnum].len = repLen;
+                        ZS_M_SET(mnum, repCode - q_ll0, repLen);
                         last_m_off = repCode - q_ll0;
                         last_m_len = repLen;
                         mnum++;
@@ -377,8 +400,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     const U32 mlen = count(p, match, iend);
                     if (mlen >= mls) {
                         bestLength = mlen;
-                        matches[0].off = (wk_current - matchIndex3) + REP_MOVE;
-                        matches[0].len = mlen;
+                        ZS_M_SET(0, (wk_current - matchIndex3) + REP_MOVE, mlen);
                         last_m_off = (wk_current - matchIndex3) + REP_MOVE;
                         last_m_len = mlen;
                         mnum = 1;
@@ -420,8 +442,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     if (matchLength > matchEndIdx - matchIndex)
                         matchEndIdx = matchIndex + matchLength;
                     bestLength = matchLength;
-                    matches[mnum].off = (wk_current - matchIndex) + REP_MOVE;
-                    matches[mnum].len = matchLength;
+                    ZS_M_SET(mnum, (wk_current - matchIndex) + REP_MOVE, matchLength);
                     last_m_off = (wk_current - matchIndex) + REP_MOVE;
                     last_m_len = matchLength;
                     mnum++;
@@ -493,8 +514,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     opt[pos].price = MAX_PRICE;
                 pr_pos = minMatch;
                 pr_matchNb = 0;
-                pm_off = matches[0].off;
-                pm_len = matches[0].len;
+                ZS_M_GET(0, pm_off, pm_len);
                 state = ST_PRICE_FIRST;
                 break;
             }
@@ -517,8 +537,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 }
             }
             pr_matchNb = 0;
-            pm_off = matches[0].off;
-            pm_len = matches[0].len;
+            ZS_M_GET(0, pm_off, pm_len);
             pm_start = minMatch;
             pr_pos = pm_len; // mlen cursor of the downward scan
             state = ST_PRICE_CUR;
@@ -540,8 +559,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                 } else {
                     pr_matchNb++;
                     if (pr_matchNb < nbMatches) {
-                        pm_off = matches[pr_matchNb].off;
-                        pm_len = matches[pr_matchNb].len;
+                        ZS_M_GET(pr_matchNb, pm_off, pm_len);
                     }
                 }
             }
@@ -601,8 +619,7 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
                     pr_matchNb++;
                     if (pr_matchNb < nbMatches) {
                         pm_start = pm_len + 1; // matches[matchNb - 1].len + 1
-                        pm_off = matches[pr_matchNb].off;
-                        pm_len = matches[pr_matchNb].len;
+                        ZS_M_GET(pr_matchNb, pm_off, pm_len);
                         pr_pos = pm_len;
                     }
                 }
@@ -637,6 +654,8 @@ ZFN U32 compressBlockOptSM(OptWs &w, U32 rep[3], const BYTE *src, U32 srcSize, i
         } while (0);
     }
     return srcSize - anchor;
+#undef ZS_M_SET
+#undef ZS_M_GET
 }
 
 } // namespace zs

@@ -30,7 +30,7 @@ struct ZFrameJob {
 // and their memory waits overlap only if they are resident together
 // USE_LDS = false: the tables stay in the workspace -- a launch that runs for a second beside the steps of the next samples must
 // not take the LDS the 128 KiB splitter-scan blocks need (with it a scan block waits until a CU has drained its frames)
-template <int WPS, bool USE_LDS>
+template <int WPS, bool USE_LDS, bool M_LDS = false>
 __global__ void __launch_bounds__(64, WPS) zstd_frames_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
                                                          uint32_t lanes_per_wave, const uint8_t *__restrict__ src_base, uint8_t *__restrict__ dst_base,
                                                          uint8_t *__restrict__ ws_base, uint32_t debug)
@@ -44,12 +44,13 @@ __global__ void __launch_bounds__(64, WPS) zstd_frames_kernel(const ZFrameJob *_
     // the three small frequency tables of the price model (121 words per frame) live in LDS: the price loops look them up for
     // every candidate length; an odd stride keeps the lanes of a wave on different banks for equal indices
     extern __shared__ uint32_t zs_lds[];
-    uint32_t *const fast = zs_lds + threadIdx.x * zs::FAST_FREQ_WORDS;
-    out_size[jb.idx] = zs::compressFrame<USE_LDS>(ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, false, debug, fast);
+    uint32_t *const fast = zs_lds + threadIdx.x * (M_LDS ? zs::FAST_WORDS : zs::FAST_FREQ_WORDS);
+    out_size[jb.idx] = zs::compressFrame<USE_LDS, M_LDS>(ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, false, debug, fast);
 }
 
-template __global__ void zstd_frames_kernel<2, true>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
 template __global__ void zstd_frames_kernel<2, false>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
+// (the default: frequency tables and the first matches of a request in LDS)
+template __global__ void zstd_frames_kernel<2, true, true>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
 
 // frames (scattered, padded slots) -> one contiguous buffer in the caller's order
 __global__ void __launch_bounds__(256) zstd_gather_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, const uint64_t *__restrict__ dst_off,

@@ -56,7 +56,7 @@ def _my_sequences(H, data):
     return res
 
 
-@pytest.mark.parametrize("loop_nest", [0, 1])
+@pytest.mark.parametrize("loop_nest", [0, 1, 2])
 def test_frames_equal_libzstd(zs, oracle, loop_nest):
     """both forms of the parser: the micro-step loop the kernel runs (0) and the plain loop nest (1)"""
     bad = []

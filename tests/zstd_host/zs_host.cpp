@@ -55,6 +55,13 @@ uint32_t zs_host_compress2(const uint8_t *src, uint32_t n, const uint32_t *cpara
     CParams cp = {cparams7[0], cparams7[1], cparams7[2], cparams7[3], cparams7[4], cparams7[5], cparams7[6]};
     const WsLayout L = wsLayout(cp, n);
     std::vector<BYTE> ws(L.total, 0);
+    // loop_nest & 2: the micro-step parser with its tables split as on the device (small frequency tables and the first
+    // FAST_MATCHES matches of a request outside the workspace)
+    if (loop_nest & 2) {
+        std::vector<U32> fast(FAST_FREQ_WORDS, 0xDEADBEEFu); // (fast memory is not zeroed on the device either)
+        std::vector<Match> fm(FAST_MATCHES);
+        return compressFrame(ws.data(), cp, src, n, dst, false, 0, fast.data(), fm.data());
+    }
     return compressFrame(ws.data(), cp, src, n, dst, loop_nest != 0);
 }
 uint32_t zs_host_compress(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint8_t *dst)
