@@ -4,6 +4,10 @@
 #pragma once
 #include "compressor.h"
 #include "host_support.h"
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "archive_read.h"
 #include "reader.h"
 #include "../../../include/agc_hip.h"
@@ -350,20 +354,48 @@ inline void preprocess_raw_contig(bytes_t &ctg)
 // FASTA(.gz) reader with the reference's framing (src/core/genome_io.cpp:208-252): id = first
 // line minus its first character, body = every byte up to the next '>'.
 class FastaReader {
-    gzFile f = nullptr;
+    gzFile f = nullptr;   // gzip input (zlib inflates; also its transparent mode for anything that is not a regular plain file)
+    int fd = -1;          // plain regular file: read() straight into the block buffer, no zlib in between
+    uint64_t remaining = 0; // plain file: bytes not yet read (upper bound for the contig being read: the reserve hint)
     std::vector<uint8_t> buf;
     size_t pos = 0, filled = 0;
     bool fill()
     {
         pos = 0;
-        int r = gzread(f, buf.data(), (unsigned)buf.size());
-        filled = r > 0 ? (size_t)r : 0;
+        if (fd >= 0) {
+            ssize_t r;
+            do
+                r = ::read(fd, buf.data(), buf.size());
+            while (r < 0 && errno == EINTR);
+            filled = r > 0 ? (size_t)r : 0;
+            remaining -= std::min<uint64_t>(remaining, filled);
+        } else {
+            int r = gzread(f, buf.data(), (unsigned)buf.size());
+            filled = r > 0 ? (size_t)r : 0;
+        }
         return filled != 0;
     }
 
 public:
     bool open(const std::string &fn)
     {
+        close();
+        // a regular file that does not start with the gzip magic is read directly
+        struct stat st;
+        int h = ::open(fn.c_str(), O_RDONLY);
+        if (h >= 0 && fstat(h, &st) == 0 && S_ISREG(st.st_mode)) {
+            uint8_t magic[2] = {0, 0};
+            const ssize_t r = ::pread(h, magic, 2, 0);
+            if (!(r == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+                fd = h;
+                remaining = (uint64_t)st.st_size;
+                buf.resize(16 << 20);
+                pos = filled = 0;
+                return true;
+            }
+        }
+        if (h >= 0)
+            ::close(h);
         f = gzopen(fn.c_str(), "rb");
         if (!f)
             return false;
@@ -377,13 +409,16 @@ public:
         if (f)
             gzclose(f);
         f = nullptr;
+        if (fd >= 0)
+            ::close(fd);
+        fd = -1;
     }
     ~FastaReader() { close(); }
     bool read_contig_raw(std::string &id, bytes_t &ctg)
     {
         id.clear();
         ctg.clear();
-        if (!f)
+        if (!f && fd < 0)
             return false;
         for (;;) {
             if (pos >= filled && !fill())
@@ -395,6 +430,10 @@ public:
         }
         if (!id.empty())
             id.erase(id.begin());
+        // plain file: the contig cannot be longer than what is left of the file -- one allocation instead of a doubling series
+        // of ever larger copies (address space only: pages are touched as they are filled)
+        if (fd >= 0)
+            ctg.reserve((size_t)std::min<uint64_t>(remaining + (filled - pos), (uint64_t)512 << 20));
         for (;;) {
             if (pos >= filled && !fill())
                 break;
@@ -408,6 +447,8 @@ public:
             ctg.insert(ctg.end(), b, e);
             pos = filled;
         }
+        if (ctg.capacity() > 2 * ctg.size() + (1u << 20))
+            ctg.shrink_to_fit(); // (a file of many contigs: the hint was the rest of the file for each of them)
         return !id.empty() && !ctg.empty();
     }
 };
