@@ -2,6 +2,10 @@
 // (reader.cpp) and by the append mode of the compressor (compressor.cpp).  Header-only, host code.
 // Citations: file:line under the reference tree.
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <array>
 #include <cstdint>
@@ -63,11 +67,65 @@ struct Archive {
         uint64_t raw_size = 0;
         std::vector<Part> parts;
     };
-    bytes_t data;
+    // The file is mapped, not read: a query touches the footer and the parts it asks for, as the reference's reader does
+    // (archive.cpp:88-139 reads the footer, :378-402 one part at a time); pointers handed out stay valid until the archive goes.
+    struct Mapped {
+        const uint8_t *p = nullptr;
+        size_t n = 0;
+        bytes_t fallback; // (something that cannot be mapped: read whole)
+        bool mapped = false;
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+        const uint8_t *data() const { return p; }
+        uint8_t operator[](size_t i) const { return p[i]; }
+        void release()
+        {
+            if (mapped && p)
+                munmap((void *)p, n);
+            p = nullptr;
+            n = 0;
+            mapped = false;
+            fallback.clear();
+        }
+        bool open(const std::string &fn, bool map)
+        {
+            release();
+            const int fd = ::open(fn.c_str(), O_RDONLY);
+            if (fd < 0)
+                return false;
+            struct stat st;
+            if (map && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    p = (const uint8_t *)m;
+                    n = (size_t)st.st_size;
+                    mapped = true;
+                    ::close(fd);
+                    return true;
+                }
+            }
+            uint8_t tmp[1 << 16];
+            for (;;) {
+                const ssize_t r = ::read(fd, tmp, sizeof(tmp));
+                if (r <= 0)
+                    break;
+                fallback.insert(fallback.end(), tmp, tmp + r);
+            }
+            ::close(fd);
+            p = fallback.data();
+            n = fallback.size();
+            return true;
+        }
+        Mapped() = default;
+        Mapped(const Mapped &) = delete;
+        Mapped &operator=(const Mapped &) = delete;
+        ~Mapped() { release(); }
+    };
+    Mapped data;
     std::vector<Stream> streams;
     std::unordered_map<std::string, int> ids;
 
-    static bool num(const bytes_t &d, uint64_t &p, uint64_t &v)
+    static bool num(const Mapped &d, uint64_t &p, uint64_t &v)
     {
         if (p >= d.size())
             return false;
@@ -79,18 +137,10 @@ struct Archive {
             v = (v << 8) | d[p++];
         return true;
     }
-    bool open(const std::string &fn)
+    // map = false: the whole file is read (append: the output may replace the input file while its parts are still in use)
+    bool open(const std::string &fn, bool map = true)
     {
-        FILE *f = fopen(fn.c_str(), "rb");
-        if (!f)
-            return false;
-        fseek(f, 0, SEEK_END);
-        const long sz = ftell(f);
-        fseek(f, 0, SEEK_SET);
-        data.resize(sz > 0 ? (size_t)sz : 0);
-        const size_t rd = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);
-        fclose(f);
-        if (rd != data.size() || data.size() < 9)
+        if (!data.open(fn, map) || data.size() < 9)
             return false;
         uint64_t fs = 0;
         for (int i = 0; i < 8; ++i)

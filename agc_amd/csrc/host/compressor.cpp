@@ -223,7 +223,7 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         I.err("cannot dlopen libzstd (set AGC_ZSTD_LIB)");
         return false;
     }
-    if (!I.in_ar.open(in_archive_name)) {
+    if (!I.in_ar.open(in_archive_name, false)) {
         I.err("Cannot open archive " + in_archive_name);
         return false;
     }
