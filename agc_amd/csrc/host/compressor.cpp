@@ -693,8 +693,21 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     // HBM as it is, the kernels drop the line ends and map the letters); small ones -- and adaptive mode, which mines new
     // splitters from host copies -- are converted by the reading thread as before
     const uint64_t GPU_A1_MIN = I.adaptive ? ~0ull : (1ull << 20);
-    auto read_file = [GPU_A1_MIN](std::string path) {
+    const unsigned read_threads = std::max(1u, std::min(8u, no_threads / 2));
+    auto read_file = [GPU_A1_MIN, read_threads](std::string path) {
         FileData fd;
+        // a big plain file: mapped, cut and copied out by a few threads
+        static const uint64_t map_min = getenv("AGC_AMD_MAP_MIN") ? strtoull(getenv("AGC_AMD_MAP_MIN"), nullptr, 10) : (64ull << 20);
+        if (FastaReader::read_all_mapped(path, fd.ids, fd.contigs, read_threads, map_min)) {
+            fd.opened = true;
+            fd.raw.resize(fd.contigs.size());
+            for (size_t i = 0; i < fd.contigs.size(); ++i) {
+                fd.raw[i] = fd.contigs[i].size() >= GPU_A1_MIN;
+                if (!fd.raw[i])
+                    preprocess_raw_contig(fd.contigs[i]);
+            }
+            return fd;
+        }
         FastaReader fr;
         if (!fr.open(path))
             return fd;

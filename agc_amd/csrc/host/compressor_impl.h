@@ -6,6 +6,7 @@
 #include "host_support.h"
 #include <cerrno>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include "archive_read.h"
@@ -414,6 +415,98 @@ public:
         fd = -1;
     }
     ~FastaReader() { close(); }
+    // A big plain file at once: the file is mapped, its '>' positions are found and the contig bodies copied out by a few
+    // threads (one 3 Gbp assembly is one file: read as a stream it is one thread's work).  Same records as the loop over
+    // read_contig_raw below -- a record starts at the beginning of the file and at every '>' that is not inside a header line,
+    // its header ends at the first '\n' or '\r', reading stops at the first record without name or without body.
+    // false: not a plain regular file of at least min_size bytes (the caller reads it as a stream).
+    static bool read_all_mapped(const std::string &fn, std::vector<std::string> &ids, std::vector<bytes_t> &ctgs, unsigned n_threads,
+                                uint64_t min_size)
+    {
+        const int h = ::open(fn.c_str(), O_RDONLY);
+        if (h < 0)
+            return false;
+        struct stat st;
+        if (fstat(h, &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t)st.st_size < std::max<uint64_t>(min_size, 2)) {
+            ::close(h);
+            return false;
+        }
+        const size_t n = (size_t)st.st_size;
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, h, 0);
+        ::close(h);
+        if (m == MAP_FAILED)
+            return false;
+        const uint8_t *d = (const uint8_t *)m;
+        if (d[0] == 0x1f && d[1] == 0x8b) { // gzip
+            munmap(m, n);
+            return false;
+        }
+        (void)madvise(m, n, MADV_SEQUENTIAL);
+        n_threads = std::max(1u, std::min(n_threads, 16u));
+        // 1. the '>' positions, range by range
+        std::vector<std::vector<size_t>> gt_part(n_threads);
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < n_threads; ++t)
+                th.emplace_back([&, t] {
+                    const size_t b = n * t / n_threads, e = n * (t + 1) / n_threads;
+                    for (size_t p = b; p < e;) {
+                        const uint8_t *q = (const uint8_t *)memchr(d + p, '>', e - p);
+                        if (!q)
+                            break;
+                        gt_part[t].push_back((size_t)(q - d));
+                        p = (size_t)(q - d) + 1;
+                    }
+                });
+            for (auto &x : th)
+                x.join();
+        }
+        std::vector<size_t> gt;
+        for (auto &v : gt_part)
+            gt.insert(gt.end(), v.begin(), v.end());
+        // 2. the records
+        struct Rec {
+            size_t id_b, id_e, body_b, body_e;
+        };
+        std::vector<Rec> recs;
+        size_t gi = 0;
+        for (size_t s = 0; s < n;) {
+            size_t e = s;
+            while (e < n && d[e] != '\n' && d[e] != '\r')
+                ++e;
+            if (e >= n)
+                break; // (the header runs into the end of the file)
+            const size_t body_b = e + 1;
+            while (gi < gt.size() && gt[gi] < body_b)
+                ++gi;
+            const size_t next = gi < gt.size() ? gt[gi] : n;
+            if (e <= s + 1 || next <= body_b)
+                break; // no name or no body: the stream reader stops here too
+            recs.push_back({s + 1, e, body_b, next});
+            s = next;
+        }
+        // 3. names and bodies
+        ids.resize(recs.size());
+        ctgs.resize(recs.size());
+        {
+            std::atomic<size_t> next_rec{0};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < std::min<size_t>(n_threads, std::max<size_t>(recs.size(), 1)); ++t)
+                th.emplace_back([&] {
+                    for (;;) {
+                        const size_t i = next_rec.fetch_add(1);
+                        if (i >= recs.size())
+                            break;
+                        ids[i].assign((const char *)d + recs[i].id_b, recs[i].id_e - recs[i].id_b);
+                        ctgs[i].assign(d + recs[i].body_b, d + recs[i].body_e);
+                    }
+                });
+            for (auto &x : th)
+                x.join();
+        }
+        munmap(m, n);
+        return true;
+    }
     bool read_contig_raw(std::string &id, bytes_t &ctg)
     {
         id.clear();

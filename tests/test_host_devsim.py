@@ -127,6 +127,47 @@ def test_pool_paths_of_the_host_stages_give_the_same_archive(cli, name, tmp_path
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_shuffled", "syn_c4_twin", "syn_viral"])
+def test_mapped_reader_gives_the_same_archive(cli, name, tmp_path, monkeypatch):
+    """AGC_AMD_MAP_MIN=1: every plain input file goes through the mapped, multi-threaded reader big assemblies get"""
+    monkeypatch.setenv("AGC_AMD_MAP_MIN", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
+def test_mapped_and_stream_reader_agree_on_odd_files(cli, tmp_path, monkeypatch):
+    """CR LF line ends, '>' inside a header line, a header without body at the end, no line end after the last base,
+    lower case: the mapped reader must cut the same records as the stream reader"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+
+    def seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    ref = seq(40000)
+    body = [ref[i:i + 70] for i in range(0, len(ref), 70)]
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "ref.fa").write_text(">r1 desc >not a record\r\n" + "\r\n".join(body) + "\r\n>r2\n" + seq(9000) + "\n")
+    mut = list(ref)
+    for p in rng.integers(0, len(mut), 60):
+        mut[int(p)] = "ACGT"[(("ACGT".index(mut[int(p)])) + 1) % 4]
+    m = "".join(mut).lower()
+    (d / "s1.fa").write_text(">r1\n" + "\n".join(m[i:i + 61] for i in range(0, len(m), 61)) + "\n>r2 x\n" + seq(5000))  # (no final newline)
+    (d / "s2.fa").write_text(">r1\n" + m[:20000] + "\n>\n" + seq(100) + "\n>r9\n" + seq(3000) + "\n")  # ('>' alone: reading stops)
+    files = [str(d / "ref.fa"), str(d / "s1.fa"), str(d / "s2.fa")]
+    args = ["-k", "21", "-l", "17", "-s", "2000", "-b", "3"]
+    a = _create(cli, args, files, str(tmp_path / "stream.agc"))
+    monkeypatch.setenv("AGC_AMD_MAP_MIN", "1")
+    b = _create(cli, args, files, str(tmp_path / "mapped.agc"))
+    assert a == b
+    ref_agc = os.path.join(ROOT, "oracle", "_ref", "agc")
+    if os.path.exists(ref_agc):  # (this container: the reference CLI reads the same records)
+        subprocess.run([ref_agc, "create"] + args + ["-t", "2", "-o", str(tmp_path / "ref.agc")] + files, check=True, capture_output=True, timeout=120)
+        assert open(tmp_path / "ref.agc", "rb").read() == a
+
+
 def test_host_pipeline_is_thread_independent(cli, tmp_path):
     args, _ = C.CONFIGS["syn_adaptive"]
     files = C.build("syn_adaptive", str(tmp_path / "in"))
