@@ -125,33 +125,52 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     I.created = true;
 
     if (!reference_file_name.empty()) {
-        FastaReader fr;
-        if (!fr.open(reference_file_name)) {
-            I.err("Cannot open file: " + reference_file_name);
-            I.created = false;
-            return false;
-        }
+        // the reference file: big plain files through the mapped reader; contigs of 1 MiB and more are converted to symbol
+        // codes on the GPU on their way in (agc_hip_preprocess = preprocess_raw_contig, agc_compressor.cpp:907-951), like the
+        // samples' (AddSampleFiles)
         std::vector<bytes_t> ref;
-        std::string id;
-        bytes_t c;
-        uint64_t tot = 0;
-        while (fr.read_contig_raw(id, c)) {
-            preprocess_raw_contig(c);
-            tot += c.size();
-            ref.emplace_back(std::move(c));
-            c.clear();
+        {
+            std::vector<std::string> ids;
+            static const uint64_t map_min = getenv("AGC_AMD_MAP_MIN") ? strtoull(getenv("AGC_AMD_MAP_MIN"), nullptr, 10) : (64ull << 20);
+            if (!FastaReader::read_all_mapped(reference_file_name, ids, ref, std::max(1u, std::min(8u, nt)), map_min)) {
+                FastaReader fr;
+                if (!fr.open(reference_file_name)) {
+                    I.err("Cannot open file: " + reference_file_name);
+                    I.created = false;
+                    return false;
+                }
+                std::string id;
+                bytes_t c;
+                while (fr.read_contig_raw(id, c)) {
+                    ref.emplace_back(std::move(c));
+                    c.clear();
+                }
+            }
         }
+        uint64_t tot_raw = 0;
+        for (auto &c : ref)
+            tot_raw += c.size();
         // determine_splitters on the GPU: contigs go to HBM back to back, k-mers are enumerated, radix
         // sorted and reduced to singletons there (include/agc_hip.h: agc_hip_determine_splitters_dev)
         uint8_t *d_ref = nullptr;
-        if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, tot, &d_ref)), "sample_buffer"))
+        if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, tot_raw, &d_ref)), "sample_buffer"))
             return false;
         std::vector<uint64_t> off(ref.size() + 1, 0);
         for (size_t i = 0; i < ref.size(); ++i) {
-            if (!I.hip_ok(DEVTI(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size())), "copy_to_device"))
-                return false;
-            off[i + 1] = off[i] + ref[i].size();
+            uint64_t n_codes = 0;
+            if (ref[i].size() >= (1ull << 20)) {
+                if (!I.hip_ok(DEVTI(agc_hip_preprocess(I.hip, ref[i].data(), ref[i].size(), d_ref + off[i], &n_codes)), "preprocess"))
+                    return false;
+            } else {
+                preprocess_raw_contig(ref[i]);
+                n_codes = ref[i].size();
+                if (!I.hip_ok(DEVTI(agc_hip_copy_to_device(I.hip, d_ref + off[i], ref[i].data(), ref[i].size())), "copy_to_device"))
+                    return false;
+            }
+            off[i + 1] = off[i] + n_codes;
+            bytes_t().swap(ref[i]); // (the host copy is not needed any more)
         }
+        const uint64_t tot = off[ref.size()];
         std::vector<uint64_t> spl(std::max<uint64_t>(1024, tot / std::max(1u, I.segment_size) * 2 + 2 * ref.size() + 16));
         std::vector<uint64_t> sorted_kmers(I.adaptive ? tot : 0);
         uint64_t n_spl = 0, n_sorted = 0;
