@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagc_hip.so")
 SOURCES = ["api.hip", "scan_kernels.hip", "lz_kernels.hip", "splitters.hip", "zstd_kernels.hip", "dev_common.h",
-           "zstd/zs_common.h", "zstd/zs_opt.h", "zstd/zs_opt_sm.h", "zstd/zs_entropy.h", "zstd/zs_frame.h", "zstd/zs_params.h"]
+           "zstd/zs_common.h", "zstd/zs_opt.h", "zstd/zs_opt_sm.h", "zstd/zs_opt_grp.h", "zstd/zs_entropy.h", "zstd/zs_frame.h", "zstd/zs_params.h"]
 
 
 def _stale():

@@ -1570,9 +1570,33 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             ++m;
         }
         CHK(ensure_z(c, c->d_zws, used));
+        // the frames of this launch: first the ones the one-lane kernel takes, then the ones a group of lanes takes
+        // (zstd/zs_opt_grp.h: inputs of the btultra2 class, <= 16 KiB -- every delta pack of a collection below ~35 samples)
+        uint32_t grp_g = c->zstd_background ? 0u : 3u;
+        if (const char *e = getenv("AGC_HIP_ZSTD_GROUP"))
+            grp_g = (uint32_t)std::min(3, std::max(0, atoi(e)));
+        if (grp_g == 1)
+            grp_g = 0;
+        std::vector<uint32_t> part;
+        part.reserve(m);
+        uint32_t m_one = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t i = order[done + t];
+                const bool grp = grp_g && zs::grpEligible(jobs[i].cp, jobs[i].src_size);
+                if (grp == (pass == 1))
+                    part.push_back(i);
+            }
+        for (uint32_t t = 0; t < m; ++t)
+            m_one += !(grp_g && zs::grpEligible(jobs[part[t]].cp, jobs[part[t]].src_size));
+        const uint32_t m_grp = m - m_one;
+        // every wave of a launch should be resident at once (a second round lasts as long as the first): 7 waves of 21 groups of
+        // 3 lanes fit a CU's LDS, 5 waves of 32 pairs
+        if (grp_g == 3 && !getenv("AGC_HIP_ZSTD_GROUP") && m_grp > 7u * 256u * 21u && m_grp <= 5u * 256u * 32u)
+            grp_g = 2;
         used = 0;
         for (uint32_t t = 0; t < m; ++t) {
-            const uint32_t i = order[done + t];
+            const uint32_t i = part[t];
             ZFrameJob jb = jobs[i];
             jb.src = h_src_off[i] - h_src_off[0];
             jb.dst = dst_o[i];
@@ -1585,27 +1609,41 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                                  zs_));
         {
             ZTimer t(c);
-            // frames per wave: fewer = fewer distinct parser states per trip of the micro-step loop, but every wave of the
-            // launch must be resident at once (2 per SIMD = 2048 on 256 CUs) or the launch takes two rounds.  Measured per
-            // 36 k frames of 13 KB: 24 lanes 1.31 s, 32 lanes 1.35 s, 48 lanes 1.38 s, 64 lanes 1.48 s, 16 lanes (two rounds) 1.82 s
-            uint32_t lanes = 64; // (background launches: as few waves as possible, the other streams' kernels need the slots)
-            if (!c->zstd_background)
-                for (uint32_t cand : {24u, 32u, 48u})
-                    if ((m + cand - 1) / cand <= 1900) {
-                        lanes = cand;
-                        break;
-                    }
-            if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
-                lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
             const uint32_t dbg = (uint32_t)(getenv("AGC_HIP_ZSTD_DEBUG") ? atoi(getenv("AGC_HIP_ZSTD_DEBUG")) : 0);
-            const dim3 grid((m + lanes - 1) / lanes), block(64);
-            const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
-            if (c->zstd_background)
-                hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs_, dj, m, (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p,
-                                   (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
-            else // (frequency tables and the first matches of a request in LDS)
-                hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs_, dj, m, (uint32_t *)c->d_zsize.p,
-                                   lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+            const dim3 block(64);
+            if (m_one) {
+                // frames per wave: fewer = fewer distinct parser states per trip of the micro-step loop, but every wave of the
+                // launch must be resident at once (2 per SIMD = 2048 on 256 CUs) or the launch takes two rounds.  Measured per
+                // 36 k frames of 13 KB: 24 lanes 1.31 s, 32 lanes 1.35 s, 48 lanes 1.38 s, 64 lanes 1.48 s, 16 lanes (two rounds) 1.82 s
+                uint32_t lanes = 64; // (background launches: as few waves as possible, the other streams' kernels need the slots)
+                if (!c->zstd_background)
+                    for (uint32_t cand : {24u, 32u, 48u})
+                        if ((m_one + cand - 1) / cand <= 1900) {
+                            lanes = cand;
+                            break;
+                        }
+                if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
+                    lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
+                const dim3 grid((m_one + lanes - 1) / lanes);
+                const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
+                if (c->zstd_background)
+                    hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs_, dj, m_one, (uint32_t *)c->d_zsize.p, lanes,
+                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+                else // (frequency tables and the first matches of a request in LDS)
+                    hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs_, dj, m_one,
+                                       (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+            }
+            if (m_grp) {
+                const uint32_t gpw = 64 / grp_g; // groups (= frames) per wave
+                const dim3 grid((m_grp + gpw - 1) / gpw);
+                const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done + m_one;
+                if (grp_g == 2)
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<2, 2>), grid, block, zgrp_lds_bytes(gpw), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
+                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+                else
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
+                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+            }
         }
         HIPCHK(c, hipGetLastError());
         done += m;

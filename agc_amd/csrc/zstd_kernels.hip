@@ -52,6 +52,38 @@ template __global__ void zstd_frames_kernel<2, false>(const ZFrameJob *, uint32_
 // (the default: frequency tables and the first matches of a request in LDS)
 template __global__ void zstd_frames_kernel<2, true, true>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
 
+
+// ---- several lanes per frame (zstd/zs_opt_grp.h): G consecutive lanes = one group = one frame ----
+// LDS per wave: per group the exchange record + the three small frequency tables, per lane the record of a tree walk.
+constexpr uint32_t ZGRP_STRIDE = (zs::GRPX_WORDS + zs::FAST_FREQ_WORDS) | 1; // words per group (odd: neighbouring groups on different banks)
+constexpr uint32_t ZGRP_REC_STRIDE = zs::GRP_RC | 1;                          // words per lane
+__host__ __device__ static inline uint32_t zgrp_lds_bytes(uint32_t groups_per_wave) { return (groups_per_wave * ZGRP_STRIDE + 64 * ZGRP_REC_STRIDE) * 4; }
+
+template <int G, int WPS>
+__global__ void __launch_bounds__(64, WPS) zstd_frames_grp_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
+                                                                 uint32_t groups_per_wave, const uint8_t *__restrict__ src_base,
+                                                                 uint8_t *__restrict__ dst_base, uint8_t *__restrict__ ws_base, uint32_t debug)
+{
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    if (grp >= groups_per_wave)
+        return;
+    const uint32_t job = blockIdx.x * groups_per_wave + grp;
+    if (job >= n_jobs)
+        return;
+    extern __shared__ uint32_t zs_lds[];
+    uint32_t *const gbase = zs_lds + grp * ZGRP_STRIDE;
+    zs::GrpX &sh = *(zs::GrpX *)gbase;
+    zs::GLane l;
+    l.j = j;
+    l.recs = (zs::ZS_LDS_U32P)(zs_lds + groups_per_wave * ZGRP_STRIDE + threadIdx.x * ZGRP_REC_STRIDE);
+    const ZFrameJob jb = jobs[job];
+    const uint32_t n = zs::compressFrameGrp<G>(&l, sh, ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, debug, gbase + zs::GRPX_WORDS);
+    if (j == 0)
+        out_size[jb.idx] = n;
+}
+template __global__ void zstd_frames_grp_kernel<2, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
+template __global__ void zstd_frames_grp_kernel<3, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
+
 // frames (scattered, padded slots) -> one contiguous buffer in the caller's order
 __global__ void __launch_bounds__(256) zstd_gather_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, const uint64_t *__restrict__ dst_off,
                                                           const uint8_t *__restrict__ dst_base, uint8_t *__restrict__ out)

@@ -24,6 +24,26 @@ def test_gpu_frames_equal_libzstd(hip_ctx, oracle, background):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("group", [0, 2, 3])
+def test_gpu_group_kernels_equal_libzstd(hip_ctx, oracle, group):
+    """the kernels with several lanes per frame (zstd/zs_opt_grp.h; 3 = the default, 2, and 0 = the one-lane kernel only) on the
+    inputs they take (<= 16 KiB) mixed with ones they leave to the one-lane kernel"""
+    import os
+    if ZC.libzstd().ZSTD_versionNumber() != 10409:
+        pytest.skip("parity is pinned against libzstd 1.4.9")
+    rng = np.random.default_rng(40 + group)
+    inputs = ZC.corpus(oracle, 555 + group, 300, max_len=16384) + ZC.corpus(oracle, 9, 40)
+    inputs += [ZC.delta_pack(oracle, rng, n, 60000, 1e-3)[:16384] for n in (5, 25, 25, 30)]
+    inputs += [b"A" * 9000, b"AB" * 4000, b"ABC" * 3000, (b"0,1234.C" * 40 + b"!!!!!!!!!!!!") * 30]
+    os.environ["AGC_HIP_ZSTD_GROUP"] = str(group)
+    try:
+        got = hip_ctx.zstd17_batch(inputs)
+    finally:
+        del os.environ["AGC_HIP_ZSTD_GROUP"]
+    bad = [(i, len(p)) for i, p in enumerate(inputs) if got[i] != ZC.ref_frame(p)]
+    assert not bad, bad
+
+
 def test_gpu_many_equal_size_packs(hip_ctx, oracle):
     """the shape Close() produces: thousands of packs of similar size in one call (several workspace-arena rounds when the
     arena is small)"""

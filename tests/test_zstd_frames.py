@@ -20,6 +20,8 @@ def zs():
     H.zs_host_compress.restype = C.c_uint32
     H.zs_host_compress2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
     H.zs_host_compress2.restype = C.c_uint32
+    H.zs_host_compress_grp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    H.zs_host_compress_grp.restype = C.c_uint32
     return H
 
 
@@ -28,6 +30,14 @@ def _my_frame(H, data, loop_nest=0):
     cp = np.array(ZC.ref_cparams(n), np.uint32)
     out = np.zeros(n + 64, np.uint8)
     k = H.zs_host_compress2(bytes(data), n, cp.ctypes.data, out.ctypes.data, loop_nest)
+    return out[:k].tobytes()
+
+
+def _my_frame_grp(H, data, g):
+    n = len(data)
+    cp = np.array(ZC.ref_cparams(n), np.uint32)
+    out = np.zeros(n + 64, np.uint8)
+    k = H.zs_host_compress_grp(bytes(data), n, cp.ctypes.data, out.ctypes.data, g)
     return out[:k].tobytes()
 
 
@@ -63,6 +73,29 @@ def test_frames_equal_libzstd(zs, oracle, loop_nest):
     for i, p in enumerate(ZC.corpus(oracle, 2024, 160)):
         if _my_frame(zs, p, loop_nest) != ZC.ref_frame(p):
             bad.append((i, len(p)))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("g", [1, 2, 3])
+def test_group_parser_frames_equal_libzstd(zs, oracle, g):
+    """zs_opt_grp.h: g lanes per frame on consecutive positions, recorded tree walks committed after an in-order validation
+    (the host build runs every segment of a trip for lane 0..g-1 in turn); g = 1 is the same code with the leader alone"""
+    bad = []
+    for i, p in enumerate(ZC.corpus(oracle, 777 + g, 120, max_len=16384)):
+        if _my_frame_grp(zs, p, g) != ZC.ref_frame(p):
+            bad.append((i, len(p)))
+    rng = np.random.default_rng(g)
+    for n_samp in (3, 11, 25, 31):  # the packs of a Close(): n_samp deltas of one group
+        p = ZC.delta_pack(oracle, rng, n_samp, 60000, 1e-3)[:16384]
+        if _my_frame_grp(zs, p, g) != ZC.ref_frame(p):
+            bad.append(("pack", n_samp, len(p)))
+    # anomalies on purpose: runs (equal hash buckets in a row, matches running to the end of the block), long repeats
+    # (immediate encoding, skipped areas), a pattern with a period below minMatch
+    for p in (b"A" * 9000, b"AB" * 4000, b"ABC" * 3000, (b"0,1234.C" * 40 + b"!!!!!!!!!!!!" ) * 30, bytes(rng.integers(65, 69, 6000, dtype=np.uint8)) * 2,
+              b"".join(bytes([65 + (i * 7) % 23]) * (1 + i % 9) for i in range(3000))):
+        p = p[:16384]
+        if _my_frame_grp(zs, p, g) != ZC.ref_frame(p):
+            bad.append(("special", len(p)))
     assert not bad, bad
 
 

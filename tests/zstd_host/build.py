@@ -13,9 +13,9 @@ LIB = os.path.join(OUT, "libzs_host.so")
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(HERE, "zs_host.cpp")
-    deps = [src] + [os.path.join(ROOT, "agc_amd", "csrc", "zstd", h) for h in ("zs_common.h", "zs_opt.h", "zs_opt_sm.h", "zs_entropy.h", "zs_frame.h")]
+    deps = [src] + [os.path.join(ROOT, "agc_amd", "csrc", "zstd", h) for h in ("zs_common.h", "zs_opt.h", "zs_opt_sm.h", "zs_opt_grp.h", "zs_entropy.h", "zs_frame.h")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", LIB])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", src, "-o", LIB])
     return LIB
 
 

@@ -83,3 +83,31 @@ void zs_host_code_tables(uint32_t *ll_bits36, uint32_t *ml_bits53, uint32_t *ll_
     for (uint32_t m = 0; m < 128; ++m) ml_code128[m] = MLcode(m);
 }
 }
+
+extern "C" {
+// the group parser (zs_opt_grp.h) run the host way: G lane states, every segment of the trip for lane 0..G-1 in turn -- the
+// same code the kernel runs with one lane state per GPU lane and the exchange record in LDS.  Inputs the group path does not
+// take (grpEligible) go through the one-lane parser, as in the kernel's dispatch.
+uint32_t zs_host_compress_grp(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint8_t *dst, int G)
+{
+    CParams cp = {cparams7[0], cparams7[1], cparams7[2], cparams7[3], cparams7[4], cparams7[5], cparams7[6]};
+    const WsLayout L = wsLayout(cp, n);
+    std::vector<BYTE> ws(L.total, 0);
+    if (!grpEligible(cp, n))
+        return compressFrame(ws.data(), cp, src, n, dst);
+    std::vector<GLane> lanes(3);
+    std::vector<U32> recs(3 * GRP_RC, 0xDEADBEEFu);
+    memset((void *)lanes.data(), 0xA5, sizeof(GLane) * 3); // (lane state is not zeroed on the device either)
+    for (int i = 0; i < 3; ++i) {
+        lanes[i].j = (U32)i;
+        lanes[i].recs = recs.data() + (size_t)i * GRP_RC;
+    }
+    GrpX sh;
+    memset(&sh, 0xA5, sizeof(sh));
+    switch (G) {
+    case 1: return compressFrameGrp<1>(lanes.data(), sh, ws.data(), cp, src, n, dst);
+    case 2: return compressFrameGrp<2>(lanes.data(), sh, ws.data(), cp, src, n, dst);
+    default: return compressFrameGrp<3>(lanes.data(), sh, ws.data(), cp, src, n, dst);
+    }
+}
+}
