@@ -32,7 +32,7 @@ SYMBOLS = [
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
     "agc_hip_ref_lag_counts_dev",
-    "agc_hip_zstd17_max_input", "agc_hip_zstd17_batch", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams",
+    "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams",
     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
 ]
 
@@ -114,6 +114,8 @@ def load():
     L.agc_hip_zstd17_cparams.argtypes = [C.c_uint64, u32p]
     L.agc_hip_zstd17_background.argtypes = [vp, C.c_int]
     L.agc_hip_zstd17_max_input.restype = C.c_uint32
+    L.agc_hip_zstd17_resident_frames.argtypes = [vp]
+    L.agc_hip_zstd17_resident_frames.restype = C.c_uint32
     L.agc_hip_packed_words_bytes.restype = C.c_uint64
     L.agc_hip_packed_words_bytes.argtypes = [C.c_uint64]
     L.agc_hip_packed_index_bytes.restype = C.c_uint64
@@ -123,7 +125,7 @@ def load():
     L.agc_hip_scan_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     for s in SYMBOLS:
         f = getattr(L, s)
-        if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count", "agc_hip_zstd17_max_input",
+        if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count", "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames",
                      "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes"):
             f.restype = C.c_int
     _lib = L

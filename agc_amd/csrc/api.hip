@@ -1499,6 +1499,17 @@ int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
     return AGC_HIP_OK;
 }
 
+uint32_t agc_hip_zstd17_resident_frames(agc_hip_ctx *c)
+{
+    if (!c)
+        return 0;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0)
+        return 0;
+    // groups of 3 lanes: 21 frames per wave; 8 waves per CU (LDS: zgrp_lds_bytes(21, 3) = 20 328 of 160 KiB / 8; registers: 2 per SIMD)
+    return (uint32_t)cus * 8u * 21u;
+}
+
 int agc_hip_zstd17_background(agc_hip_ctx *c, int on)
 {
     if (!c)
@@ -1590,10 +1601,6 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
         for (uint32_t t = 0; t < m; ++t)
             m_one += !(grp_g && zs::grpEligible(jobs[part[t]].cp, jobs[part[t]].src_size));
         const uint32_t m_grp = m - m_one;
-        // every wave of a launch should be resident at once (a second round lasts as long as the first): 7 waves of 21 groups of
-        // 3 lanes fit a CU's LDS, 5 waves of 32 pairs
-        if (grp_g == 3 && !getenv("AGC_HIP_ZSTD_GROUP") && m_grp > 7u * 256u * 21u && m_grp <= 5u * 256u * 32u)
-            grp_g = 2;
         used = 0;
         for (uint32_t t = 0; t < m; ++t) {
             const uint32_t i = part[t];
@@ -1638,10 +1645,10 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                 const dim3 grid((m_grp + gpw - 1) / gpw);
                 const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done + m_one;
                 if (grp_g == 2)
-                    hipLaunchKernelGGL((zstd_frames_grp_kernel<2, 2>), grid, block, zgrp_lds_bytes(gpw), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<2, 2>), grid, block, zgrp_lds_bytes(gpw, 2), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
                                        (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
                 else
-                    hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw, 3), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
                                        (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             }
         }

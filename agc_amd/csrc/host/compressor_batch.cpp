@@ -173,9 +173,12 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         };
         std::vector<uint32_t> by_size(dev_jobs);
         std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return chain(a) < chain(b); });
+        // (and never more frames than the device works on at once: a frame is a serial chain, a second round of a launch lasts
+        // as long as the first)
+        const uint32_t resident = std::max<uint32_t>(1u, agc_hip_zstd17_resident_frames(hip));
         std::vector<uint32_t> keep;
         for (uint32_t i : by_size) {
-            if ((double)dev_acc < gpu_zstd_share * (double)total) {
+            if ((double)dev_acc < gpu_zstd_share * (double)total && keep.size() < resident) {
                 keep.push_back(i);
                 dev_acc += jobs[i].data.size();
             } else

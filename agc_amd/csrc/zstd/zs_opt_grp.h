@@ -30,7 +30,7 @@ static unsigned long long g_grp_trips, g_grp_valid[4], g_grp_plan[4];
 #endif
 constexpr U32 GRP_MAX = 3;   // lanes per group the exchange record is sized for (= minMatch of the bt* levels <= 17)
 constexpr U32 GRP_MC = 6;    // matches of a request a lane keeps in registers (99.9 % of the requests have <= 5)
-constexpr U32 GRP_RC = 20;   // tree stores a walk may record: 18 levels + the two closing zeros (99.9 % of the walks)
+constexpr U32 GRP_RC = 16;   // tree stores a walk may record: 14 levels + the two closing zeros (99.5 % of the walks)
 constexpr U32 GRP_PT = 8;    // price targets per trip
 #ifndef ZS_GRP_WALK_LEVELS
 #define ZS_GRP_WALK_LEVELS 12
@@ -50,16 +50,17 @@ enum { GS_OK = 0, GS_ANOMALY = 1 };
 
 // what the lanes of one group tell each other (one record per group; device: LDS)
 struct GrpX {
-    U32 g;             // lanes taking part in the trip that starts now (0: none)
+    U32 g;             // bits 0-7: lanes taking part in the trip that starts now (0: none); bit 8 ("plain"): the leader's position can
+                       // go the group way (no skipped positions to insert first)
     U32 done;          // the leader has finished the block
-    U32 plain0;        // the leader's position can go the group way (no skipped positions to insert first)
     U32 cur, last_pos, ip;
-    U32 pend_n, pend_h3[2]; // positions the leader has just put into the hash-3 table (q0 - pend_n ...), and their hashes
+    U32 pend_n, pend_h3;    // the position the leader has just put into the hash-3 table (q0 - 1, if pend_n), and its hash
     U32 priceType, litSumBP, llSumBP, mlSumBP, ocSumBP; // the price model's bases (change when a chunk has been stored)
     int oc_price;      // literal chain: the entry of the lane in front
     U32 oc_mlen, oc_litlen, oc_rep[3];
     U32 h[GRP_MAX], h3[GRP_MAX];
-    U32 wdone[GRP_MAX], status[GRP_MAX], nbm[GRP_MAX], maxML[GRP_MAX], maxOff[GRP_MAX], mEnd[GRP_MAX], qlit[GRP_MAX], litback[GRP_MAX];
+    U32 wdone[GRP_MAX]; // 0: the lane's walk is under way, 1: finished, 2: finished as an anomaly (GS_ANOMALY + 1)
+    U32 nbm[GRP_MAX], maxML[GRP_MAX], maxOff[GRP_MAX], mEnd[GRP_MAX], qlit[GRP_MAX], litback[GRP_MAX];
     int cand[GRP_MAX][GRP_PT];
 };
 constexpr U32 GRPX_WORDS = (sizeof(GrpX) / 4) | 1; // odd stride in LDS: equal fields of neighbouring groups on different banks
@@ -93,6 +94,8 @@ struct GLane {
     // store loop
     U32 storePos, storeEnd;
     U64 p8;            // the 8 source bytes at the position being worked on
+    U64 p8hi;          // ... and the 8 behind them (group lanes: a walk's first levels compare inside these 16)
+    bool p16;          // p8hi holds them
     U32 p8_pos;
     // group trip
     U32 g, g_cur, g_v, g_lp0, tcur, t1;
@@ -187,7 +190,11 @@ ZFN void grpWalkIssue(GLane &l, const BYTE *src, const BYTE *iend, const U32 *bt
         if (p + 8 <= iend) {
             l.wk_pair = *(const U64 *)(bt + 2 * (l.matchIndex & btMask));
             l.wk_mb = read64(src + (l.matchIndex - l.w.idx0) + ml0);
-            l.wk_pb = read64(p);
+            if (l.p16 && ml0 <= 8 && l.p8_pos == l.wk_current - l.w.idx0) { // the position's bytes ml0 .. ml0 + 7: already in registers
+                const U32 sh = ml0 * 8;
+                l.wk_pb = sh == 0 ? l.p8 : (sh == 64 ? l.p8hi : ((l.p8 >> sh) | (l.p8hi << (64 - sh))));
+            } else
+                l.wk_pb = read64(p);
             l.wk_pre = true;
         }
     }
@@ -536,6 +543,8 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
     l.gstatus = GS_OK;
     l.p8 = 0;
     l.p8_pos = 0xFFFFFFFFu;
+    l.p16 = false;
+    l.wk_pre = false;
     l.adv = 1;
     l.g = 0;
     l.lastSequence.price = 0;
@@ -605,7 +614,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             const U32 q0 = inr0 + w.idx0;
             U32 g = 1;
             bool plain0 = grpOk && inr0 <= ilimit_off && l.cur < l.last_pos && w.nextToUpdate == q0 && l.nextToUpdate3 <= q0 &&
-                          q0 - l.nextToUpdate3 <= 2;
+                          q0 - l.nextToUpdate3 <= 1;
             if (plain0) {
                 while (g < gmax && l.cur + g < l.last_pos && inr0 + g <= ilimit_off)
                     ++g;
@@ -617,12 +626,11 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     const U32 idx = l.nextToUpdate3 + t;
                     const U32 hh = hash3(read32(src + (idx - w.idx0)), w.hashLog3);
                     w.hashTable3[hh] = idx;
-                    sh.pend_h3[t] = hh;
+                    sh.pend_h3 = hh;
                 }
                 l.nextToUpdate3 = q0;
             }
-            sh.g = g;
-            sh.plain0 = plain0;
+            sh.g = g | (plain0 ? 256u : 0u);
             sh.cur = l.cur;
             sh.last_pos = l.last_pos;
             sh.ip = l.ip;
@@ -636,6 +644,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             }
             l.p8 = read64(src + l.ip); // (ip < srcSize - 8)
             l.p8_pos = l.ip;
+            l.p16 = false;
             l.q_litlen = l.ip - l.anchor;
             l.q_ll0 = !l.q_litlen;
             l.q_current = l.ip + w.idx0;
@@ -646,14 +655,14 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             // the request of a chunk's first position goes the recorded-walk way as well (the leader alone), unless skipped
             // positions have to be inserted first
             const U32 q0 = l.q_current;
-            if (grpOk && w.nextToUpdate == q0 && l.nextToUpdate3 <= q0 && q0 - l.nextToUpdate3 <= 2) {
+            if (grpOk && w.nextToUpdate == q0 && l.nextToUpdate3 <= q0 && q0 - l.nextToUpdate3 <= 1) {
                 const U32 n = q0 - l.nextToUpdate3;
                 sh.pend_n = n;
                 for (U32 t = 0; t < n; ++t) {
                     const U32 idx = l.nextToUpdate3 + t;
                     const U32 hh = hash3(read32(src + (idx - w.idx0)), w.hashLog3);
                     w.hashTable3[hh] = idx;
-                    sh.pend_h3[t] = hh;
+                    sh.pend_h3 = hh;
                 }
                 l.nextToUpdate3 = q0;
                 l.g = 1;
@@ -667,8 +676,8 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
         Optimal *const opt = w.opt;
-        if (l.state == ST_F_IDLE && sh.g > l.j) { // a follower joins
-            l.g = sh.g;
+        if (l.state == ST_F_IDLE && (sh.g & 255u) > l.j) { // a follower joins
+            l.g = sh.g & 255u;
             l.cur = sh.cur;
             l.last_pos = sh.last_pos;
             l.ip = sh.ip;
@@ -680,6 +689,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             l.state = ST_G_BEGIN;
         }
         if (l.state == ST_G_FIRST) { // (leader) a chunk's first position: no price-table entry to finish, only the tables' answers
+            l.p16 = false;
             l.h = mls == 5 ? hash5(l.p8, cp.hashLog) : mls == 6 ? hash6(l.p8, cp.hashLog) : hash4((U32)l.p8, cp.hashLog);
             l.h3 = hash3((U32)l.p8, w.hashLog3);
             l.mi0 = w.hashTable[l.h];
@@ -696,9 +706,14 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 l.op = opt[l.g_cur - 1];
             const U32 lit_byte = src[inr - 1];
             const bool at = inr <= ilimit_off; // (a follower's position always is)
+            l.p16 = false;
             if (at) {
                 l.p8 = read64(src + inr);
                 l.p8_pos = inr;
+                if (inr + 16 <= srcSize) {
+                    l.p8hi = read64(src + inr + 8);
+                    l.p16 = true;
+                }
             }
             l.lit_freq = (w.priceType == zop_predef) ? 0 : w.litFreq[lit_byte];
             l.pr0 = l.pr1 = l.pr2 = 0;
@@ -711,7 +726,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 l.pr2 = opt[prev].rep[2];
             }
             l.h = l.h3 = l.mi0 = l.mi3 = 0;
-            if (at && sh.plain0) {
+            if (at && (sh.g >> 8)) {
                 l.h = mls == 5 ? hash5(l.p8, cp.hashLog) : mls == 6 ? hash6(l.p8, cp.hashLog) : hash4((U32)l.p8, cp.hashLog);
                 l.h3 = hash3((U32)l.p8, w.hashLog3);
                 l.mi0 = w.hashTable[l.h];
@@ -809,7 +824,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             l.q_rep1 = l.oc.rep[1];
             l.q_rep2 = l.oc.rep[2];
             l.inChunk = true;
-            if (!sh.plain0) { // (leader alone) the one-lane way
+            if (!(sh.g >> 8)) { // (leader alone) the one-lane way
                 l.state = ST_GETM_BEGIN;
                 break;
             }
@@ -820,9 +835,8 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             l.gstatus = GS_OK;
             // the hash-3 table's answer for this position: what the table held, then the positions the leader has just inserted,
             // then the trip's positions in front of this one (the latest position with the same hash wins)
-            for (U32 t = 0; t < sh.pend_n; ++t)
-                if (sh.pend_h3[t] == l.h3)
-                    l.mi3 = l.q_current - l.j - sh.pend_n + t;
+            if (sh.pend_n && sh.pend_h3 == l.h3)
+                l.mi3 = l.q_current - l.j - 1;
             for (U32 i = 0; i < l.j; ++i) {
                 if (sh.h3[i] == l.h3)
                     l.mi3 = l.q_current - l.j + i;
@@ -835,8 +849,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             l.rec = true;
             l.nrec = 0;
             if (l.gstatus != GS_OK) {
-                sh.status[l.j] = GS_ANOMALY;
-                sh.wdone[l.j] = 1;
+                sh.wdone[l.j] = 1 + GS_ANOMALY;
                 l.state = ST_G_WAIT;
             } else
                 l.state = ST_WALK;
@@ -917,14 +930,13 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             bool abort;
             if (grpWalkLevel<false>(l, src, iend, w.chainTable, btMask, abort)) {
                 if (l.rec) {
-                    sh.status[l.j] = abort ? GS_ANOMALY : GS_OK;
                     sh.nbm[l.j] = l.mnum;
                     sh.maxML[l.j] = l.last_m_len;
                     sh.maxOff[l.j] = l.last_m_off;
                     sh.mEnd[l.j] = l.matchEndIdx;
                     sh.qlit[l.j] = l.q_litlen;
                     sh.litback[l.j] = l.cur_litlen_back;
-                    sh.wdone[l.j] = 1;
+                    sh.wdone[l.j] = abort ? 1 + GS_ANOMALY : 1 + GS_OK;
                     l.nbMatches = l.mnum;
                     l.state = ST_G_WAIT;
                 } else {
@@ -950,7 +962,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             U32 v = 0, ntu = q0;
             int endLane = -1;
             for (U32 i = 0; i < l.g; ++i) {
-                if (sh.status[i] != GS_OK)
+                if (sh.wdone[i] != 1 + GS_OK)
                     break; // anomaly: this position and the ones behind it are redone
                 if (i > 0 && q0 + i < ntu)
                     break; // skipped area (a long match in front moved nextToUpdate past it)

@@ -57,7 +57,8 @@ template __global__ void zstd_frames_kernel<2, true, true>(const ZFrameJob *, ui
 // LDS per wave: per group the exchange record + the three small frequency tables, per lane the record of a tree walk.
 constexpr uint32_t ZGRP_STRIDE = (zs::GRPX_WORDS + zs::FAST_FREQ_WORDS) | 1; // words per group (odd: neighbouring groups on different banks)
 constexpr uint32_t ZGRP_REC_STRIDE = zs::GRP_RC | 1;                          // words per lane
-__host__ __device__ static inline uint32_t zgrp_lds_bytes(uint32_t groups_per_wave) { return (groups_per_wave * ZGRP_STRIDE + 64 * ZGRP_REC_STRIDE) * 4; }
+// (G = 3: 21 groups -> 20 328 bytes: EIGHT waves per CU (160 KiB), i.e. 43 008 frames of a launch resident at once)
+__host__ __device__ static inline uint32_t zgrp_lds_bytes(uint32_t groups_per_wave, uint32_t g) { return (groups_per_wave * ZGRP_STRIDE + groups_per_wave * g * ZGRP_REC_STRIDE) * 4; }
 
 template <int G, int WPS>
 __global__ void __launch_bounds__(64, WPS) zstd_frames_grp_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,

@@ -265,6 +265,11 @@ int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, con
  * a second.  For a caller that compresses packs in the background while it goes on adding samples; off (the default) is
  * ~10 % faster when nothing else runs. */
 int agc_hip_zstd17_background(agc_hip_ctx *ctx, int on);
+/* How many inputs of at most 16 KiB one launch of agc_hip_zstd17_batch works on AT THE SAME TIME (a frame is a serial chain:
+ * a launch lasts about as long as its longest frame, whatever their number -- up to this many; beyond it the launch takes
+ * a second round).  The caller that splits packs between the device and host threads (the reference's workers call
+ * ZSTD_compressCCtx one pack at a time, src/common/segment.h:199-201) keeps the device's share below it.  0 = no device. */
+uint32_t agc_hip_zstd17_resident_frames(agc_hip_ctx *ctx);
 /* The compression parameters libzstd 1.4.9 derives for level 17 and a known source size (ZSTD_getCParams(17, n, 0)):
  * windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy.  Exposed so that tests can pin them. */
 int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7]);

@@ -1,0 +1,22 @@
+#!/bin/bash
+OUT=gpurun_out/r3p3
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 120 python scripts/r3_tiny.py 3 2 0 > $OUT/tiny.log 2>&1 || { echo "TINY FAILED"; tail -5 $OUT/tiny.log; exit 1; }
+grep group $OUT/tiny.log
+timeout 300 python -m pytest tests/test_gpu_zstd.py -x -q > $OUT/test_gpu_zstd.log 2>&1
+tail -2 $OUT/test_gpu_zstd.log
+for N in 36000 42000; do
+  AGC_HIP_ZSTD_GROUP=3 timeout 120 python scripts/zstd_gpu_probe.py $N real > $OUT/probe_g3_$N.log 2>&1
+  echo "G=3 $N frames: $(grep 'run 1' $OUT/probe_g3_$N.log) $(grep -c identical $OUT/probe_g3_$N.log)"
+done
+timeout 500 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r3p3/bench_steps20.json').read().strip().splitlines()[-1])
+c=d['config']; print('value',d['value'],'ms_per_step',d['ms_per_step'],'steps_only',c['steps_only_ms'],'close',c['close_ms'],'zstd',c['zstd'])
+print('roofline', {k:v for k,v in d['roofline'].items() if k not in ('kernels','layout')})
+print('cpu_baseline', d.get('cpu_baseline'))
+PY
+timeout 900 bash scripts/profile_round.sh r3 > $OUT/profile_round.log 2>&1
+tail -5 $OUT/profile_round.log

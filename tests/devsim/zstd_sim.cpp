@@ -9,6 +9,7 @@
 extern "C" {
 
 uint32_t agc_hip_zstd17_max_input(void) { return zs::BLOCKSIZE_MAX; }
+uint32_t agc_hip_zstd17_resident_frames(agc_hip_ctx *) { return 64; } // (small on purpose: the host's split rule is exercised)
 
 int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
 {
