@@ -32,6 +32,7 @@ constexpr U32 GRP_MAX = 3;   // lanes per group the exchange record is sized for
 constexpr U32 GRP_MC = 6;    // matches of a request a lane keeps in registers (99.9 % of the requests have <= 5)
 constexpr U32 GRP_RC = 16;   // tree stores a walk may record: 14 levels + the two closing zeros (99.5 % of the walks)
 constexpr U32 GRP_PT = 8;    // price targets per trip
+constexpr U32 GRP_STORE_SEQS = 8; // sequences of a finished chunk stored per trip (a rolled loop: the group idles meanwhile)
 #ifndef ZS_GRP_WALK_LEVELS
 #define ZS_GRP_WALK_LEVELS 12
 #endif
@@ -82,6 +83,7 @@ struct GLane {
     // tree walk
     U32 wk_current, matchIndex, clSmaller, clLarger, smallerPtr, largerPtr, matchEndIdx, bestLength, nbCompares, btLow, lowLimit, mnum, upd_idx;
     bool rec;          // the walk records its stores instead of making them
+    bool grp;          // the walk belongs to a group trip (its end is reported to the group)
     // the next level's node, read ahead (grpWalkIssue): both children, 8 bytes of the match and of the position at the length
     // the two are already known to share
     bool wk_pre;
@@ -94,8 +96,6 @@ struct GLane {
     // store loop
     U32 storePos, storeEnd;
     U64 p8;            // the 8 source bytes at the position being worked on
-    U64 p8hi;          // ... and the 8 behind them (group lanes: a walk's first levels compare inside these 16)
-    bool p16;          // p8hi holds them
     U32 p8_pos;
     // group trip
     U32 g, g_cur, g_v, g_lp0, tcur, t1;
@@ -179,6 +179,22 @@ ZFN void grpPublishBases(GrpX &sh, const OptWs &w)
 #define ZS_OPAQUE(x) asm volatile("" : "+r"(x))
 #endif
 
+// The record of a walk is full.  The LEADER's position is the next one in the sequential order whatever the lanes behind it
+// find: its stores can be made now (the lanes behind walk other trees -- one that shares the leader's bucket is an anomaly
+// already) and the walk goes on storing directly.  A follower's walk is given up (false): the position will be a leader's.
+ZFN bool grpRecFull(GLane &l, U32 *bt)
+{
+    if (l.j != 0)
+        return false;
+    for (U32 r = 0; r < l.nrec; ++r) {
+        const U32 x = l.recs[r];
+        bt[x & 0x7FFFu] = x >> 15;
+    }
+    l.nrec = 0;
+    l.rec = false;
+    return true;
+}
+
 // reads ahead what the next level of the walk will look at (nothing, if the walk ends there): the waits of the walk's first level
 // coincide with those of the repcode tests, and a level's wait with the work that follows the level before
 ZFN void grpWalkIssue(GLane &l, const BYTE *src, const BYTE *iend, const U32 *bt, U32 btMask)
@@ -190,10 +206,11 @@ ZFN void grpWalkIssue(GLane &l, const BYTE *src, const BYTE *iend, const U32 *bt
         if (p + 8 <= iend) {
             l.wk_pair = *(const U64 *)(bt + 2 * (l.matchIndex & btMask));
             l.wk_mb = read64(src + (l.matchIndex - l.w.idx0) + ml0);
-            if (l.p16 && ml0 <= 8 && l.p8_pos == l.wk_current - l.w.idx0) { // the position's bytes ml0 .. ml0 + 7: already in registers
-                const U32 sh = ml0 * 8;
-                l.wk_pb = sh == 0 ? l.p8 : (sh == 64 ? l.p8hi : ((l.p8 >> sh) | (l.p8hi << (64 - sh))));
-            } else
+            // (the position's own bytes: in a register for the first level; a second 8-byte window kept for the deeper levels
+            // was spilled by the register allocator and cost a scratch round trip per level -- measured slower than this load)
+            if (ml0 == 0 && l.p8_pos == l.wk_current - l.w.idx0)
+                l.wk_pb = l.p8;
+            else
                 l.wk_pb = read64(p);
             l.wk_pre = true;
         }
@@ -207,7 +224,7 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
     bool ended = true;
     abort = false;
     if (l.nbCompares && (l.matchIndex >= l.lowLimit)) {
-        if (!UPD && l.rec && l.nrec + 3 > GRP_RC) {
+        if (!UPD && l.rec && l.nrec + 3 > GRP_RC && !grpRecFull(l, bt)) {
             abort = true;
             return true;
         }
@@ -252,7 +269,8 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
             if (matchLength > l.matchEndIdx - l.matchIndex)
                 l.matchEndIdx = l.matchIndex + matchLength;
             l.bestLength = matchLength;
-            if (l.rec && l.mnum >= GRP_MC) {
+            if (l.grp && l.j != 0 && l.mnum >= GRP_MC) { // (the group's price step works on the matches kept in registers; a leader's
+                                                         // further matches go to the workspace and its prices the one-lane way)
                 abort = true;
                 return true;
             }
@@ -312,7 +330,7 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
 ZFN void grpWalkFastLevel(GLane &l, const BYTE *src, const BYTE *iend, U32 *bt, U32 btMask)
 {
     const U64 d = l.wk_pb ^ l.wk_mb;
-    if (d == 0 || (l.rec && (l.nrec + 3 > GRP_RC || l.mnum >= GRP_MC))) {
+    if (d == 0 || (l.grp && (l.nrec + 3 > GRP_RC || (l.j != 0 && l.mnum >= GRP_MC)))) {
         l.wk_pre = false;
         return;
     }
@@ -539,11 +557,11 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
     ZS_GRP_EACH(l)
     l.inChunk = false;
     l.rec = false;
+    l.grp = false;
     l.nrec = 0;
     l.gstatus = GS_OK;
     l.p8 = 0;
     l.p8_pos = 0xFFFFFFFFu;
-    l.p16 = false;
     l.wk_pre = false;
     l.adv = 1;
     l.g = 0;
@@ -578,7 +596,8 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         Optimal *const opt = w.opt;
         if (l.j == 0)
             sh.g = 0;
-        for (U32 sq_ = 0; sq_ < SM_STORE_SEQS && l.state == ST_STORE; ++sq_) do { // a few sequences of the finished chunk per trip
+#pragma unroll 1
+        for (U32 sq_ = 0; sq_ < GRP_STORE_SEQS && l.state == ST_STORE; ++sq_) do { // a few sequences of the finished chunk per trip
             if (l.storePos > l.storeEnd) {
                 setBasePrices(w, optLevel);
                 grpPublishBases(sh, w);
@@ -644,7 +663,6 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             }
             l.p8 = read64(src + l.ip); // (ip < srcSize - 8)
             l.p8_pos = l.ip;
-            l.p16 = false;
             l.q_litlen = l.ip - l.anchor;
             l.q_ll0 = !l.q_litlen;
             l.q_current = l.ip + w.idx0;
@@ -689,7 +707,6 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             l.state = ST_G_BEGIN;
         }
         if (l.state == ST_G_FIRST) { // (leader) a chunk's first position: no price-table entry to finish, only the tables' answers
-            l.p16 = false;
             l.h = mls == 5 ? hash5(l.p8, cp.hashLog) : mls == 6 ? hash6(l.p8, cp.hashLog) : hash4((U32)l.p8, cp.hashLog);
             l.h3 = hash3((U32)l.p8, w.hashLog3);
             l.mi0 = w.hashTable[l.h];
@@ -706,14 +723,9 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 l.op = opt[l.g_cur - 1];
             const U32 lit_byte = src[inr - 1];
             const bool at = inr <= ilimit_off; // (a follower's position always is)
-            l.p16 = false;
             if (at) {
                 l.p8 = read64(src + inr);
                 l.p8_pos = inr;
-                if (inr + 16 <= srcSize) {
-                    l.p8hi = read64(src + inr + 8);
-                    l.p16 = true;
-                }
             }
             l.lit_freq = (w.priceType == zop_predef) ? 0 : w.litFreq[lit_byte];
             l.pr0 = l.pr1 = l.pr2 = 0;
@@ -847,6 +859,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             if (done)
                 l.gstatus = GS_ANOMALY; // answered without a walk and without an insertion: the one-lane path's business
             l.rec = true;
+            l.grp = true;
             l.nrec = 0;
             if (l.gstatus != GS_OK) {
                 sh.wdone[l.j] = 1 + GS_ANOMALY;
@@ -857,6 +870,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         // ---- the one-lane path (zs_opt_sm.h, state for state) ----
         if (l.state == ST_GETM_BEGIN) do {
             l.rec = false;
+            l.grp = false;
             if (l.q_current < w.nextToUpdate) { // skipped area
                 l.nbMatches = 0;
                 l.state = ST_AFTER_MATCHES;
@@ -929,7 +943,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         if (l.state == ST_WALK && !l.wk_pre) { // everything else, once per trip: the end of a walk, long common prefixes ...
             bool abort;
             if (grpWalkLevel<false>(l, src, iend, w.chainTable, btMask, abort)) {
-                if (l.rec) {
+                if (l.grp) {
                     sh.nbm[l.j] = l.mnum;
                     sh.maxML[l.j] = l.last_m_len;
                     sh.maxOff[l.j] = l.last_m_off;
@@ -961,6 +975,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             const U32 q0 = l.q_current - l.j;
             U32 v = 0, ntu = q0;
             int endLane = -1;
+            bool bigLeader = false;
             for (U32 i = 0; i < l.g; ++i) {
                 if (sh.wdone[i] != 1 + GS_OK)
                     break; // anomaly: this position and the ones behind it are redone
@@ -968,6 +983,10 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     break; // skipped area (a long match in front moved nextToUpdate past it)
                 v = i + 1;
                 ntu = sh.mEnd[i] - 8;
+                if (sh.nbm[i] > GRP_MC) { // (only a leader gets here with more matches than the registers hold)
+                    bigLeader = true;
+                    break;
+                }
                 if (l.inChunk && sh.nbm[i] && ((sh.maxML[i] > sufficient_len) || (l.cur + i + sh.maxML[i] >= OPT_NUM))) {
                     endLane = (int)i; // large match -> immediate encoding: the chunk ends at this position
                     break;
@@ -995,6 +1014,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     w.hashTable3[l.h3] = l.q_current;
             }
             l.rec = false;
+            l.grp = false;
             if (l.j == 0) {
                 if (v == 0) { // the leader's own position is an anomaly: the one-lane way (nothing has been committed)
                     l.state = ST_GETM_BEGIN;
@@ -1002,8 +1022,8 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 }
                 w.nextToUpdate = ntu;
                 l.nextToUpdate3 = q0 + v;
-                if (!l.inChunk) { // a chunk's first position: the parser's own checks follow (ST_AFTER_MATCHES below)
-                    l.state = ST_AFTER_MATCHES;
+                if (!l.inChunk || bigLeader) { // a chunk's first position, or more matches than the group's price step takes: the
+                    l.state = ST_AFTER_MATCHES; // parser's own checks and price loops follow (ST_AFTER_MATCHES below)
                     break;
                 }
                 if (endLane >= 0) {
@@ -1023,7 +1043,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     l.state = ST_CUR_NEXT;
                     break;
                 }
-            } else if (l.j >= v || endLane >= 0 || !anyMatch) {
+            } else if (l.j >= v || endLane >= 0 || !anyMatch || bigLeader) {
                 l.state = ST_F_IDLE;
                 break;
             }
