@@ -1568,7 +1568,9 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     // workspace arena: as many frames per launch as the budget allows (a frame's tables must be zero at its start)
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = std::min<uint64_t>(48ull << 30, (uint64_t)((free_b + c->d_zws.cap) * 0.6));
+    // (the call may run on a background thread beside the entry points that add samples: half of what is free, at most 32 GB --
+    // one resident round of 43 008 frames of 16 KiB needs 19 GB -- leaves the other streams' buffers room to grow)
+    uint64_t budget = std::min<uint64_t>(32ull << 30, (uint64_t)((free_b + c->d_zws.cap) * 0.5));
     if (const char *e = getenv("AGC_HIP_ZSTD_ARENA_MB"))
         budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
     budget = std::max<uint64_t>(budget, ws_need[order[0]]);

@@ -852,6 +852,7 @@ bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off
     for (ZJob &j : I.deferred_packs) // the packs that filled during the run come first (their parts are already placed)
         I.close_jobs.emplace_back(std::move(j));
     I.deferred_packs.clear();
+    I.deferred_bytes = 0;
     const size_t n_kept = I.close_jobs.size();
     I.build_close_jobs(I.close_jobs);
     if (getenv("AGC_AMD_LAPS"))
@@ -885,6 +886,11 @@ bool CAGCCompressor::CloseProvideFrames(const uint8_t *frames, const uint64_t *o
     if (!I.close_collected || (!I.close_dev_jobs.empty() && (!frames || !off)))
         return false;
     const size_t nd = I.close_dev_jobs.size();
+    if (nd == 0) { // nothing was handed out: nothing to read (the pointers may be null)
+        I.close_frames_off.assign(1, 0);
+        I.zdst_buf.resize(0, false);
+        return true;
+    }
     I.close_frames_off.assign(off, off + nd + 1);
     I.zdst_buf.resize(off[nd] - off[0], false);
     if (off[nd] > off[0])

@@ -286,7 +286,9 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     if (!dev_jobs.empty()) {
         const double t1 = now();
         const bool ok = ext ? true : dev_done.get();
-        st.t_device += now() - t1;
+        // (this runs on the entropy thread: its wait is NOT added to st.t_device, which the thread driving the steps reads for
+        // its host-only stage times; t_zstd_dev below is the device call's own time)
+        (void)t1;
         st.t_zstd_dev += t_dev;
         LAP("wait for the device");
         const double ts1 = now();
@@ -1821,10 +1823,21 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
         const uint32_t dev_max = agc_hip_zstd17_max_input();
         std::vector<ZJob> now_jobs;
         for (ZJob &j : all_jobs)
-            if (j.kind == 1 && !j.data.empty() && j.data.size() <= dev_max)
+            if (j.kind == 1 && !j.data.empty() && j.data.size() <= dev_max) {
+                deferred_bytes += j.data.size();
                 deferred_packs.emplace_back(std::move(j));
-            else
+            } else
                 now_jobs.emplace_back(std::move(j));
+        // ... up to a ceiling: behind the first kept pack every later part of the archive waits in host memory (ArchiveWriter
+        // writes its events in order), so the writer's memory would grow with the collection.  Past the ceiling the writer's own
+        // entropy stage takes what has piled up (the same frames, only not spread over the ranks) and the archive flows again.
+        static const uint64_t defer_cap = (getenv("AGC_AMD_DEFER_MAX_MB") ? strtoull(getenv("AGC_AMD_DEFER_MAX_MB"), nullptr, 10) : 2048ull) << 20;
+        if (deferred_bytes > defer_cap) {
+            for (ZJob &j : deferred_packs)
+                now_jobs.emplace_back(std::move(j));
+            deferred_packs.clear();
+            deferred_bytes = 0;
+        }
         all_jobs.swap(now_jobs);
     }
     z_submit(std::move(all_jobs));
@@ -1874,6 +1887,7 @@ void CAGCCompressor::Impl::finish_groups()
         j.slot = std::make_shared<PartSlot>();
         ar.add_part_deferred(j.stream_id, j.slot);
     }
+    deferred_bytes = 0;
     for (ZJob &j : deferred_packs) // (Close without CloseCollectPacks: the kept packs are coded here after all)
         jobs.emplace_back(std::move(j));
     deferred_packs.clear();

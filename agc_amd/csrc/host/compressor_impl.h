@@ -705,7 +705,13 @@ struct CAGCCompressor::Impl {
     std::map<std::string, std::string> in_file_type_info;
     bool unpack_group(uint32_t gid);
 
-    void err(const std::string &m) { std::cerr << m << std::endl; }
+    // (also called from the entropy thread: one message at a time)
+    void err(const std::string &m)
+    {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> g(mu);
+        std::cerr << m << std::endl;
+    }
     bool hip_ok(int rc, const char *what)
     {
         if (rc == AGC_HIP_OK)
@@ -801,6 +807,7 @@ struct CAGCCompressor::Impl {
     // single-archive mode, writer rank: delta packs that filled during the run wait here (their parts already hold their place in
     // the archive) so that Close in steps can spread them over every rank's GPU together with the packs still open
     std::vector<ZJob> deferred_packs;
+    uint64_t deferred_bytes = 0;       // their raw bytes (bounded: AGC_AMD_DEFER_MAX_MB, default 2 GiB -- compressor_batch.cpp)
     std::vector<ZJob> close_jobs;
     std::vector<uint32_t> close_dev_jobs;      // indices in close_jobs of the packs handed out
     std::vector<uint64_t> close_src_off, close_frames_off;

@@ -1,3 +1,4 @@
+// Derived from Zstandard 1.4.9 (Copyright (c) 2016-present, Facebook, Inc.; BSD license): see NOTICE in this directory.
 // zs_common.h -- shared definitions of the level-17 zstd frame encoder (S3, SURVEY 8b: ZSTD_compressCCtx at
 // src/common/segment.h:176,201) written for gfx950: one frame per lane, every table in a per-frame workspace in HBM.
 //

@@ -1,3 +1,4 @@
+// Derived from Zstandard 1.4.9 (Copyright (c) 2016-present, Facebook, Inc.; BSD license): see NOTICE in this directory.
 // zs_entropy.h -- the entropy stage of a zstd block as libzstd 1.4.9 runs it for the first block of a frame
 // (zstd_compress.c: ZSTD_entropyCompressSequences_internal; zstd_compress_literals.c; zstd_compress_sequences.c;
 // huf_compress.c; fse_compress.c; hist.c): Huffman-coded literals (1 or 4 streams, tree description FSE-compressed or

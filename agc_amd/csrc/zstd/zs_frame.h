@@ -1,3 +1,4 @@
+// Derived from Zstandard 1.4.9 (Copyright (c) 2016-present, Facebook, Inc.; BSD license): see NOTICE in this directory.
 // zs_frame.h -- one zstd frame as ZSTD_compressCCtx(level) of libzstd 1.4.9 writes it for an input of at most one block
 // (<= 128 KiB) with the bt* strategies: frame header (zstd_compress.c: ZSTD_writeFrameHeader), the block
 // (ZSTD_compressBlock_internal) and its header (ZSTD_compress_frameChunk).  Everything works inside a caller-provided

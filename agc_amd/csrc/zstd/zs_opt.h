@@ -1,3 +1,4 @@
+// Derived from Zstandard 1.4.9 (Copyright (c) 2016-present, Facebook, Inc.; BSD license): see NOTICE in this directory.
 // zs_opt.h -- binary-tree match finder + optimal parser of zstd 1.4.9 (lib/compress/zstd_opt.c), strategies btopt /
 // btultra / btultra2, no dictionary, one block.  Follows the library decision by decision: same hash functions, same tree
 // updates, same price model (fractional-bit weights, BITCOST_ACCURACY 8), same statistics updates, same tie-breaks.

@@ -1,3 +1,4 @@
+// Derived from Zstandard 1.4.9 (Copyright (c) 2016-present, Facebook, Inc.; BSD license): see NOTICE in this directory.
 // zs_opt_grp.h -- the optimal parser of zs_opt.h / zs_opt_sm.h with SEVERAL LANES PER FRAME (a "group" of G lanes).
 //
 // Why: one lane per frame (zs_opt_sm.h) leaves a frame with ONE dependent chain of ~11 memory round trips per position, and a

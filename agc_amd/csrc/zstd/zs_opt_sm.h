@@ -1,3 +1,4 @@
+// Derived from Zstandard 1.4.9 (Copyright (c) 2016-present, Facebook, Inc.; BSD license): see NOTICE in this directory.
 // zs_opt_sm.h -- ZSTD_compressBlock_opt_generic (zs_opt.h: compressBlockOpt) rewritten as ONE loop over micro-steps.
 //
 // Why: on the GPU every lane of a wave compresses its own frame.  The nested loops of the parser (positions of a chunk > tree

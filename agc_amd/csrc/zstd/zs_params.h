@@ -1,3 +1,4 @@
+// Derived from Zstandard 1.4.9 (Copyright (c) 2016-present, Facebook, Inc.; BSD license): see NOTICE in this directory.
 // zs_params.h -- ZSTD_getCParams(17, srcSize, 0) of libzstd 1.4.9 for a KNOWN source size: the level-17 rows of
 // ZSTD_defaultCParameters (one per source-size class) followed by ZSTD_adjustCParams_internal (zstd_compress.c).
 // Host code (the C ABI decides the parameters, the kernels receive them); pinned against the library by
