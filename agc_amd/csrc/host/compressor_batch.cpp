@@ -159,8 +159,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         dev_jobs.clear();
     } else if (gpu_zstd_share < 1.0 && zpool->size() > 1) {
         // both engines work at the same time: the device keeps the share of the pack bytes that makes them finish together
-        // (its measured rate against the host pool's, updated after every call).  It takes the SMALLEST packs: one lane parses
-        // one frame, so a launch lasts as long as its longest frame, while a host thread's time only follows the bytes
+        // (its measured rate against the host pool's, updated after every call)
         uint64_t total = 0, dev_acc = 0;
         for (uint32_t i : dev_jobs)
             total += jobs[i].data.size();
@@ -173,17 +172,24 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         };
         std::vector<uint32_t> by_size(dev_jobs);
         std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return chain(a) < chain(b); });
-        // (and never more frames than the device works on at once: a frame is a serial chain, a second round of a launch lasts
-        // as long as the first)
+        // The device works on agc_hip_zstd17_resident_frames() frames at once and a launch lasts about as long as its longest
+        // frame whatever their number (a frame is a serial chain; a second round would last as long as the first): when there are
+        // more packs than that, the host pool takes the SMALLEST ones (the fewest bytes per frame taken off the device); then the
+        // largest ones move over until the device's byte share is the one that lets both sides finish together.
         const uint32_t resident = std::max<uint32_t>(1u, agc_hip_zstd17_resident_frames(hip));
-        std::vector<uint32_t> keep;
-        for (uint32_t i : by_size) {
-            if ((double)dev_acc < gpu_zstd_share * (double)total && keep.size() < resident) {
-                keep.push_back(i);
-                dev_acc += jobs[i].data.size();
-            } else
-                host_jobs.push_back(i);
+        size_t lo = 0, hi = by_size.size();
+        if (hi - lo > resident)
+            lo = hi - resident;
+        dev_acc = 0;
+        for (size_t t = lo; t < hi; ++t)
+            dev_acc += jobs[by_size[t]].data.size();
+        while (hi > lo && (double)dev_acc > gpu_zstd_share * (double)total) {
+            --hi;
+            dev_acc -= jobs[by_size[hi]].data.size();
         }
+        std::vector<uint32_t> keep(by_size.begin() + lo, by_size.begin() + hi);
+        host_jobs.insert(host_jobs.end(), by_size.begin(), by_size.begin() + lo);
+        host_jobs.insert(host_jobs.end(), by_size.begin() + hi, by_size.end());
         std::sort(keep.begin(), keep.end());
         dev_jobs.swap(keep);
     }

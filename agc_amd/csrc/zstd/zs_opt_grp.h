@@ -33,7 +33,9 @@ constexpr U32 GRP_MAX = 3;   // lanes per group the exchange record is sized for
 constexpr U32 GRP_MC = 6;    // matches of a request a lane keeps in registers (99.9 % of the requests have <= 5)
 constexpr U32 GRP_RC = 16;   // tree stores a walk may record: 14 levels + the two closing zeros (99.5 % of the walks)
 constexpr U32 GRP_PT = 8;    // price targets per trip
-constexpr U32 GRP_STORE_SEQS = 8; // sequences of a finished chunk stored per trip (a rolled loop: the group idles meanwhile)
+constexpr U32 GRP_STORE_SEQS = 4; // sequences of a finished chunk stored per trip
+constexpr U32 GRP_ST_LITS = 4;    // ... without a dependent chain when their literal runs are at most this long (99 % of the runs)
+constexpr U32 GRP_ST_LAST = 0xFFFFFFF0u, GRP_ST_DONE = 0xFFFFFFF1u; // store cursor: lastSequence is next / the chunk is stored
 #ifndef ZS_GRP_WALK_LEVELS
 #define ZS_GRP_WALK_LEVELS 12
 #endif
@@ -166,6 +168,17 @@ ZFN void grpPublishBases(GrpX &sh, const OptWs &w)
 // joined).  __builtin_amdgcn_wave_barrier() is a convergent operation (no instruction): it cannot be duplicated into or moved
 // across divergent paths, so every lane passes the end of segment A before any lane starts segment B; the wavefront-scope
 // fences keep the compiler from moving LDS / global accesses across it.
+// (ZS_GRP_PROF: a variant build for scripts/ probes -- cycles per segment of the trip, summed per wave: zs_prof[k])
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZS_GRP_PROF)
+#define ZS_GRP_TICK(k)                                              \
+    do {                                                            \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        zs_prof[k] += t_ - zs_prof_t;                               \
+        zs_prof_t = t_;                                             \
+    } while (0)
+#else
+#define ZS_GRP_TICK(k)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZS_GRP_EACH(l) { GLane &l = lanes[0];
 #define ZS_GRP_END                                              \
@@ -586,7 +599,14 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         l.state = ST_F_IDLE;
     ZS_GRP_END
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZS_GRP_PROF)
+    unsigned long long zs_prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long zs_prof_t = __builtin_readcyclecounter();
+#endif
     for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZS_GRP_PROF)
+        zs_prof[9]++;
+#endif
 #ifdef ZS_GRP_STATS
         g_grp_trips++;
 #endif
@@ -597,27 +617,122 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         Optimal *const opt = w.opt;
         if (l.j == 0)
             sh.g = 0;
+        if (l.state == ST_STORE) do { // a few sequences of the finished chunk per trip
+            // the entries of this trip: four positions of the path from fw[], their heads asked for together, then stored in order
+            U32 pos[GRP_STORE_SEQS];
+            U32 llen_[GRP_STORE_SEQS], mlen_[GRP_STORE_SEQS], off_[GRP_STORE_SEQS];
+            // (storePos: index into fw[], the path's positions in forward order up to storeEnd; lastSequence follows them)
+            const U64 four = read64((const BYTE *)(w.fw + l.storePos)); // (four links in one read; the array has slack behind its end)
+            U32 p = l.storePos;
+#pragma unroll
+            for (U32 k = 0; k < GRP_STORE_SEQS; ++k) {
+                const U32 idx = l.storePos + k;
+                pos[k] = idx < l.storeEnd ? (U32)(four >> (16 * k)) & 0xFFFFu : (idx == l.storeEnd ? GRP_ST_LAST : GRP_ST_DONE);
+            }
+            p = l.storePos + GRP_STORE_SEQS;
+            const bool chunkStored = p > l.storeEnd; // lastSequence was among the four
+#pragma unroll
+            for (U32 k = 0; k < GRP_STORE_SEQS; ++k) {
+                llen_[k] = l.lastSequence.litlen;
+                mlen_[k] = l.lastSequence.mlen;
+                off_[k] = l.lastSequence.off;
+                if (pos[k] < GRP_ST_LAST) {
+                    llen_[k] = opt[pos[k]].litlen;
+                    mlen_[k] = opt[pos[k]].mlen;
+                    off_[k] = opt[pos[k]].off;
+                }
+            }
+            // where the sequences' literal runs start; the common case -- runs of at most GRP_ST_LITS literals, away from the end of
+            // the block -- is stored without a dependent chain: the runs' bytes in one round trip, the literals' counts in another
+            U32 anc[GRP_STORE_SEQS];
+            bool isSeq[GRP_STORE_SEQS];
+            bool fast = true;
+            {
+                U32 a = l.anchor;
+#pragma unroll
+                for (U32 k = 0; k < GRP_STORE_SEQS; ++k) {
+                    isSeq[k] = pos[k] != GRP_ST_DONE && mlen_[k] != 0;
+                    anc[k] = a;
+                    if (isSeq[k]) {
+                        fast = fast && llen_[k] <= GRP_ST_LITS && a <= ilimit_off; // (a + 8 <= srcSize: the run is read as 8 bytes)
+                        a += llen_[k] + mlen_[k];
+                    }
+                }
+            }
+            if (fast) {
+                U64 lb[GRP_STORE_SEQS];
+#pragma unroll
+                for (U32 k = 0; k < GRP_STORE_SEQS; ++k)
+                    lb[k] = (isSeq[k] && llen_[k]) ? read64(src + anc[k]) : 0;
+                U32 byt[GRP_STORE_SEQS * GRP_ST_LITS], frq[GRP_STORE_SEQS * GRP_ST_LITS];
+                bool on[GRP_STORE_SEQS * GRP_ST_LITS];
+#pragma unroll
+                for (U32 k = 0; k < GRP_STORE_SEQS; ++k)
+#pragma unroll
+                    for (U32 u = 0; u < GRP_ST_LITS; ++u) {
+                        const U32 i = k * GRP_ST_LITS + u;
+                        on[i] = isSeq[k] && u < llen_[k];
+                        byt[i] = (U32)(lb[k] >> (8 * u)) & 0xFF;
+                        frq[i] = on[i] ? w.litFreq[byt[i]] : 0;
+                    }
+                // ZSTD_updateStats: litFreq[literal] += ZSTD_LITFREQ_ADD, literal after literal (equal bytes of the batch see each other:
+                // the later store carries the sum)
+#pragma unroll
+                for (U32 i = 0; i < GRP_STORE_SEQS * GRP_ST_LITS; ++i)
+                    if (on[i]) {
+                        U32 c = 1;
+#pragma unroll
+                        for (U32 jj = 0; jj < i; ++jj)
+                            c += (on[jj] && byt[jj] == byt[i]) ? 1u : 0u;
+                        w.litFreq[byt[i]] = frq[i] + LITFREQ_ADD * c;
+                    }
+#pragma unroll
+                for (U32 k = 0; k < GRP_STORE_SEQS; ++k) {
+                    if (isSeq[k]) {
+                        const U32 llen = llen_[k], mlen = mlen_[k], offCode = off_[k];
+                        w.litSum += llen * LITFREQ_ADD;
+                        w.litLengthFreq[LLcode(llen)]++;
+                        w.litLengthSum++;
+                        w.offCodeFreq[highbit32(offCode + 1)]++;
+                        w.offCodeSum++;
+                        w.matchLengthFreq[MLcode(mlen - MINMATCH)]++;
+                        w.matchLengthSum++;
+                        // ZSTD_storeSeq: the run's bytes in one (wider) store -- what lies behind the run is overwritten by the next
+                        if (llen)
+                            memcpy(w.lits + w.nLits, &lb[k], 8);
+                        w.nLits += llen;
+                        Seq &sq = w.seqs[w.nSeq++];
+                        sq.offCode = offCode;
+                        sq.litLength = llen;
+                        sq.matchLength = mlen;
+                        l.anchor += llen + mlen;
+                        l.ip = l.anchor;
+                    } else if (pos[k] != GRP_ST_DONE) // only literals => must be last "sequence", actually starting a new stream of sequences
+                        l.ip = l.anchor + llen_[k];
+                }
+            } else {
 #pragma unroll 1
-        for (U32 sq_ = 0; sq_ < GRP_STORE_SEQS && l.state == ST_STORE; ++sq_) do { // a few sequences of the finished chunk per trip
-            if (l.storePos > l.storeEnd) {
+                for (U32 k = 0; k < GRP_STORE_SEQS; ++k) {
+                    if (pos[k] == GRP_ST_DONE)
+                        break;
+                    if (mlen_[k] == 0) { // only literals => must be last "sequence", actually starting a new stream of sequences
+                        l.ip = l.anchor + llen_[k];
+                    } else {
+                        updateStats(w, llen_[k], src + l.anchor, off_[k], mlen_[k]);
+                        storeSeq(w, llen_[k], src + l.anchor, off_[k], mlen_[k]);
+                        l.anchor += llen_[k] + mlen_[k];
+                        l.ip = l.anchor;
+                    }
+                }
+            }
+            l.storePos = p;
+            if (chunkStored) {
                 setBasePrices(w, optLevel);
                 grpPublishBases(sh, w);
                 l.state = ST_FIND_FIRST;
-                break;
             }
-            const U32 llen = opt[l.storePos].litlen;
-            const U32 mlen = opt[l.storePos].mlen;
-            const U32 offCode = opt[l.storePos].off;
-            if (mlen == 0) { // only literals => must be last "sequence", actually starting a new stream of sequences
-                l.ip = l.anchor + llen;
-            } else {
-                updateStats(w, llen, src + l.anchor, offCode, mlen);
-                storeSeq(w, llen, src + l.anchor, offCode, mlen);
-                l.anchor += llen + mlen;
-                l.ip = l.anchor;
-            }
-            l.storePos++;
         } while (0);
+        ZS_GRP_TICK(10);
         if (l.state == ST_CUR_NEXT) do {
             l.cur += l.adv;
             l.adv = 1;
@@ -657,6 +772,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             l.g = g;
             l.state = ST_G_BEGIN;
         } while (0);
+        ZS_GRP_TICK(11);
         if (l.state == ST_FIND_FIRST) do {
             if (!(srcSize >= 8 && l.ip < ilimit_off)) {
                 l.state = ST_DONE;
@@ -691,6 +807,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         } while (0);
         ZS_GRP_END
 
+        ZS_GRP_TICK(0);
         // ================= segment B: the lanes of the trip read what their positions need =================
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
@@ -758,6 +875,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         }
         ZS_GRP_END
 
+        ZS_GRP_TICK(1);
         // ================= segments C0 .. C(G-1): the literal step, chained through the trip's positions =================
 #pragma unroll
         for (int s = 0; s < G; ++s) {
@@ -793,6 +911,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     l.oc.rep[2] = l.op.rep[2];
                 }
                 w.opt[l.g_cur] = l.oc;
+                w.bk[l.g_cur] = (U16)(l.oc.litlen + l.oc.mlen); // (what the chunk end's walk back reads: a compact copy)
                 if (s + 1 < G) {
                     sh.oc_price = l.oc.price;
                     sh.oc_mlen = l.oc.mlen;
@@ -805,6 +924,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             ZS_GRP_END
         }
 
+        ZS_GRP_TICK(2);
         // ================= segment D: match requests: repcodes, hash-3 probe, walk set-up =================
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
@@ -934,6 +1054,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         } while (0);
         ZS_GRP_END
 
+        ZS_GRP_TICK(3);
         // ================= segment E: tree walks (recorded for the lanes of a group trip) =================
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
@@ -963,6 +1084,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         }
         ZS_GRP_END
 
+        ZS_GRP_TICK(4);
         // ================= segment F: the group is validated in order; valid lanes commit =================
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
@@ -1192,6 +1314,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         } while (0);
         ZS_GRP_END
 
+        ZS_GRP_TICK(5);
         // ================= segment H: the lanes' prices for the next targets =================
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
@@ -1217,6 +1340,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         }
         ZS_GRP_END
 
+        ZS_GRP_TICK(6);
         // ================= segment I: per target the lanes' prices compete in lane order (strict <, like the sequential loop) =================
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
@@ -1261,6 +1385,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     l.state = ST_F_IDLE;
             }
         }
+        ZS_GRP_TICK(12);
         if (l.state == ST_CHUNK_END) do {
             if (l.lastSequence.mlen != 0) {
                 U32 reps[3];
@@ -1273,23 +1398,25 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 l.rep1 = opt[l.cur].rep[1];
                 l.rep2 = opt[l.cur].rep[2];
             }
-            l.storeEnd = l.cur + 1;
-            U32 storeStart = l.storeEnd;
-            U32 seqPos = l.cur;
-            opt[l.storeEnd] = l.lastSequence;
-            while (seqPos > 0) {
-                const U32 backDist = opt[seqPos].litlen + opt[seqPos].mlen;
-                storeStart--;
-                opt[storeStart] = opt[seqPos];
-                seqPos = (seqPos > backDist) ? seqPos - backDist : 0;
+            // ZSTD's reverse traversal copies the entries of the chosen path to the front of the table; here only their POSITIONS
+            // are listed: bk[] (written with every finished entry) gives the way back, fw[] takes the list the store loop reads.
+            // Both are 2 bytes per position: the walk stays inside a cache line or two instead of one 32-byte entry per step.
+            // fw[top .. cur) = the positions of the path, in forward order (filled from the top: a path has at most cur entries)
+            l.storeEnd = l.cur;
+            U32 top = l.cur;
+            for (U32 sp = l.cur; sp > 0;) {
+                const U32 backDist = w.bk[sp];
+                w.fw[--top] = (U16)sp;
+                sp = (sp > backDist) ? sp - backDist : 0;
             }
-            l.storePos = storeStart;
+            l.storePos = top;
             l.state = ST_STORE;
         } while (0);
         if (l.j == 0 && l.state == ST_DONE)
             sh.done = 1;
         ZS_GRP_END
 
+        ZS_GRP_TICK(7);
         // ================= the group leaves the loop together =================
         bool fin = false;
         ZS_GRP_EACH(l)
@@ -1305,6 +1432,12 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
         if (fin)
             break;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZS_GRP_PROF)
+    if (threadIdx.x == 0 && blockIdx.x % 400 == 7)
+        printf("zsprof wave %u trips %llu cycles A %llu (store %llu next %llu first %llu) B %llu C %llu D %llu E %llu F %llu H %llu I %llu (price %llu chunkend %llu)\n", blockIdx.x,
+               zs_prof[9], zs_prof[0] + zs_prof[10] + zs_prof[11], zs_prof[10], zs_prof[11], zs_prof[0], zs_prof[1], zs_prof[2], zs_prof[3], zs_prof[4], zs_prof[5],
+               zs_prof[6], zs_prof[7] + zs_prof[12], zs_prof[12], zs_prof[7]);
+#endif
     return srcSize - lanes[0].anchor;
 }
 
