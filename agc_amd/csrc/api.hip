@@ -37,6 +37,8 @@ struct agc_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t zstream = nullptr; // the entropy stage's own stream: agc_hip_zstd17_batch may run beside every other entry point
+    hipStream_t zstream2 = nullptr; // ... and a second one: the one-lane kernel (inputs > 16 KiB) runs BESIDE the group kernel
+    hipEvent_t zev_a = nullptr, zev_b = nullptr;
     bool zstd_background = false;  // agc_hip_zstd17_background: launches leave the LDS to the kernels of the other streams
     std::string err;
 
@@ -229,7 +231,8 @@ int agc_hip_create(agc_hip_ctx **out, int device)
     agc_hip_ctx *c = new agc_hip_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        create_low_priority_stream(&c->zstream) != hipSuccess ||
+        create_low_priority_stream(&c->zstream) != hipSuccess || create_low_priority_stream(&c->zstream2) != hipSuccess ||
+        hipEventCreateWithFlags(&c->zev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->zev_b, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l2.e0) != hipSuccess ||
         hipEventCreate(&c->l2.e1) != hipSuccess || hipEventCreateWithFlags(&c->l2.ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess ||
@@ -249,6 +252,8 @@ void agc_hip_destroy(agc_hip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->zstream)
         (void)hipStreamSynchronize(c->zstream);
+    if (c->zstream2)
+        (void)hipStreamSynchronize(c->zstream2);
     if (c->stream2)
         (void)hipStreamSynchronize(c->stream2);
     for (void *hp : c->host_allocs)
@@ -278,6 +283,11 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipStreamDestroy(c->stream);
     if (c->zstream)
         (void)hipStreamDestroy(c->zstream);
+    if (c->zstream2)
+        (void)hipStreamDestroy(c->zstream2);
+    for (hipEvent_t e : {c->zev_a, c->zev_b})
+        if (e)
+            (void)hipEventDestroy(e);
     for (hipEvent_t e : {c->l2.e0, c->l2.e1, c->l2.ready})
         if (e)
             (void)hipEventDestroy(e);
@@ -1620,6 +1630,14 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             ZTimer t(c);
             const uint32_t dbg = (uint32_t)(getenv("AGC_HIP_ZSTD_DEBUG") ? atoi(getenv("AGC_HIP_ZSTD_DEBUG")) : 0);
             const dim3 block(64);
+            // both kinds in one call: the one-lane launch (a few large inputs, as long as a whole launch of small frames) runs on
+            // a second stream BESIDE the group launch, after the uploads and before the results are read
+            const bool both = m_one && m_grp;
+            const hipStream_t zs1 = both ? c->zstream2 : zs_;
+            if (both) {
+                HIPCHK(c, hipEventRecord(c->zev_a, zs_));
+                HIPCHK(c, hipStreamWaitEvent(c->zstream2, c->zev_a, 0));
+            }
             if (m_one) {
                 // frames per wave: fewer = fewer distinct parser states per trip of the micro-step loop, but every wave of the
                 // launch must be resident at once (2 per SIMD = 2048 on 256 CUs) or the launch takes two rounds.  Measured per
@@ -1636,10 +1654,10 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                 const dim3 grid((m_one + lanes - 1) / lanes);
                 const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
                 if (c->zstd_background)
-                    hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs_, dj, m_one, (uint32_t *)c->d_zsize.p, lanes,
+                    hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs1, dj, m_one, (uint32_t *)c->d_zsize.p, lanes,
                                        (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
                 else // (frequency tables and the first matches of a request in LDS)
-                    hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs_, dj, m_one,
+                    hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs1, dj, m_one,
                                        (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             }
             if (m_grp) {
@@ -1652,6 +1670,10 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                 else
                     hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw, 3), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
                                        (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+            }
+            if (both) {
+                HIPCHK(c, hipEventRecord(c->zev_b, c->zstream2));
+                HIPCHK(c, hipStreamWaitEvent(zs_, c->zev_b, 0));
             }
         }
         HIPCHK(c, hipGetLastError());

@@ -178,6 +178,15 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         // largest ones move over until the device's byte share is the one that lets both sides finish together.
         const uint32_t resident = std::max<uint32_t>(1u, agc_hip_zstd17_resident_frames(hip));
         size_t lo = 0, hi = by_size.size();
+        // (a handful of packs beyond 16 KiB -- the one-lane kernel's class, a launch of its own that lasts as long as a whole
+        // launch of small frames -- is the host pool's: by_size ends with them)
+        {
+            size_t big = 0;
+            while (big < hi && jobs[by_size[hi - 1 - big]].data.size() > 16384)
+                ++big;
+            if (big < 512)
+                hi -= big;
+        }
         if (hi - lo > resident)
             lo = hi - resident;
         dev_acc = 0;
