@@ -949,6 +949,10 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     if (open_batch.valid())
         open_batch.get();
     LAP("finish_groups (pack jobs + entropy stage + parts) || open collection batch");
+    if (I.verify_bad.load()) { // (AGC_AMD_VERIFY_DEV_FRAMES)
+        I.err("Close: " + std::to_string(I.verify_bad.load()) + " of " + std::to_string(I.verify_frames.load()) + " device frames differ from libzstd");
+        return false;
+    }
     I.ar.flush_out_buffers();
     LAP("flush_out_buffers");
 

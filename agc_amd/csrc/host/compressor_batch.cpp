@@ -2,6 +2,7 @@
 // scan -> classification -> placement -> [speculative encode] -> commit runs (registration, store, bookkeeping).
 // Citations: file:line under the reference tree.
 #include "compressor_impl.h"
+#include <atomic>
 
 namespace agc {
 
@@ -316,6 +317,27 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 finish(j, packed, ps, 0);
             });
         } else {
+            // AGC_AMD_VERIFY_DEV_FRAMES=1 (a checking aid, e.g. `bench.py --verify-entropy`): every frame the device returned is
+            // compressed again by libzstd and compared byte for byte -- the device entropy stage checked at full size, on the very
+            // packs of this Close()
+            static const bool verify_dev = getenv("AGC_AMD_VERIFY_DEV_FRAMES") != nullptr;
+            if (verify_dev) {
+                std::atomic<uint64_t> bad{0};
+                zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
+                    const ZJob &j = jobs[dev_jobs[t]];
+                    const size_t bound = zstd.compressBound(j.data.size());
+                    bytes_t ref(bound + 1);
+                    const size_t n = zctx[tid]->compress(ref.data(), bound, j.data.data(), j.data.size(), 17);
+                    if (n != dst_off[t + 1] - dst_off[t] || memcmp(ref.data(), zdst_buf.data() + dst_off[t], n) != 0)
+                        ++bad;
+                });
+                std::cerr << "verify: " << dev_jobs.size() << " device frames (" << src_off[dev_jobs.size()] / 1e6 << " MB) against libzstd level 17: "
+                          << bad.load() << " differ" << std::endl;
+                verify_frames += dev_jobs.size();
+                verify_bad += bad.load();
+                if (bad.load())
+                    err("entropy stage: device frames differ from libzstd");
+            }
             zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned) {
                 ZJob &j = jobs[dev_jobs[t]];
                 const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);

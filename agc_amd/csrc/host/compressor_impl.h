@@ -806,6 +806,7 @@ struct CAGCCompressor::Impl {
     // Close in steps (multi-GPU entropy stage, compressor.h: CloseCollectPacks / CloseProvideFrames)
     // single-archive mode, writer rank: delta packs that filled during the run wait here (their parts already hold their place in
     // the archive) so that Close in steps can spread them over every rank's GPU together with the packs still open
+    std::atomic<uint64_t> verify_frames{0}, verify_bad{0}; // AGC_AMD_VERIFY_DEV_FRAMES: device frames checked against libzstd / different
     std::vector<ZJob> deferred_packs;
     uint64_t deferred_bytes = 0;       // their raw bytes (bounded: AGC_AMD_DEFER_MAX_MB, default 2 GiB -- compressor_batch.cpp)
     std::vector<ZJob> close_jobs;

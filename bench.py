@@ -57,6 +57,10 @@ def parse():
                     help="N > 1: one independent archive shard per rank (no collective) instead of the default: all ranks feed ONE "
                          "archive (ordered commit from broadcast commit records, entropy stage spread over the ranks' GPUs; agc_amd/dist.py)")
     ap.add_argument("--single-archive", action="store_true", help="(the default for N > 1; kept for older command lines)")
+    ap.add_argument("--verify-entropy", action="store_true",
+                    help="CHECKING RUN, not a measurement: every frame the device entropy stage returns (all the packs of this run's Close) is "
+                         "compressed again by the host's libzstd 1.4.9 at level 17 and compared byte for byte (AGC_AMD_VERIFY_DEV_FRAMES); "
+                         "Close() fails on a difference.  The line's `value` includes that work -- keep the log, not the number")
     return ap.parse_args()
 
 
@@ -226,6 +230,8 @@ def file_mode(args):
 
 
 def main():
+    if "--verify-entropy" in sys.argv:
+        os.environ["AGC_AMD_VERIFY_DEV_FRAMES"] = "1"
     args = parse()
     if args.from_fasta:
         return file_mode(args)
