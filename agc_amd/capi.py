@@ -34,6 +34,7 @@ SYMBOLS = [
     "agc_hip_ref_lag_counts_dev",
     "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams",
     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
+    "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -123,6 +124,8 @@ def load():
     L.agc_hip_pack_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
     L.agc_hip_expand_dev.argtypes = [vp, C.POINTER(Packed), vp]
     L.agc_hip_scan_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
+    L.agc_hip_prefetch_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.agc_hip_scan_prefetched.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     for s in SYMBOLS:
         f = getattr(L, s)
         if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count", "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames",
@@ -273,6 +276,17 @@ class Context:
 
     def scan_packed_dev(self, pk, ctg_off, k, cap=1 << 16):
         fn = lambda h, arg, *rest: self.L.agc_hip_scan_packed_dev(h, C.byref(arg), *rest)
+        return self._scan(fn, pk, ctg_off, k, cap)
+
+    def prefetch_packed_dev(self, pk, ctg_off, k):
+        """queues expansion + scan of the NEXT sample; returns the device pointer of its byte staging copy"""
+        off = _a(ctg_off, np.uint64)
+        d = vp()
+        self._chk(self.L.agc_hip_prefetch_packed_dev(self.h, C.byref(pk), _p(off, u64p), off.size - 1, k, C.byref(d)))
+        return d.value
+
+    def scan_prefetched(self, pk, ctg_off, k, cap=1 << 16):
+        fn = lambda h, arg, *rest: self.L.agc_hip_scan_prefetched(h, C.byref(arg), *rest)
         return self._scan(fn, pk, ctg_off, k, cap)
 
     def scan_contigs(self, codes, ctg_off, k, cap=1 << 16):

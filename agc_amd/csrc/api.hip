@@ -74,6 +74,23 @@ struct agc_hip_ctx {
     } l2;
     hipStream_t stream2 = nullptr;
 
+    // the NEXT sample, started ahead of its turn (agc_hip_prefetch_packed_dev): expansion into one of two staging buffers and the
+    // packed splitter scan, on a stream of their own with their own scratch -- they fill the gaps the sample in front leaves on the
+    // GPU while the host registers its segments
+    struct Prefetch {
+        hipStream_t stream = nullptr;
+        DevBuf d_sample[2], d_ranges, d_hits, d_counter;
+        int cur = 0;
+        uint32_t *h_count = nullptr; // pinned
+        const void *words = nullptr; // identity of the packed sample in flight
+        uint64_t n_symbols = 0;
+        uint32_t dev_cap = 0, k = 0, n_ctg = 0;
+        uint64_t first_off = 0, last_off = 0;
+        bool valid = false, scanned = false;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool timed = false;
+    } pf;
+
     // pinned host allocations handed out by agc_hip_host_alloc
     std::vector<void *> host_allocs;
 
@@ -256,6 +273,16 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipStreamSynchronize(c->zstream2);
     if (c->stream2)
         (void)hipStreamSynchronize(c->stream2);
+    if (c->pf.stream) {
+        (void)hipStreamSynchronize(c->pf.stream);
+        (void)hipStreamDestroy(c->pf.stream);
+        (void)hipHostFree(c->pf.h_count);
+        (void)hipEventDestroy(c->pf.e0);
+        (void)hipEventDestroy(c->pf.e1);
+        for (DevBuf *b : {&c->pf.d_sample[0], &c->pf.d_sample[1], &c->pf.d_ranges, &c->pf.d_hits, &c->pf.d_counter})
+            if (b->p)
+                (void)hipFree(b->p);
+    }
     for (void *hp : c->host_allocs)
         (void)hipHostFree(hp);
     if (c->l2.h_lens)
@@ -466,12 +493,17 @@ uint64_t agc_hip_splitters_count(const agc_hip_ctx *c) { return c ? c->spl.size(
 // sorts the raw hits and applies the reference's "reset the k-mer after a hit" rule (agc_compressor.cpp:2029): the next hit of the
 // same contig must end at least k symbols later
 static int deliver_hits(agc_hip_ctx *c, uint32_t n_found, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap, uint64_t *h_n_hits,
-                        uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+                        uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc, const void *d_hits = nullptr,
+                        hipStream_t stream = nullptr)
 {
+    if (!d_hits) {
+        d_hits = c->d_hits.p;
+        stream = c->stream;
+    }
     std::vector<ScanHit> hits(n_found);
     if (n_found) {
-        HIPCHK(c, hipMemcpyAsync(hits.data(), c->d_hits.p, (size_t)n_found * sizeof(ScanHit), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(hits.data(), d_hits, (size_t)n_found * sizeof(ScanHit), hipMemcpyDeviceToHost, stream));
+        HIPCHK(c, hipStreamSynchronize(stream));
     }
     // by position (positions are unique): LSD radix sort, 11 bits a pass, as many passes as the largest position needs
     if (n_found > 1) {
@@ -775,6 +807,127 @@ int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         dev_cap = n_found;
     }
     return deliver_hits(c, n_found, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
+}
+
+// The next sample ahead of its turn (include/agc_hip.h): expansion + packed scan queued on the prefetch stream, nothing waited for.
+int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint8_t **d_codes)
+{
+    if (!c || !pk || !h_ctg_off || !d_codes || !n_ctg || k < 16 || k > 32 || !pk->d_words || !pk->d_esc_index || !pk->n_symbols ||
+        h_ctg_off[n_ctg] > pk->n_symbols)
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    agc_hip_ctx::Prefetch &pf = c->pf;
+    if (!pf.stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
+        HIPCHK(c, hipHostMalloc((void **)&pf.h_count, 64, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreate(&pf.e0));
+        HIPCHK(c, hipEventCreate(&pf.e1));
+    }
+    HIPCHK(c, hipStreamSynchronize(pf.stream)); // (a prefetch nobody asked for again: its kernels must be done before its buffers go)
+    pf.valid = false;
+    if (!c->d_table.p)
+        CHK(splitters_upload(c));
+    CHK(sbloom_upload(c, k));
+    pf.cur ^= 1;
+    DevBuf &stage = pf.d_sample[pf.cur];
+    CHK(ensure(c, stage, pk->n_symbols + 64 + 4096, pf.stream));
+    const PackedView pv = {pk->d_words, pk->d_esc_index, pk->d_esc_bytes, pk->n_symbols};
+    const uint64_t n_blocks = (pk->n_symbols + PACK_BLOCK - 1) / PACK_BLOCK;
+    pf.timed = c->timing;
+    if (pf.timed)
+        HIPCHK(c, hipEventRecord(pf.e0, pf.stream));
+    hipLaunchKernelGGL(expand_codes_kernel, dim3((uint32_t)std::min<uint64_t>((n_blocks + 3) / 4, 65536)), dim3(256), 0, pf.stream, pv, (uint8_t *)stage.p);
+    HIPCHK(c, hipGetLastError());
+    // the scan: as agc_hip_scan_packed_dev, own scratch, nothing waited for
+    const uint64_t total = h_ctg_off[n_ctg] - h_ctg_off[0];
+    const uint64_t target_waves = 4096ULL * 4;
+    uint64_t range_len = (total / target_waves + PACK_BLOCK - 1) / PACK_BLOCK * PACK_BLOCK;
+    range_len = std::min<uint64_t>(std::max<uint64_t>(range_len, 8 * PACK_BLOCK), 256 * PACK_BLOCK);
+    std::vector<ScanRange> ranges;
+    for (uint32_t ci = 0; ci < n_ctg; ++ci) {
+        const uint64_t b = h_ctg_off[ci], e = h_ctg_off[ci + 1];
+        if (e < b)
+            return AGC_HIP_EINVAL;
+        if (e - b < k)
+            continue;
+        for (uint64_t p = b; p < e;) {
+            uint64_t q = (p + range_len) & ~(uint64_t)(PACK_BLOCK - 1);
+            if (q >= e || e - q < PACK_BLOCK)
+                q = e;
+            ranges.push_back({b, e, p, q});
+            p = q;
+        }
+    }
+    pf.scanned = !ranges.empty() && ranges.size() <= 0x7fffffffULL;
+    *pf.h_count = 0;
+    if (pf.scanned) {
+        CHK(ensure(c, pf.d_ranges, ranges.size() * sizeof(ScanRange), pf.stream));
+        CHK(ensure(c, pf.d_counter, 64, pf.stream));
+        pf.dev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(total / 1000 + 4096, pf.d_hits.cap / sizeof(ScanHit)), 1u << 30);
+        CHK(ensure(c, pf.d_hits, (size_t)pf.dev_cap * sizeof(ScanHit), pf.stream));
+        // (the ranges go through a pageable vector: the copy is staged by the runtime before the call returns)
+        HIPCHK(c, hipMemcpyAsync(pf.d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), hipMemcpyHostToDevice, pf.stream));
+        HIPCHK(c, hipMemsetAsync(pf.d_counter.p, 0, 4, pf.stream));
+        static bool lds_set = false;
+        if (!lds_set) {
+            HIPCHK(c, hipFuncSetAttribute((const void *)scan_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SBLOOM_WORDS * 4));
+            lds_set = true;
+        }
+        ScanPackedArgs a;
+        a.pv = pv;
+        a.ranges = (const ScanRange *)pf.d_ranges.p;
+        a.n_ranges = (uint32_t)ranges.size();
+        a.k = k;
+        a.table = (const uint64_t *)c->d_table.p;
+        a.table_mask = c->table_mask;
+        a.sbloom = (const uint32_t *)c->d_sbloom.p;
+        a.bloom2 = (const uint32_t *)c->d_bloom2.p;
+        a.hits = (ScanHit *)pf.d_hits.p;
+        a.n_hits = (uint32_t *)pf.d_counter.p;
+        a.cap = pf.dev_cap;
+        const uint32_t grid = grid_for((uint32_t)ranges.size(), 16, 256);
+        hipLaunchKernelGGL(scan_packed_kernel, dim3(grid), dim3(1024), SBLOOM_WORDS * 4, pf.stream, a);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(pf.h_count, pf.d_counter.p, 4, hipMemcpyDeviceToHost, pf.stream));
+    }
+    if (pf.timed)
+        HIPCHK(c, hipEventRecord(pf.e1, pf.stream));
+    pf.words = pk->d_words;
+    pf.n_symbols = pk->n_symbols;
+    pf.k = k;
+    pf.n_ctg = n_ctg;
+    pf.first_off = h_ctg_off[0];
+    pf.last_off = h_ctg_off[n_ctg];
+    pf.valid = true;
+    *d_codes = (uint8_t *)stage.p;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_scan_prefetched(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap,
+                            uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+{
+    if (!c || !pk || !h_ctg_off || !h_n_hits)
+        return AGC_HIP_EINVAL;
+    agc_hip_ctx::Prefetch &pf = c->pf;
+    if (!pf.valid || pf.words != pk->d_words || pf.n_symbols != pk->n_symbols || pf.k != k || pf.n_ctg != n_ctg || pf.first_off != h_ctg_off[0] ||
+        pf.last_off != h_ctg_off[n_ctg])
+        return AGC_HIP_EINVAL; // nothing, or something else, was prefetched
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(pf.stream));
+    if (pf.timed) { // (expansion + scan of the prefetch: accounted to the scan row)
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, pf.e0, pf.e1);
+        c->ms[AGC_HIP_K_SCAN] += ms;
+        c->launches[AGC_HIP_K_SCAN] += 1;
+        pf.timed = false;
+    }
+    *h_n_hits = 0;
+    if (!pf.scanned)
+        return AGC_HIP_OK;
+    const uint32_t n_found = *pf.h_count;
+    if (n_found > pf.dev_cap) // (more hits than the list held: the scan again, the ordinary way)
+        return agc_hip_scan_packed_dev(c, pk, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
+    return deliver_hits(c, n_found, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc, pf.d_hits.p, pf.stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -94,6 +94,10 @@ int agc_cmp_add_sample_packed_dev(void *h, const char *sample_name, uint32_t n_c
         names.emplace_back(contig_names[i]);
     return ((CAGCCompressor *)h)->AddSamplePackedDevice(sample_name, names, packed, ctg_off) ? 1 : 0;
 }
+int agc_cmp_set_next_sample_packed_dev(void *h, const void *packed, const uint64_t *ctg_off, uint32_t n_ctg)
+{
+    return ((CAGCCompressor *)h)->SetNextSamplePackedDevice(packed, ctg_off, n_ctg) ? 1 : 0;
+}
 int agc_cmp_commit_prepared(void *h) { return ((CAGCCompressor *)h)->CommitPrepared() ? 1 : 0; }
 
 int agc_cmp_close_collect_packs(void *h, const uint8_t **src, const uint64_t **off, uint32_t *n)

@@ -534,15 +534,50 @@ bool CAGCCompressor::PrepareSamplePackedDevice(const std::string &sample_name, c
     if (!I.created || !packed)
         return false;
     const agc_hip_packed &pk = *(const agc_hip_packed *)packed;
-    // byte staging copy for the LZ kernels (context-owned buffer, valid until the next sample)
+    // byte staging copy for the LZ kernels (context-owned buffer, valid until the next sample): made ahead of time when this is
+    // the sample that was announced (its scan is then collected instead of launched: scan_batch)
     uint8_t *d_codes = nullptr;
-    if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, pk.n_symbols + 64, &d_codes)), "sample_buffer") ||
-        !I.hip_ok(DEVTI(agc_hip_expand_dev(I.hip, &pk, d_codes)), "expand"))
+    I.scan_from_prefetch = false;
+    if (I.pf_live.valid && I.pf_live.pk.d_words == pk.d_words && I.pf_live.pk.n_symbols == pk.n_symbols &&
+        I.pf_live.ctg_off.size() == contig_names.size() + 1 && std::equal(I.pf_live.ctg_off.begin(), I.pf_live.ctg_off.end(), ctg_off)) {
+        d_codes = I.pf_live.d_codes;
+        I.scan_from_prefetch = true;
+    } else if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, pk.n_symbols + 64, &d_codes)), "sample_buffer") ||
+               !I.hip_ok(DEVTI(agc_hip_expand_dev(I.hip, &pk, d_codes)), "expand"))
         return false;
+    I.pf_live.valid = false;
     I.packed_sample = pk;
     const bool ok = PrepareSampleDevice(sample_name, contig_names, d_codes, ctg_off);
     I.packed_sample.n_symbols = 0; // (scans of the commit phase -- adaptive mode -- run inside PrepareSampleDevice as well)
+    I.scan_from_prefetch = false;
     return ok;
+}
+
+bool CAGCCompressor::SetNextSamplePackedDevice(const void *packed, const uint64_t *ctg_off, uint32_t n_ctg)
+{
+    Impl &I = *p;
+    I.pf_next.valid = false;
+    if (!I.created || !packed || !ctg_off || !n_ctg || I.adaptive || I.appending || I.concatenated || I.k < 16)
+        return false;
+    I.pf_next.pk = *(const agc_hip_packed *)packed;
+    I.pf_next.ctg_off.assign(ctg_off, ctg_off + n_ctg + 1);
+    I.pf_next.valid = I.pf_next.pk.n_symbols != 0;
+    return I.pf_next.valid;
+}
+
+// queues the announced sample's expansion + scan on the device (called once the current sample's own scan is in)
+void CAGCCompressor::Impl::launch_prefetch()
+{
+    if (!pf_next.valid)
+        return;
+    pf_next.valid = false;
+    uint8_t *d = nullptr;
+    if (agc_hip_prefetch_packed_dev(hip, &pf_next.pk, pf_next.ctg_off.data(), (uint32_t)pf_next.ctg_off.size() - 1, k, &d) != AGC_HIP_OK)
+        return; // (nothing lost: the sample goes the ordinary way when its turn comes)
+    pf_live.pk = pf_next.pk;
+    pf_live.ctg_off.swap(pf_next.ctg_off);
+    pf_live.d_codes = d;
+    pf_live.valid = true;
 }
 
 // scan + classification + speculative encode of a sample, against the state this process has NOW; nothing is registered

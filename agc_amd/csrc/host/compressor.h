@@ -100,6 +100,12 @@ public:
                                    const uint64_t *ctg_off);
     bool AddSamplePackedDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const void *packed,
                                const uint64_t *ctg_off);
+    // The caller that knows its NEXT packed sample says so before it adds the current one: the next sample's expansion and splitter
+    // scan are queued on the device (include/agc_hip.h: agc_hip_prefetch_packed_dev) as soon as the current sample's scan is in,
+    // and run beside its classification / encode / registration -- the reference's workers likewise take contigs of later samples
+    // from the queue while earlier ones register (agc_compressor.cpp:1093-1272).  The announced sample must then be the next one
+    // added (otherwise the work is dropped); not used in adaptive mode (new splitters change later scans).
+    bool SetNextSamplePackedDevice(const void *packed, const uint64_t *ctg_off, uint32_t n_ctg);
 
     // src/core/agc_compressor.cpp:2094-2115 (close_compression) + ~CArchive
     bool Close(uint32_t no_threads);

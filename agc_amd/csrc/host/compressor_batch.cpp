@@ -411,8 +411,10 @@ int CAGCCompressor::Impl::scan_batch(const std::vector<uint64_t> &ctg_off, uint3
         }
         cap = h_ctg.size();
         int rc = (packed_sample.n_symbols && k >= 16)
-                     ? DEVT(agc_hip_scan_packed_dev(hip, &packed_sample, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(),
-                                                    h_dir.data(), h_rc.data()))
+                     ? (scan_from_prefetch ? DEVT(agc_hip_scan_prefetched(hip, &packed_sample, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(),
+                                                                          h_pos.data(), h_dir.data(), h_rc.data()))
+                                           : DEVT(agc_hip_scan_packed_dev(hip, &packed_sample, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(),
+                                                                          h_pos.data(), h_dir.data(), h_rc.data())))
                      : DEVT(agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
                                                      h_rc.data()));
         if (rc == AGC_HIP_ECAP) {
@@ -421,6 +423,7 @@ int CAGCCompressor::Impl::scan_batch(const std::vector<uint64_t> &ctg_off, uint3
         }
         if (!hip_ok(rc, "scan_contigs"))
             return rc;
+        launch_prefetch(); // the announced next sample: its expansion + scan run beside the rest of this one
         return AGC_HIP_OK;
     }
 }

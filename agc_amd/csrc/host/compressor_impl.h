@@ -771,6 +771,15 @@ struct CAGCCompressor::Impl {
     std::unique_ptr<BatchState> prepared;
     std::vector<Contig> prepared_ctgs;
     std::vector<uint64_t> changed_log;
+    // the next sample, announced by SetNextSamplePackedDevice (pf_next) / already queued on the device (pf_live: its staging copy)
+    struct NextSample {
+        agc_hip_packed pk{};
+        std::vector<uint64_t> ctg_off;
+        uint8_t *d_codes = nullptr;
+        bool valid = false;
+    } pf_next, pf_live;
+    bool scan_from_prefetch = false;   // the sample being prepared is pf_live: its first scan is collected, not launched
+    void launch_prefetch();
     agc_hip_packed packed_sample{};    // the sample being prepared is resident in the 2-bit layout (n_symbols != 0): scans read it
     bool gpu_zstd = false;             // delta packs are entropy-coded on the GPU (libzstd 1.4.x frames; AGC_AMD_HOST_ZSTD=1 turns it off)
     // share of the pack bytes the device takes when both engines run (AGC_AMD_GPU_ZSTD_SHARE fixes it); the start value is the

@@ -47,6 +47,7 @@ def bind(L):
     L.agc_cmp_prepare_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_prepare_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_add_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
+    L.agc_cmp_set_next_sample_packed_dev.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32]
     L.agc_cmp_commit_prepared.argtypes = [vp]
     L.agc_cmp_append.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32]
     return L
@@ -116,6 +117,11 @@ class Compressor:
         off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
         if not self.L.agc_cmp_add_sample_packed_dev(self.h, sample_name.encode(), n, names, C.byref(packed), off.ctypes.data_as(C.POINTER(C.c_uint64))):
             raise RuntimeError("AddSamplePackedDevice failed (see stderr)")
+
+    def set_next_sample_packed_dev(self, packed, ctg_off):
+        """the packed sample that will be added after the next add call: its expansion + scan run ahead on the device"""
+        off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+        return bool(self.L.agc_cmp_set_next_sample_packed_dev(self.h, C.byref(packed), off.ctypes.data_as(C.POINTER(C.c_uint64)), off.size - 1))
 
     def prepare_sample_packed_dev(self, sample_name, contig_names, packed, ctg_off):
         n = len(contig_names)

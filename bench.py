@@ -57,6 +57,7 @@ def parse():
                     help="N > 1: one independent archive shard per rank (no collective) instead of the default: all ranks feed ONE "
                          "archive (ordered commit from broadcast commit records, entropy stage spread over the ranks' GPUs; agc_amd/dist.py)")
     ap.add_argument("--single-archive", action="store_true", help="(the default for N > 1; kept for older command lines)")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not announce the next sample (its expansion + scan then run inside its own step)")
     ap.add_argument("--verify-entropy", action="store_true",
                     help="CHECKING RUN, not a measurement: every frame the device entropy stage returns (all the packs of this run's Close) is "
                          "compressed again by the host's libzstd 1.4.9 at level 17 and compared byte for byte (AGC_AMD_VERIFY_DEV_FRAMES); "
@@ -300,6 +301,11 @@ def main():
     def add_step(s, tag):
         """one step = one sample per GPU; in single-archive mode the N samples of a step are committed in rank order"""
         if not single:
+            # the next sample is known (as a reader that runs ahead of the compressor knows its next file): its expansion and
+            # splitter scan are queued on the device beside this sample's classification / encode / registration.  Not across
+            # the warm-up / timed boundary: every timed sample's scan runs inside the timed region.
+            if s + 1 < n_steps and s + 1 != args.warmup and not args.no_prefetch:
+                cmp_.set_next_sample_packed_dev(samples[s + 1][0], off)
             cmp_.add_sample_packed_dev(f"{tag}{rank}_{s}", names, samples[s][0], off)
             return
         dc.compress(1 + (s + 1) * world, get_sample, start=1 + s * world)  # (each step: the N samples prepared in parallel)

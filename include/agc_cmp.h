@@ -45,6 +45,10 @@ int agc_cmp_add_sample_packed_dev(void *h, const char *sample_name, uint32_t n_c
                                   const uint64_t *ctg_off);
 int agc_cmp_prepare_sample_packed_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const void *packed,
                                       const uint64_t *ctg_off);
+/* announces the packed sample that will be added NEXT: its expansion and splitter scan run on the device beside the sample
+ * added in between (the reference's workers take later contigs from the queue while earlier ones register,
+ * agc_compressor.cpp:1093-1272); 0 when not applicable (adaptive / append / -c mode): the sample then goes the ordinary way */
+int agc_cmp_set_next_sample_packed_dev(void *h, const void *packed, const uint64_t *ctg_off, uint32_t n_ctg);
 /* CAGCCompressor::Close (agc_compressor.cpp:2094-2115, 2386-2400) */
 int agc_cmp_close(void *h, uint32_t n_threads);
 /* The entropy stage runs beside the add calls (the reference's workers compress a pack when it fills while the others go on,

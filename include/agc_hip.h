@@ -145,6 +145,19 @@ int agc_hip_expand_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, uint8_t *d_co
 int agc_hip_scan_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
                             uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos,
                             uint64_t *h_hit_dir, uint64_t *h_hit_rc);
+/* The NEXT sample ahead of its turn.  The reference's workers take contigs of later samples from the priority queue while
+ * earlier ones are being registered (src/core/agc_compressor.cpp:1093-1272); here the caller that knows its next sample hands
+ * it over early: agc_hip_prefetch_packed_dev QUEUES, on a stream of its own and without waiting, the expansion of the 2-bit
+ * words into one of two context-owned byte staging buffers (*d_codes: what the LZ entry points take as d_base for that
+ * sample; valid until the prefetch after next) and the splitter scan of agc_hip_scan_packed_dev into a hit list of its own --
+ * they run in the gaps the entry points of the sample in front leave on the GPU.  agc_hip_scan_prefetched then waits for that
+ * work and delivers the hits exactly as agc_hip_scan_packed_dev would (same arguments, same results; AGC_HIP_EINVAL when
+ * this sample was not the one prefetched).  The splitter set must not change in between (not for adaptive mode). */
+int agc_hip_prefetch_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                                uint8_t **d_codes);
+int agc_hip_scan_prefetched(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                            uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir,
+                            uint64_t *h_hit_rc);
 
 /* ---- S2: LZ-diff against group references (a10, a11, a6, a7) ---------- */
 /* A "slice" names one sequence inside a device buffer: symbols

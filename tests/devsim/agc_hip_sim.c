@@ -53,6 +53,11 @@ struct agc_hip_ctx {
     u64 *enc_off;
     u8 *enc_rc;
     const u8 *enc_base;
+    /* the next sample ahead of its turn: two staging buffers, the identity of what was prefetched */
+    u8 *pf_buf[2];
+    u64 pf_cap[2];
+    int pf_cur;
+    const void *pf_words;
 };
 
 static int cmp_u64(const void *a, const void *b)
@@ -534,6 +539,31 @@ int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     const int r = agc_hip_scan_contigs_dev(c, codes, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
     free(codes);
     return r;
+}
+
+/* the prefetch entry points: the stand-in expands at once and scans when asked (same results, no concurrency) */
+int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint8_t **d_codes)
+{
+    if (!c || !pk || !h_ctg_off || !d_codes || !n_ctg || k < 16 || !pk->n_symbols)
+        return AGC_HIP_EINVAL;
+    c->pf_cur ^= 1;
+    if (c->pf_cap[c->pf_cur] < pk->n_symbols + 64) {
+        free(c->pf_buf[c->pf_cur]);
+        c->pf_cap[c->pf_cur] = pk->n_symbols + pk->n_symbols / 4 + 64;
+        c->pf_buf[c->pf_cur] = (u8 *)malloc(c->pf_cap[c->pf_cur]);
+    }
+    agc_hip_expand_dev(c, pk, c->pf_buf[c->pf_cur]);
+    memset(c->pf_buf[c->pf_cur] + pk->n_symbols, 4, 64);
+    c->pf_words = pk->d_words;
+    *d_codes = c->pf_buf[c->pf_cur];
+    return AGC_HIP_OK;
+}
+int agc_hip_scan_prefetched(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap,
+                            uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+{
+    if (!c || !pk || c->pf_words != pk->d_words)
+        return AGC_HIP_EINVAL;
+    return agc_hip_scan_packed_dev(c, pk, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
 }
 
 /* a1 on the stand-in: the oracle's preprocess_raw_contig */

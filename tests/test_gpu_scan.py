@@ -166,6 +166,48 @@ def test_packed_scan_matches_oracle(hip_ctx, oracle, k):
     assert np.array_equal(out[:codes.size].cpu().numpy(), codes)
 
 
+@pytest.mark.parametrize("k", [21, 31])
+def test_prefetched_scan_matches_oracle(hip_ctx, oracle, k):
+    """agc_hip_prefetch_packed_dev + agc_hip_scan_prefetched (the next sample's expansion and scan queued ahead on their own
+    stream) deliver what the oracle's scan reports and the symbols the pack held; two prefetches in a row alternate the staging
+    buffers; a scan_prefetched for another sample is refused"""
+    import ctypes as C
+    import torch
+    from agc_amd import capi
+    rng = np.random.default_rng(900 + k)
+    hip_ctx.splitters_set(_packed_case(oracle, rng, k)[0])
+    cases = []
+    for _ in range(3):
+        spl, contigs = _packed_case(oracle, rng, k)
+        cases.append(contigs)
+    hip_ctx.splitters_set(spl)
+    ptrs = []
+    packed = []
+    for contigs in cases:
+        off = np.zeros(len(contigs) + 1, np.uint64)
+        off[1:] = np.cumsum([c.size for c in contigs])
+        codes = np.concatenate(contigs)
+        d = torch.from_numpy(codes).cuda()
+        torch.cuda.synchronize()
+        pk, keep = hip_ctx.pack_dev(d)
+        packed.append((pk, keep, off, codes, contigs))
+    for i, (pk, keep, off, codes, contigs) in enumerate(packed):
+        d_codes = hip_ctx.prefetch_packed_dev(pk, off, k)
+        ptrs.append(d_codes)
+        if i == 0:  # another sample than the one in flight
+            other = packed[1]
+            n = C.c_uint64()
+            rc = hip_ctx.L.agc_hip_scan_prefetched(hip_ctx.h, C.byref(other[0]), capi._p(other[2], capi.u64p), other[2].size - 1, k, 0, C.byref(n), None, None, None, None)
+            assert rc == capi.EINVAL
+        got = hip_ctx.scan_prefetched(pk, off, k)
+        want = _oracle_hits(oracle, contigs, k, spl)
+        for g, w, name in zip(got, want, ("ctg", "pos", "dir", "rc")):
+            assert np.array_equal(g, w), (i, name)
+        back, _ = hip_ctx.fetch_slices_dev(d_codes, [0], [codes.size])  # (the library's own stream: after the prefetch was waited for)
+        assert np.array_equal(back, codes), i
+    assert ptrs[0] != ptrs[1]  # two staging buffers in turn
+
+
 def test_packed_scan_equals_byte_scan_on_a_big_sample(hip_ctx, oracle):
     """size-independent property at a larger size: the two scan kernels agree (50 Mbp, 6 contigs, a few escaped blocks)"""
     import torch

@@ -202,6 +202,7 @@ sim.agc_hip_pack_dev.argtypes = [ct.c_void_p] * 2 + [ct.c_uint64] + [ct.c_void_p
 cmp_ = host.Compressor(lib=lib)
 cmp_.create(out, pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"], min_match_len=opt["-l"], n_threads=2)
 ctx = ct.c_void_p(1)  # the stand-in's pack entry point only checks for a context pointer
+packed, keep = [], []
 for f in files:
     names, codes, off = fasta.read_codes(f)
     n = codes.size
@@ -210,16 +211,22 @@ for f in files:
     esc = np.zeros((n // 1024 + 2) * 1024, np.uint8)
     cnt = np.zeros(1, np.uint64)
     assert sim.agc_hip_pack_dev(ctx, codes.ctypes.data, n, words.ctypes.data, index.ctypes.data, esc.ctypes.data, n // 1024 + 2, cnt.ctypes.data) == 0
-    pk = capi.Packed(words.ctypes.data, index.ctypes.data, esc.ctypes.data, n)
-    cmp_.add_sample_packed_dev(fasta.sample_name(f), names, pk, off)
+    keep.append((words, index, esc))
+    packed.append((fasta.sample_name(f), names, capi.Packed(words.ctypes.data, index.ctypes.data, esc.ctypes.data, n), off))
+announce = int(sys.argv[5])  # 0: never; 1: the next sample before every add; 2: sometimes the WRONG one (must be dropped, not used)
+for i, (sn, names, pk, off) in enumerate(packed):
+    if announce and i + 1 < len(packed) and all(len(x[1]) for x in packed):
+        j = i + 1 if (announce == 1 or i % 2 == 0 or i + 2 >= len(packed)) else i + 2
+        cmp_.set_next_sample_packed_dev(packed[j][2], packed[j][3])
+    cmp_.add_sample_packed_dev(sn, names, pk, off)
 cmp_.close()
 cmp_.close_handle()
 """
 
 
-@pytest.mark.parametrize("overlap", ["off", "early"])
+@pytest.mark.parametrize("overlap,announce", [("off", 0), ("early", 0), ("off", 1), ("off", 2)])
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_snp", "syn_shuffled"])
-def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, overlap, tmp_path, monkeypatch):
+def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, overlap, announce, tmp_path, monkeypatch):
     """AddSamplePackedDevice: every sample handed over in the 2-bit layout (escaped blocks for N runs / IUPAC codes, contigs at
     arbitrary symbol offsets); the archive must be the one the reference CLI writes from the FASTA files.  (In a child process:
     the host library linked with the CPU stand-in must not meet the product's libagc_hip.so of the same name.)"""
@@ -234,6 +241,7 @@ def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, over
     out = str(tmp_path / "packed.agc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.setenv("AGC_AMD_ENCODE_OVERLAP", overlap)  # (one registration per window here: the overlapped encode runs)
-    subprocess.check_call([sys.executable, "-c", _PACKED_CHILD, root, json.dumps(opt), json.dumps(files), out])
+    # announce: SetNextSamplePackedDevice before every add (the next sample's expansion + scan queued ahead), also with a wrong guess
+    subprocess.check_call([sys.executable, "-c", _PACKED_CHILD, root, json.dumps(opt), json.dumps(files), out, str(announce)])
     got = open(out, "rb").read()
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
