@@ -418,12 +418,11 @@ int CAGCCompressor::Impl::scan_batch(const std::vector<uint64_t> &ctg_off, uint3
                      : DEVT(agc_hip_scan_contigs_dev(hip, d_base, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(), h_pos.data(), h_dir.data(),
                                                      h_rc.data()));
         if (rc == AGC_HIP_ECAP) {
-            cap = n_hits;
+            cap = n_hits + n_hits / 8 + 64; // (headroom: a retry scans again)
             continue;
         }
         if (!hip_ok(rc, "scan_contigs"))
             return rc;
-        launch_prefetch(); // the announced next sample: its expansion + scan run beside the rest of this one
         return AGC_HIP_OK;
     }
 }
@@ -546,7 +545,7 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
         int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), b.d_base, off.data(), len.data(), rc.data(), enc.data() + base, cap,
                                                  eoff.data()));
         if (r == AGC_HIP_ECAP) {
-            cap = eoff[ne] + 64;
+            cap = eoff[ne] + eoff[ne] / 8 + 4096; // (headroom: the next sample's deltas are a little longer, and a retry runs the kernel again)
             continue;
         }
         if (!hip_ok(r, "lz_encode_batch"))
@@ -1221,6 +1220,9 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
     (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
     std::vector<Seg> &segs = seg_buf;
     LAP("splitpoints");
+    // the announced next sample: its expansion + scan are queued NOW -- the classification kernels of this sample are done, what
+    // follows is host work (placement, ordering, new group ids: ~2.5 ms at human scale) before the encode needs the GPU again
+    launch_prefetch();
     if (b.overlap_encode && overlap_mode == 2 && !b.enc_in_flight && !overlap_encode_begin(b))
         return false;
     // ---- add_segment, part 4: final placement + part numbers ----
@@ -1649,7 +1651,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
                 int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap,
                                                          eoff.data()));
                 if (r == AGC_HIP_ECAP) {
-                    cap = eoff[ne] + 64;
+                    cap = eoff[ne] + eoff[ne] / 8 + 4096; // (headroom: the next sample's deltas are a little longer, and a retry runs the kernel again)
                     continue;
                 }
                 if (!hip_ok(r, "lz_encode_batch"))
