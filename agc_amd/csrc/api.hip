@@ -1753,19 +1753,25 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             grp_g = (uint32_t)std::min(3, std::max(0, atoi(e)));
         if (grp_g == 1)
             grp_g = 0;
+        // three classes: one-lane kernel (inputs the group parser does not take: < 8 bytes; everything in background mode), groups
+        // with one-word records (inputs <= 16 KiB), groups with two-word records (the rest, up to one block)
+        auto cls = [&](uint32_t i) -> int {
+            if (!grp_g || !zs::grpEligible(jobs[i].cp, jobs[i].src_size))
+                return 0;
+            return zs::grpWide(jobs[i].cp, jobs[i].src_size) ? 2 : 1;
+        };
         std::vector<uint32_t> part;
         part.reserve(m);
-        uint32_t m_one = 0;
-        for (int pass = 0; pass < 2; ++pass)
+        uint32_t m_cls[3] = {0, 0, 0};
+        for (int want = 0; want < 3; ++want)
             for (uint32_t t = 0; t < m; ++t) {
                 const uint32_t i = order[done + t];
-                const bool grp = grp_g && zs::grpEligible(jobs[i].cp, jobs[i].src_size);
-                if (grp == (pass == 1))
+                if (cls(i) == want) {
                     part.push_back(i);
+                    ++m_cls[want];
+                }
             }
-        for (uint32_t t = 0; t < m; ++t)
-            m_one += !(grp_g && zs::grpEligible(jobs[part[t]].cp, jobs[part[t]].src_size));
-        const uint32_t m_grp = m - m_one;
+        const uint32_t m_one = m_cls[0], m_grp = m_cls[1], m_wide = m_cls[2];
         used = 0;
         for (uint32_t t = 0; t < m; ++t) {
             const uint32_t i = part[t];
@@ -1783,14 +1789,6 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
             ZTimer t(c);
             const uint32_t dbg = (uint32_t)(getenv("AGC_HIP_ZSTD_DEBUG") ? atoi(getenv("AGC_HIP_ZSTD_DEBUG")) : 0);
             const dim3 block(64);
-            // both kinds in one call: the one-lane launch (a few large inputs, as long as a whole launch of small frames) runs on
-            // a second stream BESIDE the group launch, after the uploads and before the results are read
-            const bool both = m_one && m_grp;
-            const hipStream_t zs1 = both ? c->zstream2 : zs_;
-            if (both) {
-                HIPCHK(c, hipEventRecord(c->zev_a, zs_));
-                HIPCHK(c, hipStreamWaitEvent(c->zstream2, c->zev_a, 0));
-            }
             if (m_one) {
                 // frames per wave: fewer = fewer distinct parser states per trip of the micro-step loop, but every wave of the
                 // launch must be resident at once (2 per SIMD = 2048 on 256 CUs) or the launch takes two rounds.  Measured per
@@ -1807,23 +1805,35 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                 const dim3 grid((m_one + lanes - 1) / lanes);
                 const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
                 if (c->zstd_background)
-                    hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs1, dj, m_one, (uint32_t *)c->d_zsize.p, lanes,
+                    hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs_, dj, m_one, (uint32_t *)c->d_zsize.p, lanes,
                                        (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
                 else // (frequency tables and the first matches of a request in LDS)
-                    hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs1, dj, m_one,
+                    hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs_, dj, m_one,
                                        (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             }
-            if (m_grp) {
-                const uint32_t gpw = 64 / grp_g; // groups (= frames) per wave
-                const dim3 grid((m_grp + gpw - 1) / gpw);
-                const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done + m_one;
-                if (grp_g == 2)
-                    hipLaunchKernelGGL((zstd_frames_grp_kernel<2, 2>), grid, block, zgrp_lds_bytes(gpw, 2), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
-                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
-                else
-                    hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw, 3), zs_, dj, m_grp, (uint32_t *)c->d_zsize.p, gpw,
-                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+            // both group classes in one call: side by side on two streams (a launch lasts as long as its longest frame)
+            const bool both = m_grp && m_wide;
+            const hipStream_t zs_w = both ? c->zstream2 : zs_;
+            if (both) {
+                HIPCHK(c, hipEventRecord(c->zev_a, zs_));
+                HIPCHK(c, hipStreamWaitEvent(c->zstream2, c->zev_a, 0));
             }
+            const uint32_t gpw = grp_g ? 64 / grp_g : 1; // groups (= frames) per wave
+            auto launch_grp = [&](uint32_t first, uint32_t count, bool wide, hipStream_t st) {
+                const dim3 grid((count + gpw - 1) / gpw);
+                const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done + first;
+                const uint32_t stride = wide ? ZGRP_REC_STRIDE_WIDE : ZGRP_REC_STRIDE;
+                if (grp_g == 2)
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<2, 2>), grid, block, zgrp_lds_bytes(gpw, 2, wide), st, dj, count, (uint32_t *)c->d_zsize.p, gpw,
+                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
+                else
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw, 3, wide), st, dj, count, (uint32_t *)c->d_zsize.p, gpw,
+                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
+            };
+            if (m_wide)
+                launch_grp(m_one + m_grp, m_wide, true, zs_w);
+            if (m_grp)
+                launch_grp(m_one, m_grp, false, zs_);
             if (both) {
                 HIPCHK(c, hipEventRecord(c->zev_b, c->zstream2));
                 HIPCHK(c, hipStreamWaitEvent(zs_, c->zev_b, 0));

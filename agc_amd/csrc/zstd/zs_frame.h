@@ -43,8 +43,8 @@ ZHD WsLayout wsLayout(const CParams &cp, U32 srcSize)
     o += align16(3 * ((size_t)srcSize / 3 + 16));
     L.ent = o;
     o += align16(sizeof(EntWs));
-    L.bkfw = o; // (two U16 per position of a chunk: zs_opt_grp.h)
-    o += align16(4 * (size_t)(OPT_NUM + 2));
+    L.bkfw = o; // (a U32 and a U16 per position of a chunk: zs_opt_grp.h)
+    o += align16(6 * (size_t)(OPT_NUM + 2) + 16);
     L.total = o;
     return L;
 }
@@ -207,8 +207,8 @@ template <int G> ZFN U32 compressFrameGrp(GLane *lanes, GrpX &sh, BYTE *ws, cons
         w.chainTable = (U32 *)(ws + L.chainTable);
         w.opt = (Optimal *)(ws + L.opt);
         w.matches = (Match *)(ws + L.matches);
-        w.bk = (U16 *)(ws + L.bkfw);
-        w.fw = w.bk + (OPT_NUM + 2);
+        w.bk = (U32 *)(ws + L.bkfw);
+        w.fw = (U16 *)(w.bk + (OPT_NUM + 2));
         w.litFreq = (U32 *)(ws + L.freqs);
 #if defined(__HIP_DEVICE_COMPILE__)
         w.litLengthFreq = fast_freqs; // (always LDS on the device: ONE address space behind the pointer)

@@ -32,7 +32,8 @@ struct OptWs {
     // optimal parser
     Optimal *opt;      // OPT_NUM + 1 entries
     Match *matches;    // OPT_NUM + 1 entries
-    U16 *bk, *fw;      // group parser (zs_opt_grp.h): per position of the chunk, the length of the sequence ending there / the position
+    U32 *bk;           // (32 bits: a run of literals can be as long as the block)
+    U16 *fw;           // group parser (zs_opt_grp.h): per position of the chunk, the length of the sequence ending there / the position
                        // the next sequence of the chosen path ends at (OPT_NUM + 2 entries each)
     Match *fastMatches; // the first fastMatchCap matches of a request live here instead (fast memory: LDS on the device)
     U32 fastMatchCap;

@@ -75,6 +75,7 @@ struct GLane {
     U32 j;             // lane of the group, 0 = leader
     U32 state;
     ZS_LDS_U32P recs;  // GRP_RC recorded tree stores (device: LDS)
+    bool wide;         // ... of two words each (slot, value) instead of one packed word: inputs beyond the btultra2 class
     // parser state (leader)
     U32 ip, anchor, cur, last_pos, adv;
     Optimal lastSequence;
@@ -111,6 +112,29 @@ struct GLane {
     U32 oldp_t0;       // ... and the first of those targets
 };
 
+// a recorded store in one word: slot < 2^15 (chainLog <= 15), value < 2^17 (index <= 2 * 16 KiB + 1) -- the btultra2 class
+ZFN U32 grpRecPack(U32 slot, U32 val) { return (val << 15) | slot; }
+ZFN void grpRecPut(GLane &l, U32 slot, U32 val)
+{
+    if (l.wide) {
+        l.recs[2 * l.nrec] = slot;
+        l.recs[2 * l.nrec + 1] = val;
+    } else
+        l.recs[l.nrec] = grpRecPack(slot, val);
+    l.nrec++;
+}
+ZFN void grpRecGet(const GLane &l, U32 r, U32 &slot, U32 &val)
+{
+    if (l.wide) {
+        slot = l.recs[2 * r];
+        val = l.recs[2 * r + 1];
+    } else {
+        const U32 x = l.recs[r];
+        slot = x & 0x7FFFu;
+        val = x >> 15;
+    }
+}
+
 ZFN U32 grpSel3(U32 a0, U32 a1, U32 a2, U32 i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
 
 ZFN void grpMSet(GLane &l, U32 i, U32 off, U32 len)
@@ -145,12 +169,14 @@ ZFN void grpMGet(const GLane &l, U32 i, U32 &off, U32 &len)
     }
 }
 
-// a recorded store: slot < 2^15 (chainLog <= 15), value < 2^17 (index <= 2 * 16 KiB + 1) -- the btultra2 class
-ZFN U32 grpRecPack(U32 slot, U32 val) { return (val << 15) | slot; }
+
+// (larger inputs -- up to one block: tree slots < 2^18, indices < 2^18 -- take two words per record: GLane::wide)
 ZHD bool grpEligible(const CParams &cp, U32 srcSize)
 {
-    return cp.chainLog <= 15 && srcSize <= (1u << 14) && cp.minMatch == 3 && cp.strategy >= STRAT_BTULTRA && srcSize >= 8;
+    return cp.minMatch == 3 && cp.strategy >= STRAT_BTULTRA && srcSize >= 8 && srcSize <= BLOCKSIZE_MAX && cp.chainLog <= 18;
 }
+// the packed one-word record holds the btultra2 class (inputs <= 16 KiB); everything else takes two words
+ZHD bool grpWide(const CParams &cp, U32 srcSize) { return !(cp.chainLog <= 15 && srcSize <= (1u << 14)); }
 
 ZFN void grpPublishBases(GrpX &sh, const OptWs &w)
 {
@@ -201,8 +227,9 @@ ZFN bool grpRecFull(GLane &l, U32 *bt)
     if (l.j != 0)
         return false;
     for (U32 r = 0; r < l.nrec; ++r) {
-        const U32 x = l.recs[r];
-        bt[x & 0x7FFFu] = x >> 15;
+        U32 slot, val;
+        grpRecGet(l, r, slot, val);
+        bt[slot] = val;
     }
     l.nrec = 0;
     l.rec = false;
@@ -301,7 +328,7 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
             const U32 ptr = smaller ? l.smallerPtr : l.largerPtr;
             if (ptr != SM_NOPTR) {
                 if (!UPD && l.rec)
-                    l.recs[l.nrec++] = grpRecPack(ptr, l.matchIndex);
+                    grpRecPut(l, ptr, l.matchIndex);
                 else
                     bt[ptr] = l.matchIndex;
             }
@@ -322,13 +349,13 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
     if (ended) {
         if (l.smallerPtr != SM_NOPTR) {
             if (!UPD && l.rec)
-                l.recs[l.nrec++] = grpRecPack(l.smallerPtr, 0);
+                grpRecPut(l, l.smallerPtr, 0);
             else
                 bt[l.smallerPtr] = 0;
         }
         if (l.largerPtr != SM_NOPTR) {
             if (!UPD && l.rec)
-                l.recs[l.nrec++] = grpRecPack(l.largerPtr, 0);
+                grpRecPut(l, l.largerPtr, 0);
             else
                 bt[l.largerPtr] = 0;
         }
@@ -374,7 +401,7 @@ ZFN void grpWalkFastLevel(GLane &l, const BYTE *src, const BYTE *iend, U32 *bt, 
         const U32 ptr = smaller ? l.smallerPtr : l.largerPtr;
         if (ptr != SM_NOPTR) {
             if (l.rec)
-                l.recs[l.nrec++] = grpRecPack(ptr, l.matchIndex);
+                grpRecPut(l, ptr, l.matchIndex);
             else
                 bt[ptr] = l.matchIndex;
         }
@@ -570,6 +597,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
 
     ZS_GRP_EACH(l)
     l.inChunk = false;
+    l.wide = grpWide(cp, srcSize);
     l.rec = false;
     l.grp = false;
     l.nrec = 0;
@@ -911,7 +939,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     l.oc.rep[2] = l.op.rep[2];
                 }
                 w.opt[l.g_cur] = l.oc;
-                w.bk[l.g_cur] = (U16)(l.oc.litlen + l.oc.mlen); // (what the chunk end's walk back reads: a compact copy)
+                w.bk[l.g_cur] = l.oc.litlen + l.oc.mlen; // (what the chunk end's walk back reads: a compact copy)
                 if (s + 1 < G) {
                     sh.oc_price = l.oc.price;
                     sh.oc_mlen = l.oc.mlen;
@@ -1126,8 +1154,9 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
             if (l.j < v) { // commit: the stores of ZSTD_insertBtAndGetAllMatches, the hash tables
                 U32 *const bt = w.chainTable;
                 for (U32 r = 0; r < l.nrec; ++r) {
-                    const U32 x = l.recs[r];
-                    bt[x & 0x7FFFu] = x >> 15;
+                    U32 slot, val;
+                    grpRecGet(l, r, slot, val);
+                    bt[slot] = val;
                 }
                 w.hashTable[l.h] = l.q_current;
                 bool later = false;

@@ -56,14 +56,19 @@ template __global__ void zstd_frames_kernel<2, true, true>(const ZFrameJob *, ui
 // ---- several lanes per frame (zstd/zs_opt_grp.h): G consecutive lanes = one group = one frame ----
 // LDS per wave: per group the exchange record + the three small frequency tables, per lane the record of a tree walk.
 constexpr uint32_t ZGRP_STRIDE = (zs::GRPX_WORDS + zs::FAST_FREQ_WORDS) | 1; // words per group (odd: neighbouring groups on different banks)
-constexpr uint32_t ZGRP_REC_STRIDE = zs::GRP_RC | 1;                          // words per lane
+constexpr uint32_t ZGRP_REC_STRIDE = zs::GRP_RC | 1;                          // words per lane (inputs <= 16 KiB: one word per record)
+constexpr uint32_t ZGRP_REC_STRIDE_WIDE = (2 * zs::GRP_RC) | 1;               // ... two words per record (zs::grpWide)
 // (G = 3: 21 groups -> 20 328 bytes: EIGHT waves per CU (160 KiB), i.e. 43 008 frames of a launch resident at once)
-__host__ __device__ static inline uint32_t zgrp_lds_bytes(uint32_t groups_per_wave, uint32_t g) { return (groups_per_wave * ZGRP_STRIDE + groups_per_wave * g * ZGRP_REC_STRIDE) * 4; }
+__host__ __device__ static inline uint32_t zgrp_lds_bytes(uint32_t groups_per_wave, uint32_t g, bool wide = false)
+{
+    return (groups_per_wave * ZGRP_STRIDE + groups_per_wave * g * (wide ? ZGRP_REC_STRIDE_WIDE : ZGRP_REC_STRIDE)) * 4;
+}
 
 template <int G, int WPS>
 __global__ void __launch_bounds__(64, WPS) zstd_frames_grp_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
                                                                  uint32_t groups_per_wave, const uint8_t *__restrict__ src_base,
-                                                                 uint8_t *__restrict__ dst_base, uint8_t *__restrict__ ws_base, uint32_t debug)
+                                                                 uint8_t *__restrict__ dst_base, uint8_t *__restrict__ ws_base, uint32_t debug,
+                                                                 uint32_t rec_stride)
 {
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     if (grp >= groups_per_wave)
@@ -76,14 +81,14 @@ __global__ void __launch_bounds__(64, WPS) zstd_frames_grp_kernel(const ZFrameJo
     zs::GrpX &sh = *(zs::GrpX *)gbase;
     zs::GLane l;
     l.j = j;
-    l.recs = (zs::ZS_LDS_U32P)(zs_lds + groups_per_wave * ZGRP_STRIDE + threadIdx.x * ZGRP_REC_STRIDE);
+    l.recs = (zs::ZS_LDS_U32P)(zs_lds + groups_per_wave * ZGRP_STRIDE + threadIdx.x * rec_stride);
     const ZFrameJob jb = jobs[job];
     const uint32_t n = zs::compressFrameGrp<G>(&l, sh, ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, debug, gbase + zs::GRPX_WORDS);
     if (j == 0)
         out_size[jb.idx] = n;
 }
-template __global__ void zstd_frames_grp_kernel<2, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
-template __global__ void zstd_frames_grp_kernel<3, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t);
+template __global__ void zstd_frames_grp_kernel<2, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
+template __global__ void zstd_frames_grp_kernel<3, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
 
 // frames (scattered, padded slots) -> one contiguous buffer in the caller's order
 __global__ void __launch_bounds__(256) zstd_gather_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, const uint64_t *__restrict__ dst_off,

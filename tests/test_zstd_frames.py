@@ -99,6 +99,18 @@ def test_group_parser_frames_equal_libzstd(zs, oracle, g):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("g", [2, 3])
+def test_group_parser_takes_inputs_up_to_one_block(zs, oracle, g):
+    """beyond the btultra2 class (> 16 KiB: btultra, one pass, deeper trees, tree slots and indices beyond 16 bits) the walks are
+    recorded with two words per store (zs::grpWide); full packs of a collection (100 deltas) are of that size"""
+    rng = np.random.default_rng(60 + g)
+    inputs = [p for p in ZC.corpus(oracle, 4000 + g, 96) if len(p) > 16384]
+    inputs += [ZC.delta_pack(oracle, rng, n, 60000, 1e-3) for n in (40, 100)] + [b"A" * 70000, b"ABC" * 30000, b"x" * 131072]
+    assert len(inputs) > 20
+    bad = [(i, len(p)) for i, p in enumerate(inputs) if _my_frame_grp(zs, p, g) != ZC.ref_frame(p)]
+    assert not bad, bad
+
+
 def test_parser_sequences_equal_generate_sequences(zs, oracle):
     rng = np.random.default_rng(7)
     for n_samp, seg in ((1, 60000), (20, 60000), (100, 60000), (100, 30000), (7, 5000)):

@@ -96,11 +96,11 @@ uint32_t zs_host_compress_grp(const uint8_t *src, uint32_t n, const uint32_t *cp
     if (!grpEligible(cp, n))
         return compressFrame(ws.data(), cp, src, n, dst);
     std::vector<GLane> lanes(3);
-    std::vector<U32> recs(3 * GRP_RC, 0xDEADBEEFu);
+    std::vector<U32> recs(3 * 2 * GRP_RC, 0xDEADBEEFu);
     memset((void *)lanes.data(), 0xA5, sizeof(GLane) * 3); // (lane state is not zeroed on the device either)
     for (int i = 0; i < 3; ++i) {
         lanes[i].j = (U32)i;
-        lanes[i].recs = recs.data() + (size_t)i * GRP_RC;
+        lanes[i].recs = recs.data() + (size_t)i * 2 * GRP_RC;
     }
     GrpX sh;
     memset(&sh, 0xA5, sizeof(sh));
