@@ -1484,11 +1484,14 @@ int agc_hip_lz_cost_vector_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t 
     HIPCHK(c, hipSetDevice(c->device));
     Batch b;
     CHK(prepare_batch(c, MODE_COSTVEC, n, h_gid, d_base, h_off, h_len, h_rc, h_prefix_costs, b));
-    CHK(ensure(c, c->d_scratch, b.out_total * 4 + 64));
+    CHK(ensure(c, c->d_scratch, b.out_total + 64)); // (one byte per position on the device: lz_kernels.hip, cost_t)
     CHK(launch_parse<MODE_COSTVEC>(c, n, nullptr, (uint32_t *)c->d_scratch.p));
+    std::vector<uint8_t> tmp(b.out_total);
     if (b.out_total)
-        HIPCHK(c, hipMemcpyAsync(h_costs, c->d_scratch.p, b.out_total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_scratch.p, b.out_total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint64_t i = 0; i < b.out_total; ++i)
+        h_costs[i] = tmp[i];
     return AGC_HIP_OK;
 }
 
@@ -1554,7 +1557,7 @@ int agc_hip_lz_split_point_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t 
     }
     Batch b;
     CHK(prepare_batch(c, MODE_COSTVEC, m, gid.data(), d_base, off.data(), len.data(), rc.data(), pf.data(), b));
-    CHK(ensure(c, c->d_scratch, b.out_total * 4 + 64));
+    CHK(ensure(c, c->d_scratch, b.out_total + 64));
     CHK(launch_parse<MODE_COSTVEC>(c, m, nullptr, (uint32_t *)c->d_scratch.p));
     std::vector<SplitJob> jobs(n);
     uint64_t o = 0;
@@ -1574,7 +1577,7 @@ int agc_hip_lz_split_point_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t 
     {
         KTimer t(c, AGC_HIP_K_COSTVEC);
         hipLaunchKernelGGL(split_point_kernel, dim3(n), dim3(256), 0, c->stream, (const SplitJob *)c->d_jobs.p,
-                           (const uint32_t *)c->d_scratch.p, d_pos, d_sum);
+                           (const cost_t *)c->d_scratch.p, d_pos, d_sum);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_best_pos, d_pos, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

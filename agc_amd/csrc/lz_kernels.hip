@@ -270,6 +270,10 @@ __device__ __forceinline__ uint32_t base_cost_match(uint32_t mml, uint32_t ref_p
 // The parse, one wavefront per segment.
 // ---------------------------------------------------------------------------
 enum { MODE_ENCODE = 0, MODE_ESTIMATE = 1, MODE_COSTVEC = 2 };
+// a per-position coding cost (GetCodingCostVector, lz_diff.cpp:159-284): 0 inside a run, 1 per literal, the token's length
+// (a few decimal digits and separators, <= 2 * 10 + 2) at one end of a match or N run -- ONE BYTE in HBM: the vectors are written
+// once and read by split_point_kernel; as 32-bit words they were 1.4 GB written + 2.1 GB read per 3 Gbp sample (round 2)
+typedef uint8_t cost_t;
 
 struct ParseOut {
     uint32_t value; // encode: delta length; estimate: cost; cost vector: number of costs
@@ -280,7 +284,7 @@ struct ParseOut {
 // index: a certain literal); nullptr: literal runs are found by probing the table (wide probe)
 template <int MODE>
 __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text, const uint32_t n,
-                             uint8_t *__restrict__ out, uint32_t *__restrict__ costs, const bool prefix_costs, uint8_t *win_lds,
+                             uint8_t *__restrict__ out, cost_t *__restrict__ costs, const bool prefix_costs, uint8_t *win_lds,
                              const unsigned long long *__restrict__ maybe)
 {
     const uint32_t lane = lane_id();
@@ -606,7 +610,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                         costs[o + t] = 0;
                     __builtin_amdgcn_s_waitcnt(0); // the run's zeros land before lane 0 stores its cost
                     if (writer)
-                        costs[prefix_costs ? o : o + nrun - 1] = tc;
+                        costs[prefix_costs ? o : o + nrun - 1] = (cost_t)tc;
                     o += nrun;
                 }
                 i += nrun;
@@ -785,7 +789,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 costs[o + t] = 0;
             __builtin_amdgcn_s_waitcnt(0);
             if (writer)
-                costs[prefix_costs ? o : o + len - 1] = tc;
+                costs[prefix_costs ? o : o + len - 1] = (cost_t)tc;
             o += len;
         }
         pred_pos = match_pos + len;
@@ -845,7 +849,7 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
     else if (MODE == MODE_ESTIMATE)
         r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, nullptr, false, win_lds, sd.maybe);
     else
-        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, out_u32 + sd.out_off, (sd.flags & 1u) != 0, win_lds, sd.maybe);
+        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, (cost_t *)out_u32 + sd.out_off, (sd.flags & 1u) != 0, win_lds, sd.maybe);
     AGC_TRACE(9, r.value);
     if (lane_id() == 0) {
         res_value[sd.pad] = r.value; // sd.pad = index in the caller's order
@@ -1205,20 +1209,48 @@ struct SplitJob {
     uint32_t pad;
 };
 
-__global__ void __launch_bounds__(256) split_point_kernel(const SplitJob *__restrict__ jobs, const uint32_t *__restrict__ costs,
+// eight consecutive costs of a vector read forwards (c[i0 .. i0+8)) or backwards (c[n-1-i0], c[n-2-i0] ...) in one 8-byte load;
+// positions >= n give 0
+__device__ inline void split_load8(const cost_t *__restrict__ c, uint32_t n, uint32_t i0, bool rev, uint32_t x[8])
+{
+    uint64_t w = 0;
+    if (i0 + 8 <= n) {
+        const cost_t *p = rev ? c + (n - 8 - i0) : c + i0;
+        uint64_t v;
+        memcpy(&v, p, 8);
+        w = rev ? __builtin_bswap64(v) : v;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            x[j] = (uint32_t)(w >> (8 * j)) & 0xFF;
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t i = i0 + j;
+            x[j] = i < n ? (uint32_t)(rev ? c[n - 1 - i] : c[i]) : 0u;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) split_point_kernel(const SplitJob *__restrict__ jobs, const cost_t *__restrict__ costs,
                                                           uint32_t *__restrict__ best_pos, uint32_t *__restrict__ best_sum)
 {
     const SplitJob jb = jobs[blockIdx.x];
     const uint32_t n = jb.n;
-    const uint32_t *c1 = costs + jb.off1, *c2 = costs + jb.off2;
+    const cost_t *c1 = costs + jb.off1, *c2 = costs + jb.off2;
     __shared__ uint32_t s_a[256], s_b[256];
     __shared__ uint32_t s_carry1, s_carry2, s_total2;
     const uint32_t tid = threadIdx.x;
+    constexpr uint32_t PER = 8;
 
     // total of c2
     uint32_t t2 = 0;
-    for (uint32_t i = tid; i < n; i += 256)
-        t2 += c2[i];
+    for (uint32_t base = 0; base < n; base += 256 * PER) {
+        uint32_t x[PER];
+        split_load8(c2, n, base + tid * PER, false, x);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j)
+            t2 += x[j];
+    }
     s_a[tid] = t2;
     __syncthreads();
     for (uint32_t o = 128; o > 0; o >>= 1) {
@@ -1235,23 +1267,16 @@ __global__ void __launch_bounds__(256) split_point_kernel(const SplitJob *__rest
     const uint32_t total2 = s_total2;
 
     uint32_t my_best = 0xFFFFFFFFu, my_pos = 0xFFFFFFFFu;
-    constexpr uint32_t PER = 8;
     for (uint32_t base = 0; base < n; base += 256 * PER) {
         const uint32_t b = base + tid * PER;
         uint32_t a1[PER], a2[PER];
         uint32_t sum1 = 0, sum2 = 0;
+        split_load8(c1, n, b, jb.rev1 != 0, a1);
+        split_load8(c2, n, b, jb.rev2 != 0, a2);
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
-            const uint32_t i = b + j;
-            uint32_t x1 = 0, x2 = 0;
-            if (i < n) {
-                x1 = jb.rev1 ? c1[n - 1 - i] : c1[i];
-                x2 = jb.rev2 ? c2[n - 1 - i] : c2[i];
-            }
-            a1[j] = x1;
-            a2[j] = x2;
-            sum1 += x1;
-            sum2 += x2;
+            sum1 += a1[j];
+            sum2 += a2[j];
         }
         s_a[tid] = sum1;
         s_b[tid] = sum2;
