@@ -32,7 +32,7 @@ SYMBOLS = [
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
     "agc_hip_ref_lag_counts_dev",
-    "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams",
+    "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_batch_dev", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams",
     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
     "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched",
 ]
@@ -113,6 +113,7 @@ def load():
     L.agc_hip_ref_lag_counts_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_zstd17_batch.argtypes = [vp, C.c_uint32, u8p, u64p, u8p, C.c_uint64, u64p]
     L.agc_hip_zstd17_cparams.argtypes = [C.c_uint64, u32p]
+    L.agc_hip_zstd17_batch_dev.argtypes = [vp, C.c_uint32, vp, u64p, u8p, C.c_uint64, u64p]
     L.agc_hip_zstd17_background.argtypes = [vp, C.c_int]
     L.agc_hip_zstd17_max_input.restype = C.c_uint32
     L.agc_hip_zstd17_resident_frames.argtypes = [vp]
@@ -430,6 +431,16 @@ class Context:
         if src.size == 0:
             src = np.zeros(1, np.uint8)
         self._chk(self.L.agc_hip_zstd17_batch(self.h, n, _p(src, u8p), _p(off, u64p), _p(dst, u8p), cap, _p(doff, u64p)))
+        return dst[:int(doff[-1])], doff
+
+    def zstd17_batch_raw_dev(self, d_src_ptr, off):
+        """the same with the packs already in HBM (d_src_ptr: device address of pack 0's first byte minus off[0])"""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = off.size - 1
+        cap = int(off[-1] - off[0]) + 32 * n + 64
+        dst = np.empty(cap, np.uint8)
+        doff = np.zeros(n + 1, np.uint64)
+        self._chk(self.L.agc_hip_zstd17_batch_dev(self.h, n, d_src_ptr, _p(off, u64p), _p(dst, u8p), cap, _p(doff, u64p)))
         return dst[:int(doff[-1])], doff
 
     def fetch_slices_dev(self, d_base, off, length, rc=None):

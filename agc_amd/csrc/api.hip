@@ -1684,8 +1684,9 @@ int agc_hip_zstd17_background(agc_hip_ctx *c, int on)
     return AGC_HIP_OK;
 }
 
-int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
-                         uint64_t *h_dst_off)
+// d_src_ext != nullptr: the inputs are in HBM already (input i = d_src_ext[h_src_off[i] .. h_src_off[i+1])); h_src is not looked at
+static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint8_t *d_src_ext, const uint64_t *h_src_off, uint8_t *h_dst,
+                             uint64_t dst_cap, uint64_t *h_dst_off)
 {
     if (!c || !h_dst_off || (n && (!h_src_off)))
         return AGC_HIP_EINVAL;
@@ -1695,7 +1696,7 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     HIPCHK(c, hipSetDevice(c->device));
     const hipStream_t zs_ = c->zstream; // (this call shares no buffer, stream or event with the other entry points)
     const uint64_t src_total = h_src_off[n] - h_src_off[0];
-    if (src_total && !h_src)
+    if (src_total && !h_src && !d_src_ext)
         return AGC_HIP_EINVAL;
     // per frame: parameters, workspace size; longest first so that the lanes of a wave finish together
     std::vector<ZFrameJob> jobs(n);
@@ -1725,11 +1726,13 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].src_size > jobs[b].src_size; });
 
-    CHK(ensure_z(c, c->d_zsrc, src_total + 64));
+    if (!d_src_ext)
+        CHK(ensure_z(c, c->d_zsrc, src_total + 64));
+    const uint8_t *const d_src = d_src_ext ? d_src_ext + h_src_off[0] : (const uint8_t *)c->d_zsrc.p;
     CHK(ensure_z(c, c->d_zdst, dst_total + 64));
     CHK(ensure_z(c, c->d_zsize, (size_t)n * 4));
     CHK(ensure_z(c, c->d_zjobs, (size_t)n * sizeof(ZFrameJob)));
-    if (src_total)
+    if (src_total && !d_src_ext)
         HIPCHK(c, hipMemcpyAsync(c->d_zsrc.p, h_src + h_src_off[0], src_total, hipMemcpyHostToDevice, zs_));
     // workspace arena: as many frames per launch as the budget allows (a frame's tables must be zero at its start)
     size_t free_b = 0, total_b = 0;
@@ -1809,10 +1812,10 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                 const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
                 if (c->zstd_background)
                     hipLaunchKernelGGL((zstd_frames_kernel<2, false>), grid, block, 0, zs_, dj, m_one, (uint32_t *)c->d_zsize.p, lanes,
-                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+                                       d_src, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
                 else // (frequency tables and the first matches of a request in LDS)
                     hipLaunchKernelGGL((zstd_frames_kernel<2, true, true>), grid, block, (size_t)lanes * zs::FAST_WORDS * 4, zs_, dj, m_one,
-                                       (uint32_t *)c->d_zsize.p, lanes, (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
+                                       (uint32_t *)c->d_zsize.p, lanes, d_src, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg);
             }
             // both group classes in one call: side by side on two streams (a launch lasts as long as its longest frame)
             const bool both = m_grp && m_wide;
@@ -1828,10 +1831,10 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
                 const uint32_t stride = wide ? ZGRP_REC_STRIDE_WIDE : ZGRP_REC_STRIDE;
                 if (grp_g == 2)
                     hipLaunchKernelGGL((zstd_frames_grp_kernel<2, 2>), grid, block, zgrp_lds_bytes(gpw, 2, wide), st, dj, count, (uint32_t *)c->d_zsize.p, gpw,
-                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
+                                       d_src, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
                 else
                     hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw, 3, wide), st, dj, count, (uint32_t *)c->d_zsize.p, gpw,
-                                       (const uint8_t *)c->d_zsrc.p, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
+                                       d_src, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
             };
             if (m_wide)
                 launch_grp(m_one + m_grp, m_wide, true, zs_w);
@@ -1865,6 +1868,20 @@ int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const
     HIPCHK(c, hipMemcpyAsync(h_dst, c->d_zout.p, tot, hipMemcpyDeviceToHost, zs_));
     HIPCHK(c, hipStreamSynchronize(zs_));
     return AGC_HIP_OK;
+}
+
+int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
+                         uint64_t *h_dst_off)
+{
+    return zstd17_batch_impl(c, n, h_src, nullptr, h_src_off, h_dst, dst_cap, h_dst_off);
+}
+
+int agc_hip_zstd17_batch_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
+                             uint64_t *h_dst_off)
+{
+    if (n && h_src_off && h_src_off[n] > h_src_off[0] && !d_src)
+        return AGC_HIP_EINVAL;
+    return zstd17_batch_impl(c, n, nullptr, d_src ? d_src : (const uint8_t *)1, h_src_off, h_dst, dst_cap, h_dst_off);
 }
 
 } // extern "C"

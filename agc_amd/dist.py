@@ -110,6 +110,8 @@ class DistCompressor:
         zstd_raw(src uint8 array, off uint64[n + 1]) -> (frames uint8 array, foff uint64[n + 1]); default: this rank's GPU.
         Every rank must call this instead of Compressor.close()."""
         torch, dist = self.torch, self.dist
+        default_raw = zstd_raw is None
+        ctx = None
         if zstd_raw is None:
             from agc_amd import capi
             ctx = capi.Context.from_handle(self.cmp.hip_ctx())
@@ -132,14 +134,24 @@ class DistCompressor:
         dist.broadcast(d_off, src=self.writer)
         dist.broadcast(d_src, src=self.writer)   # (nccl: HBM -> HBM over xGMI)
         h_off = d_off.cpu().numpy().astype(np.uint64)
-        h_src = d_src.cpu().numpy()
+        # the packs stay where the broadcast put them: with a GPU the kernel reads them from HBM (RCCL delivered them there; under
+        # gloo they are uploaded once) -- no HBM -> host -> HBM round trip of the inputs
+        dev_path = self.hbm is not None and default_raw
+        if dev_path:
+            d_hbm = d_src if d_src.is_cuda else d_src.to(self.hbm)
+            torch.cuda.synchronize(self.hbm)
+        else:
+            h_src = d_src.cpu().numpy()
         # rank r takes packs [cut[r], cut[r + 1]): equal shares of the bytes
         cut = np.searchsorted(h_off, (np.arange(self.world + 1, dtype=np.float64) * total / self.world).astype(np.uint64), side="left")
         cut[0], cut[-1] = 0, n
         cut = np.maximum.accumulate(np.minimum(cut, n))
         a, b = int(cut[self.rank]), int(cut[self.rank + 1])
         if b > a:
-            frames, foff = zstd_raw(h_src[int(h_off[a]):int(h_off[b])], h_off[a:b + 1] - h_off[a])
+            if dev_path:
+                frames, foff = ctx.zstd17_batch_raw_dev(d_hbm.data_ptr(), h_off[a:b + 1])
+            else:
+                frames, foff = zstd_raw(h_src[int(h_off[a]):int(h_off[b])], h_off[a:b + 1] - h_off[a])
             frames = np.ascontiguousarray(frames, dtype=np.uint8)
             sizes = np.diff(foff.astype(np.int64))
         else:

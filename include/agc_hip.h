@@ -273,6 +273,10 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_ba
 uint32_t agc_hip_zstd17_max_input(void);
 int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off,
                          uint8_t *h_dst, uint64_t dst_cap, uint64_t *h_dst_off);
+/* The same for inputs that are in HBM already (input i = d_src[h_src_off[i] .. h_src_off[i+1]); e.g. packs another GPU sent over
+ * xGMI: agc_amd/dist.py): no host round trip of the inputs.  The caller makes sure whatever wrote d_src has finished. */
+int agc_hip_zstd17_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_src, const uint64_t *h_src_off,
+                             uint8_t *h_dst, uint64_t dst_cap, uint64_t *h_dst_off);
 /* on != 0: the launches of agc_hip_zstd17_batch keep their tables out of the LDS, so that kernels of the context's other
  * streams that need most of a CU's LDS (the packed splitter scan: 128 KiB per block) can start beside a launch that runs for
  * a second.  For a caller that compresses packs in the background while it goes on adding samples; off (the default) is

@@ -9,7 +9,14 @@
 extern "C" {
 
 uint32_t agc_hip_zstd17_max_input(void) { return zs::BLOCKSIZE_MAX; }
-uint32_t agc_hip_zstd17_resident_frames(agc_hip_ctx *) { return 64; } // (small on purpose: the host's split rule is exercised)
+uint32_t agc_hip_zstd17_resident_frames(agc_hip_ctx *) { return 64; }
+int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
+                         uint64_t *h_dst_off);
+int agc_hip_zstd17_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
+                             uint64_t *h_dst_off)
+{
+    return agc_hip_zstd17_batch(ctx, n, d_src, h_src_off, h_dst, dst_cap, h_dst_off); // (the stand-in's "HBM" is host memory)
+} // (small on purpose: the host's split rule is exercised)
 
 int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
 {

@@ -44,6 +44,24 @@ def test_gpu_group_kernels_equal_libzstd(hip_ctx, oracle, group):
     assert not bad, bad
 
 
+def test_gpu_frames_from_inputs_resident_in_hbm(hip_ctx, oracle):
+    """agc_hip_zstd17_batch_dev: the packs are in HBM already (the multi-GPU Close: another rank sent them); a run that does not
+    start at the buffer's first byte"""
+    import torch
+    rng = np.random.default_rng(12)
+    inputs = [ZC.delta_pack(oracle, rng, n, 60000, 1e-3) for n in (3, 25, 30, 60)] + ZC.corpus(oracle, 77, 40, max_len=40000)
+    src = np.frombuffer(b"".join(inputs), np.uint8)
+    off = np.zeros(len(inputs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(p) for p in inputs])
+    d = torch.from_numpy(src.copy()).cuda()
+    torch.cuda.synchronize()
+    for a, b in ((0, len(inputs)), (5, 31)):
+        frames, foff = hip_ctx.zstd17_batch_raw_dev(d.data_ptr(), off[a:b + 1])
+        for i in range(a, b):
+            got = frames[int(foff[i - a]):int(foff[i - a + 1])].tobytes()
+            assert got == ZC.ref_frame(inputs[i]), (a, b, i)
+
+
 def test_gpu_many_equal_size_packs(hip_ctx, oracle):
     """the shape Close() produces: thousands of packs of similar size in one call (several workspace-arena rounds when the
     arena is small)"""
