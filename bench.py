@@ -122,7 +122,7 @@ def cpu_baseline(args, mbp):
     n = int(mbp * 1e6)
     ctg_len = [n // 4] * 4
     refc = [synth.random_seq(rng, l) for l in ctg_len]
-    n_samples = 5
+    n_samples = 8
     cores = host_cpus()
     if os.path.exists(ref_bin):
         with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
