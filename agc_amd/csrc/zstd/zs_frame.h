@@ -27,8 +27,8 @@ ZHD WsLayout wsLayout(const CParams &cp, U32 srcSize)
     o += align16(((size_t)4) << cp.hashLog);
     L.hashTable3 = o;
     o += align16(((size_t)4) << hl3);
-    L.chainTable = o; // (room for the group parser's 16-byte nodes: zs_opt_grp.h; the one-lane parser uses the first half)
-    o += align16(((size_t)8) << cp.chainLog);
+    L.chainTable = o;
+    o += align16(((size_t)4) << cp.chainLog);
     L.opt = o;
     o += align16(sizeof(Optimal) * (OPT_NUM + 2));
     L.matches = o;

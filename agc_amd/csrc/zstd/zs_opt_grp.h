@@ -88,9 +88,10 @@ struct GLane {
     U32 wk_current, matchIndex, clSmaller, clLarger, smallerPtr, largerPtr, matchEndIdx, bestLength, nbCompares, btLow, lowLimit, mnum, upd_idx;
     bool rec;          // the walk records its stores instead of making them
     bool grp;          // the walk belongs to a group trip (its end is reported to the group)
-    // the next level's node, read ahead (grpWalkIssue): both children and the first 8 bytes of the node's position
+    // the next level's node, read ahead (grpWalkIssue): both children, 8 bytes of the match and of the position at the length
+    // the two are already known to share
     bool wk_pre;
-    U64 wk_pair, wk_mb;
+    U64 wk_pair, wk_mb, wk_pb;
     U32 nrec, gstatus;
     U32 m_off[GRP_MC], m_len[GRP_MC]; // the first matches of the request
     U32 last_m_off, last_m_len;
@@ -111,13 +112,8 @@ struct GLane {
     U32 oldp_t0;       // ... and the first of those targets
 };
 
-// The group parser's TREE NODES are 16 bytes: {larger child, smaller child, the first 8 source bytes of the node's position}
-// (ZSTD's: 8 bytes, the two children).  A level of a walk compares the position with the node's position -- with the bytes beside
-// the children that is ONE 16-byte read from one line instead of three reads from two lines (children, 8 bytes of the match, 8 of
-// the position: the position's own first 8 bytes are in a register).  Same tree, same decisions: only where things lie differs.
-constexpr U32 GRP_NODE_WORDS = 4;
-// a recorded store in one word: slot < 2^16 (4 words x 2^14 nodes: chainLog <= 15), value < 2^16 (index <= 2 * 16 KiB + 1)
-ZFN U32 grpRecPack(U32 slot, U32 val) { return (val << 16) | slot; }
+// a recorded store in one word: slot < 2^15 (chainLog <= 15), value < 2^17 (index <= 2 * 16 KiB + 1) -- the btultra2 class
+ZFN U32 grpRecPack(U32 slot, U32 val) { return (val << 15) | slot; }
 ZFN void grpRecPut(GLane &l, U32 slot, U32 val)
 {
     if (l.wide) {
@@ -134,8 +130,8 @@ ZFN void grpRecGet(const GLane &l, U32 r, U32 &slot, U32 &val)
         val = l.recs[2 * r + 1];
     } else {
         const U32 x = l.recs[r];
-        slot = x & 0xFFFFu;
-        val = x >> 16;
+        slot = x & 0x7FFFu;
+        val = x >> 15;
     }
 }
 
@@ -226,9 +222,6 @@ ZFN void grpPublishBases(GrpX &sh, const OptWs &w)
 // The record of a walk is full.  The LEADER's position is the next one in the sequential order whatever the lanes behind it
 // find: its stores can be made now (the lanes behind walk other trees -- one that shares the leader's bucket is an anomaly
 // already) and the walk goes on storing directly.  A follower's walk is given up (false): the position will be a leader's.
-// a position enters the tree: its node gets the position's first 8 bytes (the children follow from its walk)
-ZFN void grpNodeBytes(U32 *bt, U32 btMask, U32 index, U64 bytes8) { *(U64 *)(bt + GRP_NODE_WORDS * (index & btMask) + 2) = bytes8; }
-
 ZFN bool grpRecFull(GLane &l, U32 *bt)
 {
     if (l.j != 0)
@@ -247,15 +240,21 @@ ZFN bool grpRecFull(GLane &l, U32 *bt)
 // coincide with those of the repcode tests, and a level's wait with the work that follows the level before
 ZFN void grpWalkIssue(GLane &l, const BYTE *src, const BYTE *iend, const U32 *bt, U32 btMask)
 {
-    (void)src;
-    (void)iend;
     l.wk_pre = false;
-    // (the position's first 8 bytes must be at hand: they are for every walk but those of ZSTD_updateTree)
-    if (l.nbCompares && (l.matchIndex >= l.lowLimit) && l.p8_pos == l.wk_current - l.w.idx0) {
-        const U64 *const node = (const U64 *)(bt + GRP_NODE_WORDS * (l.matchIndex & btMask));
-        l.wk_pair = node[0]; // (one 16-byte read)
-        l.wk_mb = node[1];
-        l.wk_pre = true;
+    if (l.nbCompares && (l.matchIndex >= l.lowLimit)) {
+        const U32 ml0 = l.clSmaller < l.clLarger ? l.clSmaller : l.clLarger;
+        const BYTE *const p = src + (l.wk_current - l.w.idx0) + ml0;
+        if (p + 8 <= iend) {
+            l.wk_pair = *(const U64 *)(bt + 2 * (l.matchIndex & btMask));
+            l.wk_mb = read64(src + (l.matchIndex - l.w.idx0) + ml0);
+            // (the position's own bytes: in a register for the first level; a second 8-byte window kept for the deeper levels
+            // was spilled by the register allocator and cost a scratch round trip per level -- measured slower than this load)
+            if (ml0 == 0 && l.p8_pos == l.wk_current - l.w.idx0)
+                l.wk_pb = l.p8;
+            else
+                l.wk_pb = read64(p);
+            l.wk_pre = true;
+        }
     }
 }
 
@@ -272,7 +271,7 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
         }
         l.nbCompares--;
         const BYTE *const p = src + (l.wk_current - l.w.idx0);
-        const U32 nextPtr = GRP_NODE_WORDS * (l.matchIndex & btMask);
+        const U32 nextPtr = 2 * (l.matchIndex & btMask);
         U32 matchLength = l.clSmaller < l.clLarger ? l.clSmaller : l.clLarger;
         const BYTE *const match = src + (l.matchIndex - l.w.idx0);
         // both children are read before the stores below (a store to this walk's own pointers never hits the node read here)
@@ -282,16 +281,15 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
         if (!UPD && l.wk_pre) {
             childLarger = (U32)l.wk_pair;          // nextPtr[0]
             childSmaller = (U32)(l.wk_pair >> 32); // nextPtr[1]
-            // the node's 8 bytes against the position's: what the two are known to share (matchLength) lies inside them or not
-            const U64 d = l.p8 ^ l.wk_mb;
+            const U64 d = l.wk_pb ^ l.wk_mb;
             if (d) {
                 const U32 sh = (U32)__builtin_ctzll(d) & ~7u;
-                pByte = (U32)(l.p8 >> sh) & 0xFF;
+                pByte = (U32)(l.wk_pb >> sh) & 0xFF;
                 mByte = (U32)(l.wk_mb >> sh) & 0xFF;
                 differ = true;
-                matchLength = sh >> 3; // (>= the known common length: those bytes are equal)
+                matchLength += sh >> 3;
             } else {
-                matchLength = matchLength > 8 ? matchLength : 8;
+                matchLength += 8;
                 matchLength += countEx(p + matchLength, match + matchLength, iend, &pByte, &mByte, &differ);
             }
         } else {
@@ -372,19 +370,20 @@ template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE 
 // these (a level of grpWalkLevel is ~650 instructions, half of them control flow; the trip is issue-bound).
 ZFN void grpWalkFastLevel(GLane &l, const BYTE *src, const BYTE *iend, U32 *bt, U32 btMask)
 {
-    const U64 d = l.p8 ^ l.wk_mb; // (the position's first 8 bytes against the node's)
+    const U64 d = l.wk_pb ^ l.wk_mb;
     if (d == 0 || (l.grp && (l.nrec + 3 > GRP_RC || (l.j != 0 && l.mnum >= GRP_MC)))) {
         l.wk_pre = false;
         return;
     }
     l.nbCompares--;
-    const U32 nextPtr = GRP_NODE_WORDS * (l.matchIndex & btMask);
+    const U32 nextPtr = 2 * (l.matchIndex & btMask);
+    const U32 ml0 = l.clSmaller < l.clLarger ? l.clSmaller : l.clLarger;
     const U32 childLarger = (U32)l.wk_pair;          // nextPtr[0]
     const U32 childSmaller = (U32)(l.wk_pair >> 32); // nextPtr[1]
     const U32 sh = (U32)__builtin_ctzll(d) & ~7u;
-    const U32 pByte = (U32)(l.p8 >> sh) & 0xFF;
+    const U32 pByte = (U32)(l.wk_pb >> sh) & 0xFF;
     const U32 mByte = (U32)(l.wk_mb >> sh) & 0xFF;
-    const U32 matchLength = sh >> 3; // (>= what the two were known to share: those bytes are equal)
+    const U32 matchLength = ml0 + (sh >> 3);
     bool brk = false;
     if (matchLength > l.bestLength) {
         if (matchLength > l.matchEndIdx - l.matchIndex)
@@ -434,9 +433,8 @@ ZFN U32 grpCount8(U64 pv, U64 qv, const BYTE *p, const BYTE *q, const BYTE *iend
 // The group lanes' form of grpRepsAndHash3 (below): the bytes every test starts from -- the sources of the (up to) three
 // repcodes, the hash-3 candidate, the root node of the tree walk -- are asked for TOGETHER, then looked at: one round trip
 // instead of up to five.  Same decisions in the same order.
-ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const BYTE *iend, U32 minMatch, U32 mls, U32 sufficient_len, U32 btMask, U32 endOff)
+ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const BYTE *iend, U32 minMatch, U32 mls, U32 sufficient_len, U32 btMask)
 {
-    const U32 posOff = l.wk_current - l.w.idx0; // ("reaches the end of the block" is tested on offsets: 32 bits, nothing to reload)
     const CParams &cp = l.w.cp;
     const BYTE *const p = src + (l.wk_current - l.w.idx0);
     const U64 pv = l.p8; // (segment B read it at this position)
@@ -446,7 +444,7 @@ ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const BYTE *iend, U32 min
     const U32 maxDistance = 1u << cp.windowLog;
     const U32 windowLow = (l.wk_current - dictLimit > maxDistance) ? l.wk_current - maxDistance : dictLimit;
     l.lowLimit = windowLow ? windowLow : 1; // matchLow
-    l.smallerPtr = GRP_NODE_WORDS * (l.wk_current & btMask);
+    l.smallerPtr = 2 * (l.wk_current & btMask);
     l.largerPtr = l.smallerPtr + 1;
     l.matchEndIdx = l.wk_current + 8 + 1;
     l.mnum = 0;
@@ -488,7 +486,7 @@ ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const BYTE *iend, U32 min
             l.last_m_off = k;
             l.last_m_len = repLen;
             l.mnum++;
-            if ((repLen > sufficient_len) | (posOff + repLen == endOff))
+            if ((repLen > sufficient_len) | (p + repLen == iend))
                 done = true; // best possible
         }
     }
@@ -500,7 +498,7 @@ ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const BYTE *iend, U32 min
             l.last_m_off = (l.wk_current - l.mi3) + REP_MOVE;
             l.last_m_len = mlen;
             l.mnum = 1;
-            if ((mlen > sufficient_len) | (posOff + mlen == endOff))
+            if ((mlen > sufficient_len) | (p + mlen == iend))
                 done = true;
         }
     }
@@ -521,7 +519,7 @@ ZFN bool grpRepsAndHash3(GLane &l, const BYTE *src, const BYTE *iend, U32 minMat
     const U32 maxDistance = 1u << cp.windowLog;
     const U32 windowLow = (l.wk_current - dictLimit > maxDistance) ? l.wk_current - maxDistance : dictLimit;
     l.lowLimit = windowLow ? windowLow : 1; // matchLow
-    l.smallerPtr = GRP_NODE_WORDS * (l.wk_current & btMask);
+    l.smallerPtr = 2 * (l.wk_current & btMask);
     l.largerPtr = l.smallerPtr + 1;
     l.matchEndIdx = l.wk_current + 8 + 1;
     l.mnum = 0;
@@ -1006,7 +1004,7 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 if (sh.h[i] == l.h)
                     l.gstatus = GS_ANOMALY; // same tree as a position in front: the walk would miss that position
             }
-            const bool done = grpRepsAndHash3Pre(l, src, iend, minMatch, mls, sufficient_len, btMask, ilimit_off + 8);
+            const bool done = grpRepsAndHash3Pre(l, src, iend, minMatch, mls, sufficient_len, btMask);
             if (done)
                 l.gstatus = GS_ANOMALY; // answered without a walk and without an insertion: the one-lane path's business
             l.rec = true;
@@ -1044,14 +1042,13 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 l.matchIndex = w.hashTable[h];
                 l.clSmaller = l.clLarger = 0;
                 l.btLow = btMask >= l.wk_current ? 0 : l.wk_current - btMask;
-                l.smallerPtr = GRP_NODE_WORDS * (l.wk_current & btMask);
+                l.smallerPtr = 2 * (l.wk_current & btMask);
                 l.largerPtr = l.smallerPtr + 1;
                 l.lowLimit = w.dictLimit;
                 l.matchEndIdx = l.wk_current + 8 + 1;
                 l.bestLength = 8;
                 l.nbCompares = 1u << cp.searchLog;
                 w.hashTable[h] = l.wk_current;
-                grpNodeBytes(w.chainTable, btMask, l.wk_current, read64(p)); // (a skipped position lies at least 8 bytes before the end)
                 l.wk_pre = false;
                 l.state = ST_UPD_WALK;
             } while (0);
@@ -1080,9 +1077,6 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                 break;
             }
             w.hashTable[h] = l.wk_current;
-            grpNodeBytes(w.chainTable, btMask, l.wk_current, pv);
-            l.p8 = pv; // (the walk compares against the position's first 8 bytes)
-            l.p8_pos = l.wk_current - w.idx0;
             grpWalkIssue(l, src, iend, w.chainTable, btMask);
             l.state = ST_WALK;
         } while (0);
@@ -1164,7 +1158,6 @@ template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3],
                     grpRecGet(l, r, slot, val);
                     bt[slot] = val;
                 }
-                grpNodeBytes(bt, btMask, l.q_current, l.p8);
                 w.hashTable[l.h] = l.q_current;
                 bool later = false;
                 for (U32 i = l.j + 1; i < v; ++i)
