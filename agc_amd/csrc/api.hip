@@ -1711,10 +1711,7 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
         uint32_t p[7];
         zs::level17Params(len, p);
         const zs::CParams cp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6]};
-        // (the group kernels keep 16-bit tables for inputs of the btultra2 class; background launches use the one-lane kernel)
-        const bool narrow16 = !c->zstd_background && !(getenv("AGC_HIP_ZSTD_GROUP") && atoi(getenv("AGC_HIP_ZSTD_GROUP")) < 2) &&
-                              zs::grpEligible(cp, (uint32_t)len) && !zs::grpWide(cp, (uint32_t)len);
-        ws_need[i] = zs::wsLayout(cp, (uint32_t)len, narrow16 ? 2 : 4).total;
+        ws_need[i] = zs::wsLayout(cp, (uint32_t)len).total;
         dst_o[i] = dst_total;
         dst_total += (zs::frameBound((uint32_t)len) + 15) & ~15u;
         jobs[i].src = 0;
@@ -1832,21 +1829,12 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
                 const dim3 grid((count + gpw - 1) / gpw);
                 const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done + first;
                 const uint32_t stride = wide ? ZGRP_REC_STRIDE_WIDE : ZGRP_REC_STRIDE;
-#define ZGRP_LAUNCH(G_, T_)                                                                                                                  \
-    hipLaunchKernelGGL((zstd_frames_grp_kernel<G_, 2, T_>), grid, block, zgrp_lds_bytes(gpw, G_, wide), st, dj, count, (uint32_t *)c->d_zsize.p, gpw, \
-                       d_src, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride)
-                if (grp_g == 2) {
-                    if (wide)
-                        ZGRP_LAUNCH(2, uint32_t);
-                    else
-                        ZGRP_LAUNCH(2, uint16_t);
-                } else {
-                    if (wide)
-                        ZGRP_LAUNCH(3, uint32_t);
-                    else
-                        ZGRP_LAUNCH(3, uint16_t);
-                }
-#undef ZGRP_LAUNCH
+                if (grp_g == 2)
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<2, 2>), grid, block, zgrp_lds_bytes(gpw, 2, wide), st, dj, count, (uint32_t *)c->d_zsize.p, gpw,
+                                       d_src, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
+                else
+                    hipLaunchKernelGGL((zstd_frames_grp_kernel<3, 2>), grid, block, zgrp_lds_bytes(gpw, 3, wide), st, dj, count, (uint32_t *)c->d_zsize.p, gpw,
+                                       d_src, (uint8_t *)c->d_zdst.p, (uint8_t *)c->d_zws.p, dbg, stride);
             };
             if (m_wide)
                 launch_grp(m_one + m_grp, m_wide, true, zs_w);

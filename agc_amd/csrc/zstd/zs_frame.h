@@ -18,18 +18,17 @@ struct WsLayout {
     size_t hashTable, hashTable3, chainTable, opt, matches, freqs, seqs, lits, codes, ent, bkfw, total;
 };
 
-// tblBytes: bytes per entry of the hash / hash-3 / tree tables (4; 2 for the group parser on inputs of the btultra2 class)
-ZHD WsLayout wsLayout(const CParams &cp, U32 srcSize, U32 tblBytes = 4)
+ZHD WsLayout wsLayout(const CParams &cp, U32 srcSize)
 {
     WsLayout L;
     const U32 hl3 = cp.minMatch == 3 ? (HASHLOG3_MAX < cp.windowLog ? HASHLOG3_MAX : cp.windowLog) : 0;
     size_t o = 0;
     L.hashTable = o;
-    o += align16(((size_t)tblBytes) << cp.hashLog);
+    o += align16(((size_t)4) << cp.hashLog);
     L.hashTable3 = o;
-    o += align16(((size_t)tblBytes) << hl3);
+    o += align16(((size_t)4) << hl3);
     L.chainTable = o;
-    o += align16(((size_t)tblBytes) << cp.chainLog);
+    o += align16(((size_t)4) << cp.chainLog);
     L.opt = o;
     o += align16(sizeof(Optimal) * (OPT_NUM + 2));
     L.matches = o;
@@ -183,8 +182,8 @@ ZFN U32 compressFrame(BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize,
 // The same frame by a GROUP of G lanes (zs_opt_grp.h): every lane of the group calls this with its own lane state; the leader
 // (lanes[0].j == 0 on the device; lanes[0] on the host) writes the frame and returns its size, the others return 0.
 // fast_freqs: the group's FAST_FREQ_WORDS words of fast memory (device: LDS) or nullptr (host: the tables live in ws).
-template <int G, class T> ZFN U32 compressFrameGrp(GLane *lanes, GrpX &sh, BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, U32 debug = 0,
-                                                   U32 *fast_freqs = nullptr)
+template <int G> ZFN U32 compressFrameGrp(GLane *lanes, GrpX &sh, BYTE *ws, const CParams &cp, const BYTE *src, U32 srcSize, BYTE *dst, U32 debug = 0,
+                                          U32 *fast_freqs = nullptr)
 {
     const bool leader = lanes[0].j == 0;
     BYTE *op = dst;
@@ -200,7 +199,7 @@ template <int G, class T> ZFN U32 compressFrameGrp(GLane *lanes, GrpX &sh, BYTE 
     }
     U32 cSize = 0;
     if (srcSize >= 8) { // (7-byte inputs -- parsed by the library, never compressible -- take the raw block below as well)
-        const WsLayout L = wsLayout(cp, srcSize, (U32)sizeof(T));
+        const WsLayout L = wsLayout(cp, srcSize);
         ZS_GRP_EACH(l)
         OptWs &w = l.w;
         w.hashTable = (U32 *)(ws + L.hashTable);
@@ -238,7 +237,7 @@ template <int G, class T> ZFN U32 compressFrameGrp(GLane *lanes, GrpX &sh, BYTE 
         U32 lastLits = 0;
         for (U32 pass = 0; pass < passes; ++pass) {
             U32 rep[3] = {1, 4, 8};
-            lastLits = compressBlockOptGrp<G, T>(lanes, sh, rep, src, srcSize, optLevel);
+            lastLits = compressBlockOptGrp<G>(lanes, sh, rep, src, srcSize, optLevel);
             if (pass + 1 < passes) {
                 ZS_GRP_EACH(l)
                 l.w.nSeq = 0;

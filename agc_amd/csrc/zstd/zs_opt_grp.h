@@ -135,19 +135,6 @@ ZFN void grpRecGet(const GLane &l, U32 r, U32 &slot, U32 &val)
     }
 }
 
-// The tables of a frame (hash, hash-3, binary tree) hold INDICES: for the btultra2 class (inputs <= 16 KiB: indices <= 2 * 16 KiB + 1)
-// 16 bits are enough.  Half the bytes per frame = twice the entries per cache line of tables that are far larger than any cache
-// (a frame's tables: 320 -> 160 KB; ten random lines per parsed position: §4.6 of DESIGN.md).  T = U16 for that class, U32 beyond.
-#define ZT_LOAD(ptr, i) ((U32)((const T *)(const void *)(ptr))[(i)])
-#define ZT_STORE(ptr, i, v) (((T *)(void *)(ptr))[(i)] = (T)(v))
-template <class T> ZFN U64 grpPairLoad(const U32 *bt, U32 nextPtr) // {nextPtr[0] = larger child, nextPtr[1] = smaller child} as (lo, hi)
-{
-    if (sizeof(T) == 4)
-        return *(const U64 *)(bt + nextPtr);
-    const U32 v = *(const U32 *)((const U16 *)(const void *)bt + nextPtr);
-    return (U64)(v & 0xFFFFu) | ((U64)(v >> 16) << 32);
-}
-
 ZFN U32 grpSel3(U32 a0, U32 a1, U32 a2, U32 i) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
 
 ZFN void grpMSet(GLane &l, U32 i, U32 off, U32 len)
@@ -235,14 +222,14 @@ ZFN void grpPublishBases(GrpX &sh, const OptWs &w)
 // The record of a walk is full.  The LEADER's position is the next one in the sequential order whatever the lanes behind it
 // find: its stores can be made now (the lanes behind walk other trees -- one that shares the leader's bucket is an anomaly
 // already) and the walk goes on storing directly.  A follower's walk is given up (false): the position will be a leader's.
-template <class T> ZFN bool grpRecFull(GLane &l, U32 *bt)
+ZFN bool grpRecFull(GLane &l, U32 *bt)
 {
     if (l.j != 0)
         return false;
     for (U32 r = 0; r < l.nrec; ++r) {
         U32 slot, val;
         grpRecGet(l, r, slot, val);
-        ZT_STORE(bt, slot, val);
+        bt[slot] = val;
     }
     l.nrec = 0;
     l.rec = false;
@@ -251,14 +238,14 @@ template <class T> ZFN bool grpRecFull(GLane &l, U32 *bt)
 
 // reads ahead what the next level of the walk will look at (nothing, if the walk ends there): the waits of the walk's first level
 // coincide with those of the repcode tests, and a level's wait with the work that follows the level before
-template <class T> ZFN void grpWalkIssue(GLane &l, const BYTE *src, const BYTE *iend, const U32 *bt, U32 btMask)
+ZFN void grpWalkIssue(GLane &l, const BYTE *src, const BYTE *iend, const U32 *bt, U32 btMask)
 {
     l.wk_pre = false;
     if (l.nbCompares && (l.matchIndex >= l.lowLimit)) {
         const U32 ml0 = l.clSmaller < l.clLarger ? l.clSmaller : l.clLarger;
         const BYTE *const p = src + (l.wk_current - l.w.idx0) + ml0;
         if (p + 8 <= iend) {
-            l.wk_pair = grpPairLoad<T>(bt, 2 * (l.matchIndex & btMask));
+            l.wk_pair = *(const U64 *)(bt + 2 * (l.matchIndex & btMask));
             l.wk_mb = read64(src + (l.matchIndex - l.w.idx0) + ml0);
             // (the position's own bytes: in a register for the first level; a second 8-byte window kept for the deeper levels
             // was spilled by the register allocator and cost a scratch round trip per level -- measured slower than this load)
@@ -273,12 +260,12 @@ template <class T> ZFN void grpWalkIssue(GLane &l, const BYTE *src, const BYTE *
 
 // one level of a binary-tree walk (ZSTD_insertBt1 when `upd`, else ZSTD_insertBtAndGetAllMatches); returns true when the
 // walk has ended (the closing stores made or recorded).  `abort` = the record is full: the walk is given up (group lanes only).
-template <bool UPD, class T> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE *iend, U32 *bt, U32 btMask, bool &abort)
+template <bool UPD> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, const BYTE *iend, U32 *bt, U32 btMask, bool &abort)
 {
     bool ended = true;
     abort = false;
     if (l.nbCompares && (l.matchIndex >= l.lowLimit)) {
-        if (!UPD && l.rec && l.nrec + 3 > GRP_RC && !grpRecFull<T>(l, bt)) {
+        if (!UPD && l.rec && l.nrec + 3 > GRP_RC && !grpRecFull(l, bt)) {
             abort = true;
             return true;
         }
@@ -306,7 +293,7 @@ template <bool UPD, class T> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, co
                 matchLength += countEx(p + matchLength, match + matchLength, iend, &pByte, &mByte, &differ);
             }
         } else {
-            const U64 pair = grpPairLoad<T>(bt, nextPtr);
+            const U64 pair = *(const U64 *)(bt + nextPtr);
             childLarger = (U32)pair;
             childSmaller = (U32)(pair >> 32);
             matchLength += countEx(p + matchLength, match + matchLength, iend, &pByte, &mByte, &differ);
@@ -343,7 +330,7 @@ template <bool UPD, class T> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, co
                 if (!UPD && l.rec)
                     grpRecPut(l, ptr, l.matchIndex);
                 else
-                    ZT_STORE(bt, ptr, l.matchIndex);
+                    bt[ptr] = l.matchIndex;
             }
             const bool low = l.matchIndex <= l.btLow;
             if (smaller) {
@@ -364,16 +351,16 @@ template <bool UPD, class T> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, co
             if (!UPD && l.rec)
                 grpRecPut(l, l.smallerPtr, 0);
             else
-                ZT_STORE(bt, l.smallerPtr, 0);
+                bt[l.smallerPtr] = 0;
         }
         if (l.largerPtr != SM_NOPTR) {
             if (!UPD && l.rec)
                 grpRecPut(l, l.largerPtr, 0);
             else
-                ZT_STORE(bt, l.largerPtr, 0);
+                bt[l.largerPtr] = 0;
         }
     } else if (!UPD)
-        grpWalkIssue<T>(l, src, iend, bt, btMask);
+        grpWalkIssue(l, src, iend, bt, btMask);
     return ended;
 }
 
@@ -381,7 +368,7 @@ template <bool UPD, class T> ZFN bool grpWalkLevel(GLane &l, const BYTE *src, co
 // match differ inside the 8 bytes read.  Everything else -- no node left (the walk closes), 8 equal bytes, a node near the end of
 // the block, a full record -- clears wk_pre and is left to grpWalkLevel, which segment E runs ONCE per trip behind a row of
 // these (a level of grpWalkLevel is ~650 instructions, half of them control flow; the trip is issue-bound).
-template <class T> ZFN void grpWalkFastLevel(GLane &l, const BYTE *src, const BYTE *iend, U32 *bt, U32 btMask)
+ZFN void grpWalkFastLevel(GLane &l, const BYTE *src, const BYTE *iend, U32 *bt, U32 btMask)
 {
     const U64 d = l.wk_pb ^ l.wk_mb;
     if (d == 0 || (l.grp && (l.nrec + 3 > GRP_RC || (l.j != 0 && l.mnum >= GRP_MC)))) {
@@ -416,7 +403,7 @@ template <class T> ZFN void grpWalkFastLevel(GLane &l, const BYTE *src, const BY
             if (l.rec)
                 grpRecPut(l, ptr, l.matchIndex);
             else
-                ZT_STORE(bt, ptr, l.matchIndex);
+                bt[ptr] = l.matchIndex;
         }
         const bool low = l.matchIndex <= l.btLow;
         l.clSmaller = smaller ? matchLength : l.clSmaller;
@@ -431,7 +418,7 @@ template <class T> ZFN void grpWalkFastLevel(GLane &l, const BYTE *src, const BY
         l.nbCompares = 0;
         l.wk_pre = false;
     } else
-        grpWalkIssue<T>(l, src, iend, bt, btMask);
+        grpWalkIssue(l, src, iend, bt, btMask);
 }
 
 // common length of p and q given their first 8 bytes (p + 8 <= iend): the loop of ZSTD_count only runs when all 8 are equal
@@ -446,7 +433,7 @@ ZFN U32 grpCount8(U64 pv, U64 qv, const BYTE *p, const BYTE *q, const BYTE *iend
 // The group lanes' form of grpRepsAndHash3 (below): the bytes every test starts from -- the sources of the (up to) three
 // repcodes, the hash-3 candidate, the root node of the tree walk -- are asked for TOGETHER, then looked at: one round trip
 // instead of up to five.  Same decisions in the same order.
-template <class T> ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const BYTE *iend, U32 minMatch, U32 mls, U32 sufficient_len, U32 btMask)
+ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const BYTE *iend, U32 minMatch, U32 mls, U32 sufficient_len, U32 btMask)
 {
     const CParams &cp = l.w.cp;
     const BYTE *const p = src + (l.wk_current - l.w.idx0);
@@ -480,7 +467,7 @@ template <class T> ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const 
     if (ok3)
         m3v = read64(src + (l.mi3 - l.w.idx0));
     l.matchIndex = l.mi0;
-    grpWalkIssue<T>(l, src, iend, l.w.chainTable, btMask);
+    grpWalkIssue(l, src, iend, l.w.chainTable, btMask);
     // ---- and looked at ----
     bool done = false;
 #pragma unroll
@@ -521,7 +508,7 @@ template <class T> ZFN bool grpRepsAndHash3Pre(GLane &l, const BYTE *src, const 
 // repcodes and the hash-3 probe of ZSTD_insertBtAndGetAllMatches for the lane's request (wk_current, q_*), and the set-up of
 // the tree walk.  Returns true when the request is answered without a walk ("done" in the library: best possible match).
 // mi3 < 0xFFFFFFFF: the hash-3 table's answer is already known (group lanes); else it is read (and the table brought up to date).
-template <class T> ZFN bool grpRepsAndHash3(GLane &l, const BYTE *src, const BYTE *iend, U32 minMatch, U32 mls, U32 sufficient_len, U32 btMask, bool group)
+ZFN bool grpRepsAndHash3(GLane &l, const BYTE *src, const BYTE *iend, U32 minMatch, U32 mls, U32 sufficient_len, U32 btMask, bool group)
 {
     const CParams &cp = l.w.cp;
     const BYTE *const p = src + (l.wk_current - l.w.idx0);
@@ -569,9 +556,9 @@ template <class T> ZFN bool grpRepsAndHash3(GLane &l, const BYTE *src, const BYT
         else { // ZSTD_insertAndFindFirstIndexHash3
             const U32 h3 = hash3((U32)pv, l.w.hashLog3);
             for (U32 idx = l.nextToUpdate3; idx < l.wk_current; ++idx)
-                ZT_STORE(l.w.hashTable3, hash3(read32(src + (idx - l.w.idx0)), l.w.hashLog3), idx);
+                l.w.hashTable3[hash3(read32(src + (idx - l.w.idx0)), l.w.hashLog3)] = idx;
             l.nextToUpdate3 = l.wk_current;
-            matchIndex3 = ZT_LOAD(l.w.hashTable3, h3);
+            matchIndex3 = l.w.hashTable3[h3];
         }
         if ((matchIndex3 >= l.lowLimit) & (l.wk_current - matchIndex3 < (1u << 18))) {
             const BYTE *const match = src + (matchIndex3 - l.w.idx0);
@@ -595,7 +582,7 @@ template <class T> ZFN bool grpRepsAndHash3(GLane &l, const BYTE *src, const BYT
 
 // ZSTD_compressBlock_opt_generic for a group of G lanes; lanes = the group's lane states (device: the calling lane's own),
 // sh = the group's exchange record.  rep[] (the block's repcodes) is the leader's.  Returns the last literals (leader).
-template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3], const BYTE *src, U32 srcSize, int optLevel)
+template <int G> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U32 rep[3], const BYTE *src, U32 srcSize, int optLevel)
 {
     static_assert(G >= 1 && G <= (int)GRP_MAX, "group size");
     const BYTE *const iend = src + srcSize;
@@ -801,7 +788,7 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
                 for (U32 t = 0; t < n; ++t) {
                     const U32 idx = l.nextToUpdate3 + t;
                     const U32 hh = hash3(read32(src + (idx - w.idx0)), w.hashLog3);
-                    ZT_STORE(w.hashTable3, hh, idx);
+                    w.hashTable3[hh] = idx;
                     sh.pend_h3 = hh;
                 }
                 l.nextToUpdate3 = q0;
@@ -837,7 +824,7 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
                 for (U32 t = 0; t < n; ++t) {
                     const U32 idx = l.nextToUpdate3 + t;
                     const U32 hh = hash3(read32(src + (idx - w.idx0)), w.hashLog3);
-                    ZT_STORE(w.hashTable3, hh, idx);
+                    w.hashTable3[hh] = idx;
                     sh.pend_h3 = hh;
                 }
                 l.nextToUpdate3 = q0;
@@ -868,8 +855,8 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
         if (l.state == ST_G_FIRST) { // (leader) a chunk's first position: no price-table entry to finish, only the tables' answers
             l.h = mls == 5 ? hash5(l.p8, cp.hashLog) : mls == 6 ? hash6(l.p8, cp.hashLog) : hash4((U32)l.p8, cp.hashLog);
             l.h3 = hash3((U32)l.p8, w.hashLog3);
-            l.mi0 = ZT_LOAD(w.hashTable, l.h);
-            l.mi3 = ZT_LOAD(w.hashTable3, l.h3);
+            l.mi0 = w.hashTable[l.h];
+            l.mi3 = w.hashTable3[l.h3];
             sh.h[0] = l.h;
             sh.h3[0] = l.h3;
             sh.wdone[0] = 0;
@@ -900,8 +887,8 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
             if (at && (sh.g >> 8)) {
                 l.h = mls == 5 ? hash5(l.p8, cp.hashLog) : mls == 6 ? hash6(l.p8, cp.hashLog) : hash4((U32)l.p8, cp.hashLog);
                 l.h3 = hash3((U32)l.p8, w.hashLog3);
-                l.mi0 = ZT_LOAD(w.hashTable, l.h);
-                l.mi3 = ZT_LOAD(w.hashTable3, l.h3);
+                l.mi0 = w.hashTable[l.h];
+                l.mi3 = w.hashTable3[l.h3];
                 sh.h[l.j] = l.h;
                 sh.h3[l.j] = l.h3;
             }
@@ -1017,7 +1004,7 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
                 if (sh.h[i] == l.h)
                     l.gstatus = GS_ANOMALY; // same tree as a position in front: the walk would miss that position
             }
-            const bool done = grpRepsAndHash3Pre<T>(l, src, iend, minMatch, mls, sufficient_len, btMask);
+            const bool done = grpRepsAndHash3Pre(l, src, iend, minMatch, mls, sufficient_len, btMask);
             if (done)
                 l.gstatus = GS_ANOMALY; // answered without a walk and without an insertion: the one-lane path's business
             l.rec = true;
@@ -1052,7 +1039,7 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
                 l.wk_current = l.upd_idx;
                 const BYTE *const p = src + (l.wk_current - w.idx0);
                 const U32 h = hashPtr(p, cp.hashLog, mls);
-                l.matchIndex = ZT_LOAD(w.hashTable, h);
+                l.matchIndex = w.hashTable[h];
                 l.clSmaller = l.clLarger = 0;
                 l.btLow = btMask >= l.wk_current ? 0 : l.wk_current - btMask;
                 l.smallerPtr = 2 * (l.wk_current & btMask);
@@ -1061,13 +1048,13 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
                 l.matchEndIdx = l.wk_current + 8 + 1;
                 l.bestLength = 8;
                 l.nbCompares = 1u << cp.searchLog;
-                ZT_STORE(w.hashTable, h, l.wk_current);
+                w.hashTable[h] = l.wk_current;
                 l.wk_pre = false;
                 l.state = ST_UPD_WALK;
             } while (0);
             if (l.state == ST_UPD_WALK) {
                 bool abort;
-                if (grpWalkLevel<true, T>(l, src, iend, w.chainTable, btMask, abort)) {
+                if (grpWalkLevel<true>(l, src, iend, w.chainTable, btMask, abort)) {
                     U32 positions = 0;
                     if (l.bestLength > 384)
                         positions = l.bestLength - 384 < 192 ? l.bestLength - 384 : 192;
@@ -1082,15 +1069,15 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
             const BYTE *const p = src + (l.wk_current - w.idx0);
             const U64 pv = (l.p8_pos == l.wk_current - w.idx0) ? l.p8 : read64(p);
             const U32 h = mls == 5 ? hash5(pv, cp.hashLog) : mls == 6 ? hash6(pv, cp.hashLog) : hash4((U32)pv, cp.hashLog);
-            l.matchIndex = ZT_LOAD(w.hashTable, h);
-            const bool done = grpRepsAndHash3<T>(l, src, iend, minMatch, mls, sufficient_len, btMask, false);
+            l.matchIndex = w.hashTable[h];
+            const bool done = grpRepsAndHash3(l, src, iend, minMatch, mls, sufficient_len, btMask, false);
             if (done) {
                 l.nbMatches = l.mnum;
                 l.state = ST_AFTER_MATCHES;
                 break;
             }
-            ZT_STORE(w.hashTable, h, l.wk_current);
-            grpWalkIssue<T>(l, src, iend, w.chainTable, btMask);
+            w.hashTable[h] = l.wk_current;
+            grpWalkIssue(l, src, iend, w.chainTable, btMask);
             l.state = ST_WALK;
         } while (0);
         ZS_GRP_END
@@ -1102,10 +1089,10 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
 #pragma unroll
         for (U32 lv_ = 0; lv_ < GRP_WALK_LEVELS; ++lv_) // the common levels (read ahead, decided inside 8 bytes)
             if (l.state == ST_WALK && l.wk_pre)
-                grpWalkFastLevel<T>(l, src, iend, w.chainTable, btMask);
+                grpWalkFastLevel(l, src, iend, w.chainTable, btMask);
         if (l.state == ST_WALK && !l.wk_pre) { // everything else, once per trip: the end of a walk, long common prefixes ...
             bool abort;
-            if (grpWalkLevel<false, T>(l, src, iend, w.chainTable, btMask, abort)) {
+            if (grpWalkLevel<false>(l, src, iend, w.chainTable, btMask, abort)) {
                 if (l.grp) {
                     sh.nbm[l.j] = l.mnum;
                     sh.maxML[l.j] = l.last_m_len;
@@ -1169,14 +1156,14 @@ template <int G, class T> ZFN U32 compressBlockOptGrp(GLane *lanes, GrpX &sh, U3
                 for (U32 r = 0; r < l.nrec; ++r) {
                     U32 slot, val;
                     grpRecGet(l, r, slot, val);
-                    ZT_STORE(bt, slot, val);
+                    bt[slot] = val;
                 }
-                ZT_STORE(w.hashTable, l.h, l.q_current);
+                w.hashTable[l.h] = l.q_current;
                 bool later = false;
                 for (U32 i = l.j + 1; i < v; ++i)
                     later = later || (sh.h3[i] == l.h3);
                 if (!later)
-                    ZT_STORE(w.hashTable3, l.h3, l.q_current);
+                    w.hashTable3[l.h3] = l.q_current;
             }
             l.rec = false;
             l.grp = false;

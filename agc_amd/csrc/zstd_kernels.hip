@@ -64,7 +64,7 @@ __host__ __device__ static inline uint32_t zgrp_lds_bytes(uint32_t groups_per_wa
     return (groups_per_wave * ZGRP_STRIDE + groups_per_wave * g * (wide ? ZGRP_REC_STRIDE_WIDE : ZGRP_REC_STRIDE)) * 4;
 }
 
-template <int G, int WPS, class T>
+template <int G, int WPS>
 __global__ void __launch_bounds__(64, WPS) zstd_frames_grp_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, uint32_t *__restrict__ out_size,
                                                                  uint32_t groups_per_wave, const uint8_t *__restrict__ src_base,
                                                                  uint8_t *__restrict__ dst_base, uint8_t *__restrict__ ws_base, uint32_t debug,
@@ -83,15 +83,12 @@ __global__ void __launch_bounds__(64, WPS) zstd_frames_grp_kernel(const ZFrameJo
     l.j = j;
     l.recs = (zs::ZS_LDS_U32P)(zs_lds + groups_per_wave * ZGRP_STRIDE + threadIdx.x * rec_stride);
     const ZFrameJob jb = jobs[job];
-    const uint32_t n = zs::compressFrameGrp<G, T>(&l, sh, ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, debug, gbase + zs::GRPX_WORDS);
+    const uint32_t n = zs::compressFrameGrp<G>(&l, sh, ws_base + jb.ws, jb.cp, src_base + jb.src, jb.src_size, dst_base + jb.dst, debug, gbase + zs::GRPX_WORDS);
     if (j == 0)
         out_size[jb.idx] = n;
 }
-// (T = the tables' entry type: uint16_t for inputs of the btultra2 class -- zs::grpWide false --, uint32_t beyond)
-template __global__ void zstd_frames_grp_kernel<2, 2, uint16_t>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
-template __global__ void zstd_frames_grp_kernel<3, 2, uint16_t>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
-template __global__ void zstd_frames_grp_kernel<2, 2, uint32_t>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
-template __global__ void zstd_frames_grp_kernel<3, 2, uint32_t>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
+template __global__ void zstd_frames_grp_kernel<2, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
+template __global__ void zstd_frames_grp_kernel<3, 2>(const ZFrameJob *, uint32_t, uint32_t *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, uint32_t);
 
 // frames (scattered, padded slots) -> one contiguous buffer in the caller's order
 __global__ void __launch_bounds__(256) zstd_gather_kernel(const ZFrameJob *__restrict__ jobs, uint32_t n_jobs, const uint64_t *__restrict__ dst_off,

@@ -91,14 +91,10 @@ extern "C" {
 uint32_t zs_host_compress_grp(const uint8_t *src, uint32_t n, const uint32_t *cparams7, uint8_t *dst, int G)
 {
     CParams cp = {cparams7[0], cparams7[1], cparams7[2], cparams7[3], cparams7[4], cparams7[5], cparams7[6]};
-    if (!grpEligible(cp, n)) {
-        const WsLayout L1 = wsLayout(cp, n);
-        std::vector<BYTE> ws1(L1.total, 0);
-        return compressFrame(ws1.data(), cp, src, n, dst);
-    }
-    const bool wide = grpWide(cp, n); // (16-bit tables for the btultra2 class, as in the kernel's dispatch)
-    const WsLayout L = wsLayout(cp, n, wide ? 4 : 2);
+    const WsLayout L = wsLayout(cp, n);
     std::vector<BYTE> ws(L.total, 0);
+    if (!grpEligible(cp, n))
+        return compressFrame(ws.data(), cp, src, n, dst);
     std::vector<GLane> lanes(3);
     std::vector<U32> recs(3 * 2 * GRP_RC, 0xDEADBEEFu);
     memset((void *)lanes.data(), 0xA5, sizeof(GLane) * 3); // (lane state is not zeroed on the device either)
@@ -108,16 +104,10 @@ uint32_t zs_host_compress_grp(const uint8_t *src, uint32_t n, const uint32_t *cp
     }
     GrpX sh;
     memset(&sh, 0xA5, sizeof(sh));
-    if (wide)
-        switch (G) {
-        case 1: return compressFrameGrp<1, U32>(lanes.data(), sh, ws.data(), cp, src, n, dst);
-        case 2: return compressFrameGrp<2, U32>(lanes.data(), sh, ws.data(), cp, src, n, dst);
-        default: return compressFrameGrp<3, U32>(lanes.data(), sh, ws.data(), cp, src, n, dst);
-        }
     switch (G) {
-    case 1: return compressFrameGrp<1, U16>(lanes.data(), sh, ws.data(), cp, src, n, dst);
-    case 2: return compressFrameGrp<2, U16>(lanes.data(), sh, ws.data(), cp, src, n, dst);
-    default: return compressFrameGrp<3, U16>(lanes.data(), sh, ws.data(), cp, src, n, dst);
+    case 1: return compressFrameGrp<1>(lanes.data(), sh, ws.data(), cp, src, n, dst);
+    case 2: return compressFrameGrp<2>(lanes.data(), sh, ws.data(), cp, src, n, dst);
+    default: return compressFrameGrp<3>(lanes.data(), sh, ws.data(), cp, src, n, dst);
     }
 }
 }
