@@ -61,9 +61,16 @@ int agc_cmp_last_record(void *h, const uint8_t **ptr, uint64_t *n)
     *n = r.size();
     return 1;
 }
-int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record)
+int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record, const uint8_t *body, uint64_t body_n)
 {
-    return ((CAGCCompressor *)h)->ApplyRecord(record, n, d_record) ? 1 : 0;
+    return ((CAGCCompressor *)h)->ApplyRecord(record, n, d_record, body, body_n) ? 1 : 0;
+}
+int agc_cmp_last_record_body(void *h, const uint8_t **ptr, uint64_t *n)
+{
+    const std::vector<uint8_t> &r = ((CAGCCompressor *)h)->LastRecordBody();
+    *ptr = r.data();
+    *n = r.size();
+    return 1;
 }
 int agc_cmp_append(void *h, const char *in_archive, const char *out_archive, uint32_t verbosity, int concatenated, int adaptive, uint32_t n_threads)
 {

@@ -36,11 +36,12 @@ bool CAGCCompressor::SetDistributed(uint32_t rank, uint32_t world_size, uint32_t
     return true;
 }
 const std::vector<uint8_t> &CAGCCompressor::LastRecord() const { return p->dist_record; }
-bool CAGCCompressor::ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record)
+const std::vector<uint8_t> &CAGCCompressor::LastRecordBody() const { return p->dist_record_body; }
+bool CAGCCompressor::ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record, const uint8_t *body, size_t body_n)
 {
     if (!p->created || p->dist_world < 2 || p->appending || p->concatenated)
         return false;
-    return p->apply_record(record, n, d_record);
+    return p->apply_record(record, n, d_record, body, body_n);
 }
 
 // determine_splitters for a reference genome that already lives in HBM (bench.py)
@@ -616,6 +617,7 @@ bool CAGCCompressor::CommitPrepared()
         return false;
     std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
     I.dist_record.clear();
+    I.dist_record_body.clear();
     I.coll.reset_prev_sample_name();
     for (auto &ct : I.prepared_ctgs)
         if (!I.coll.register_sample_contig(ct.sample, ct.name)) {

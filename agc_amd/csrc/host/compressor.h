@@ -84,8 +84,9 @@ public:
     // need), ApplyRecord everywhere else.  d_record = optional copy of the record in this rank's HBM (e.g. the buffer an
     // RCCL broadcast delivered): the newly minted references are then registered from there without a host round trip.
     bool SetDistributed(uint32_t rank, uint32_t world_size, uint32_t writer_rank);
-    const std::vector<uint8_t> &LastRecord() const;
-    bool ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record);
+    const std::vector<uint8_t> &LastRecord() const;     // the head: every rank
+    const std::vector<uint8_t> &LastRecordBody() const; // the LZ deltas: the writer rank only
+    bool ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record, const uint8_t *body = nullptr, size_t body_n = 0);
 
     // AddSampleDevice in two halves: everything that only reads the classification state (scan, classification, LZ encode of
     // the segments whose group is known), and the order-dependent commit.  Between the two other samples may be committed

@@ -12,9 +12,12 @@ namespace agc {
 // record (apply_record): same group ids, same map/terminator updates, references registered in their own HBM;
 // the writer rank also runs the bookkeeping / zstd / archive stage from it.  Samples are committed strictly in
 // order, so the archive equals the single-GPU one byte for byte.
-// Record layout (little endian): "AGCR" | n_ctg | n_lists | n_new_splitters | first_new_gid | n_new_groups |
+// Record layout (little endian): HEAD = "AGCR" | n_ctg | n_lists | n_new_splitters | first_new_gid | n_new_groups |
 //   contigs: sample\0 name\0 ... | splitters u64... | lists: gid, n_items, items: ctg, part_no, len, rc, kind,
-//   [pk1, pk2, repetitive for kind 0], payload_len, payload
+//   [pk1, pk2, repetitive for kind 0], payload_len, [payload for kinds 0 (new reference) and 1 (raw)]
+// BODY = the payloads of the kind-2 items (LZ deltas) back to back, in item order.  Every rank needs the head (ids, keys, the
+// new references: ~3 MB per human-size sample); only the WRITER needs the body (~22 MB): agc_amd/dist.py broadcasts the one and
+// sends the other point to point.
 // ---------------------------------------------------------------------------
 namespace {
 void put32(bytes_t &d, uint32_t x)
@@ -71,7 +74,9 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
     const std::vector<Contig> &ctgs = *cd.ctgs;
     const std::vector<Placed> &placed = *cd.placed;
     bytes_t &r = dist_record;
+    bytes_t &body = dist_record_body;
     r.clear();
+    body.clear();
     r.insert(r.end(), {'A', 'G', 'C', 'R'});
     put32(r, (uint32_t)ctgs.size());
     const SampleLists &sl = cd.per_sample.at(0); // one registration per record
@@ -134,7 +139,10 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
                 n = cd.enc_len[ei];
             }
             put32(r, (uint32_t)n);
-            r.insert(r.end(), b, b + n);
+            if (kind[idx] == 2)
+                body.insert(body.end(), b, b + n);
+            else
+                r.insert(r.end(), b, b + n);
         }
     }
     // the owner keeps what later classifications read of its new groups (book_and_store does it on the writer)
@@ -151,6 +159,7 @@ void CAGCCompressor::Impl::make_empty_record()
 {
     bytes_t &r = dist_record;
     r.clear();
+    dist_record_body.clear();
     r.insert(r.end(), {'A', 'G', 'C', 'R'});
     put32(r, 0);
     put32(r, 0);
@@ -159,7 +168,7 @@ void CAGCCompressor::Impl::make_empty_record()
     put32(r, 0);
 }
 
-bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec)
+bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n)
 {
     RecReader rr{rec, rec + n};
     if (n < 24 || memcmp(rec, "AGCR", 4) != 0) {
@@ -184,6 +193,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     if (n_ctg == 0 && n_lists == 0 && n_spl == 0 && n_new == 0)
         return rr.p == rr.e; // empty sample: skipped on every rank
     const bool writer = dist_rank == dist_writer;
+    size_t body_pos = 0; // (a record without deltas has no body: every kind-2 payload is checked against body_n below)
     if (!add.empty()) { // adaptive mode: the owner's new splitters (agc_compressor.cpp:1191-1209)
         splitters.insert(splitters.end(), add.begin(), add.end());
         std::sort(splitters.begin(), splitters.end());
@@ -242,8 +252,15 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
                 rep = rr.u8();
             }
             const uint32_t pn = rr.u32();
-            if (!rr.need(pn) || pl.ctg >= n_ctg || gid >= groups.size())
+            if ((kind != 2 && !rr.need(pn)) || pl.ctg >= n_ctg || gid >= groups.size()) {
+                rr.ok = false;
                 break;
+            }
+            if (!writer && kind != 0) { // the other ranks only need what classification reads: groups, keys, references
+                if (kind == 1)
+                    rr.p += pn;
+                continue;
+            }
             const uint32_t idx = (uint32_t)placed.size();
             if (kind == 0) {
                 cd.new_ref_items.push_back(idx);
@@ -261,21 +278,29 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
                 raws.insert(raws.end(), rr.p, rr.p + pn);
                 raw_off.push_back(raws.size());
             } else {
+                if (body_pos + pn > body_n) {
+                    rr.ok = false;
+                    break;
+                }
                 cd.enc_items.push_back(idx);
-                enc.insert(enc.end(), rr.p, rr.p + pn);
+                if (pn)
+                    enc.insert(enc.end(), body + body_pos, body + body_pos + pn);
                 enc_off.push_back(enc.size());
+                body_pos += pn;
             }
-            rr.p += pn;
+            if (kind != 2)
+                rr.p += pn;
             sl.items.push_back(idx);
             placed.push_back(pl);
         }
     }
     sl.begin.push_back((uint32_t)sl.items.size());
-    if (!rr.ok || rr.p != rr.e) {
+    if (!rr.ok || rr.p != rr.e || (writer && body_pos != body_n)) {
         err("malformed commit record");
         return false;
     }
-    st.segments += placed.size();
+    if (writer)
+        st.segments += placed.size();
     // the newly minted references go to this rank's HBM (from the device copy of the record when there is one)
     if (!reg_gid.empty()) {
         if (d_rec) {

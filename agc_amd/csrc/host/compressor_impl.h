@@ -802,10 +802,10 @@ struct CAGCCompressor::Impl {
     }
     // multi-GPU single-archive mode: one registration at a time, committed on every rank from the owner's record
     uint32_t dist_rank = 0, dist_world = 1, dist_writer = 0;
-    bytes_t dist_record;
+    bytes_t dist_record, dist_record_body; // head (every rank) and delta body (the writer only): compressor_dist.cpp
     void make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters);
     void make_empty_record();
-    bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec);
+    bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n);
     void note_new_group(const pk_t &pk, uint32_t gid);
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);

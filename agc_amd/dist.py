@@ -7,14 +7,15 @@ classify and LZ-encode any sample.  What orders the job is the reference's regis
 first-come in sample order, agc_compressor.cpp:954-1050): samples are therefore COMMITTED in order.  Per sample:
 
     owner:   add_sample_dev()            scan + classification + LZ-encode on its GPU, commit record built
-    all:     broadcast(record)           one collective per sample: length, then the bytes (uint8 tensor on the backend's device)
-    others:  apply_record(record)        same group ids / map / terminator updates; the newly minted reference segments inside the
-                                         record are registered in this rank's HBM straight from the broadcast buffer
-    writer:  (inside add/apply)          bookkeeping, zstd parts, collection metadata, archive
+    all:     broadcast(record head)      one collective per sample: lengths, then the bytes (uint8 tensor on the backend's device)
+    owner -> writer: send(record body)   the LZ deltas, point to point: only the writer needs them
+    others:  apply_record(head)          same group ids / map / terminator updates; the newly minted reference segments inside the
+                                         head are registered in this rank's HBM straight from the broadcast buffer
+    writer:  apply_record(head, body)    the same + bookkeeping, zstd parts, collection metadata, archive
 
-The record carries the symbols of every new reference (the "all-gather of newly-minted reference segments" of the north
-star -- a broadcast from the minting rank, since exactly one rank mints at a time), the raw segments and the deltas
-(~16 B per SNP), i.e. MBs per human-size sample.  The archive is byte-identical to the single-GPU / reference one.
+The head carries the symbols of every new reference (the "all-gather of newly-minted reference segments" of the north
+star -- a broadcast from the minting rank, since exactly one rank mints at a time) and the raw segments: ~3 MB per human-size
+sample; the body the deltas (~16 B per SNP): ~22 MB.  The archive is byte-identical to the single-GPU / reference one.
 
 Not covered in this mode: -c (concatenated) and append.
 """
@@ -35,7 +36,8 @@ class DistCompressor:
         self.hbm = device if device is not None and device.type == "cuda" else None
         self.comm = self.hbm if (self.hbm is not None and dist.get_backend() == "nccl") else torch.device("cpu")
         self.next_sample = 0
-        self.bytes_broadcast = 0
+        self.bytes_broadcast = 0  # record heads, to every rank
+        self.bytes_p2p = 0        # record bodies (deltas), owner -> writer
 
     def owner_of(self, i):
         return i % self.world
@@ -46,26 +48,11 @@ class DistCompressor:
         i = self.next_sample
         self.next_sample += 1
         owner = self.owner_of(i)
-        n = torch.zeros(1, dtype=torch.int64, device=self.comm)
+        rec = body = None
         if self.rank == owner:
             self.cmp.add_sample_dev(sample_name, contig_names, d_codes, ctg_off)
-            rec = self.cmp.last_record()
-            n[0] = rec.size
-        dist.broadcast(n, src=owner)
-        size = int(n.item())
-        if self.rank == owner:
-            buf = torch.from_numpy(rec).to(self.comm)
-        else:
-            buf = torch.empty(size, dtype=torch.uint8, device=self.comm)
-        dist.broadcast(buf, src=owner)
-        self.bytes_broadcast += size
-        if self.rank != owner:
-            # parsed on the host; the new references are registered from the copy in this rank's HBM when there is one
-            host = np.ascontiguousarray(buf.cpu().numpy())
-            d_buf = buf if buf.is_cuda else (buf.to(self.hbm) if self.hbm is not None else None)
-            if d_buf is not None:
-                torch.cuda.synchronize(self.hbm)
-            self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None)
+            rec, body = self.cmp.last_record(), self.cmp.last_record_body()
+        self._publish(owner, rec, body)
         return owner
 
     def compress(self, n_total, get_sample, prefetch=True, start=0):
@@ -178,29 +165,41 @@ class DistCompressor:
             self.cmp.close_provide_frames(out, foff_all)
         self.cmp.close(n_threads)
 
-    def _broadcast(self, owner, rec):
+    def _publish(self, owner, rec, body):
+        """one sample's commit record: the head to every rank (broadcast), the delta body to the writer only (point to point);
+        ranks other than the owner apply it.  rec / body: the owner's (numpy uint8), None elsewhere."""
         torch, dist = self.torch, self.dist
-        n = torch.zeros(1, dtype=torch.int64, device=self.comm)
+        n = torch.zeros(2, dtype=torch.int64, device=self.comm)
         if rec is not None:
-            n[0] = rec.size
+            n[0], n[1] = rec.size, body.size
         dist.broadcast(n, src=owner)
-        size = int(n.item())
+        size, bsize = int(n[0]), int(n[1])
         buf = torch.from_numpy(rec).to(self.comm) if rec is not None else torch.empty(size, dtype=torch.uint8, device=self.comm)
         dist.broadcast(buf, src=owner)
         self.bytes_broadcast += size
-        return buf, size
+        b_host = None
+        if bsize and owner != self.writer:
+            if self.rank == owner:
+                dist.send(torch.from_numpy(body).to(self.comm), dst=self.writer)
+            elif self.rank == self.writer:
+                bt = torch.empty(bsize, dtype=torch.uint8, device=self.comm)
+                dist.recv(bt, src=owner)
+                b_host = np.ascontiguousarray(bt.cpu().numpy())
+            self.bytes_p2p += bsize
+        if self.rank != owner:
+            # the head is parsed on the host; the new references are registered from the copy in this rank's HBM when there is one
+            host = np.ascontiguousarray(buf.cpu().numpy())
+            d_buf = buf if buf.is_cuda else (buf.to(self.hbm) if self.hbm is not None else None)
+            if d_buf is not None:
+                torch.cuda.synchronize(self.hbm)
+            self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None,
+                                  b_host.ctypes.data if b_host is not None else None, bsize if b_host is not None else 0)
 
     def _commit_and_publish(self, i):
         self.cmp.commit_prepared()
-        self._broadcast(self.rank, self.cmp.last_record())
+        self._publish(self.rank, self.cmp.last_record(), self.cmp.last_record_body())
         self.next_sample = i + 1
 
     def _receive(self, owner):
-        torch = self.torch
-        buf, size = self._broadcast(owner, None)
-        host = np.ascontiguousarray(buf.cpu().numpy())
-        d_buf = buf if buf.is_cuda else (buf.to(self.hbm) if self.hbm is not None else None)
-        if d_buf is not None:
-            torch.cuda.synchronize(self.hbm)
-        self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None)
+        self._publish(owner, None, None)
         self.next_sample += 1

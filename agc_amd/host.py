@@ -43,7 +43,8 @@ def bind(L):
     L.agc_cmp_stats.argtypes = [vp, C.POINTER(C.c_double), C.c_uint32]
     L.agc_cmp_set_distributed.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.agc_cmp_last_record.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
-    L.agc_cmp_apply_record.argtypes = [vp, vp, C.c_uint64, vp]
+    L.agc_cmp_apply_record.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64]
+    L.agc_cmp_last_record_body.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
     L.agc_cmp_prepare_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_prepare_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_add_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
@@ -158,8 +159,15 @@ class Compressor:
         self.L.agc_cmp_last_record(self.h, C.byref(p), C.byref(n))
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
 
-    def apply_record(self, h_ptr, n, d_ptr=None):
-        if not self.L.agc_cmp_apply_record(self.h, h_ptr, n, d_ptr):
+    def last_record_body(self):
+        """the LZ deltas of the sample just added (the part of its commit record only the writer rank needs)"""
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        self.L.agc_cmp_last_record_body(self.h, C.byref(p), C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+
+    def apply_record(self, h_ptr, n, d_ptr=None, body_ptr=None, body_n=0):
+        if not self.L.agc_cmp_apply_record(self.h, h_ptr, n, d_ptr, body_ptr, body_n):
             raise RuntimeError("ApplyRecord failed (see stderr)")
 
     def drain(self):

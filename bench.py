@@ -451,7 +451,8 @@ def main():
                                 "mb_s_per_host_thread": round((stats["zstd_in"] - stats["zstd_dev_in"]) / 1e6 / max(stats["t_zstd_host"], 1e-9) / threads, 2)},
                        "host_stage_seconds_rank0": {k_: round(stats[k_], 4) for k_ in stats if k_.startswith("t_")},
                        "parallelism": (f"samples round-robin over {world} GPUs into ONE archive: ordered commit, one RCCL broadcast of the commit "
-                                       f"record (new reference segments + deltas) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each; "
+                                       f"record's head (ids, keys, new reference segments) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each, "
+                                       f"its delta body point to point to the writer ({dc.bytes_p2p / max(dc.next_sample, 1) / 1e6:.1f} MB per sample on average); "
                                        "at Close the pending packs are broadcast, every rank's GPU compresses its share, rank 0 gathers and writes") if single else
                                       f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dominant), "achieved": dom.get("as_built", {}).get("achieved"),

@@ -67,7 +67,10 @@ int agc_cmp_close_provide_frames(void *h, const uint8_t *frames, const uint64_t 
  * must pass to agc_cmp_apply_record (d_record: optional copy in that rank's HBM, or NULL). */
 int agc_cmp_set_distributed(void *h, uint32_t rank, uint32_t world_size, uint32_t writer_rank);
 int agc_cmp_last_record(void *h, const uint8_t **ptr, uint64_t *n);
-int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record);
+/* the record has a HEAD every rank applies (group ids, keys, the newly minted reference segments) and a BODY (the LZ deltas) only
+ * the writer rank needs: body / body_n = NULL / 0 on the other ranks */
+int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record, const uint8_t *body, uint64_t body_n);
+int agc_cmp_last_record_body(void *h, const uint8_t **ptr, uint64_t *n);
 
 /* version string of the libzstd in use (archives are byte-identical to the reference's only with the same libzstd) */
 const char *agc_cmp_zstd_version(void *h);
