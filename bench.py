@@ -57,6 +57,10 @@ def parse():
                     help="N > 1: one independent archive shard per rank (no collective) instead of the default: all ranks feed ONE "
                          "archive (ordered commit from broadcast commit records, entropy stage spread over the ranks' GPUs; agc_amd/dist.py)")
     ap.add_argument("--single-archive", action="store_true", help="(the default for N > 1; kept for older command lines)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c1"],
+                    help="c2 (default): BASELINE configs[2], the headline (HBM-resident 3 Gbp samples).  c1: BASELINE configs[1] -- 1000 "
+                         "SARS-CoV-2-size genomes (30 kb, 1 %% SNP from one reference), default parameters, from FASTA files through the product "
+                         "CLI path; the reference CLI is timed beside it on the same files and the two archives are compared")
     ap.add_argument("--no-prefetch", action="store_true", help="do not announce the next sample (its expansion + scan then run inside its own step)")
     ap.add_argument("--verify-entropy", action="store_true",
                     help="CHECKING RUN, not a measurement: every frame the device entropy stage returns (all the packs of this run's Close) is "
@@ -188,6 +192,54 @@ def cpu_baseline(args, mbp):
             "sample": f"oracle/agc_oracle.c scan + index + encode of one {mbp:g} Mbp sample, {dt:.2f} s"}
 
 
+def config_c1(args):
+    """BASELINE configs[1]: 1000 genomes x 30 kb, 1 % SNP from one reference, AGC's defaults (k 31, l 20, s 60000, b 50), one FASTA
+    file per genome (tmpfs).  A collection of 30 Mbp in 1000 tiny contigs is bound by per-file and per-registration host work (open,
+    parse, collection records, 1000 reference-side decisions), not by any kernel: the line says what the product path does on it
+    and what the reference CLI does on the same files -- no GPU benefit is claimed for this shape."""
+    import hashlib
+    from agc_amd import build, synth
+    n = 1000
+    rng = np.random.default_rng(2)
+    ref = synth.random_seq(rng, 30_000)
+    threads = args.threads or host_cpus()
+    amd = os.path.join(ROOT, "agc_amd", "bin", "agc_amd")
+    refbin = os.path.join(ROOT, "oracle", "_ref", "agc")
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        files = []
+        for i in range(n):
+            g = ref if i == 0 else synth.mutate(rng, ref, 0.01)
+            fn = os.path.join(td, f"g{i:04d}.fa")
+            synth.to_fasta(fn, [g], [f"MN{i:06d}.1 synthetic genome {i}"])
+            files.append(fn)
+
+        def run(binary, out):
+            t0 = time.perf_counter()
+            subprocess.run([binary, "create", "-t", str(threads), "-o", out] + files, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return time.perf_counter() - t0
+        run(amd, os.path.join(td, "w.agc"))  # warm-up (HIP context creation, page cache)
+        ts = sorted(run(amd, os.path.join(td, "a.agc")) for _ in range(args.steps if args.steps > 1 else 3))
+        t_amd = ts[len(ts) // 2]
+        cpu = None
+        if os.path.exists(refbin) and not args.no_cpu_baseline:
+            env_t = sorted(run(refbin, os.path.join(td, "r.agc")) for _ in range(3))
+            same = hashlib.sha256(open(os.path.join(td, "a.agc"), "rb").read()).digest() == hashlib.sha256(open(os.path.join(td, "r.agc"), "rb").read()).digest()
+            cpu = {"value": round(n * 30_000 / env_t[1] / 1e9, 4), "unit": "Gbp/s", "cores": threads, "kind": "reference",
+                   "sample": f"oracle/_ref/agc create -t {threads} on the same 1000 files: median of 3 = {env_t[1]:.2f} s", "archives_identical": same}
+        bases = n * 30_000
+        out = {"metric": "input Gbp/s compressed (create), BASELINE configs[1]: whole CLI run from 1000 FASTA files", "value": round(bases / t_amd / 1e9, 4),
+               "unit": "Gbp/s", "n_gpus": 1, "steps": len(ts), "warmup": 1, "ms_per_step": round(t_amd * 1e3, 1), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: 1000 synthetic SARS-CoV-2-size genomes (30 kb, 1 % SNP from one reference), k=31 l=20 s=60000 b=50, "
+                                      "one FASTA file each (tmpfs), `agc_amd create` (process start, HIP context, files, archive) -- median wall of "
+                                      f"{len(ts)} runs; a host-bound shape: 30 Mbp in 1000 one-contig registrations",
+                          "host_threads": threads},
+               "roofline": None}
+        if cpu:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+
+
 def file_mode(args):
     """`agc_amd create` from FASTA files at the bench's sample size: the PCIe- and file-system-inclusive rate (never `value`
     of the HBM-resident bench)."""
@@ -240,6 +292,8 @@ def main():
     if "--verify-entropy" in sys.argv:
         os.environ["AGC_AMD_VERIFY_DEV_FRAMES"] = "1"
     args = parse()
+    if args.config == "c1":
+        return config_c1(args)
     if args.from_fasta:
         return file_mode(args)
     import torch
