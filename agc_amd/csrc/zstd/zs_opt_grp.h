@@ -33,7 +33,10 @@ constexpr U32 GRP_MAX = 3;   // lanes per group the exchange record is sized for
 constexpr U32 GRP_MC = 6;    // matches of a request a lane keeps in registers (99.9 % of the requests have <= 5)
 constexpr U32 GRP_RC = 16;   // tree stores a walk may record: 14 levels + the two closing zeros (99.5 % of the walks)
 constexpr U32 GRP_PT = 8;    // price targets per trip
-constexpr U32 GRP_STORE_SEQS = 4; // sequences of a finished chunk stored per trip
+#ifndef ZS_GRP_STORE_SEQS
+#define ZS_GRP_STORE_SEQS 4
+#endif
+constexpr U32 GRP_STORE_SEQS = ZS_GRP_STORE_SEQS; // sequences of a finished chunk stored per trip (<= 4: one 8-byte read of the path list)
 constexpr U32 GRP_ST_LITS = 4;    // ... without a dependent chain when their literal runs are at most this long (99 % of the runs)
 constexpr U32 GRP_ST_LAST = 0xFFFFFFF0u, GRP_ST_DONE = 0xFFFFFFF1u; // store cursor: lastSequence is next / the chunk is stored
 #ifndef ZS_GRP_WALK_LEVELS
