@@ -114,6 +114,9 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
     I.zpool.reset(new ThreadPool(nt, 10));
+    I.bpool.reset(new ThreadPool(std::max(1u, std::min(4u, nt / 2))));
+    if (const char *e = getenv("AGC_AMD_ASYNC_BOOK"))
+        I.async_book = atoi(e) != 0;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
@@ -289,6 +292,9 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
     I.zpool.reset(new ThreadPool(nt, 10));
+    I.bpool.reset(new ThreadPool(std::max(1u, std::min(4u, nt / 2))));
+    if (const char *e = getenv("AGC_AMD_ASYNC_BOOK"))
+        I.async_book = atoi(e) != 0;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
@@ -618,12 +624,15 @@ bool CAGCCompressor::CommitPrepared()
     std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
     I.dist_record.clear();
     I.dist_record_body.clear();
-    I.coll.reset_prev_sample_name();
-    for (auto &ct : I.prepared_ctgs)
-        if (!I.coll.register_sample_contig(ct.sample, ct.name)) {
-            I.err("Error: Pair sample_name:contig_name " + ct.sample + ":" + ct.name + " is already in the archive!");
-            return false; // (AddSampleFiles skips such contigs; a device-resident sample is all or nothing)
-        }
+    {
+        std::lock_guard<std::mutex> coll_lk(I.coll_mtx); // (the bookkeeping of the previous sample may be looking its contigs up)
+        I.coll.reset_prev_sample_name();
+        for (auto &ct : I.prepared_ctgs)
+            if (!I.coll.register_sample_contig(ct.sample, ct.name)) {
+                I.err("Error: Pair sample_name:contig_name " + ct.sample + ":" + ct.name + " is already in the archive!");
+                return false; // (AddSampleFiles skips such contigs; a device-resident sample is all or nothing)
+            }
+    }
     if (I.prepared_ctgs.empty()) {
         // a sample without contigs registers nothing (the reference warns and skips such a file, agc_compressor.cpp:2187-2195);
         // the other ranks still expect one record per sample: an empty one
@@ -653,6 +662,8 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         return false;
     if (files.empty())
         return true;
+    if (!I.book_wait())
+        return false;
     I.processed_samples = I.appending ? (uint32_t)I.coll.no_samples() : 0; // agc_compressor.cpp:2150-2153
     I.stored_samples = I.processed_samples / I.pack_cardinality * I.pack_cardinality;
     if (I.concatenated)
@@ -670,7 +681,9 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     std::deque<Pending> pending;
     uint64_t pending_bytes = 0;
     const uint64_t WINDOW_BYTES = 64ull << 20;
-    const uint32_t WINDOW_MAX = I.adaptive ? 1u : 256u; // new splitters change later scans: no speculation in -a mode
+    // (AGC_AMD_WINDOW_MAX: tests pin the window, e.g. to 1 = every registration on its own, bookkeeping beside the next one)
+    static const uint32_t window_cap = getenv("AGC_AMD_WINDOW_MAX") ? (uint32_t)std::max(1, atoi(getenv("AGC_AMD_WINDOW_MAX"))) : 256u;
+    const uint32_t WINDOW_MAX = I.adaptive ? 1u : window_cap; // new splitters change later scans: no speculation in -a mode
     uint32_t window = 1; // grows while whole windows commit, shrinks to what did commit otherwise
 
     auto run_window = [&]() -> bool {
@@ -809,7 +822,10 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
 
     Pending cur;
     for (auto &sf : files) {
-        I.coll.reset_prev_sample_name();
+        {
+            std::lock_guard<std::mutex> coll_lk(I.coll_mtx);
+            I.coll.reset_prev_sample_name();
+        }
         double t0 = now();
         launch();
         FileData fd = inflight.front().get();
@@ -826,7 +842,12 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
             const std::string &id = fd.ids[ci];
             bytes_t &contig = fd.contigs[ci];
             const std::string sname = I.concatenated ? std::string() : sf.first;
-            if (!I.coll.register_sample_contig(sname, id))
+            bool registered;
+            {
+                std::lock_guard<std::mutex> coll_lk(I.coll_mtx); // (the bookkeeping of an earlier file may be looking its contigs up)
+                registered = I.coll.register_sample_contig(sname, id);
+            }
+            if (!registered)
                 I.err("Error: Pair sample_name:contig_name " + (I.concatenated ? id : sf.first) + ":" + id + " is already in the archive!");
             else {
                 Contig ct;
@@ -869,6 +890,8 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         I.processed_samples = (uint32_t)I.coll.no_samples();
     } else if (!drain())
         return false;
+    if (!I.book_wait())
+        return false;
     if (I.processed_samples % I.pack_cardinality != 0) {
         I.coll.store_contig_batch((I.processed_samples / I.pack_cardinality) * I.pack_cardinality, I.processed_samples);
         I.stored_samples = I.processed_samples;
@@ -882,6 +905,8 @@ bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off
 {
     Impl &I = *p;
     if (!I.created || I.close_collected || !src || !off || !n)
+        return false;
+    if (!I.book_wait())
         return false;
     I.z_wait_all(); // (the staging buffers below are the entropy thread's)
     I.store_open_batch();
@@ -940,7 +965,7 @@ bool CAGCCompressor::CloseProvideFrames(const uint8_t *frames, const uint64_t *o
 
 bool CAGCCompressor::Drain()
 {
-    if (!p->created)
+    if (!p->created || !p->book_wait())
         return false;
     p->z_wait_all();
     return true;
@@ -968,6 +993,8 @@ bool CAGCCompressor::Close(uint32_t no_threads)
         I.err("Close: CloseCollectPacks was called but the frames were never provided");
         return false;
     }
+    if (!I.book_wait()) // every registration is in the books
+        return false;
     // the open collection batch (contig details of up to pack_cardinality samples: one thread of zstd-19 work, 0.4 s at human
     // scale) is serialised while the entropy stage of the delta packs runs; both only buffer parts, which are flushed below in
     // stream-id order whatever their arrival order

@@ -116,6 +116,74 @@ void CAGCCompressor::Impl::z_shutdown()
     z_thread.join();
 }
 
+// ---- the asynchronous bookkeeping stage (compressor_impl.h) ------------------
+void CAGCCompressor::Impl::book_submit(std::unique_ptr<BookTask> &&t)
+{
+    {
+        std::unique_lock<std::mutex> lk(book_mtx);
+        // (a task holds up to a sample's deltas: the queue stays short)
+        book_idle_cv.wait(lk, [&] { return book_queue.size() < 4; });
+        if (!book_thread.joinable())
+            book_thread = std::thread([this] { book_main(); });
+        book_queue.emplace_back(std::move(t));
+    }
+    book_cv.notify_all();
+}
+
+void CAGCCompressor::Impl::book_main()
+{
+    for (;;) {
+        std::unique_ptr<BookTask> t;
+        {
+            std::unique_lock<std::mutex> lk(book_mtx);
+            book_cv.wait(lk, [&] { return book_stop || !book_queue.empty(); });
+            if (book_queue.empty())
+                return; // (book_stop)
+            t = std::move(book_queue.front());
+            book_queue.pop_front();
+            book_busy = true;
+        }
+        const double t0 = now();
+        book_on_thread = true;
+        const bool ok = book_and_store(t->cd);
+        book_on_thread = false;
+        t.reset();
+        {
+            std::lock_guard<std::mutex> lk(book_mtx);
+            book_busy = false;
+            book_seconds += now() - t0;
+            if (!ok)
+                book_failed = true;
+        }
+        book_idle_cv.notify_all();
+    }
+}
+
+// every queued registration is in the books; false: one of them failed (the message is out already)
+bool CAGCCompressor::Impl::book_wait()
+{
+    if (!book_thread.joinable())
+        return true;
+    std::unique_lock<std::mutex> lk(book_mtx);
+    book_idle_cv.wait(lk, [&] { return book_queue.empty() && !book_busy; });
+    st.t_store += book_seconds;
+    st.h_store += book_seconds;
+    book_seconds = 0;
+    return !book_failed;
+}
+
+void CAGCCompressor::Impl::book_shutdown()
+{
+    if (!book_thread.joinable())
+        return;
+    {
+        std::lock_guard<std::mutex> lk(book_mtx);
+        book_stop = true;
+    }
+    book_cv.notify_all();
+    book_thread.join();
+}
+
 void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
 {
     double t0 = now();
@@ -177,7 +245,10 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         // frame whatever their number (a frame is a serial chain; a second round would last as long as the first): when there are
         // more packs than that, the host pool takes the SMALLEST ones (the fewest bytes per frame taken off the device); then the
         // largest ones move over until the device's byte share is the one that lets both sides finish together.
-        const uint32_t resident = std::max<uint32_t>(1u, agc_hip_zstd17_resident_frames(hip));
+        // (AGC_AMD_ZSTD_EXTRA_FRAMES: frames beyond one resident round.  The launch is sorted longest first, so the waves of the
+        // smallest frames retire early and the extra ones -- smaller still -- take their slots while the largest are still at work)
+        static const uint32_t extra_frames = getenv("AGC_AMD_ZSTD_EXTRA_FRAMES") ? (uint32_t)strtoul(getenv("AGC_AMD_ZSTD_EXTRA_FRAMES"), nullptr, 10) : 0u;
+        const uint32_t resident = std::max<uint32_t>(1u, agc_hip_zstd17_resident_frames(hip)) + extra_frames;
         size_t lo = 0, hi = by_size.size();
         // (a handful of packs beyond 16 KiB -- the one-lane kernel's class, a launch of its own that lasts as long as a whole
         // launch of small frames -- is the host pool's: by_size ends with them)
@@ -390,6 +461,7 @@ void CAGCCompressor::Impl::after_registration()
             processed_samples = max_ps;
     }
     if (processed_samples % pack_cardinality == 0) {
+        std::lock_guard<std::mutex> coll_lk(coll_mtx); // (the other thread may be adding the next sample's contigs)
         coll.store_contig_batch(processed_samples - pack_cardinality, processed_samples);
         stored_samples = processed_samples;
     }
@@ -1226,6 +1298,10 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
     if (b.overlap_encode && overlap_mode == 2 && !b.enc_in_flight && !overlap_encode_begin(b))
         return false;
     // ---- add_segment, part 4: final placement + part numbers ----
+    // (the bookkeeping of the previous registration may still be reading placed_buf / fetch_buf / enc_buf*: from here on they
+    // are this window's)
+    if (!book_wait())
+        return false;
     std::vector<Placed> &placed = placed_buf;
     placed.clear();
     placed.reserve(segs.size() + segs.size() / 8 + 16);
@@ -1422,6 +1498,8 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
                 placed[idx].gid = (int32_t)it->second;
             }
         const uint32_t no_new = gid - no_segments;
+        if (no_new && !book_wait()) // (`groups` grows: no queued bookkeeping -- records applied since the prepare -- may hold a reference into it)
+            return false;
         for (uint32_t i = 0; i < no_new; ++i) {
             groups.emplace_back();
             Group &g = groups.back();
@@ -1534,6 +1612,9 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     b.changed.clear();
     for (uint32_t idx : new_ref_items) {
         note_new_group(placed[idx].pk, (uint32_t)placed[idx].gid);
+        // (what later classifications read of the group; its packs are the bookkeeping stage's)
+        groups[(uint32_t)placed[idx].gid].exists = true;
+        groups[(uint32_t)placed[idx].gid].ref_size = (uint64_t)placed[idx].len + 1;
         if (placed[idx].pk.first != NO_KMER && placed[idx].pk.second != NO_KMER) { // terminator lists that gained an entry
             b.changed.push_back(placed[idx].pk.first);
             b.changed.push_back(placed[idx].pk.second);
@@ -1689,7 +1770,18 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
         if (dist_rank != dist_writer)
             return true; // the writer rank does the bookkeeping from the record
     }
-    const bool ok = book_and_store(cdta);
+    if (book_can_async(b.n_samples)) {
+        // beside the next sample: the task points into placed_buf / fetch_buf / enc_buf*, which stage_place of the next
+        // window waits for (book_wait) before it writes them again
+        std::unique_ptr<BookTask> t(new BookTask());
+        t->ctgs = *b.ctgs;
+        t->cd = std::move(cdta);
+        t->cd.ctgs = &t->ctgs;
+        book_submit(std::move(t));
+        LAP("book_and_store (queued)");
+        return true;
+    }
+    const bool ok = book_wait() && book_and_store(cdta);
     LAP("book_and_store");
     return ok;
 }
@@ -1697,7 +1789,7 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
 // store_segments, second half (agc_compressor.cpp:989-1050): per-group bookkeeping, zstd parts, collection records
 bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
 {
-    double t0 = now(), dev0 = st.t_device;
+    double t0 = now(), dev0 = book_on_thread ? 0.0 : st.t_device;
     const std::vector<Contig> &ctgs = *cdta.ctgs;
     const std::vector<Placed> &placed = *cdta.placed;
     const uint32_t n_ctg = (uint32_t)ctgs.size(), commit_upto = cdta.commit_upto;
@@ -1716,10 +1808,16 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
     for (uint32_t i = 0; i < enc_items.size(); ++i)
         pos_enc[enc_items[i]] = i;
     std::vector<uint32_t> in_group_id(placed.size(), 0);
-    // contig descriptors of the collection (agc_compressor.cpp:1038-1049)
+    std::vector<uint8_t> is_new_ref(placed.size(), 0); // the item that becomes its group's reference (stage_store / the record decided)
+    for (uint32_t idx : new_ref_items)
+        is_new_ref[idx] = 1;
+    ThreadPool *const wp = book_on_thread ? bpool.get() : pool.get();
+    // contig descriptors of the collection (agc_compressor.cpp:1038-1049).  (The sample table may grow on the other thread --
+    // the next sample's contigs --; the descriptors found here stay where they are.)
     std::vector<CollectionV3::ContigDesc *> cd(n_ctg, nullptr);
     bool dup_names_in_batch = false;
     {
+        std::lock_guard<std::mutex> coll_lk(coll_mtx);
         std::set<CollectionV3::ContigDesc *> seen;
         for (uint32_t c = 0; c < n_ctg; ++c) {
             if (ctgs[c].sample_idx < sample_from || ctgs[c].sample_idx >= commit_upto)
@@ -1750,7 +1848,6 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                 Group &g = groups[gid];
                 for (uint32_t ii = sl.begin[li]; ii < sl.begin[li + 1]; ++ii) {
                     const uint32_t idx = sl.items[ii];
-                    const Placed &pl = placed[idx];
                     uint32_t igid;
                     if (gid < NO_RAW_GROUPS) {
                         if (g.raw_off.size() == pack_cardinality)
@@ -1759,8 +1856,7 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                         ++g.no_seqs;
                         Group::push(g.raw_data, g.raw_off, fetched.data() + fetched_off[fi], fetched_off[fi + 1] - fetched_off[fi]);
                         igid = g.no_seqs - 1;
-                    } else if (!g.exists) {
-                        g.exists = true;
+                    } else if (is_new_ref[idx]) {
                         const uint32_t fi = pos_newref[idx];
                         ZJob j;
                         j.stream_id = g.stream_ref;
@@ -1768,7 +1864,6 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                         j.data.assign(fetched.begin() + fetched_off[fi], fetched.begin() + fetched_off[fi + 1]);
                         j.repetitive = cdta.repetitive[fi] != 0;
                         jobs.emplace_back(std::move(j));
-                        g.ref_size = (uint64_t)pl.len + 1;
                         g.no_seqs = 1;
                         igid = 0;
                     } else {
@@ -1797,10 +1892,10 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
         // groups are independent of each other (the reference runs them on all worker threads,
         // agc_compressor.cpp:989-1050): big samples go to the pool in chunks, jobs merged in list order
         if (sl.n_lists() >= par_min) {
-            const size_t n_chunks = std::min<size_t>(sl.n_lists(), (size_t)pool->size() * 8);
+            const size_t n_chunks = std::min<size_t>(sl.n_lists(), (size_t)wp->size() * 8);
             std::vector<std::vector<ZJob>> chunk_jobs(n_chunks);
             defer_stream_reg = true;
-            pool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
+            wp->parallel_for(n_chunks, [&](size_t ci, unsigned) {
                 book(sl.n_lists() * ci / n_chunks, sl.n_lists() * (ci + 1) / n_chunks, chunk_jobs[ci]);
             });
             // a group taken over from an input archive without a delta stream (append mode) registers it with its first pack
@@ -1846,8 +1941,9 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
             all_jobs.emplace_back(std::move(j));
         jobs_end[sidx] = all_jobs.size();
     }
-    stage_end(st.t_store, st.h_store, t0, dev0);
-    if (verbosity > 1)
+    if (!book_on_thread) // (a queued task's time is added by book_wait)
+        stage_end(st.t_store, st.h_store, t0, dev0);
+    if (verbosity > 1 && !book_on_thread)
         std::cerr << "registration: " << placed.size() << " items; host-only seconds so far: scan " << st.h_scan << " classify " << st.h_classify
                   << " register " << st.h_register << " encode " << st.h_encode << " store " << st.h_store << std::endl;
     // the parts take their places in the archive now (per registration, then its end-of-registration steps); their payload

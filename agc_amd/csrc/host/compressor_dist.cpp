@@ -145,13 +145,6 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
                 r.insert(r.end(), b, b + n);
         }
     }
-    // the owner keeps what later classifications read of its new groups (book_and_store does it on the writer)
-    if (dist_rank != dist_writer)
-        for (uint32_t idx : cd.new_ref_items) {
-            Group &g = groups[(uint32_t)placed[idx].gid];
-            g.exists = true;
-            g.ref_size = (uint64_t)placed[idx].len + 1;
-        }
 }
 
 // the record of a sample without contigs: nothing to register anywhere
@@ -202,6 +195,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
             return false;
     }
     if (writer) {
+        std::lock_guard<std::mutex> coll_lk(coll_mtx);
         coll.reset_prev_sample_name();
         for (auto &c : ctgs)
             if (!coll.register_sample_contig(c.sample, c.name)) {
@@ -210,6 +204,8 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
             }
     }
     if (n_new) {
+        if (!book_wait()) // (`groups` grows: no queued bookkeeping may hold a reference into it)
+            return false;
         if (first_new != no_segments) {
             err("commit record out of order: new groups start at " + std::to_string(first_new) + ", expected " + std::to_string(no_segments));
             return false;
@@ -271,7 +267,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
                 reg_len.push_back(pn);
                 reg_off.push_back((uint64_t)(rr.p - rec));
                 note_new_group(pl.pk, gid);
-                groups[gid].exists = !writer; // the writer's bookkeeping turns it on (first item = reference)
+                groups[gid].exists = true;
                 groups[gid].ref_size = (uint64_t)pn + 1;
             } else if (kind == 1) {
                 cd.raw_items.push_back(idx);
@@ -314,22 +310,32 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     }
     if (!writer)
         return true;
-    // fetched = new references, then raw items (the layout book_and_store indexes)
-    bytes_t fetched;
+    // fetched = new references, then raw items (the layout book_and_store indexes).  Everything the bookkeeping reads is the
+    // task's own: it runs beside the next owner's commit
+    std::unique_ptr<BookTask> t(new BookTask());
+    bytes_t &fetched = t->fetched;
     fetched.reserve(refs_raw.size() + raws.size());
     fetched.insert(fetched.end(), refs_raw.begin(), refs_raw.end());
     fetched.insert(fetched.end(), raws.begin(), raws.end());
     cd.fetched_off = ref_off;
     for (size_t i = 1; i < raw_off.size(); ++i)
         cd.fetched_off.push_back(refs_raw.size() + raw_off[i]);
-    cd.ctgs = &ctgs;
-    cd.placed = &placed;
-    cd.fetched = &fetched;
+    t->ctgs = std::move(ctgs);
+    t->placed = std::move(placed);
+    t->enc = std::move(enc);
     for (size_t i = 0; i + 1 < enc_off.size(); ++i) {
-        cd.enc_ptr.push_back(enc.data() + enc_off[i]);
+        cd.enc_ptr.push_back(t->enc.data() + enc_off[i]);
         cd.enc_len.push_back((uint32_t)(enc_off[i + 1] - enc_off[i]));
     }
-    return book_and_store(cd);
+    t->cd = std::move(cd);
+    t->cd.ctgs = &t->ctgs;
+    t->cd.placed = &t->placed;
+    t->cd.fetched = &t->fetched;
+    if (book_can_async(1)) {
+        book_submit(std::move(t));
+        return true;
+    }
+    return book_wait() && book_and_store(t->cd);
 }
 
 } // namespace agc

@@ -679,7 +679,43 @@ struct CAGCCompressor::Impl {
     void z_wait_all();
     void z_main();
     void z_shutdown();
-    ~Impl() { z_shutdown(); }
+    ~Impl()
+    {
+        book_shutdown();
+        z_shutdown();
+    }
+
+    // Asynchronous bookkeeping stage.  The second half of store_segments (book_and_store: packs, in-group ids, collection
+    // records, the parts' places in the archive) reads nothing the classification of the next sample needs and writes nothing
+    // it reads: it runs on one background thread, in registration order, beside the next sample's scan and classification (and,
+    // on the writer rank of the multi-GPU mode, beside the next owner's commit).  What orders the two threads:
+    //   * book_wait() before the main thread reuses the buffers a queued task points into (stage_place), grows `groups`
+    //     (stage_register, apply_record) or reads what the stage produces (Close, the sync path);
+    //   * coll_mtx around every access to the collection's sample table;
+    //   * Group::exists / ref_size belong to the main thread (set when the group is minted), the packs to the book thread.
+    // Not used in append / concatenated mode, for windows of several registrations, or with AGC_AMD_SYNC_ENTROPY;
+    // AGC_AMD_ASYNC_BOOK=0 turns it off.
+    struct BookTask {
+        CommitData cd;
+        std::vector<Contig> ctgs;   // own copy (the caller's vector does not outlive its call)
+        std::vector<Placed> placed; // apply_record: everything is the task's own
+        bytes_t fetched, enc;
+    };
+    std::thread book_thread;
+    std::mutex book_mtx;
+    std::condition_variable book_cv, book_idle_cv;
+    std::deque<std::unique_ptr<BookTask>> book_queue;
+    bool book_busy = false, book_stop = false, book_failed = false;
+    bool async_book = true;
+    double book_seconds = 0;            // the book thread's own time (added to st.t_store / h_store by book_wait)
+    std::unique_ptr<ThreadPool> bpool;  // the stage's own workers (`pool` belongs to the thread that drives the steps)
+    std::mutex coll_mtx;
+    bool book_can_async(uint32_t n_samples) const { return async_book && !appending && !concatenated && !sync_entropy && n_samples == 1; }
+    void book_submit(std::unique_ptr<BookTask> &&t);
+    void book_main();
+    bool book_wait();
+    void book_shutdown();
+    bool book_on_thread = false; // (book thread only) book_and_store runs as a queued task
 
     bool created = false;
     uint32_t pack_cardinality = 50, k = 31, segment_size = 60000, mml = 20, verbosity = 0;

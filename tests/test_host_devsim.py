@@ -127,6 +127,28 @@ def test_pool_paths_of_the_host_stages_give_the_same_archive(cli, name, tmp_path
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("name,par_min", [("syn_c4_twin", "1"), ("syn_shuffled", "100000")])
+def test_bookkeeping_beside_the_next_registration_gives_the_same_archive(cli, name, par_min, tmp_path, monkeypatch):
+    """AGC_AMD_WINDOW_MAX=1: every file is a window of its own, so its bookkeeping (packs, in-group ids, collection records,
+    archive parts) is queued to the bookkeeping thread and runs beside the next file's scan and classification -- the path
+    device-resident samples (bench.py, the multi-GPU mode) always take; with the stage's own worker pool and without.
+    AGC_AMD_ASYNC_BOOK=0 (the same windows, bookkeeping on the calling thread) must give the same bytes."""
+    monkeypatch.setenv("AGC_AMD_WINDOW_MAX", "1")
+    monkeypatch.setenv("AGC_AMD_PAR_MIN", par_min)
+    monkeypatch.setenv("AGC_AMD_LAPS", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "o.agc")
+    r = subprocess.run([cli, "create"] + args + ["-t", "4", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    assert r.stderr.count("book_and_store (queued)") == len(files), r.stderr[-2000:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
+    if name == "syn_shuffled":
+        monkeypatch.setenv("AGC_AMD_ASYNC_BOOK", "0")
+        r = subprocess.run([cli, "create"] + args + ["-t", "4", "-o", out] + files, capture_output=True, text=True, timeout=300)
+        assert "(queued)" not in r.stderr
+        assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
+
+
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_shuffled", "syn_c4_twin", "syn_viral"])
 def test_mapped_reader_gives_the_same_archive(cli, name, tmp_path, monkeypatch):
     """AGC_AMD_MAP_MIN=1: every plain input file goes through the mapped, multi-threaded reader big assemblies get"""
