@@ -67,10 +67,15 @@ int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8
 }
 int agc_cmp_last_record_body(void *h, const uint8_t **ptr, uint64_t *n)
 {
-    const std::vector<uint8_t> &r = ((CAGCCompressor *)h)->LastRecordBody();
-    *ptr = r.data();
-    *n = r.size();
+    size_t m = 0;
+    *ptr = ((CAGCCompressor *)h)->LastRecordBody(&m);
+    *n = m;
     return 1;
+}
+int agc_cmp_record_body_buffer(void *h, uint64_t n, uint8_t **ptr)
+{
+    *ptr = ((CAGCCompressor *)h)->RecordBodyBuffer(n);
+    return *ptr ? 1 : 0;
 }
 int agc_cmp_append(void *h, const char *in_archive, const char *out_archive, uint32_t verbosity, int concatenated, int adaptive, uint32_t n_threads)
 {

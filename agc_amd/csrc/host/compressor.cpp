@@ -36,7 +36,31 @@ bool CAGCCompressor::SetDistributed(uint32_t rank, uint32_t world_size, uint32_t
     return true;
 }
 const std::vector<uint8_t> &CAGCCompressor::LastRecord() const { return p->dist_record; }
-const std::vector<uint8_t> &CAGCCompressor::LastRecordBody() const { return p->dist_record_body; }
+const uint8_t *CAGCCompressor::LastRecordBody(size_t *n) const
+{
+    *n = p->dist_body_n;
+    return p->dist_body_buf.data();
+}
+uint8_t *CAGCCompressor::RecordBodyBuffer(size_t n)
+{
+    Impl &I = *p;
+    if (!I.created || I.dist_world < 2)
+        return nullptr;
+    if (!I.body_recv) {
+        std::lock_guard<std::mutex> lk(I.body_pool_mtx);
+        if (!I.body_pool.empty()) {
+            I.body_recv = std::move(I.body_pool.back());
+            I.body_pool.pop_back();
+        }
+    }
+    if (!I.body_recv) {
+        I.body_recv.reset(new PinnedBytes());
+        I.body_recv->ctx = I.hip;
+    }
+    if (!I.body_recv->resize(n + n / 8 + 64, false)) // (headroom: the next samples' bodies are about as long)
+        return nullptr;
+    return I.body_recv->data();
+}
 bool CAGCCompressor::ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record, const uint8_t *body, size_t body_n)
 {
     if (!p->created || p->dist_world < 2 || p->appending || p->concatenated)
@@ -120,7 +144,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
-    I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
+    I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_PAR_MIN"))
         I.par_min = (size_t)std::max(1LL, atoll(e));
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
@@ -298,7 +322,7 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
-    I.enc_buf.ctx = I.enc_buf2.ctx = I.hip;
+    I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_PAR_MIN"))
         I.par_min = (size_t)std::max(1LL, atoll(e));
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
@@ -623,7 +647,7 @@ bool CAGCCompressor::CommitPrepared()
         return false;
     std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
     I.dist_record.clear();
-    I.dist_record_body.clear();
+    I.dist_body_n = 0;
     {
         std::lock_guard<std::mutex> coll_lk(I.coll_mtx); // (the bookkeeping of the previous sample may be looking its contigs up)
         I.coll.reset_prev_sample_name();

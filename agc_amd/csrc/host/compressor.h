@@ -85,7 +85,10 @@ public:
     // RCCL broadcast delivered): the newly minted references are then registered from there without a host round trip.
     bool SetDistributed(uint32_t rank, uint32_t world_size, uint32_t writer_rank);
     const std::vector<uint8_t> &LastRecord() const;     // the head: every rank
-    const std::vector<uint8_t> &LastRecordBody() const; // the LZ deltas: the writer rank only
+    const uint8_t *LastRecordBody(size_t *n) const;     // the LZ deltas: the writer rank only (pinned host memory)
+    // writer rank: where the next record's body should be received (pinned host memory, n bytes); an ApplyRecord whose `body` is
+    // this pointer takes the buffer over instead of copying it (any other pointer is copied)
+    uint8_t *RecordBodyBuffer(size_t n);
     bool ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record, const uint8_t *body = nullptr, size_t body_n = 0);
 
     // AddSampleDevice in two halves: everything that only reads the classification state (scan, classification, LZ encode of

@@ -74,9 +74,10 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
     const std::vector<Contig> &ctgs = *cd.ctgs;
     const std::vector<Placed> &placed = *cd.placed;
     bytes_t &r = dist_record;
-    bytes_t &body = dist_record_body;
     r.clear();
-    body.clear();
+    dist_body_n = 0;
+    std::vector<const uint8_t *> body_src; // kind-2 payloads in item order: gathered below by the worker pool
+    std::vector<uint64_t> body_off{0};
     r.insert(r.end(), {'A', 'G', 'C', 'R'});
     put32(r, (uint32_t)ctgs.size());
     const SampleLists &sl = cd.per_sample.at(0); // one registration per record
@@ -139,12 +140,31 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
                 n = cd.enc_len[ei];
             }
             put32(r, (uint32_t)n);
-            if (kind[idx] == 2)
-                body.insert(body.end(), b, b + n);
-            else
+            if (kind[idx] == 2) {
+                body_src.push_back(b);
+                body_off.push_back(body_off.back() + n);
+            } else
                 r.insert(r.end(), b, b + n);
         }
     }
+    // the body: ~22 MB per human-size sample, into pinned memory (its next stop is the writer's GPU or socket)
+    const size_t nb = body_src.size();
+    if (!dist_body_buf.resize(body_off[nb] + body_off[nb] / 8 + 64, false)) {
+        err("out of memory (commit record)");
+        return;
+    }
+    uint8_t *const dst = dist_body_buf.data();
+    auto copy_range = [&](size_t from, size_t to) {
+        for (size_t i = from; i < to; ++i)
+            if (body_off[i + 1] > body_off[i])
+                memcpy(dst + body_off[i], body_src[i], body_off[i + 1] - body_off[i]);
+    };
+    if (nb >= par_min) {
+        const size_t n_chunks = std::min<size_t>(nb, (size_t)pool->size() * 4);
+        pool->parallel_for(n_chunks, [&](size_t ci, unsigned) { copy_range(nb * ci / n_chunks, nb * (ci + 1) / n_chunks); });
+    } else
+        copy_range(0, nb);
+    dist_body_n = body_off[nb];
 }
 
 // the record of a sample without contigs: nothing to register anywhere
@@ -152,7 +172,7 @@ void CAGCCompressor::Impl::make_empty_record()
 {
     bytes_t &r = dist_record;
     r.clear();
-    dist_record_body.clear();
+    dist_body_n = 0;
     r.insert(r.end(), {'A', 'G', 'C', 'R'});
     put32(r, 0);
     put32(r, 0);
@@ -187,6 +207,10 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
         return rr.p == rr.e; // empty sample: skipped on every rank
     const bool writer = dist_rank == dist_writer;
     size_t body_pos = 0; // (a record without deltas has no body: every kind-2 payload is checked against body_n below)
+    // the body came in through RecordBodyBuffer: the bookkeeping reads it where it is
+    std::unique_ptr<PinnedBytes> adopted;
+    if (body_recv && body == body_recv->data() && body_n <= body_recv->size())
+        adopted = std::move(body_recv);
     if (!add.empty()) { // adaptive mode: the owner's new splitters (agc_compressor.cpp:1191-1209)
         splitters.insert(splitters.end(), add.begin(), add.end());
         std::sort(splitters.begin(), splitters.end());
@@ -279,10 +303,10 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
                     break;
                 }
                 cd.enc_items.push_back(idx);
-                if (pn)
+                if (pn && !adopted)
                     enc.insert(enc.end(), body + body_pos, body + body_pos + pn);
-                enc_off.push_back(enc.size());
                 body_pos += pn;
+                enc_off.push_back(adopted ? body_pos : enc.size());
             }
             if (kind != 2)
                 rr.p += pn;
@@ -323,8 +347,11 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     t->ctgs = std::move(ctgs);
     t->placed = std::move(placed);
     t->enc = std::move(enc);
+    t->owner = this;
+    t->enc_recv = std::move(adopted);
+    const uint8_t *const enc_base = t->enc_recv ? t->enc_recv->data() : t->enc.data();
     for (size_t i = 0; i + 1 < enc_off.size(); ++i) {
-        cd.enc_ptr.push_back(t->enc.data() + enc_off[i]);
+        cd.enc_ptr.push_back(enc_base + enc_off[i]);
         cd.enc_len.push_back((uint32_t)(enc_off[i + 1] - enc_off[i]));
     }
     t->cd = std::move(cd);

@@ -700,6 +700,15 @@ struct CAGCCompressor::Impl {
         std::vector<Contig> ctgs;   // own copy (the caller's vector does not outlive its call)
         std::vector<Placed> placed; // apply_record: everything is the task's own
         bytes_t fetched, enc;
+        std::unique_ptr<PinnedBytes> enc_recv; // (the received body itself, when it came in through RecordBodyBuffer)
+        Impl *owner = nullptr;
+        ~BookTask()
+        {
+            if (enc_recv && owner) {
+                std::lock_guard<std::mutex> lk(owner->body_pool_mtx);
+                owner->body_pool.emplace_back(std::move(enc_recv));
+            }
+        }
     };
     std::thread book_thread;
     std::mutex book_mtx;
@@ -838,7 +847,14 @@ struct CAGCCompressor::Impl {
     }
     // multi-GPU single-archive mode: one registration at a time, committed on every rank from the owner's record
     uint32_t dist_rank = 0, dist_world = 1, dist_writer = 0;
-    bytes_t dist_record, dist_record_body; // head (every rank) and delta body (the writer only): compressor_dist.cpp
+    bytes_t dist_record;        // head of the commit record (every rank): compressor_dist.cpp
+    PinnedBytes dist_body_buf;  // its delta body (the writer only), dist_body_n bytes
+    size_t dist_body_n = 0;
+    // writer rank: receive buffers for the bodies of the other ranks' records (pinned; a queued bookkeeping task keeps its
+    // buffer until it is done, then the buffer comes back here)
+    std::mutex body_pool_mtx;
+    std::vector<std::unique_ptr<PinnedBytes>> body_pool;
+    std::unique_ptr<PinnedBytes> body_recv; // handed out by RecordBodyBuffer, adopted by the next apply_record
     void make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters);
     void make_empty_record();
     bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n);

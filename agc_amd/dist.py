@@ -19,6 +19,8 @@ sample; the body the deltas (~16 B per SNP): ~22 MB.  The archive is byte-identi
 
 Not covered in this mode: -c (concatenated) and append.
 """
+import time
+
 import numpy as np
 
 
@@ -38,6 +40,10 @@ class DistCompressor:
         self.next_sample = 0
         self.bytes_broadcast = 0  # record heads, to every rank
         self.bytes_p2p = 0        # record bodies (deltas), owner -> writer
+        # host seconds of this rank per stage: prepare (scan + classification + speculative encode of an own sample), commit (its
+        # order-dependent half), head (record sizes + head broadcast), body (delta body to the writer), apply (the other ranks'
+        # records applied here)
+        self.seconds = {"prepare": 0.0, "commit": 0.0, "head": 0.0, "body": 0.0, "apply": 0.0}
 
     def owner_of(self, i):
         return i % self.world
@@ -50,8 +56,10 @@ class DistCompressor:
         owner = self.owner_of(i)
         rec = body = None
         if self.rank == owner:
+            t0 = time.perf_counter()
             self.cmp.add_sample_dev(sample_name, contig_names, d_codes, ctg_off)
-            rec, body = self.cmp.last_record(), self.cmp.last_record_body()
+            self.seconds["commit"] += time.perf_counter() - t0
+            rec, body = self.cmp.last_record(copy=False), self.cmp.last_record_body(copy=False)
         self._publish(owner, rec, body)
         return owner
 
@@ -84,10 +92,12 @@ class DistCompressor:
     def _prepare(self, sample):
         """sample = (name, contig names, d_codes pointer | agc_amd.capi.Packed, ctg_off)"""
         name, names, data, off = sample
+        t0 = time.perf_counter()
         if isinstance(data, int) or data is None:
             self.cmp.prepare_sample_dev(name, names, data, off)
         else:
             self.cmp.prepare_sample_packed_dev(name, names, data, off)
+        self.seconds["prepare"] += time.perf_counter() - t0
 
     def close(self, zstd_raw=None, n_threads=8):
         """Close() with the entropy stage of the delta packs spread over all ranks: the writer hands the pending packs out
@@ -167,8 +177,9 @@ class DistCompressor:
 
     def _publish(self, owner, rec, body):
         """one sample's commit record: the head to every rank (broadcast), the delta body to the writer only (point to point);
-        ranks other than the owner apply it.  rec / body: the owner's (numpy uint8), None elsewhere."""
+        ranks other than the owner apply it.  rec / body: the owner's (numpy uint8 views into its compressor), None elsewhere."""
         torch, dist = self.torch, self.dist
+        t0 = time.perf_counter()
         n = torch.zeros(2, dtype=torch.int64, device=self.comm)
         if rec is not None:
             n[0], n[1] = rec.size, body.size
@@ -177,15 +188,22 @@ class DistCompressor:
         buf = torch.from_numpy(rec).to(self.comm) if rec is not None else torch.empty(size, dtype=torch.uint8, device=self.comm)
         dist.broadcast(buf, src=owner)
         self.bytes_broadcast += size
-        b_host = None
+        t1 = time.perf_counter()
+        b_view = None
         if bsize and owner != self.writer:
             if self.rank == owner:
                 dist.send(torch.from_numpy(body).to(self.comm), dst=self.writer)
             elif self.rank == self.writer:
-                bt = torch.empty(bsize, dtype=torch.uint8, device=self.comm)
-                dist.recv(bt, src=owner)
-                b_host = np.ascontiguousarray(bt.cpu().numpy())
+                # straight into the pinned buffer the bookkeeping will read (no staging copy on the host)
+                b_view = self.cmp.record_body_buffer(bsize)
+                if self.comm.type == "cpu":
+                    dist.recv(torch.from_numpy(b_view), src=owner)
+                else:
+                    bt = torch.empty(bsize, dtype=torch.uint8, device=self.comm)
+                    dist.recv(bt, src=owner)
+                    torch.from_numpy(b_view).copy_(bt)
             self.bytes_p2p += bsize
+        t2 = time.perf_counter()
         if self.rank != owner:
             # the head is parsed on the host; the new references are registered from the copy in this rank's HBM when there is one
             host = np.ascontiguousarray(buf.cpu().numpy())
@@ -193,11 +211,17 @@ class DistCompressor:
             if d_buf is not None:
                 torch.cuda.synchronize(self.hbm)
             self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None,
-                                  b_host.ctypes.data if b_host is not None else None, bsize if b_host is not None else 0)
+                                  b_view.ctypes.data if b_view is not None else None, bsize if b_view is not None else 0)
+        t3 = time.perf_counter()
+        self.seconds["head"] += t1 - t0
+        self.seconds["body"] += t2 - t1
+        self.seconds["apply"] += t3 - t2
 
     def _commit_and_publish(self, i):
+        t0 = time.perf_counter()
         self.cmp.commit_prepared()
-        self._publish(self.rank, self.cmp.last_record(), self.cmp.last_record_body())
+        self.seconds["commit"] += time.perf_counter() - t0
+        self._publish(self.rank, self.cmp.last_record(copy=False), self.cmp.last_record_body(copy=False))
         self.next_sample = i + 1
 
     def _receive(self, owner):

@@ -45,6 +45,7 @@ def bind(L):
     L.agc_cmp_last_record.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
     L.agc_cmp_apply_record.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64]
     L.agc_cmp_last_record_body.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+    L.agc_cmp_record_body_buffer.argtypes = [vp, C.c_uint64, C.POINTER(C.POINTER(C.c_uint8))]
     L.agc_cmp_prepare_sample_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_prepare_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_add_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
@@ -152,19 +153,34 @@ class Compressor:
         if not self.L.agc_cmp_commit_prepared(self.h):
             raise RuntimeError("CommitPrepared failed (see stderr)")
 
-    def last_record(self):
-        """the commit record of the sample just added (numpy uint8 view copied out of the compressor)"""
+    def last_record(self, copy=True):
+        """the commit record of the sample just added (numpy uint8; copy=False: a view into the compressor, valid until this
+        rank's next commit -- agc_amd.dist hands it straight to the collective)"""
         p = C.POINTER(C.c_uint8)()
         n = C.c_uint64()
         self.L.agc_cmp_last_record(self.h, C.byref(p), C.byref(n))
-        return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+        if not n.value:
+            return np.zeros(0, np.uint8)
+        a = np.ctypeslib.as_array(p, shape=(n.value,))
+        return a.copy() if copy else a
 
-    def last_record_body(self):
-        """the LZ deltas of the sample just added (the part of its commit record only the writer rank needs)"""
+    def last_record_body(self, copy=True):
+        """the LZ deltas of the sample just added (the part of its commit record only the writer rank needs; pinned host memory)"""
         p = C.POINTER(C.c_uint8)()
         n = C.c_uint64()
         self.L.agc_cmp_last_record_body(self.h, C.byref(p), C.byref(n))
-        return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+        if not n.value:
+            return np.zeros(0, np.uint8)
+        a = np.ctypeslib.as_array(p, shape=(n.value,))
+        return a.copy() if copy else a
+
+    def record_body_buffer(self, n):
+        """writer rank: pinned host buffer (numpy uint8 view, n bytes) to receive the next record's body into; apply_record takes
+        it over without a copy when it is given this buffer's address"""
+        p = C.POINTER(C.c_uint8)()
+        if not self.L.agc_cmp_record_body_buffer(self.h, n, C.byref(p)):
+            raise RuntimeError("RecordBodyBuffer failed")
+        return np.ctypeslib.as_array(p, shape=(n,))
 
     def apply_record(self, h_ptr, n, d_ptr=None, body_ptr=None, body_n=0):
         if not self.L.agc_cmp_apply_record(self.h, h_ptr, n, d_ptr, body_ptr, body_n):

@@ -71,6 +71,9 @@ int agc_cmp_last_record(void *h, const uint8_t **ptr, uint64_t *n);
  * the writer rank needs: body / body_n = NULL / 0 on the other ranks */
 int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record, const uint8_t *body, uint64_t body_n);
 int agc_cmp_last_record_body(void *h, const uint8_t **ptr, uint64_t *n);
+/* writer rank: a pinned host buffer of n bytes to receive the next record's body into; agc_cmp_apply_record takes it over (no
+ * copy) when its `body` argument is this pointer.  The bookkeeping that reads it runs beside the next sample's commit. */
+int agc_cmp_record_body_buffer(void *h, uint64_t n, uint8_t **ptr);
 
 /* version string of the libzstd in use (archives are byte-identical to the reference's only with the same libzstd) */
 const char *agc_cmp_zstd_version(void *h);
