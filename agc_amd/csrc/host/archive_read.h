@@ -94,7 +94,10 @@ struct Archive {
             if (fd < 0)
                 return false;
             struct stat st;
-            if (map && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            // (a mapped file must not be truncated or rewritten in place while it is open -- the pages would fault; append reads its
+            // input whole for that reason, and AGC_AMD_NO_MMAP=1 makes every reader do so)
+            static const bool no_mmap = getenv("AGC_AMD_NO_MMAP") != nullptr;
+            if (map && !no_mmap && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
                 void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
                 if (m != MAP_FAILED) {
                     p = (const uint8_t *)m;

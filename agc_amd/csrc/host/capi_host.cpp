@@ -111,6 +111,8 @@ int agc_cmp_set_next_sample_packed_dev(void *h, const void *packed, const uint64
     return ((CAGCCompressor *)h)->SetNextSamplePackedDevice(packed, ctg_off, n_ctg) ? 1 : 0;
 }
 int agc_cmp_commit_prepared(void *h) { return ((CAGCCompressor *)h)->CommitPrepared() ? 1 : 0; }
+int agc_cmp_commit_prepared_head(void *h) { return ((CAGCCompressor *)h)->CommitPreparedHead() ? 1 : 0; }
+int agc_cmp_commit_prepared_finish(void *h) { return ((CAGCCompressor *)h)->CommitPreparedFinish() ? 1 : 0; }
 
 int agc_cmp_close_collect_packs(void *h, const uint8_t **src, const uint64_t **off, uint32_t *n)
 {

@@ -618,7 +618,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
                                          const uint64_t *ctg_off)
 {
     Impl &I = *p;
-    if (!I.created || I.concatenated || I.prepared)
+    if (!I.created || I.concatenated || I.prepared || I.committing)
         return false;
     I.prepared_ctgs.clear();
     for (size_t c = 0; c < contig_names.size(); ++c) {
@@ -640,10 +640,14 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
 }
 
 // the order-dependent half: collection registration, revalidation against what changed since PrepareSampleDevice, commit
-bool CAGCCompressor::CommitPrepared()
+bool CAGCCompressor::CommitPrepared() { return CommitPreparedHead() && CommitPreparedFinish(); }
+
+// ... in two steps.  After the first one the sample is registered (group ids, keys, terminators) and, in the multi-GPU mode, the
+// HEAD of its commit record is ready (LastRecord): the other ranks can apply it and go on while this rank finishes.
+bool CAGCCompressor::CommitPreparedHead()
 {
     Impl &I = *p;
-    if (!I.prepared)
+    if (!I.prepared || I.committing)
         return false;
     std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
     I.dist_record.clear();
@@ -675,8 +679,23 @@ bool CAGCCompressor::CommitPrepared()
         if (!I.revalidate(*b))
             return false;
     }
-    uint32_t n_done = 0;
-    return I.batch_commit(*b, n_done);
+    // (a prepared sample is a window of one registration: one commit run, batch_commit's loop body in two halves)
+    b->s_from = 0;
+    ++I.st.commit_runs;
+    if (!I.stage_register(*b) || !I.stage_store_head(*b))
+        return false;
+    I.committing = std::move(b);
+    return true;
+}
+
+// the rest: the new references' index on this GPU, the deltas the speculative encode did not cover, the record's body, bookkeeping
+bool CAGCCompressor::CommitPreparedFinish()
+{
+    Impl &I = *p;
+    if (!I.committing)
+        return I.created; // (a sample without contigs: nothing was left to do)
+    std::unique_ptr<Impl::BatchState> b = std::move(I.committing);
+    return I.stage_store_finish(*b);
 }
 
 bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std::string>> &files, uint32_t no_threads)

@@ -97,6 +97,10 @@ public:
     bool PrepareSampleDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const uint8_t *d_codes,
                              const uint64_t *ctg_off);
     bool CommitPrepared();
+    // CommitPrepared in two steps (multi-GPU mode): after the first, LastRecord (the head) is ready and every other rank can go
+    // on; the second indexes the new references on this GPU, encodes what is left and builds LastRecordBody.
+    bool CommitPreparedHead();
+    bool CommitPreparedFinish();
     // the same for a sample resident in HBM in the 2-bit layout (include/agc_hip.h: agc_hip_packed; contig c = symbols
     // [ctg_off[c], ctg_off[c+1]) of the packed buffer): the splitter scan reads the packed words, the LZ kernels a byte staging
     // copy expanded inside the call

@@ -1565,25 +1565,28 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
 }
 
 // store_segments, first half: new references into HBM, LZ-encode of everything else, then the bookkeeping stage
-bool CAGCCompressor::Impl::stage_store(BatchState &b)
+bool CAGCCompressor::Impl::stage_store(BatchState &b) { return stage_store_head(b) && stage_store_finish(b); }
+
+// store_segments (agc_compressor.cpp:974-1050), first half: everything the OTHER ranks of a multi-GPU job need to go on -- which
+// item becomes a reference, the key -> group and terminator updates, the symbols of the new references and raw items -- and, in
+// that mode, the head of the commit record.  Nothing here waits for an LZ encode.
+bool CAGCCompressor::Impl::stage_store_head(BatchState &b)
 {
-    const std::vector<Contig> &ctgs = *b.ctgs;
     const uint8_t *d_base = b.d_base;
-    const uint32_t n_ctg = b.n_ctg;
     double &t0 = b.t0, &dev0 = b.dev0;
     auto LAP = [&](const char *what) { lap(b, what); };
-    (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
+    (void)t0; (void)dev0;
     std::vector<Placed> &placed = placed_buf;
-    const uint32_t commit_upto = b.commit_upto;
     std::vector<SampleLists> &per_sample = b.per_sample;
-    std::vector<uint64_t> &new_splitters_added = b.new_splitters_added;
     LAP("per_sample");
-    // ---- store_segments (agc_compressor.cpp:974-1050) ----
     // (a) what each item needs: new groups' first item becomes the reference (segment.cpp:39-48), raw
     // groups keep the symbols, everything else is LZ-encoded -- decided per group across the committed samples
-    std::vector<uint32_t> new_ref_items; // placed indices, one per new group with items
-    std::vector<uint32_t> raw_items;
-    std::vector<uint32_t> enc_items;
+    std::vector<uint32_t> &new_ref_items = b.sto.new_ref_items; // placed indices, one per new group with items
+    std::vector<uint32_t> &raw_items = b.sto.raw_items;
+    std::vector<uint32_t> &enc_items = b.sto.enc_items;
+    new_ref_items.clear();
+    raw_items.clear();
+    enc_items.clear();
     {
         std::vector<uint8_t> will_exist(groups.size(), 0);
         for (uint32_t sidx = 0; sidx < per_sample.size(); ++sidx)
@@ -1620,29 +1623,27 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
             b.changed.push_back(placed[idx].pk.second);
         }
     }
-    // GPU: register the new references (index build) and pull back what the host must pack
+    LAP("note_new_groups");
+    // GPU: what the host must pack of the new references and raw items, and the repetitiveness probe of the references
     std::vector<uint32_t> lag_cnt, lag_cur;
-    std::vector<uint8_t> repetitive;
+    std::vector<uint8_t> &repetitive = b.sto.repetitive;
+    repetitive.clear();
     bytes_t &fetched = fetch_buf;
-    std::vector<uint64_t> fetched_off;
+    std::vector<uint64_t> &fetched_off = b.sto.fetched_off;
+    fetched_off.clear();
     {
         const size_t nr = new_ref_items.size();
         if (nr) {
-            std::vector<uint32_t> gid(nr), len(nr);
+            std::vector<uint32_t> len(nr);
             std::vector<uint64_t> off(nr);
             std::vector<uint8_t> rc(nr);
             for (size_t i = 0; i < nr; ++i) {
                 const Placed &pl = placed[new_ref_items[i]];
-                gid[i] = (uint32_t)pl.gid;
                 off[i] = pl.off;
                 len[i] = pl.len;
                 rc[i] = pl.rc;
                 st.ref_bytes += pl.len;
             }
-            LAP("note_new_groups");
-            if (!hip_ok(DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml)), "ref_register_batch"))
-                return false;
-            LAP("ref_register");
             lag_cnt.resize(nr * 28);
             lag_cur.resize(nr * 28);
             if (!hip_ok(DEVT(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data())), "ref_lag_counts"))
@@ -1687,6 +1688,42 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
         }
     }
     LAP("fetch_slices");
+    if (dist_world > 1) {
+        make_record_head(b);
+        LAP("record head");
+    }
+    return true;
+}
+
+// second half: the new references' index on this GPU, the deltas, the bookkeeping (and the body of the commit record)
+bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
+{
+    const uint8_t *d_base = b.d_base;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    auto LAP = [&](const char *what) { lap(b, what); };
+    std::vector<Placed> &placed = placed_buf;
+    const uint32_t commit_upto = b.commit_upto;
+    std::vector<SampleLists> &per_sample = b.per_sample;
+    std::vector<uint32_t> &new_ref_items = b.sto.new_ref_items, &raw_items = b.sto.raw_items, &enc_items = b.sto.enc_items;
+    bytes_t &fetched = fetch_buf;
+    {
+        const size_t nr = new_ref_items.size();
+        if (nr) { // register the new references (index build)
+            std::vector<uint32_t> gid(nr), len(nr);
+            std::vector<uint64_t> off(nr);
+            std::vector<uint8_t> rc(nr);
+            for (size_t i = 0; i < nr; ++i) {
+                const Placed &pl = placed[new_ref_items[i]];
+                gid[i] = (uint32_t)pl.gid;
+                off[i] = pl.off;
+                len[i] = pl.len;
+                rc[i] = pl.rc;
+            }
+            if (!hip_ok(DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml)), "ref_register_batch"))
+                return false;
+            LAP("ref_register");
+        }
+    }
     stage_end(st.t_register, st.h_register, t0, dev0);
     t0 = now();
     // LZ deltas (segment.cpp:50-58): items whose group already had its reference when the window was classified were encoded
@@ -1760,13 +1797,14 @@ bool CAGCCompressor::Impl::stage_store(BatchState &b)
     cdta.new_ref_items = std::move(new_ref_items);
     cdta.raw_items = std::move(raw_items);
     cdta.enc_items = std::move(enc_items);
-    cdta.repetitive = std::move(repetitive);
+    cdta.repetitive = std::move(b.sto.repetitive);
     cdta.fetched = &fetched;
-    cdta.fetched_off = std::move(fetched_off);
+    cdta.fetched_off = std::move(b.sto.fetched_off);
     cdta.enc_ptr = std::move(enc_ptr);
     cdta.enc_len = std::move(enc_len);
     if (dist_world > 1) {
-        make_record(cdta, new_splitters_added);
+        make_record_body(cdta);
+        LAP("record body");
         if (dist_rank != dist_writer)
             return true; // the writer rank does the bookkeeping from the record
     }

@@ -14,10 +14,11 @@ namespace agc {
 // order, so the archive equals the single-GPU one byte for byte.
 // Record layout (little endian): HEAD = "AGCR" | n_ctg | n_lists | n_new_splitters | first_new_gid | n_new_groups |
 //   contigs: sample\0 name\0 ... | splitters u64... | lists: gid, n_items, items: ctg, part_no, len, rc, kind,
-//   [pk1, pk2, repetitive for kind 0], payload_len, [payload for kinds 0 (new reference) and 1 (raw)]
-// BODY = the payloads of the kind-2 items (LZ deltas) back to back, in item order.  Every rank needs the head (ids, keys, the
+//   [pk1, pk2, repetitive for kind 0], [payload_len, payload for kinds 0 (new reference) and 1 (raw)]
+// BODY = for every kind-2 item (LZ delta), in item order: payload_len, payload.  Every rank needs the head (ids, keys, the
 // new references: ~3 MB per human-size sample); only the WRITER needs the body (~22 MB): agc_amd/dist.py broadcasts the one and
-// sends the other point to point.
+// sends the other point to point.  The head is complete before any delta is encoded (CommitPreparedHead): the other ranks
+// go on while the owner indexes its new references, encodes what is left and builds the body (CommitPreparedFinish).
 // ---------------------------------------------------------------------------
 namespace {
 void put32(bytes_t &d, uint32_t x)
@@ -69,22 +70,24 @@ struct RecReader {
 };
 } // namespace
 
-void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters)
+// The head: built in the first half of store_segments (stage_store_head) -- before the new references are indexed on this GPU and
+// before any leftover delta is encoded -- so that the other ranks can go on as early as possible.
+void CAGCCompressor::Impl::make_record_head(BatchState &b)
 {
-    const std::vector<Contig> &ctgs = *cd.ctgs;
-    const std::vector<Placed> &placed = *cd.placed;
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const std::vector<Placed> &placed = placed_buf;
+    const BatchState::Store &sto = b.sto;
     bytes_t &r = dist_record;
     r.clear();
     dist_body_n = 0;
-    std::vector<const uint8_t *> body_src; // kind-2 payloads in item order: gathered below by the worker pool
-    std::vector<uint64_t> body_off{0};
+    dist_body_items.clear();
     r.insert(r.end(), {'A', 'G', 'C', 'R'});
     put32(r, (uint32_t)ctgs.size());
-    const SampleLists &sl = cd.per_sample.at(0); // one registration per record
+    const SampleLists &sl = b.per_sample.at(0); // one registration per record
     put32(r, (uint32_t)sl.n_lists());
-    put32(r, (uint32_t)new_splitters.size());
+    put32(r, (uint32_t)b.new_splitters_added.size());
     uint32_t first_new = ~0u, n_new = 0;
-    for (uint32_t idx : cd.new_ref_items) {
+    for (uint32_t idx : sto.new_ref_items) {
         first_new = std::min(first_new, (uint32_t)placed[idx].gid);
         ++n_new;
     }
@@ -96,20 +99,19 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
         r.insert(r.end(), c.name.begin(), c.name.end());
         r.push_back(0);
     }
-    for (uint64_t x : new_splitters)
+    for (uint64_t x : b.new_splitters_added)
         put64(r, x);
-    std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size()), pos_enc(placed.size());
-    for (uint32_t i = 0; i < cd.new_ref_items.size(); ++i)
-        pos_newref[cd.new_ref_items[i]] = i;
-    for (uint32_t i = 0; i < cd.raw_items.size(); ++i)
-        pos_raw[cd.raw_items[i]] = i;
-    for (uint32_t i = 0; i < cd.enc_items.size(); ++i)
-        pos_enc[cd.enc_items[i]] = i;
+    std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size());
+    for (uint32_t i = 0; i < sto.new_ref_items.size(); ++i)
+        pos_newref[sto.new_ref_items[i]] = i;
+    for (uint32_t i = 0; i < sto.raw_items.size(); ++i)
+        pos_raw[sto.raw_items[i]] = i;
     std::vector<uint8_t> kind(placed.size(), 2);
-    for (uint32_t idx : cd.new_ref_items)
+    for (uint32_t idx : sto.new_ref_items)
         kind[idx] = 0;
-    for (uint32_t idx : cd.raw_items)
+    for (uint32_t idx : sto.raw_items)
         kind[idx] = 1;
+    const bytes_t &fetched = fetch_buf;
     for (size_t li = 0; li < sl.n_lists(); ++li) {
         put32(r, sl.gids[li]);
         put32(r, sl.begin[li + 1] - sl.begin[li]);
@@ -121,43 +123,52 @@ void CAGCCompressor::Impl::make_record(const CommitData &cd, const std::vector<u
             put32(r, pl.len);
             r.push_back((uint8_t)pl.rc);
             r.push_back(kind[idx]);
-            const uint8_t *b;
-            size_t n;
+            if (kind[idx] == 2) {
+                dist_body_items.push_back(idx); // (its length and bytes travel in the body)
+                continue;
+            }
+            uint32_t fi;
             if (kind[idx] == 0) {
                 put64(r, pl.pk.first);
                 put64(r, pl.pk.second);
-                const uint32_t fi = pos_newref[idx];
-                r.push_back(cd.repetitive[fi]);
-                b = cd.fetched->data() + cd.fetched_off[fi];
-                n = cd.fetched_off[fi + 1] - cd.fetched_off[fi];
-            } else if (kind[idx] == 1) {
-                const uint32_t fi = (uint32_t)cd.new_ref_items.size() + pos_raw[idx];
-                b = cd.fetched->data() + cd.fetched_off[fi];
-                n = cd.fetched_off[fi + 1] - cd.fetched_off[fi];
-            } else {
-                const uint32_t ei = pos_enc[idx];
-                b = cd.enc_ptr[ei];
-                n = cd.enc_len[ei];
-            }
-            put32(r, (uint32_t)n);
-            if (kind[idx] == 2) {
-                body_src.push_back(b);
-                body_off.push_back(body_off.back() + n);
+                fi = pos_newref[idx];
+                r.push_back(sto.repetitive[fi]);
             } else
-                r.insert(r.end(), b, b + n);
+                fi = (uint32_t)sto.new_ref_items.size() + pos_raw[idx];
+            const uint8_t *p = fetched.data() + sto.fetched_off[fi];
+            const size_t n = sto.fetched_off[fi + 1] - sto.fetched_off[fi];
+            put32(r, (uint32_t)n);
+            r.insert(r.end(), p, p + n);
         }
     }
-    // the body: ~22 MB per human-size sample, into pinned memory (its next stop is the writer's GPU or socket)
-    const size_t nb = body_src.size();
+}
+
+// The body: every delta item of the head, in the same order: u32 length + bytes.  ~22 MB per human-size sample, gathered by the
+// worker pool into pinned memory (its next stop is the writer's GPU or socket).
+void CAGCCompressor::Impl::make_record_body(const CommitData &cd)
+{
+    const std::vector<Placed> &placed = *cd.placed;
+    std::vector<uint32_t> pos_enc(placed.size());
+    for (uint32_t i = 0; i < cd.enc_items.size(); ++i)
+        pos_enc[cd.enc_items[i]] = i;
+    const size_t nb = dist_body_items.size();
+    std::vector<uint64_t> body_off(nb + 1, 0);
+    for (size_t i = 0; i < nb; ++i)
+        body_off[i + 1] = body_off[i] + 4 + cd.enc_len[pos_enc[dist_body_items[i]]];
+    dist_body_n = 0;
     if (!dist_body_buf.resize(body_off[nb] + body_off[nb] / 8 + 64, false)) {
         err("out of memory (commit record)");
         return;
     }
     uint8_t *const dst = dist_body_buf.data();
     auto copy_range = [&](size_t from, size_t to) {
-        for (size_t i = from; i < to; ++i)
-            if (body_off[i + 1] > body_off[i])
-                memcpy(dst + body_off[i], body_src[i], body_off[i + 1] - body_off[i]);
+        for (size_t i = from; i < to; ++i) {
+            const uint32_t ei = pos_enc[dist_body_items[i]], n = cd.enc_len[ei];
+            uint8_t *d = dst + body_off[i];
+            d[0] = (uint8_t)n, d[1] = (uint8_t)(n >> 8), d[2] = (uint8_t)(n >> 16), d[3] = (uint8_t)(n >> 24);
+            if (n)
+                memcpy(d + 4, cd.enc_ptr[ei], n);
+        }
     };
     if (nb >= par_min) {
         const size_t n_chunks = std::min<size_t>(nb, (size_t)pool->size() * 4);
@@ -249,7 +260,8 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     cd.per_sample.resize(1);
     SampleLists &sl = cd.per_sample[0];
     bytes_t refs_raw, raws, enc;
-    std::vector<uint64_t> ref_off{0}, raw_off{0}, enc_off{0};
+    std::vector<uint64_t> ref_off{0}, raw_off{0}, enc_start;
+    std::vector<uint32_t> enc_len;
     std::vector<uint32_t> reg_gid, reg_len;
     std::vector<uint64_t> reg_off; // payload offsets inside the record (device copy)
     for (uint32_t li = 0; li < n_lists && rr.ok; ++li) {
@@ -271,8 +283,21 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
                 pl.pk.second = rr.u64();
                 rep = rr.u8();
             }
-            const uint32_t pn = rr.u32();
-            if ((kind != 2 && !rr.need(pn)) || pl.ctg >= n_ctg || gid >= groups.size()) {
+            uint32_t pn = 0;
+            if (kind != 2) {
+                pn = rr.u32();
+                if (!rr.need(pn))
+                    break;
+            } else if (writer) { // (length + bytes of a delta are in the body)
+                if (body_pos + 4 > body_n) {
+                    rr.ok = false;
+                    break;
+                }
+                const uint8_t *q = body + body_pos;
+                pn = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                body_pos += 4;
+            }
+            if (kind > 2 || pl.ctg >= n_ctg || gid >= groups.size()) {
                 rr.ok = false;
                 break;
             }
@@ -303,10 +328,11 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
                     break;
                 }
                 cd.enc_items.push_back(idx);
+                enc_start.push_back(adopted ? body_pos : enc.size());
+                enc_len.push_back(pn);
                 if (pn && !adopted)
                     enc.insert(enc.end(), body + body_pos, body + body_pos + pn);
                 body_pos += pn;
-                enc_off.push_back(adopted ? body_pos : enc.size());
             }
             if (kind != 2)
                 rr.p += pn;
@@ -350,10 +376,9 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     t->owner = this;
     t->enc_recv = std::move(adopted);
     const uint8_t *const enc_base = t->enc_recv ? t->enc_recv->data() : t->enc.data();
-    for (size_t i = 0; i + 1 < enc_off.size(); ++i) {
-        cd.enc_ptr.push_back(enc_base + enc_off[i]);
-        cd.enc_len.push_back((uint32_t)(enc_off[i + 1] - enc_off[i]));
-    }
+    for (size_t i = 0; i < enc_start.size(); ++i)
+        cd.enc_ptr.push_back(enc_base + enc_start[i]);
+    cd.enc_len = std::move(enc_len);
     t->cd = std::move(cd);
     t->cd.ctgs = &t->ctgs;
     t->cd.placed = &t->placed;

@@ -795,12 +795,19 @@ struct CAGCCompressor::Impl {
         uint32_t commit_upto = 0;                  // registrations of the window that are committed now
         std::vector<uint32_t> order;               // committed items in registration order
         std::vector<SampleLists> per_sample;
+        struct Store {                             // stage_store's working set between its two halves
+            std::vector<uint32_t> new_ref_items, raw_items, enc_items; // placed indices
+            std::vector<uint8_t> repetitive;
+            std::vector<uint64_t> fetched_off;
+        } sto;
     };
     bool stage_scan(BatchState &b);
     bool stage_classify(BatchState &b);
     bool stage_place(BatchState &b);
     bool stage_register(BatchState &b);
     bool stage_store(BatchState &b);
+    bool stage_store_head(BatchState &b);
+    bool stage_store_finish(BatchState &b);
     bool spec_encode(BatchState &b);
     bool overlap_encode_begin(BatchState &b);
     bool overlap_encode_end(BatchState &b);
@@ -814,6 +821,7 @@ struct CAGCCompressor::Impl {
     // a sample classified ahead of its turn (multi-GPU mode, PrepareSampleDevice): its working set, and the k-mers whose
     // terminator lists changed since (through other ranks' records)
     std::unique_ptr<BatchState> prepared;
+    std::unique_ptr<BatchState> committing; // between CommitPreparedHead and CommitPreparedFinish
     std::vector<Contig> prepared_ctgs;
     std::vector<uint64_t> changed_log;
     // the next sample, announced by SetNextSamplePackedDevice (pf_next) / already queued on the device (pf_live: its staging copy)
@@ -855,7 +863,9 @@ struct CAGCCompressor::Impl {
     std::mutex body_pool_mtx;
     std::vector<std::unique_ptr<PinnedBytes>> body_pool;
     std::unique_ptr<PinnedBytes> body_recv; // handed out by RecordBodyBuffer, adopted by the next apply_record
-    void make_record(const CommitData &cd, const std::vector<uint64_t> &new_splitters);
+    std::vector<uint32_t> dist_body_items; // the record's delta items (placed indices) in list order: head and body agree on it
+    void make_record_head(BatchState &b);
+    void make_record_body(const CommitData &cd);
     void make_empty_record();
     bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n);
     void note_new_group(const pk_t &pk, uint32_t gid);

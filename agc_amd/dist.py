@@ -6,8 +6,10 @@ splitters, the (k1,k2) -> group map, terminator lists and all group references i
 classify and LZ-encode any sample.  What orders the job is the reference's registration contract (group ids are minted
 first-come in sample order, agc_compressor.cpp:954-1050): samples are therefore COMMITTED in order.  Per sample:
 
-    owner:   add_sample_dev()            scan + classification + LZ-encode on its GPU, commit record built
-    all:     broadcast(record head)      one collective per sample: lengths, then the bytes (uint8 tensor on the backend's device)
+    owner:   prepare + commit (head)     scan + classification + speculative LZ-encode on its GPU ahead of its turn; at its turn
+                                         the order-dependent registration and the HEAD of the commit record
+    all:     broadcast(record head)      one collective per sample: length, then the bytes (uint8 tensor on the backend's device)
+    owner:   commit (finish)             new references indexed on its GPU, leftover deltas, the record's BODY -- after the head is out
     owner -> writer: send(record body)   the LZ deltas, point to point: only the writer needs them
     others:  apply_record(head)          same group ids / map / terminator updates; the newly minted reference segments inside the
                                          head are registered in this rank's HBM straight from the broadcast buffer
@@ -41,9 +43,9 @@ class DistCompressor:
         self.bytes_broadcast = 0  # record heads, to every rank
         self.bytes_p2p = 0        # record bodies (deltas), owner -> writer
         # host seconds of this rank per stage: prepare (scan + classification + speculative encode of an own sample), commit (its
-        # order-dependent half), head (record sizes + head broadcast), body (delta body to the writer), apply (the other ranks'
-        # records applied here)
-        self.seconds = {"prepare": 0.0, "commit": 0.0, "head": 0.0, "body": 0.0, "apply": 0.0}
+        # order-dependent half up to the record's head), head (head size + head broadcast), finish (the owner's rest: new references
+        # indexed, leftover deltas, the body), body (finish + delta body to the writer), apply (the other ranks' records applied here)
+        self.seconds = {"prepare": 0.0, "commit": 0.0, "head": 0.0, "finish": 0.0, "body": 0.0, "apply": 0.0}
 
     def owner_of(self, i):
         return i % self.world
@@ -177,23 +179,36 @@ class DistCompressor:
 
     def _publish(self, owner, rec, body):
         """one sample's commit record: the head to every rank (broadcast), the delta body to the writer only (point to point);
-        ranks other than the owner apply it.  rec / body: the owner's (numpy uint8 views into its compressor), None elsewhere."""
+        ranks other than the owner apply it.  rec: the owner's head (numpy uint8 view into its compressor), None elsewhere.
+        body: the owner's body, or a function that finishes the commit and returns it -- called AFTER the head is out, so the
+        other ranks go on while the owner indexes its new references, encodes what is left and builds the body."""
         torch, dist = self.torch, self.dist
         t0 = time.perf_counter()
-        n = torch.zeros(2, dtype=torch.int64, device=self.comm)
+        n = torch.zeros(1, dtype=torch.int64, device=self.comm)
         if rec is not None:
-            n[0], n[1] = rec.size, body.size
+            n[0] = rec.size
         dist.broadcast(n, src=owner)
-        size, bsize = int(n[0]), int(n[1])
+        size = int(n[0])
         buf = torch.from_numpy(rec).to(self.comm) if rec is not None else torch.empty(size, dtype=torch.uint8, device=self.comm)
         dist.broadcast(buf, src=owner)
         self.bytes_broadcast += size
         t1 = time.perf_counter()
-        b_view = None
-        if bsize and owner != self.writer:
-            if self.rank == owner:
-                dist.send(torch.from_numpy(body).to(self.comm), dst=self.writer)
-            elif self.rank == self.writer:
+        b_view, bsize = None, 0
+        if self.rank == owner:
+            if callable(body):
+                tf = time.perf_counter()
+                body = body()
+                self.seconds["finish"] += time.perf_counter() - tf
+            if owner != self.writer:
+                bsize = int(body.size)
+                dist.send(torch.tensor([bsize], dtype=torch.int64, device=self.comm), dst=self.writer)
+                if bsize:
+                    dist.send(torch.from_numpy(body).to(self.comm), dst=self.writer)
+        elif self.rank == self.writer:
+            nb = torch.zeros(1, dtype=torch.int64, device=self.comm)
+            dist.recv(nb, src=owner)
+            bsize = int(nb[0])
+            if bsize:
                 # straight into the pinned buffer the bookkeeping will read (no staging copy on the host)
                 b_view = self.cmp.record_body_buffer(bsize)
                 if self.comm.type == "cpu":
@@ -202,7 +217,7 @@ class DistCompressor:
                     bt = torch.empty(bsize, dtype=torch.uint8, device=self.comm)
                     dist.recv(bt, src=owner)
                     torch.from_numpy(b_view).copy_(bt)
-            self.bytes_p2p += bsize
+        self.bytes_p2p += bsize
         t2 = time.perf_counter()
         if self.rank != owner:
             # the head is parsed on the host; the new references are registered from the copy in this rank's HBM when there is one
@@ -219,10 +234,14 @@ class DistCompressor:
 
     def _commit_and_publish(self, i):
         t0 = time.perf_counter()
-        self.cmp.commit_prepared()
+        self.cmp.commit_prepared_head()
         self.seconds["commit"] += time.perf_counter() - t0
-        self._publish(self.rank, self.cmp.last_record(copy=False), self.cmp.last_record_body(copy=False))
+        self._publish(self.rank, self.cmp.last_record(copy=False), self._finish_commit)
         self.next_sample = i + 1
+
+    def _finish_commit(self):
+        self.cmp.commit_prepared_finish()
+        return self.cmp.last_record_body(copy=False)
 
     def _receive(self, owner):
         self._publish(owner, None, None)

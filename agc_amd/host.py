@@ -51,6 +51,8 @@ def bind(L):
     L.agc_cmp_add_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_set_next_sample_packed_dev.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32]
     L.agc_cmp_commit_prepared.argtypes = [vp]
+    L.agc_cmp_commit_prepared_head.argtypes = [vp]
+    L.agc_cmp_commit_prepared_finish.argtypes = [vp]
     L.agc_cmp_append.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32]
     return L
 
@@ -152,6 +154,16 @@ class Compressor:
     def commit_prepared(self):
         if not self.L.agc_cmp_commit_prepared(self.h):
             raise RuntimeError("CommitPrepared failed (see stderr)")
+
+    def commit_prepared_head(self):
+        """first step of commit_prepared(): the sample is registered and last_record() (the head of its commit record) is ready"""
+        if not self.L.agc_cmp_commit_prepared_head(self.h):
+            raise RuntimeError("CommitPreparedHead failed (see stderr)")
+
+    def commit_prepared_finish(self):
+        """second step: new references indexed on this GPU, remaining deltas encoded, last_record_body() built, bookkeeping"""
+        if not self.L.agc_cmp_commit_prepared_finish(self.h):
+            raise RuntimeError("CommitPreparedFinish failed (see stderr)")
 
     def last_record(self, copy=True):
         """the commit record of the sample just added (numpy uint8; copy=False: a view into the compressor, valid until this

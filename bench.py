@@ -396,10 +396,12 @@ def main():
     st0 = cmp_.stats()
     cmp_.hip_timing(True)  # HIP events on the library's stream around every kernel of the timed region
     barrier()
+    sec0 = dict(dc.seconds) if dc is not None else None
     t0 = time.perf_counter()
     for s in range(args.warmup, n_steps):
         add_step(s, "s")
     t_steps = time.perf_counter() - t0
+    sec1 = dict(dc.seconds) if dc is not None else None
     # Close(): zstd of every pending delta pack + metadata + footer -- the deferred part of the steps' work
     if single:
         dc.close(n_threads=threads)  # packs handed out to every rank's GPU, frames gathered by the writer
@@ -504,6 +506,10 @@ def main():
                                 "overlap": round(1.0 - stats["t_zstd_wait"] / stats["t_zstd"], 3) if stats["t_zstd"] > 0 else None,
                                 "mb_s_per_host_thread": round((stats["zstd_in"] - stats["zstd_dev_in"]) / 1e6 / max(stats["t_zstd_host"], 1e-9) / threads, 2)},
                        "host_stage_seconds_rank0": {k_: round(stats[k_], 4) for k_ in stats if k_.startswith("t_")},
+                       # ONE archive from N ranks: rank 0's host milliseconds per sample of the timed steps -- prepare / commit of its
+                       # own samples (prepare runs beside the other ranks'), head / body / apply of every sample's record (serial)
+                       "single_archive_ms_per_sample_rank0": ({k_: round((sec1[k_] - sec0[k_]) * 1e3 / max(args.steps * (1 if k_ in ("prepare", "commit", "finish") else world), 1), 3)
+                                                               for k_ in sec1} if sec1 is not None else None),
                        "parallelism": (f"samples round-robin over {world} GPUs into ONE archive: ordered commit, one RCCL broadcast of the commit "
                                        f"record's head (ids, keys, new reference segments) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each, "
                                        f"its delta body point to point to the writer ({dc.bytes_p2p / max(dc.next_sample, 1) / 1e6:.1f} MB per sample on average); "

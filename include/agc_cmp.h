@@ -39,6 +39,11 @@ int agc_cmp_add_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, con
 int agc_cmp_prepare_sample_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const uint8_t *d_codes,
                                const uint64_t *ctg_off);
 int agc_cmp_commit_prepared(void *h);
+/* ... in two steps (multi-GPU mode): after _head the sample is registered and agc_cmp_last_record (the record's head) is ready --
+ * the other ranks can apply it and go on --; _finish indexes the new references on this GPU, encodes what the speculative encode
+ * did not cover, and builds agc_cmp_last_record_body */
+int agc_cmp_commit_prepared_head(void *h);
+int agc_cmp_commit_prepared_finish(void *h);
 /* the same for a sample resident in HBM in the 2-bit layout (packed: const agc_hip_packed *, include/agc_hip.h; contig c =
  * symbols [ctg_off[c], ctg_off[c+1]) of the packed buffer) */
 int agc_cmp_add_sample_packed_dev(void *h, const char *sample_name, uint32_t n_ctg, const char **contig_names, const void *packed,
