@@ -138,7 +138,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
     I.zpool.reset(new ThreadPool(nt, 10));
-    I.bpool.reset(new ThreadPool(std::max(1u, std::min(4u, nt / 2))));
+    I.bpool.reset(new ThreadPool(std::max(1u, std::min(8u, nt / 2))));
     if (const char *e = getenv("AGC_AMD_ASYNC_BOOK"))
         I.async_book = atoi(e) != 0;
     for (unsigned i = 0; i < nt; ++i)
@@ -316,7 +316,7 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
     I.zpool.reset(new ThreadPool(nt, 10));
-    I.bpool.reset(new ThreadPool(std::max(1u, std::min(4u, nt / 2))));
+    I.bpool.reset(new ThreadPool(std::max(1u, std::min(8u, nt / 2))));
     if (const char *e = getenv("AGC_AMD_ASYNC_BOOK"))
         I.async_book = atoi(e) != 0;
     for (unsigned i = 0; i < nt; ++i)

@@ -8,10 +8,11 @@ namespace agc {
 
 // ---------------------------------------------------------------------------
 // store_in_archive(pack), segment.h:258-280: sequences + 0xFF separators -> zstd 17
-void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off)
+void CAGCCompressor::Impl::make_pack_job(std::vector<ZJob> &jobs, uint32_t gid, bytes_t &data, std::vector<uint32_t> &off)
 {
+    Group &g = groups[gid];
     ZJob j;
-    j.gid = (uint32_t)(&g - groups.data());
+    j.gid = gid;
     if (g.stream_delta < 0 && !defer_stream_reg) // segment.h:262-266
         g.stream_delta = ar.register_stream(ss_delta_name(j.gid));
     j.stream_id = g.stream_delta; // (< 0: registered by the caller, in list order)
@@ -1498,8 +1499,6 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
                 placed[idx].gid = (int32_t)it->second;
             }
         const uint32_t no_new = gid - no_segments;
-        if (no_new && !book_wait()) // (`groups` grows: no queued bookkeeping -- records applied since the prepare -- may hold a reference into it)
-            return false;
         for (uint32_t i = 0; i < no_new; ++i) {
             groups.emplace_back();
             Group &g = groups.back();
@@ -1889,7 +1888,7 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                     uint32_t igid;
                     if (gid < NO_RAW_GROUPS) {
                         if (g.raw_off.size() == pack_cardinality)
-                            make_pack_job(jobs, g, g.raw_data, g.raw_off);
+                            make_pack_job(jobs, gid, g.raw_data, g.raw_off);
                         const uint32_t fi = (uint32_t)new_ref_items.size() + pos_raw[idx];
                         ++g.no_seqs;
                         Group::push(g.raw_data, g.raw_off, fetched.data() + fetched_off[fi], fetched_off[fi + 1] - fetched_off[fi]);
@@ -1906,7 +1905,7 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                         igid = 0;
                     } else {
                         if (g.lzp_off.size() == pack_cardinality)
-                            make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
+                            make_pack_job(jobs, gid, g.lzp_data, g.lzp_off);
                         const uint32_t ei = pos_enc[idx];
                         const uint8_t *dp = cdta.enc_ptr[ei];
                         const size_t dn = cdta.enc_len[ei];
@@ -2077,9 +2076,9 @@ void CAGCCompressor::Impl::build_close_jobs(std::vector<ZJob> &jobs)
     for (uint32_t gid = 0; gid < groups.size(); ++gid) {
         Group &g = groups[gid];
         if (!g.lzp_off.empty())
-            make_pack_job(jobs, g, g.lzp_data, g.lzp_off);
+            make_pack_job(jobs, gid, g.lzp_data, g.lzp_off);
         if (!g.raw_off.empty())
-            make_pack_job(jobs, g, g.raw_data, g.raw_off);
+            make_pack_job(jobs, gid, g.raw_data, g.raw_off);
         if (g.packed && g.pk_delta) { // store_compressed_delta_in_archive, segment.h:283-292
             if (g.stream_delta < 0)
                 g.stream_delta = ar.register_stream(ss_delta_name(gid));

@@ -239,8 +239,6 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
             }
     }
     if (n_new) {
-        if (!book_wait()) // (`groups` grows: no queued bookkeeping may hold a reference into it)
-            return false;
         if (first_new != no_segments) {
             err("commit record out of order: new groups start at " + std::to_string(first_new) + ", expected " + std::to_string(no_segments));
             return false;

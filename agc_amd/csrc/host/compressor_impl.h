@@ -213,6 +213,39 @@ struct SampleLists { // one registration: the items of every group it touches (C
 
 // what store_segments' bookkeeping needs about the committed registrations (filled by process_batch on the rank that
 // classified them, or rebuilt from a commit record on the other ranks of a multi-GPU job)
+// Grow-only array whose elements never move: chunks of 4096 behind a fixed directory.  One thread appends (the one that mints
+// groups); another may use elements that existed when it was handed its work (the bookkeeping thread) -- no reference it holds
+// is ever invalidated, and reading element i never touches memory an append writes.
+template <class T> class StableVec {
+    static constexpr size_t CH_BITS = 12, CH = (size_t)1 << CH_BITS, N_DIR = (size_t)1 << 15; // 134 M elements
+    std::unique_ptr<std::unique_ptr<T[]>[]> dir{new std::unique_ptr<T[]>[N_DIR]};
+    size_t n = 0;
+
+public:
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return dir[i >> CH_BITS][i & (CH - 1)]; }
+    const T &operator[](size_t i) const { return dir[i >> CH_BITS][i & (CH - 1)]; }
+    T &back() { return (*this)[n - 1]; }
+    T &emplace_back()
+    {
+        if ((n & (CH - 1)) == 0 && !dir[n >> CH_BITS])
+            dir[n >> CH_BITS].reset(new T[CH]);
+        (*this)[n] = T();
+        return (*this)[n++];
+    }
+    void resize(size_t m) // (grows only)
+    {
+        while (n < m)
+            emplace_back();
+    }
+    void clear()
+    {
+        for (size_t c = 0; c < N_DIR && dir[c]; ++c)
+            dir[c].reset();
+        n = 0;
+    }
+};
+
 struct CommitData {
     const std::vector<Contig> *ctgs = nullptr;
     const std::vector<Placed> *placed = nullptr;
@@ -689,8 +722,8 @@ struct CAGCCompressor::Impl {
     // records, the parts' places in the archive) reads nothing the classification of the next sample needs and writes nothing
     // it reads: it runs on one background thread, in registration order, beside the next sample's scan and classification (and,
     // on the writer rank of the multi-GPU mode, beside the next owner's commit).  What orders the two threads:
-    //   * book_wait() before the main thread reuses the buffers a queued task points into (stage_place), grows `groups`
-    //     (stage_register, apply_record) or reads what the stage produces (Close, the sync path);
+    //   * book_wait() before the main thread reuses the buffers a queued task points into (stage_place) or reads what the stage
+    //     produces (Close, the sync path); `groups` may grow meanwhile (StableVec: its elements never move);
     //   * coll_mtx around every access to the collection's sample table;
     //   * Group::exists / ref_size belong to the main thread (set when the group is minted), the packs to the book thread.
     // Not used in append / concatenated mode, for windows of several registrations, or with AGC_AMD_SYNC_ENTROPY;
@@ -736,7 +769,7 @@ struct CAGCCompressor::Impl {
 
     PkMap map_segments;                                                       // agc_compressor.h:628
     std::unordered_map<uint64_t, std::vector<uint64_t>> terminators;          // agc_compressor.h:629
-    std::vector<Group> groups;                                                // v_segments
+    StableVec<Group> groups;                                                  // v_segments (elements never move: see StableVec)
     uint32_t no_segments = 0;
     uint32_t processed_samples = 0, stored_samples = 0;
     size_t cnt_contigs_in_sample = 0;
@@ -886,7 +919,7 @@ struct CAGCCompressor::Impl {
     bool close_collected = false;
     void choose_entropy_stage();
     void add_job_parts(std::vector<ZJob> &jobs, size_t from, size_t to);
-    void make_pack_job(std::vector<ZJob> &jobs, Group &g, bytes_t &data, std::vector<uint32_t> &off);
+    void make_pack_job(std::vector<ZJob> &jobs, uint32_t gid, bytes_t &data, std::vector<uint32_t> &off);
     PinnedBytes enc_buf, enc_buf2; // grown, never shrunk (enc_buf: the window's speculative deltas, enc_buf2: per commit run); pinned
     bytes_t fetch_buf;
     // scratch reused across registrations (no reallocation / page faults / zero fill per sample)

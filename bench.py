@@ -368,7 +368,10 @@ def main():
                 cmp_.set_next_sample_packed_dev(samples[s + 1][0], off)
             cmp_.add_sample_packed_dev(f"{tag}{rank}_{s}", names, samples[s][0], off)
             return
-        dc.compress(1 + (s + 1) * world, get_sample, start=1 + s * world)  # (each step: the N samples prepared in parallel)
+        # (each step: the N samples prepared in parallel.  AGC_BENCH_SERIAL_PREPARE=1, a measuring aid for ranks that SHARE one GPU:
+        # every rank prepares at its own turn, so the per-stage times of config.single_archive_ms_per_sample_rank0 are those of an
+        # uncontended device)
+        dc.compress(1 + (s + 1) * world, get_sample, prefetch=not os.environ.get("AGC_BENCH_SERIAL_PREPARE"), start=1 + s * world)
 
     n_steps = args.steps + args.warmup
     # weak scaling: samples are partitioned round-robin over ranks (one archive shard per rank), no data-path collective

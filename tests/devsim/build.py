@@ -43,5 +43,18 @@ def build(force=False):
     return SIM_CLI
 
 
+SIM_TWO = os.path.join(OUT, "two_ranks_one_process")
+
+
+def build_two_ranks(force=False):
+    """tests/devsim/two_ranks_one_process.cpp (two ranks of the multi-GPU mode in one process) against the stand-in libraries"""
+    build(force)
+    src = os.path.join(HERE, "two_ranks_one_process.cpp")
+    if force or not _newer(SIM_TWO, [src, SIM_HOST]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", SIM_TWO, "-L" + OUT, "-lagc_host", "-lagc_hip",
+                               "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"])
+    return SIM_TWO
+
+
 if __name__ == "__main__":
     print(build(force=True))

@@ -149,6 +149,25 @@ def test_bookkeeping_beside_the_next_registration_gives_the_same_archive(cli, na
         assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_adaptive"])
+def test_two_ranks_in_one_process_write_the_reference_archive(name, tmp_path):
+    """the multi-GPU protocol without torch: two compressors in one process (tests/devsim/two_ranks_one_process.cpp) -- prepare
+    ahead, commit in two steps (head out first, then finish + body), the writer applying records into its bookkeeping queue --
+    give the reference's archive.  scripts/tsan_check.sh runs the same tool under ThreadSanitizer."""
+    exe = simbuild.build_two_ranks()
+    args, _ = C.CONFIGS[name]
+    opt = {"-k": 31, "-l": 20, "-s": 60000, "-b": 50}
+    for i in range(len(args) - 1):
+        if args[i] in opt:
+            opt[args[i]] = int(args[i + 1])
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "o.agc")
+    r = subprocess.run([exe, out] + [str(opt[x]) for x in ("-k", "-l", "-s", "-b")] + ["1" if "-a" in args else "0"] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
+
+
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_shuffled", "syn_c4_twin", "syn_viral"])
 def test_mapped_reader_gives_the_same_archive(cli, name, tmp_path, monkeypatch):
     """AGC_AMD_MAP_MIN=1: every plain input file goes through the mapped, multi-threaded reader big assemblies get"""
