@@ -26,11 +26,6 @@ void put32(bytes_t &d, uint32_t x)
     for (int i = 0; i < 4; ++i, x >>= 8)
         d.push_back((uint8_t)(x & 0xff));
 }
-void put64(bytes_t &d, uint64_t x)
-{
-    for (int i = 0; i < 8; ++i, x >>= 8)
-        d.push_back((uint8_t)(x & 0xff));
-}
 struct RecReader {
     const uint8_t *p, *e;
     bool ok = true;
@@ -78,29 +73,9 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
     const std::vector<Placed> &placed = placed_buf;
     const BatchState::Store &sto = b.sto;
     bytes_t &r = dist_record;
-    r.clear();
     dist_body_n = 0;
     dist_body_items.clear();
-    r.insert(r.end(), {'A', 'G', 'C', 'R'});
-    put32(r, (uint32_t)ctgs.size());
     const SampleLists &sl = b.per_sample.at(0); // one registration per record
-    put32(r, (uint32_t)sl.n_lists());
-    put32(r, (uint32_t)b.new_splitters_added.size());
-    uint32_t first_new = ~0u, n_new = 0;
-    for (uint32_t idx : sto.new_ref_items) {
-        first_new = std::min(first_new, (uint32_t)placed[idx].gid);
-        ++n_new;
-    }
-    put32(r, first_new);
-    put32(r, n_new);
-    for (auto &c : ctgs) {
-        r.insert(r.end(), c.sample.begin(), c.sample.end());
-        r.push_back(0);
-        r.insert(r.end(), c.name.begin(), c.name.end());
-        r.push_back(0);
-    }
-    for (uint64_t x : b.new_splitters_added)
-        put64(r, x);
     std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size());
     for (uint32_t i = 0; i < sto.new_ref_items.size(); ++i)
         pos_newref[sto.new_ref_items[i]] = i;
@@ -111,36 +86,74 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
         kind[idx] = 0;
     for (uint32_t idx : sto.raw_items)
         kind[idx] = 1;
+    // size first (50 k items of 14 bytes and a few MB of symbols: written through a pointer, not byte by byte)
+    size_t need = 24 + 8 * b.new_splitters_added.size() + 8 * sl.n_lists() + 14 * sl.items.size();
+    for (auto &c : ctgs)
+        need += c.sample.size() + c.name.size() + 2;
+    need += 21 * sto.new_ref_items.size() + 4 * sto.raw_items.size() + (sto.fetched_off.empty() ? 0 : sto.fetched_off.back());
+    r.resize(need);
+    uint8_t *w = r.data();
+    auto w32 = [&](uint32_t x) {
+        w[0] = (uint8_t)x, w[1] = (uint8_t)(x >> 8), w[2] = (uint8_t)(x >> 16), w[3] = (uint8_t)(x >> 24);
+        w += 4;
+    };
+    auto w64 = [&](uint64_t x) {
+        w32((uint32_t)x);
+        w32((uint32_t)(x >> 32));
+    };
+    memcpy(w, "AGCR", 4);
+    w += 4;
+    w32((uint32_t)ctgs.size());
+    w32((uint32_t)sl.n_lists());
+    w32((uint32_t)b.new_splitters_added.size());
+    uint32_t first_new = ~0u, n_new = 0;
+    for (uint32_t idx : sto.new_ref_items) {
+        first_new = std::min(first_new, (uint32_t)placed[idx].gid);
+        ++n_new;
+    }
+    w32(first_new);
+    w32(n_new);
+    for (auto &c : ctgs) {
+        memcpy(w, c.sample.data(), c.sample.size());
+        w += c.sample.size();
+        *w++ = 0;
+        memcpy(w, c.name.data(), c.name.size());
+        w += c.name.size();
+        *w++ = 0;
+    }
+    for (uint64_t x : b.new_splitters_added)
+        w64(x);
     const bytes_t &fetched = fetch_buf;
     for (size_t li = 0; li < sl.n_lists(); ++li) {
-        put32(r, sl.gids[li]);
-        put32(r, sl.begin[li + 1] - sl.begin[li]);
+        w32(sl.gids[li]);
+        w32(sl.begin[li + 1] - sl.begin[li]);
         for (uint32_t ii = sl.begin[li]; ii < sl.begin[li + 1]; ++ii) {
             const uint32_t idx = sl.items[ii];
             const Placed &pl = placed[idx];
-            put32(r, pl.ctg);
-            put32(r, pl.part_no);
-            put32(r, pl.len);
-            r.push_back((uint8_t)pl.rc);
-            r.push_back(kind[idx]);
+            w32(pl.ctg);
+            w32(pl.part_no);
+            w32(pl.len);
+            *w++ = (uint8_t)pl.rc;
+            *w++ = kind[idx];
             if (kind[idx] == 2) {
                 dist_body_items.push_back(idx); // (its length and bytes travel in the body)
                 continue;
             }
             uint32_t fi;
             if (kind[idx] == 0) {
-                put64(r, pl.pk.first);
-                put64(r, pl.pk.second);
+                w64(pl.pk.first);
+                w64(pl.pk.second);
                 fi = pos_newref[idx];
-                r.push_back(sto.repetitive[fi]);
+                *w++ = sto.repetitive[fi];
             } else
                 fi = (uint32_t)sto.new_ref_items.size() + pos_raw[idx];
-            const uint8_t *p = fetched.data() + sto.fetched_off[fi];
             const size_t n = sto.fetched_off[fi + 1] - sto.fetched_off[fi];
-            put32(r, (uint32_t)n);
-            r.insert(r.end(), p, p + n);
+            w32((uint32_t)n);
+            memcpy(w, fetched.data() + sto.fetched_off[fi], n);
+            w += n;
         }
     }
+    r.resize((size_t)(w - r.data()));
 }
 
 // The body: every delta item of the head, in the same order: u32 length + bytes.  ~22 MB per human-size sample, gathered by the
