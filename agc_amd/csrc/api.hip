@@ -71,6 +71,11 @@ struct agc_hip_ctx {
         uint32_t n = 0;          // segments of the encode in flight
         bool pending = false, timed = false;
         hipEvent_t e0 = nullptr, e1 = nullptr, ready = nullptr;
+        // `done`: recorded behind the parse of the encode in flight.  A caller may collect that encode from another thread while
+        // this one already works on the next sample (agc_hip_lz_encode_end only touches this lane): whatever overwrites a buffer
+        // the parse reads -- the sample staging buffers -- waits for the event on its own stream (sample_buffer, prefetch)
+        hipEvent_t done = nullptr;
+        bool done_valid = false;
     } l2;
     hipStream_t stream2 = nullptr;
 
@@ -252,6 +257,7 @@ int agc_hip_create(agc_hip_ctx **out, int device)
         hipEventCreateWithFlags(&c->zev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->zev_b, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l2.e0) != hipSuccess ||
         hipEventCreate(&c->l2.e1) != hipSuccess || hipEventCreateWithFlags(&c->l2.ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->l2.done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->zev0) != hipSuccess || hipEventCreate(&c->zev1) != hipSuccess) {
         delete c;
@@ -315,7 +321,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
     for (hipEvent_t e : {c->zev_a, c->zev_b})
         if (e)
             (void)hipEventDestroy(e);
-    for (hipEvent_t e : {c->l2.e0, c->l2.e1, c->l2.ready})
+    for (hipEvent_t e : {c->l2.e0, c->l2.e1, c->l2.ready, c->l2.done})
         if (e)
             (void)hipEventDestroy(e);
     if (c->stream2)
@@ -368,6 +374,13 @@ int agc_hip_sample_buffer(agc_hip_ctx *c, uint64_t bytes, uint8_t **d_ptr)
     if (!c || !d_ptr)
         return AGC_HIP_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    // (the encode of the previous sample may still be reading the buffer on the second lane: see Lane2::done)
+    if (c->l2.done_valid) {
+        if (bytes + 4096 > c->d_sample.cap)
+            HIPCHK(c, hipEventSynchronize(c->l2.done)); // the buffer is about to be replaced
+        else
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->l2.done, 0));
+    }
     CHK(ensure(c, c->d_sample, bytes + 4096));
     *d_ptr = (uint8_t *)c->d_sample.p;
     return AGC_HIP_OK;
@@ -830,6 +843,13 @@ int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const 
     CHK(sbloom_upload(c, k));
     pf.cur ^= 1;
     DevBuf &stage = pf.d_sample[pf.cur];
+    // (this staging buffer held the sample before the current one: its encode may still be reading it on the second lane)
+    if (c->l2.done_valid) {
+        if (pk->n_symbols + 64 + 4096 > stage.cap)
+            HIPCHK(c, hipEventSynchronize(c->l2.done));
+        else
+            HIPCHK(c, hipStreamWaitEvent(pf.stream, c->l2.done, 0));
+    }
     CHK(ensure(c, stage, pk->n_symbols + 64 + 4096, pf.stream));
     const PackedView pv = {pk->d_words, pk->d_esc_index, pk->d_esc_bytes, pk->n_symbols};
     const uint64_t n_blocks = (pk->n_symbols + PACK_BLOCK - 1) / PACK_BLOCK;
@@ -1376,6 +1396,8 @@ int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gi
     CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)c->l2.d_scratch.p, nullptr, true));
     if (c->l2.timed)
         (void)hipEventRecord(c->l2.e1, c->stream2);
+    HIPCHK(c, hipEventRecord(c->l2.done, c->stream2));
+    c->l2.done_valid = true;
     HIPCHK(c, hipMemcpyAsync(c->l2.h_lens, c->l2.d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream2));
     c->l2.pending = true;
     return AGC_HIP_OK;

@@ -7,9 +7,15 @@ namespace agc {
 CAGCCompressor::CAGCCompressor() : p(new Impl) {}
 CAGCCompressor::~CAGCCompressor()
 {
-    p->z_shutdown(); // the entropy thread uses the device context
+    p->book_shutdown(); // the bookkeeping and the entropy thread use the device context
+    p->z_shutdown();
     p->enc_buf.release(); // (pinned memory of that context)
     p->enc_buf2.release();
+    p->enc_alt.release();
+    p->enc_alt2.release();
+    p->dist_body_buf.release();
+    p->body_recv.reset();
+    p->body_pool.clear();
     if (p->hip)
         agc_hip_destroy(p->hip);
 }
@@ -141,6 +147,9 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     I.bpool.reset(new ThreadPool(std::max(1u, std::min(8u, nt / 2))));
     if (const char *e = getenv("AGC_AMD_ASYNC_BOOK"))
         I.async_book = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_ASYNC_ENCODE"))
+        I.async_encode = atoi(e) != 0;
+    I.enc_alt.ctx = I.enc_alt2.ctx = I.hip;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
@@ -319,6 +328,9 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     I.bpool.reset(new ThreadPool(std::max(1u, std::min(8u, nt / 2))));
     if (const char *e = getenv("AGC_AMD_ASYNC_BOOK"))
         I.async_book = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_ASYNC_ENCODE"))
+        I.async_encode = atoi(e) != 0;
+    I.enc_alt.ctx = I.enc_alt2.ctx = I.hip;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
@@ -578,7 +590,9 @@ bool CAGCCompressor::PrepareSamplePackedDevice(const std::string &sample_name, c
         return false;
     I.pf_live.valid = false;
     I.packed_sample = pk;
+    I.next_base_owned = true; // (the byte staging copy is the device context's: it outlives this sample's calls)
     const bool ok = PrepareSampleDevice(sample_name, contig_names, d_codes, ctg_off);
+    I.next_base_owned = false;
     I.packed_sample.n_symbols = 0; // (scans of the commit phase -- adaptive mode -- run inside PrepareSampleDevice as well)
     I.scan_from_prefetch = false;
     return ok;
@@ -762,7 +776,10 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
             }
         I.st.t_io += now() - t0;
         uint32_t n_done = 0;
-        if (!I.process_batch(batch, d_base, I.adaptive ? &batch_data : nullptr, n_done))
+        I.next_base_owned = true; // (agc_hip_sample_buffer)
+        const bool batch_ok = I.process_batch(batch, d_base, I.adaptive ? &batch_data : nullptr, n_done);
+        I.next_base_owned = false;
+        if (!batch_ok)
             return false;
         if (nb == 0) // an empty registration (the reference's trailing token in -c mode)
             return true;

@@ -118,8 +118,9 @@ void CAGCCompressor::Impl::z_shutdown()
 }
 
 // ---- the asynchronous bookkeeping stage (compressor_impl.h) ------------------
-void CAGCCompressor::Impl::book_submit(std::unique_ptr<BookTask> &&t)
+uint64_t CAGCCompressor::Impl::book_submit(std::unique_ptr<BookTask> &&t)
 {
+    uint64_t seq;
     {
         std::unique_lock<std::mutex> lk(book_mtx);
         // (a task holds up to a sample's deltas: the queue stays short)
@@ -127,8 +128,10 @@ void CAGCCompressor::Impl::book_submit(std::unique_ptr<BookTask> &&t)
         if (!book_thread.joinable())
             book_thread = std::thread([this] { book_main(); });
         book_queue.emplace_back(std::move(t));
+        seq = ++book_seq_submitted;
     }
     book_cv.notify_all();
+    return seq;
 }
 
 void CAGCCompressor::Impl::book_main()
@@ -145,14 +148,46 @@ void CAGCCompressor::Impl::book_main()
             book_busy = true;
         }
         const double t0 = now();
+        bool ok = true;
+        uint64_t delta_bytes = 0;
+        if (t->enc_pending) {
+            // the registration's LZ encode was left in flight on the device's second lane: collect it (only that lane is touched)
+            const size_t ne = t->enc_todo.size();
+            std::vector<uint64_t> eoff(ne + 1, 0);
+            PinnedBytes &enc = *t->enc_dst;
+            uint64_t cap = std::max<uint64_t>(enc.size(), t->enc_text / 64 + (1u << 16));
+            for (;;) {
+                if (!enc.resize(cap, false)) {
+                    err("out of memory (delta buffer)");
+                    ok = false;
+                    break;
+                }
+                const int r = agc_hip_lz_encode_end(hip, enc.data(), cap, eoff.data());
+                if (r == AGC_HIP_ECAP) {
+                    cap = eoff[ne] + eoff[ne] / 8 + 4096; // (headroom: the next sample's deltas are a little longer)
+                    continue;
+                }
+                ok = hip_ok(r, "lz_encode_end");
+                break;
+            }
+            if (ok) {
+                for (size_t i = 0; i < ne; ++i) {
+                    t->cd.enc_ptr[t->enc_todo[i]] = enc.data() + eoff[i];
+                    t->cd.enc_len[t->enc_todo[i]] = (uint32_t)(eoff[i + 1] - eoff[i]);
+                }
+                delta_bytes = eoff[ne];
+            }
+        }
         book_on_thread = true;
-        const bool ok = book_and_store(t->cd);
+        ok = ok && book_and_store(t->cd);
         book_on_thread = false;
         t.reset();
         {
             std::lock_guard<std::mutex> lk(book_mtx);
             book_busy = false;
+            ++book_seq_done;
             book_seconds += now() - t0;
+            book_delta_bytes += delta_bytes;
             if (!ok)
                 book_failed = true;
         }
@@ -169,7 +204,18 @@ bool CAGCCompressor::Impl::book_wait()
     book_idle_cv.wait(lk, [&] { return book_queue.empty() && !book_busy; });
     st.t_store += book_seconds;
     st.h_store += book_seconds;
+    st.delta_bytes += book_delta_bytes;
     book_seconds = 0;
+    book_delta_bytes = 0;
+    return !book_failed;
+}
+
+bool CAGCCompressor::Impl::book_wait_seq(uint64_t seq)
+{
+    if (!seq || !book_thread.joinable())
+        return true;
+    std::unique_lock<std::mutex> lk(book_mtx);
+    book_idle_cv.wait(lk, [&] { return book_seq_done >= seq; });
     return !book_failed;
 }
 
@@ -539,6 +585,7 @@ bool CAGCCompressor::Impl::batch_prepare(BatchState &b, std::vector<Contig> &ctg
     b.d_base = d_base;
     b.host_data = host_data;
     b.n_ctg = (uint32_t)ctgs.size();
+    b.base_owned = next_base_owned;
     b.t0 = now();
     b.dev0 = st.t_device;
     b.lap_t = b.t0;
@@ -1299,10 +1346,6 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
     if (b.overlap_encode && overlap_mode == 2 && !b.enc_in_flight && !overlap_encode_begin(b))
         return false;
     // ---- add_segment, part 4: final placement + part numbers ----
-    // (the bookkeeping of the previous registration may still be reading placed_buf / fetch_buf / enc_buf*: from here on they
-    // are this window's)
-    if (!book_wait())
-        return false;
     std::vector<Placed> &placed = placed_buf;
     placed.clear();
     placed.reserve(segs.size() + segs.size() / 8 + 16);
@@ -1705,6 +1748,11 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
     std::vector<SampleLists> &per_sample = b.per_sample;
     std::vector<uint32_t> &new_ref_items = b.sto.new_ref_items, &raw_items = b.sto.raw_items, &enc_items = b.sto.enc_items;
     bytes_t &fetched = fetch_buf;
+    // the previous registration's task is done with the second buffer set and with the device's second lane (long ago: it was
+    // queued a whole step earlier)
+    if (!book_wait_seq(last_own_seq))
+        return false;
+    const bool hand_over = book_can_async(b.n_samples) && (dist_world == 1 || dist_rank == dist_writer);
     {
         const size_t nr = new_ref_items.size();
         if (nr) { // register the new references (index build)
@@ -1733,6 +1781,8 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
     if (b.enc_in_flight && !overlap_encode_end(b))
         return false;
     LAP("encode_end");
+    std::vector<uint32_t> enc_later; // positions in enc_items whose encode is in flight on the second lane
+    uint64_t enc_later_text = 0;
     {
         std::vector<uint32_t> todo; // positions in enc_items
         for (uint32_t i = 0; i < enc_items.size(); ++i) {
@@ -1760,6 +1810,16 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
                 st.enc_text += pl.len;
                 st.enc_ref += groups[pl.gid].ref_size ? groups[pl.gid].ref_size - 1 : 0;
             }
+            // The encode is only LAUNCHED here when its result is first read by the bookkeeping task: the task collects it (second
+            // device lane) while this thread goes on with the next sample.  Needs a sample in a staging buffer the device context
+            // owns (it outlives the call) and nothing else on that lane.
+            if (hand_over && async_encode && dist_world == 1 && b.base_owned && overlap_mode == 0 && !b.enc_in_flight && b.spec_bytes == 0) {
+                if (!hip_ok(DEVT(agc_hip_lz_encode_begin_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data())), "lz_encode_begin"))
+                    return false;
+                enc_later.swap(todo);
+                enc_later_text = tot;
+                st.lz_encoded += ne;
+            } else {
             PinnedBytes &enc = enc_buf2;
             uint64_t cap = std::max<uint64_t>(enc.size(), tot / 64 + (1u << 16));
             for (;;) {
@@ -1781,9 +1841,10 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             }
             st.lz_encoded += ne;
             st.delta_bytes += eoff[ne];
+            }
         }
     }
-    LAP("encode");
+    LAP(enc_later.empty() ? "encode" : "encode (in flight)");
     stage_end(st.t_encode, st.h_encode, t0, dev0);
     t0 = now();
 
@@ -1807,14 +1868,26 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
         if (dist_rank != dist_writer)
             return true; // the writer rank does the bookkeeping from the record
     }
-    if (book_can_async(b.n_samples)) {
-        // beside the next sample: the task points into placed_buf / fetch_buf / enc_buf*, which stage_place of the next
-        // window waits for (book_wait) before it writes them again
+    if (hand_over) {
+        // beside the next sample: the registration's buffers change places with the second set, which is the task's until it is
+        // done (the raw pointers of cdta stay valid: the blocks themselves do not move)
         std::unique_ptr<BookTask> t(new BookTask());
         t->ctgs = *b.ctgs;
+        placed_buf.swap(placed_alt);
+        fetch_buf.swap(fetch_alt);
+        enc_buf.swap(enc_alt);
+        enc_buf2.swap(enc_alt2);
         t->cd = std::move(cdta);
         t->cd.ctgs = &t->ctgs;
-        book_submit(std::move(t));
+        t->cd.placed = &placed_alt;
+        t->cd.fetched = &fetch_alt;
+        if (!enc_later.empty()) {
+            t->enc_pending = true;
+            t->enc_todo = std::move(enc_later);
+            t->enc_text = enc_later_text;
+            t->enc_dst = &enc_alt2;
+        }
+        last_own_seq = book_submit(std::move(t));
         LAP("book_and_store (queued)");
         return true;
     }

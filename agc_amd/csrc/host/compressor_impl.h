@@ -301,6 +301,13 @@ struct PinnedBytes {
         p = nullptr;
         n = 0;
     }
+    void swap(PinnedBytes &o)
+    {
+        std::swap(ctx, o.ctx);
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(pinned, o.pinned);
+    }
     PinnedBytes() = default;
     PinnedBytes(const PinnedBytes &) = delete;
     PinnedBytes &operator=(const PinnedBytes &) = delete;
@@ -722,8 +729,13 @@ struct CAGCCompressor::Impl {
     // records, the parts' places in the archive) reads nothing the classification of the next sample needs and writes nothing
     // it reads: it runs on one background thread, in registration order, beside the next sample's scan and classification (and,
     // on the writer rank of the multi-GPU mode, beside the next owner's commit).  What orders the two threads:
-    //   * book_wait() before the main thread reuses the buffers a queued task points into (stage_place) or reads what the stage
-    //     produces (Close, the sync path); `groups` may grow meanwhile (StableVec: its elements never move);
+    //   * a registration's buffers (placed items, fetched symbols, the pinned delta buffers) are handed over by SWAPPING them with
+    //     a second set (*_alt) that only the queued task touches; before the next hand-over swaps again the previous own task
+    //     must be done (book_wait_seq(last_own_seq): it has been for a long time).  book_wait() before anything reads what the
+    //     stage produces (Close, the sync path); `groups` may grow meanwhile (StableVec: its elements never move);
+    //   * the LZ encode of the registration may still be in flight on the device's second lane when the call returns: the task
+    //     collects it.  Only for samples in a staging buffer the device context owns (whatever overwrites that buffer waits for
+    //     the encode on its stream, api.hip Lane2::done); AGC_AMD_ASYNC_ENCODE=0 turns it off;
     //   * coll_mtx around every access to the collection's sample table;
     //   * Group::exists / ref_size belong to the main thread (set when the group is minted), the packs to the book thread.
     // Not used in append / concatenated mode, for windows of several registrations, or with AGC_AMD_SYNC_ENTROPY;
@@ -734,6 +746,12 @@ struct CAGCCompressor::Impl {
         std::vector<Placed> placed; // apply_record: everything is the task's own
         bytes_t fetched, enc;
         std::unique_ptr<PinnedBytes> enc_recv; // (the received body itself, when it came in through RecordBodyBuffer)
+        // an LZ encode still in flight on the device's second lane (agc_hip_lz_encode_begin_dev): the task collects it
+        // (agc_hip_lz_encode_end) into *enc_dst before it does the books; enc_todo = positions in cd.enc_items it covers
+        bool enc_pending = false;
+        std::vector<uint32_t> enc_todo;
+        uint64_t enc_text = 0;
+        PinnedBytes *enc_dst = nullptr;
         Impl *owner = nullptr;
         ~BookTask()
         {
@@ -748,14 +766,18 @@ struct CAGCCompressor::Impl {
     std::condition_variable book_cv, book_idle_cv;
     std::deque<std::unique_ptr<BookTask>> book_queue;
     bool book_busy = false, book_stop = false, book_failed = false;
-    bool async_book = true;
+    bool async_book = true, async_encode = true;
+    uint64_t book_seq_submitted = 0, book_seq_done = 0; // tasks are numbered; they complete in order
+    uint64_t last_own_seq = 0;          // the last task that points into this object's buffers (the *_alt set below)
     double book_seconds = 0;            // the book thread's own time (added to st.t_store / h_store by book_wait)
+    uint64_t book_delta_bytes = 0;      // deltas collected by the book thread (added to st.delta_bytes by book_wait)
     std::unique_ptr<ThreadPool> bpool;  // the stage's own workers (`pool` belongs to the thread that drives the steps)
     std::mutex coll_mtx;
     bool book_can_async(uint32_t n_samples) const { return async_book && !appending && !concatenated && !sync_entropy && n_samples == 1; }
-    void book_submit(std::unique_ptr<BookTask> &&t);
+    uint64_t book_submit(std::unique_ptr<BookTask> &&t);
     void book_main();
     bool book_wait();
+    bool book_wait_seq(uint64_t seq); // the tasks up to `seq` are done
     void book_shutdown();
     bool book_on_thread = false; // (book thread only) book_and_store runs as a queued task
 
@@ -811,6 +833,7 @@ struct CAGCCompressor::Impl {
         std::vector<uint64_t> new_splitters_added; // adaptive mode
         std::vector<uint32_t> subset;              // segments stage_classify works on
         uint32_t n_samples = 1, s_from = 0;        // registrations of the window; first one not committed yet
+        bool base_owned = false;                   // d_base is a staging buffer of the device context (see Impl::next_base_owned)
         struct Spec {                              // speculative delta of a placed item (by Placed::key)
             uint64_t off = 0, enc_off = 0;
             uint32_t gid = 0, len = 0, enc_len = 0;
@@ -922,6 +945,11 @@ struct CAGCCompressor::Impl {
     void make_pack_job(std::vector<ZJob> &jobs, uint32_t gid, bytes_t &data, std::vector<uint32_t> &off);
     PinnedBytes enc_buf, enc_buf2; // grown, never shrunk (enc_buf: the window's speculative deltas, enc_buf2: per commit run); pinned
     bytes_t fetch_buf;
+    // the second set: what the queued bookkeeping task of the previous registration reads (swapped at the hand-over)
+    PinnedBytes enc_alt, enc_alt2;
+    bytes_t fetch_alt;
+    std::vector<Placed> placed_alt;
+    bool next_base_owned = false; // the sample being prepared sits in a staging buffer of the device context (not the caller's)
     // scratch reused across registrations (no reallocation / page faults / zero fill per sample)
     std::vector<uint32_t> gid_slot, gid_epoch;
     uint32_t gid_epoch_ctr = 0;

@@ -46,13 +46,11 @@ struct agc_hip_ctx {
     u64 n_spl;
     void **lz; /* by gid */
     u32 n_lz;
-    /* encode in two halves: the arguments of begin, replayed by end */
+    /* encode in two halves: parsed at begin (see agc_hip_lz_encode_begin_dev), handed out by end */
     int enc_pending;
     u32 enc_n;
-    u32 *enc_gid, *enc_len;
-    u64 *enc_off;
-    u8 *enc_rc;
-    const u8 *enc_base;
+    u8 *enc_out;
+    u64 *enc_eoff;
     /* the next sample ahead of its turn: two staging buffers, the identity of what was prefetched */
     u8 *pf_buf[2];
     u64 pf_cap[2];
@@ -314,16 +312,16 @@ static void *dup_mem(const void *p, size_t n)
 
 static void enc_clear(agc_hip_ctx *c)
 {
-    free(c->enc_gid);
-    free(c->enc_len);
-    free(c->enc_off);
-    free(c->enc_rc);
-    c->enc_gid = c->enc_len = NULL;
-    c->enc_off = NULL;
-    c->enc_rc = NULL;
+    free(c->enc_out);
+    free(c->enc_eoff);
+    c->enc_out = NULL;
+    c->enc_eoff = NULL;
     c->enc_pending = 0;
 }
 
+/* The device runs the parse in stream order behind `begin` and makes whatever overwrites the sample buffer wait for it (api.hip,
+ * Lane2::done); the stand-in has no streams, so it models the same thing by parsing AT begin into a buffer of its own.  `_end`
+ * (possibly on another thread: it only touches the enc_* fields) hands the result out. */
 int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off, const uint32_t *len,
                                 const uint8_t *rc)
 {
@@ -332,11 +330,26 @@ int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid,
     if (c->enc_pending)
         enc_clear(c); /* an abandoned encode is dropped */
     c->enc_n = n;
-    c->enc_gid = (u32 *)dup_mem(gid, (size_t)n * 4);
-    c->enc_len = (u32 *)dup_mem(len, (size_t)n * 4);
-    c->enc_off = (u64 *)dup_mem(off, (size_t)n * 8);
-    c->enc_rc = rc ? (u8 *)dup_mem(rc, n) : NULL;
-    c->enc_base = d;
+    c->enc_eoff = (u64 *)calloc((size_t)n + 1, 8);
+    u64 cap = 1u << 16;
+    for (u32 i = 0; i < n; ++i)
+        cap += len[i] / 64 + 16;
+    for (;;) {
+        free(c->enc_out);
+        c->enc_out = (u8 *)malloc(cap ? cap : 1);
+        if (!c->enc_out || !c->enc_eoff)
+            return AGC_HIP_ENOMEM;
+        const int r = agc_hip_lz_encode_batch_dev(c, n, gid, d, off, len, rc, c->enc_out, cap, c->enc_eoff);
+        if (r == AGC_HIP_ECAP) {
+            cap = c->enc_eoff[n] + 64;
+            continue;
+        }
+        if (r != AGC_HIP_OK) {
+            enc_clear(c);
+            return r;
+        }
+        break;
+    }
     c->enc_pending = 1;
     return AGC_HIP_OK;
 }
@@ -347,10 +360,17 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t cap, uint64_t
         return AGC_HIP_EINVAL;
     if (!c->enc_pending)
         return fail(c, AGC_HIP_EINVAL, "encode_end: no encode in flight");
-    const int r = agc_hip_lz_encode_batch_dev(c, c->enc_n, c->enc_gid, c->enc_base, c->enc_off, c->enc_len, c->enc_rc, h_enc, cap, h_enc_off);
-    if (r != AGC_HIP_ECAP)
-        enc_clear(c);
-    return r;
+    const u32 n = c->enc_n;
+    memcpy(h_enc_off, c->enc_eoff, ((size_t)n + 1) * 8);
+    if (c->enc_eoff[n] > cap)
+        return AGC_HIP_ECAP; /* (still in flight: call again with a larger buffer) */
+    if (c->enc_eoff[n]) {
+        if (!h_enc)
+            return AGC_HIP_EINVAL;
+        memcpy(h_enc, c->enc_out, c->enc_eoff[n]);
+    }
+    enc_clear(c);
+    return AGC_HIP_OK;
 }
 
 int agc_hip_zstd17_background(agc_hip_ctx *c, int on)

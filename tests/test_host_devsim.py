@@ -141,6 +141,9 @@ def test_bookkeeping_beside_the_next_registration_gives_the_same_archive(cli, na
     out = str(tmp_path / "o.agc")
     r = subprocess.run([cli, "create"] + args + ["-t", "4", "-o", out] + files, capture_output=True, text=True, timeout=300)
     assert r.stderr.count("book_and_store (queued)") == len(files), r.stderr[-2000:]
+    # ... and its LZ encode is only launched by the registration; the bookkeeping task collects it (the reference sample has
+    # nothing to encode)
+    assert r.stderr.count("encode (in flight)") >= len(files) - 2, r.stderr[-2000:]
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
     if name == "syn_shuffled":
         monkeypatch.setenv("AGC_AMD_ASYNC_BOOK", "0")
