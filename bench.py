@@ -288,6 +288,15 @@ def file_mode(args):
         print(json.dumps(out), flush=True)
 
 
+def _sha256_file(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
 def main():
     if "--verify-entropy" in sys.argv:
         os.environ["AGC_AMD_VERIFY_DEV_FRAMES"] = "1"
@@ -329,7 +338,12 @@ def main():
         cmp_.set_distributed(rank, world, 0)
     # archive bytes are produced and discarded (out path ""): file I/O is not the path under test
     pack_card = args.pack_cardinality or PACK
-    cmp_.create("", pack_card, K, None, SEG, MML, n_threads=threads)
+    # (AGC_BENCH_ARCHIVE=<path>, a checking aid: the archive is written there and its sha256 reported in config.archive_sha256 -- two
+    # runs of the same command must agree whatever AGC_AMD_ASYNC_ENCODE / AGC_AMD_ASYNC_BOOK / --no-prefetch say)
+    archive_path = os.environ.get("AGC_BENCH_ARCHIVE", "") if rank == 0 or not single else ""
+    if archive_path and world > 1 and not single:
+        archive_path += f".{rank}"
+    cmp_.create(archive_path, pack_card, K, None, SEG, MML, n_threads=threads)
     # reference preprocessing (once per archive, not timed): the reference's determine_splitters on the GPU
     t_spl0 = time.perf_counter()
     if args.positional_splitters:
@@ -498,6 +512,7 @@ def main():
                        "setup_not_timed": f"determine_splitters ({'positional shortcut' if args.positional_splitters else 'GPU: enumerate + radix sort + singletons'}): "
                                           f"{t_spl:.2f} s; reference genome as first sample (mints ~{int(st0['new_groups'])} groups): {t_ref:.2f} s",
                        "steps_only_ms": round(t_steps / max(args.steps, 1) * 1e3, 3),
+                       **({"archive_sha256": _sha256_file(archive_path), "archive_bytes": os.path.getsize(archive_path)} if archive_path else {}),
                        "close_ms": round((elapsed - t_steps) * 1e3, 1),
                        "segments_per_step": int(per(stats["segments"])), "lz_encoded_per_step": int(per(stats["lz_encoded"])),
                        "missing_middle_per_step": int(per(stats["middle_tried"])), "one_splitter_per_step": int(per(stats["one_splitter"])),
