@@ -39,6 +39,7 @@ struct agc_hip_ctx {
     hipStream_t zstream = nullptr; // the entropy stage's own stream: agc_hip_zstd17_batch may run beside every other entry point
     hipStream_t zstream2 = nullptr; // ... and a second one: the one-lane kernel (inputs > 16 KiB) runs BESIDE the group kernel
     hipEvent_t zev_a = nullptr, zev_b = nullptr;
+    hipEvent_t zev_wait = nullptr; // (blocking-sync: the thread that waits for a launch of the entropy stage sleeps, its core is the host pool's)
     bool zstd_background = false;  // agc_hip_zstd17_background: launches leave the LDS to the kernels of the other streams
     std::string err;
 
@@ -255,6 +256,7 @@ int agc_hip_create(agc_hip_ctx **out, int device)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         create_low_priority_stream(&c->zstream) != hipSuccess || create_low_priority_stream(&c->zstream2) != hipSuccess ||
         hipEventCreateWithFlags(&c->zev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->zev_b, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->zev_wait, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l2.e0) != hipSuccess ||
         hipEventCreate(&c->l2.e1) != hipSuccess || hipEventCreateWithFlags(&c->l2.ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->l2.done, hipEventDisableTiming) != hipSuccess ||
@@ -318,7 +320,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipStreamDestroy(c->zstream);
     if (c->zstream2)
         (void)hipStreamDestroy(c->zstream2);
-    for (hipEvent_t e : {c->zev_a, c->zev_b})
+    for (hipEvent_t e : {c->zev_a, c->zev_b, c->zev_wait})
         if (e)
             (void)hipEventDestroy(e);
     for (hipEvent_t e : {c->l2.e0, c->l2.e1, c->l2.ready, c->l2.done})
@@ -1872,7 +1874,9 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
     }
     std::vector<uint32_t> sizes(n);
     HIPCHK(c, hipMemcpyAsync(sizes.data(), c->d_zsize.p, (size_t)n * 4, hipMemcpyDeviceToHost, zs_));
-    HIPCHK(c, hipStreamSynchronize(zs_));
+    // (the launch lasts hundreds of ms and the host pool compresses its share of the packs meanwhile: this thread sleeps)
+    HIPCHK(c, hipEventRecord(c->zev_wait, zs_));
+    HIPCHK(c, hipEventSynchronize(c->zev_wait));
     for (uint32_t i = 0; i < n; ++i)
         h_dst_off[i + 1] = h_dst_off[i] + sizes[i];
     const uint64_t tot = h_dst_off[n];
