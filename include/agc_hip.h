@@ -201,7 +201,11 @@ int agc_hip_lz_encode_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
  * agc_compressor.cpp:989-1050).  begin queues the work on the context's second stream and returns at once; between begin and
  * end every other entry point may be used (own stream, own scratch); end waits and delivers exactly what
  * agc_hip_lz_encode_batch_dev would have (AGC_HIP_ECAP: h_enc_off[n] holds the size needed, call end again).  One encode in
- * flight per context (a begin while one is in flight drops the earlier one).  The texts and every reference named must stay unchanged until end returns. */
+ * flight per context (a begin while one is in flight drops the earlier one).  The texts and every reference named must stay unchanged
+ * until end returns -- with one exception the library takes care of itself: texts in a staging buffer of the context
+ * (agc_hip_sample_buffer, the buffers of agc_hip_prefetch_packed_dev) may be "overwritten" by the next sample at once, whatever
+ * writes such a buffer is ordered behind the parse on the device.  end may be called from ANOTHER thread than the one that goes on
+ * using the context (it touches nothing but the second lane's state); that thread must not call begin again before end has returned. */
 int agc_hip_lz_encode_begin_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
                                 const uint32_t *h_len, const uint8_t *h_rc);
 int agc_hip_lz_encode_end(agc_hip_ctx *ctx, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
