@@ -32,7 +32,7 @@ SYMBOLS = [
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
     "agc_hip_lz_split_point_batch_dev", "agc_hip_fetch_slices_dev",
     "agc_hip_ref_lag_counts_dev",
-    "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_batch_dev", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams",
+    "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_batch_dev", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams", "agc_hip_zstd_batch", "agc_hip_zstd_cparams",
     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
     "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched",
 ]
@@ -113,6 +113,8 @@ def load():
     L.agc_hip_ref_lag_counts_dev.argtypes = [vp, C.c_uint32, vp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_zstd17_batch.argtypes = [vp, C.c_uint32, u8p, u64p, u8p, C.c_uint64, u64p]
     L.agc_hip_zstd17_cparams.argtypes = [C.c_uint64, u32p]
+    L.agc_hip_zstd_cparams.argtypes = [C.c_int, C.c_uint64, u32p]
+    L.agc_hip_zstd_batch.argtypes = [vp, C.c_uint32, u8p, u64p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_zstd17_batch_dev.argtypes = [vp, C.c_uint32, vp, u64p, u8p, C.c_uint64, u64p]
     L.agc_hip_zstd17_background.argtypes = [vp, C.c_int]
     L.agc_hip_zstd17_max_input.restype = C.c_uint32
@@ -417,6 +419,20 @@ class Context:
         dst = np.zeros(cap, np.uint8)
         doff = np.zeros(n + 1, np.uint64)
         self._chk(self.L.agc_hip_zstd17_batch(self.h, n, _p(src, u8p), _p(off, u64p), _p(dst, u8p), cap, _p(doff, u64p)))
+        return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)]
+
+    def zstd_batch(self, inputs, levels):
+        """inputs: list of bytes-like, levels: 13 / 17 / 19 per input; returns the list of zstd frames (S3 on the GPU)"""
+        n = len(inputs)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in inputs])
+        src = np.frombuffer(b"".join(bytes(x) for x in inputs), np.uint8) if off[-1] else np.zeros(1, np.uint8)
+        lv = np.ascontiguousarray(levels, dtype=np.uint8)
+        assert lv.size == n
+        cap = int(off[-1]) + 32 * n + 64
+        dst = np.zeros(cap, np.uint8)
+        doff = np.zeros(n + 1, np.uint64)
+        self._chk(self.L.agc_hip_zstd_batch(self.h, n, _p(src, u8p), _p(off, u64p), _p(lv, u8p), _p(dst, u8p), cap, _p(doff, u64p)))
         return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)]
 
     def zstd17_batch_raw(self, src, off):

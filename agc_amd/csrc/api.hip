@@ -1689,6 +1689,14 @@ int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
     return AGC_HIP_OK;
 }
 
+int agc_hip_zstd_cparams(int level, uint64_t src_size, uint32_t out7[7])
+{
+    if (!out7 || (level != 13 && level != 17 && level != 19))
+        return AGC_HIP_EINVAL;
+    zs::levelParams(level, src_size, out7);
+    return AGC_HIP_OK;
+}
+
 uint32_t agc_hip_zstd17_resident_frames(agc_hip_ctx *c)
 {
     if (!c)
@@ -1710,7 +1718,7 @@ int agc_hip_zstd17_background(agc_hip_ctx *c, int on)
 
 // d_src_ext != nullptr: the inputs are in HBM already (input i = d_src_ext[h_src_off[i] .. h_src_off[i+1])); h_src is not looked at
 static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint8_t *d_src_ext, const uint64_t *h_src_off, uint8_t *h_dst,
-                             uint64_t dst_cap, uint64_t *h_dst_off)
+                             uint64_t dst_cap, uint64_t *h_dst_off, const uint8_t *h_level = nullptr)
 {
     if (!c || !h_dst_off || (n && (!h_src_off)))
         return AGC_HIP_EINVAL;
@@ -1732,8 +1740,13 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
             c->err = "zstd17_batch: input " + std::to_string(i) + " is larger than one block";
             return AGC_HIP_EINVAL;
         }
+        const int level = h_level ? h_level[i] : 17;
+        if (level != 13 && level != 17 && level != 19) {
+            c->err = "zstd_batch: level " + std::to_string(level) + " (input " + std::to_string(i) + "): 13, 17 or 19";
+            return AGC_HIP_EINVAL;
+        }
         uint32_t p[7];
-        zs::level17Params(len, p);
+        zs::levelParams(level, len, p);
         const zs::CParams cp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6]};
         ws_need[i] = zs::wsLayout(cp, (uint32_t)len).total;
         dst_o[i] = dst_total;
@@ -1894,6 +1907,12 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
     HIPCHK(c, hipMemcpyAsync(h_dst, c->d_zout.p, tot, hipMemcpyDeviceToHost, zs_));
     HIPCHK(c, hipStreamSynchronize(zs_));
     return AGC_HIP_OK;
+}
+
+int agc_hip_zstd_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, const uint8_t *h_level, uint8_t *h_dst,
+                       uint64_t dst_cap, uint64_t *h_dst_off)
+{
+    return zstd17_batch_impl(c, n, h_src, nullptr, h_src_off, h_dst, dst_cap, h_dst_off, h_level);
 }
 
 int agc_hip_zstd17_batch(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,

@@ -554,6 +554,8 @@ void CAGCCompressor::Impl::choose_entropy_stage()
         gpu_zstd_share = std::min(1.0, std::max(0.0, atof(e)));
     if (const char *e = getenv("AGC_AMD_GPU_ZSTD_MIN"))
         gpu_zstd_min = (uint32_t)std::max(1, atoi(e));
+    if (const char *e = getenv("AGC_AMD_GPU_ZSTD_REFS"))
+        gpu_zstd_refs_min = (uint32_t)std::max(0, atoi(e));
     if (verbosity > 0)
         std::cerr << "entropy stage: delta packs on " << (gpu_zstd ? "the GPU (zstd 1.4.9 frames)" : "host libzstd") << ", libzstd " << v << std::endl;
 }

@@ -262,12 +262,36 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
             is_dev[i] = 1;
         for (uint32_t i = 0; i < jobs.size(); ++i)
             (is_dev[i] ? dev_jobs : host_jobs).push_back(i);
-    } else
-    for (uint32_t i = 0; i < jobs.size(); ++i)
-        if (gpu_zstd && jobs[i].kind == 1 && !jobs[i].data.empty() && jobs[i].data.size() <= dev_max)
-            dev_jobs.push_back(i);
-        else
-            host_jobs.push_back(i);
+    } else {
+        // references: only when there are many of them (the reference sample), tuple-packed here (bytes2tuples is a byte loop)
+        size_t n_refs = 0;
+        for (const ZJob &j : jobs)
+            n_refs += j.kind == 0 && !j.data.empty();
+        const bool refs_too = gpu_zstd && gpu_zstd_refs_min && n_refs >= gpu_zstd_refs_min;
+        if (refs_too)
+            zpool->parallel_for(jobs.size(), [&](size_t i, unsigned) {
+                ZJob &j = jobs[i];
+                if (j.kind != 0 || j.data.empty())
+                    return;
+                j.staged.clear();
+                if (!j.repetitive) {
+                    bytes2tuples(j.data, j.staged);
+                    j.level = 13;
+                    j.marker = 1;
+                } else {
+                    j.level = 19;
+                    j.marker = 0;
+                }
+            });
+        for (uint32_t i = 0; i < jobs.size(); ++i) {
+            const ZJob &j = jobs[i];
+            const size_t src_n = j.staged.empty() ? j.data.size() : j.staged.size();
+            if (gpu_zstd && !j.data.empty() && src_n <= dev_max && (j.kind == 1 || (j.kind == 0 && refs_too)))
+                dev_jobs.push_back(i);
+            else
+                host_jobs.push_back(i);
+        }
+    }
     if (ext) {
     } else if (dev_jobs.size() < gpu_zstd_min) { // not worth a launch
         host_jobs.insert(host_jobs.end(), dev_jobs.begin(), dev_jobs.end());
@@ -277,14 +301,17 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         // both engines work at the same time: the device keeps the share of the pack bytes that makes them finish together
         // (its measured rate against the host pool's, updated after every call)
         uint64_t total = 0, dev_acc = 0;
+        auto src_size = [&](uint32_t i) -> uint64_t { return jobs[i].staged.empty() ? jobs[i].data.size() : jobs[i].staged.size(); }; // what the encoder reads
         for (uint32_t i : dev_jobs)
-            total += jobs[i].data.size();
+            total += src_size(i);
         // (length of a frame's serial chain: level 17 parses inputs of up to 16 KB twice -- btultra2 -- and larger ones once,
         // with a deeper search; AGC_AMD_ZSTD_CHAIN_W: relative cost of a position of the larger class, in percent)
         static const uint64_t w_big = getenv("AGC_AMD_ZSTD_CHAIN_W") ? strtoull(getenv("AGC_AMD_ZSTD_CHAIN_W"), nullptr, 10) : 150;
         auto chain = [&](uint32_t i) -> uint64_t {
-            const uint64_t sz = jobs[i].data.size();
-            return sz <= 16384 ? 200 * sz : w_big * sz;
+            const uint64_t sz = src_size(i);
+            if (jobs[i].kind == 0 && jobs[i].level == 13) // one pass, a shallow search (searchLog 5 / 3)
+                return 60 * sz;
+            return sz <= 16384 || jobs[i].level == 19 ? 200 * sz : w_big * sz; // (level 19: two passes whatever the size)
         };
         std::vector<uint32_t> by_size(dev_jobs);
         std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return chain(a) < chain(b); });
@@ -301,7 +328,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         // launch of small frames -- is the host pool's: by_size ends with them)
         {
             size_t big = 0;
-            while (big < hi && jobs[by_size[hi - 1 - big]].data.size() > 16384)
+            while (big < hi && src_size(by_size[hi - 1 - big]) > 16384)
                 ++big;
             if (big < 512)
                 hi -= big;
@@ -310,10 +337,10 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
             lo = hi - resident;
         dev_acc = 0;
         for (size_t t = lo; t < hi; ++t)
-            dev_acc += jobs[by_size[t]].data.size();
+            dev_acc += src_size(by_size[t]);
         while (hi > lo && (double)dev_acc > gpu_zstd_share * (double)total) {
             --hi;
-            dev_acc -= jobs[by_size[hi]].data.size();
+            dev_acc -= src_size(by_size[hi]);
         }
         std::vector<uint32_t> keep(by_size.begin() + lo, by_size.begin() + hi);
         host_jobs.insert(host_jobs.end(), by_size.begin(), by_size.begin() + lo);
@@ -347,8 +374,14 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     } else if (!dev_jobs.empty()) {
         const size_t nd = dev_jobs.size();
         src_off.assign(nd + 1, 0);
-        for (size_t t = 0; t < nd; ++t)
-            src_off[t + 1] = src_off[t] + jobs[dev_jobs[t]].data.size();
+        std::vector<uint8_t> levels(nd);
+        bool any_ref = false;
+        for (size_t t = 0; t < nd; ++t) {
+            const ZJob &j = jobs[dev_jobs[t]];
+            src_off[t + 1] = src_off[t] + (j.staged.empty() ? j.data.size() : j.staged.size());
+            levels[t] = j.kind == 0 ? j.level : 17;
+            any_ref = any_ref || j.kind == 0;
+        }
         const uint64_t cap = src_off[nd] + 32 * nd + 64; // a frame never exceeds its input by more than the headers
         dst_off.assign(nd + 1, 0);
         // the packs are gathered by the whole pool (hundreds of MB into fresh pages: a tenth of a second for one thread, and the
@@ -358,12 +391,15 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         {
             const size_t n_chunks = std::min<size_t>(nd, (size_t)zpool->size() * 4);
             zpool->parallel_for(n_chunks, [&](size_t ci, unsigned) {
-                for (size_t t = nd * ci / n_chunks; t < nd * (ci + 1) / n_chunks; ++t)
-                    memcpy(zsrc_buf.data() + src_off[t], jobs[dev_jobs[t]].data.data(), jobs[dev_jobs[t]].data.size());
+                for (size_t t = nd * ci / n_chunks; t < nd * (ci + 1) / n_chunks; ++t) {
+                    const ZJob &j = jobs[dev_jobs[t]];
+                    const bytes_t &srcb = j.staged.empty() ? j.data : j.staged;
+                    memcpy(zsrc_buf.data() + src_off[t], srcb.data(), srcb.size());
+                }
             });
         }
         const double t_gather = now() - tg;
-        dev_done = std::async(std::launch::async, [&, nd, cap, t_gather] {
+        dev_done = std::async(std::launch::async, [&, nd, cap, t_gather, levels, any_ref] {
             const double td = now() - t_gather; // (the gather counts as device-side time for the split rule)
             zdst_buf.resize(cap + cap / 8, false);
             if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
@@ -379,7 +415,9 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 }
             }
 
-            const bool ok = hip_ok(agc_hip_zstd17_batch(hip, (uint32_t)nd, zsrc_buf.data(), src_off.data(), zdst_buf.data(), cap, dst_off.data()), "zstd17_batch");
+            const bool ok = hip_ok(agc_hip_zstd_batch(hip, (uint32_t)nd, zsrc_buf.data(), src_off.data(), any_ref ? levels.data() : nullptr, zdst_buf.data(), cap,
+                                                      dst_off.data()),
+                                   "zstd_batch");
             t_dev = now() - td;
             return ok;
         });
@@ -402,8 +440,12 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         uint8_t marker = 0;
         if (j.kind == 0) {
             if (!j.repetitive) {
-                bytes2tuples(j.data, tuples);
-                src = &tuples;
+                if (!j.staged.empty())
+                    src = &j.staged; // (packed for the device, which then left it to the pool)
+                else {
+                    bytes2tuples(j.data, tuples);
+                    src = &tuples;
+                }
                 level = 13;
                 marker = 1;
             } else
@@ -429,10 +471,11 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         if (!ok) { // the device refused: libzstd does them after all (same bytes)
             zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
                 ZJob &j = jobs[dev_jobs[t]];
-                size_t bound = zstd.compressBound(j.data.size());
+                const bytes_t &srcb = j.staged.empty() ? j.data : j.staged;
+                size_t bound = zstd.compressBound(srcb.size());
                 bytes_t packed(bound + 1);
-                uint32_t ps = (uint32_t)zctx[tid]->compress(packed.data(), bound, j.data.data(), j.data.size(), 17);
-                finish(j, packed, ps, 0);
+                uint32_t ps = (uint32_t)zctx[tid]->compress(packed.data(), bound, srcb.data(), srcb.size(), j.kind == 0 ? j.level : 17);
+                finish(j, packed, ps, j.kind == 0 ? j.marker : 0);
             });
         } else {
             // AGC_AMD_VERIFY_DEV_FRAMES=1 (a checking aid, e.g. `bench.py --verify-entropy`): every frame the device returned is
@@ -443,13 +486,14 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 std::atomic<uint64_t> bad{0};
                 zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned tid) {
                     const ZJob &j = jobs[dev_jobs[t]];
-                    const size_t bound = zstd.compressBound(j.data.size());
+                    const bytes_t &srcb = j.staged.empty() ? j.data : j.staged;
+                    const size_t bound = zstd.compressBound(srcb.size());
                     bytes_t ref(bound + 1);
-                    const size_t n = zctx[tid]->compress(ref.data(), bound, j.data.data(), j.data.size(), 17);
+                    const size_t n = zctx[tid]->compress(ref.data(), bound, srcb.data(), srcb.size(), j.kind == 0 ? j.level : 17);
                     if (n != dst_off[t + 1] - dst_off[t] || memcmp(ref.data(), zdst_buf.data() + dst_off[t], n) != 0)
                         ++bad;
                 });
-                std::cerr << "verify: " << dev_jobs.size() << " device frames (" << src_off[dev_jobs.size()] / 1e6 << " MB) against libzstd level 17: "
+                std::cerr << "verify: " << dev_jobs.size() << " device frames (" << src_off[dev_jobs.size()] / 1e6 << " MB) against libzstd (level 17; references 13 / 19): "
                           << bad.load() << " differ" << std::endl;
                 verify_frames += dev_jobs.size();
                 verify_bad += bad.load();
@@ -461,7 +505,8 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);
                 bytes_t packed(zdst_buf.data() + dst_off[t], zdst_buf.data() + dst_off[t + 1]);
                 packed.push_back(0);
-                finish(j, packed, ps, 0);
+                finish(j, packed, ps, j.kind == 0 ? j.marker : 0);
+                bytes_t().swap(j.staged);
             });
             if (!ext)
                 st.zstd_dev_in += src_off[dev_jobs.size()];

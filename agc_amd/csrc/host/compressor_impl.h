@@ -320,6 +320,9 @@ struct ZJob { // one archive part to produce
     int kind;          // 0 = reference (tuples/zstd13 or zstd19), 1 = pack (zstd17)
     bytes_t data;      // raw bytes (reference symbols or concatenated pack)
     bool repetitive = false;
+    // a reference the device entropy stage takes: what it compresses (tuples of `data`; empty = `data` itself), at which level
+    bytes_t staged;
+    uint8_t level = 17, marker = 0;
     bytes_t out;
     uint64_t meta = 0;
     std::shared_ptr<PartSlot> slot; // asynchronous entropy stage: where the finished part goes (already queued in the archive)
@@ -895,6 +898,9 @@ struct CAGCCompressor::Impl {
     // ratio measured on MI355X + 16 host threads (0.7 GB/s against 0.1 GB/s), every call with real work on both sides updates it
     double gpu_zstd_share = 0.88;
     uint32_t gpu_zstd_min = 64;        // fewer packs than this in one call stay on the host (AGC_AMD_GPU_ZSTD_MIN)
+    // references (level 13 on their tuples, level 19 for repetitive ones) on the device too when a call brings at least this many
+    // (the reference sample: ~50 k); 0 = never (AGC_AMD_GPU_ZSTD_REFS)
+    uint32_t gpu_zstd_refs_min = 0;
     PinnedBytes zsrc_buf, zdst_buf;    // staging of the device entropy stage (plain malloc: no zero fill of hundreds of MB)
     bool defer_stream_reg = false;     // parallel bookkeeping: pack jobs leave a missing delta stream to the merging thread
     bool minted_since_prepare = false; // a group of any key (also one-sided) was minted while a sample was prepared

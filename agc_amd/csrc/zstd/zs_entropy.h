@@ -710,13 +710,17 @@ ZFN U32 hufWriteCTable(EntWs &e, BYTE *dst, U32 maxSymbolValue, U32 huffLog)
 }
 
 // HUF_compress1X_usingCTable: symbols from the end
-ZFN U32 hufCompress1X(const EntWs &e, BYTE *dst, const BYTE *src, U32 srcSize)
+// `limit`: a stream that reaches it is longer than anything the caller would keep (HUF_compress's own capacity check answers 0 =
+// "not compressible" there: the literals then go out raw either way); nothing is written beyond limit + 8
+ZFN U32 hufCompress1X(const EntWs &e, BYTE *dst, const BYTE *src, U32 srcSize, const BYTE *limit)
 {
     BitW b;
     bitInit(b, dst);
     for (U32 n = srcSize; n > 0; --n) {
         const HufCElt c = e.hufCTable[src[n - 1]];
         bitAdd(b, c.val, c.nbBits);
+        if (b.ptr >= limit)
+            return 0;
     }
     return bitClose(b);
 }
@@ -762,8 +766,10 @@ ZFN U32 hufCompress(EntWs &e, BYTE *dst, const BYTE *src, U32 srcSize, bool sing
             return 0;
         op += hSize;
     }
+    // (a result of srcSize - 1 bytes or more is dropped below: a stream that gets there is cut short)
+    const BYTE *const limit = dst + (srcSize > 1 ? srcSize - 1 : 0);
     if (singleStream) {
-        const U32 c = hufCompress1X(e, op, src, srcSize);
+        const U32 c = hufCompress1X(e, op, src, srcSize, limit);
         if (!c)
             return 0;
         op += c;
@@ -775,7 +781,7 @@ ZFN U32 hufCompress(EntWs &e, BYTE *dst, const BYTE *src, U32 srcSize, bool sing
             return 0;
         op += 6;
         for (int sidx = 0; sidx < 3; ++sidx) {
-            const U32 c = hufCompress1X(e, op, ip, segmentSize);
+            const U32 c = hufCompress1X(e, op, ip, segmentSize, limit);
             if (!c)
                 return 0;
             jump[2 * sidx] = (BYTE)c;
@@ -783,7 +789,7 @@ ZFN U32 hufCompress(EntWs &e, BYTE *dst, const BYTE *src, U32 srcSize, bool sing
             op += c;
             ip += segmentSize;
         }
-        const U32 c = hufCompress1X(e, op, ip, (U32)(src + srcSize - ip));
+        const U32 c = hufCompress1X(e, op, ip, (U32)(src + srcSize - ip), limit);
         if (!c)
             return 0;
         op += c;

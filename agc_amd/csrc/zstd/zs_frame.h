@@ -50,7 +50,9 @@ ZHD WsLayout wsLayout(const CParams &cp, U32 srcSize)
 }
 
 // upper bound of a frame: header (<= 9) + block header (3) + raw block
-ZHD U32 frameBound(U32 srcSize) { return srcSize + 16; }
+// room a frame's buffer must have: the frame itself never exceeds srcSize + 12 (a raw block), but a Huffman attempt that turns out
+// longer than the literals is only cut short at the literals' size (zs_entropy.h: hufCompress1X) behind up to 17 bytes of headers
+ZHD U32 frameBound(U32 srcSize) { return srcSize + 48; }
 
 // frame header: magic, descriptor, [window], content size (contentSizeFlag = 1, no checksum, no dictID); returns the end
 ZFN BYTE *writeFrameHeader(BYTE *op, const CParams &cp, U32 srcSize)

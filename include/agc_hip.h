@@ -281,6 +281,13 @@ int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, con
  * xGMI: agc_amd/dist.py): no host round trip of the inputs.  The caller makes sure whatever wrote d_src has finished. */
 int agc_hip_zstd17_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_src, const uint64_t *h_src_off,
                              uint8_t *h_dst, uint64_t dst_cap, uint64_t *h_dst_off);
+/* The same encoder for the other two levels the archive uses: 13 -- CSegment::add_to_archive_tuples (src/common/segment.h:172-197:
+ * references packed 2-4 symbols per byte) -- and 19 -- store_in_archive(ref) of repetitive references (segment.h:218-255).
+ * h_level[i] = 13, 17 or 19 per input (NULL: all 17); input sizes as for level 17 (one block).  Frames equal
+ * ZSTD_compressCCtx(.., level) of libzstd 1.4.9 byte for byte.  Level 13 inputs above 16 KiB (btopt, minMatch 4) take the one-lane
+ * kernel, everything else the lane-group kernel. */
+int agc_hip_zstd_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, const uint8_t *h_level,
+                       uint8_t *h_dst, uint64_t dst_cap, uint64_t *h_dst_off);
 /* on != 0: the launches of agc_hip_zstd17_batch keep their tables out of the LDS, so that kernels of the context's other
  * streams that need most of a CU's LDS (the packed splitter scan: 128 KiB per block) can start beside a launch that runs for
  * a second.  For a caller that compresses packs in the background while it goes on adding samples; off (the default) is
@@ -294,6 +301,7 @@ uint32_t agc_hip_zstd17_resident_frames(agc_hip_ctx *ctx);
 /* The compression parameters libzstd 1.4.9 derives for level 17 and a known source size (ZSTD_getCParams(17, n, 0)):
  * windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy.  Exposed so that tests can pin them. */
 int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7]);
+int agc_hip_zstd_cparams(int level /* 13, 17, 19 */, uint64_t src_size, uint32_t out7[7]);
 
 #ifdef __cplusplus
 }

@@ -26,8 +26,22 @@ int agc_hip_zstd17_cparams(uint64_t src_size, uint32_t out7[7])
     return AGC_HIP_OK;
 }
 
+int agc_hip_zstd_cparams(int level, uint64_t src_size, uint32_t out7[7])
+{
+    if (!out7 || (level != 13 && level != 17 && level != 19))
+        return AGC_HIP_EINVAL;
+    zs::levelParams(level, src_size, out7);
+    return AGC_HIP_OK;
+}
+
 int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, uint8_t *h_dst, uint64_t dst_cap,
                          uint64_t *h_dst_off)
+{
+    return agc_hip_zstd_batch(ctx, n, h_src, h_src_off, nullptr, h_dst, dst_cap, h_dst_off);
+}
+
+int agc_hip_zstd_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, const uint64_t *h_src_off, const uint8_t *h_level, uint8_t *h_dst,
+                       uint64_t dst_cap, uint64_t *h_dst_off)
 {
     if (!ctx || !h_dst_off || (n && !h_src_off))
         return AGC_HIP_EINVAL;
@@ -37,8 +51,11 @@ int agc_hip_zstd17_batch(agc_hip_ctx *ctx, uint32_t n, const uint8_t *h_src, con
         const uint64_t len = h_src_off[i + 1] - h_src_off[i];
         if (len > zs::BLOCKSIZE_MAX)
             return AGC_HIP_EINVAL;
+        const int level = h_level ? h_level[i] : 17;
+        if (level != 13 && level != 17 && level != 19)
+            return AGC_HIP_EINVAL;
         uint32_t p[7];
-        zs::level17Params(len, p);
+        zs::levelParams(level, len, p);
         const zs::CParams cp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6]};
         std::vector<uint8_t> ws(zs::wsLayout(cp, (uint32_t)len).total, 0);
         frames[i].resize(zs::frameBound((uint32_t)len));

@@ -79,3 +79,16 @@ def test_gpu_many_equal_size_packs(hip_ctx, oracle):
         if p not in want:
             want[p] = ZC.ref_frame(p)
         assert got[i] == want[p], i
+
+
+@pytest.mark.gpu
+def test_gpu_frames_of_levels_13_and_19_equal_libzstd(hip_ctx):
+    """agc_hip_zstd_batch: tuple-packed references at level 13 (lane-group kernel up to 16 KiB, one-lane kernel above: btopt,
+    minMatch 4), repetitive references at level 19 (btultra2 at every size), delta packs at level 17 -- mixed in one call"""
+    from tests.test_zstd_frames import reference_like_inputs
+    rng = np.random.default_rng(1319)
+    items = reference_like_inputs(rng)
+    items += [(17, bytes(rng.integers(65, 69, 9000, dtype=np.uint8))), (13, b""), (19, b"A" * 3), (13, b"ACGT" * 2000)]
+    got = hip_ctx.zstd_batch([d for _, d in items], [lv for lv, _ in items])
+    bad = [(lv, len(d)) for (lv, d), g in zip(items, got) if g != ZC.ref_frame(d, lv)]
+    assert not bad, bad

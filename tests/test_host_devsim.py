@@ -93,6 +93,22 @@ def test_host_pipeline_with_every_pack_on_the_device_entropy_stage(cli, name, tm
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("name", ["toy_c1", "syn_mixed", "syn_viral", "syn_adaptive", "syn_c4_twin"])
+def test_host_pipeline_with_the_references_on_the_device_entropy_stage_too(cli, name, tmp_path, monkeypatch):
+    """AGC_AMD_GPU_ZSTD_REFS=1 (with AGC_AMD_GPU_ZSTD_MIN=1 and the whole share): every reference goes through agc_hip_zstd_batch as
+    well -- tuple-packed at level 13, the repetitive ones as they are at level 19 (segment.h:172-255) -- instead of libzstd"""
+    monkeypatch.setenv("AGC_AMD_GPU_ZSTD_REFS", "1")
+    monkeypatch.setenv("AGC_AMD_GPU_ZSTD_MIN", "1")
+    monkeypatch.setenv("AGC_AMD_GPU_ZSTD_SHARE", "1.0")
+    monkeypatch.setenv("AGC_AMD_VERIFY_DEV_FRAMES", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "o.agc")
+    r = subprocess.run([cli, "create"] + args + ["-t", "4", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    assert "references 13 / 19" in r.stderr and " 0 differ" in r.stderr and "differ from libzstd" not in r.stderr, r.stderr[-2000:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
+
+
 def test_host_zstd_switch_gives_the_same_archive(cli, tmp_path, monkeypatch):
     monkeypatch.setenv("AGC_AMD_HOST_ZSTD", "1")
     args, _ = C.CONFIGS["syn_c3_twin"]

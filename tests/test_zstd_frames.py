@@ -130,6 +130,65 @@ def test_level17_parameters_equal_getcparams():
     assert L.agc_hip_zstd17_max_input() == 131072
 
 
+def test_level_parameters_equal_getcparams():
+    """the rows of levels 13 (tuple-packed references) and 19 (repetitive references) as well: segment.h:172-255"""
+    from agc_amd import capi
+    L = capi.load()
+    out = (C.c_uint32 * 7)()
+    sizes = list(range(1, 600)) + list(range(600, 140000, 389)) + [16383, 16384, 16385, 131071, 131072, 131073, 262144, 262145, 1 << 20, 1 << 24]
+    for level in (13, 17, 19):
+        for n in sizes:
+            assert L.agc_hip_zstd_cparams(level, n, out) == 0
+            assert list(out) == ZC.ref_cparams(n, level), (level, n)
+    assert L.agc_hip_zstd_cparams(12, 1000, out) != 0
+
+
+def _my_frame_level(H, data, level, mode):
+    n = len(data)
+    cp = np.array(ZC.ref_cparams(n, level), np.uint32)
+    out = np.zeros(n + 64, np.uint8)
+    if mode >= 10:
+        k = H.zs_host_compress_grp(bytes(data), n, cp.ctypes.data, out.ctypes.data, mode - 10)
+    else:
+        k = H.zs_host_compress2(bytes(data), n, cp.ctypes.data, out.ctypes.data, mode)
+    return out[:k].tobytes()
+
+
+def reference_like_inputs(rng):
+    """what CSegment::add_to_archive_tuples / store_in_archive(ref) compress: ACGT segments packed 4 symbols per byte (level 13),
+    segments with N (3 per byte), and repetitive segments as raw symbols (level 19)"""
+    from agc_amd import synth
+    out = []
+    for n_sym in (9000, 40000, 61000, 65000, 66000, 120000, 400000):
+        c = np.asarray(synth.random_seq(rng, n_sym), dtype=np.uint8)
+        c4 = c[:len(c) // 4 * 4].reshape(-1, 4)
+        out.append((13, (c4[:, 0] * 64 + c4[:, 1] * 16 + c4[:, 2] * 4 + c4[:, 3]).astype(np.uint8).tobytes()))
+        c[rng.integers(0, n_sym, 5)] = 4
+        c3 = c[:len(c) // 3 * 3].reshape(-1, 3)
+        out.append((13, (c3[:, 0] * 36 + c3[:, 1] * 6 + c3[:, 2]).astype(np.uint8).tobytes()))
+    for n_sym in (5000, 16384, 16385, 60000, 131072):
+        unit = np.asarray(synth.random_seq(rng, 41), dtype=np.uint8)
+        s = np.tile(unit, n_sym // 41 + 1)[:n_sym].copy()
+        idx = rng.integers(0, n_sym, n_sym // 300)
+        s[idx] = rng.integers(0, 4, len(idx))
+        out.append((19, s.tobytes()))
+    return [(lv, d) for lv, d in out if len(d) <= 131072]
+
+
+def test_frames_of_levels_13_and_19_equal_libzstd(zs):
+    """the same headers at the other two levels of the archive: level 13 is btultra (minMatch 3) up to 16 KiB and btopt (minMatch 4,
+    bit-weight prices) above, level 19 btultra2 (two passes) at every size -- loop nest, micro-step loop with the device's table
+    split, and the lane-group parser where it is eligible"""
+    rng = np.random.default_rng(1319)
+    bad = []
+    for level, data in reference_like_inputs(rng):
+        want = ZC.ref_frame(data, level)
+        for mode in (0, 2, 13):
+            if _my_frame_level(zs, data, level, mode) != want:
+                bad.append((level, len(data), mode))
+    assert not bad, bad
+
+
 def test_code_functions_equal_the_format_tables(zs):
     """LL_bits / ML_bits / LL_Code / ML_Code of zstd_internal.h (RFC 8878 3.1.1.3.2.1.1) against the arithmetic the kernels use"""
     LL_bits = [0] * 16 + [1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
