@@ -634,7 +634,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
                                          const uint64_t *ctg_off)
 {
     Impl &I = *p;
-    if (!I.created || I.concatenated || I.prepared || I.committing)
+    if (!I.created || I.concatenated || I.prepared || I.committing || I.prep.deferred)
         return false;
     I.prepared_ctgs.clear();
     for (size_t c = 0; c < contig_names.size(); ++c) {
@@ -648,9 +648,23 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
     I.changed_log.clear();
     I.minted_since_prepare = false;
     I.prepared.reset(new Impl::BatchState());
-    if (!I.batch_prepare(*I.prepared, I.prepared_ctgs, d_codes, nullptr, I.dist_world > 1 && !I.adaptive && !I.appending)) {
+    // one archive from N ranks: the sample may be ahead of its turn.  Everything that can be encoded already is; in adaptive mode
+    // the scan must not extend the splitter set (the samples in front come first): a sample that would have to is prepared again
+    // at its turn (CommitPreparedHead), and so is one whose splitter set grew meanwhile
+    const bool ahead = I.dist_world > 1 && !I.appending;
+    I.prep.d_codes = d_codes;
+    I.prep.packed = I.packed_sample;
+    I.prep.base_owned = I.next_base_owned;
+    I.prep.deferred = false;
+    I.prep.spl_version = I.spl_version;
+    I.prepared->no_new_splitters = ahead && I.adaptive;
+    if (!I.batch_prepare(*I.prepared, I.prepared_ctgs, d_codes, nullptr, ahead)) {
         I.prepared.reset();
         return false;
+    }
+    if (I.prepared->needs_turn) {
+        I.prepared.reset();
+        I.prep.deferred = true;
     }
     return true;
 }
@@ -663,7 +677,28 @@ bool CAGCCompressor::CommitPrepared() { return CommitPreparedHead() && CommitPre
 bool CAGCCompressor::CommitPreparedHead()
 {
     Impl &I = *p;
-    if (!I.prepared || I.committing)
+    if (I.committing)
+        return false;
+    if (I.dist_world > 1 && I.adaptive && (I.prep.deferred || (I.prepared && I.prep.spl_version != I.spl_version))) {
+        // adaptive mode, the sample's turn: the speculative prepare did not stand (new splitters needed, or brought by the samples
+        // in front) -- the plain prepare, against the state as it is now
+        ++I.st.reprepared;
+        I.prepared.reset(new Impl::BatchState());
+        I.changed_log.clear();
+        I.minted_since_prepare = false;
+        I.prep.deferred = false;
+        I.packed_sample = I.prep.packed;
+        I.next_base_owned = I.prep.base_owned;
+        I.scan_from_prefetch = false;
+        const bool ok = I.batch_prepare(*I.prepared, I.prepared_ctgs, I.prep.d_codes, nullptr, false);
+        I.packed_sample.n_symbols = 0;
+        I.next_base_owned = false;
+        if (!ok) {
+            I.prepared.reset();
+            return false;
+        }
+    }
+    if (!I.prepared)
         return false;
     std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
     I.dist_record.clear();

@@ -636,6 +636,8 @@ bool CAGCCompressor::Impl::batch_prepare(BatchState &b, std::vector<Contig> &ctg
     b.lap_t = b.t0;
     if (!stage_scan(b))
         return false;
+    if (b.needs_turn)
+        return true;
     b.n_samples = ctgs.empty() ? 1u : ctgs.back().sample_idx + 1;
     b.overlap_encode = overlap_mode != 0 && b.n_samples == 1 && !always_speculate;
     b.subset.resize(seg_buf.size());
@@ -934,7 +936,15 @@ bool CAGCCompressor::Impl::stage_scan(BatchState &b)
             size_t n_new = 0;
             for (auto &f : found)
                 n_new += f.size();
+            if (n_new && b.no_new_splitters) {
+                // prepared ahead of its turn: the set is not this sample's to extend yet -- the sample is prepared again at its turn
+                b.needs_turn = true;
+                for (uint32_t i = 0; i < n_ctg; ++i)
+                    st.bases -= ctgs[i].len;
+                return true;
+            }
             if (n_new) {
+                ++spl_version;
                 std::vector<uint64_t> add;
                 for (auto &f : found)
                     add.insert(add.end(), f.begin(), f.end());

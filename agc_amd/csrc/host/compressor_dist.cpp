@@ -236,6 +236,7 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     if (body_recv && body == body_recv->data() && body_n <= body_recv->size())
         adopted = std::move(body_recv);
     if (!add.empty()) { // adaptive mode: the owner's new splitters (agc_compressor.cpp:1191-1209)
+        ++spl_version; // (a sample prepared here before this point was scanned with the smaller set: CommitPreparedHead prepares it again)
         splitters.insert(splitters.end(), add.begin(), add.end());
         std::sort(splitters.begin(), splitters.end());
         splitters.erase(std::unique(splitters.begin(), splitters.end()), splitters.end());

@@ -837,6 +837,9 @@ struct CAGCCompressor::Impl {
         std::vector<uint32_t> subset;              // segments stage_classify works on
         uint32_t n_samples = 1, s_from = 0;        // registrations of the window; first one not committed yet
         bool base_owned = false;                   // d_base is a staging buffer of the device context (see Impl::next_base_owned)
+        // adaptive mode, a sample prepared ahead of its turn (multi-GPU mode): the scan must not extend the splitter set; when it
+        // would have to, it only says so (needs_turn) and the sample is prepared again at its turn
+        bool no_new_splitters = false, needs_turn = false;
         struct Spec {                              // speculative delta of a placed item (by Placed::key)
             uint64_t off = 0, enc_off = 0;
             uint32_t gid = 0, len = 0, enc_len = 0;
@@ -881,6 +884,16 @@ struct CAGCCompressor::Impl {
     // terminator lists changed since (through other ranks' records)
     std::unique_ptr<BatchState> prepared;
     std::unique_ptr<BatchState> committing; // between CommitPreparedHead and CommitPreparedFinish
+    // multi-GPU + adaptive mode: what PrepareSampleDevice was given, to prepare the sample AGAIN at its turn when the speculative
+    // prepare could not stand (the sample needs new splitters, or other samples brought some since: spl_version)
+    struct PrepArgs {
+        const uint8_t *d_codes = nullptr;
+        agc_hip_packed packed{};
+        bool base_owned = false;
+        bool deferred = false;      // no prepared state: prepare at the turn
+        uint64_t spl_version = 0;   // splitter set the prepared state was scanned with
+    } prep;
+    uint64_t spl_version = 0;       // bumped whenever splitters are added (own samples, applied records)
     std::vector<Contig> prepared_ctgs;
     std::vector<uint64_t> changed_log;
     // the next sample, announced by SetNextSamplePackedDevice (pf_next) / already queued on the device (pf_live: its staging copy)

@@ -71,7 +71,9 @@ class DistCompressor:
         this rank owns only; whatever backs d_codes_ptr must stay alive and unchanged until that sample is committed.
         prefetch: a rank classifies and speculatively encodes its NEXT sample (PrepareSampleDevice) before it joins the broadcasts of
         the samples in front of it, so the GPUs work in parallel and only the short commit (revalidation of the decisions that read
-        state changed meanwhile + registration + record) is serial.  Not in adaptive mode: new splitters change later scans."""
+        state changed meanwhile + registration + record) is serial.  Adaptive mode (new splitters change later scans): the prepare
+        ahead of the turn does not extend the splitter set; a sample that would have to, or whose set grew while it waited, is
+        prepared again at its turn (CommitPreparedHead) -- collections whose samples rarely bring new splitters keep the overlap."""
         nxt = start + (self.rank - start) % self.world
         nxt = nxt if nxt < n_total else None
         prepared = None

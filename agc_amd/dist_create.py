@@ -57,7 +57,7 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
         return fasta.sample_name(files[i]), names, keep[i].data_ptr(), off
 
-    dc.compress(len(files), get_sample, prefetch=not a.a)
+    dc.compress(len(files), get_sample, prefetch=True)  # (-a too: a sample that needs new splitters is prepared again at its turn)
     dc.close(n_threads=threads if rank == 0 else 2)  # the delta packs are entropy-coded on every rank's GPU
     cmp_.close_handle()
     dist.barrier()

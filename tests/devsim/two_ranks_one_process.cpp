@@ -63,7 +63,7 @@ int main(int argc, char **argv)
     std::vector<long> prepared(W, -1);
     for (size_t i = 0; i < n; ++i) {
         const uint32_t o = (uint32_t)(i % W);
-        for (uint32_t r = 0; r < W && !adaptive; ++r) { // every rank prepares its next sample before it joins the commits in front of it
+        for (uint32_t r = 0; r < W; ++r) { // every rank prepares its next sample before it joins the commits in front of it (adaptive mode too)
             size_t nxt = i + (r + W - o) % W;
             if (prepared[r] < 0 && nxt < n) {
                 if (!prepare(r, nxt))

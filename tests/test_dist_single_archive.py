@@ -81,7 +81,7 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
             return sn, names, codes.ctypes.data, off
 
         if prefetch:
-            dc.compress(len(files), get_sample, prefetch="-a" not in args)
+            dc.compress(len(files), get_sample, prefetch=True)  # (also in adaptive mode: a prepare that needs new splitters waits for its turn)
         for i, f in enumerate(files if not prefetch else []):
             if dc.owner_of(i) == rank:
                 names, codes, off = fasta_codes(f)
@@ -102,10 +102,10 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
             dc.close(zstd_raw=_sim_zstd_batch())  # the stand-in's agc_hip_zstd17_batch (same encoder headers as the kernel)
         st = cmp_.stats()
         cmp_.close_handle()
-        q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"], st["revalidated"]))
+        q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"], st["revalidated"], st["reprepared"], sum(1 for i in range(len(files)) if i % world == rank)))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
-        q.put((rank, "error: %r" % (e,), 0, 0, 0))
+        q.put((rank, "error: %r" % (e,), 0, 0, 0, 0, 0))
 
 
 def _run(name, world, tmp_path, on_gpu, prefetch=False):
@@ -143,7 +143,7 @@ def test_one_archive_from_n_ranks_equals_the_reference(name, world, tmp_path):
 
 
 @pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_snp", 3), ("syn_mixed", 2), ("syn_mixed", 3), ("syn_shuffled", 3), ("syn_viral", 2),
-                                        ("syn_adaptive", 2), ("syn_c3_twin", 3), ("syn_c5_twin", 2)])
+                                        ("syn_adaptive", 2), ("syn_adaptive", 3), ("syn_c3_twin", 3), ("syn_c5_twin", 2), ("syn_c5_twin", 3)])
 def test_prefetching_ranks_still_write_the_reference_archive(name, world, tmp_path):
     """every rank classifies and speculatively encodes its next sample BEFORE the samples in front of it are committed; at its
     turn only the decisions that read changed state are revalidated -- the archive must not notice"""
@@ -152,6 +152,13 @@ def test_prefetching_ranks_still_write_the_reference_archive(name, world, tmp_pa
     res = _run(name, world, tmp_path, on_gpu=False, prefetch=True)
     if name == "syn_snp":  # groups are minted by every sample here: some prepared decisions must have been taken again
         assert sum(r[4] for r in res) > 0
+    if name in ("syn_adaptive", "syn_c5_twin"):
+        # adaptive mode: a prepare ahead of the turn must not extend the splitter set -- the samples that bring new splitters (or wait
+        # while others do) were prepared again at their turn, the others kept their speculative prepare
+        again, own = sum(r[5] for r in res), sum(r[6] for r in res)
+        assert 0 < again < own, (again, own)
+    else:
+        assert sum(r[5] for r in res) == 0
 
 
 @pytest.mark.gpu
