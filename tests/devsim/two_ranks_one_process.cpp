@@ -50,8 +50,8 @@ int main(int argc, char **argv)
     for (int i = 7; i < argc; ++i)
         if (!load(argv[i], smp[i - 7]))
             return 3;
-    const uint32_t W = 2;
-    CAGCCompressor cmp[W];
+    const uint32_t W = getenv("TWO_RANKS_W") ? (uint32_t)std::max(2, atoi(getenv("TWO_RANKS_W"))) : 2u; // (more ranks than two on request)
+    std::vector<CAGCCompressor> cmp(W);
     for (uint32_t r = 0; r < W; ++r) {
         if (!cmp[r].SetDistributed(r, W, 0))
             return 4;
