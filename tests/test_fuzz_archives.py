@@ -61,6 +61,22 @@ def test_fuzz_host_pipeline(seed, tmp_path):
     _check(simbuild.build(), seed, tmp_path)
 
 
+@pytest.mark.parametrize("ranks,first", [(2, 100), (3, 300)])
+def test_fuzz_n_ranks_in_one_process(ranks, first):
+    """the multi-GPU single-archive protocol (tests/devsim/two_ranks_one_process.cpp: W compressors in one process, prefetching
+    schedule, two-step commit, the writer's bookkeeping queue, adaptive mode included) on random collections against the live
+    reference CLI -- scripts/fuzz_two_ranks.py runs the long campaigns"""
+    if not os.path.exists(REF_AGC):
+        pytest.skip("oracle/_ref/agc not prebuilt")
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_two_ranks.py"), "--from", str(first), "--count", "30", "--ranks", str(ranks)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+    compared = int(r.stdout.rsplit("compared: ", 1)[1].split(",")[0])
+    assert compared >= 15, r.stdout[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", GPU_SEEDS)
 def test_fuzz_gpu(seed, tmp_path):
