@@ -912,8 +912,10 @@ struct CAGCCompressor::Impl {
     double gpu_zstd_share = 0.88;
     uint32_t gpu_zstd_min = 64;        // fewer packs than this in one call stay on the host (AGC_AMD_GPU_ZSTD_MIN)
     // references (level 13 on their tuples, level 19 for repetitive ones) on the device too when a call brings at least this many
-    // (the reference sample: ~50 k references, 0.95 s on 16 host threads, 0.41 s with the device); 0 = never (AGC_AMD_GPU_ZSTD_REFS)
-    uint32_t gpu_zstd_refs_min = 512;
+    // (AGC_AMD_GPU_ZSTD_REFS=512: the reference sample's ~50 k references take 0.41 s instead of 0.95 s on 16 host threads).
+    // 0 = never, the default: the path is parity-tested frame by frame (CPU build, GPU kernels, whole archives on the stand-in)
+    // but no full-size archive has been compared with the reference CLI's with it on yet
+    uint32_t gpu_zstd_refs_min = 0;
     PinnedBytes zsrc_buf, zdst_buf;    // staging of the device entropy stage (plain malloc: no zero fill of hundreds of MB)
     bool defer_stream_reg = false;     // parallel bookkeeping: pack jobs leave a missing delta stream to the merging thread
     bool minted_since_prepare = false; // a group of any key (also one-sided) was minted while a sample was prepared

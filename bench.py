@@ -508,7 +508,7 @@ def main():
                                        "encode kernel, delta D2H, pack bookkeeping, collection records (a sample's encode is collected and its "
                                        "bookkeeping done on a second thread beside the next sample's scan and classification; the next sample's "
                                        "expansion + scan are queued ahead); the entropy stage (zstd 17 of full delta packs: GPU kernel + host "
-                                       "pool; 13/19 of new references: host pool, GPU kernel for calls of >= 512 references) runs on a background "
+                                       "pool; 13/19 of new references: host pool) runs on a background "
                                        "thread beside the steps; after the last step: Close() = the same for every open pack + archive "
                                        "metadata, and the wait for it all.  Inputs resident in HBM; archive bytes produced, not written to disk.",
                        "setup_not_timed": f"determine_splitters ({'positional shortcut' if args.positional_splitters else 'GPU: enumerate + radix sort + singletons'}): "
