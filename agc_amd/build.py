@@ -5,6 +5,22 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+
+
+class _Locked:
+    """one build at a time per checkout (test workers of one run may all find the libraries stale at once)"""
+
+    def __enter__(self):
+        import fcntl
+        import hashlib
+        import tempfile
+        self.f = open(os.path.join(tempfile.gettempdir(), "agc_amd_build_%s.lock" % hashlib.sha1(HERE.encode()).hexdigest()[:12]), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
 LIB = os.path.join(HERE, "libagc_hip.so")
 SOURCES = ["api.hip", "scan_kernels.hip", "lz_kernels.hip", "splitters.hip", "zstd_kernels.hip", "dev_common.h",
            "zstd/zs_common.h", "zstd/zs_opt.h", "zstd/zs_opt_sm.h", "zstd/zs_opt_grp.h", "zstd/zs_entropy.h", "zstd/zs_frame.h", "zstd/zs_params.h"]
@@ -20,15 +36,17 @@ def _stale():
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 ... -> agc_amd/libagc_hip.so (cross-compiles without a GPU)."""
-    if not force and not _stale():
+    with _Locked():
+        if not force and not _stale():
+            return LIB
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
+               os.path.join(CSRC, "api.hip"), "-o", LIB + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(LIB + ".tmp", LIB)  # (never a half-written library under the final name)
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           os.path.join(CSRC, "api.hip"), "-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
 
 
 HOST = os.path.join(CSRC, "host")
@@ -44,13 +62,14 @@ def build_read(force=False, verbose=False):
     """g++ for the read side (include/agc_read.h): libagc_read.so -- host only, no HIP dependency."""
     srcs = [os.path.join(HOST, s) for s in ("reader.cpp", "capi_read.cpp")]
     deps = srcs + [os.path.join(HOST, "reader.h"), os.path.join(HOST, "archive_read.h"), os.path.join(HERE, "..", "include", "agc_read.h")]
-    if not force and os.path.exists(READ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(READ_LIB) for d in deps):
+    with _Locked():
+        if not force and os.path.exists(READ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(READ_LIB) for d in deps):
+            return READ_LIB
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB, "-ldl", "-pthread"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
         return READ_LIB
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB, "-ldl", "-pthread"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    return READ_LIB
 
 
 def build_host(force=False, verbose=False):
@@ -59,22 +78,23 @@ def build_host(force=False, verbose=False):
     build()
     build_read(force, verbose)
     deps = [os.path.join(HOST, s) for s in HOST_SOURCES] + [LIB]
-    stale = force or not os.path.exists(HOST_LIB) or not os.path.exists(HOST_BIN) or \
-        any(os.path.getmtime(d) > min(os.path.getmtime(HOST_LIB), os.path.getmtime(HOST_BIN)) for d in deps)
-    if not stale:
+    with _Locked():
+        stale = force or not os.path.exists(HOST_LIB) or not os.path.exists(HOST_BIN) or \
+            any(os.path.getmtime(d) > min(os.path.getmtime(HOST_LIB), os.path.getmtime(HOST_BIN)) for d in deps)
+        if not stale:
+            return HOST_LIB
+        os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
+        cxx = os.environ.get("CXX", "g++")
+        common = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
+        cmd1 = common + ["-shared"] + [os.path.join(HOST, s) for s in HOST_LIB_SOURCES] + ["-o", HOST_LIB,
+                         "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"]
+        cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
+                         "-Wl,-rpath,$ORIGIN/..", "-lz", "-ldl"]
+        for cmd in (cmd1, cmd2):
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
         return HOST_LIB
-    os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
-    cxx = os.environ.get("CXX", "g++")
-    common = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
-    cmd1 = common + ["-shared"] + [os.path.join(HOST, s) for s in HOST_LIB_SOURCES] + ["-o", HOST_LIB,
-                     "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"]
-    cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
-                     "-Wl,-rpath,$ORIGIN/..", "-lz", "-ldl"]
-    for cmd in (cmd1, cmd2):
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-    return HOST_LIB
 
 
 if __name__ == "__main__":

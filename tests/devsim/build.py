@@ -17,7 +17,27 @@ def _newer(target, deps):
     return os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps)
 
 
+class _Locked:
+    """one build at a time (pytest-xdist workers may all find the stand-in stale at once)"""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(OUT, exist_ok=True)
+        self.f = open(os.path.join(OUT, ".lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
 def build(force=False):
+    with _Locked():
+        return _build(force)
+
+
+def _build(force=False):
     os.makedirs(OUT, exist_ok=True)
     sim_src = [os.path.join(HERE, "agc_hip_sim.c"), os.path.join(ROOT, "oracle", "agc_oracle.c")]
     hdr = os.path.join(ROOT, "include", "agc_hip.h")
@@ -50,9 +70,10 @@ def build_two_ranks(force=False):
     """tests/devsim/two_ranks_one_process.cpp (two ranks of the multi-GPU mode in one process) against the stand-in libraries"""
     build(force)
     src = os.path.join(HERE, "two_ranks_one_process.cpp")
-    if force or not _newer(SIM_TWO, [src, SIM_HOST]):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", SIM_TWO, "-L" + OUT, "-lagc_host", "-lagc_hip",
-                               "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"])
+    with _Locked():
+        if force or not _newer(SIM_TWO, [src, SIM_HOST]):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", SIM_TWO, "-L" + OUT, "-lagc_host", "-lagc_hip",
+                                   "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"])
     return SIM_TWO
 
 

@@ -11,7 +11,14 @@ LIB = os.path.join(OUT, "libzs_host.so")
 
 
 def build(force=False):
+    import fcntl
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, ".lock"), "w") as lock:  # (one build at a time: pytest-xdist workers)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force=False):
     src = os.path.join(HERE, "zs_host.cpp")
     deps = [src] + [os.path.join(ROOT, "agc_amd", "csrc", "zstd", h) for h in ("zs_common.h", "zs_opt.h", "zs_opt_sm.h", "zs_opt_grp.h", "zs_entropy.h", "zs_frame.h")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
