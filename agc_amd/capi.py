@@ -34,7 +34,9 @@ SYMBOLS = [
     "agc_hip_ref_lag_counts_dev",
     "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_batch_dev", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams", "agc_hip_zstd_batch", "agc_hip_zstd_cparams",
     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
-    "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched",
+    "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched", "agc_hip_sample_pack",
+    "agc_hip_ref_register_batch_packed", "agc_hip_lz_encode_batch_packed", "agc_hip_lz_encode_begin_packed", "agc_hip_lz_estimate_batch_packed",
+    "agc_hip_lz_cost_vector_batch_packed", "agc_hip_lz_split_point_batch_packed", "agc_hip_fetch_slices_packed", "agc_hip_ref_lag_counts_packed",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -127,7 +129,17 @@ def load():
     L.agc_hip_pack_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
     L.agc_hip_expand_dev.argtypes = [vp, C.POINTER(Packed), vp]
     L.agc_hip_scan_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
-    L.agc_hip_prefetch_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.agc_hip_prefetch_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32]
+    pkp = C.POINTER(Packed)
+    L.agc_hip_sample_pack.argtypes = [vp, vp, C.c_uint64, pkp]
+    L.agc_hip_ref_register_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, C.c_uint32]
+    L.agc_hip_lz_encode_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
+    L.agc_hip_lz_encode_begin_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p]
+    L.agc_hip_lz_estimate_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u32p, u32p]
+    L.agc_hip_lz_cost_vector_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u8p, u32p]
+    L.agc_hip_lz_split_point_batch_packed.argtypes = [vp, C.c_uint32, u32p, u32p, pkp, u64p, u32p, u8p, u8p, u8p, u8p, u32p, u32p]
+    L.agc_hip_fetch_slices_packed.argtypes = [vp, C.c_uint32, pkp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
+    L.agc_hip_ref_lag_counts_packed.argtypes = [vp, C.c_uint32, pkp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_scan_prefetched.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     for s in SYMBOLS:
         f = getattr(L, s)
@@ -282,11 +294,15 @@ class Context:
         return self._scan(fn, pk, ctg_off, k, cap)
 
     def prefetch_packed_dev(self, pk, ctg_off, k):
-        """queues expansion + scan of the NEXT sample; returns the device pointer of its byte staging copy"""
+        """queues the scan of the NEXT sample on the prefetch stream"""
         off = _a(ctg_off, np.uint64)
-        d = vp()
-        self._chk(self.L.agc_hip_prefetch_packed_dev(self.h, C.byref(pk), _p(off, u64p), off.size - 1, k, C.byref(d)))
-        return d.value
+        self._chk(self.L.agc_hip_prefetch_packed_dev(self.h, C.byref(pk), _p(off, u64p), off.size - 1, k))
+
+    def sample_pack(self, d_codes_ptr, n_symbols):
+        """codes in HBM -> the context's own packed buffers (valid until the next call)"""
+        pk = Packed()
+        self._chk(self.L.agc_hip_sample_pack(self.h, d_codes_ptr, n_symbols, C.byref(pk)))
+        return pk
 
     def scan_prefetched(self, pk, ctg_off, k, cap=1 << 16):
         fn = lambda h, arg, *rest: self.L.agc_hip_scan_prefetched(h, C.byref(arg), *rest)
@@ -305,6 +321,11 @@ class Context:
         g, o, l = _a(gids, np.uint32), _a(off, np.uint64), _a(length, np.uint32)
         r = _a(rc, np.uint8) if rc is not None else None
         self._chk(self.L.agc_hip_ref_register_batch_dev(self.h, g.size, _p(g, u32p), d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p), min_match_len))
+
+    def ref_register_batch_packed(self, gids, pk, off, length, rc, min_match_len):
+        g, o, l = _a(gids, np.uint32), _a(off, np.uint64), _a(length, np.uint32)
+        r = _a(rc, np.uint8) if rc is not None else None
+        self._chk(self.L.agc_hip_ref_register_batch_packed(self.h, g.size, _p(g, u32p), C.byref(pk), _p(o, u64p), _p(l, u32p), _p(r, u8p), min_match_len))
 
     def ref_get(self, gid):
         n = C.c_uint32()
@@ -351,6 +372,30 @@ class Context:
         g, o, l, r = self._batch(gids, off, length, rc)
         self._enc_pending = (g, o, l, r)  # (the arrays stay alive until the end call)
         self._chk(self.L.agc_hip_lz_encode_begin_dev(self.h, g.size, _p(g, u32p), d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p)))
+
+    # the same entry points on sequences of a packed sample (pk: Packed)
+    def lz_encode_batch_packed(self, pk, gids, off, length, rc=None, enc_cap=None):
+        return self._encode(self.L.agc_hip_lz_encode_batch_packed, C.byref(pk), gids, off, length, rc, enc_cap)
+
+    def lz_encode_begin_packed(self, pk, gids, off, length, rc=None):
+        g, o, l, r = self._batch(gids, off, length, rc)
+        self._enc_pending = (g, o, l, r)
+        self._chk(self.L.agc_hip_lz_encode_begin_packed(self.h, g.size, _p(g, u32p), C.byref(pk), _p(o, u64p), _p(l, u32p), _p(r, u8p)))
+
+    def lz_estimate_batch_packed(self, pk, gids, off, length, rc=None):
+        return self._estimate(self.L.agc_hip_lz_estimate_batch_packed, C.byref(pk), gids, off, length, rc)
+
+    def lz_cost_vector_batch_packed(self, pk, gids, off, length, rc, prefix):
+        return self._costvec(self.L.agc_hip_lz_cost_vector_batch_packed, C.byref(pk), gids, off, length, rc, prefix)
+
+    def lz_split_point_batch_packed(self, pk, gid1, gid2, off, length, rc1, prefix1, rc2, prefix2):
+        return self._split(self.L.agc_hip_lz_split_point_batch_packed, C.byref(pk), gid1, gid2, off, length, rc1, prefix1, rc2, prefix2)
+
+    def fetch_slices_packed(self, pk, off, length, rc=None):
+        return self._fetch(self.L.agc_hip_fetch_slices_packed, C.byref(pk), off, length, rc)
+
+    def ref_lag_counts_packed(self, pk, off, length, rc=None):
+        return self._lag(self.L.agc_hip_ref_lag_counts_packed, C.byref(pk), off, length, rc)
 
     def lz_encode_end(self, enc_cap=None):
         """second half: waits, -> (enc bytes, enc_off[n+1]) exactly as lz_encode_batch_dev"""
@@ -400,14 +445,17 @@ class Context:
         text = _a(text, np.uint8)
         return self._costvec(self.L.agc_hip_lz_cost_vector_batch, _p(text, u8p), gids, off, length, rc, prefix)
 
-    def lz_split_point_batch_dev(self, d_base, gid1, gid2, off, length, rc1, prefix1, rc2, prefix2):
+    def _split(self, fn, base, gid1, gid2, off, length, rc1, prefix1, rc2, prefix2):
         g1, g2, o, l = _a(gid1, np.uint32), _a(gid2, np.uint32), _a(off, np.uint64), _a(length, np.uint32)
         r1, p1, r2, p2 = (_a(x, np.uint8) for x in (rc1, prefix1, rc2, prefix2))
         pos = np.zeros(g1.size, np.uint32)
         sm = np.zeros(g1.size, np.uint32)
-        self._chk(self.L.agc_hip_lz_split_point_batch_dev(self.h, g1.size, _p(g1, u32p), _p(g2, u32p), d_base, _p(o, u64p), _p(l, u32p),
-                                                          _p(r1, u8p), _p(p1, u8p), _p(r2, u8p), _p(p2, u8p), _p(pos, u32p), _p(sm, u32p)))
+        self._chk(fn(self.h, g1.size, _p(g1, u32p), _p(g2, u32p), base, _p(o, u64p), _p(l, u32p),
+                     _p(r1, u8p), _p(p1, u8p), _p(r2, u8p), _p(p2, u8p), _p(pos, u32p), _p(sm, u32p)))
         return pos, sm
+
+    def lz_split_point_batch_dev(self, d_base, gid1, gid2, off, length, rc1, prefix1, rc2, prefix2):
+        return self._split(self.L.agc_hip_lz_split_point_batch_dev, d_base, gid1, gid2, off, length, rc1, prefix1, rc2, prefix2)
 
     def zstd17_batch(self, inputs):
         """inputs: list of bytes-like; returns the list of level-17 zstd frames (S3 on the GPU)"""
@@ -459,19 +507,25 @@ class Context:
         self._chk(self.L.agc_hip_zstd17_batch_dev(self.h, n, d_src_ptr, _p(off, u64p), _p(dst, u8p), cap, _p(doff, u64p)))
         return dst[:int(doff[-1])], doff
 
-    def fetch_slices_dev(self, d_base, off, length, rc=None):
+    def _fetch(self, fn, base, off, length, rc):
         o, l = _a(off, np.uint64), _a(length, np.uint32)
         r = _a(rc, np.uint8) if rc is not None else None
         cap = int(l.astype(np.uint64).sum())
         out = np.empty(cap, np.uint8)
         ooff = np.zeros(o.size + 1, np.uint64)
-        self._chk(self.L.agc_hip_fetch_slices_dev(self.h, o.size, d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(out, u8p), cap, _p(ooff, u64p)))
+        self._chk(fn(self.h, o.size, base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(out, u8p), cap, _p(ooff, u64p)))
         return out, ooff
 
-    def ref_lag_counts_dev(self, d_base, off, length, rc=None):
+    def fetch_slices_dev(self, d_base, off, length, rc=None):
+        return self._fetch(self.L.agc_hip_fetch_slices_dev, d_base, off, length, rc)
+
+    def _lag(self, fn, base, off, length, rc):
         o, l = _a(off, np.uint64), _a(length, np.uint32)
         r = _a(rc, np.uint8) if rc is not None else None
         cnt = np.zeros((o.size, 28), np.uint32)
         cur = np.zeros((o.size, 28), np.uint32)
-        self._chk(self.L.agc_hip_ref_lag_counts_dev(self.h, o.size, d_base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(cnt, u32p), _p(cur, u32p)))
+        self._chk(fn(self.h, o.size, base, _p(o, u64p), _p(l, u32p), _p(r, u8p), _p(cnt, u32p), _p(cur, u32p)))
         return cnt, cur
+
+    def ref_lag_counts_dev(self, d_base, off, length, rc=None):
+        return self._lag(self.L.agc_hip_ref_lag_counts_dev, d_base, off, length, rc)

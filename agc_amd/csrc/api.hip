@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -29,6 +30,20 @@ struct DevBuf {
 struct ArenaChunk {
     uint8_t *p;
     size_t size, used;
+};
+
+// a 2-bit packed buffer the LZ entry points read sequences from (sym_view.h): the caller's sample, or a temporary one
+struct PackedSrc {
+    const uint32_t *words = nullptr;
+    const int32_t *esc_index = nullptr;
+    const uint8_t *esc_bytes = nullptr;
+    uint64_t n_symbols = 0;
+};
+
+// context-owned packed form of byte input (the entry points that take one byte per symbol pack what they are given first:
+// every LZ kernel reads the 2-bit layout only)
+struct PackTemp {
+    DevBuf words, index, esc, cnt;
 };
 
 } // namespace
@@ -57,16 +72,19 @@ struct agc_hip_ctx {
     std::vector<ArenaChunk> arena;
 
     // scratch
-    DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_stage, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
+    DevBuf d_esc_jobs, d_flags;
+    DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
         d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_zdstoff, d_maybe, d_fjobs;
 
-    std::vector<SliceDesc> h_slices;
+    PackTemp pk1;        // byte-input entry points on the first stream
+    PackTemp pk_sample;  // agc_hip_sample_pack
+    std::mutex host_alloc_mtx; // host_allocs: agc_hip_host_alloc / _free may be called from the thread that collects an encode
 
     // second LZ lane: agc_hip_lz_encode_begin_dev / _end run the encode of a whole sample on `stream2` with their own scratch,
     // beside the estimates / cost vectors / index builds the caller goes on with on `stream`
     struct Lane2 {
-        DevBuf d_stage, d_slices, d_segs, d_counter, d_resv, d_resp, d_scratch, d_dstoff, d_compact;
-        std::vector<SliceDesc> h_slices;
+        DevBuf d_segs, d_counter, d_resv, d_resp, d_scratch, d_dstoff, d_compact;
+        PackTemp pk;
         uint32_t *h_lens = nullptr; // pinned (a device-to-host copy into pageable memory would make begin wait for the kernel)
         size_t h_lens_cap = 0;
         uint32_t n = 0;          // segments of the encode in flight
@@ -85,8 +103,7 @@ struct agc_hip_ctx {
     // GPU while the host registers its segments
     struct Prefetch {
         hipStream_t stream = nullptr;
-        DevBuf d_sample[2], d_ranges, d_hits, d_counter;
-        int cur = 0;
+        DevBuf d_ranges, d_hits, d_counter;
         uint32_t *h_count = nullptr; // pinned
         const void *words = nullptr; // identity of the packed sample in flight
         uint64_t n_symbols = 0;
@@ -236,12 +253,73 @@ uint32_t grid_for(uint32_t n_items, uint32_t per_block, uint32_t max_blocks)
     return (uint32_t)std::min<uint64_t>(b, max_blocks);
 }
 
+// bytes (one per symbol, device) -> 2-bit layout in the context-owned buffers of `t`, queued on `st`; every block may be
+// escaped (room for all of them), so nothing has to be read back
+int pack_bytes(agc_hip_ctx *c, const uint8_t *d_codes, uint64_t n, PackTemp &t, hipStream_t st, PackedSrc &out)
+{
+    out = PackedSrc();
+    if (!n)
+        return AGC_HIP_OK;
+    const uint64_t n_blocks = (n + PACK_BLOCK - 1) / PACK_BLOCK;
+    CHK(ensure(c, t.words, n_blocks * (PACK_BLOCK / 4) + 64, st));
+    CHK(ensure(c, t.index, n_blocks * 4 + 64, st));
+    CHK(ensure(c, t.esc, n_blocks * PACK_BLOCK + 64, st));
+    CHK(ensure(c, t.cnt, 64, st));
+    HIPCHK(c, hipMemsetAsync(t.cnt.p, 0, 4, st));
+    hipLaunchKernelGGL(pack_codes_kernel, dim3((uint32_t)std::min<uint64_t>((n_blocks + 3) / 4, 65536)), dim3(256), 0, st, d_codes, n, (uint32_t *)t.words.p,
+                       (int32_t *)t.index.p, (uint8_t *)t.esc.p, (uint32_t *)t.cnt.p, (uint32_t)std::min<uint64_t>(n_blocks, 0x7fffffffu));
+    HIPCHK(c, hipGetLastError());
+    out.words = (const uint32_t *)t.words.p;
+    out.esc_index = (const int32_t *)t.index.p;
+    out.esc_bytes = (const uint8_t *)t.esc.p;
+    out.n_symbols = n;
+    return AGC_HIP_OK;
+}
+
+// the sequences [h_off[i], h_off[i] + h_len[i]) of a byte buffer: the range they span is packed, off2 = their offsets in it
+int pack_range(agc_hip_ctx *c, const uint8_t *d_base, uint32_t n, const uint64_t *h_off, const uint32_t *h_len, PackTemp &t, hipStream_t st,
+               PackedSrc &out, std::vector<uint64_t> &off2)
+{
+    uint64_t lo = ~0ULL, hi = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (h_len[i]) {
+            lo = std::min<uint64_t>(lo, h_off[i]);
+            hi = std::max<uint64_t>(hi, h_off[i] + h_len[i]);
+        }
+    off2.assign(n, 0);
+    if (hi <= lo) {
+        out = PackedSrc();
+        return AGC_HIP_OK;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        off2[i] = h_len[i] ? h_off[i] - lo : 0;
+    return pack_bytes(c, d_base + lo, hi - lo, t, st, out);
+}
+
+PackedSrc src_of(const agc_hip_packed *pk) 
+{
+    PackedSrc s;
+    s.words = pk->d_words;
+    s.esc_index = pk->d_esc_index;
+    s.esc_bytes = pk->d_esc_bytes;
+    s.n_symbols = pk->n_symbols;
+    return s;
+}
+
+bool slices_inside(const PackedSrc &src, uint32_t n, const uint64_t *h_off, const uint32_t *h_len)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        if (h_len[i] && (h_off[i] > src.n_symbols || h_len[i] > src.n_symbols - h_off[i]))
+            return false;
+    return true;
+}
+
 } // namespace
 
 // ===========================================================================
 extern "C" {
 
-uint32_t agc_hip_abi_version(void) { return 1; }
+uint32_t agc_hip_abi_version(void) { return 2; }
 
 int agc_hip_create(agc_hip_ctx **out, int device)
 {
@@ -287,7 +365,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipHostFree(c->pf.h_count);
         (void)hipEventDestroy(c->pf.e0);
         (void)hipEventDestroy(c->pf.e1);
-        for (DevBuf *b : {&c->pf.d_sample[0], &c->pf.d_sample[1], &c->pf.d_ranges, &c->pf.d_hits, &c->pf.d_counter})
+        for (DevBuf *b : {&c->pf.d_ranges, &c->pf.d_hits, &c->pf.d_counter})
             if (b->p)
                 (void)hipFree(b->p);
     }
@@ -296,11 +374,15 @@ void agc_hip_destroy(agc_hip_ctx *c)
     if (c->l2.h_lens)
         (void)hipHostFree(c->l2.h_lens);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_sbloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
-                      &c->d_stage, &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
+                      &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
                       &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs,
-                      &c->l2.d_stage, &c->l2.d_slices, &c->l2.d_segs, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
-                      &c->l2.d_compact};
+                      &c->l2.d_segs, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
+                      &c->l2.d_compact, &c->d_esc_jobs, &c->d_flags};
+    for (PackTemp *t : {&c->pk1, &c->pk_sample, &c->l2.pk})
+        for (DevBuf *b : {&t->words, &t->index, &t->esc, &t->cnt})
+            if (b->p)
+                (void)hipFree(b->p);
     for (DevBuf *b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -397,6 +479,26 @@ int agc_hip_copy_to_device(agc_hip_ctx *c, uint8_t *d_dst, const uint8_t *h_src,
         HIPCHK(c, hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return AGC_HIP_OK;
+}
+
+int agc_hip_sample_pack(agc_hip_ctx *c, const uint8_t *d_codes, uint64_t n_symbols, agc_hip_packed *out)
+{
+    if (!c || !out || (n_symbols && !d_codes))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    // (the encode of the previous sample may still be reading these buffers on the second lane: see Lane2::done)
+    if (c->l2.done_valid)
+        HIPCHK(c, hipEventSynchronize(c->l2.done));
+    PackedSrc src;
+    {
+        KTimer t(c, AGC_HIP_K_PREPROCESS);
+        CHK(pack_bytes(c, d_codes, n_symbols, c->pk_sample, c->stream, src));
+    }
+    out->d_words = src.words;
+    out->d_esc_index = src.esc_index;
+    out->d_esc_bytes = src.esc_bytes;
+    out->n_symbols = n_symbols;
     return AGC_HIP_OK;
 }
 
@@ -824,10 +926,10 @@ int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     return deliver_hits(c, n_found, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
 }
 
-// The next sample ahead of its turn (include/agc_hip.h): expansion + packed scan queued on the prefetch stream, nothing waited for.
-int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint8_t **d_codes)
+// The next sample ahead of its turn (include/agc_hip.h): its packed scan queued on the prefetch stream, nothing waited for.
+int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k)
 {
-    if (!c || !pk || !h_ctg_off || !d_codes || !n_ctg || k < 16 || k > 32 || !pk->d_words || !pk->d_esc_index || !pk->n_symbols ||
+    if (!c || !pk || !h_ctg_off || !n_ctg || k < 16 || k > 32 || !pk->d_words || !pk->d_esc_index || !pk->n_symbols ||
         h_ctg_off[n_ctg] > pk->n_symbols)
         return AGC_HIP_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
@@ -843,23 +945,10 @@ int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const 
     if (!c->d_table.p)
         CHK(splitters_upload(c));
     CHK(sbloom_upload(c, k));
-    pf.cur ^= 1;
-    DevBuf &stage = pf.d_sample[pf.cur];
-    // (this staging buffer held the sample before the current one: its encode may still be reading it on the second lane)
-    if (c->l2.done_valid) {
-        if (pk->n_symbols + 64 + 4096 > stage.cap)
-            HIPCHK(c, hipEventSynchronize(c->l2.done));
-        else
-            HIPCHK(c, hipStreamWaitEvent(pf.stream, c->l2.done, 0));
-    }
-    CHK(ensure(c, stage, pk->n_symbols + 64 + 4096, pf.stream));
     const PackedView pv = {pk->d_words, pk->d_esc_index, pk->d_esc_bytes, pk->n_symbols};
-    const uint64_t n_blocks = (pk->n_symbols + PACK_BLOCK - 1) / PACK_BLOCK;
     pf.timed = c->timing;
     if (pf.timed)
         HIPCHK(c, hipEventRecord(pf.e0, pf.stream));
-    hipLaunchKernelGGL(expand_codes_kernel, dim3((uint32_t)std::min<uint64_t>((n_blocks + 3) / 4, 65536)), dim3(256), 0, pf.stream, pv, (uint8_t *)stage.p);
-    HIPCHK(c, hipGetLastError());
     // the scan: as agc_hip_scan_packed_dev, own scratch, nothing waited for
     const uint64_t total = h_ctg_off[n_ctg] - h_ctg_off[0];
     const uint64_t target_waves = 4096ULL * 4;
@@ -921,7 +1010,6 @@ int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const 
     pf.first_off = h_ctg_off[0];
     pf.last_off = h_ctg_off[n_ctg];
     pf.valid = true;
-    *d_codes = (uint8_t *)stage.p;
     return AGC_HIP_OK;
 }
 
@@ -936,7 +1024,7 @@ int agc_hip_scan_prefetched(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         return AGC_HIP_EINVAL; // nothing, or something else, was prefetched
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(pf.stream));
-    if (pf.timed) { // (expansion + scan of the prefetch: accounted to the scan row)
+    if (pf.timed) { // (the prefetched scan: the scan row)
         float ms = 0;
         (void)hipEventElapsedTime(&ms, pf.e0, pf.e1);
         c->ms[AGC_HIP_K_SCAN] += ms;
@@ -955,16 +1043,16 @@ int agc_hip_scan_prefetched(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
 // ---------------------------------------------------------------------------
 // references
 // ---------------------------------------------------------------------------
-int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_gid, const uint8_t *d_base,
-                                   const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc, uint32_t min_match_len)
+} // extern "C"
+
+// new references out of a packed buffer: stored form (2-bit words from bit 0, escape blocks where needed), index, key filter
+static int ref_register_impl(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off,
+                             const uint32_t *h_len, const uint8_t *h_rc, uint32_t min_match_len)
 {
-    if (!c || (n_refs && (!h_gid || !h_off || !h_len || !d_base)))
-        return AGC_HIP_EINVAL;
     if (min_match_len < HASHING_STEP + 4 || min_match_len > 32)
         return AGC_HIP_EINVAL; // key_len = mml-3 must fit 2 bits x key_len <= 58 and the wave's 64 lanes
     if (!n_refs)
         return AGC_HIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
     const uint32_t key_len = min_match_len - HASHING_STEP + 1;
     uint32_t max_gid = 0;
     for (uint32_t i = 0; i < n_refs; ++i) {
@@ -981,25 +1069,21 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
             return AGC_HIP_EINVAL;
     }
 
-    // 1. store (optionally reverse-complemented) + pad with INVALID_SYMBOL
-    std::vector<SliceDesc> sl(n_refs);
+    // 1. stored form: ref_size symbols in 2-bit words + REF_TAIL_WORDS words of slack, 16-byte aligned
     std::vector<IdxBuild> jobs(n_refs);
     size_t ref_bytes = 0;
     std::vector<size_t> roff(n_refs);
     for (uint32_t i = 0; i < n_refs; ++i) {
         roff[i] = ref_bytes;
-        ref_bytes += ((size_t)h_len[i] + key_len + REF_TAIL_PAD + 15) & ~(size_t)15;
+        ref_bytes += ((((size_t)h_len[i] + 15) / 16 + REF_TAIL_WORDS) * 4 + 15) & ~(size_t)15;
     }
     uint8_t *rbase = nullptr;
     CHK(arena_alloc(c, ref_bytes, &rbase));
     for (uint32_t i = 0; i < n_refs; ++i) {
-        sl[i].src = d_base + h_off[i];
-        sl[i].dst = rbase + roff[i];
-        sl[i].len = h_len[i];
-        sl[i].rc = h_rc ? h_rc[i] : 0;
-        sl[i].pad_len = key_len + REF_TAIL_PAD;
-        sl[i].pad2 = 0;
-        jobs[i].ref = rbase + roff[i];
+        jobs[i].src = {src.words, src.esc_index, src.esc_bytes, h_off[i], h_len[i], h_rc ? (uint32_t)(h_rc[i] != 0) : 0u};
+        jobs[i].words = (uint32_t *)(rbase + roff[i]);
+        jobs[i].esc_index = nullptr;
+        jobs[i].esc_bytes = nullptr;
         jobs[i].table = nullptr;
         jobs[i].bloom = nullptr;
         jobs[i].ref_size = h_len[i];
@@ -1007,22 +1091,21 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
         jobs[i].ht_mask = 0;
         jobs[i].is_short = (h_len[i] / HASHING_STEP) < 65535u; // lz_diff.cpp:146
     }
-    CHK(ensure(c, c->d_slices, (size_t)n_refs * sizeof(SliceDesc)));
     CHK(ensure(c, c->d_jobs, (size_t)n_refs * sizeof(IdxBuild)));
     CHK(ensure(c, c->d_counts, (size_t)n_refs * 4));
-    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n_refs * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
+    CHK(ensure(c, c->d_flags, (size_t)n_refs * 4));
     HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
+    // few references per batch (steady state): spread each over several blocks to fill the chip
+    const uint32_t split = n_refs >= 2048 ? 1u : std::min<uint32_t>(16u, 2048u / n_refs);
+    HIPCHK(c, hipMemsetAsync(c->d_flags.p, 0, (size_t)n_refs * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, (size_t)n_refs * 4, c->stream));
     {
         KTimer t(c, AGC_HIP_K_REFSTORE);
-        hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n_refs, 1, 65536)), dim3(256), 0, c->stream,
-                           (const SliceDesc *)c->d_slices.p, n_refs);
+        hipLaunchKernelGGL(ref_pack_kernel, dim3(n_refs * split), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p, (uint32_t *)c->d_flags.p, split);
     }
     // 2. count keys -> table sizes (prepare_index, lz_diff.cpp:81-125: double division by 0.7,
     //    round down to a power of two, double it, at least 8)
-    std::vector<uint32_t> counts(n_refs);
-    // few references per batch (steady state): spread each over several blocks to fill the chip
-    const uint32_t split = n_refs >= 2048 ? 1u : std::min<uint32_t>(16u, 2048u / n_refs);
-    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, (size_t)n_refs * 4, c->stream));
+    std::vector<uint32_t> counts(n_refs), flags(n_refs);
     {
         KTimer t(c, AGC_HIP_K_INDEX);
         hipLaunchKernelGGL(idx_count_kernel, dim3(n_refs * split), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p,
@@ -1030,6 +1113,7 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(counts.data(), c->d_counts.p, (size_t)n_refs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags.p, (size_t)n_refs * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     size_t tab_bytes = 0;
     std::vector<size_t> toff(n_refs);
@@ -1053,9 +1137,26 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     const size_t bloom_bytes = (size_t)n_refs * KEY_BLOOM_WORDS * 8;
     CHK(arena_alloc(c, bloom_bytes, &bbase));
     HIPCHK(c, hipMemsetAsync(bbase, 0, bloom_bytes, c->stream));
+    // references that hold a symbol outside ACGT: escape index + one byte per symbol for the blocks that need it
+    std::vector<EscJob> ejobs;
     for (uint32_t i = 0; i < n_refs; ++i) {
         jobs[i].table = tbase + toff[i];
         jobs[i].bloom = (unsigned long long *)(bbase + (size_t)i * KEY_BLOOM_WORDS * 8);
+        if (flags[i]) {
+            const uint32_t nb = (h_len[i] + PACK_BLOCK - 1) / PACK_BLOCK;
+            uint8_t *eb = nullptr;
+            CHK(arena_alloc(c, (size_t)nb * 4 + 64 + (size_t)nb * PACK_BLOCK, &eb));
+            jobs[i].esc_index = (int32_t *)eb;
+            jobs[i].esc_bytes = eb + (((size_t)nb * 4 + 64 + 15) & ~(size_t)15);
+            for (uint32_t b = 0; b < nb; ++b)
+                ejobs.push_back({jobs[i].src, jobs[i].esc_index, jobs[i].esc_bytes, b, 0u});
+        }
+    }
+    if (!ejobs.empty()) {
+        CHK(ensure(c, c->d_esc_jobs, ejobs.size() * sizeof(EscJob)));
+        HIPCHK(c, hipMemcpyAsync(c->d_esc_jobs.p, ejobs.data(), ejobs.size() * sizeof(EscJob), hipMemcpyHostToDevice, c->stream));
+        KTimer t(c, AGC_HIP_K_REFSTORE);
+        hipLaunchKernelGGL(ref_esc_kernel, dim3((uint32_t)ejobs.size()), dim3(256), 0, c->stream, (const EscJob *)c->d_esc_jobs.p);
     }
     HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
     {
@@ -1066,10 +1167,12 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     if (c->refs.size() <= max_gid)
-        c->refs.resize((size_t)max_gid + 1, RefDesc{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0});
+        c->refs.resize((size_t)max_gid + 1, RefDesc{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0});
     for (uint32_t i = 0; i < n_refs; ++i) {
         RefDesc &r = c->refs[h_gid[i]];
-        r.ref = jobs[i].ref;
+        r.words = jobs[i].words;
+        r.esc_index = jobs[i].esc_index;
+        r.esc_bytes = jobs[i].esc_bytes;
         r.table = jobs[i].table;
         r.bloom = jobs[i].bloom;
         r.ref_size = h_len[i];
@@ -1081,6 +1184,36 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32
     }
     c->refs_dirty = true;
     return AGC_HIP_OK;
+}
+
+extern "C" {
+
+int agc_hip_ref_register_batch_packed(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
+                                      const uint32_t *h_len, const uint8_t *h_rc, uint32_t min_match_len)
+{
+    if (!c || (n_refs && (!h_gid || !h_off || !h_len || !pk || !pk->d_words)))
+        return AGC_HIP_EINVAL;
+    if (!n_refs)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const PackedSrc src = src_of(pk);
+    if (!slices_inside(src, n_refs, h_off, h_len))
+        return AGC_HIP_EINVAL;
+    return ref_register_impl(c, n_refs, h_gid, src, h_off, h_len, h_rc, min_match_len);
+}
+
+int agc_hip_ref_register_batch_dev(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_gid, const uint8_t *d_base,
+                                   const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc, uint32_t min_match_len)
+{
+    if (!c || (n_refs && (!h_gid || !h_off || !h_len || !d_base)))
+        return AGC_HIP_EINVAL;
+    if (!n_refs)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n_refs, h_off, h_len, c->pk1, c->stream, src, off2));
+    return ref_register_impl(c, n_refs, h_gid, src, off2.data(), h_len, h_rc, min_match_len);
 }
 
 int agc_hip_ref_register(agc_hip_ctx *c, uint32_t gid, const uint8_t *h_ref, uint32_t n, uint32_t min_match_len)
@@ -1107,8 +1240,16 @@ int agc_hip_ref_get(agc_hip_ctx *c, uint32_t gid, uint8_t *h_ref, uint32_t cap, 
     *h_n = r.ref_size;
     if (cap < r.ref_size)
         return AGC_HIP_ECAP;
-    if (r.ref_size)
-        HIPCHK(c, hipMemcpy(h_ref, r.ref, r.ref_size, hipMemcpyDeviceToHost));
+    if (r.ref_size) { // the stored 2-bit form back as one byte per symbol
+        CHK(ensure(c, c->d_compact, (size_t)r.ref_size + 64));
+        const ViewJob vj = {{r.words, r.esc_index, r.esc_bytes, 0, r.ref_size, 0}, c->d_compact.p};
+        CHK(ensure(c, c->d_slices, sizeof(ViewJob)));
+        HIPCHK(c, hipMemcpyAsync(c->d_slices.p, &vj, sizeof(ViewJob), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(slice_expand_kernel, dim3(1), dim3(256), 0, c->stream, (const ViewJob *)c->d_slices.p, 1u);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h_ref, c->d_compact.p, r.ref_size, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return AGC_HIP_OK;
 }
 
@@ -1151,15 +1292,13 @@ struct Batch {
     uint64_t out_total = 0;    // scratch units (bytes or u32s)
 };
 
-// Builds descriptors; reverse-complemented texts are materialised once in the staging buffer.
-int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+// Builds descriptors: every text is a view into the packed buffer (either orientation -- nothing is copied or staged).
+int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off,
                   const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix, Batch &b, bool lane2 = false)
 {
     // (lane 2: encode only -- no filter bitmaps; its own scratch and stream)
-    DevBuf &L_stage = lane2 ? c->l2.d_stage : c->d_stage, &L_slices = lane2 ? c->l2.d_slices : c->d_slices,
-           &L_segs = lane2 ? c->l2.d_segs : c->d_segs, &L_counter = lane2 ? c->l2.d_counter : c->d_counter,
+    DevBuf &L_segs = lane2 ? c->l2.d_segs : c->d_segs, &L_counter = lane2 ? c->l2.d_counter : c->d_counter,
            &L_resv = lane2 ? c->l2.d_resv : c->d_resv, &L_resp = lane2 ? c->l2.d_resp : c->d_resp;
-    std::vector<SliceDesc> &L_hslices = lane2 ? c->l2.h_slices : c->h_slices;
     const hipStream_t L_stream = lane2 ? c->stream2 : c->stream;
     static const bool laps = getenv("AGC_HIP_LAPS") != nullptr;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1176,36 +1315,12 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
             c->err = "group " + std::to_string(h_gid[i]) + " has no registered reference";
             return AGC_HIP_ENOREF;
         }
+    if (!slices_inside(src, n, h_off, h_len)) {
+        c->err = "a sequence runs past the end of its buffer";
+        return AGC_HIP_EINVAL;
+    }
     LAP("valid");
     CHK(upload_refs(c));
-    // staging for rc texts
-    size_t stage = 0;
-    std::vector<size_t> soff(n, 0);
-    uint32_t n_rc = 0;
-    for (uint32_t i = 0; i < n; ++i)
-        if (h_rc && h_rc[i]) {
-            soff[i] = stage;
-            stage += ((size_t)h_len[i] + 15) & ~(size_t)15;
-            ++n_rc;
-        }
-    if (n_rc) {
-        CHK(ensure(c, L_stage, stage + 64, L_stream));
-        std::vector<SliceDesc> &sl = L_hslices; // outlives the asynchronous upload
-        sl.clear();
-        sl.reserve(n_rc);
-        for (uint32_t i = 0; i < n; ++i)
-            if (h_rc[i])
-                sl.push_back({d_base + h_off[i], (uint8_t *)L_stage.p + soff[i], h_len[i], 1u, 0u, 0u});
-        CHK(ensure(c, L_slices, sl.size() * sizeof(SliceDesc), L_stream));
-        HIPCHK(c, hipMemcpyAsync(L_slices.p, sl.data(), sl.size() * sizeof(SliceDesc), hipMemcpyHostToDevice, L_stream));
-        {
-            KTimer t(c, lane2 ? -1 : AGC_HIP_K_REVCOMP);
-            hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n_rc, 1, 65536)), dim3(256), 0, L_stream,
-                               (const SliceDesc *)L_slices.p, n_rc);
-        }
-        HIPCHK(c, hipGetLastError());
-    }
-    LAP("rc_staging");
     // longest first, stable in the index: LSD radix sort on ~len (3 passes of 11 bits; a comparison sort of the 50 k segments
     // of a human sample costs milliseconds of host time per call)
     std::vector<uint32_t> order(n);
@@ -1255,17 +1370,17 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         const uint32_t i = order[p];
         SegDesc &s = b.segs[p];
         s.maybe = nullptr;
-        s.text = (h_rc && h_rc[i]) ? (const uint8_t *)L_stage.p + soff[i] : d_base + h_off[i];
+        s.text = {src.words, src.esc_index, src.esc_bytes, h_off[i], h_len[i], (h_rc && h_rc[i]) ? 1u : 0u};
         s.out_off = ooff[i];
-        s.len = h_len[i];
         s.ref_slot = h_gid[i];
         s.flags = (h_prefix && h_prefix[i]) ? 1u : 0u;
-        s.pad = i;
+        s.idx = i;
+        s.pad = 0;
         const RefDesc &rd = c->refs[h_gid[i]];
         if (mode != MODE_ENCODE && rd.bloom && h_len[i] > 4 * WAVE) { // (short texts: not worth a block)
             s.maybe = (const unsigned long long *)c->d_maybe.p + moff[i];
             for (uint32_t ch = 0; ch < h_len[i]; ch += FILTER_CHUNK)
-                fjobs.push_back({s.text, rd.bloom, (unsigned long long *)c->d_maybe.p + moff[i], h_len[i], rd.key_len, ch, 0u});
+                fjobs.push_back({s.text, rd.bloom, (unsigned long long *)c->d_maybe.p + moff[i], rd.key_len, ch});
         }
     }
     if (!fjobs.empty()) {
@@ -1323,17 +1438,13 @@ int stage_host_texts(agc_hip_ctx *c, uint32_t n, const uint8_t *h_text, const ui
 
 extern "C" {
 
-int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
-                                const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
+} // extern "C"
+
+static int lz_encode_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off, const uint32_t *h_len,
+                          const uint8_t *h_rc, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
 {
-    if (!c || !h_enc_off || (n && (!h_gid || !h_off || !h_len || !d_base)))
-        return AGC_HIP_EINVAL;
-    h_enc_off[0] = 0;
-    if (!n)
-        return AGC_HIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
     Batch b;
-    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, d_base, h_off, h_len, h_rc, nullptr, b));
+    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, src, h_off, h_len, h_rc, nullptr, b));
     CHK(ensure(c, c->d_scratch, b.out_total + 64));
     CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)c->d_scratch.p, nullptr));
     std::vector<uint32_t> lens(n);
@@ -1360,29 +1471,14 @@ int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gi
     return AGC_HIP_OK;
 }
 
-// The same encode in two halves (include/agc_hip.h): begin queues the reverse-complement staging, the parse and the copy of
-// the delta lengths on the context's second stream and returns; end waits, lays the deltas out back to back and brings them
-// over.  Between the two the caller may use every other entry point (they run on the first stream with their own scratch).
-int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
-                                const uint32_t *h_len, const uint8_t *h_rc)
+// The encode in two halves (include/agc_hip.h): begin queues the parse and the copy of the delta lengths on the context's second
+// stream and returns; end waits, lays the deltas out back to back and brings them over.  Between the two the caller may use every
+// other entry point (they run on the first stream with their own scratch).
+static int lz_encode_begin_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off, const uint32_t *h_len,
+                                const uint8_t *h_rc)
 {
-    if (!c || (n && (!h_gid || !h_off || !h_len || !d_base)))
-        return AGC_HIP_EINVAL;
-    if (c->l2.pending) { // (an abandoned encode: a caller that failed between the two halves) -- dropped
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->l2.pending = false;
-    }
-    c->l2.n = n;
-    if (!n) {
-        c->l2.pending = true;
-        return AGC_HIP_OK;
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    // everything queued on the first stream so far (the sample's staging copy, index builds) comes first
-    HIPCHK(c, hipEventRecord(c->l2.ready, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->l2.ready, 0));
     static thread_local Batch b; // (its descriptors are read by an asynchronous upload: they outlive this call)
-    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, d_base, h_off, h_len, h_rc, nullptr, b, true));
+    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, src, h_off, h_len, h_rc, nullptr, b, true));
     CHK(ensure(c, c->l2.d_scratch, b.out_total + 64, c->stream2));
     if (c->l2.h_lens_cap < n) {
         if (c->l2.h_lens)
@@ -1403,6 +1499,79 @@ int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gi
     HIPCHK(c, hipMemcpyAsync(c->l2.h_lens, c->l2.d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream2));
     c->l2.pending = true;
     return AGC_HIP_OK;
+}
+
+// common start of the two begin entry points: an abandoned encode is dropped, the first stream's work so far comes first
+static int lz_encode_begin_enter(agc_hip_ctx *c, uint32_t n)
+{
+    if (c->l2.pending) { // (an abandoned encode: a caller that failed between the two halves) -- dropped
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        c->l2.pending = false;
+    }
+    c->l2.n = n;
+    if (!n) {
+        c->l2.pending = true;
+        return 1; // nothing to launch
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    // everything queued on the first stream so far (index builds, a sample being packed) comes first
+    HIPCHK(c, hipEventRecord(c->l2.ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->l2.ready, 0));
+    return AGC_HIP_OK;
+}
+
+extern "C" {
+
+int agc_hip_lz_encode_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
+                                   const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off || (n && (!h_gid || !h_off || !h_len || !pk || !pk->d_words)))
+        return AGC_HIP_EINVAL;
+    h_enc_off[0] = 0;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return lz_encode_impl(c, n, h_gid, src_of(pk), h_off, h_len, h_rc, h_enc, enc_cap, h_enc_off);
+}
+
+int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off || (n && (!h_gid || !h_off || !h_len || !d_base)))
+        return AGC_HIP_EINVAL;
+    h_enc_off[0] = 0;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n, h_off, h_len, c->pk1, c->stream, src, off2));
+    return lz_encode_impl(c, n, h_gid, src, off2.data(), h_len, h_rc, h_enc, enc_cap, h_enc_off);
+}
+
+int agc_hip_lz_encode_begin_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
+                                   const uint32_t *h_len, const uint8_t *h_rc)
+{
+    if (!c || (n && (!h_gid || !h_off || !h_len || !pk || !pk->d_words)))
+        return AGC_HIP_EINVAL;
+    const int e = lz_encode_begin_enter(c, n);
+    if (e)
+        return e > 0 ? AGC_HIP_OK : e;
+    return lz_encode_begin_impl(c, n, h_gid, src_of(pk), h_off, h_len, h_rc);
+}
+
+int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc)
+{
+    if (!c || (n && (!h_gid || !h_off || !h_len || !d_base)))
+        return AGC_HIP_EINVAL;
+    const int e = lz_encode_begin_enter(c, n);
+    if (e)
+        return e > 0 ? AGC_HIP_OK : e;
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n, h_off, h_len, c->l2.pk, c->stream2, src, off2)); // (the lane's own packed copy: it lives until end)
+    return lz_encode_begin_impl(c, n, h_gid, src, off2.data(), h_len, h_rc);
 }
 
 int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
@@ -1460,7 +1629,10 @@ int agc_hip_host_alloc(agc_hip_ctx *c, uint64_t bytes, void **out)
     HIPCHK(c, hipSetDevice(c->device));
     void *p = nullptr;
     HIPCHK(c, hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
-    c->host_allocs.push_back(p);
+    {
+        std::lock_guard<std::mutex> lk(c->host_alloc_mtx);
+        c->host_allocs.push_back(p);
+    }
     *out = p;
     return AGC_HIP_OK;
 }
@@ -1471,14 +1643,216 @@ int agc_hip_host_free(agc_hip_ctx *c, void *p)
         return AGC_HIP_EINVAL;
     if (!p)
         return AGC_HIP_OK;
-    auto it = std::find(c->host_allocs.begin(), c->host_allocs.end(), p);
-    if (it == c->host_allocs.end())
-        return AGC_HIP_EINVAL;
-    c->host_allocs.erase(it);
-    HIPCHK(c, hipHostFree(p));
+    {
+        std::lock_guard<std::mutex> lk(c->host_alloc_mtx);
+        auto it = std::find(c->host_allocs.begin(), c->host_allocs.end(), p);
+        if (it == c->host_allocs.end())
+            return AGC_HIP_EINVAL;
+        c->host_allocs.erase(it);
+    }
+    if (hipHostFree(p) != hipSuccess) // (no write to the shared error string: this may be the thread that collects an encode)
+        return AGC_HIP_ENODEV;
     return AGC_HIP_OK;
 }
 
+} // extern "C"
+
+static int lz_estimate_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off, const uint32_t *h_len,
+                            const uint8_t *h_rc, uint32_t *h_cost, uint32_t *h_peak)
+{
+    Batch b;
+    CHK(prepare_batch(c, MODE_ESTIMATE, n, h_gid, src, h_off, h_len, h_rc, nullptr, b));
+    CHK(launch_parse<MODE_ESTIMATE>(c, n, nullptr, nullptr));
+    HIPCHK(c, hipMemcpyAsync(h_cost, c->d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_peak)
+        HIPCHK(c, hipMemcpyAsync(h_peak, c->d_resp.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+static int lz_cost_vector_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off, const uint32_t *h_len,
+                               const uint8_t *h_rc, const uint8_t *h_prefix_costs, uint32_t *h_costs)
+{
+    Batch b;
+    CHK(prepare_batch(c, MODE_COSTVEC, n, h_gid, src, h_off, h_len, h_rc, h_prefix_costs, b));
+    CHK(ensure(c, c->d_scratch, b.out_total + 64)); // (one byte per position on the device: lz_kernels.hip, cost_t)
+    CHK(launch_parse<MODE_COSTVEC>(c, n, nullptr, (uint32_t *)c->d_scratch.p));
+    std::vector<uint8_t> tmp(b.out_total);
+    if (b.out_total)
+        HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_scratch.p, b.out_total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint64_t i = 0; i < b.out_total; ++i)
+        h_costs[i] = tmp[i];
+    return AGC_HIP_OK;
+}
+
+static int lz_split_point_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid1, const uint32_t *h_gid2, const PackedSrc &src, const uint64_t *h_off,
+                               const uint32_t *h_len, const uint8_t *h_rc1, const uint8_t *h_prefix1, const uint8_t *h_rc2, const uint8_t *h_prefix2,
+                               uint32_t *h_best_pos, uint32_t *h_best_sum)
+{
+    // 2n cost-vector parses: job 2s = (gid1, rc1, prefix1), job 2s+1 = (gid2, rc2, prefix2)
+    const uint32_t m = 2 * n;
+    std::vector<uint32_t> gid(m), len(m);
+    std::vector<uint64_t> off(m);
+    std::vector<uint8_t> rc(m), pf(m);
+    for (uint32_t s = 0; s < n; ++s) {
+        gid[2 * s] = h_gid1[s];
+        gid[2 * s + 1] = h_gid2[s];
+        off[2 * s] = off[2 * s + 1] = h_off[s];
+        len[2 * s] = len[2 * s + 1] = h_len[s];
+        rc[2 * s] = h_rc1[s];
+        rc[2 * s + 1] = h_rc2[s];
+        pf[2 * s] = h_prefix1[s];
+        pf[2 * s + 1] = h_prefix2[s];
+    }
+    Batch b;
+    CHK(prepare_batch(c, MODE_COSTVEC, m, gid.data(), src, off.data(), len.data(), rc.data(), pf.data(), b));
+    CHK(ensure(c, c->d_scratch, b.out_total + 64));
+    CHK(launch_parse<MODE_COSTVEC>(c, m, nullptr, (uint32_t *)c->d_scratch.p));
+    std::vector<SplitJob> jobs(n);
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        jobs[s].off1 = o;
+        jobs[s].off2 = o + h_len[s];
+        jobs[s].n = h_len[s];
+        jobs[s].rev1 = h_prefix1[s] ? 0u : 1u;
+        jobs[s].rev2 = h_prefix2[s] ? 1u : 0u;
+        jobs[s].pad = 0;
+        o += 2ULL * h_len[s];
+    }
+    CHK(ensure(c, c->d_jobs, (size_t)n * sizeof(SplitJob)));
+    CHK(ensure(c, c->d_dstoff, (size_t)n * 8));
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n * sizeof(SplitJob), hipMemcpyHostToDevice, c->stream));
+    uint32_t *d_pos = (uint32_t *)c->d_dstoff.p, *d_sum = d_pos + n;
+    {
+        KTimer t(c, AGC_HIP_K_COSTVEC);
+        hipLaunchKernelGGL(split_point_kernel, dim3(n), dim3(256), 0, c->stream, (const SplitJob *)c->d_jobs.p,
+                           (const cost_t *)c->d_scratch.p, d_pos, d_sum);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_best_pos, d_pos, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_best_sum)
+        HIPCHK(c, hipMemcpyAsync(h_best_sum, d_sum, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+static int fetch_slices_impl(agc_hip_ctx *c, uint32_t n, const PackedSrc &src, const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
+                             uint8_t *h_out, uint64_t out_cap, uint64_t *h_out_off)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        h_out_off[i + 1] = h_out_off[i] + h_len[i];
+    const uint64_t tot = h_out_off[n];
+    if (tot > out_cap)
+        return AGC_HIP_ECAP;
+    if (!tot)
+        return AGC_HIP_OK;
+    if (!h_out)
+        return AGC_HIP_EINVAL;
+    if (!slices_inside(src, n, h_off, h_len))
+        return AGC_HIP_EINVAL;
+    CHK(ensure(c, c->d_compact, tot + 64));
+    std::vector<ViewJob> sl(n);
+    for (uint32_t i = 0; i < n; ++i)
+        sl[i] = {{src.words, src.esc_index, src.esc_bytes, h_off[i], h_len[i], h_rc ? (uint32_t)(h_rc[i] != 0) : 0u}, (uint8_t *)c->d_compact.p + h_out_off[i]};
+    CHK(ensure(c, c->d_slices, (size_t)n * sizeof(ViewJob)));
+    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(ViewJob), hipMemcpyHostToDevice, c->stream));
+    {
+        KTimer t(c, AGC_HIP_K_REVCOMP);
+        hipLaunchKernelGGL(slice_expand_kernel, dim3(grid_for(n, 1, 65536)), dim3(256), 0, c->stream, (const ViewJob *)c->d_slices.p, n);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_out, c->d_compact.p, tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+static int ref_lag_counts_impl(agc_hip_ctx *c, uint32_t n, const PackedSrc &src, const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
+                               uint32_t *h_cnt, uint32_t *h_cur)
+{
+    if (!slices_inside(src, n, h_off, h_len))
+        return AGC_HIP_EINVAL;
+    std::vector<ViewJob> sl(n);
+    for (uint32_t i = 0; i < n; ++i)
+        sl[i] = {{src.words, src.esc_index, src.esc_bytes, h_off[i], h_len[i], h_rc ? (uint32_t)(h_rc[i] != 0) : 0u}, nullptr};
+    CHK(ensure(c, c->d_slices, (size_t)n * sizeof(ViewJob)));
+    CHK(ensure(c, c->d_lag, (size_t)n * 28 * 4 * 2));
+    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(ViewJob), hipMemcpyHostToDevice, c->stream));
+    uint32_t *d_cnt = (uint32_t *)c->d_lag.p, *d_cur = d_cnt + (size_t)n * 28;
+    const uint32_t split = n >= 2048 ? 1u : std::min<uint32_t>(32u, 2048u / n);
+    HIPCHK(c, hipMemsetAsync(c->d_lag.p, 0, (size_t)n * 28 * 4 * 2, c->stream));
+    {
+        KTimer t(c, AGC_HIP_K_REFSTORE);
+        hipLaunchKernelGGL(lag_counts_kernel, dim3(n * split), dim3(256), 0, c->stream, (const ViewJob *)c->d_slices.p, d_cnt, d_cur, split);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_cur, d_cur, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AGC_HIP_OK;
+}
+
+extern "C" {
+
+// ---- sequences in a 2-bit packed buffer -------------------------------------
+int agc_hip_lz_estimate_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
+                                     const uint32_t *h_len, const uint8_t *h_rc, uint32_t *h_cost, uint32_t *h_peak)
+{
+    if (!c || (n && (!h_gid || !h_off || !h_len || !pk || !pk->d_words || !h_cost)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return lz_estimate_impl(c, n, h_gid, src_of(pk), h_off, h_len, h_rc, h_cost, h_peak);
+}
+
+int agc_hip_lz_cost_vector_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
+                                        const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix_costs, uint32_t *h_costs)
+{
+    if (!c || (n && (!h_gid || !h_off || !h_len || !pk || !pk->d_words || !h_costs)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return lz_cost_vector_impl(c, n, h_gid, src_of(pk), h_off, h_len, h_rc, h_prefix_costs, h_costs);
+}
+
+int agc_hip_lz_split_point_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid1, const uint32_t *h_gid2, const agc_hip_packed *pk,
+                                        const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc1, const uint8_t *h_prefix1,
+                                        const uint8_t *h_rc2, const uint8_t *h_prefix2, uint32_t *h_best_pos, uint32_t *h_best_sum)
+{
+    if (!c || (n && (!h_gid1 || !h_gid2 || !pk || !pk->d_words || !h_off || !h_len || !h_rc1 || !h_prefix1 || !h_rc2 || !h_prefix2 || !h_best_pos)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return lz_split_point_impl(c, n, h_gid1, h_gid2, src_of(pk), h_off, h_len, h_rc1, h_prefix1, h_rc2, h_prefix2, h_best_pos, h_best_sum);
+}
+
+int agc_hip_fetch_slices_packed(agc_hip_ctx *c, uint32_t n, const agc_hip_packed *pk, const uint64_t *h_off, const uint32_t *h_len,
+                                const uint8_t *h_rc, uint8_t *h_out, uint64_t out_cap, uint64_t *h_out_off)
+{
+    if (!c || !h_out_off || (n && (!pk || !pk->d_words || !h_off || !h_len)))
+        return AGC_HIP_EINVAL;
+    h_out_off[0] = 0;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return fetch_slices_impl(c, n, src_of(pk), h_off, h_len, h_rc, h_out, out_cap, h_out_off);
+}
+
+int agc_hip_ref_lag_counts_packed(agc_hip_ctx *c, uint32_t n, const agc_hip_packed *pk, const uint64_t *h_off, const uint32_t *h_len,
+                                  const uint8_t *h_rc, uint32_t *h_cnt, uint32_t *h_cur)
+{
+    if (!c || (n && (!pk || !pk->d_words || !h_off || !h_len || !h_cnt || !h_cur)))
+        return AGC_HIP_EINVAL;
+    if (!n)
+        return AGC_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return ref_lag_counts_impl(c, n, src_of(pk), h_off, h_len, h_rc, h_cnt, h_cur);
+}
+
+// ---- one byte per symbol (device): packed first -------------------------------
 int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
                                   const uint32_t *h_len, const uint8_t *h_rc, uint32_t *h_cost, uint32_t *h_peak)
 {
@@ -1487,14 +1861,10 @@ int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_
     if (!n)
         return AGC_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    Batch b;
-    CHK(prepare_batch(c, MODE_ESTIMATE, n, h_gid, d_base, h_off, h_len, h_rc, nullptr, b));
-    CHK(launch_parse<MODE_ESTIMATE>(c, n, nullptr, nullptr));
-    HIPCHK(c, hipMemcpyAsync(h_cost, c->d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_peak)
-        HIPCHK(c, hipMemcpyAsync(h_peak, c->d_resp.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return AGC_HIP_OK;
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n, h_off, h_len, c->pk1, c->stream, src, off2));
+    return lz_estimate_impl(c, n, h_gid, src, off2.data(), h_len, h_rc, h_cost, h_peak);
 }
 
 int agc_hip_lz_cost_vector_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base,
@@ -1506,17 +1876,10 @@ int agc_hip_lz_cost_vector_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t 
     if (!n)
         return AGC_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    Batch b;
-    CHK(prepare_batch(c, MODE_COSTVEC, n, h_gid, d_base, h_off, h_len, h_rc, h_prefix_costs, b));
-    CHK(ensure(c, c->d_scratch, b.out_total + 64)); // (one byte per position on the device: lz_kernels.hip, cost_t)
-    CHK(launch_parse<MODE_COSTVEC>(c, n, nullptr, (uint32_t *)c->d_scratch.p));
-    std::vector<uint8_t> tmp(b.out_total);
-    if (b.out_total)
-        HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_scratch.p, b.out_total, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (uint64_t i = 0; i < b.out_total; ++i)
-        h_costs[i] = tmp[i];
-    return AGC_HIP_OK;
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n, h_off, h_len, c->pk1, c->stream, src, off2));
+    return lz_cost_vector_impl(c, n, h_gid, src, off2.data(), h_len, h_rc, h_prefix_costs, h_costs);
 }
 
 // host-resident texts --------------------------------------------------------
@@ -1564,51 +1927,10 @@ int agc_hip_lz_split_point_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t 
     if (!n)
         return AGC_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    // 2n cost-vector parses: job 2s = (gid1, rc1, prefix1), job 2s+1 = (gid2, rc2, prefix2)
-    const uint32_t m = 2 * n;
-    std::vector<uint32_t> gid(m), len(m);
-    std::vector<uint64_t> off(m);
-    std::vector<uint8_t> rc(m), pf(m);
-    for (uint32_t s = 0; s < n; ++s) {
-        gid[2 * s] = h_gid1[s];
-        gid[2 * s + 1] = h_gid2[s];
-        off[2 * s] = off[2 * s + 1] = h_off[s];
-        len[2 * s] = len[2 * s + 1] = h_len[s];
-        rc[2 * s] = h_rc1[s];
-        rc[2 * s + 1] = h_rc2[s];
-        pf[2 * s] = h_prefix1[s];
-        pf[2 * s + 1] = h_prefix2[s];
-    }
-    Batch b;
-    CHK(prepare_batch(c, MODE_COSTVEC, m, gid.data(), d_base, off.data(), len.data(), rc.data(), pf.data(), b));
-    CHK(ensure(c, c->d_scratch, b.out_total + 64));
-    CHK(launch_parse<MODE_COSTVEC>(c, m, nullptr, (uint32_t *)c->d_scratch.p));
-    std::vector<SplitJob> jobs(n);
-    uint64_t o = 0;
-    for (uint32_t s = 0; s < n; ++s) {
-        jobs[s].off1 = o;
-        jobs[s].off2 = o + h_len[s];
-        jobs[s].n = h_len[s];
-        jobs[s].rev1 = h_prefix1[s] ? 0u : 1u;
-        jobs[s].rev2 = h_prefix2[s] ? 1u : 0u;
-        jobs[s].pad = 0;
-        o += 2ULL * h_len[s];
-    }
-    CHK(ensure(c, c->d_jobs, (size_t)n * sizeof(SplitJob)));
-    CHK(ensure(c, c->d_dstoff, (size_t)n * 8));
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n * sizeof(SplitJob), hipMemcpyHostToDevice, c->stream));
-    uint32_t *d_pos = (uint32_t *)c->d_dstoff.p, *d_sum = d_pos + n;
-    {
-        KTimer t(c, AGC_HIP_K_COSTVEC);
-        hipLaunchKernelGGL(split_point_kernel, dim3(n), dim3(256), 0, c->stream, (const SplitJob *)c->d_jobs.p,
-                           (const cost_t *)c->d_scratch.p, d_pos, d_sum);
-    }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(h_best_pos, d_pos, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_best_sum)
-        HIPCHK(c, hipMemcpyAsync(h_best_sum, d_sum, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return AGC_HIP_OK;
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n, h_off, h_len, c->pk1, c->stream, src, off2));
+    return lz_split_point_impl(c, n, h_gid1, h_gid2, src, off2.data(), h_len, h_rc1, h_prefix1, h_rc2, h_prefix2, h_best_pos, h_best_sum);
 }
 
 int agc_hip_fetch_slices_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base, const uint64_t *h_off, const uint32_t *h_len,
@@ -1620,29 +1942,10 @@ int agc_hip_fetch_slices_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base, 
     if (!n)
         return AGC_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    for (uint32_t i = 0; i < n; ++i)
-        h_out_off[i + 1] = h_out_off[i] + h_len[i];
-    const uint64_t tot = h_out_off[n];
-    if (tot > out_cap)
-        return AGC_HIP_ECAP;
-    if (!tot)
-        return AGC_HIP_OK;
-    if (!h_out)
-        return AGC_HIP_EINVAL;
-    CHK(ensure(c, c->d_compact, tot + 64));
-    std::vector<SliceDesc> sl(n);
-    for (uint32_t i = 0; i < n; ++i)
-        sl[i] = {d_base + h_off[i], (uint8_t *)c->d_compact.p + h_out_off[i], h_len[i], h_rc ? (uint32_t)h_rc[i] : 0u, 0u, 0u};
-    CHK(ensure(c, c->d_slices, (size_t)n * sizeof(SliceDesc)));
-    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
-    {
-        KTimer t(c, AGC_HIP_K_REVCOMP);
-        hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(n, 1, 65536)), dim3(256), 0, c->stream, (const SliceDesc *)c->d_slices.p, n);
-    }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(h_out, c->d_compact.p, tot, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return AGC_HIP_OK;
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n, h_off, h_len, c->pk1, c->stream, src, off2));
+    return fetch_slices_impl(c, n, src, off2.data(), h_len, h_rc, h_out, out_cap, h_out_off);
 }
 
 // ---------------------------------------------------------------------------
@@ -1656,24 +1959,10 @@ int agc_hip_ref_lag_counts_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_base
     if (!n)
         return AGC_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<SliceDesc> sl(n);
-    for (uint32_t i = 0; i < n; ++i)
-        sl[i] = {d_base + h_off[i], nullptr, h_len[i], h_rc ? (uint32_t)h_rc[i] : 0u, 0u, 0u};
-    CHK(ensure(c, c->d_slices, (size_t)n * sizeof(SliceDesc)));
-    CHK(ensure(c, c->d_lag, (size_t)n * 28 * 4 * 2));
-    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(SliceDesc), hipMemcpyHostToDevice, c->stream));
-    uint32_t *d_cnt = (uint32_t *)c->d_lag.p, *d_cur = d_cnt + (size_t)n * 28;
-    const uint32_t split = n >= 2048 ? 1u : std::min<uint32_t>(32u, 2048u / n);
-    HIPCHK(c, hipMemsetAsync(c->d_lag.p, 0, (size_t)n * 28 * 4 * 2, c->stream));
-    {
-        KTimer t(c, AGC_HIP_K_REFSTORE);
-        hipLaunchKernelGGL(lag_counts_kernel, dim3(n * split), dim3(256), 0, c->stream, (const SliceDesc *)c->d_slices.p, d_cnt, d_cur, split);
-    }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_cur, d_cur, (size_t)n * 28 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return AGC_HIP_OK;
+    PackedSrc src;
+    std::vector<uint64_t> off2;
+    CHK(pack_range(c, d_base, n, h_off, h_len, c->pk1, c->stream, src, off2));
+    return ref_lag_counts_impl(c, n, src, off2.data(), h_len, h_rc, h_cnt, h_cur);
 }
 
 // ---------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "sym_view.h"
 
 namespace agc {
 
@@ -12,7 +13,6 @@ constexpr uint8_t INVALID_SYMBOL = 31;   // lz_diff.h:33
 constexpr uint8_t N_CODE = 4;            // lz_diff.h:34
 constexpr uint8_t N_RUN_STARTER = 30;    // lz_diff.h:35
 constexpr uint32_t MIN_NRUN_LEN = 4;     // lz_diff.h:36
-constexpr uint32_t REF_TAIL_PAD = 64;    // bytes of INVALID_SYMBOL kept after every stored reference
 
 // One registered group reference in HBM.
 // Index entries: short form (ref/4 < 65535, lz_diff.cpp:146): u32 = pos16<<16 | fp16,
@@ -37,7 +37,14 @@ __host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t &word, uin
 }
 
 struct RefDesc {
-    const uint8_t *ref;   // ref_size symbols + >= key_len + REF_TAIL_PAD bytes of 31
+    // the reference's symbols in the 2-bit layout (sym_view.h): symbol i at bits [2 (i & 15), +1] of words[i >> 4], followed by
+    // at least REF_TAIL_WORDS words of slack.  A reference holding anything outside ACGT (rare: N runs, IUPAC codes) also has
+    // esc_index / esc_bytes: esc_index[b] = b when block b (1024 symbols) holds such a symbol -- its symbols are then read one
+    // byte each from esc_bytes + 1024 b -- and -1 otherwise.  esc_index == nullptr: every symbol is ACGT.
+    // There is no padding with INVALID_SYMBOL (prepare_gen, lz_diff.cpp:48-53): compares are bounded by ref_size instead.
+    const uint32_t *words;
+    const int32_t *esc_index;
+    const uint8_t *esc_bytes;
     const void *table;    // ht_mask+1 entries
     const unsigned long long *bloom; // KEY_BLOOM_WORDS words (nullptr: none)
     uint32_t ref_size;
@@ -47,25 +54,24 @@ struct RefDesc {
     uint32_t is_short;
     uint32_t valid;
 };
+constexpr uint32_t REF_TAIL_WORDS = 4;
 
-// One sequence to parse.
+// One sequence to parse: a view into a 2-bit packed buffer (the sample), read reverse-complemented when text.rc.
 struct SegDesc {
-    const uint8_t *text;  // oriented symbols (already reverse-complemented if needed)
+    SymView text;
     const unsigned long long *maybe; // estimate / cost vector: one bit per text position, 0 = certainly a literal (nullptr: none)
-    uint64_t out_off;     // encode: byte offset in the scratch output; cost vector: u32 offset
-    uint32_t len;
+    uint64_t out_off;     // encode: byte offset in the scratch output; cost vector: cost_t offset
     uint32_t ref_slot;    // index into the RefDesc array
     uint32_t flags;       // bit0: prefix_costs (cost-vector mode)
+    uint32_t idx;         // index in the caller's order
     uint32_t pad;
 };
 
-struct SliceDesc {
-    const uint8_t *src;
-    uint8_t *dst;
-    uint32_t len;
-    uint32_t rc;          // reverse-complement while copying
-    uint32_t pad_len;     // bytes of INVALID_SYMBOL appended after dst[len)
-    uint32_t pad2;
+// a sequence to copy out of a packed buffer: as bytes (slice_expand_kernel), as 2-bit words from bit 0 (ref_pack_kernel), or
+// to count lags in (lag_counts_kernel)
+struct ViewJob {
+    SymView src;
+    void *dst;
 };
 
 struct ScanRange {

@@ -579,21 +579,16 @@ bool CAGCCompressor::PrepareSamplePackedDevice(const std::string &sample_name, c
     if (!I.created || !packed)
         return false;
     const agc_hip_packed &pk = *(const agc_hip_packed *)packed;
-    // byte staging copy for the LZ kernels (context-owned buffer, valid until the next sample): made ahead of time when this is
-    // the sample that was announced (its scan is then collected instead of launched: scan_batch)
-    uint8_t *d_codes = nullptr;
-    I.scan_from_prefetch = false;
-    if (I.pf_live.valid && I.pf_live.pk.d_words == pk.d_words && I.pf_live.pk.n_symbols == pk.n_symbols &&
-        I.pf_live.ctg_off.size() == contig_names.size() + 1 && std::equal(I.pf_live.ctg_off.begin(), I.pf_live.ctg_off.end(), ctg_off)) {
-        d_codes = I.pf_live.d_codes;
-        I.scan_from_prefetch = true;
-    } else if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, pk.n_symbols + 64, &d_codes)), "sample_buffer") ||
-               !I.hip_ok(DEVTI(agc_hip_expand_dev(I.hip, &pk, d_codes)), "expand"))
-        return false;
+    // every kernel reads the 2-bit words where they lie (no byte copy is made).  When this is the sample that was announced its
+    // scan ran ahead of its turn and is collected instead of launched (scan_batch).
+    I.scan_from_prefetch = I.pf_live.valid && I.pf_live.pk.d_words == pk.d_words && I.pf_live.pk.n_symbols == pk.n_symbols &&
+                           I.pf_live.ctg_off.size() == contig_names.size() + 1 && std::equal(I.pf_live.ctg_off.begin(), I.pf_live.ctg_off.end(), ctg_off);
     I.pf_live.valid = false;
     I.packed_sample = pk;
-    I.next_base_owned = true; // (the byte staging copy is the device context's: it outlives this sample's calls)
-    const bool ok = PrepareSampleDevice(sample_name, contig_names, d_codes, ctg_off);
+    // (the caller keeps a packed sample untouched until the NEXT sample call, Drain or Close returns: its LZ encode may be
+    // collected by the bookkeeping thread after this call has returned -- compressor.h)
+    I.next_base_owned = true;
+    const bool ok = PrepareSampleDevice(sample_name, contig_names, nullptr, ctg_off);
     I.next_base_owned = false;
     I.packed_sample.n_symbols = 0; // (scans of the commit phase -- adaptive mode -- run inside PrepareSampleDevice as well)
     I.scan_from_prefetch = false;
@@ -612,18 +607,25 @@ bool CAGCCompressor::SetNextSamplePackedDevice(const void *packed, const uint64_
     return I.pf_next.valid;
 }
 
-// queues the announced sample's expansion + scan on the device (called once the current sample's own scan is in)
+// bytes in HBM -> the 2-bit layout in the device context's own buffers: every LZ entry point reads that form only
+bool CAGCCompressor::Impl::pack_sample(const uint8_t *d_codes, uint64_t n_symbols)
+{
+    packed_sample = agc_hip_packed{};
+    if (!n_symbols)
+        return true;
+    return hip_ok(DEVT(agc_hip_sample_pack(hip, d_codes, n_symbols, &packed_sample)), "sample_pack");
+}
+
+// queues the announced sample's scan on the device (called once the current sample's own classification kernels are in)
 void CAGCCompressor::Impl::launch_prefetch()
 {
     if (!pf_next.valid)
         return;
     pf_next.valid = false;
-    uint8_t *d = nullptr;
-    if (agc_hip_prefetch_packed_dev(hip, &pf_next.pk, pf_next.ctg_off.data(), (uint32_t)pf_next.ctg_off.size() - 1, k, &d) != AGC_HIP_OK)
+    if (agc_hip_prefetch_packed_dev(hip, &pf_next.pk, pf_next.ctg_off.data(), (uint32_t)pf_next.ctg_off.size() - 1, k) != AGC_HIP_OK)
         return; // (nothing lost: the sample goes the ordinary way when its turn comes)
     pf_live.pk = pf_next.pk;
     pf_live.ctg_off.swap(pf_next.ctg_off);
-    pf_live.d_codes = d;
     pf_live.valid = true;
 }
 
@@ -636,6 +638,25 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
     Impl &I = *p;
     if (!I.created || I.concatenated || I.prepared || I.committing || I.prep.deferred)
         return false;
+    // a sample handed over one byte per symbol is packed first (context-owned buffers: they outlive this call)
+    struct Unpack {
+        Impl &I;
+        bool on = false, owned = false;
+        ~Unpack()
+        {
+            if (on) {
+                I.packed_sample.n_symbols = 0;
+                I.next_base_owned = owned;
+            }
+        }
+    } unpack{I};
+    if (!I.packed_sample.n_symbols && d_codes && !contig_names.empty() && ctg_off[contig_names.size()]) {
+        if (!I.pack_sample(d_codes, ctg_off[contig_names.size()]))
+            return false;
+        unpack.on = true;
+        unpack.owned = I.next_base_owned;
+        I.next_base_owned = true;
+    }
     I.prepared_ctgs.clear();
     for (size_t c = 0; c < contig_names.size(); ++c) {
         Contig ct;
@@ -813,8 +834,10 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
             }
         I.st.t_io += now() - t0;
         uint32_t n_done = 0;
-        I.next_base_owned = true; // (agc_hip_sample_buffer)
-        const bool batch_ok = I.process_batch(batch, d_base, I.adaptive ? &batch_data : nullptr, n_done);
+        I.next_base_owned = true; // (agc_hip_sample_buffer / agc_hip_sample_pack)
+        // the window in the 2-bit layout: what the scan (k >= 16) and every LZ entry point read
+        const bool batch_ok = I.pack_sample(d_base, o) && I.process_batch(batch, d_base, I.adaptive ? &batch_data : nullptr, n_done);
+        I.packed_sample.n_symbols = 0;
         I.next_base_owned = false;
         if (!batch_ok)
             return false;

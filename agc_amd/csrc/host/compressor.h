@@ -36,6 +36,7 @@ struct CompressorStats {
     double t_zstd_dev = 0, t_zstd_host = 0, t_zstd_stage = 0; // entropy stage: device call, host pool, staging copies (all inside t_zstd)
     double t_zstd_wait = 0;        // time the caller stood still for the entropy stage (t_zstd runs beside the steps; this part was not hidden)
     uint64_t zstd_dev_in = 0;      // bytes entropy-coded on the GPU (part of zstd_in)
+    uint64_t zstd_dev_out = 0;     // bytes of the frames it wrote (counted, not estimated)
     uint64_t enc_text = 0, enc_ref = 0, est_text = 0, est_ref = 0, cv_text = 0, cv_ref = 0;
     uint64_t windows = 0, commit_runs = 0, revalidated = 0; // process_batch calls, commit runs inside them, segments classified again
     uint64_t reprepared = 0;       // multi-GPU + adaptive mode: samples whose prepare ahead of the turn did not stand (prepared again at the turn)
@@ -103,15 +104,17 @@ public:
     bool CommitPreparedHead();
     bool CommitPreparedFinish();
     // the same for a sample resident in HBM in the 2-bit layout (include/agc_hip.h: agc_hip_packed; contig c = symbols
-    // [ctg_off[c], ctg_off[c+1]) of the packed buffer): the splitter scan reads the packed words, the LZ kernels a byte staging
-    // copy expanded inside the call
+    // [ctg_off[c], ctg_off[c+1]) of the packed buffer): scan, LZ estimates / cost vectors / encode and the store of new references
+    // all read the packed words where they lie -- no byte copy of the sample is made.  The caller leaves the packed buffers
+    // untouched until the NEXT sample call, Drain or Close has returned (the sample's LZ encode may still be in flight on the
+    // device's second lane when the call returns; the bookkeeping thread collects it)
     bool PrepareSamplePackedDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const void *packed,
                                    const uint64_t *ctg_off);
     bool AddSamplePackedDevice(const std::string &sample_name, const std::vector<std::string> &contig_names, const void *packed,
                                const uint64_t *ctg_off);
-    // The caller that knows its NEXT packed sample says so before it adds the current one: the next sample's expansion and splitter
-    // scan are queued on the device (include/agc_hip.h: agc_hip_prefetch_packed_dev) as soon as the current sample's scan is in,
-    // and run beside its classification / encode / registration -- the reference's workers likewise take contigs of later samples
+    // The caller that knows its NEXT packed sample says so before it adds the current one: the next sample's splitter
+    // scan is queued on the device (include/agc_hip.h: agc_hip_prefetch_packed_dev) as soon as the current sample's classification
+    // kernels are in, and runs beside its classification / encode / registration -- the reference's workers likewise take contigs of later samples
     // from the queue while earlier ones register (agc_compressor.cpp:1093-1272).  The announced sample must then be the next one
     // added (otherwise the work is dropped); not used in adaptive mode (new splitters change later scans).
     bool SetNextSamplePackedDevice(const void *packed, const uint64_t *ctg_off, uint32_t n_ctg);

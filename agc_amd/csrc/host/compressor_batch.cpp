@@ -508,8 +508,10 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 finish(j, packed, ps, j.kind == 0 ? j.marker : 0);
                 bytes_t().swap(j.staged);
             });
-            if (!ext)
+            if (!ext) {
                 st.zstd_dev_in += src_off[dev_jobs.size()];
+                st.zstd_dev_out += dst_off[dev_jobs.size()];
+            }
             st.t_zstd_stage += now() - ts1;
             // rates of this call -> share of the next one (only meaningful when both had a real amount of work)
             if (!ext && src_off[dev_jobs.size()] > (8u << 20) && host_bytes > (8u << 20) && t_dev > 0 && t_host > 0 && !getenv("AGC_AMD_GPU_ZSTD_SHARE")) {
@@ -574,6 +576,14 @@ int CAGCCompressor::Impl::scan_batch(const std::vector<uint64_t> &ctg_off, uint3
             h_rc.resize(cap);
         }
         cap = h_ctg.size();
+        if (packed_sample.n_symbols && k < 16 && !d_base) {
+            // (the packed scan's suffix filter needs k >= 16: such a sample is expanded once for the byte scan)
+            uint8_t *d = nullptr;
+            if (!hip_ok(DEVT(agc_hip_sample_buffer(hip, packed_sample.n_symbols + 64, &d)), "sample_buffer") ||
+                !hip_ok(DEVT(agc_hip_expand_dev(hip, &packed_sample, d)), "expand"))
+                return AGC_HIP_ENODEV;
+            d_base = d;
+        }
         int rc = (packed_sample.n_symbols && k >= 16)
                      ? (scan_from_prefetch ? DEVT(agc_hip_scan_prefetched(hip, &packed_sample, ctg_off.data(), n_ctg, k, cap, &n_hits, h_ctg.data(),
                                                                           h_pos.data(), h_dir.data(), h_rc.data()))
@@ -631,6 +641,7 @@ bool CAGCCompressor::Impl::batch_prepare(BatchState &b, std::vector<Contig> &ctg
     b.host_data = host_data;
     b.n_ctg = (uint32_t)ctgs.size();
     b.base_owned = next_base_owned;
+    b.pk = packed_sample; // (n_symbols != 0: the LZ entry points read the sample's 2-bit words where they lie)
     b.t0 = now();
     b.dev0 = st.t_device;
     b.lap_t = b.t0;
@@ -709,8 +720,10 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
     for (;;) {
         if (enc.size() < base + cap)
             enc.resize(base + cap);
-        int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), b.d_base, off.data(), len.data(), rc.data(), enc.data() + base, cap,
-                                                 eoff.data()));
+        int r = b.pk.n_symbols ? DEVT(agc_hip_lz_encode_batch_packed(hip, (uint32_t)ne, gid.data(), &b.pk, off.data(), len.data(), rc.data(), enc.data() + base,
+                                                                      cap, eoff.data()))
+                               : DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), b.d_base, off.data(), len.data(), rc.data(), enc.data() + base, cap,
+                                                                  eoff.data()));
         if (r == AGC_HIP_ECAP) {
             cap = eoff[ne] + eoff[ne] / 8 + 4096; // (headroom: the next sample's deltas are a little longer, and a retry runs the kernel again)
             continue;
@@ -773,8 +786,10 @@ bool CAGCCompressor::Impl::overlap_encode_begin(BatchState &b)
     }
     if (b.flight_keys.empty())
         return true;
-    if (!hip_ok(DEVT(agc_hip_lz_encode_begin_dev(hip, (uint32_t)b.flight_keys.size(), b.flight_gid.data(), b.d_base, b.flight_off.data(),
-                                                 b.flight_len.data(), b.flight_rc.data())),
+    if (!hip_ok(b.pk.n_symbols ? DEVT(agc_hip_lz_encode_begin_packed(hip, (uint32_t)b.flight_keys.size(), b.flight_gid.data(), &b.pk, b.flight_off.data(),
+                                                                     b.flight_len.data(), b.flight_rc.data()))
+                               : DEVT(agc_hip_lz_encode_begin_dev(hip, (uint32_t)b.flight_keys.size(), b.flight_gid.data(), b.d_base, b.flight_off.data(),
+                                                                  b.flight_len.data(), b.flight_rc.data())),
                 "lz_encode_begin"))
         return false;
     b.enc_in_flight = true;
@@ -924,7 +939,9 @@ bool CAGCCompressor::Impl::stage_scan(BatchState &b)
                     tot += len[i];
                 }
                 bytes_t buf(tot);
-                if (!hip_ok(DEVT(agc_hip_fetch_slices_dev(hip, (uint32_t)need.size(), d_base, off.data(), len.data(), nullptr, buf.data(), tot, ooff.data())), "fetch_slices"))
+                if (!hip_ok(b.pk.n_symbols ? DEVT(agc_hip_fetch_slices_packed(hip, (uint32_t)need.size(), &b.pk, off.data(), len.data(), nullptr, buf.data(), tot, ooff.data()))
+                                           : DEVT(agc_hip_fetch_slices_dev(hip, (uint32_t)need.size(), d_base, off.data(), len.data(), nullptr, buf.data(), tot, ooff.data())),
+                            "fetch_slices"))
                     return false;
                 for (size_t i = 0; i < need.size(); ++i)
                     fetched_ctg[i].assign(buf.begin() + ooff[i], buf.begin() + ooff[i + 1]);
@@ -1181,8 +1198,10 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         }
         std::vector<uint32_t> cost(which.size()), peak(which.size());
         if (!which.empty() &&
-            !hip_ok(DEVT(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)which.size(), gid.data(), d_base, off.data(), len.data(), rc.data(), cost.data(),
-                                                  peak.data())),
+            !hip_ok(b.pk.n_symbols ? DEVT(agc_hip_lz_estimate_batch_packed(hip, (uint32_t)which.size(), gid.data(), &b.pk, off.data(), len.data(), rc.data(),
+                                                                           cost.data(), peak.data()))
+                                   : DEVT(agc_hip_lz_estimate_batch_dev(hip, (uint32_t)which.size(), gid.data(), d_base, off.data(), len.data(), rc.data(),
+                                                                        cost.data(), peak.data())),
                     "lz_estimate_batch"))
             return false;
         for (size_t i = 0; i < which.size(); ++i) {
@@ -1371,8 +1390,10 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
             st.cv_text += 2ull * s.len;
             st.cv_ref += groups[g1[i]].ref_size + groups[g2[i]].ref_size - 2;
         }
-        if (!hip_ok(DEVT(agc_hip_lz_split_point_batch_dev(hip, (uint32_t)n, g1.data(), g2.data(), d_base, off.data(), len.data(), r1.data(),
-                                                     p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr)),
+        if (!hip_ok(b.pk.n_symbols ? DEVT(agc_hip_lz_split_point_batch_packed(hip, (uint32_t)n, g1.data(), g2.data(), &b.pk, off.data(), len.data(), r1.data(),
+                                                                              p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr))
+                                   : DEVT(agc_hip_lz_split_point_batch_dev(hip, (uint32_t)n, g1.data(), g2.data(), d_base, off.data(), len.data(), r1.data(),
+                                                                           p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr)),
                     "lz_split_point_batch"))
             return false;
     }
@@ -1743,7 +1764,9 @@ bool CAGCCompressor::Impl::stage_store_head(BatchState &b)
             }
             lag_cnt.resize(nr * 28);
             lag_cur.resize(nr * 28);
-            if (!hip_ok(DEVT(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data())), "ref_lag_counts"))
+            if (!hip_ok(b.pk.n_symbols ? DEVT(agc_hip_ref_lag_counts_packed(hip, (uint32_t)nr, &b.pk, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data()))
+                                       : DEVT(agc_hip_ref_lag_counts_dev(hip, (uint32_t)nr, d_base, off.data(), len.data(), rc.data(), lag_cnt.data(), lag_cur.data())),
+                        "ref_lag_counts"))
                 return false;
             // repetitiveness probe with the reference's double arithmetic (segment.h:224-247)
             repetitive.resize(nr);
@@ -1780,7 +1803,9 @@ bool CAGCCompressor::Impl::stage_store_head(BatchState &b)
             if (fetched.size() < tot)
                 fetched.resize(tot);
             fetched_off.resize(nf + 1);
-            if (!hip_ok(DEVT(agc_hip_fetch_slices_dev(hip, (uint32_t)nf, d_base, off.data(), len.data(), rc.data(), fetched.data(), tot, fetched_off.data())), "fetch_slices"))
+            if (!hip_ok(b.pk.n_symbols ? DEVT(agc_hip_fetch_slices_packed(hip, (uint32_t)nf, &b.pk, off.data(), len.data(), rc.data(), fetched.data(), tot, fetched_off.data()))
+                                       : DEVT(agc_hip_fetch_slices_dev(hip, (uint32_t)nf, d_base, off.data(), len.data(), rc.data(), fetched.data(), tot, fetched_off.data())),
+                        "fetch_slices"))
                 return false;
         }
     }
@@ -1821,7 +1846,9 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
                 len[i] = pl.len;
                 rc[i] = pl.rc;
             }
-            if (!hip_ok(DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml)), "ref_register_batch"))
+            if (!hip_ok(b.pk.n_symbols ? DEVT(agc_hip_ref_register_batch_packed(hip, (uint32_t)nr, gid.data(), &b.pk, off.data(), len.data(), rc.data(), mml))
+                                       : DEVT(agc_hip_ref_register_batch_dev(hip, (uint32_t)nr, gid.data(), d_base, off.data(), len.data(), rc.data(), mml)),
+                        "ref_register_batch"))
                 return false;
             LAP("ref_register");
         }
@@ -1868,8 +1895,8 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             // The encode is only LAUNCHED here when its result is first read by the bookkeeping task: the task collects it (second
             // device lane) while this thread goes on with the next sample.  Needs a sample in a staging buffer the device context
             // owns (it outlives the call) and nothing else on that lane.
-            if (hand_over && async_encode && dist_world == 1 && b.base_owned && overlap_mode == 0 && !b.enc_in_flight && b.spec_bytes == 0) {
-                if (!hip_ok(DEVT(agc_hip_lz_encode_begin_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data())), "lz_encode_begin"))
+            if (hand_over && async_encode && dist_world == 1 && b.base_owned && b.pk.n_symbols && overlap_mode == 0 && !b.enc_in_flight && b.spec_bytes == 0) {
+                if (!hip_ok(DEVT(agc_hip_lz_encode_begin_packed(hip, (uint32_t)ne, gid.data(), &b.pk, off.data(), len.data(), rc.data())), "lz_encode_begin"))
                     return false;
                 enc_later.swap(todo);
                 enc_later_text = tot;
@@ -1880,8 +1907,10 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             for (;;) {
                 if (enc.size() < cap)
                     enc.resize(cap);
-                int r = DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap,
-                                                         eoff.data()));
+                int r = b.pk.n_symbols ? DEVT(agc_hip_lz_encode_batch_packed(hip, (uint32_t)ne, gid.data(), &b.pk, off.data(), len.data(), rc.data(), enc.data(), cap,
+                                                                              eoff.data()))
+                                       : DEVT(agc_hip_lz_encode_batch_dev(hip, (uint32_t)ne, gid.data(), d_base, off.data(), len.data(), rc.data(), enc.data(), cap,
+                                                                          eoff.data()));
                 if (r == AGC_HIP_ECAP) {
                     cap = eoff[ne] + eoff[ne] / 8 + 4096; // (headroom: the next sample's deltas are a little longer, and a retry runs the kernel again)
                     continue;

@@ -829,7 +829,8 @@ struct CAGCCompressor::Impl {
     bool process_batch(std::vector<Contig> &ctgs, const uint8_t *d_base, const std::vector<bytes_t> *host_data, uint32_t &n_committed);
     struct BatchState { // working set of one process_batch call
         std::vector<Contig> *ctgs = nullptr;
-        const uint8_t *d_base = nullptr;
+        const uint8_t *d_base = nullptr;           // one byte per symbol (nullptr when the sample came packed and nothing needed bytes)
+        agc_hip_packed pk{};                       // the sample in the 2-bit layout: what every LZ entry point reads (n_symbols != 0)
         const std::vector<bytes_t> *host_data = nullptr;
         uint32_t n_ctg = 0;
         double t0 = 0, dev0 = 0, lap_t = 0;
@@ -900,7 +901,6 @@ struct CAGCCompressor::Impl {
     struct NextSample {
         agc_hip_packed pk{};
         std::vector<uint64_t> ctg_off;
-        uint8_t *d_codes = nullptr;
         bool valid = false;
     } pf_next, pf_live;
     bool scan_from_prefetch = false;   // the sample being prepared is pf_live: its first scan is collected, not launched
@@ -982,6 +982,7 @@ struct CAGCCompressor::Impl {
     // (v_candidate_kmers / v_duplicated_kmers, agc_compressor.cpp:493-497)
     std::vector<uint64_t> ref_singletons, ref_duplicates;
     bool find_new_splitters(const bytes_t &ctg, std::vector<uint64_t> &out);
+    bool pack_sample(const uint8_t *d_codes, uint64_t n_symbols); // bytes in HBM -> packed_sample (the context's own packed buffers)
     int scan_batch(const std::vector<uint64_t> &ctg_off, uint32_t n_ctg, const uint8_t *d_base, std::vector<uint32_t> &h_ctg,
                    std::vector<uint64_t> &h_pos, std::vector<uint64_t> &h_dir, std::vector<uint64_t> &h_rc, uint64_t &n_hits);
     void after_registration();

@@ -48,36 +48,61 @@ __device__ __forceinline__ uint64_t spread_bits(uint64_t x)
     return x;
 }
 
-__device__ __forceinline__ uint32_t first_diff_byte16(const uint4 &a, const uint4 &b)
+// wave-uniform values the compiler cannot prove uniform (descriptor fields loaded through an index derived from threadIdx):
+// kept in scalar registers explicitly
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
 {
-    uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
-    if (d0)
-        return (uint32_t)(__builtin_ctz(d0) >> 3);
-    if (d1)
-        return 4 + (uint32_t)(__builtin_ctz(d1) >> 3);
-    if (d2)
-        return 8 + (uint32_t)(__builtin_ctz(d2) >> 3);
-    if (d3)
-        return 12 + (uint32_t)(__builtin_ctz(d3) >> 3);
-    return 16;
+    const uint32_t lo = uniform_u32((uint32_t)v), hi = uniform_u32((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ T *uniform_ptr(T *p) { return (T *)uniform_u64((uint64_t)p); }
+__device__ __forceinline__ SymView uniform_view(const SymView &v)
+{
+    SymView u;
+    u.words = uniform_ptr(v.words);
+    u.esc_index = uniform_ptr(v.esc_index);
+    u.esc_bytes = uniform_ptr(v.esc_bytes);
+    u.start = uniform_u64(v.start);
+    u.len = uniform_u32(v.len);
+    u.rc = uniform_u32(v.rc);
+    return u;
 }
 
-__device__ __forceinline__ uint4 load16(const uint8_t *p)
+// no block the sequence touches is escaped (whole wave; one index entry per lane and step)
+__device__ bool wave_view_clean(const SymView &v)
 {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16); // byte-aligned global_load_dwordx4 (unaligned access mode)
-    return v;
+    if (!v.esc_index || !v.len)
+        return true;
+    const uint64_t b0 = v.start / SV_BLOCK, b1 = (v.start + v.len - 1) / SV_BLOCK;
+    bool any = false;
+    for (uint64_t b = b0 + lane_id(); b <= b1; b += WAVE)
+        any = any || v.esc_index[b] >= 0;
+    return __ballot(any) == 0;
 }
 
-// Per-wave window of the text in LDS: the symbols the parse is about to look at (keys of the next
-// positions) without another trip to HBM.  It is refilled from global memory when the parse
-// position leaves it and -- for free -- by the last 1 KiB step of every forward compare, whose text
-// chunk contains the position right after the match.
-constexpr uint32_t WIN_BYTES = 1024;
+// 32 symbols (P, I as sv_fetch32 delivers them; cnt of them valid) as bytes at dst (LDS, 32-byte aligned)
+__device__ __forceinline__ void store_syms32(uint8_t *dst, const SymView &v, uint32_t pos, uint32_t cnt, uint64_t P, uint32_t I)
+{
+    if (cnt == 32 && I == 0) {
+        const uint32_t lo = (uint32_t)P, hi = (uint32_t)(P >> 32);
+        *(uint4 *)dst = make_uint4(sv_expand4(lo), sv_expand4(lo >> 8), sv_expand4(lo >> 16), sv_expand4(lo >> 24));
+        *(uint4 *)(dst + 16) = make_uint4(sv_expand4(hi), sv_expand4(hi >> 8), sv_expand4(hi >> 16), sv_expand4(hi >> 24));
+    } else {
+        for (uint32_t j = 0; j < cnt; ++j)
+            dst[j] = (uint8_t)(((I >> j) & 1u) ? sv_sym(v, pos + j) : (uint32_t)(P >> (2u * j)) & 3u);
+    }
+}
+
+// Per-wave window of the text in LDS, one byte per symbol: the symbols the parse is about to look at (keys of the next
+// positions) without another trip to HBM.  It is refilled from the packed words when the parse position leaves it (512 bytes
+// of HBM for 2048 symbols) and -- for free -- by the last step of every forward compare, whose text chunk contains the
+// position right after the match.
+constexpr uint32_t CMP_SYMS = 32;              // symbols a lane compares per step: one 64-bit XOR
+constexpr uint32_t WIN_SYMS = WAVE * CMP_SYMS; // 2048
 struct TextWin {
-    uint8_t *lds;   // WIN_BYTES bytes of LDS owned by this wave
+    uint8_t *lds;   // WIN_SYMS bytes of LDS owned by this wave
     uint32_t base;  // text position of lds[0]
-    uint32_t len;   // valid bytes
+    uint32_t len;   // valid symbols
 };
 
 __device__ __forceinline__ bool win_has(const TextWin &w, uint32_t pos, uint32_t cnt)
@@ -85,85 +110,84 @@ __device__ __forceinline__ bool win_has(const TextWin &w, uint32_t pos, uint32_t
     return pos >= w.base && pos + cnt <= w.base + w.len;
 }
 
-__device__ __forceinline__ void win_fill(TextWin &w, const uint8_t *__restrict__ text, uint32_t n, uint32_t pos)
+__device__ __forceinline__ void win_fill(TextWin &w, const SymView &tv, bool t_clean, uint32_t n, uint32_t pos)
 {
     const uint32_t lane = lane_id();
-    const uint32_t len = n - pos < WIN_BYTES ? n - pos : WIN_BYTES;
-    const uint32_t off = lane * 16;
+    const uint32_t len = n - pos < WIN_SYMS ? n - pos : WIN_SYMS;
+    const uint32_t off = lane * CMP_SYMS;
     if (off < len) {
-        if (len - off >= 16) {
-            const uint4 v = load16(text + pos + off);
-            *(uint4 *)(w.lds + off) = v;
-        } else {
-            for (uint32_t t = off; t < len; ++t)
-                w.lds[t] = text[pos + t];
-        }
+        const uint32_t cnt = len - off < CMP_SYMS ? len - off : CMP_SYMS;
+        uint64_t P;
+        uint32_t I;
+        sv_fetch32(tv, pos + off, cnt, t_clean, P, I);
+        store_syms32(w.lds + off, tv, pos + off, cnt, P, I);
     }
     w.base = pos;
     w.len = len;
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS stores are done before the wave reads them back
 }
 
-// Length of the common prefix of p[0..max_len) and q[0..max_len), whole wave.
-// Semantics of refresh::matching_length (3rd_party/refresh/string_operations/lib/
-// string_operations.h:18-69) as used by compare_fwd (lz_diff.h:264-266).
-// Every 16-byte load is issued only when the whole chunk lies below max_len.
-// When `win` is given, p is the text at position p_pos and the text chunk of the final step is
-// captured into the window.
-__device__ uint32_t wave_common_prefix(const uint8_t *__restrict__ p, const uint8_t *__restrict__ q, uint32_t max_len,
-                                       TextWin *win = nullptr, uint32_t p_pos = 0)
+// Length of the common prefix of text[tp ..) and ref[rp ..), at most max_len symbols (the caller bounds it by both ends),
+// whole wave: a lane takes 32 symbols of both sides per step (three dwords each) and finds its first difference with one
+// 64-bit XOR; symbols outside ACGT (escaped blocks) are compared by value, one at a time.
+// Semantics of refresh::matching_length (3rd_party/refresh/string_operations/lib/string_operations.h:18-69) as used by
+// compare_fwd (lz_diff.h:264-266).  When `win` is given the text chunk of the final step is captured into the window.
+__device__ uint32_t wave_match_fwd(const SymView &tv, uint32_t tp, bool t_clean, const SymView &rv, uint32_t rp, bool r_clean, uint32_t max_len,
+                                   TextWin *win = nullptr)
 {
     const uint32_t lane = lane_id();
-    for (uint32_t base = 0;; base += WAVE * 16) {
-        const uint32_t off = base + lane * 16;
-        bool stop;
-        uint32_t so;
-        uint4 a = make_uint4(0, 0, 0, 0);
-        bool full = false;
-        if (off >= max_len) {
-            stop = true;
-            so = 0;
-        } else if (max_len - off >= 16) {
-            a = load16(p + off);
-            const uint4 b = load16(q + off);
-            so = first_diff_byte16(a, b);
-            stop = so < 16;
-            full = true;
-        } else {
-            const uint32_t rem = max_len - off;
-            so = 0;
-            while (so < rem && p[off + so] == q[off + so])
-                ++so;
-            stop = true;
+    for (uint32_t base = 0;; base += WIN_SYMS) {
+        const uint32_t off = base + lane * CMP_SYMS;
+        bool stop = true;
+        uint32_t so = 0, cnt = 0, It = 0;
+        uint64_t Pt = 0;
+        if (off < max_len) {
+            cnt = max_len - off < CMP_SYMS ? max_len - off : CMP_SYMS;
+            uint64_t Pr;
+            uint32_t Ir;
+            sv_fetch32(tv, tp + off, cnt, t_clean, Pt, It);
+            sv_fetch32(rv, rp + off, cnt, r_clean, Pr, Ir);
+            const uint64_t d = Pt ^ Pr;
+            uint32_t j = d ? sv_ctz64(d) >> 1 : CMP_SYMS;
+            const uint32_t inv = It | Ir;
+            if (inv) {
+                const uint32_t ji = (uint32_t)__builtin_ctz(inv);
+                if (ji < j) { // from the first symbol outside ACGT on: by value
+                    j = ji;
+                    while (j < cnt && sv_sym(tv, tp + off + j) == sv_sym(rv, rp + off + j))
+                        ++j;
+                }
+            }
+            so = j < cnt ? j : cnt;
+            stop = so < CMP_SYMS; // (a chunk cut by max_len stops too)
         }
         const uint64_t m = __ballot(stop);
         if (m) {
             if (win) {
                 // lanes holding a full chunk form a prefix of the wave: capture them
+                const bool full = cnt == CMP_SYMS;
                 const uint64_t fm = __ballot(full);
                 if (full)
-                    *(uint4 *)(win->lds + lane * 16) = a;
-                win->base = p_pos + base;
-                win->len = (uint32_t)__builtin_popcountll(fm) * 16;
+                    store_syms32(win->lds + lane * CMP_SYMS, tv, tp + off, CMP_SYMS, Pt, It);
+                win->base = tp + base;
+                win->len = (uint32_t)__builtin_popcountll(fm) * CMP_SYMS;
                 __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
             }
             const uint32_t l = ctz64(m);
-            const uint32_t r = base + l * 16 + bcast_u32(so, l);
-            return r < max_len ? r : max_len;
+            return base + l * CMP_SYMS + bcast_u32(so, l);
         }
     }
 }
 
-// Backward extension (lz_diff.cpp:308-311): number of equal symbols walking left from
-// s[-1] / p[-1], at most lim.
-__device__ uint32_t wave_common_suffix(const uint8_t *__restrict__ s, const uint8_t *__restrict__ p, uint32_t lim)
+// Backward extension (lz_diff.cpp:308-311): number of equal symbols walking left from text[tp - 1] / ref[rp - 1], at most lim.
+__device__ uint32_t wave_common_suffix(const SymView &tv, uint32_t tp, const SymView &rv, uint32_t rp, uint32_t lim)
 {
     const uint32_t lane = lane_id();
     for (uint32_t base = 0; base < lim; base += WAVE) {
         const uint32_t idx = base + lane;
         bool mism = true;
         if (idx < lim)
-            mism = *(s - 1 - (int64_t)idx) != *(p - 1 - (int64_t)idx);
+            mism = sv_sym(tv, tp - 1 - idx) != sv_sym(rv, rp - 1 - idx);
         const uint64_t m = __ballot(mism);
         if (m)
             return base + ctz64(m);
@@ -283,22 +307,24 @@ struct ParseOut {
 // maybe: one bit per text position from key_filter_kernel (0 = the key at this position is valid and not in the reference's
 // index: a certain literal); nullptr: literal runs are found by probing the table (wide probe)
 template <int MODE>
-__device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text, const uint32_t n,
-                             uint8_t *__restrict__ out, cost_t *__restrict__ costs, const bool prefix_costs, uint8_t *win_lds,
-                             const unsigned long long *__restrict__ maybe)
+__device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__restrict__ out, cost_t *__restrict__ costs,
+                             const bool prefix_costs, uint8_t *win_lds, const unsigned long long *__restrict__ maybe)
 {
     const uint32_t lane = lane_id();
     const bool writer = lane == 0;
+    const uint32_t n = tv.len;
     const uint32_t key_len = rd.key_len;
     const uint32_t mml = rd.min_match_len;
-    const uint8_t *__restrict__ ref = rd.ref;
     const uint32_t ref_size = rd.ref_size;
     const uint32_t ht_mask = rd.ht_mask;
+    const SymView rv = {rd.words, rd.esc_index, rd.esc_bytes, 0, ref_size, 0};
+    const bool r_clean = rd.esc_index == nullptr; // (a reference has an escape index only when it holds a symbol outside ACGT)
+    const bool t_clean = wave_view_clean(tv);
     ParseOut res{0, 0};
 
     if (MODE != MODE_COSTVEC) {
         // identical sequence (lz_diff.cpp:678-680 / 849-851)
-        if (n == ref_size && wave_common_prefix(text, ref, n) == n)
+        if (n == ref_size && wave_match_fwd(tv, 0, t_clean, rv, 0, r_clean, n) == n)
             return res;
     }
 
@@ -327,7 +353,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             // symbols i .. i+64+key_len+2 (as far as the text goes) must be in the LDS window
             const uint32_t need = n - i < WAVE + key_len + 2 ? n - i : WAVE + key_len + 2;
             if (!win_has(win, i, need))
-                win_fill(win, text, n, i);
+                win_fill(win, tv, t_clean, n, i);
         }
         const uint8_t *__restrict__ wtext = win.lds - win.base; // wtext[pos] for positions inside the window
         // ---- wide literal probe: lanes look at positions i .. i+63 at once.  A position is a
@@ -565,7 +591,6 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             if (est > peak)
                 peak = est; // the reference's loop-top check sees this value (lz_diff.cpp:868-869)
         }
-        const uint8_t *tp = text + i;
         const uint32_t max_len = n - i;
         uint32_t s0;
         if (have_cands)
@@ -584,7 +609,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 nrun = max_len; // runs to the end unless a non-N is found
                 for (uint32_t base = 3; base < max_len; base += WAVE) {
                     const uint32_t p = base + lane;
-                    const bool not_n = p < max_len ? tp[p] != N_CODE : true;
+                    const bool not_n = p < max_len ? sv_sym(tv, i + p, t_clean) != N_CODE : true;
                     const uint64_t m = __ballot(not_n);
                     if (m) {
                         uint32_t e = base + ctz64(m);
@@ -668,23 +693,25 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             const uint32_t j = ctz64(cand);
             cand &= cand - 1;
             const uint32_t h_pos = bcast_u32(epos, j) * HASHING_STEP;
-            const uint8_t *p = ref + h_pos;
-            // backward bytes of the first 64 positions (lz_diff.cpp:308-311), issued before the forward
+            // backward symbols of the first 64 positions (lz_diff.cpp:308-311), issued before the forward
             // compare so that both arrive in one round trip
             const uint32_t lim = npl < h_pos ? npl : h_pos;
             uint32_t tb = 0x100u, rb = 0x200u; // lanes >= lim: never equal
             if (lane < lim) {
-                tb = *(tp - 1 - (int64_t)lane);
-                rb = *(p - 1 - (int64_t)lane);
+                tb = sv_sym(tv, i - 1 - lane, t_clean);
+                rb = sv_sym(rv, h_pos - 1 - lane, r_clean);
             }
-            const uint32_t f_len = wave_common_prefix(tp, p, max_len, &win, i);
+            // (the reference pads its copy with key_len symbols no text holds, lz_diff.cpp:48-53: a compare ends at the
+            // reference's end at the latest -- here by the bound)
+            const uint32_t ref_left = ref_size - h_pos;
+            const uint32_t f_len = wave_match_fwd(tv, i, t_clean, rv, h_pos, r_clean, max_len < ref_left ? max_len : ref_left, &win);
             if (f_len >= key_len) {
                 const uint64_t mm = __ballot(tb != rb);
                 uint32_t b_len;
                 if (mm)
                     b_len = ctz64(mm);
                 else
-                    b_len = lim <= WAVE ? lim : WAVE + wave_common_suffix(tp - WAVE, p - WAVE, lim - WAVE);
+                    b_len = lim <= WAVE ? lim : WAVE + wave_common_suffix(tv, i - WAVE, rv, h_pos - WAVE, lim - WAVE);
                 if (b_len + f_len > min_to_update) {
                     len_bck = b_len;
                     len_fwd = f_len;
@@ -760,10 +787,10 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
                 // trailing literals beyond the 64 probed ones (rare): serial walk on text/ref
                 if (!brk && len_bck + n_trail > WAVE && writer) {
                     for (uint32_t tt = len_bck >= WAVE ? 1u : WAVE - len_bck + 1; tt <= n_trail && tt < o && tt < match_pos; ++tt) {
-                        const uint8_t c = text[i - tt];
+                        const uint32_t c = sv_sym(tv, i - tt);
                         if (c >= 26)
                             break;
-                        if (c == ref[match_pos - tt])
+                        if (c == sv_sym(rv, match_pos - tt))
                             out[o - tt] = '!';
                     }
                 }
@@ -810,7 +837,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const uint8_t *__restrict__ text
             // one lane owns every byte of the delta: no cross-lane stores to one address
             if (writer)
                 for (uint32_t t = 0; t < cnt; ++t)
-                    out[o + t] = (uint8_t)('A' + text[i + t]);
+                    out[o + t] = (uint8_t)('A' + sv_sym(tv, i + t));
         } else {
             __builtin_amdgcn_s_waitcnt(0);
             for (uint32_t t = lane; t < cnt; t += WAVE)
@@ -838,23 +865,40 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
     AGC_TRACE(1, idx);
     if (idx >= n_segs)
         return;
-    const SegDesc sd = segs[idx];
-    const RefDesc rd = refs[sd.ref_slot];
-    AGC_TRACE(2, sd.len);
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_BYTES];
+    const SegDesc &sdm = segs[idx];
+    const RefDesc &rdm = refs[uniform_u32(sdm.ref_slot)];
+    // (everything in the two descriptors is the same for the whole wave: scalar registers)
+    RefDesc rd;
+    rd.words = uniform_ptr(rdm.words);
+    rd.esc_index = uniform_ptr(rdm.esc_index);
+    rd.esc_bytes = uniform_ptr(rdm.esc_bytes);
+    rd.table = uniform_ptr(rdm.table);
+    rd.bloom = uniform_ptr(rdm.bloom);
+    rd.ref_size = uniform_u32(rdm.ref_size);
+    rd.ht_mask = uniform_u32(rdm.ht_mask);
+    rd.key_len = uniform_u32(rdm.key_len);
+    rd.min_match_len = uniform_u32(rdm.min_match_len);
+    rd.is_short = uniform_u32(rdm.is_short);
+    rd.valid = 1;
+    const SymView tv = uniform_view(sdm.text);
+    const uint64_t out_off = uniform_u64(sdm.out_off);
+    const unsigned long long *maybe = uniform_ptr(sdm.maybe);
+    const uint32_t flags = uniform_u32(sdm.flags), oidx = uniform_u32(sdm.idx);
+    AGC_TRACE(2, tv.len);
+    __shared__ __attribute__((aligned(32))) uint8_t s_win[4][WIN_SYMS];
     uint8_t *win_lds = s_win[threadIdx.x >> 6];
     ParseOut r;
     if (MODE == MODE_ENCODE)
-        r = lz_parse<MODE>(rd, sd.text, sd.len, out_bytes + sd.out_off, nullptr, false, win_lds, nullptr);
+        r = lz_parse<MODE>(rd, tv, out_bytes + out_off, nullptr, false, win_lds, nullptr);
     else if (MODE == MODE_ESTIMATE)
-        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, nullptr, false, win_lds, sd.maybe);
+        r = lz_parse<MODE>(rd, tv, nullptr, nullptr, false, win_lds, maybe);
     else
-        r = lz_parse<MODE>(rd, sd.text, sd.len, nullptr, (cost_t *)out_u32 + sd.out_off, (sd.flags & 1u) != 0, win_lds, sd.maybe);
+        r = lz_parse<MODE>(rd, tv, nullptr, (cost_t *)out_u32 + out_off, (flags & 1u) != 0, win_lds, maybe);
     AGC_TRACE(9, r.value);
     if (lane_id() == 0) {
-        res_value[sd.pad] = r.value; // sd.pad = index in the caller's order
+        res_value[oidx] = r.value;
         if (MODE == MODE_ESTIMATE)
-            res_peak[sd.pad] = r.peak;
+            res_peak[oidx] = r.peak;
     }
 }
 
@@ -868,7 +912,7 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__rest
                                                            uint32_t n_segs, uint8_t *__restrict__ dst)
 {
     for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
-        const uint32_t orig = segs[s].pad;
+        const uint32_t orig = segs[s].idx;
         const uint8_t *src = scratch + segs[s].out_off;
         uint8_t *d = dst + dst_off[orig];
         const uint32_t n = lens[orig];
@@ -888,38 +932,30 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__rest
 constexpr uint32_t FILTER_CHUNK = 16384;
 
 struct FilterJob {
-    const uint8_t *text;
+    SymView text;
     const unsigned long long *bloom;
     unsigned long long *out;   // (len + 63) / 64 words
-    uint32_t len;
     uint32_t key_len;
     uint32_t chunk;            // first position of this block's chunk
-    uint32_t pad;
 };
 
-__device__ __forceinline__ void pack16(const uint8_t *__restrict__ text, uint32_t len, uint32_t pos, uint32_t &P, uint32_t &I)
+__device__ __forceinline__ void pack16(const SymView &tv, uint32_t pos, uint32_t &P, uint32_t &I)
 {
     // 16 symbols at pos: P = 2-bit codes (first symbol most significant), I = mask of symbols > 3 (first symbol = bit 15);
     // positions at or after len count as invalid
     P = 0;
     I = 0xFFFF;
-    if (pos + 16 <= len) {
-        const uint4 v = load16(text + pos);
-        auto pk = [](uint32_t w) { return ((w & 0x03030303u) * 0x40100401u) >> 24; };
-        auto iv = [](uint32_t w) {
-            uint32_t x = w & 0xFCFCFCFCu;
-            uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-            return ((nz >> 7) & 1u) << 3 | ((nz >> 15) & 1u) << 2 | ((nz >> 23) & 1u) << 1 | (nz >> 31);
-        };
-        P = (pk(v.x) << 24) | (pk(v.y) << 16) | (pk(v.z) << 8) | pk(v.w);
-        I = (iv(v.x) << 12) | (iv(v.y) << 8) | (iv(v.z) << 4) | iv(v.w);
-    } else if (pos < len) {
-        I = 0;
-        for (uint32_t j = 0; j < 16; ++j) {
-            const uint32_t c = pos + j < len ? text[pos + j] : 4u;
-            P = (P << 2) | (c & 3u);
-            I = (I << 1) | (c > 3u);
+    if (pos < tv.len) {
+        const uint32_t cnt = tv.len - pos < 16 ? tv.len - pos : 16;
+        uint64_t Q;
+        uint32_t J;
+        sv_fetch32(tv, pos, cnt, false, Q, J);
+        if (cnt < 16) {
+            J |= 0xFFFFu << cnt;
+            Q &= (1ULL << (2 * cnt)) - 1ULL;
         }
+        P = (uint32_t)(sv_rev2_64(Q) >> 32);
+        I = sv_brev32(J & 0xFFFFu) >> 16;
     }
 }
 
@@ -938,19 +974,17 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
     const uint32_t k = jb.key_len;
     const uint64_t kmask = (1ULL << (2 * k)) - 1ULL;     // key_len <= 29
     const uint32_t imask = (1u << k) - 1u;
-    const uint32_t end = min(jb.len, jb.chunk + FILTER_CHUNK);
+    const uint32_t len = jb.text.len;
+    const uint32_t end = min(len, jb.chunk + FILTER_CHUNK);
     for (uint32_t base = jb.chunk + wave * 1024; base < end; base += 4 * 1024) {
         const uint32_t pos = base + lane * 16;
         uint32_t P, I;
-        pack16(jb.text, jb.len, pos, P, I);
+        pack16(jb.text, pos, P, I);
         uint32_t P1 = __shfl_down(P, 1), I1 = __shfl_down(I, 1), P2 = __shfl_down(P, 2), I2 = __shfl_down(I, 2);
         if (lane >= 62) { // the followers of the last two lanes belong to the next step
             if (lane == 63)
-                pack16(jb.text, jb.len, pos + 16, P1, I1);
-            pack16(jb.text, jb.len, pos + 32, P2, I2);
-            if (lane == 62) {
-                // P1 came from lane 63 by the shuffle; P2 is the chunk after lane 63's
-            }
+                pack16(jb.text, pos + 16, P1, I1);
+            pack16(jb.text, pos + 32, P2, I2);
         }
         // 96-bit window: symbols 0..15 (P), 16..31 (P1), 32..47 (P2); symbol s at bits [94 - 2s, 95 - 2s]
         const uint64_t hi = ((uint64_t)P << 32) | P1;            // symbols 0..31
@@ -969,14 +1003,14 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
             uint64_t bm;
             key_bloom_slot(key, bw, bm);
             const bool in_f = (s_bloom[bw] & bm) == bm;
-            const bool past = !(pos + j + k < jb.len);
+            const bool past = !(pos + j + k < len);
             bits |= (uint32_t)(bad || in_f || past) << j;
         }
         // 4 lanes make one 64-bit word (positions ascending = bits ascending)
         const uint64_t mine = (uint64_t)bits << (16 * (lane & 3));
         uint64_t word = mine | __shfl_xor(mine, 1);
         word |= __shfl_xor(word, 2);
-        if ((lane & 3) == 0 && pos < jb.len)
+        if ((lane & 3) == 0 && pos < len)
             jb.out[pos >> 6] = word;
     }
 }
@@ -985,7 +1019,10 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
 // Index build.
 // ---------------------------------------------------------------------------
 struct IdxBuild {
-    const uint8_t *ref;  // padded reference
+    SymView src;         // the new reference where it lies in the sample (read reverse-complemented when src.rc)
+    uint32_t *words;     // its stored form: 2-bit words from bit 0 (ref_pack_kernel writes them)
+    int32_t *esc_index;  // nullptr unless the reference holds a symbol outside ACGT (ref_esc_kernel fills both)
+    uint8_t *esc_bytes;
     void *table;         // filled by the insert kernel (pre-set to all ones)
     unsigned long long *bloom; // key filter (zeroed), filled by the insert kernel
     uint32_t ref_size;
@@ -994,22 +1031,77 @@ struct IdxBuild {
     uint32_t is_short;
 };
 
-// key at ref[i..i+key_len) or ~0 (get_code, lz_diff.h:58-106)
-__device__ __forceinline__ uint64_t key_at(const uint8_t *__restrict__ r, uint32_t key_len)
+// key at positions [pos, pos + key_len) of a sequence or ~0 when one of its symbols is not ACGT or it runs past the end
+// (get_code, lz_diff.h:58-106; the reference's copy ends in key_len symbols no key may hold, lz_diff.cpp:48-53)
+__device__ __forceinline__ uint64_t key_at(const SymView &v, uint32_t pos, uint32_t key_len)
 {
-    uint64_t x = 0;
-    for (uint32_t j = 0; j < key_len; ++j) {
-        const uint32_t c = r[j];
-        if (c > 3)
-            return ~0ULL;
-        x = (x << 2) + c;
+    if ((uint64_t)pos + key_len > v.len)
+        return ~0ULL;
+    uint64_t P;
+    uint32_t I;
+    sv_fetch32(v, pos, key_len, false, P, I);
+    if (I)
+        return ~0ULL;
+    return sv_key_from_packed(P, key_len);
+}
+
+// The new references into their stored form: 16 symbols per thread and word, read through the sample's view (any offset,
+// either orientation), written from bit 0 of the reference's own words.  flags[job] != 0 afterwards: the reference holds a
+// symbol outside ACGT (its escape blocks are then filled by ref_esc_kernel).  The tail words (REF_TAIL_WORDS) are zeroed.
+__global__ void __launch_bounds__(256) ref_pack_kernel(const IdxBuild *__restrict__ jobs, uint32_t *__restrict__ flags, uint32_t split)
+{
+    const uint32_t job = blockIdx.x / split, part = blockIdx.x % split;
+    const IdxBuild jb = jobs[job];
+    const uint32_t n_words = (jb.ref_size + 15) / 16;
+    bool high = false;
+    for (uint32_t w = part * blockDim.x + threadIdx.x; w < n_words + REF_TAIL_WORDS; w += blockDim.x * split) {
+        uint32_t out = 0;
+        if (w < n_words) {
+            const uint32_t pos = w * 16, cnt = jb.ref_size - pos < 16 ? jb.ref_size - pos : 16;
+            uint64_t P;
+            uint32_t I;
+            sv_fetch32(jb.src, pos, cnt, false, P, I);
+            out = cnt < 16 ? (uint32_t)P & ((1u << (2 * cnt)) - 1u) : (uint32_t)P;
+            high = high || I != 0;
+        }
+        jb.words[w] = out;
     }
-    return x;
+    if (high)
+        atomicOr(&flags[job], 1u);
+}
+
+// escape blocks of a reference that holds symbols outside ACGT: one thread block per (reference, 1024-symbol block)
+struct EscJob {
+    SymView src;
+    int32_t *esc_index;
+    uint8_t *esc_bytes;
+    uint32_t block;
+    uint32_t pad;
+};
+__global__ void __launch_bounds__(256) ref_esc_kernel(const EscJob *__restrict__ jobs)
+{
+    const EscJob jb = jobs[blockIdx.x];
+    uint8_t c[4];
+    bool high = false;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t pos = jb.block * SV_BLOCK + threadIdx.x * 4 + j;
+        c[j] = pos < jb.src.len ? (uint8_t)sv_sym(jb.src, pos) : (uint8_t)0;
+        high = high || c[j] > 3;
+    }
+    const int any = __syncthreads_or(high ? 1 : 0);
+    if (threadIdx.x == 0)
+        jb.esc_index[jb.block] = any ? (int32_t)jb.block : -1;
+    if (any) {
+        uint32_t v;
+        __builtin_memcpy(&v, c, 4);
+        *(uint32_t *)(jb.esc_bytes + (size_t)jb.block * SV_BLOCK + threadIdx.x * 4) = v;
+    }
 }
 
 // number of valid keys at positions 0,4,8,... (the count prepare_index sizes the table by,
 // lz_diff.cpp:88-101: a key is counted where the last key_len symbols are all ACGT and the
-// key starts at a multiple of hashing_step)
+// key starts at a multiple of hashing_step); read from the sample's view (the stored form may still be in the making)
 // A reference may be spread over `split` blocks (few, long references): counts[] must be zeroed.
 __global__ void __launch_bounds__(256) idx_count_kernel(const IdxBuild *__restrict__ jobs, uint32_t *__restrict__ counts, uint32_t split)
 {
@@ -1017,7 +1109,7 @@ __global__ void __launch_bounds__(256) idx_count_kernel(const IdxBuild *__restri
     const IdxBuild jb = jobs[job];
     uint32_t c = 0;
     for (uint32_t t = part * blockDim.x + threadIdx.x; (uint64_t)t * HASHING_STEP + jb.key_len <= jb.ref_size; t += blockDim.x * split)
-        c += key_at(jb.ref + (uint64_t)t * HASHING_STEP, jb.key_len) != ~0ULL;
+        c += key_at(jb.src, t * HASHING_STEP, jb.key_len) != ~0ULL;
     // block reduce
     for (int o = 32; o > 0; o >>= 1)
         c += __shfl_down(c, o);
@@ -1037,9 +1129,9 @@ __global__ void __launch_bounds__(256) idx_count_kernel(const IdxBuild *__restri
 // displaces onward.  Entries only ever decrease, which makes the result independent of
 // thread timing and identical to the sequential build.
 template <typename E, int FPBITS>
-__device__ void idx_insert_one(const IdxBuild &jb, uint32_t t)
+__device__ void idx_insert_one(const IdxBuild &jb, const SymView &rv, uint32_t t)
 {
-    const uint64_t x = key_at(jb.ref + (uint64_t)t * HASHING_STEP, jb.key_len);
+    const uint64_t x = key_at(rv, t * HASHING_STEP, jb.key_len);
     if (x == ~0ULL)
         return;
     E *tab = (E *)jb.table;
@@ -1064,7 +1156,7 @@ __device__ void idx_insert_one(const IdxBuild &jb, uint32_t t)
             // we took the slot from `old`: continue inserting `old` after this slot
             cur = old;
             const uint32_t ot = (uint32_t)(old >> FPBITS);
-            const uint64_t ox = key_at(jb.ref + (uint64_t)ot * HASHING_STEP, jb.key_len);
+            const uint64_t ox = key_at(rv, ot * HASHING_STEP, jb.key_len);
             const uint32_t ohome = (uint32_t)murmur64(ox) & jb.ht_mask;
             tries = ((slot - ohome) & jb.ht_mask) + 1;
         }
@@ -1078,75 +1170,50 @@ __global__ void __launch_bounds__(256) idx_insert_kernel(const IdxBuild *__restr
 {
     // the atomicMin fixpoint does not depend on which block inserts which key
     const IdxBuild jb = jobs[blockIdx.x / split];
+    const SymView rv = {jb.words, jb.esc_index, jb.esc_bytes, 0, jb.ref_size, 0}; // the stored form
     for (uint32_t t = (blockIdx.x % split) * blockDim.x + threadIdx.x; (uint64_t)t * HASHING_STEP < jb.ref_size; t += blockDim.x * split) {
         if (jb.is_short)
-            idx_insert_one<uint32_t, 16>(jb, t);
+            idx_insert_one<uint32_t, 16>(jb, rv, t);
         else
-            idx_insert_one<unsigned long long, 32>(jb, t);
+            idx_insert_one<unsigned long long, 32>(jb, rv, t);
     }
 }
 
 // ---------------------------------------------------------------------------
-// slice copy with optional reverse complement + INVALID_SYMBOL padding
-// (reverse_complement_copy, src/common/agc_basic.cpp:282-315; prepare_gen padding,
-// src/common/lz_diff.cpp:48-53)
+// sequences out of a packed buffer as bytes, optionally reverse-complemented (reverse_complement_copy,
+// src/common/agc_basic.cpp:282-315): what the host packs itself (new references, raw segments)
 // ---------------------------------------------------------------------------
-// complement of four packed symbols: c < 4 ? 3 - c : c  (3 - c == c ^ 3 for c in 0..3)
-__device__ __forceinline__ uint32_t comp4(uint32_t x)
-{
-    const uint32_t m = x & 0xFCFCFCFCu;                                              // non-zero byte <=> symbol >= 4
-    const uint32_t nz = (((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;       // bit 7 of every byte with symbol >= 4
-    const uint32_t lt4 = (nz ^ 0x80808080u) >> 7;                                    // 0x01 in every byte with symbol < 4
-    return x ^ (lt4 * 3u);
-}
-
-__device__ __forceinline__ uint8_t slice_byte(const SliceDesc &sd, uint32_t t)
-{
-    if (sd.rc) {
-        const uint8_t c = sd.src[sd.len - 1 - t];
-        return c < 4 ? (uint8_t)(3 - c) : c;
-    }
-    return sd.src[t];
-}
-
-// 16 bytes per thread: aligned 16-B stores, byte-aligned 16-B loads (mirrored source window for rc)
-__global__ void __launch_bounds__(256) slice_copy_kernel(const SliceDesc *__restrict__ jobs, uint32_t n_jobs)
+__global__ void __launch_bounds__(256) slice_expand_kernel(const ViewJob *__restrict__ jobs, uint32_t n_jobs)
 {
     for (uint32_t s = blockIdx.x; s < n_jobs; s += gridDim.x) {
-        const SliceDesc sd = jobs[s];
-        const uint32_t head = min(sd.len, (uint32_t)((16u - (uint32_t)((uintptr_t)sd.dst & 15u)) & 15u));
-        const uint32_t n_vec = (sd.len - head) >> 4;
-        const uint32_t tail = head + (n_vec << 4);
-        if (threadIdx.x < head)
-            sd.dst[threadIdx.x] = slice_byte(sd, threadIdx.x);
-        for (uint32_t v = threadIdx.x; v < n_vec; v += blockDim.x) {
-            const uint32_t t = head + (v << 4);
-            uint4 y;
-            if (sd.rc) {
-                const uint4 x = load16(sd.src + (sd.len - 16u - t)); // dst[t + j] = comp(src[len - 1 - t - j])
-                y.x = comp4(__builtin_bswap32(x.w));
-                y.y = comp4(__builtin_bswap32(x.z));
-                y.z = comp4(__builtin_bswap32(x.y));
-                y.w = comp4(__builtin_bswap32(x.x));
+        const ViewJob jb = jobs[s];
+        uint8_t *dst = (uint8_t *)jb.dst;
+        const uint32_t len = jb.src.len;
+        for (uint32_t pos = threadIdx.x * 16; pos < len; pos += blockDim.x * 16) {
+            const uint32_t cnt = len - pos < 16 ? len - pos : 16;
+            uint64_t P;
+            uint32_t I;
+            sv_fetch32(jb.src, pos, cnt, false, P, I);
+            if (cnt == 16 && I == 0) {
+                const uint32_t lo = (uint32_t)P;
+                const uint4 v = make_uint4(sv_expand4(lo), sv_expand4(lo >> 8), sv_expand4(lo >> 16), sv_expand4(lo >> 24));
+                __builtin_memcpy(dst + pos, &v, 16);
             } else
-                y = load16(sd.src + t);
-            *(uint4 *)(sd.dst + t) = y;
+                for (uint32_t j = 0; j < cnt; ++j)
+                    dst[pos + j] = (uint8_t)(((I >> j) & 1u) ? sv_sym(jb.src, pos + j) : (uint32_t)(P >> (2u * j)) & 3u);
         }
-        for (uint32_t t = tail + threadIdx.x; t < sd.len; t += blockDim.x)
-            sd.dst[t] = slice_byte(sd, t);
-        for (uint32_t t = threadIdx.x; t < sd.pad_len; t += blockDim.x)
-            sd.dst[sd.len + t] = INVALID_SYMBOL;
     }
 }
 
 // repetitiveness probe counters (segment.h:224-247): for lag 4..31,
 // cnt = #{j : j+lag < n, d[j]==d[j+lag]}, cur = #{j : j+lag < n, d[j] < 4}
-// cnt_out / cur_out must be zeroed; a slice may be spread over `split` blocks
-__global__ void __launch_bounds__(256) lag_counts_kernel(const SliceDesc *__restrict__ jobs, uint32_t *__restrict__ cnt_out,
+// cnt_out / cur_out must be zeroed; a sequence may be spread over `split` blocks.  A thread takes 32 positions: on clean
+// sequence the 28 comparisons are XORs of the 64-bit chunk with itself shifted (the next chunk funnelled in) + a popcount.
+__global__ void __launch_bounds__(256) lag_counts_kernel(const ViewJob *__restrict__ jobs, uint32_t *__restrict__ cnt_out,
                                                          uint32_t *__restrict__ cur_out, uint32_t split)
 {
     const uint32_t job = blockIdx.x / split, part = blockIdx.x % split;
-    const SliceDesc sd = jobs[job];
+    const SymView sv = jobs[job].src;
     __shared__ uint32_t s_cnt[28], s_cur[28];
     if (threadIdx.x < 28) {
         s_cnt[threadIdx.x] = 0;
@@ -1157,21 +1224,46 @@ __global__ void __launch_bounds__(256) lag_counts_kernel(const SliceDesc *__rest
 #pragma unroll
     for (int l = 0; l < 28; ++l)
         cnt[l] = cur[l] = 0;
-    const uint32_t n = sd.len;
-    for (uint32_t j = part * blockDim.x + threadIdx.x; j < n; j += blockDim.x * split) {
-        uint8_t c = sd.rc ? sd.src[n - 1 - j] : sd.src[j];
-        if (sd.rc && c < 4)
-            c = 3 - c;
-        const uint32_t v = c < 4;
+    const uint32_t n = sv.len;
+    for (uint32_t j0 = (part * blockDim.x + threadIdx.x) * 32; j0 < n; j0 += blockDim.x * split * 32) {
+        const uint32_t c0 = n - j0 < 32 ? n - j0 : 32;
+        const uint32_t c1 = n - j0 > 32 ? (n - j0 - 32 < 32 ? n - j0 - 32 : 32) : 0;
+        uint64_t X, Y = 0;
+        uint32_t IX, IY = 0;
+        sv_fetch32(sv, j0, c0, false, X, IX);
+        if (c1)
+            sv_fetch32(sv, j0 + 32, c1, false, Y, IY);
+        if ((IX | IY) == 0) {
 #pragma unroll
-        for (int l = 0; l < 28; ++l) {
-            const uint32_t lag = 4 + l;
-            if (j + lag < n) {
-                uint8_t d = sd.rc ? sd.src[n - 1 - (j + lag)] : sd.src[j + lag];
-                if (sd.rc && d < 4)
-                    d = 3 - d;
-                cnt[l] += c == d;
-                cur[l] += v;
+            for (int l = 0; l < 28; ++l) {
+                const uint32_t lag = 4 + l;
+                // positions j0 + t (t < 32) with j0 + t + lag < n
+                if (j0 + lag >= n)
+                    continue;
+                const uint32_t m = n - lag - j0 < 32 ? n - lag - j0 : 32;
+                const uint64_t Z = (X >> (2 * lag)) | (Y << (64 - 2 * lag));
+                const uint64_t e = ~(X ^ Z);
+                uint64_t eq = e & (e >> 1) & 0x5555555555555555ULL;
+                if (m < 32)
+                    eq &= (1ULL << (2 * m)) - 1ULL;
+                cnt[l] += (uint32_t)__builtin_popcountll(eq);
+                cur[l] += m;
+            }
+        } else {
+            // symbols outside ACGT around: by value (equal codes count, whatever they are)
+            uint8_t s[64];
+            for (uint32_t t = 0; t < 64; ++t)
+                s[t] = j0 + t < n ? (uint8_t)sv_sym(sv, j0 + t) : (uint8_t)0xFF;
+            for (uint32_t t = 0; t < c0; ++t) {
+                const uint32_t v = s[t] < 4;
+#pragma unroll
+                for (int l = 0; l < 28; ++l) {
+                    const uint32_t lag = 4 + l;
+                    if (j0 + t + lag < n) {
+                        cnt[l] += s[t] == s[t + lag];
+                        cur[l] += v;
+                    }
+                }
             }
         }
     }

@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 K, MML, SEG, PACK = 31, 15, 60000, 100
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-BYTES_PER_SYMBOL = 1.0  # layout the LZ kernels read (byte staging copy of the sample, references); the scan reads the 2-bit layout
+BYTES_PER_SYMBOL = 0.25  # the layout every kernel of the step reads: samples AND group references in 2-bit words (sym_view.h)
 
 
 def parse():
@@ -61,7 +61,7 @@ def parse():
                     help="c2 (default): BASELINE configs[2], the headline (HBM-resident 3 Gbp samples).  c1: BASELINE configs[1] -- 1000 "
                          "SARS-CoV-2-size genomes (30 kb, 1 %% SNP from one reference), default parameters, from FASTA files through the product "
                          "CLI path; the reference CLI is timed beside it on the same files and the two archives are compared")
-    ap.add_argument("--no-prefetch", action="store_true", help="do not announce the next sample (its expansion + scan then run inside its own step)")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not announce the next sample (its scan then runs inside its own step)")
     ap.add_argument("--verify-entropy", action="store_true",
                     help="CHECKING RUN, not a measurement: every frame the device entropy stage returns (all the packs of this run's Close) is "
                          "compressed again by the host's libzstd 1.4.9 at level 17 and compared byte for byte (AGC_AMD_VERIFY_DEV_FRAMES); "
@@ -82,15 +82,15 @@ def host_cpus():
     return n
 
 
-PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r3", "r2"))
-                    if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r3", "pmc_summary.csv"))
+PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r4", "r3"))
+                    if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r4", "pmc_summary.csv"))
 KERNEL_SYMBOL = {"scan": "agc::scan_packed_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
-                 "costvec": "agc::lz_parse_kernel<2>", "preprocess": "agc::expand_codes_kernel", "filter": "agc::key_filter_kernel",
+                 "costvec": "agc::lz_parse_kernel<2>", "filter": "agc::key_filter_kernel",
                  "zstd": "agc::zstd_frames_grp_kernel<3, 2>"}
-# bytes per symbol each kernel reads/writes in the layout AS BUILT: the scan reads the 2-bit layout, the expansion reads it and
-# writes the byte staging copy, the LZ kernels read bytes (text + reference)
-AS_BUILT_BPS = {"scan": 0.25, "preprocess": 1.25, "encode": 1.0, "estimate": 1.0, "costvec": 1.0, "filter": 1.0}
-PACKED_BPS = {"scan": 0.25, "preprocess": 0.0, "encode": 0.25, "estimate": 0.25, "costvec": 0.25, "filter": 0.25}
+# bytes per symbol each kernel reads in the layout AS BUILT = SURVEY 8d's 2-bit column since round 4: scan, key filter and the
+# three LZ parses read texts and references as 2-bit words where they lie (no expansion, no reverse-complement staging)
+AS_BUILT_BPS = {"scan": 0.25, "encode": 0.25, "estimate": 0.25, "costvec": 0.25, "filter": 0.25}
+PACKED_BPS = AS_BUILT_BPS
 
 
 def pmc_table():
@@ -110,11 +110,21 @@ def pmc_table():
 
 def pmc_traffic(tab, name):
     """HBM bytes per launch: FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies the 128-B requests of wide coalesced
-    loads as 64 B; profiles/r2/fetch_calibration.txt holds this repo's own calibration incl. the 16-B table probes) + WRITE_SIZE."""
+    loads as 64 B; profiles/r2/fetch_calibration.txt holds this repo's own calibration incl. the 16-B table probes) + WRITE_SIZE.
+    The x2 is calibrated for wide coalesced reads only: for kernels whose reads are narrow and scattered (the zstd match finder)
+    the true figure lies between the uncorrected and the corrected sum -- pmc_traffic_range() states both."""
     c = tab.get(KERNEL_SYMBOL[name])
     if not c or "FETCH_SIZE" not in c:
         return None
     return int((2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
+
+
+def pmc_traffic_range(tab, name):
+    """[FETCH_SIZE + WRITE_SIZE, 2 x FETCH_SIZE + WRITE_SIZE] in bytes per launch (see pmc_traffic)"""
+    c = tab.get(KERNEL_SYMBOL[name])
+    if not c or "FETCH_SIZE" not in c:
+        return None
+    return [int((f * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024) for f in (1.0, 2.0)]
 
 
 def cpu_baseline(args, mbp):
@@ -375,8 +385,8 @@ def main():
     def add_step(s, tag):
         """one step = one sample per GPU; in single-archive mode the N samples of a step are committed in rank order"""
         if not single:
-            # the next sample is known (as a reader that runs ahead of the compressor knows its next file): its expansion and
-            # splitter scan are queued on the device beside this sample's classification / encode / registration.  Not across
+            # the next sample is known (as a reader that runs ahead of the compressor knows its next file): its
+            # splitter scan is queued on the device beside this sample's classification / encode / registration.  Not across
             # the warm-up / timed boundary: every timed sample's scan runs inside the timed region.
             if s + 1 < n_steps and s + 1 != args.warmup and not args.no_prefetch:
                 cmp_.set_next_sample_packed_dev(samples[s + 1][0], off)
@@ -390,8 +400,7 @@ def main():
     n_steps = args.steps + args.warmup
     # weak scaling: samples are partitioned round-robin over ranks (one archive shard per rank), no data-path collective
     # samples are RESIDENT IN HBM IN THE 2-BIT LAYOUT (0.25 B per base; include/agc_hip.h: agc_hip_packed): generated as codes,
-    # packed, and the codes dropped.  Inside a step the scan reads the packed words; the LZ kernels read a byte staging copy
-    # expanded at the start of the step (timed).
+    # packed, and the codes dropped.  Inside a step every kernel reads the packed words where they lie.
     from agc_amd import capi
     hctx = capi.Context.from_handle(cmp_.hip_ctx())
     samples = []
@@ -449,15 +458,14 @@ def main():
         # Kernel time = HIP events on the library's own stream around every launch of the timed region, summed per step
         # (scan and encode are one launch per step; "costvec" = cost-vector parse + split-point reduction; "filter" = the
         # key-filter kernel that writes the "may match" bitmaps of the estimate / cost-vector parses: it reads every text once;
-        # "preprocess" = expansion of the packed sample into the byte staging copy; the algorithmic bytes of a kernel with
-        # nothing to do on a fully packed path (the expansion) are 0 in the packed column).
+        # there is no expansion kernel any more: every row's time is that kernel's alone).
         n_rank_steps = max(args.steps * world, 1)
-        sym = {"scan": stats["bases"], "preprocess": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"],
+        sym = {"scan": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"],
                "estimate": stats["est_text"] + stats["est_ref"], "costvec": stats["cv_text"] + stats["cv_ref"],
                "filter": stats["est_text"] + stats["cv_text"]}
         tab = pmc_table()
         kern = {}
-        for name in ("scan", "preprocess", "encode", "estimate", "costvec", "filter"):
+        for name in ("scan", "encode", "estimate", "costvec", "filter"):
             ms_, n_ = tm[name]
             if not n_:
                 continue
@@ -480,7 +488,7 @@ def main():
         ms_z, n_z = tm.get("zstd", (0.0, 0))
         if n_z and stats["zstd_dev_in"] > 0:
             dev_in = stats["zstd_dev_in"]
-            dev_out = dev_in * (stats["zstd_out"] / stats["zstd_in"]) if stats["zstd_in"] else 0.0
+            dev_out = stats["zstd_dev_out"]  # (counted: the bytes of the frames the device wrote)
             alg = dev_in + dev_out
             ach = alg / (ms_z * 1e-3) / 1e9
             tr = pmc_traffic(tab, "zstd")
@@ -491,7 +499,8 @@ def main():
                                          "frac": round(ach / HBM_PEAK_GBS, 6)},
                             "packed_2bit": {"bytes_per_symbol": None, "algorithmic_bytes": int(alg / n_z), "achieved": round(ach, 3),
                                             "frac": round(ach / HBM_PEAK_GBS, 6)},
-                            "traffic": tr, "waste": round(tr / (alg / n_z), 2) if tr else None}
+                            "traffic": tr, "traffic_range": pmc_traffic_range(tab, "zstd"),
+                            "waste": round(tr / (alg / n_z), 2) if tr else None}
         dominant = max(kern, key=lambda k_: kern[k_]["ms_per_step"]) if kern else None
         dom = kern.get(dominant, {})
         per = lambda x: x / max(args.steps * world, 1)
@@ -507,7 +516,7 @@ def main():
                                        "missing-middle split points on the GPU), group registration, index build of new references, LZ-diff "
                                        "encode kernel, delta D2H, pack bookkeeping, collection records (a sample's encode is collected and its "
                                        "bookkeeping done on a second thread beside the next sample's scan and classification; the next sample's "
-                                       "expansion + scan are queued ahead); the entropy stage (zstd 17 of full delta packs: GPU kernel + host "
+                                       "scan is queued ahead); the entropy stage (zstd 17 of full delta packs: GPU kernel + host "
                                        "pool; 13/19 of new references: host pool) runs on a background "
                                        "thread beside the steps; after the last step: Close() = the same for every open pack + archive "
                                        "metadata, and the wait for it all.  Inputs resident in HBM; archive bytes produced, not written to disk.",
@@ -538,15 +547,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dominant), "achieved": dom.get("as_built", {}).get("achieved"),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("as_built", {}).get("frac"),
                          "frac_packed_2bit": dom.get("packed_2bit", {}).get("frac"),
-                         "traffic": dom.get("traffic"), "waste": dom.get("waste"),
+                         "traffic": dom.get("traffic"), "traffic_range": dom.get("traffic_range"), "waste": dom.get("waste"),
                          "traffic_source": PMC_SUMMARY + " (2 x FETCH_SIZE + WRITE_SIZE, max over dispatches, per launch)" if dom.get("traffic") else None,
                          "algorithmic_bytes_per_launch": dom.get("as_built", {}).get("algorithmic_bytes"),
                          "avg_launch_ms": dom.get("avg_launch_ms", dom.get("ms_per_step")),
-                         "dominant_by": "largest kernel time per step among ALL kernels of the path (scan, expansion, encode, estimate, cost vectors, "
+                         "dominant_by": "largest kernel time per step among ALL kernels of the path (scan, encode, estimate, cost vectors, "
                                         "key filter, zstd frames)",
-                         "layout": "samples resident in HBM at 0.25 B per symbol (2-bit words + escaped blocks); the scan reads that; the LZ "
-                                   "kernels read a 1 B per symbol staging copy made at the start of the step ('preprocess' = that expansion) "
-                                   "and 1 B per symbol references",
+                         "layout": "samples AND group references resident in HBM at 0.25 B per symbol (2-bit words + escaped blocks for "
+                                   "anything outside ACGT); scan, key filter and the LZ parses read that layout where it lies, in either "
+                                   "orientation: no expansion kernel, no reverse-complement staging (as_built == packed_2bit)",
                          "kernels": kern,
                          "kernel_ms_per_step_rank0": {n: round(v[0] / max(args.steps, 1), 4) for n, v in tm.items() if v[1]}},
         }

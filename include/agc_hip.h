@@ -10,8 +10,11 @@
  * members, each one citing the reference interface it replaces
  * (file:line under the reference tree).
  *
- * Symbol layout: one byte per symbol, the codes of src/common/agc_basic.h:40-50
- * (A0 C1 G2 T3 N4 IUPAC5..15, 30 other letter, 32 '@'/'`').
+ * Symbols: the codes of src/common/agc_basic.h:40-50 (A0 C1 G2 T3 N4 IUPAC5..15, 30 other letter, 32 '@'/'`').
+ * In HBM a sample lives in the 2-bit layout (agc_hip_packed below: 0.25 byte per symbol, blocks holding anything
+ * outside ACGT kept verbatim); group references are kept the same way.  EVERY LZ kernel reads that layout only: the
+ * *_packed entry points take sequences of a packed sample as they are, the *_dev / host variants taking one byte per
+ * symbol pack what they are given first (a convenience for small inputs and tests, not the fast path).
  * Pointer naming: h_* = host memory, d_* = device (HBM) memory.
  */
 #ifndef AGC_HIP_H
@@ -137,9 +140,13 @@ uint64_t agc_hip_packed_index_bytes(uint64_t n_symbols);
  * esc_cap_blocks blocks have to be escaped. */
 int agc_hip_pack_dev(agc_hip_ctx *ctx, const uint8_t *d_codes, uint64_t n_symbols, uint32_t *d_words, int32_t *d_esc_index,
                      uint8_t *d_esc_bytes, uint64_t esc_cap_blocks, uint64_t *h_n_esc_blocks);
-/* packed -> codes (d_codes: n_symbols bytes, 16-byte aligned): the staging form the LZ kernels read.  Asynchronous on
- * the context's stream (ordered before every later call). */
+/* packed -> codes (d_codes: n_symbols bytes, 16-byte aligned).  Nothing on the create path needs it (the LZ kernels read the
+ * packed form); a utility for callers and tests.  Asynchronous on the context's stream (ordered before every later call). */
 int agc_hip_expand_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, uint8_t *d_codes);
+/* codes (device, one byte per symbol) -> packed, into buffers the CONTEXT owns (*out names them; valid until the next
+ * agc_hip_sample_pack): what a host that reads FASTA files calls once per uploaded sample before it uses the *_packed entry
+ * points.  An encode left in flight on the previous sample (agc_hip_lz_encode_begin_packed) is waited for first. */
+int agc_hip_sample_pack(agc_hip_ctx *ctx, const uint8_t *d_codes, uint64_t n_symbols, agc_hip_packed *out);
 /* agc_hip_scan_contigs_dev on a packed sample (contig c = symbols [h_ctg_off[c], h_ctg_off[c+1]) of the buffer), 16 <= k <= 32.
  * Same results; reads 0.25 B per symbol. */
 int agc_hip_scan_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
@@ -147,22 +154,23 @@ int agc_hip_scan_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, const ui
                             uint64_t *h_hit_dir, uint64_t *h_hit_rc);
 /* The NEXT sample ahead of its turn.  The reference's workers take contigs of later samples from the priority queue while
  * earlier ones are being registered (src/core/agc_compressor.cpp:1093-1272); here the caller that knows its next sample hands
- * it over early: agc_hip_prefetch_packed_dev QUEUES, on a stream of its own and without waiting, the expansion of the 2-bit
- * words into one of two context-owned byte staging buffers (*d_codes: what the LZ entry points take as d_base for that
- * sample; valid until the prefetch after next) and the splitter scan of agc_hip_scan_packed_dev into a hit list of its own --
- * they run in the gaps the entry points of the sample in front leave on the GPU.  agc_hip_scan_prefetched then waits for that
- * work and delivers the hits exactly as agc_hip_scan_packed_dev would (same arguments, same results; AGC_HIP_EINVAL when
- * this sample was not the one prefetched).  The splitter set must not change in between (not for adaptive mode). */
-int agc_hip_prefetch_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
-                                uint8_t **d_codes);
+ * it over early: agc_hip_prefetch_packed_dev QUEUES, on a stream of its own and without waiting, the splitter scan of
+ * agc_hip_scan_packed_dev into a hit list of its own -- it runs in the gaps the entry points of the sample in front leave on
+ * the GPU.  agc_hip_scan_prefetched then waits for that work and delivers the hits exactly as agc_hip_scan_packed_dev would
+ * (same arguments, same results; AGC_HIP_EINVAL when this sample was not the one prefetched).  The splitter set must not
+ * change in between (not for adaptive mode). */
+int agc_hip_prefetch_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k);
 int agc_hip_scan_prefetched(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
                             uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir,
                             uint64_t *h_hit_rc);
 
 /* ---- S2: LZ-diff against group references (a10, a11, a6, a7) ---------- */
-/* A "slice" names one sequence inside a device buffer: symbols
- * d_base[off .. off+len), read reverse-complemented when rc != 0
- * (CAGCBasic::reverse_complement_copy, src/common/agc_basic.cpp:282-315). */
+/* A "slice" names one sequence inside a device buffer: symbols [off, off+len) of a packed sample *pk (the *_packed
+ * entry points) or d_base[off .. off+len) of a byte buffer (*_dev), read reverse-complemented when rc != 0
+ * (CAGCBasic::reverse_complement_copy, src/common/agc_basic.cpp:282-315).  Nothing is copied or staged per slice: the
+ * kernels read the packed words where they lie, in either orientation.
+ * Each *_packed entry point below takes the same arguments as the *_dev one of the same name, with (pk) in place of (d_base),
+ * and delivers the same results. */
 
 /* Replaces CLZDiffBase::Prepare + prepare_index (src/common/lz_diff.cpp:48-78,
  * 81-141, 375-428) as used by CSegment::add for the first sequence of a group
@@ -175,6 +183,10 @@ int agc_hip_ref_register_batch_dev(agc_hip_ctx *ctx, uint32_t n_refs, const uint
                                    const uint8_t *d_base, const uint64_t *h_off,
                                    const uint32_t *h_len, const uint8_t *h_rc,
                                    uint32_t min_match_len);
+int agc_hip_ref_register_batch_packed(agc_hip_ctx *ctx, uint32_t n_refs, const uint32_t *h_gid,
+                                      const agc_hip_packed *pk, const uint64_t *h_off,
+                                      const uint32_t *h_len, const uint8_t *h_rc,
+                                      uint32_t min_match_len);
 /* Copies a registered reference back (GetReference, lz_diff.cpp:431-437);
  * also returns the index for parity checks: table entries hold pos/4 exactly
  * as ht16/ht32 do (0xFFFF / 0xFFFFFFFF = empty), widened to u32. */
@@ -190,6 +202,10 @@ int agc_hip_lz_encode_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_
                                 const uint8_t *d_base, const uint64_t *h_off,
                                 const uint32_t *h_len, const uint8_t *h_rc,
                                 uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
+int agc_hip_lz_encode_batch_packed(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                                   const agc_hip_packed *pk, const uint64_t *h_off,
+                                   const uint32_t *h_len, const uint8_t *h_rc,
+                                   uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
 /* Host-resident texts: text s = h_text[h_off[s] .. h_off[s]+h_len[s]). */
 int agc_hip_lz_encode_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
                             const uint8_t *h_text, const uint64_t *h_off,
@@ -201,13 +217,16 @@ int agc_hip_lz_encode_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
  * agc_compressor.cpp:989-1050).  begin queues the work on the context's second stream and returns at once; between begin and
  * end every other entry point may be used (own stream, own scratch); end waits and delivers exactly what
  * agc_hip_lz_encode_batch_dev would have (AGC_HIP_ECAP: h_enc_off[n] holds the size needed, call end again).  One encode in
- * flight per context (a begin while one is in flight drops the earlier one).  The texts and every reference named must stay unchanged
- * until end returns -- with one exception the library takes care of itself: texts in a staging buffer of the context
- * (agc_hip_sample_buffer, the buffers of agc_hip_prefetch_packed_dev) may be "overwritten" by the next sample at once, whatever
- * writes such a buffer is ordered behind the parse on the device.  end may be called from ANOTHER thread than the one that goes on
- * using the context (it touches nothing but the second lane's state); that thread must not call begin again before end has returned. */
+ * flight per context (a begin while one is in flight drops the earlier one).  The packed sample (begin_packed) and every reference
+ * named must stay unchanged until end returns -- with one exception the library takes care of itself: the buffers of
+ * agc_hip_sample_pack may be handed the next sample at once, that call waits for the parse.  begin_dev packs its byte input into
+ * a buffer of the second lane before it returns to the caller's stream, so d_base need not outlive the call's device work.
+ * end may be called from ANOTHER thread than the one that goes on using the context (it touches nothing but the second lane's
+ * state); that thread must not call begin again before end has returned. */
 int agc_hip_lz_encode_begin_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
                                 const uint32_t *h_len, const uint8_t *h_rc);
+int agc_hip_lz_encode_begin_packed(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
+                                   const uint32_t *h_len, const uint8_t *h_rc);
 int agc_hip_lz_encode_end(agc_hip_ctx *ctx, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
 
 /* Pinned host memory for result buffers (device-to-host copies into pageable memory go through a bounce buffer at a
@@ -224,6 +243,10 @@ int agc_hip_lz_estimate_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *
                                   const uint8_t *d_base, const uint64_t *h_off,
                                   const uint32_t *h_len, const uint8_t *h_rc,
                                   uint32_t *h_cost, uint32_t *h_peak);
+int agc_hip_lz_estimate_batch_packed(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                                     const agc_hip_packed *pk, const uint64_t *h_off,
+                                     const uint32_t *h_len, const uint8_t *h_rc,
+                                     uint32_t *h_cost, uint32_t *h_peak);
 int agc_hip_lz_estimate_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
                               const uint8_t *h_text, const uint64_t *h_off,
                               const uint32_t *h_len, const uint8_t *h_rc,
@@ -235,6 +258,10 @@ int agc_hip_lz_cost_vector_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_
                                      const uint8_t *d_base, const uint64_t *h_off,
                                      const uint32_t *h_len, const uint8_t *h_rc,
                                      const uint8_t *h_prefix_costs, uint32_t *h_costs);
+int agc_hip_lz_cost_vector_batch_packed(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
+                                        const agc_hip_packed *pk, const uint64_t *h_off,
+                                        const uint32_t *h_len, const uint8_t *h_rc,
+                                        const uint8_t *h_prefix_costs, uint32_t *h_costs);
 int agc_hip_lz_cost_vector_batch(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid,
                                  const uint8_t *h_text, const uint64_t *h_off,
                                  const uint32_t *h_len, const uint8_t *h_rc,
@@ -252,12 +279,22 @@ int agc_hip_lz_split_point_batch_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_
                                      const uint8_t *h_rc2, const uint8_t *h_prefix2,
                                      uint32_t *h_best_pos, uint32_t *h_best_sum);
 
+int agc_hip_lz_split_point_batch_packed(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid1, const uint32_t *h_gid2,
+                                        const agc_hip_packed *pk, const uint64_t *h_off, const uint32_t *h_len,
+                                        const uint8_t *h_rc1, const uint8_t *h_prefix1,
+                                        const uint8_t *h_rc2, const uint8_t *h_prefix2,
+                                        uint32_t *h_best_pos, uint32_t *h_best_sum);
+
 /* Copies slices (optionally reverse-complemented) from HBM into one host buffer, back to back:
  * slice s = h_out[h_out_off[s] .. h_out_off[s+1]).  Used for the sequences the host must pack
  * itself (new group references, raw contigs; src/common/segment.cpp:14-48). */
 int agc_hip_fetch_slices_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_base, const uint64_t *h_off,
                              const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_out, uint64_t out_cap,
                              uint64_t *h_out_off);
+
+int agc_hip_fetch_slices_packed(agc_hip_ctx *ctx, uint32_t n, const agc_hip_packed *pk, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc, uint8_t *h_out, uint64_t out_cap,
+                                uint64_t *h_out_off);
 
 /* ---- a13: reference storage helpers ----------------------------------- */
 /* Repetitiveness probe of CSegment::store_in_archive (src/common/segment.h:224-247):
@@ -266,6 +303,9 @@ int agc_hip_fetch_slices_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_base
 int agc_hip_ref_lag_counts_dev(agc_hip_ctx *ctx, uint32_t n, const uint8_t *d_base,
                                const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
                                uint32_t *h_cnt /* n*28 */, uint32_t *h_cur /* n*28 */);
+int agc_hip_ref_lag_counts_packed(agc_hip_ctx *ctx, uint32_t n, const agc_hip_packed *pk,
+                                  const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
+                                  uint32_t *h_cnt /* n*28 */, uint32_t *h_cur /* n*28 */);
 
 /* ---- S3: entropy coding of delta packs (a14) -------------------------- */
 /* Replaces ZSTD_compressCCtx(cctx, dst, bound, src, n, 17) as CSegment::add_to_archive calls it for delta packs

@@ -51,11 +51,12 @@ struct agc_hip_ctx {
     u32 enc_n;
     u8 *enc_out;
     u64 *enc_eoff;
-    /* the next sample ahead of its turn: two staging buffers, the identity of what was prefetched */
-    u8 *pf_buf[2];
-    u64 pf_cap[2];
-    int pf_cur;
+    /* the next sample ahead of its turn: the identity of what was announced */
     const void *pf_words;
+    /* agc_hip_sample_pack: the context's own packed buffers */
+    uint32_t *sp_words;
+    int32_t *sp_index;
+    u8 *sp_esc;
 };
 
 static int cmp_u64(const void *a, const void *b)
@@ -110,6 +111,9 @@ void agc_hip_destroy(agc_hip_ctx *c)
     free(c->lz);
     free(c->spl);
     free(c->sample);
+    free(c->sp_words);
+    free(c->sp_index);
+    free(c->sp_esc);
     free(c);
 }
 
@@ -561,21 +565,12 @@ int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     return r;
 }
 
-/* the prefetch entry points: the stand-in expands at once and scans when asked (same results, no concurrency) */
-int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint8_t **d_codes)
+/* the prefetch entry points: the stand-in remembers which sample was announced and scans when asked (same results, no concurrency) */
+int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k)
 {
-    if (!c || !pk || !h_ctg_off || !d_codes || !n_ctg || k < 16 || !pk->n_symbols)
+    if (!c || !pk || !h_ctg_off || !n_ctg || k < 16 || !pk->n_symbols)
         return AGC_HIP_EINVAL;
-    c->pf_cur ^= 1;
-    if (c->pf_cap[c->pf_cur] < pk->n_symbols + 64) {
-        free(c->pf_buf[c->pf_cur]);
-        c->pf_cap[c->pf_cur] = pk->n_symbols + pk->n_symbols / 4 + 64;
-        c->pf_buf[c->pf_cur] = (u8 *)malloc(c->pf_cap[c->pf_cur]);
-    }
-    agc_hip_expand_dev(c, pk, c->pf_buf[c->pf_cur]);
-    memset(c->pf_buf[c->pf_cur] + pk->n_symbols, 4, 64);
     c->pf_words = pk->d_words;
-    *d_codes = c->pf_buf[c->pf_cur];
     return AGC_HIP_OK;
 }
 int agc_hip_scan_prefetched(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap,
@@ -584,6 +579,140 @@ int agc_hip_scan_prefetched(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     if (!c || !pk || c->pf_words != pk->d_words)
         return AGC_HIP_EINVAL;
     return agc_hip_scan_packed_dev(c, pk, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
+}
+
+/* codes -> the context's own packed buffers */
+int agc_hip_sample_pack(agc_hip_ctx *c, const uint8_t *d_codes, uint64_t n, agc_hip_packed *out)
+{
+    if (!c || !out || (n && !d_codes))
+        return AGC_HIP_EINVAL;
+    const uint64_t nb = (n + 1023) / 1024;
+    free(c->sp_words);
+    free(c->sp_index);
+    free(c->sp_esc);
+    c->sp_words = (uint32_t *)malloc(agc_hip_packed_words_bytes(n));
+    c->sp_index = (int32_t *)malloc(agc_hip_packed_index_bytes(n));
+    c->sp_esc = (u8 *)malloc(nb * 1024 + 64);
+    uint64_t cnt = 0;
+    const int r = agc_hip_pack_dev(c, d_codes, n, c->sp_words, c->sp_index, c->sp_esc, nb, &cnt);
+    out->d_words = c->sp_words;
+    out->d_esc_index = c->sp_index;
+    out->d_esc_bytes = c->sp_esc;
+    out->n_symbols = n;
+    return r;
+}
+
+/* The *_packed entry points: the stand-in expands the range the sequences span and calls the byte variant (the device reads the
+ * packed words in place, sym_view.h; the results are the same by the tests of both). */
+static u8 *expand_span(const agc_hip_packed *pk, u32 n, const u64 *off, const u32 *len, u64 **off2)
+{
+    u64 lo = ~0ull, hi = 0;
+    for (u32 i = 0; i < n; ++i)
+        if (len[i]) {
+            if (off[i] < lo)
+                lo = off[i];
+            if (off[i] + len[i] > hi)
+                hi = off[i] + len[i];
+        }
+    *off2 = (u64 *)calloc((size_t)n + 1, 8);
+    if (hi <= lo)
+        return (u8 *)calloc(64, 1);
+    if (hi > pk->n_symbols)
+        return NULL;
+    u8 *buf = (u8 *)malloc(hi - lo + 64);
+    for (u64 i = lo; i < hi; ++i) {
+        const int32_t s_ = pk->d_esc_index[i / 1024];
+        buf[i - lo] = s_ >= 0 ? pk->d_esc_bytes[(u64)s_ * 1024 + (i & 1023)] : (u8)((pk->d_words[i >> 4] >> (2 * (i & 15))) & 3);
+    }
+    for (u32 i = 0; i < n; ++i)
+        (*off2)[i] = len[i] ? off[i] - lo : 0;
+    return buf;
+}
+#define WITH_SPAN(call)                                             \
+    u64 *off2 = NULL;                                               \
+    u8 *buf = expand_span(pk, n, off, len, &off2);                  \
+    if (!buf) {                                                     \
+        free(off2);                                                 \
+        return fail(c, AGC_HIP_EINVAL, "sequence past the buffer"); \
+    }                                                               \
+    const int r_ = (call);                                          \
+    free(buf);                                                      \
+    free(off2);                                                     \
+    return r_;
+
+int agc_hip_ref_register_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
+                                      const uint32_t *len, const uint8_t *rc, uint32_t mml)
+{
+    if (!c || (n && (!gid || !pk || !off || !len)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_ref_register_batch_dev(c, n, gid, buf, off2, len, rc, mml))
+}
+int agc_hip_lz_encode_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
+                                   const uint32_t *len, const uint8_t *rc, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off || (n && (!gid || !pk || !off || !len)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_lz_encode_batch_dev(c, n, gid, buf, off2, len, rc, h_enc, cap, h_enc_off))
+}
+int agc_hip_lz_encode_begin_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
+                                   const uint32_t *len, const uint8_t *rc)
+{
+    if (!c || (n && (!gid || !pk || !off || !len)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_lz_encode_begin_dev(c, n, gid, buf, off2, len, rc))
+}
+int agc_hip_lz_estimate_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
+                                     const uint32_t *len, const uint8_t *rc, uint32_t *h_cost, uint32_t *h_peak)
+{
+    if (!c || (n && (!gid || !pk || !off || !len || !h_cost)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_lz_estimate_batch_dev(c, n, gid, buf, off2, len, rc, h_cost, h_peak))
+}
+int agc_hip_lz_cost_vector_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,
+                                     const uint32_t *len, const uint8_t *rc, const uint8_t *pf, uint32_t *h_costs)
+{
+    if (!c || (n && (!gid || !d || !off || !len || !h_costs)))
+        return AGC_HIP_EINVAL;
+    u64 o = 0;
+    for (u32 i = 0; i < n; ++i) {
+        void *z = find_ref(c, gid[i]);
+        if (!z)
+            return fail(c, AGC_HIP_ENOREF, "cost vector: unknown group");
+        u8 *t = slice(d, off[i], len[i], rc && rc[i]);
+        agco_lz_cost_vector(z, t, len[i], pf && pf[i], h_costs + o);
+        o += len[i];
+        free(t);
+    }
+    return AGC_HIP_OK;
+}
+int agc_hip_lz_cost_vector_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
+                                        const uint32_t *len, const uint8_t *rc, const uint8_t *pf, uint32_t *h_costs)
+{
+    if (!c || (n && (!gid || !pk || !off || !len || !h_costs)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_lz_cost_vector_batch_dev(c, n, gid, buf, off2, len, rc, pf, h_costs))
+}
+int agc_hip_lz_split_point_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *g1, const uint32_t *g2, const agc_hip_packed *pk,
+                                        const uint64_t *off, const uint32_t *len, const uint8_t *rc1, const uint8_t *pf1, const uint8_t *rc2,
+                                        const uint8_t *pf2, uint32_t *best_pos, uint32_t *best_sum)
+{
+    if (!c || (n && (!g1 || !g2 || !pk || !off || !len)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_lz_split_point_batch_dev(c, n, g1, g2, buf, off2, len, rc1, pf1, rc2, pf2, best_pos, best_sum))
+}
+int agc_hip_fetch_slices_packed(agc_hip_ctx *c, uint32_t n, const agc_hip_packed *pk, const uint64_t *off, const uint32_t *len, const uint8_t *rc,
+                                uint8_t *h_out, uint64_t cap, uint64_t *h_out_off)
+{
+    if (!c || !h_out_off || (n && (!pk || !off || !len)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_fetch_slices_dev(c, n, buf, off2, len, rc, h_out, cap, h_out_off))
+}
+int agc_hip_ref_lag_counts_packed(agc_hip_ctx *c, uint32_t n, const agc_hip_packed *pk, const uint64_t *off, const uint32_t *len, const uint8_t *rc,
+                                  uint32_t *h_cnt, uint32_t *h_cur)
+{
+    if (!c || (n && (!pk || !off || !len || !h_cnt || !h_cur)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(agc_hip_ref_lag_counts_dev(c, n, buf, off2, len, rc, h_cnt, h_cur))
 }
 
 /* a1 on the stand-in: the oracle's preprocess_raw_contig */

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported():
     for s in decl:
         assert hasattr(L, s), f"{s} declared in include/agc_hip.h but not exported"
     assert sorted(capi.SYMBOLS) == decl, "agc_amd/capi.py binds a different symbol set than the header declares"
-    assert L.agc_hip_abi_version() == 1
+    assert L.agc_hip_abi_version() == 2
 
 
 def test_no_device_means_loud_failure():

@@ -226,3 +226,92 @@ def test_split_point_matches_oracle(hip_ctx, oracle):
     pos, sm = hip_ctx.lz_split_point_batch_dev(d.data_ptr(), g1, g2, oo, ll, r1, p1, r2, p2)
     for j, (wp, ws) in enumerate(want):
         assert (int(pos[j]), int(sm[j])) == (wp, ws), f"job {j} (segment {j // 16}, combo {j % 16}): got {(int(pos[j]), int(sm[j]))} want {(wp, ws)}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the same entry points on sequences of a 2-bit packed sample (agc_hip_*_packed): what the create path calls.  The byte-input
+# tests above reach the same kernels through a packed copy whose blocks are nearly all escaped (their texts sit between N
+# gaps); here the texts lie in clean blocks, at every alignment inside the 16-symbol words, so that the 64-bit XOR compare,
+# the funnel shifts and the reversed reads of reverse-complemented texts are what runs.
+# ---------------------------------------------------------------------------------------------------------------------
+def _packed_sample(hip_ctx, texts, rng, gap_fill="acgt"):
+    """texts back to back with ragged gaps of random ACGT (clean blocks) or of N (escaped blocks) -> (Packed, keep, off, len, buf)"""
+    import torch
+    off, parts, o = [], [], 0
+    for i, t in enumerate(texts):
+        g = int(rng.integers(1, 40))
+        parts.append(rng.integers(0, 4, g).astype(np.uint8) if gap_fill == "acgt" else np.full(g, 4, np.uint8))
+        o += g
+        off.append(o)
+        parts.append(t)
+        o += t.size
+    parts.append(rng.integers(0, 4, 70).astype(np.uint8))
+    buf = np.concatenate(parts)
+    d = torch.from_numpy(buf).cuda()
+    torch.cuda.synchronize()
+    pk, keep = hip_ctx.pack_dev(d)
+    return pk, (keep, d), np.array(off, np.uint64), np.array([t.size for t in texts], np.uint32), buf
+
+
+@pytest.mark.parametrize("gap_fill", ["acgt", "n"])
+def test_packed_entry_points_match_oracle(hip_ctx, oracle, registered, gap_fill):
+    rng = np.random.default_rng(2024)
+    texts = [t for (_m, _r, t) in registered]
+    pk, keep, off, ln, buf = _packed_sample(hip_ctx, texts, rng, gap_fill)
+    gids = 1000 + np.arange(len(registered))
+    for rcflag in (0, 1):
+        rc = np.full(len(registered), rcflag, np.uint8)
+        enc, eoff = hip_ctx.lz_encode_batch_packed(pk, gids, off, ln, rc=rc)
+        cost, peak = hip_ctx.lz_estimate_batch_packed(pk, gids, off, ln, rc=rc)
+        for prefix in (0, 1):
+            costs = hip_ctx.lz_cost_vector_batch_packed(pk, gids, off, ln, rc, np.full(len(registered), prefix, np.uint8))
+            p = 0
+            for i, (mml, ref, text) in enumerate(registered):
+                t = oracle.rev_comp(text) if rcflag else text
+                assert np.array_equal(costs[p:p + t.size], oracle.LZ(ref, mml).cost_vector(t, prefix)), f"cost vector case {i} rc={rcflag} prefix={prefix}"
+                p += t.size
+        for i, (mml, ref, text) in enumerate(registered):
+            z = oracle.LZ(ref, mml)
+            t = oracle.rev_comp(text) if rcflag else text
+            assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], z.encode(t)), f"encode case {i} rc={rcflag} gaps={gap_fill}"
+            want, wpeak = z.estimate(t, want_peak=True)
+            assert (int(cost[i]), int(peak[i])) == (want, wpeak), f"estimate case {i} rc={rcflag}"
+    # the encode in two halves, the other entry points in between
+    hip_ctx.lz_encode_begin_packed(pk, gids, off, ln)
+    back, boff = hip_ctx.fetch_slices_packed(pk, off, ln, rc=(np.arange(len(registered)) % 2).astype(np.uint8))
+    enc2, eoff2 = hip_ctx.lz_encode_end()
+    one, ooff = hip_ctx.lz_encode_batch_packed(pk, gids, off, ln)
+    assert np.array_equal(enc2, one) and np.array_equal(eoff2, ooff)
+    for i, (_m, _r, text) in enumerate(registered):
+        assert np.array_equal(back[int(boff[i]):int(boff[i + 1])], oracle.rev_comp(text) if i % 2 else text), i
+    cnt, cur = hip_ctx.ref_lag_counts_packed(pk, off, ln)
+    for i, (_m, _r, text) in enumerate(registered):
+        wc, wu = oracle.ref_lag_counts(text)
+        assert np.array_equal(cnt[i], wc) and np.array_equal(cur[i], wu), i
+
+
+def test_packed_references_out_of_a_sample(hip_ctx, oracle):
+    """agc_hip_ref_register_batch_packed: new references cut out of a packed sample at odd offsets, both orientations, clean and
+    with N runs / IUPAC codes (escape blocks of the stored form): stored symbols, index tables, and encodes against them"""
+    from agc_amd import synth
+    rng = np.random.default_rng(77)
+    mml = 20
+    refs = [synth.random_seq(rng, n) for n in (37, 1000, 1024, 5000, 70_001)]
+    refs += [synth.mutate(rng, synth.random_seq(rng, 9000), 0.0, n_runs=3, iupac=3), synth.mutate(rng, synth.random_seq(rng, 2500), 0.0, n_runs=1)]
+    pk, keep, off, ln, buf = _packed_sample(hip_ctx, refs, rng, "acgt")
+    rc = (np.arange(len(refs)) % 2).astype(np.uint8)
+    gid0 = 9000
+    hip_ctx.ref_register_batch_packed(gid0 + np.arange(len(refs)), pk, off, ln, rc, mml)
+    texts = []
+    for i, r in enumerate(refs):
+        stored = oracle.rev_comp(r) if rc[i] else r
+        assert np.array_equal(hip_ctx.ref_get(gid0 + i), stored), i
+        tab, is16 = hip_ctx.ref_index_get(gid0 + i)
+        want = oracle.LZ(stored, mml).index()
+        assert np.array_equal(tab.astype(np.uint32), want.astype(np.uint32)), i
+        texts.append(synth.mutate(rng, stored, 0.004, n_runs=1 if i % 2 else 0, indels=1) if stored.size > 200 else stored.copy())
+    pk2, keep2, off2, ln2, _ = _packed_sample(hip_ctx, texts, rng, "acgt")
+    enc, eoff = hip_ctx.lz_encode_batch_packed(pk2, gid0 + np.arange(len(refs)), off2, ln2)
+    for i, r in enumerate(refs):
+        stored = oracle.rev_comp(r) if rc[i] else r
+        assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], oracle.LZ(stored, mml).encode(texts[i])), i

@@ -168,9 +168,9 @@ def test_packed_scan_matches_oracle(hip_ctx, oracle, k):
 
 @pytest.mark.parametrize("k", [21, 31])
 def test_prefetched_scan_matches_oracle(hip_ctx, oracle, k):
-    """agc_hip_prefetch_packed_dev + agc_hip_scan_prefetched (the next sample's expansion and scan queued ahead on their own
-    stream) deliver what the oracle's scan reports and the symbols the pack held; two prefetches in a row alternate the staging
-    buffers; a scan_prefetched for another sample is refused"""
+    """agc_hip_prefetch_packed_dev + agc_hip_scan_prefetched (the next sample's scan queued ahead on its own stream) deliver
+    what the oracle's scan reports; the packed sample reads back symbol for symbol (agc_hip_fetch_slices_packed); a
+    scan_prefetched for another sample is refused"""
     import ctypes as C
     import torch
     from agc_amd import capi
@@ -181,7 +181,6 @@ def test_prefetched_scan_matches_oracle(hip_ctx, oracle, k):
         spl, contigs = _packed_case(oracle, rng, k)
         cases.append(contigs)
     hip_ctx.splitters_set(spl)
-    ptrs = []
     packed = []
     for contigs in cases:
         off = np.zeros(len(contigs) + 1, np.uint64)
@@ -192,8 +191,7 @@ def test_prefetched_scan_matches_oracle(hip_ctx, oracle, k):
         pk, keep = hip_ctx.pack_dev(d)
         packed.append((pk, keep, off, codes, contigs))
     for i, (pk, keep, off, codes, contigs) in enumerate(packed):
-        d_codes = hip_ctx.prefetch_packed_dev(pk, off, k)
-        ptrs.append(d_codes)
+        hip_ctx.prefetch_packed_dev(pk, off, k)
         if i == 0:  # another sample than the one in flight
             other = packed[1]
             n = C.c_uint64()
@@ -203,9 +201,10 @@ def test_prefetched_scan_matches_oracle(hip_ctx, oracle, k):
         want = _oracle_hits(oracle, contigs, k, spl)
         for g, w, name in zip(got, want, ("ctg", "pos", "dir", "rc")):
             assert np.array_equal(g, w), (i, name)
-        back, _ = hip_ctx.fetch_slices_dev(d_codes, [0], [codes.size])  # (the library's own stream: after the prefetch was waited for)
+        back, _ = hip_ctx.fetch_slices_packed(pk, [0], [codes.size])
         assert np.array_equal(back, codes), i
-    assert ptrs[0] != ptrs[1]  # two staging buffers in turn
+        back, _ = hip_ctx.fetch_slices_packed(pk, [3], [codes.size - 5], rc=[1])
+        assert np.array_equal(back, oracle.rev_comp(codes[3:codes.size - 2])), i
 
 
 def test_packed_scan_equals_byte_scan_on_a_big_sample(hip_ctx, oracle):
