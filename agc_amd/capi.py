@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libagc_hip.so")
 
 OK, ENODEV, EINVAL, ENOMEM, ECAP, ENOREF = 0, -1, -2, -3, -4, -5
 K_SCAN, K_INDEX, K_ENCODE, K_ESTIMATE, K_COSTVEC, K_REVCOMP, K_PREPROCESS, K_REFSTORE = range(8)
-K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd", "filter"]
+K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd", "filter", "segments"]
 
 # every symbol include/agc_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -37,6 +37,7 @@ SYMBOLS = [
     "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched", "agc_hip_sample_pack",
     "agc_hip_ref_register_batch_packed", "agc_hip_lz_encode_batch_packed", "agc_hip_lz_encode_begin_packed", "agc_hip_lz_estimate_batch_packed",
     "agc_hip_lz_cost_vector_batch_packed", "agc_hip_lz_split_point_batch_packed", "agc_hip_fetch_slices_packed", "agc_hip_ref_lag_counts_packed",
+    "agc_hip_group_hash", "agc_hip_group_map_set", "agc_hip_group_map_update", "agc_hip_segments_packed",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -48,6 +49,23 @@ vp = C.c_void_p
 class Packed(C.Structure):
     """agc_hip_packed (include/agc_hip.h): a sample in the 2-bit HBM layout"""
     _fields_ = [("d_words", C.c_void_p), ("d_esc_index", C.c_void_p), ("d_esc_bytes", C.c_void_p), ("n_symbols", C.c_uint64)]
+
+
+class GroupSlot(C.Structure):
+    """agc_hip_group_slot: one slot of the (k-mer 1, k-mer 2) -> group table"""
+    _fields_ = [("k1", C.c_uint64), ("k2", C.c_uint64), ("gid", C.c_int32), ("used", C.c_uint32)]
+
+
+class Segment(C.Structure):
+    """agc_hip_segment"""
+    _fields_ = [("start", C.c_uint64), ("front_dir", C.c_uint64), ("front_rc", C.c_uint64), ("back_dir", C.c_uint64), ("back_rc", C.c_uint64),
+                ("ctg", C.c_uint32), ("len", C.c_uint32), ("map_gid", C.c_int32), ("front_full", C.c_uint8), ("back_full", C.c_uint8),
+                ("store_rc", C.c_uint8), ("encoded", C.c_uint8)]
+
+
+SEGMENT_DTYPE = np.dtype([("start", "<u8"), ("front_dir", "<u8"), ("front_rc", "<u8"), ("back_dir", "<u8"), ("back_rc", "<u8"), ("ctg", "<u4"), ("len", "<u4"),
+                          ("map_gid", "<i4"), ("front_full", "u1"), ("back_full", "u1"), ("store_rc", "u1"), ("encoded", "u1")])
+GROUP_SLOT_DTYPE = np.dtype([("k1", "<u8"), ("k2", "<u8"), ("gid", "<i4"), ("used", "<u4")])
 
 
 class AgcHipError(RuntimeError):
@@ -140,11 +158,16 @@ def load():
     L.agc_hip_lz_split_point_batch_packed.argtypes = [vp, C.c_uint32, u32p, u32p, pkp, u64p, u32p, u8p, u8p, u8p, u8p, u32p, u32p]
     L.agc_hip_fetch_slices_packed.argtypes = [vp, C.c_uint32, pkp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_ref_lag_counts_packed.argtypes = [vp, C.c_uint32, pkp, u64p, u32p, u8p, u32p, u32p]
+    L.agc_hip_group_hash.argtypes = [C.c_uint64, C.c_uint64]
+    L.agc_hip_group_hash.restype = C.c_uint64
+    L.agc_hip_group_map_set.argtypes = [vp, vp, C.c_uint64]
+    L.agc_hip_group_map_update.argtypes = [vp, C.c_uint32, u64p, vp]
+    L.agc_hip_segments_packed.argtypes = [vp, pkp, u64p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint64, vp, u64p, u32p]
     L.agc_hip_scan_prefetched.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     for s in SYMBOLS:
         f = getattr(L, s)
         if s not in ("agc_hip_destroy", "agc_hip_last_error", "agc_hip_abi_version", "agc_hip_splitters_count", "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames",
-                     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes"):
+                     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_group_hash"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -307,6 +330,44 @@ class Context:
     def scan_prefetched(self, pk, ctg_off, k, cap=1 << 16):
         fn = lambda h, arg, *rest: self.L.agc_hip_scan_prefetched(h, C.byref(arg), *rest)
         return self._scan(fn, pk, ctg_off, k, cap)
+
+    # ---- segments and their groups on the device ------------------------------
+    def group_map_set(self, keys_to_gid, n_slots=None):
+        """{(k1, k2): gid} -> the open-addressing array of include/agc_hip.h, uploaded whole; returns the numpy table"""
+        n = max(16, n_slots or 16)
+        while n < 2 * len(keys_to_gid):
+            n *= 2
+        tab = np.zeros(n, GROUP_SLOT_DTYPE)
+        for (k1, k2), gid in keys_to_gid.items():
+            i = int(self.L.agc_hip_group_hash(k1, k2)) & (n - 1)
+            while tab[i]["used"]:
+                i = (i + 1) & (n - 1)
+            tab[i] = (k1, k2, gid, 1)
+        self._chk(self.L.agc_hip_group_map_set(self.h, tab.ctypes.data, n))
+        return tab
+
+    def group_map_update(self, idx, slots):
+        idx = _a(idx, np.uint64)
+        slots = np.ascontiguousarray(slots, dtype=GROUP_SLOT_DTYPE)
+        self._chk(self.L.agc_hip_group_map_update(self.h, idx.size, _p(idx, u64p), slots.ctypes.data))
+
+    def segments_packed(self, pk, ctg_off, k, prefetched=False, encode_known=False, cap=1 << 12):
+        """-> (segments as a structured numpy array, number of deltas the launched encode will deliver)"""
+        off = _a(ctg_off, np.uint64)
+        while True:
+            segs = np.zeros(cap, SEGMENT_DTYPE)
+            n = C.c_uint64()
+            ne = C.c_uint32()
+            rc = self.L.agc_hip_segments_packed(self.h, C.byref(pk), _p(off, u64p), off.size - 1, k, int(prefetched), int(encode_known), cap, segs.ctypes.data,
+                                                C.byref(n), C.byref(ne))
+            if rc == ECAP:
+                cap = int(n.value)
+                continue
+            self._chk(rc)
+            if encode_known:
+                ln = segs["len"][:n.value][segs["encoded"][:n.value] != 0].astype(np.uint32)
+                self._enc_pending = (np.zeros(ln.size, np.uint32), None, ln, None)  # (what lz_encode_end sizes its buffers by)
+            return segs[:n.value], int(ne.value)
 
     def scan_contigs(self, codes, ctg_off, k, cap=1 << 16):
         codes = _a(codes, np.uint8)

@@ -16,6 +16,7 @@
 
 #include "scan_kernels.hip"
 #include "lz_kernels.hip"
+#include "seg_kernels.hip"
 #include "zstd_kernels.hip"
 
 using namespace agc;
@@ -73,6 +74,10 @@ struct agc_hip_ctx {
 
     // scratch
     DevBuf d_esc_jobs, d_flags;
+    // the (k1, k2) -> group table (mirror of the host's map_segments) and the work area of agc_hip_segments_packed
+    DevBuf d_gmap, d_gmap_stage, d_segwork, d_segtmp;
+    uint64_t gmap_slots = 0;
+    void *h_segcounts = nullptr; // pinned: SegCounts of the call in flight
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
         d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_zdstoff, d_maybe, d_fjobs;
 
@@ -378,7 +383,9 @@ void agc_hip_destroy(agc_hip_ctx *c)
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
                       &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs,
                       &c->l2.d_segs, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
-                      &c->l2.d_compact, &c->d_esc_jobs, &c->d_flags};
+                      &c->l2.d_compact, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
+    if (c->h_segcounts)
+        (void)hipHostFree(c->h_segcounts);
     for (PackTemp *t : {&c->pk1, &c->pk_sample, &c->l2.pk})
         for (DevBuf *b : {&t->words, &t->index, &t->esc, &t->cnt})
             if (b->p)
@@ -846,15 +853,12 @@ static int sbloom_upload(agc_hip_ctx *c, uint32_t k)
     return AGC_HIP_OK;
 }
 
-int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap,
-                            uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+} // extern "C"
+
+// the packed splitter scan of a sample on the context's stream: raw hits (unsorted, before the reset rule) in c->d_hits
+static int packed_scan_raw(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint32_t *n_found_out)
 {
-    if (!c || !pk || !h_ctg_off || !h_n_hits || k < 16 || k > 32)
-        return AGC_HIP_EINVAL; // (k < 16: the last-16-symbols filter does not apply; expand and use agc_hip_scan_contigs_dev)
-    if (cap && (!h_hit_ctg || !h_hit_pos || !h_hit_dir || !h_hit_rc))
-        return AGC_HIP_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
-    *h_n_hits = 0;
+    *n_found_out = 0;
     if (!c->d_table.p)
         CHK(splitters_upload(c));
     const uint64_t total = n_ctg ? h_ctg_off[n_ctg] - h_ctg_off[0] : 0;
@@ -923,6 +927,25 @@ int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
             break;
         dev_cap = n_found;
     }
+    *n_found_out = n_found;
+    return AGC_HIP_OK;
+}
+
+extern "C" {
+
+int agc_hip_scan_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, uint64_t cap,
+                            uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir, uint64_t *h_hit_rc)
+{
+    if (!c || !pk || !h_ctg_off || !h_n_hits || k < 16 || k > 32)
+        return AGC_HIP_EINVAL; // (k < 16: the last-16-symbols filter does not apply; expand and use agc_hip_scan_contigs_dev)
+    if (cap && (!h_hit_ctg || !h_hit_pos || !h_hit_dir || !h_hit_rc))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    *h_n_hits = 0;
+    uint32_t n_found = 0;
+    CHK(packed_scan_raw(c, pk, h_ctg_off, n_ctg, k, &n_found));
+    if (!n_found)
+        return AGC_HIP_OK;
     return deliver_hits(c, n_found, h_ctg_off, n_ctg, k, cap, h_n_hits, h_hit_ctg, h_hit_pos, h_hit_dir, h_hit_rc);
 }
 
@@ -1405,14 +1428,14 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
 }
 
 template <int MODE>
-int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, bool lane2 = false)
+int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, bool lane2 = false, const uint32_t *n_dev = nullptr)
 {
     const uint32_t grid = (n + 3) / 4; // one wave per segment, 4 waves per block
     {
         KTimer t(c, lane2 ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
         hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, lane2 ? c->stream2 : c->stream, (const RefDesc *)c->d_refs.p,
                            (const SegDesc *)(lane2 ? c->l2.d_segs.p : c->d_segs.p), n, out_bytes, out_u32,
-                           (uint32_t *)(lane2 ? c->l2.d_resv.p : c->d_resv.p), (uint32_t *)(lane2 ? c->l2.d_resp.p : c->d_resp.p));
+                           (uint32_t *)(lane2 ? c->l2.d_resv.p : c->d_resv.p), (uint32_t *)(lane2 ? c->l2.d_resp.p : c->d_resp.p), n_dev);
     }
     HIPCHK(c, hipGetLastError());
     return AGC_HIP_OK;
@@ -1598,6 +1621,24 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint
         }
         c->l2.timed = false; // (a second call after AGC_HIP_ECAP must not count the launch twice)
     }
+#ifdef AGC_PHASES
+    {
+        unsigned long long acc[8], cnt[8];
+        (void)hipMemcpyFromSymbol(acc, HIP_SYMBOL(agc::g_phase_acc), sizeof acc);
+        (void)hipMemcpyFromSymbol(cnt, HIP_SYMBOL(agc::g_phase_cnt), sizeof cnt);
+        static const char *nm[5] = {"emit", "window", "probe", "literals", "verify"};
+        unsigned long long tot = 0;
+        for (int k = 0; k < 5; ++k)
+            tot += acc[k];
+        for (int k = 0; k < 5; ++k)
+            fprintf(stderr, "phase %-8s %6.2f %%  %.0f cycles per visit (%llu visits)\n", nm[k], 100.0 * acc[k] / (tot ? tot : 1), cnt[k] ? (double)acc[k] / cnt[k] : 0.0, cnt[k]);
+        fprintf(stderr, "phase total %.0f cycles per wave (%u waves)\n", (double)tot / n, n);
+        (void)hipMemset((void *)nullptr, 0, 0);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(agc::g_phase_acc), z, sizeof z);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(agc::g_phase_cnt), z, sizeof z);
+    }
+#endif
     for (uint32_t i = 0; i < n; ++i)
         h_enc_off[i + 1] = h_enc_off[i] + c->l2.h_lens[i];
     const uint64_t tot = h_enc_off[n];
@@ -2221,3 +2262,4 @@ int agc_hip_zstd17_batch_dev(agc_hip_ctx *c, uint32_t n, const uint8_t *d_src, c
 } // extern "C"
 
 #include "splitters.hip"
+#include "segments.hip"

@@ -159,6 +159,12 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
         I.overlap_mode = !strcmp(e, "early") || !strcmp(e, "1") ? 1 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 0;
     I.choose_entropy_stage();
+    if (const char *e = getenv("AGC_AMD_DEV_SEGMENTS"))
+        I.dev_segments = atoi(e) != 0;
+    if (!PkMap::hash_agrees()) {
+        I.err("internal: the host's and the device library's group hash differ");
+        return false;
+    }
     I.created = true;
 
     if (!reference_file_name.empty()) {
@@ -340,6 +346,12 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
         I.overlap_mode = !strcmp(e, "early") || !strcmp(e, "1") ? 1 : !strcmp(e, "late") || !strcmp(e, "2") ? 2 : 0;
     I.choose_entropy_stage();
+    if (const char *e = getenv("AGC_AMD_DEV_SEGMENTS"))
+        I.dev_segments = atoi(e) != 0;
+    if (!PkMap::hash_agrees()) {
+        I.err("internal: the host's and the device library's group hash differ");
+        return false;
+    }
 
     if (!I.ar.open(out_archive_name)) {
         I.err("Cannot create archive " + out_archive_name);

@@ -170,8 +170,11 @@ void CAGCCompressor::Impl::book_main()
                 ok = hip_ok(r, "lz_encode_end");
                 break;
             }
+            lane2_release(); // (the thread that drives the steps may launch the next sample's encode)
             if (ok) {
                 for (size_t i = 0; i < ne; ++i) {
+                    if (t->enc_todo[i] == ~0u)
+                        continue; // (a delta the device made ahead of the classification and the placement did not use)
                     t->cd.enc_ptr[t->enc_todo[i]] = enc.data() + eoff[i];
                     t->cd.enc_len[t->enc_todo[i]] = (uint32_t)(eoff[i + 1] - eoff[i]);
                 }
@@ -229,6 +232,23 @@ void CAGCCompressor::Impl::book_shutdown()
     }
     book_cv.notify_all();
     book_thread.join();
+}
+
+// the device's second LZ lane: one encode at a time
+void CAGCCompressor::Impl::lane2_acquire()
+{
+    std::unique_lock<std::mutex> lk(book_mtx);
+    book_idle_cv.wait(lk, [&] { return !lane2_inflight; });
+    lane2_inflight = true;
+}
+
+void CAGCCompressor::Impl::lane2_release()
+{
+    {
+        std::lock_guard<std::mutex> lk(book_mtx);
+        lane2_inflight = false;
+    }
+    book_idle_cv.notify_all();
 }
 
 void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
@@ -883,8 +903,111 @@ void CAGCCompressor::Impl::lap(BatchState &b, const char *what)
 }
 
 // compress_contig for every contig of the window: splitter hits from the GPU, adaptive-mode re-scan, segments
+// the device delivers segments, not hits: scan (or its prefetched result), reset rule, cut, keys and their look-up in the group
+// table all run there (agc_hip_segments_packed), and the encode of every segment whose group is known is launched from there
+bool CAGCCompressor::Impl::use_dev_segments(const BatchState &b) const
+{
+    return dev_segments && b.pk.n_symbols && k >= 16 && !adaptive && !appending && !concatenated && dist_world == 1 && b.n_ctg &&
+           (*b.ctgs).back().sample_idx == 0 && overlap_mode == 0;
+}
+
+bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
+{
+    const std::vector<Contig> &ctgs = *b.ctgs;
+    const uint32_t n_ctg = b.n_ctg;
+    double &t0 = b.t0, &dev0 = b.dev0;
+    std::vector<uint64_t> ctg_off(n_ctg + 1, 0);
+    for (uint32_t i = 0; i < n_ctg; ++i) {
+        ctg_off[i] = ctgs[i].off;
+        st.bases += ctgs[i].len;
+        if (i + 1 < n_ctg && ctgs[i].off + ctgs[i].len != ctgs[i + 1].off) {
+            err("internal: contigs of a batch must be contiguous in HBM");
+            return false;
+        }
+    }
+    ctg_off[n_ctg] = ctgs.back().off + ctgs.back().len;
+    // the groups minted since the last sample go to the device's table first
+    if (!hip_ok(DEVT(map_segments.sync_device(hip)), "group_map"))
+        return false;
+    // the encode of the known segments is launched by the same call when its deltas can be collected beside the next sample
+    // (bookkeeping thread); otherwise the commit encodes as before
+    const bool enc = async_encode && book_can_async(1) && b.base_owned;
+    if (enc)
+        lane2_acquire(); // (the previous sample's encode has been collected)
+    uint64_t cap = std::max<uint64_t>(dev_seg_buf.size(), std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000 + n_ctg));
+    uint64_t n_segs = 0;
+    uint32_t n_enc = 0;
+    for (;;) {
+        if (dev_seg_buf.size() < cap)
+            dev_seg_buf.resize(cap);
+        const int rc = DEVT(agc_hip_segments_packed(hip, &b.pk, ctg_off.data(), n_ctg, k, scan_from_prefetch ? 1 : 0, enc ? 1 : 0, dev_seg_buf.size(),
+                                                    dev_seg_buf.data(), &n_segs, &n_enc));
+        if (rc == AGC_HIP_ECAP) {
+            cap = n_segs + n_segs / 8 + 64;
+            continue;
+        }
+        if (!hip_ok(rc, "segments_packed")) {
+            if (enc)
+                lane2_release();
+            return false;
+        }
+        break;
+    }
+    if (enc && !n_enc)
+        lane2_release(); // (nothing was launched: no group known yet)
+    b.dev_keys = true;
+    b.dev_enc_n = n_enc;
+    stage_end(st.t_scan, st.h_scan, t0, dev0);
+    t0 = now();
+    lap(b, "scan + segments (device)");
+    std::vector<Seg> &segs = seg_buf;
+    segs.resize(n_segs);
+    if (b.spec.size() != 2 * segs.size()) {
+        b.spec.assign(2 * segs.size(), BatchState::Spec());
+        b.spec_bytes = 0;
+    }
+    uint32_t r = 0;
+    for (size_t i = 0; i < n_segs; ++i) {
+        const agc_hip_segment &d = dev_seg_buf[i];
+        Seg &s = segs[i];
+        s.ctg = d.ctg;
+        s.start = d.start;
+        s.len = d.len;
+        s.front.dir = d.front_dir;
+        s.front.rc = d.front_rc;
+        s.front.full = d.front_full != 0;
+        s.back.dir = d.back_dir;
+        s.back.rc = d.back_rc;
+        s.back.full = d.back_full != 0;
+        s.dev_gid = d.front_full && d.back_full ? d.map_gid : -2;
+        if (d.encoded) {
+            // the delta of this segment is being made: matched to the placed item at commit time like every speculative delta
+            BatchState::Spec &sp = b.spec[2 * i];
+            sp.valid = true;
+            sp.gid = (uint32_t)d.map_gid;
+            sp.off = ctgs[d.ctg].off + d.start;
+            sp.len = d.len;
+            sp.rc = d.store_rc != 0;
+            sp.enc_off = 0;
+            sp.enc_len = 0;
+            sp.pending = (int32_t)r++;
+            st.enc_text += d.len;
+            st.enc_ref += groups[(uint32_t)d.map_gid].ref_size ? groups[(uint32_t)d.map_gid].ref_size - 1 : 0;
+        }
+    }
+    if (r != n_enc) {
+        err("internal: the device's encode list and its segment flags disagree");
+        return false;
+    }
+    st.lz_encoded += n_enc;
+    lap(b, "segments -> host records");
+    return true;
+}
+
 bool CAGCCompressor::Impl::stage_scan(BatchState &b)
 {
+    if (use_dev_segments(b))
+        return stage_scan_dev(b);
     const std::vector<Contig> &ctgs = *b.ctgs;
     const uint8_t *d_base = b.d_base;
     const uint32_t n_ctg = b.n_ctg;
@@ -1111,7 +1234,9 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
                         s.pk = {s.back.data(), s.front.data()};
                         s.store_rc = true;
                     }
-                    if (const int32_t *m = map_segments.find(s.pk))
+                    if (b.dev_keys && s.dev_gid != -2)
+                        s.map_gid = s.dev_gid; // (looked up on the device against the same table, with the cut)
+                    else if (const int32_t *m = map_segments.find(s.pk))
                         s.map_gid = *m;
                 } // (no splitter at all: pk stays {NO_KMER, NO_KMER}, agc_compressor.cpp:1286-1301, fallback filter off)
             }
@@ -1401,6 +1526,7 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
         segs[mids[i].seg].bp = best_pos[i];
     stage_end(st.t_gpu_aux, st.h_gpu_aux, t0, dev0);
     t0 = now();
+    b.dev_keys = false; // (a later pass -- revalidation -- reads the map as it is then)
 
     return true;
 }
@@ -1863,16 +1989,24 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
     if (b.enc_in_flight && !overlap_encode_end(b))
         return false;
     LAP("encode_end");
-    std::vector<uint32_t> enc_later; // positions in enc_items whose encode is in flight on the second lane
+    std::vector<uint32_t> enc_later; // per result of the encode in flight on the second lane: its position in enc_items (~0u: unused)
     uint64_t enc_later_text = 0;
+    const bool bulk = b.dev_enc_n != 0; // the device launched the encode of the segments whose group it knew (stage_scan_dev)
+    if (bulk)
+        enc_later.assign(b.dev_enc_n, ~0u);
     {
         std::vector<uint32_t> todo; // positions in enc_items
         for (uint32_t i = 0; i < enc_items.size(); ++i) {
             const Placed &pl = placed[enc_items[i]];
             const BatchState::Spec *sp = pl.key < b.spec.size() ? &b.spec[pl.key] : nullptr;
             if (sp && sp->valid && sp->gid == (uint32_t)pl.gid && sp->off == pl.off && sp->len == pl.len && sp->rc == pl.rc) {
-                enc_ptr[i] = enc_buf.data() + sp->enc_off;
-                enc_len[i] = sp->enc_len;
+                if (sp->pending >= 0) {
+                    enc_later[(uint32_t)sp->pending] = i;
+                    enc_later_text += pl.len;
+                } else {
+                    enc_ptr[i] = enc_buf.data() + sp->enc_off;
+                    enc_len[i] = sp->enc_len;
+                }
             } else
                 todo.push_back(i);
         }
@@ -1895,9 +2029,12 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             // The encode is only LAUNCHED here when its result is first read by the bookkeeping task: the task collects it (second
             // device lane) while this thread goes on with the next sample.  Needs a sample in a staging buffer the device context
             // owns (it outlives the call) and nothing else on that lane.
-            if (hand_over && async_encode && dist_world == 1 && b.base_owned && b.pk.n_symbols && overlap_mode == 0 && !b.enc_in_flight && b.spec_bytes == 0) {
-                if (!hip_ok(DEVT(agc_hip_lz_encode_begin_packed(hip, (uint32_t)ne, gid.data(), &b.pk, off.data(), len.data(), rc.data())), "lz_encode_begin"))
+            if (!bulk && hand_over && async_encode && dist_world == 1 && b.base_owned && b.pk.n_symbols && overlap_mode == 0 && !b.enc_in_flight && b.spec_bytes == 0) {
+                lane2_acquire();
+                if (!hip_ok(DEVT(agc_hip_lz_encode_begin_packed(hip, (uint32_t)ne, gid.data(), &b.pk, off.data(), len.data(), rc.data())), "lz_encode_begin")) {
+                    lane2_release();
                     return false;
+                }
                 enc_later.swap(todo);
                 enc_later_text = tot;
                 st.lz_encoded += ne;
@@ -1929,6 +2066,34 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
         }
     }
     LAP(enc_later.empty() ? "encode" : "encode (in flight)");
+    if (bulk && !hand_over) {
+        // the synchronous path after all: the device's encode is collected here
+        const size_t ne = enc_later.size();
+        std::vector<uint64_t> eoff(ne + 1, 0);
+        uint64_t cap = std::max<uint64_t>(enc_buf.size(), enc_later_text / 64 + (1u << 16));
+        for (;;) {
+            if (!enc_buf.resize(cap, false)) {
+                err("out of memory (delta buffer)");
+                return false;
+            }
+            const int r = DEVT(agc_hip_lz_encode_end(hip, enc_buf.data(), cap, eoff.data()));
+            if (r == AGC_HIP_ECAP) {
+                cap = eoff[ne] + eoff[ne] / 8 + 4096;
+                continue;
+            }
+            lane2_release();
+            if (!hip_ok(r, "lz_encode_end"))
+                return false;
+            break;
+        }
+        for (size_t i = 0; i < ne; ++i)
+            if (enc_later[i] != ~0u) {
+                enc_ptr[enc_later[i]] = enc_buf.data() + eoff[i];
+                enc_len[enc_later[i]] = (uint32_t)(eoff[i + 1] - eoff[i]);
+            }
+        st.delta_bytes += eoff[ne];
+        enc_later.clear();
+    }
     stage_end(st.t_encode, st.h_encode, t0, dev0);
     t0 = now();
 
@@ -1969,7 +2134,9 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             t->enc_pending = true;
             t->enc_todo = std::move(enc_later);
             t->enc_text = enc_later_text;
-            t->enc_dst = &enc_alt2;
+            // (the deltas encoded at commit time sit in enc_alt2 now; the device-launched encode of the whole sample is collected
+            // into the other buffer of the set, which holds nothing in this mode: spec_bytes == 0)
+            t->enc_dst = bulk ? &enc_alt : &enc_alt2;
         }
         last_own_seq = book_submit(std::move(t));
         LAP("book_and_store (queued)");
@@ -2184,8 +2351,10 @@ void CAGCCompressor::Impl::note_new_group(const pk_t &pk, uint32_t gid)
     int32_t *it = map_segments.find(pk);
     if (!it)
         map_segments[pk] = (int32_t)gid;
-    else if (*it > (int32_t)gid)
+    else if (*it > (int32_t)gid) {
         *it = (int32_t)gid;
+        map_segments.touch(it);
+    }
     if (prepared)
         minted_since_prepare = true;
     if (prepared && pk.first != NO_KMER && pk.second != NO_KMER) {

@@ -46,24 +46,45 @@ struct PairHash {
 #define DEVTI(call) DEVT_(I.st, call)
 #define DEVTP(call) DEVT_(p->st, call)
 
-// (kmer1, kmer2) -> group id: flat open-addressing table (one cache line per lookup instead of a node chase)
+// (kmer1, kmer2) -> group id: flat open-addressing table (one cache line per lookup instead of a node chase).  The same array,
+// slot for slot, is what the device's look-up kernel probes (include/agc_hip.h: agc_hip_group_slot, agc_hip_group_hash): the
+// map remembers which slots changed since the mirror in HBM was last brought up to date (sync_device).
 class PkMap {
     struct Slot {
         uint64_t a, b;
         int32_t v;
         uint32_t used;
     };
+    static_assert(sizeof(Slot) == sizeof(agc_hip_group_slot), "the device mirrors this array");
     std::vector<Slot> t;
     size_t n = 0, mask = 0;
+    std::vector<uint64_t> dirty; // slots written since the last sync_device
+    bool rebuilt = true;         // the whole array was laid out anew
+    // == agc_hip_group_hash (inlined: the look-ups of a sample run in the pool's inner loops; hash_agrees() checks it once)
+    static size_t home(const pk_t &k) { return PairHash()(k); }
+
+public:
+    static bool hash_agrees()
+    {
+        const pk_t probes[3] = {{1, 2}, {0x0123456789ABCDEFULL, ~0ULL}, {~0ULL, 0x9E3779B97F4A7C15ULL}};
+        for (const pk_t &q : probes)
+            if (home(q) != (size_t)agc_hip_group_hash(q.first, q.second))
+                return false;
+        return true;
+    }
+
+private:
     void grow()
     {
         std::vector<Slot> old;
         old.swap(t);
         t.assign(old.empty() ? 1024 : old.size() * 2, Slot{0, 0, 0, 0});
         mask = t.size() - 1;
+        rebuilt = true;
+        dirty.clear();
         for (const Slot &s : old)
             if (s.used) {
-                size_t i = PairHash()(pk_t{s.a, s.b}) & mask;
+                size_t i = home(pk_t{s.a, s.b}) & mask;
                 while (t[i].used)
                     i = (i + 1) & mask;
                 t[i] = s;
@@ -76,12 +97,40 @@ public:
     {
         t.clear();
         n = mask = 0;
+        rebuilt = true;
+        dirty.clear();
+    }
+    // the slot of p (a pointer find / operator[] returned) was written
+    void touch(const int32_t *p)
+    {
+        if (!rebuilt)
+            dirty.push_back((uint64_t)(((const uint8_t *)p - (const uint8_t *)t.data()) / sizeof(Slot)));
+    }
+    // brings the device's copy up to date: the whole array after a re-layout, the changed slots otherwise
+    int sync_device(agc_hip_ctx *ctx)
+    {
+        int rc = AGC_HIP_OK;
+        if (rebuilt)
+            rc = agc_hip_group_map_set(ctx, (const agc_hip_group_slot *)t.data(), t.size());
+        else if (!dirty.empty()) {
+            std::sort(dirty.begin(), dirty.end());
+            dirty.erase(std::unique(dirty.begin(), dirty.end()), dirty.end());
+            std::vector<agc_hip_group_slot> sl(dirty.size());
+            for (size_t i = 0; i < dirty.size(); ++i)
+                memcpy(&sl[i], &t[dirty[i]], sizeof(Slot));
+            rc = agc_hip_group_map_update(ctx, (uint32_t)dirty.size(), dirty.data(), sl.data());
+        }
+        if (rc == AGC_HIP_OK) {
+            rebuilt = false;
+            dirty.clear();
+        }
+        return rc;
     }
     int32_t *find(const pk_t &k)
     {
         if (t.empty())
             return nullptr;
-        for (size_t i = PairHash()(k) & mask;; i = (i + 1) & mask) {
+        for (size_t i = home(k) & mask;; i = (i + 1) & mask) {
             Slot &s = t[i];
             if (!s.used)
                 return nullptr;
@@ -95,11 +144,12 @@ public:
             return *p;
         if ((n + 1) * 2 > t.size())
             grow();
-        size_t i = PairHash()(k) & mask;
+        size_t i = home(k) & mask;
         while (t[i].used)
             i = (i + 1) & mask;
         t[i] = Slot{k.first, k.second, 0, 1};
         ++n;
+        touch(&t[i].v); // (the caller assigns the value right away: the slot is read when the mirror is synchronised)
         return t[i].v;
     }
     template <typename F> void for_each(F f) const
@@ -146,6 +196,7 @@ struct Seg { // one segment as compress_contig cuts it (agc_compressor.cpp:2007-
     int32_t mid_job = -1;
     int32_t known_gid = -2; // group of pk when classification looked it up (-1: not there, -2: not looked up)
     int32_t map_gid = -1;   // both splitters: what map_segments holds for pk (looked up once, by the pool; -1: not there)
+    int32_t dev_gid = -2;   // ... as the device's look-up delivered it with the segment (agc_hip_segments_packed); -2: not looked up there
     uint32_t bp = 0;        // split position of a missing-middle job (before the k+1 clamps)
     Kmer kmer1, kmer2;
     bool use_rc = false;
@@ -844,6 +895,7 @@ struct CAGCCompressor::Impl {
         struct Spec {                              // speculative delta of a placed item (by Placed::key)
             uint64_t off = 0, enc_off = 0;
             uint32_t gid = 0, len = 0, enc_len = 0;
+            int32_t pending = -1; // >= 0: the delta is result no. `pending` of the encode in flight on the device's second lane
             bool rc = false, valid = false;
         };
         std::vector<Spec> spec;
@@ -851,6 +903,10 @@ struct CAGCCompressor::Impl {
         // single-registration window: the segments whose group is known from their two splitters (nearly all) are encoded
         // on the device's second stream while the rest of the window is still being classified
         bool overlap_encode = false, enc_in_flight = false;
+        // the segments came from the device with their groups (agc_hip_segments_packed): the first classification takes the keys as
+        // delivered; dev_enc_n != 0: the encode of the segments whose group was known is in flight on the device's second lane
+        bool dev_keys = false;
+        uint32_t dev_enc_n = 0;
         std::vector<uint32_t> flight_keys, flight_gid, flight_len;
         std::vector<uint64_t> flight_off;
         std::vector<uint8_t> flight_rc;
@@ -865,6 +921,15 @@ struct CAGCCompressor::Impl {
         } sto;
     };
     bool stage_scan(BatchState &b);
+    bool stage_scan_dev(BatchState &b);
+    bool use_dev_segments(const BatchState &b) const;
+    bool dev_segments = true;          // AGC_AMD_DEV_SEGMENTS=0: scan hits to the host, cut and key look-up there (the round-3 path)
+    std::vector<agc_hip_segment> dev_seg_buf;
+    // the device's second LZ lane carries one encode at a time: launched by the thread that drives the steps, collected by the
+    // bookkeeping thread (or by the driver itself on the synchronous path)
+    bool lane2_inflight = false;       // (guarded by book_mtx)
+    void lane2_acquire();
+    void lane2_release();
     bool stage_classify(BatchState &b);
     bool stage_place(BatchState &b);
     bool stage_register(BatchState &b);

@@ -16,6 +16,24 @@
 #ifndef AGC_TRACE
 #define AGC_TRACE(code, val)
 #endif
+// -DAGC_PHASES (a profiling build, scripts/lz_phase_probe.sh): shader-clock time of the parse loop's phases, accumulated per wave
+// and printed by a few waves of the encode launch.  Costs ~10 %; never part of the product build.
+#ifdef AGC_PHASES
+namespace agc {
+__device__ unsigned long long g_phase_acc[8], g_phase_cnt[8];
+}
+#define PH_DECL uint64_t ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_amdgcn_s_memtime();
+#define PH(k)                                                  \
+    {                                                          \
+        const uint64_t ph_now = __builtin_amdgcn_s_memtime();  \
+        ph_acc[k] += ph_now - ph_last;                         \
+        ph_cnt[k] += 1;                                        \
+        ph_last = ph_now;                                      \
+    }
+#else
+#define PH_DECL
+#define PH(k)
+#endif
 
 namespace agc {
 
@@ -80,13 +98,15 @@ __device__ bool wave_view_clean(const SymView &v)
     return __ballot(any) == 0;
 }
 
-// 32 symbols (P, I as sv_fetch32 delivers them; cnt of them valid) as bytes at dst (LDS, 32-byte aligned)
-__device__ __forceinline__ void store_syms32(uint8_t *dst, const SymView &v, uint32_t pos, uint32_t cnt, uint64_t P, uint32_t I)
+// a lane's chunk (N = 16 or 32 symbols: P, I as sv_fetch delivers them; cnt of them valid) as bytes at dst (LDS, N-byte aligned)
+template <uint32_t N>
+__device__ __forceinline__ void store_syms(uint8_t *dst, const SymView &v, uint32_t pos, uint32_t cnt, uint64_t P, uint32_t I)
 {
-    if (cnt == 32 && I == 0) {
+    if (cnt == N && I == 0) {
         const uint32_t lo = (uint32_t)P, hi = (uint32_t)(P >> 32);
         *(uint4 *)dst = make_uint4(sv_expand4(lo), sv_expand4(lo >> 8), sv_expand4(lo >> 16), sv_expand4(lo >> 24));
-        *(uint4 *)(dst + 16) = make_uint4(sv_expand4(hi), sv_expand4(hi >> 8), sv_expand4(hi >> 16), sv_expand4(hi >> 24));
+        if (N == 32)
+            *(uint4 *)(dst + 16) = make_uint4(sv_expand4(hi), sv_expand4(hi >> 8), sv_expand4(hi >> 16), sv_expand4(hi >> 24));
     } else {
         for (uint32_t j = 0; j < cnt; ++j)
             dst[j] = (uint8_t)(((I >> j) & 1u) ? sv_sym(v, pos + j) : (uint32_t)(P >> (2u * j)) & 3u);
@@ -97,8 +117,14 @@ __device__ __forceinline__ void store_syms32(uint8_t *dst, const SymView &v, uin
 // positions) without another trip to HBM.  It is refilled from the packed words when the parse position leaves it (512 bytes
 // of HBM for 2048 symbols) and -- for free -- by the last step of every forward compare, whose text chunk contains the
 // position right after the match.
-constexpr uint32_t CMP_SYMS = 32;              // symbols a lane compares per step: one 64-bit XOR
-constexpr uint32_t WIN_SYMS = WAVE * CMP_SYMS; // 2048
+#ifndef AGC_LZ_CMP
+#define AGC_LZ_CMP 16
+#endif
+// symbols a lane compares per step: 16 (two dwords per side) or 32 (three).  Measured on the 3 Gbp step: the same kernel time
+// (4.2 ms) -- a second step for the 37 % of matches beyond 1024 symbols costs what the narrower loads save -- and a third less
+// HBM traffic with 16.
+constexpr uint32_t CMP_SYMS = AGC_LZ_CMP;
+constexpr uint32_t WIN_SYMS = WAVE * CMP_SYMS; // 1024 / 2048
 struct TextWin {
     uint8_t *lds;   // WIN_SYMS bytes of LDS owned by this wave
     uint32_t base;  // text position of lds[0]
@@ -119,8 +145,8 @@ __device__ __forceinline__ void win_fill(TextWin &w, const SymView &tv, bool t_c
         const uint32_t cnt = len - off < CMP_SYMS ? len - off : CMP_SYMS;
         uint64_t P;
         uint32_t I;
-        sv_fetch32(tv, pos + off, cnt, t_clean, P, I);
-        store_syms32(w.lds + off, tv, pos + off, cnt, P, I);
+        sv_fetch<CMP_SYMS>(tv, pos + off, cnt, t_clean, P, I);
+        store_syms<CMP_SYMS>(w.lds + off, tv, pos + off, cnt, P, I);
     }
     w.base = pos;
     w.len = len;
@@ -145,9 +171,9 @@ __device__ uint32_t wave_match_fwd(const SymView &tv, uint32_t tp, bool t_clean,
             cnt = max_len - off < CMP_SYMS ? max_len - off : CMP_SYMS;
             uint64_t Pr;
             uint32_t Ir;
-            sv_fetch32(tv, tp + off, cnt, t_clean, Pt, It);
-            sv_fetch32(rv, rp + off, cnt, r_clean, Pr, Ir);
-            const uint64_t d = Pt ^ Pr;
+            sv_fetch<CMP_SYMS>(tv, tp + off, cnt, t_clean, Pt, It);
+            sv_fetch<CMP_SYMS>(rv, rp + off, cnt, r_clean, Pr, Ir);
+            const uint64_t d = CMP_SYMS == 32 ? Pt ^ Pr : (uint64_t)(uint32_t)(Pt ^ Pr);
             uint32_t j = d ? sv_ctz64(d) >> 1 : CMP_SYMS;
             const uint32_t inv = It | Ir;
             if (inv) {
@@ -168,7 +194,7 @@ __device__ uint32_t wave_match_fwd(const SymView &tv, uint32_t tp, bool t_clean,
                 const bool full = cnt == CMP_SYMS;
                 const uint64_t fm = __ballot(full);
                 if (full)
-                    store_syms32(win->lds + lane * CMP_SYMS, tv, tp + off, CMP_SYMS, Pt, It);
+                    store_syms<CMP_SYMS>(win->lds + lane * CMP_SYMS, tv, tp + off, CMP_SYMS, Pt, It);
                 win->base = tp + base;
                 win->len = (uint32_t)__builtin_popcountll(fm) * CMP_SYMS;
                 __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
@@ -347,14 +373,17 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
     bool try_wide = false;
     bool force_exact = false; // the grouped probe could not settle position i: the next step is the exact one
     TextWin win{win_lds, 0, 0};
+    PH_DECL
     while (i + key_len < n) {
         AGC_TRACE(4, i);
+        PH(0) // everything after the previous iteration's last mark (emission of a match / literal)
         {
             // symbols i .. i+64+key_len+2 (as far as the text goes) must be in the LDS window
             const uint32_t need = n - i < WAVE + key_len + 2 ? n - i : WAVE + key_len + 2;
             if (!win_has(win, i, need))
                 win_fill(win, tv, t_clean, n, i);
         }
+        PH(1) // window check / refill
         const uint8_t *__restrict__ wtext = win.lds - win.base; // wtext[pos] for positions inside the window
         // ---- wide literal probe: lanes look at positions i .. i+63 at once.  A position is a
         // certain literal when its key is valid and no slot of its probe chain (up to the first
@@ -541,6 +570,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
                 }
             }
             const uint64_t em = __ballot(is_empty), fm = __ballot(fp_ok && !is_empty);
+            PH(2) // grouped probe: keys, hashes, table rows (+ the speculative chunk loads) until the rows are in
             uint32_t f = 0;
             bool to_exact = false;
             for (; f < MP_G; ++f) {
@@ -560,13 +590,13 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
             }
             if (f) {
                 if (MODE == MODE_ENCODE) {
-                    if (stale_out) {
-                        __builtin_amdgcn_s_waitcnt(0); // lane 0's rolled-back bytes land before other lanes overwrite them
-                        stale_out = false;
+                    // (lane 0 owns these bytes like every token of the match / SNP rhythm: stores of one lane to one address
+                    // keep their order, so nothing has to be drained when a match rolls literals back or patches them)
+                    for (uint32_t t = 0; t < f; ++t) {
+                        const uint32_t c = bcast_u32(sa, t);
+                        if (writer)
+                            out[o + t] = (uint8_t)('A' + c);
                     }
-                    if (lane < f)
-                        out[o + lane] = (uint8_t)('A' + sa);
-                    coop_out = true;
                 } else if (MODE == MODE_ESTIMATE) {
                     if (est + f - 1 > peak)
                         peak = est + f - 1; // loop-top checks of these f literal steps
@@ -685,6 +715,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
             cand &= (1ULL << ctz64(em)) - 1ULL; // probes stop at the first empty slot
         }
 
+        PH(3) // literals of the grouped probe / the exact step's probe
         uint32_t len_bck = 0, len_fwd = 0, match_pos = 0;
         uint32_t min_to_update = mml;
         uint32_t best_tb = 0;      // lane b: text symbol at i-1-b for the chosen candidate
@@ -693,18 +724,21 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
             const uint32_t j = ctz64(cand);
             cand &= cand - 1;
             const uint32_t h_pos = bcast_u32(epos, j) * HASHING_STEP;
-            // backward symbols of the first 64 positions (lz_diff.cpp:308-311), issued before the forward
-            // compare so that both arrive in one round trip
             const uint32_t lim = npl < h_pos ? npl : h_pos;
             uint32_t tb = 0x100u, rb = 0x200u; // lanes >= lim: never equal
-            if (lane < lim) {
-                tb = sv_sym(tv, i - 1 - lane, t_clean);
-                rb = sv_sym(rv, h_pos - 1 - lane, r_clean);
+            uint32_t f_len;
+            {
+                // backward symbols of the first 64 positions (lz_diff.cpp:308-311), issued before the forward
+                // compare so that both arrive in one round trip
+                if (lane < lim) {
+                    tb = sv_sym(tv, i - 1 - lane, t_clean);
+                    rb = sv_sym(rv, h_pos - 1 - lane, r_clean);
+                }
+                // (the reference pads its copy with key_len symbols no text holds, lz_diff.cpp:48-53: a compare ends at the
+                // reference's end at the latest -- here by the bound)
+                const uint32_t ref_left = ref_size - h_pos;
+                f_len = wave_match_fwd(tv, i, t_clean, rv, h_pos, r_clean, max_len < ref_left ? max_len : ref_left, &win);
             }
-            // (the reference pads its copy with key_len symbols no text holds, lz_diff.cpp:48-53: a compare ends at the
-            // reference's end at the latest -- here by the bound)
-            const uint32_t ref_left = ref_size - h_pos;
-            const uint32_t f_len = wave_match_fwd(tv, i, t_clean, rv, h_pos, r_clean, max_len < ref_left ? max_len : ref_left, &win);
             if (f_len >= key_len) {
                 const uint64_t mm = __ballot(tb != rb);
                 uint32_t b_len;
@@ -723,6 +757,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
             }
         }
 
+        PH(4) // candidate verification
         if (len_bck + len_fwd < mml) {
             // literal
             if (MODE == MODE_ENCODE) {
@@ -763,9 +798,9 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
 
         if (MODE == MODE_ENCODE) {
             const uint32_t n_trail = npl - len_bck; // literal bytes now ending the delta
-            if (coop_out || (match_pos == pred_pos && n_trail)) {
-                // stores of other lanes to bytes that are about to be re-written (rolled-back or patched
-                // literals) must have landed first
+            if (coop_out) {
+                // stores of other lanes (the wide probe's literal runs) to bytes that are about to be re-written by lane 0
+                // (rolled-back or patched literals) must have landed first
                 __builtin_amdgcn_s_waitcnt(0);
                 coop_out = false;
             }
@@ -782,8 +817,14 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
                 // t <= n_trail implies b <= npl-1 and t < match_pos implies b < h_pos-1: only lanes with real data
                 const uint64_t brk = __ballot(in_first && best_tb >= 26);
                 const uint32_t first_brk = brk ? ctz64(brk) : WAVE;
-                if (in_first && b < first_brk && best_eq)
-                    out[o - t] = '!';
+                // (lane 0 stores the patches too: it wrote the literals they replace)
+                uint64_t pm = __ballot(in_first && b < first_brk && best_eq);
+                while (pm) {
+                    const uint32_t pb = ctz64(pm);
+                    pm &= pm - 1;
+                    if (writer)
+                        out[o - (pb - len_bck + 1)] = '!';
+                }
                 // trailing literals beyond the 64 probed ones (rare): serial walk on text/ref
                 if (!brk && len_bck + n_trail > WAVE && writer) {
                     for (uint32_t tt = len_bck >= WAVE ? 1u : WAVE - len_bck + 1; tt <= n_trail && tt < o && tt < match_pos; ++tt) {
@@ -794,7 +835,6 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
                             out[o - tt] = '!';
                     }
                 }
-                coop_out = true; // '!' bytes were stored by lanes other than 0
             }
             const bool to_end = (i + len == n) && (match_pos + len == ref_size);
             o += emit_int(out, o, (int32_t)((int)match_pos - (int)pred_pos), writer);
@@ -824,6 +864,13 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
         npl = 0;
     }
 
+#ifdef AGC_PHASES
+    if (MODE == MODE_ENCODE && writer)
+        for (int k = 0; k < 8; ++k) {
+            atomicAdd(&g_phase_acc[k], (unsigned long long)ph_acc[k]);
+            atomicAdd(&g_phase_cnt[k], (unsigned long long)ph_cnt[k]);
+        }
+#endif
     // tail literals (lz_diff.cpp:795-796 / 943 / 282-283)
     if (MODE == MODE_ESTIMATE) {
         est += n - i; // u32 wrap-around exactly as the reference
@@ -859,11 +906,13 @@ template <int MODE>
 __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs,
                                                        uint32_t n_segs, uint8_t *__restrict__ out_bytes,
                                                        uint32_t *__restrict__ out_u32, uint32_t *__restrict__ res_value,
-                                                       uint32_t *__restrict__ res_peak)
+                                                       uint32_t *__restrict__ res_peak, const uint32_t *__restrict__ n_segs_dev)
 {
     const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     AGC_TRACE(1, idx);
-    if (idx >= n_segs)
+    // (n_segs_dev: the number of descriptors is known on the device only -- they were made there, seg_kernels.hip -- and the grid
+    // covers an upper bound)
+    if (idx >= (n_segs_dev ? *n_segs_dev : n_segs))
         return;
     const SegDesc &sdm = segs[idx];
     const RefDesc &rdm = refs[uniform_u32(sdm.ref_slot)];
@@ -902,9 +951,9 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
     }
 }
 
-template __global__ void lz_parse_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
-template __global__ void lz_parse_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
-template __global__ void lz_parse_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
+template __global__ void lz_parse_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
+template __global__ void lz_parse_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
+template __global__ void lz_parse_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
 
 // gathers the per-segment deltas (scratch slots) into one contiguous buffer
 __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__restrict__ scratch, const SegDesc *__restrict__ segs,

@@ -131,6 +131,57 @@ SV_HD void sv_fetch32(const SymView &v, uint32_t p, uint32_t cnt, bool clean, ui
     }
 }
 
+// the same for cnt (1..16) symbols: two dwords per fetch instead of three (P in the low 32 bits)
+SV_HD uint32_t sv_raw32(const uint32_t *__restrict__ words, uint64_t s)
+{
+    const uint32_t *p = words + (s >> 4);
+    const uint32_t sh = 2u * (uint32_t)(s & 15u);
+    return (uint32_t)(((((uint64_t)p[1]) << 32) | p[0]) >> sh);
+}
+SV_HD uint32_t sv_rev2_32(uint32_t x)
+{
+    x = sv_brev32(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+SV_HD void sv_fetch16(const SymView &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
+{
+    I = 0;
+    uint64_t s0, s1;
+    if (v.rc) {
+        s1 = v.start + (v.len - 1u - p);
+        s0 = s1 - (cnt - 1u);
+    } else {
+        s0 = v.start + p;
+        s1 = s0 + (cnt - 1u);
+    }
+    bool fast = clean || !v.esc_index;
+    if (!fast) {
+        const int32_t e0 = v.esc_index[s0 / SV_BLOCK], e1 = v.esc_index[s1 / SV_BLOCK];
+        fast = e0 < 0 && e1 < 0;
+    }
+    if (fast) {
+        if (v.rc) {
+            const uint32_t x = s1 >= 15 ? sv_raw32(v.words, s1 - 15) : sv_raw32(v.words, 0) << (2u * (15u - (uint32_t)s1));
+            P = (uint32_t)~sv_rev2_32(x);
+        } else
+            P = sv_raw32(v.words, s0);
+        return;
+    }
+    P = 0;
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t c = sv_sym(v, p + j, false);
+        P |= (uint64_t)(c & 3u) << (2u * j);
+        I |= (uint32_t)(c > 3u) << j;
+    }
+}
+template <uint32_t N> SV_HD void sv_fetch(const SymView &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
+{
+    if (N == 16)
+        sv_fetch16(v, p, cnt, clean, P, I);
+    else
+        sv_fetch32(v, p, cnt, clean, P, I);
+}
+
 // four packed symbols (8 bits) -> four bytes
 SV_HD uint32_t sv_expand4(uint32_t x)
 {

@@ -58,7 +58,8 @@ enum {
     AGC_HIP_K_REFSTORE = 7,
     AGC_HIP_K_ZSTD = 8,
     AGC_HIP_K_FILTER = 9, /* key_filter_kernel: the "may match" bitmaps of the estimate / cost-vector parses */
-    AGC_HIP_K_COUNT = 10
+    AGC_HIP_K_SEGMENTS = 10, /* agc_hip_segments_packed: hits -> segments -> group look-up -> encode descriptors (seg_kernels.hip) */
+    AGC_HIP_K_COUNT = 11
 };
 int agc_hip_timing_enable(agc_hip_ctx *ctx, int on);
 int agc_hip_timing_reset(agc_hip_ctx *ctx);
@@ -163,6 +164,46 @@ int agc_hip_prefetch_packed_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, cons
 int agc_hip_scan_prefetched(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
                             uint64_t cap, uint64_t *h_n_hits, uint32_t *h_hit_ctg, uint64_t *h_hit_pos, uint64_t *h_hit_dir,
                             uint64_t *h_hit_rc);
+
+/* ---- S1 -> S2 on the device: segments and their groups (a3's cut, a5's first decision) ------------------------ */
+/* The (k-mer 1, k-mer 2) -> group table, map_segments of the reference (src/core/agc_compressor.h:628; filled by store_segments,
+ * agc_compressor.cpp:1003-1028, read by add_segment :1275-1330), as an open-addressing array in HBM: n_slots (a power of two)
+ * slots, home slot of a key = agc_hip_group_hash(k1, k2) & (n_slots - 1), linear probing, `used` = 0 ends a chain.  The host
+ * keeps the authoritative copy (it mints the groups) and mirrors it: _set replaces the whole array, _update overwrites the
+ * slots named in h_idx (the handful a registration changed). */
+typedef struct {
+    uint64_t k1, k2;
+    int32_t gid;
+    uint32_t used;
+} agc_hip_group_slot;
+uint64_t agc_hip_group_hash(uint64_t k1, uint64_t k2);
+int agc_hip_group_map_set(agc_hip_ctx *ctx, const agc_hip_group_slot *h_slots, uint64_t n_slots);
+int agc_hip_group_map_update(agc_hip_ctx *ctx, uint32_t n, const uint64_t *h_idx, const agc_hip_group_slot *h_slots);
+
+/* One segment as compress_contig cuts it (agc_compressor.cpp:2018-2048) with add_segment's first decision (:1286-1301):
+ * contig, start (relative to the contig) and length; the k-mers in front and at the back (dir / rev-comp forms, left-aligned as
+ * CKmer keeps them; *_full = 0: the segment starts / ends at a contig end); for a segment with both k-mers: store_rc = the
+ * orientation rule of the key (min, max) of the two canonical k-mers, map_gid = the group the table holds for that key or -1;
+ * encoded = its LZ encode against that group's reference was launched by the call (see below). */
+typedef struct {
+    uint64_t start;
+    uint64_t front_dir, front_rc, back_dir, back_rc;
+    uint32_t ctg, len;
+    int32_t map_gid;
+    uint8_t front_full, back_full, store_rc, encoded;
+} agc_hip_segment;
+/* A whole sample from splitter hits to classified segments without the host in between: the packed scan (or, prefetched != 0,
+ * the collection of the scan agc_hip_prefetch_packed_dev queued), the "reset the k-mer after a hit" rule, the cut, the key of
+ * every segment with two splitters and its look-up in the table above (bucket ranges of the table staged in LDS), all on the
+ * device; h_segs receives the segments in (contig, position) order.  encode_known != 0: the LZ encode of every segment whose
+ * group the table knows is LAUNCHED from here as well, on the context's second lane, from descriptors made on the device
+ * (longest first) -- exactly as agc_hip_lz_encode_begin_packed would for those segments; agc_hip_lz_encode_end collects the
+ * *h_n_encoded deltas, in the order of the segments flagged `encoded`.  What is left to the host are the segments that need
+ * more than a table look-up (one splitter, destroyed middle splitter, new groups).
+ * AGC_HIP_ECAP (+ the needed capacity in *h_n_segs) when cap is too small: nothing was launched, call again. */
+int agc_hip_segments_packed(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
+                            int prefetched, int encode_known, uint64_t cap, agc_hip_segment *h_segs, uint64_t *h_n_segs,
+                            uint32_t *h_n_encoded);
 
 /* ---- S2: LZ-diff against group references (a10, a11, a6, a7) ---------- */
 /* A "slice" names one sequence inside a device buffer: symbols [off, off+len) of a packed sample *pk (the *_packed

@@ -53,6 +53,9 @@ struct agc_hip_ctx {
     u64 *enc_eoff;
     /* the next sample ahead of its turn: the identity of what was announced */
     const void *pf_words;
+    /* the mirrored (k-mer 1, k-mer 2) -> group table */
+    agc_hip_group_slot *gmap;
+    u64 gmap_slots;
     /* agc_hip_sample_pack: the context's own packed buffers */
     uint32_t *sp_words;
     int32_t *sp_index;
@@ -114,6 +117,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
     free(c->sp_words);
     free(c->sp_index);
     free(c->sp_esc);
+    free(c->gmap);
     free(c);
 }
 
@@ -713,6 +717,134 @@ int agc_hip_ref_lag_counts_packed(agc_hip_ctx *c, uint32_t n, const agc_hip_pack
     if (!c || (n && (!pk || !off || !len || !h_cnt || !h_cur)))
         return AGC_HIP_EINVAL;
     WITH_SPAN(agc_hip_ref_lag_counts_dev(c, n, buf, off2, len, rc, h_cnt, h_cur))
+}
+
+/* ---- segments and their groups (include/agc_hip.h): the oracle's compress_contig per contig, a probe of the mirrored table, and
+ * -- encode_known -- the encode of the segments whose group is known, parsed at once like agc_hip_lz_encode_begin_dev ---- */
+uint64_t agc_hip_group_hash(uint64_t k1, uint64_t k2)
+{
+    uint64_t h = k1 * 0x9E3779B97F4A7C15ULL;
+    h ^= (h >> 32) ^ (k2 * 0xC2B2AE3D27D4EB4FULL);
+    return h ^ (h >> 29);
+}
+
+int agc_hip_group_map_set(agc_hip_ctx *c, const agc_hip_group_slot *h_slots, uint64_t n_slots)
+{
+    if (!c || (n_slots && !h_slots) || (n_slots & (n_slots - 1)))
+        return AGC_HIP_EINVAL;
+    free(c->gmap);
+    c->gmap = (agc_hip_group_slot *)malloc((n_slots ? n_slots : 1) * sizeof(agc_hip_group_slot));
+    if (n_slots)
+        memcpy(c->gmap, h_slots, n_slots * sizeof(agc_hip_group_slot));
+    c->gmap_slots = n_slots;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_group_map_update(agc_hip_ctx *c, uint32_t n, const uint64_t *h_idx, const agc_hip_group_slot *h_slots)
+{
+    if (!c || (n && (!h_idx || !h_slots || !c->gmap_slots)))
+        return AGC_HIP_EINVAL;
+    for (u32 i = 0; i < n; ++i) {
+        if (h_idx[i] >= c->gmap_slots)
+            return AGC_HIP_EINVAL;
+        c->gmap[h_idx[i]] = h_slots[i];
+    }
+    return AGC_HIP_OK;
+}
+
+int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, int prefetched,
+                            int encode_known, uint64_t cap, agc_hip_segment *h_segs, uint64_t *h_n_segs, uint32_t *h_n_encoded)
+{
+    if (!c || !pk || !h_ctg_off || !h_n_segs || k < 16 || k > 32)
+        return AGC_HIP_EINVAL;
+    if (prefetched && c->pf_words != pk->d_words)
+        return AGC_HIP_EINVAL;
+    if (encode_known && c->enc_pending)
+        return fail(c, AGC_HIP_EINVAL, "segments_packed: the previous encode was not collected");
+    *h_n_segs = 0;
+    if (h_n_encoded)
+        *h_n_encoded = 0;
+    if (!n_ctg)
+        return AGC_HIP_OK;
+    u8 *codes = (u8 *)malloc(pk->n_symbols + 64);
+    agc_hip_expand_dev(c, pk, codes);
+    u64 n = 0;
+    int over = 0;
+    for (u32 ci = 0; ci < n_ctg; ++ci) {
+        const u64 len = h_ctg_off[ci + 1] - h_ctg_off[ci];
+        u64 scap = len / (k ? k : 1) + 2;
+        u64 *st_ = (u64 *)malloc(scap * 8 * 6);
+        u8 *fl = (u8 *)malloc(scap * 2);
+        const size_t m = agco_scan_contig(codes + h_ctg_off[ci], len, k, c->spl, c->n_spl, scap, st_, st_ + scap, st_ + 2 * scap, st_ + 3 * scap, fl,
+                                          st_ + 4 * scap, st_ + 5 * scap, fl + scap);
+        for (size_t i = 0; i < m; ++i, ++n) {
+            if (n >= cap) {
+                over = 1;
+                continue;
+            }
+            agc_hip_segment *s_ = &h_segs[n];
+            memset(s_, 0, sizeof *s_);
+            s_->ctg = ci;
+            s_->start = st_[i];
+            s_->len = (u32)st_[scap + i];
+            s_->front_full = fl[i];
+            s_->back_full = fl[scap + i];
+            if (s_->front_full) {
+                s_->front_dir = st_[2 * scap + i];
+                s_->front_rc = st_[3 * scap + i];
+            }
+            if (s_->back_full) {
+                s_->back_dir = st_[4 * scap + i];
+                s_->back_rc = st_[5 * scap + i];
+            }
+            s_->map_gid = -1;
+            if (s_->front_full && s_->back_full) {
+                const u64 f = s_->front_dir < s_->front_rc ? s_->front_dir : s_->front_rc, b = s_->back_dir < s_->back_rc ? s_->back_dir : s_->back_rc;
+                const u64 k1 = f < b ? f : b, k2 = f < b ? b : f;
+                s_->store_rc = f < b ? 0 : 1;
+                if (c->gmap_slots)
+                    for (u64 j = agc_hip_group_hash(k1, k2) & (c->gmap_slots - 1); c->gmap[j].used; j = (j + 1) & (c->gmap_slots - 1))
+                        if (c->gmap[j].k1 == k1 && c->gmap[j].k2 == k2) {
+                            s_->map_gid = c->gmap[j].gid;
+                            break;
+                        }
+            }
+        }
+        free(st_);
+        free(fl);
+    }
+    if (over) {
+        free(codes);
+        *h_n_segs = n;
+        return AGC_HIP_ECAP;
+    }
+    *h_n_segs = n;
+    int r = AGC_HIP_OK;
+    if (encode_known && c->gmap_slots) {
+        u32 ne = 0;
+        u32 *gid = (u32 *)malloc((n + 1) * 4), *len = (u32 *)malloc((n + 1) * 4);
+        u64 *off = (u64 *)malloc((n + 1) * 8);
+        u8 *rc = (u8 *)malloc(n + 1);
+        for (u64 i = 0; i < n; ++i) {
+            agc_hip_segment *s_ = &h_segs[i];
+            if (s_->front_full && s_->back_full && s_->map_gid >= 16 && find_ref(c, (u32)s_->map_gid)) {
+                s_->encoded = 1;
+                gid[ne] = (u32)s_->map_gid;
+                off[ne] = h_ctg_off[s_->ctg] + s_->start;
+                len[ne] = s_->len;
+                rc[ne] = s_->store_rc;
+                ++ne;
+            }
+        }
+        if (ne) {
+            r = agc_hip_lz_encode_begin_dev(c, ne, gid, codes, off, len, rc);
+            if (r == AGC_HIP_OK && h_n_encoded)
+                *h_n_encoded = ne;
+        }
+        free(gid), free(len), free(off), free(rc);
+    }
+    free(codes);
+    return r;
 }
 
 /* a1 on the stand-in: the oracle's preprocess_raw_contig */

@@ -94,7 +94,7 @@ int main(int argc, char **argv)
                         return 1;
                     }
                     ++checks;
-                    const uint32_t cnts[4] = {32, 1, 1 + (uint32_t)(rng() % 32), 17};
+                    const uint32_t cnts[5] = {32, 1, 1 + (uint32_t)(rng() % 32), 17, 16};
                     for (uint32_t cnt : cnts) {
                         if (p + cnt > v.len)
                             cnt = v.len - p;
@@ -121,6 +121,21 @@ int main(int argc, char **argv)
                             return 1;
                         }
                         ++checks;
+                        if (cnt <= 16) { // the two-dword variant delivers the same
+                            uint64_t P16;
+                            uint32_t I16;
+                            sv_fetch16(v, p, cnt, cl != 0, P16, I16);
+                            const uint64_t m = cnt == 32 ? ~0ULL : (1ULL << (2 * cnt)) - 1ULL;
+                            uint64_t vm = 0; // compare the codes of the ACGT positions only
+                            for (uint32_t j = 0; j < cnt; ++j)
+                                if (!((I >> j) & 1))
+                                    vm |= 3ULL << (2 * j);
+                            if (I16 != I || ((P16 ^ P) & m & vm) != 0) {
+                                printf("sv_fetch16 differs: round %d start %llu len %u rc %u p %u cnt %u\n", round, (unsigned long long)v.start, v.len, v.rc, p, cnt);
+                                return 1;
+                            }
+                            ++checks;
+                        }
                     }
                 }
                 // keys: first symbol most significant

@@ -227,3 +227,91 @@ def test_packed_scan_equals_byte_scan_on_a_big_sample(hip_ctx, oracle):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert a[0].size > 2000
+
+
+# ---- segments and their groups on the device (agc_hip_segments_packed) ------------------------------------------------------
+@pytest.mark.parametrize("k,prefetched,big_table", [(21, False, False), (31, True, False), (25, False, True)])
+def test_segments_on_the_device_match_oracle(hip_ctx, oracle, k, prefetched, big_table):
+    """hits -> reset rule -> cut -> key -> table look-up -> encode launch, all on the device, against the oracle's compress_contig
+    per contig, a dictionary look-up of the keys, and the oracle's Encode of every segment whose group the table knows.  Both
+    look-up variants (bucket ranges staged in LDS / straight from HBM: the table is made large against the batch), with and
+    without the scan prefetched."""
+    import torch
+    rng = np.random.default_rng(4000 + k)
+    spl, contigs = _packed_case(oracle, rng, k)
+    off = np.zeros(len(contigs) + 1, np.uint64)
+    off[1:] = np.cumsum([c.size for c in contigs])
+    codes = np.concatenate(contigs)
+    d = torch.from_numpy(codes).cuda()
+    torch.cuda.synchronize()
+    pk, keep = hip_ctx.pack_dev(d)
+    hip_ctx.splitters_set(spl)
+    # what the oracle cuts
+    want = []
+    for ci, c in enumerate(contigs):
+        s = oracle.scan_contig(c, k, spl)
+        for i in range(len(s["start"])):
+            want.append((ci, int(s["start"][i]), int(s["len"][i]), int(s["front_dir"][i]), int(s["front_rc"][i]), int(s["front_full"][i]),
+                         int(s["back_dir"][i]), int(s["back_rc"][i]), int(s["back_full"][i])))
+    # groups: every other distinct key of the segments with two splitters gets a group whose reference is that segment, oriented
+    # as the key says (add_segment, agc_compressor.cpp:1286-1301), and slightly edited so that the deltas are not empty
+    mml, gid0 = 20, 20_000 + 1000 * k
+    keys, refs = {}, {}
+    for (ci, st, ln, fd, fr, ff, bd, br, bf) in want:
+        if not (ff and bf):
+            continue
+        f, b = min(fd, fr), min(bd, br)
+        key, rc = ((f, b), 0) if f < b else ((b, f), 1)
+        if key in keys or (len(keys) + len(refs)) % 2 == 1:
+            refs.setdefault(key, None)
+            continue
+        keys[key] = gid0 + len(keys)
+        text = contigs[ci][st:st + ln]
+        text = oracle.rev_comp(text) if rc else text
+        ref = synth.mutate(rng, text, 0.003)
+        hip_ctx.ref_register(keys[key], ref, mml)
+        refs[key] = ref
+    assert len(keys) > 20
+    hip_ctx.group_map_set(keys, n_slots=(1 << 22) if big_table else 16)
+    if prefetched:
+        hip_ctx.prefetch_packed_dev(pk, off, k)
+    segs, n_enc = hip_ctx.segments_packed(pk, off, k, prefetched=prefetched, encode_known=True, cap=16)
+    assert len(segs) == len(want)
+    n_known = 0
+    texts = []
+    for sg, (ci, st, ln, fd, fr, ff, bd, br, bf) in zip(segs, want):
+        assert (int(sg["ctg"]), int(sg["start"]), int(sg["len"]), int(sg["front_full"]), int(sg["back_full"])) == (ci, st, ln, ff, bf)
+        if ff:
+            assert (int(sg["front_dir"]), int(sg["front_rc"])) == (fd, fr)
+        if bf:
+            assert (int(sg["back_dir"]), int(sg["back_rc"])) == (bd, br)
+        if ff and bf:
+            f, b = min(fd, fr), min(bd, br)
+            key, rc = ((f, b), 0) if f < b else ((b, f), 1)
+            assert int(sg["store_rc"]) == rc
+            assert int(sg["map_gid"]) == keys.get(key, -1)
+            if key in keys:
+                assert sg["encoded"]
+                n_known += 1
+                t = contigs[ci][st:st + ln]
+                texts.append((key, oracle.rev_comp(t) if rc else t))
+            else:
+                assert not sg["encoded"]
+        else:
+            assert int(sg["map_gid"]) == -1 and not sg["encoded"]
+    assert n_enc == n_known and n_known > 20
+    enc, eoff = hip_ctx.lz_encode_end()
+    assert eoff.size == n_known + 1
+    for i, (key, t) in enumerate(texts):
+        assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], oracle.LZ(refs[key], mml).encode(t)), i
+    # single slots of the table replaced: a key moves to another group, the look-up follows
+    key0 = next(iter(keys))
+    tab = hip_ctx.group_map_set(keys, n_slots=(1 << 22) if big_table else 16)
+    idx = [i for i in range(tab.size) if tab[i]["used"] and (int(tab[i]["k1"]), int(tab[i]["k2"])) == key0]
+    slot = tab[idx].copy()
+    slot["gid"] = -7
+    hip_ctx.group_map_update(idx, slot)
+    segs2, _ = hip_ctx.segments_packed(pk, off, k, cap=1 << 14)
+    moved = [int(sg["map_gid"]) for sg in segs2 if sg["front_full"] and sg["back_full"] and
+             (min(int(sg["front_dir"]), int(sg["front_rc"])), min(int(sg["back_dir"]), int(sg["back_rc"]))) in (key0, key0[::-1])]
+    assert moved and all(g == -7 for g in moved)

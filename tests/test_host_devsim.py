@@ -305,3 +305,23 @@ def test_samples_in_the_packed_layout_give_the_reference_archive(cli, name, over
     subprocess.check_call([sys.executable, "-c", _PACKED_CHILD, root, json.dumps(opt), json.dumps(files), out, str(announce)])
     got = open(out, "rb").read()
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_c4_twin"])
+def test_segments_from_the_device_or_cut_on_the_host_give_the_same_archive(cli, name, tmp_path, monkeypatch):
+    """Single-registration windows take their segments, keys and group look-ups from the device (agc_hip_segments_packed; the
+    encode of the segments whose group is known is launched there too) -- the laps say so; AGC_AMD_DEV_SEGMENTS=0 (hits to the
+    host, cut and look-up there) must write the same bytes."""
+    monkeypatch.setenv("AGC_AMD_WINDOW_MAX", "1")
+    monkeypatch.setenv("AGC_AMD_LAPS", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "o.agc")
+    r = subprocess.run([cli, "create"] + args + ["-t", "4", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    if "-a" not in args and "-c" not in args:
+        assert r.stderr.count("scan + segments (device)") == len(files), r.stderr[-2000:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
+    monkeypatch.setenv("AGC_AMD_DEV_SEGMENTS", "0")
+    r = subprocess.run([cli, "create"] + args + ["-t", "4", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    assert "segments (device)" not in r.stderr
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
