@@ -26,7 +26,7 @@ SYMBOLS = [
     "agc_hip_determine_splitters_dev",
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
     "agc_hip_ref_register", "agc_hip_ref_register_batch_dev", "agc_hip_ref_get", "agc_hip_ref_index_get",
-    "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch", "agc_hip_lz_encode_begin_dev", "agc_hip_lz_encode_end",
+    "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch", "agc_hip_lz_encode_begin_dev", "agc_hip_lz_encode_end", "agc_hip_lz_encode_pending",
     "agc_hip_host_alloc", "agc_hip_host_free",
     "agc_hip_lz_estimate_batch_dev", "agc_hip_lz_estimate_batch",
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
@@ -37,7 +37,7 @@ SYMBOLS = [
     "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched", "agc_hip_sample_pack",
     "agc_hip_ref_register_batch_packed", "agc_hip_lz_encode_batch_packed", "agc_hip_lz_encode_begin_packed", "agc_hip_lz_estimate_batch_packed",
     "agc_hip_lz_cost_vector_batch_packed", "agc_hip_lz_split_point_batch_packed", "agc_hip_fetch_slices_packed", "agc_hip_ref_lag_counts_packed",
-    "agc_hip_group_hash", "agc_hip_group_map_set", "agc_hip_group_map_update", "agc_hip_segments_packed",
+    "agc_hip_group_hash", "agc_hip_group_map_set", "agc_hip_group_map_update", "agc_hip_segments_packed", "agc_hip_segments_encode_known",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -122,6 +122,7 @@ def load():
     L.agc_hip_lz_encode_batch.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_lz_encode_begin_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p]
     L.agc_hip_lz_encode_end.argtypes = [vp, u8p, C.c_uint64, u64p]
+    L.agc_hip_lz_encode_pending.argtypes = [vp, u32p]
     L.agc_hip_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.agc_hip_host_free.argtypes = [vp, vp]
     L.agc_hip_lz_estimate_batch_dev.argtypes = [vp, C.c_uint32, u32p, vp, u64p, u32p, u8p, u32p, u32p]
@@ -163,6 +164,7 @@ def load():
     L.agc_hip_group_map_set.argtypes = [vp, vp, C.c_uint64]
     L.agc_hip_group_map_update.argtypes = [vp, C.c_uint32, u64p, vp]
     L.agc_hip_segments_packed.argtypes = [vp, pkp, u64p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint64, vp, u64p, u32p]
+    L.agc_hip_segments_encode_known.argtypes = [vp]
     L.agc_hip_scan_prefetched.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     for s in SYMBOLS:
         f = getattr(L, s)
@@ -369,6 +371,15 @@ class Context:
                 self._enc_pending = (np.zeros(ln.size, np.uint32), None, ln, None)  # (what lz_encode_end sizes its buffers by)
             return segs[:n.value], int(ne.value)
 
+    def segments_encode_known(self, segs, known_gids):
+        """launches the encode of the segments of the last segments_packed call whose group the table knew (second lane);
+        known_gids: the groups with a registered reference -- what tells the caller which deltas lz_encode_end will deliver"""
+        self._chk(self.L.agc_hip_segments_encode_known(self.h))
+        m = (segs["front_full"] != 0) & (segs["back_full"] != 0) & (segs["map_gid"] >= 16) & np.isin(segs["map_gid"], np.asarray(list(known_gids), np.int64))
+        ln = segs["len"][m].astype(np.uint32)
+        self._enc_pending = (np.zeros(ln.size, np.uint32), None, ln, None)
+        return m
+
     def scan_contigs(self, codes, ctg_off, k, cap=1 << 16):
         codes = _a(codes, np.uint8)
         return self._scan(self.L.agc_hip_scan_contigs, _p(codes, u8p), ctg_off, k, cap)
@@ -461,6 +472,9 @@ class Context:
     def lz_encode_end(self, enc_cap=None):
         """second half: waits, -> (enc bytes, enc_off[n+1]) exactly as lz_encode_batch_dev"""
         g, o, l, r = self._enc_pending
+        n_dev = C.c_uint32()
+        self._chk(self.L.agc_hip_lz_encode_pending(self.h, C.byref(n_dev)))
+        assert n_dev.value == g.size, (n_dev.value, g.size)
         if enc_cap is None:
             enc_cap = int(l.astype(np.uint64).sum()) * 21 // 16 + 64 * g.size + 64
         enc = np.empty(enc_cap, np.uint8)

@@ -77,7 +77,21 @@ struct agc_hip_ctx {
     // the (k1, k2) -> group table (mirror of the host's map_segments) and the work area of agc_hip_segments_packed
     DevBuf d_gmap, d_gmap_stage, d_segwork, d_segtmp;
     uint64_t gmap_slots = 0;
-    void *h_segcounts = nullptr; // pinned: SegCounts of the call in flight
+    void *h_gmap_stage = nullptr; // pinned staging of agc_hip_group_map_update
+    size_t h_gmap_stage_cap = 0;
+    hipEvent_t gmap_ev = nullptr;
+    bool gmap_ev_valid = false;
+    void *h_segcounts = nullptr; // pinned: SegCounts of the call in flight (+ 64: the count of the encode launched from them)
+    // what agc_hip_segments_packed left on the device for agc_hip_segments_encode_known
+    struct SegState {
+        bool valid = false;
+        uint32_t n_ub = 0;
+        uint64_t total = 0;
+        agc_hip_packed pk{};
+        void *segs = nullptr, *counts = nullptr, *d_ctg_off = nullptr;
+        void *flag = nullptr, *capv = nullptr, *known_rank = nullptr, *cap_off = nullptr, *descs = nullptr, *skey0 = nullptr, *skey1 = nullptr, *sval0 = nullptr,
+             *sval1 = nullptr;
+    } seg_state;
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
         d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_zdstoff, d_maybe, d_fjobs;
 
@@ -93,6 +107,7 @@ struct agc_hip_ctx {
         uint32_t *h_lens = nullptr; // pinned (a device-to-host copy into pageable memory would make begin wait for the kernel)
         size_t h_lens_cap = 0;
         uint32_t n = 0;          // segments of the encode in flight
+        const uint32_t *n_pinned = nullptr; // != nullptr: their number arrives with the parse (descriptors made on the device)
         bool pending = false, timed = false;
         hipEvent_t e0 = nullptr, e1 = nullptr, ready = nullptr;
         // `done`: recorded behind the parse of the encode in flight.  A caller may collect that encode from another thread while
@@ -386,6 +401,10 @@ void agc_hip_destroy(agc_hip_ctx *c)
                       &c->l2.d_compact, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
     if (c->h_segcounts)
         (void)hipHostFree(c->h_segcounts);
+    if (c->h_gmap_stage)
+        (void)hipHostFree(c->h_gmap_stage);
+    if (c->gmap_ev)
+        (void)hipEventDestroy(c->gmap_ev);
     for (PackTemp *t : {&c->pk1, &c->pk_sample, &c->l2.pk})
         for (DevBuf *b : {&t->words, &t->index, &t->esc, &t->cnt})
             if (b->p)
@@ -1597,6 +1616,23 @@ int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gi
     return lz_encode_begin_impl(c, n, h_gid, src, off2.data(), h_len, h_rc);
 }
 
+int agc_hip_lz_encode_pending(agc_hip_ctx *c, uint32_t *h_n)
+{
+    if (!c || !h_n)
+        return AGC_HIP_EINVAL;
+    *h_n = 0;
+    if (!c->l2.pending)
+        return AGC_HIP_OK;
+    if (c->l2.n_pinned) { // (launched from descriptors made on the device: the count was copied behind the parse)
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        c->l2.n = *c->l2.n_pinned;
+        c->l2.n_pinned = nullptr;
+    }
+    *h_n = c->l2.n;
+    return AGC_HIP_OK;
+}
+
 int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
 {
     if (!c || !h_enc_off)
@@ -1605,8 +1641,14 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint
         c->err = "lz_encode_end: no encode in flight";
         return AGC_HIP_EINVAL;
     }
-    const uint32_t n = c->l2.n;
     h_enc_off[0] = 0;
+    if (c->l2.n_pinned) { // (launched by agc_hip_segments_encode_known: the count was copied behind the parse)
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        c->l2.n = *c->l2.n_pinned;
+        c->l2.n_pinned = nullptr;
+    }
+    const uint32_t n = c->l2.n;
     if (!n) {
         c->l2.pending = false;
         return AGC_HIP_OK;

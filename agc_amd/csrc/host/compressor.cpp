@@ -10,6 +10,7 @@ CAGCCompressor::~CAGCCompressor()
     p->book_shutdown(); // the bookkeeping and the entropy thread use the device context
     p->z_shutdown();
     p->enc_buf.release(); // (pinned memory of that context)
+    p->dev_seg_buf.release();
     p->enc_buf2.release();
     p->enc_alt.release();
     p->enc_alt2.release();

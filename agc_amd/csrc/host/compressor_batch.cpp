@@ -155,6 +155,15 @@ void CAGCCompressor::Impl::book_main()
             const size_t ne = t->enc_todo.size();
             std::vector<uint64_t> eoff(ne + 1, 0);
             PinnedBytes &enc = *t->enc_dst;
+            {
+                uint32_t n_dev = 0;
+                ok = hip_ok(agc_hip_lz_encode_pending(hip, &n_dev), "lz_encode_pending");
+                if (ok && n_dev != ne) {
+                    err("internal: the device's encode delivers another number of deltas than the host expects");
+                    ok = false;
+                }
+            }
+            if (ok) {
             uint64_t cap = std::max<uint64_t>(enc.size(), t->enc_text / 64 + (1u << 16));
             for (;;) {
                 if (!enc.resize(cap, false)) {
@@ -169,6 +178,7 @@ void CAGCCompressor::Impl::book_main()
                 }
                 ok = hip_ok(r, "lz_encode_end");
                 break;
+            }
             }
             lane2_release(); // (the thread that drives the steps may launch the next sample's encode)
             if (ok) {
@@ -929,59 +939,77 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
     // the groups minted since the last sample go to the device's table first
     if (!hip_ok(DEVT(map_segments.sync_device(hip)), "group_map"))
         return false;
-    // the encode of the known segments is launched by the same call when its deltas can be collected beside the next sample
-    // (bookkeeping thread); otherwise the commit encodes as before
-    const bool enc = async_encode && book_can_async(1) && b.base_owned;
-    if (enc)
-        lane2_acquire(); // (the previous sample's encode has been collected)
-    uint64_t cap = std::max<uint64_t>(dev_seg_buf.size(), std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000 + n_ctg));
+    lap(b, "group map -> device");
+    if (!dev_seg_buf.ctx)
+        dev_seg_buf.ctx = hip;
+    uint64_t cap = std::max<uint64_t>(dev_seg_buf.size() / sizeof(agc_hip_segment), std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000 + n_ctg));
     uint64_t n_segs = 0;
-    uint32_t n_enc = 0;
     for (;;) {
-        if (dev_seg_buf.size() < cap)
-            dev_seg_buf.resize(cap);
-        const int rc = DEVT(agc_hip_segments_packed(hip, &b.pk, ctg_off.data(), n_ctg, k, scan_from_prefetch ? 1 : 0, enc ? 1 : 0, dev_seg_buf.size(),
-                                                    dev_seg_buf.data(), &n_segs, &n_enc));
+        if (!dev_seg_buf.resize(cap * sizeof(agc_hip_segment), false)) {
+            err("out of memory (segment table)");
+            return false;
+        }
+        const int rc = DEVT(agc_hip_segments_packed(hip, &b.pk, ctg_off.data(), n_ctg, k, scan_from_prefetch ? 1 : 0, 0, dev_seg_buf.size() / sizeof(agc_hip_segment),
+                                                    (agc_hip_segment *)dev_seg_buf.data(), &n_segs, nullptr));
         if (rc == AGC_HIP_ECAP) {
             cap = n_segs + n_segs / 8 + 64;
             continue;
         }
-        if (!hip_ok(rc, "segments_packed")) {
-            if (enc)
-                lane2_release();
+        if (!hip_ok(rc, "segments_packed"))
             return false;
-        }
         break;
     }
-    if (enc && !n_enc)
-        lane2_release(); // (nothing was launched: no group known yet)
     b.dev_keys = true;
-    b.dev_enc_n = n_enc;
     stage_end(st.t_scan, st.h_scan, t0, dev0);
     t0 = now();
     lap(b, "scan + segments (device)");
+    // the device's records -> the host's (the pool: 50 k records of a human sample)
+    const agc_hip_segment *dsegs = (const agc_hip_segment *)dev_seg_buf.data();
     std::vector<Seg> &segs = seg_buf;
     segs.resize(n_segs);
-    if (b.spec.size() != 2 * segs.size()) {
-        b.spec.assign(2 * segs.size(), BatchState::Spec());
-        b.spec_bytes = 0;
+    // the encode of the segments whose group the table knew is launched on the device's second lane when its deltas can be
+    // collected beside the next sample (bookkeeping thread); otherwise the commit encodes as before
+    const bool enc = async_encode && book_can_async(1) && b.base_owned;
+    std::vector<uint8_t> is_known(enc ? n_segs : 0, 0);
+    {
+        const size_t n_chunks = n_segs >= par_min ? std::min<size_t>(std::max<size_t>(n_segs / 2048, 2), (size_t)pool->size() * 4) : 1;
+        auto conv = [&](size_t ci, unsigned) {
+            for (size_t i = n_segs * ci / n_chunks; i < n_segs * (ci + 1) / n_chunks; ++i) {
+                const agc_hip_segment &d = dsegs[i];
+                Seg &s = segs[i];
+                s.ctg = d.ctg;
+                s.start = d.start;
+                s.len = d.len;
+                s.front.dir = d.front_dir;
+                s.front.rc = d.front_rc;
+                s.front.full = d.front_full != 0;
+                s.back.dir = d.back_dir;
+                s.back.rc = d.back_rc;
+                s.back.full = d.back_full != 0;
+                s.dev_gid = d.front_full && d.back_full ? d.map_gid : -2;
+                // (the rule of known_flag_kernel: two splitters, a group of its own, its reference in HBM)
+                if (enc && d.front_full && d.back_full && d.map_gid >= (int32_t)NO_RAW_GROUPS && (size_t)d.map_gid < groups.size() &&
+                    groups[(uint32_t)d.map_gid].exists && !groups[(uint32_t)d.map_gid].packed)
+                    is_known[i] = 1;
+            }
+        };
+        if (n_chunks > 1)
+            pool->parallel_for(n_chunks, conv);
+        else
+            conv(0, 0);
     }
-    uint32_t r = 0;
-    for (size_t i = 0; i < n_segs; ++i) {
-        const agc_hip_segment &d = dev_seg_buf[i];
-        Seg &s = segs[i];
-        s.ctg = d.ctg;
-        s.start = d.start;
-        s.len = d.len;
-        s.front.dir = d.front_dir;
-        s.front.rc = d.front_rc;
-        s.front.full = d.front_full != 0;
-        s.back.dir = d.back_dir;
-        s.back.rc = d.back_rc;
-        s.back.full = d.back_full != 0;
-        s.dev_gid = d.front_full && d.back_full ? d.map_gid : -2;
-        if (d.encoded) {
-            // the delta of this segment is being made: matched to the placed item at commit time like every speculative delta
+    lap(b, "segments -> host records");
+    uint32_t n_enc = 0;
+    if (enc) {
+        if (b.spec.size() != 2 * segs.size()) {
+            b.spec.assign(2 * segs.size(), BatchState::Spec());
+            b.spec_bytes = 0;
+        }
+        for (size_t i = 0; i < n_segs; ++i) {
+            if (!is_known[i])
+                continue;
+            const agc_hip_segment &d = dsegs[i];
+            // the delta of this segment is about to be made: matched to the placed item at commit time like every speculative delta
             BatchState::Spec &sp = b.spec[2 * i];
             sp.valid = true;
             sp.gid = (uint32_t)d.map_gid;
@@ -990,17 +1018,22 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             sp.rc = d.store_rc != 0;
             sp.enc_off = 0;
             sp.enc_len = 0;
-            sp.pending = (int32_t)r++;
+            sp.pending = (int32_t)n_enc++;
             st.enc_text += d.len;
             st.enc_ref += groups[(uint32_t)d.map_gid].ref_size ? groups[(uint32_t)d.map_gid].ref_size - 1 : 0;
         }
+        if (n_enc) {
+            lane2_acquire(); // (the previous sample's deltas have been collected: they were while the table came over)
+            lap(b, "second lane free");
+            if (!hip_ok(DEVT(agc_hip_segments_encode_known(hip)), "segments_encode_known")) {
+                lane2_release();
+                return false;
+            }
+            st.lz_encoded += n_enc;
+        }
+        lap(b, "encode of the known segments launched");
     }
-    if (r != n_enc) {
-        err("internal: the device's encode list and its segment flags disagree");
-        return false;
-    }
-    st.lz_encoded += n_enc;
-    lap(b, "segments -> host records");
+    b.dev_enc_n = n_enc;
     return true;
 }
 

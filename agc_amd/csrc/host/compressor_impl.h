@@ -924,7 +924,7 @@ struct CAGCCompressor::Impl {
     bool stage_scan_dev(BatchState &b);
     bool use_dev_segments(const BatchState &b) const;
     bool dev_segments = true;          // AGC_AMD_DEV_SEGMENTS=0: scan hits to the host, cut and key look-up there (the round-3 path)
-    std::vector<agc_hip_segment> dev_seg_buf;
+    PinnedBytes dev_seg_buf;           // (pinned: the segment table of a human sample is 3 MB per step)
     // the device's second LZ lane carries one encode at a time: launched by the thread that drives the steps, collected by the
     // bookkeeping thread (or by the driver itself on the synchronous path)
     bool lane2_inflight = false;       // (guarded by book_mtx)

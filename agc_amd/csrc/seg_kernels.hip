@@ -79,97 +79,107 @@ __global__ void __launch_bounds__(256) hit_contig_kernel(const uint64_t *__restr
 
 // ---- 3. which hits are taken.  A hit whose predecessor (in its contig) ends at least k symbols earlier is taken whatever
 // happened before it; it starts a chain, and the thread that owns a chain start resolves the (short) run of closer hits behind it
-// in order.  per_ctg[c] = hits taken in contig c, last_pos[c] = the last of them.
+// in order.  take[n] = 0 closes the array for the exclusive scan that ranks the taken hits (acc_rank[n] = their number).
 __global__ void __launch_bounds__(256) hit_accept_kernel(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ ctg, uint32_t n, uint32_t k,
-                                                         uint32_t *__restrict__ take, uint32_t *__restrict__ per_ctg, unsigned long long *__restrict__ last_pos)
+                                                         uint32_t *__restrict__ take)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == n)
+        take[n] = 0;
     if (j >= n)
         return;
     auto is_start = [&](uint32_t t) { return t == 0 || ctg[t] != ctg[t - 1] || pos[t] - pos[t - 1] >= k; };
     if (!is_start(j))
         return;
     uint64_t last = pos[j];
-    uint32_t cnt = 1;
     take[j] = 1;
-    uint32_t t = j + 1;
-    for (; t < n && !is_start(t); ++t) {
+    for (uint32_t t = j + 1; t < n && !is_start(t); ++t) {
         if (pos[t] >= last + k) {
             take[t] = 1;
             last = pos[t];
-            ++cnt;
         } else
             take[t] = 0;
     }
-    atomicAdd(&per_ctg[ctg[j]], cnt);
-    atomicMax(&last_pos[ctg[j]], (unsigned long long)last + 1ULL); // (+1: 0 = no hit)
 }
 
-// ---- 4. per contig: does it end in a tail segment; exclusive sums of hits and tails over the contigs (one block) --------------
-__global__ void __launch_bounds__(1024) contig_sums_kernel(const uint64_t *__restrict__ ctg_off, uint32_t n_ctg, uint32_t k, const uint32_t *__restrict__ per_ctg,
-                                                           const unsigned long long *__restrict__ last_pos, uint32_t *__restrict__ hits_before,
-                                                           uint32_t *__restrict__ tails_before, SegCounts *__restrict__ counts)
-{
-    __shared__ uint32_t s_a[1024], s_b[1024];
-    __shared__ uint32_t carry_a, carry_b;
-    if (threadIdx.x == 0)
-        carry_a = carry_b = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_ctg; base += 1024) {
-        const uint32_t c = base + threadIdx.x;
-        uint32_t a = 0, b = 0;
-        if (c < n_ctg) {
-            a = per_ctg[c];
-            const uint64_t len = ctg_off[c + 1] - ctg_off[c];
-            // split_pos after the last taken hit (relative to the contig): pos + 1 - k; a tail segment follows when it is < len
-            const uint64_t split = last_pos[c] ? (uint64_t)(last_pos[c] - 1ULL) - ctg_off[c] + 1 - k : 0;
-            b = split < len ? 1u : 0u;
-        }
-        s_a[threadIdx.x] = a;
-        s_b[threadIdx.x] = b;
-        __syncthreads();
-        for (uint32_t o = 1; o < 1024; o <<= 1) {
-            uint32_t va = 0, vb = 0;
-            if (threadIdx.x >= o) {
-                va = s_a[threadIdx.x - o];
-                vb = s_b[threadIdx.x - o];
-            }
-            __syncthreads();
-            s_a[threadIdx.x] += va;
-            s_b[threadIdx.x] += vb;
-            __syncthreads();
-        }
-        if (c < n_ctg) {
-            hits_before[c] = carry_a + s_a[threadIdx.x] - a;
-            tails_before[c] = carry_b + s_b[threadIdx.x] - b;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-            carry_a += s_a[1023];
-            carry_b += s_b[1023];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        hits_before[n_ctg] = carry_a;
-        tails_before[n_ctg] = carry_b;
-        counts->n_acc = carry_a;
-        counts->n_segs = carry_a + carry_b;
-    }
-}
-
-// ---- 5. the segments.  acc_rank[j] = number of taken hits before sorted hit j (exclusive scan of take[]).
-// Segment index of taken hit a (a-th taken overall) = a + tails_before[its contig]; the tail segment of contig c sits right after
-// the contig's last hit segment.  First half: the list of taken hits, and the tail segments as far as the contig alone defines them.
-__global__ void __launch_bounds__(256) seg_cut_kernel(const uint32_t *__restrict__ take, const uint32_t *__restrict__ acc_rank, uint32_t n,
-                                                      const uint64_t *__restrict__ ctg_off, uint32_t n_ctg, const uint32_t *__restrict__ hits_before,
-                                                      const uint32_t *__restrict__ tails_before, uint32_t *__restrict__ acc_sorted_idx, DevSeg *__restrict__ segs)
+// the list of taken hits: acc_idx[a] = sorted index of the a-th taken hit
+__global__ void __launch_bounds__(256) hit_compact_kernel(const uint32_t *__restrict__ take, const uint32_t *__restrict__ acc_rank, uint32_t n,
+                                                          uint32_t *__restrict__ acc_idx)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n && take[j])
-        acc_sorted_idx[acc_rank[j]] = j;
-    if (j < n_ctg && tails_before[j + 1] != tails_before[j]) {
-        const uint32_t c = j;
+        acc_idx[acc_rank[j]] = j;
+}
+
+// ---- 4. per contig: its taken hits [hits_before[c], hits_before[c + 1]) (the contigs lie in position order, so this is a binary
+// search in the list of taken hits), whether it ends in a tail segment, and the exclusive sum of the tails (one block)
+__global__ void __launch_bounds__(1024) contig_sums_kernel(const uint64_t *__restrict__ ctg_off, uint32_t n_ctg, uint32_t k, const uint64_t *__restrict__ pos,
+                                                           const uint32_t *__restrict__ ctg, const uint32_t *__restrict__ acc_idx,
+                                                           const uint32_t *__restrict__ acc_rank, uint32_t n, uint32_t *__restrict__ hits_before,
+                                                           uint32_t *__restrict__ tails_before, SegCounts *__restrict__ counts)
+{
+    __shared__ uint32_t s_b[1024];
+    __shared__ uint32_t carry_b;
+    const uint32_t n_acc = n ? acc_rank[n] : 0;
+    if (threadIdx.x == 0)
+        carry_b = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_ctg; base += 1024) {
+        const uint32_t c = base + threadIdx.x;
+        uint32_t b = 0;
+        if (c < n_ctg) {
+            // first taken hit whose contig is >= c / > c
+            auto lower = [&](uint32_t cc) {
+                uint32_t lo = 0, hi = n_acc;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ctg[acc_idx[mid]] < cc)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                return lo;
+            };
+            const uint32_t h0 = lower(c), h1 = lower(c + 1);
+            hits_before[c] = h0;
+            if (c + 1 == n_ctg)
+                hits_before[n_ctg] = h1;
+            const uint64_t len = ctg_off[c + 1] - ctg_off[c];
+            // split_pos after the last taken hit (relative to the contig): pos + 1 - k; a tail segment follows when it is < len
+            const uint64_t split = h1 > h0 ? pos[acc_idx[h1 - 1]] - ctg_off[c] + 1 - k : 0;
+            b = split < len ? 1u : 0u;
+        }
+        s_b[threadIdx.x] = b;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            uint32_t vb = 0;
+            if (threadIdx.x >= o)
+                vb = s_b[threadIdx.x - o];
+            __syncthreads();
+            s_b[threadIdx.x] += vb;
+            __syncthreads();
+        }
+        if (c < n_ctg)
+            tails_before[c] = carry_b + s_b[threadIdx.x] - b;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry_b += s_b[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tails_before[n_ctg] = carry_b;
+        counts->n_acc = n_acc;
+        counts->n_segs = n_acc + carry_b;
+    }
+}
+
+// ---- 5. the segments.  Segment index of taken hit a (a-th taken overall) = a + tails_before[its contig]; the tail segment of
+// contig c sits right after the contig's last hit segment.  First the tail segments as far as the contig alone defines them.
+__global__ void __launch_bounds__(256) seg_tail_kernel(const uint64_t *__restrict__ ctg_off, uint32_t n_ctg, const uint32_t *__restrict__ hits_before,
+                                                       const uint32_t *__restrict__ tails_before, DevSeg *__restrict__ segs)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_ctg && tails_before[c + 1] != tails_before[c]) {
         DevSeg s;
         s.ctg = c;
         s.front_dir = s.front_rc = s.back_dir = s.back_rc = 0;
@@ -184,7 +194,7 @@ __global__ void __launch_bounds__(256) seg_cut_kernel(const uint32_t *__restrict
     }
 }
 
-// (second half: needs acc_sorted_idx complete) one thread per taken hit a: its segment, and -- for the last hit of a contig -- the
+// one thread per taken hit a: its segment, and -- for the last hit of a contig -- the
 // start / front k-mer of the contig's tail segment
 __global__ void __launch_bounds__(256) seg_fill_kernel(const ScanHit *__restrict__ hits, const uint32_t *__restrict__ order,
                                                        const uint32_t *__restrict__ ctg, const uint32_t *__restrict__ acc_sorted_idx, const SegCounts *__restrict__ counts,

@@ -45,15 +45,31 @@ int agc_hip_group_map_update(agc_hip_ctx *c, uint32_t n, const uint64_t *h_idx, 
         if (h_idx[i] >= c->gmap_slots)
             return AGC_HIP_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t idx_bytes = ((size_t)n * 8 + 15) & ~(size_t)15;
-    CHK(ensure(c, c->d_gmap_stage, idx_bytes + (size_t)n * sizeof(GroupSlot) + 64));
+    // through a pinned staging buffer of the context: nothing waits (the scatter is ordered before every later launch of the
+    // context's stream); the buffer is reused once the event behind its last scatter has passed
+    const size_t idx_bytes = ((size_t)n * 8 + 15) & ~(size_t)15, need = idx_bytes + (size_t)n * sizeof(GroupSlot);
+    if (!c->gmap_ev)
+        HIPCHK(c, hipEventCreateWithFlags(&c->gmap_ev, hipEventDisableTiming));
+    if (c->gmap_ev_valid)
+        HIPCHK(c, hipEventSynchronize(c->gmap_ev));
+    if (c->h_gmap_stage_cap < need) {
+        if (c->h_gmap_stage)
+            HIPCHK(c, hipHostFree(c->h_gmap_stage));
+        c->h_gmap_stage = nullptr;
+        c->h_gmap_stage_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_gmap_stage, need + need / 2 + 4096, hipHostMallocDefault));
+        c->h_gmap_stage_cap = need + need / 2 + 4096;
+    }
+    CHK(ensure(c, c->d_gmap_stage, need + 64));
+    memcpy(c->h_gmap_stage, h_idx, (size_t)n * 8);
+    memcpy((uint8_t *)c->h_gmap_stage + idx_bytes, h_slots, (size_t)n * sizeof(GroupSlot));
     uint8_t *st = (uint8_t *)c->d_gmap_stage.p;
-    HIPCHK(c, hipMemcpyAsync(st, h_idx, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st + idx_bytes, h_slots, (size_t)n * sizeof(GroupSlot), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st, c->h_gmap_stage, need, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(gmap_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (GroupSlot *)c->d_gmap.p, (const uint64_t *)st,
                        (const GroupSlot *)(st + idx_bytes), n);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(c->gmap_ev, c->stream));
+    c->gmap_ev_valid = true;
     return AGC_HIP_OK;
 }
 
@@ -71,6 +87,75 @@ template <typename T> T *carve(uint8_t *&p, size_t n)
 
 } // namespace
 
+// launches, on the second lane, the encode of the segments of the last agc_hip_segments_packed call whose group the table knew
+static int launch_known(agc_hip_ctx *c)
+{
+    agc_hip_ctx::SegState &S = c->seg_state;
+    const uint32_t n_ub = S.n_ub;
+    const hipStream_t st = c->stream;
+    DevSeg *segs = (DevSeg *)S.segs;
+    SegCounts *counts = (SegCounts *)S.counts;
+    uint32_t *flag = (uint32_t *)S.flag, *known_rank = (uint32_t *)S.known_rank;
+    unsigned long long *capv = (unsigned long long *)S.capv, *cap_off = (unsigned long long *)S.cap_off;
+    SegDesc *descs = (SegDesc *)S.descs;
+    uint32_t *skey0 = (uint32_t *)S.skey0, *skey1 = (uint32_t *)S.skey1, *sval0 = (uint32_t *)S.sval0, *sval1 = (uint32_t *)S.sval1;
+    CHK(upload_refs(c));
+    const size_t scratch_ub = (size_t)(S.total + 5 * S.total / 16) + 96 * (size_t)n_ub + 64;
+    CHK(ensure(c, c->l2.d_segs, (size_t)n_ub * sizeof(SegDesc), c->stream2));
+    CHK(ensure(c, c->l2.d_resv, (size_t)n_ub * 4, c->stream2));
+    CHK(ensure(c, c->l2.d_resp, (size_t)n_ub * 4, c->stream2));
+    CHK(ensure(c, c->l2.d_scratch, scratch_ub, c->stream2));
+    if (c->l2.h_lens_cap < n_ub) {
+        if (c->l2.h_lens)
+            HIPCHK(c, hipHostFree(c->l2.h_lens));
+        c->l2.h_lens = nullptr;
+        c->l2.h_lens_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->l2.h_lens, ((size_t)n_ub + n_ub / 4 + 1024) * 4, hipHostMallocDefault));
+        c->l2.h_lens_cap = (size_t)n_ub + n_ub / 4 + 1024;
+    }
+    hipLaunchKernelGGL(known_flag_kernel, dim3((n_ub + 256) / 256), dim3(256), 0, st, segs, counts, (const RefDesc *)c->d_refs.p, (uint32_t)c->refs.size(), n_ub, flag,
+                       capv);
+    size_t tb = 0, tb2 = 0;
+    if (rocprim::exclusive_scan(nullptr, tb, flag, known_rank, 0u, (size_t)n_ub + 1, rocprim::plus<uint32_t>(), st) != hipSuccess ||
+        rocprim::exclusive_scan(nullptr, tb2, capv, cap_off, 0ull, (size_t)n_ub + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess)
+        return AGC_HIP_ENODEV;
+    CHK(ensure(c, c->d_segtmp, std::max(tb, tb2) + 256));
+    if (rocprim::exclusive_scan(c->d_segtmp.p, tb, flag, known_rank, 0u, (size_t)n_ub + 1, rocprim::plus<uint32_t>(), st) != hipSuccess ||
+        rocprim::exclusive_scan(c->d_segtmp.p, tb2, capv, cap_off, 0ull, (size_t)n_ub + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess)
+        return AGC_HIP_ENODEV;
+    HIPCHK(c, hipMemsetAsync(skey0, 0xFF, (size_t)n_ub * 4, st));
+    const PackedView pv = {S.pk.d_words, S.pk.d_esc_index, S.pk.d_esc_bytes, S.pk.n_symbols};
+    hipLaunchKernelGGL(known_emit_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, segs, counts, flag, known_rank, cap_off, n_ub, pv, (const uint64_t *)S.d_ctg_off,
+                       descs, skey0, sval0);
+    rocprim::double_buffer<uint32_t> sk(skey0, skey1), sv(sval0, sval1);
+    tb = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tb, sk, sv, (size_t)n_ub, 0, 32, st) != hipSuccess)
+        return AGC_HIP_ENODEV;
+    CHK(ensure(c, c->d_segtmp, tb + 256));
+    if (rocprim::radix_sort_pairs(c->d_segtmp.p, tb, sk, sv, (size_t)n_ub, 0, 32, st) != hipSuccess)
+        return AGC_HIP_ENODEV;
+    hipLaunchKernelGGL(known_order_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, descs, sv.current(), counts, (SegDesc *)c->l2.d_segs.p);
+    HIPCHK(c, hipGetLastError());
+    // the parse on the second lane, behind everything queued here
+    HIPCHK(c, hipEventRecord(c->l2.ready, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->l2.ready, 0));
+    c->l2.timed = c->timing;
+    if (c->l2.timed)
+        (void)hipEventRecord(c->l2.e0, c->stream2);
+    CHK(launch_parse<MODE_ENCODE>(c, n_ub, (uint8_t *)c->l2.d_scratch.p, nullptr, true, &counts->n_known));
+    if (c->l2.timed)
+        (void)hipEventRecord(c->l2.e1, c->stream2);
+    HIPCHK(c, hipEventRecord(c->l2.done, c->stream2));
+    c->l2.done_valid = true;
+    HIPCHK(c, hipMemcpyAsync(c->l2.h_lens, c->l2.d_resv.p, (size_t)n_ub * 4, hipMemcpyDeviceToHost, c->stream2));
+    uint32_t *n_pinned = (uint32_t *)((uint8_t *)c->h_segcounts + 64);
+    HIPCHK(c, hipMemcpyAsync(n_pinned, &counts->n_known, 4, hipMemcpyDeviceToHost, c->stream2));
+    c->l2.n_pinned = n_pinned;
+    c->l2.n = 0;
+    c->l2.pending = true;
+    return AGC_HIP_OK;
+}
+
 extern "C" {
 
 int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k, int prefetched,
@@ -83,6 +168,7 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     *h_n_segs = 0;
     if (h_n_encoded)
         *h_n_encoded = 0;
+    c->seg_state.valid = false;
     if (!n_ctg)
         return AGC_HIP_OK;
     if (!pk->d_words || !pk->d_esc_index || h_ctg_off[n_ctg] > pk->n_symbols)
@@ -91,6 +177,16 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         c->err = "segments_packed: the previous encode was not collected (agc_hip_lz_encode_end)";
         return AGC_HIP_EINVAL;
     }
+    static const bool laps = getenv("AGC_HIP_LAPS") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double lt = laps ? tnow() : 0;
+    auto LAP = [&](const char *what) {
+        if (laps) {
+            const double t = tnow();
+            fprintf(stderr, "    segments_packed lap %s %.3f ms\n", what, t - lt);
+            lt = t;
+        }
+    };
     // ---- raw hits: collected from the prefetch, or scanned now
     uint32_t n = 0;
     const ScanHit *d_hits = nullptr;
@@ -119,6 +215,7 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
             CHK(packed_scan_raw(c, pk, h_ctg_off, n_ctg, k, &n));
         d_hits = (const ScanHit *)c->d_hits.p;
     }
+    LAP("hits");
     const uint64_t n_ub64 = (uint64_t)n + n_ctg;
     if (n_ub64 > 0x3fffffffULL)
         return AGC_HIP_EINVAL;
@@ -130,42 +227,52 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     if (!c->h_segcounts)
         HIPCHK(c, hipHostMalloc(&c->h_segcounts, 256, hipHostMallocDefault));
     // ---- work area
-    size_t need = 0;
+    auto layout = [&](uint8_t *p, bool assign) -> size_t {
+        uint8_t *p0 = p;
+        agc_hip_ctx::SegState &S = c->seg_state;
+        auto take_ = [&](void **dst, size_t bytes) {
+            if (assign && dst)
+                *dst = p;
+            p += (bytes + 255) & ~(size_t)255;
+        };
+        take_(&S.segs, (size_t)n_ub * sizeof(DevSeg));
+        take_(&S.counts, sizeof(SegCounts));
+        take_(&S.d_ctg_off, ((size_t)n_ctg + 1) * 8);
+        take_(&S.flag, ((size_t)n_ub + 1) * 4);
+        take_(&S.capv, ((size_t)n_ub + 1) * 8);
+        take_(&S.known_rank, ((size_t)n_ub + 1) * 4);
+        take_(&S.cap_off, ((size_t)n_ub + 1) * 8);
+        take_(&S.descs, (size_t)n_ub * sizeof(SegDesc));
+        take_(&S.skey0, (size_t)n_ub * 4);
+        take_(&S.skey1, (size_t)n_ub * 4);
+        take_(&S.sval0, (size_t)n_ub * 4);
+        take_(&S.sval1, (size_t)n_ub * 4);
+        return (size_t)(p - p0);
+    };
+    const size_t fixed_bytes = layout(nullptr, false);
+    size_t hit_bytes = 0;
     {
         uint8_t *p = nullptr;
-        carve<uint64_t>(p, n), carve<uint64_t>(p, n), carve<uint32_t>(p, n), carve<uint32_t>(p, n);           // sort buffers of the hits
-        carve<uint32_t>(p, n), carve<uint32_t>(p, n), carve<uint32_t>(p, (size_t)n + 1), carve<uint32_t>(p, n); // ctg, take, acc_rank, acc_idx
-        carve<uint64_t>(p, (size_t)n_ctg + 1), carve<uint32_t>(p, n_ctg), carve<unsigned long long>(p, n_ctg);
+        carve<uint64_t>(p, n), carve<uint64_t>(p, n), carve<uint32_t>(p, n), carve<uint32_t>(p, n);                 // sort buffers of the hits
+        carve<uint32_t>(p, n), carve<uint32_t>(p, (size_t)n + 1), carve<uint32_t>(p, (size_t)n + 1), carve<uint32_t>(p, n); // ctg, take, acc_rank, acc_idx
         carve<uint32_t>(p, (size_t)n_ctg + 1), carve<uint32_t>(p, (size_t)n_ctg + 1);
-        carve<DevSeg>(p, n_ub), carve<SegCounts>(p, 1);
-        carve<uint32_t>(p, (size_t)n_ub + 1), carve<unsigned long long>(p, (size_t)n_ub + 1), carve<uint32_t>(p, (size_t)n_ub + 1),
-            carve<unsigned long long>(p, (size_t)n_ub + 1);
-        carve<SegDesc>(p, n_ub), carve<uint32_t>(p, n_ub), carve<uint32_t>(p, n_ub), carve<uint32_t>(p, n_ub), carve<uint32_t>(p, n_ub);
-        need = (size_t)(p - (uint8_t *)nullptr);
+        hit_bytes = (size_t)(p - (uint8_t *)nullptr);
     }
-    CHK(ensure(c, c->d_segwork, need + 256));
-    uint8_t *p = (uint8_t *)c->d_segwork.p;
+    CHK(ensure(c, c->d_segwork, fixed_bytes + hit_bytes + 256));
+    layout((uint8_t *)c->d_segwork.p, true);
+    agc_hip_ctx::SegState &S = c->seg_state;
+    uint8_t *p = (uint8_t *)c->d_segwork.p + fixed_bytes;
     uint64_t *keys0 = carve<uint64_t>(p, n), *keys1 = carve<uint64_t>(p, n);
     uint32_t *vals0 = carve<uint32_t>(p, n), *vals1 = carve<uint32_t>(p, n);
-    uint32_t *ctg = carve<uint32_t>(p, n), *take = carve<uint32_t>(p, n), *acc_rank = carve<uint32_t>(p, (size_t)n + 1), *acc_idx = carve<uint32_t>(p, n);
-    uint64_t *d_ctg_off = carve<uint64_t>(p, (size_t)n_ctg + 1);
-    uint32_t *per_ctg = carve<uint32_t>(p, n_ctg);
-    unsigned long long *last_pos = carve<unsigned long long>(p, n_ctg);
+    uint32_t *ctg = carve<uint32_t>(p, n), *take = carve<uint32_t>(p, (size_t)n + 1), *acc_rank = carve<uint32_t>(p, (size_t)n + 1), *acc_idx = carve<uint32_t>(p, n);
     uint32_t *hits_before = carve<uint32_t>(p, (size_t)n_ctg + 1), *tails_before = carve<uint32_t>(p, (size_t)n_ctg + 1);
-    DevSeg *segs = carve<DevSeg>(p, n_ub);
-    SegCounts *counts = carve<SegCounts>(p, 1);
-    uint32_t *flag = carve<uint32_t>(p, (size_t)n_ub + 1);
-    unsigned long long *capv = carve<unsigned long long>(p, (size_t)n_ub + 1);
-    uint32_t *known_rank = carve<uint32_t>(p, (size_t)n_ub + 1);
-    unsigned long long *cap_off = carve<unsigned long long>(p, (size_t)n_ub + 1);
-    SegDesc *descs = carve<SegDesc>(p, n_ub);
-    uint32_t *skey0 = carve<uint32_t>(p, n_ub), *skey1 = carve<uint32_t>(p, n_ub), *sval0 = carve<uint32_t>(p, n_ub), *sval1 = carve<uint32_t>(p, n_ub);
+    DevSeg *segs = (DevSeg *)S.segs;
+    SegCounts *counts = (SegCounts *)S.counts;
+    uint64_t *d_ctg_off = (uint64_t *)S.d_ctg_off;
     const hipStream_t st = c->stream;
     auto tmp_for = [&](size_t bytes) -> int { return ensure(c, c->d_segtmp, bytes + 256); };
 
     HIPCHK(c, hipMemcpyAsync(d_ctg_off, h_ctg_off, ((size_t)n_ctg + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(per_ctg, 0, (size_t)n_ctg * 4, st));
-    HIPCHK(c, hipMemsetAsync(last_pos, 0, (size_t)n_ctg * 8, st));
     HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(SegCounts), st));
     const uint64_t *pos_sorted = keys0;
     const uint32_t *order = vals0;
@@ -184,19 +291,17 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         pos_sorted = dk.current();
         order = dv.current();
         hipLaunchKernelGGL(hit_contig_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pos_sorted, n, d_ctg_off, n_ctg, ctg);
-        hipLaunchKernelGGL(hit_accept_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pos_sorted, ctg, n, k, take, per_ctg, last_pos);
+        hipLaunchKernelGGL(hit_accept_kernel, dim3((n + 256) / 256), dim3(256), 0, st, pos_sorted, ctg, n, k, take);
         tb = 0;
-        if (rocprim::exclusive_scan(nullptr, tb, take, acc_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) != hipSuccess)
+        if (rocprim::exclusive_scan(nullptr, tb, take, acc_rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess)
             return AGC_HIP_ENODEV;
         CHK(tmp_for(tb));
-        if (rocprim::exclusive_scan(c->d_segtmp.p, tb, take, acc_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) != hipSuccess)
+        if (rocprim::exclusive_scan(c->d_segtmp.p, tb, take, acc_rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess)
             return AGC_HIP_ENODEV;
+        hipLaunchKernelGGL(hit_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, st, take, acc_rank, n, acc_idx);
     }
-    hipLaunchKernelGGL(contig_sums_kernel, dim3(1), dim3(1024), 0, st, d_ctg_off, n_ctg, k, per_ctg, last_pos, hits_before, tails_before, counts);
-    {
-        const uint32_t m = std::max(n, n_ctg);
-        hipLaunchKernelGGL(seg_cut_kernel, dim3((m + 255) / 256), dim3(256), 0, st, take, acc_rank, n, d_ctg_off, n_ctg, hits_before, tails_before, acc_idx, segs);
-    }
+    hipLaunchKernelGGL(contig_sums_kernel, dim3(1), dim3(1024), 0, st, d_ctg_off, n_ctg, k, pos_sorted, ctg, acc_idx, acc_rank, n, hits_before, tails_before, counts);
+    hipLaunchKernelGGL(seg_tail_kernel, dim3((n_ctg + 255) / 256), dim3(256), 0, st, d_ctg_off, n_ctg, hits_before, tails_before, segs);
     if (n)
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_hits, order, ctg, acc_idx, counts, k, d_ctg_off, hits_before, tails_before, segs);
     HIPCHK(c, hipGetLastError());
@@ -219,76 +324,61 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
                                segs, counts, 0u);
         HIPCHK(c, hipGetLastError());
     }
-    // ---- the encode of the segments whose group is known, launched from here (second lane)
-    const uint64_t total = h_ctg_off[n_ctg] - h_ctg_off[0];
+    LAP("cut + look-up queued");
+    S.n_ub = n_ub;
+    S.total = h_ctg_off[n_ctg] - h_ctg_off[0];
+    S.pk = *pk;
+    S.valid = c->gmap_slots != 0 && n_ub != 0;
+    // ---- the encode of the segments whose group is known, launched from here (second lane) when asked
     bool launched = false;
-    if (encode_known && c->gmap_slots && n_ub) {
-        CHK(upload_refs(c));
-        const size_t scratch_ub = (size_t)(total + 5 * total / 16) + 96 * (size_t)n_ub + 64;
-        CHK(ensure(c, c->l2.d_segs, (size_t)n_ub * sizeof(SegDesc), c->stream2));
-        CHK(ensure(c, c->l2.d_resv, (size_t)n_ub * 4, c->stream2));
-        CHK(ensure(c, c->l2.d_resp, (size_t)n_ub * 4, c->stream2));
-        CHK(ensure(c, c->l2.d_scratch, scratch_ub, c->stream2));
-        if (c->l2.h_lens_cap < n_ub) {
-            if (c->l2.h_lens)
-                HIPCHK(c, hipHostFree(c->l2.h_lens));
-            c->l2.h_lens = nullptr;
-            c->l2.h_lens_cap = 0;
-            HIPCHK(c, hipHostMalloc((void **)&c->l2.h_lens, ((size_t)n_ub + n_ub / 4 + 1024) * 4, hipHostMallocDefault));
-            c->l2.h_lens_cap = (size_t)n_ub + n_ub / 4 + 1024;
-        }
-        hipLaunchKernelGGL(known_flag_kernel, dim3((n_ub + 256) / 256), dim3(256), 0, st, segs, counts, (const RefDesc *)c->d_refs.p, (uint32_t)c->refs.size(), n_ub,
-                           flag, capv);
-        size_t tb = 0, tb2 = 0;
-        if (rocprim::exclusive_scan(nullptr, tb, flag, known_rank, 0u, (size_t)n_ub + 1, rocprim::plus<uint32_t>(), st) != hipSuccess ||
-            rocprim::exclusive_scan(nullptr, tb2, capv, cap_off, 0ull, (size_t)n_ub + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess)
-            return AGC_HIP_ENODEV;
-        CHK(tmp_for(std::max(tb, tb2)));
-        if (rocprim::exclusive_scan(c->d_segtmp.p, tb, flag, known_rank, 0u, (size_t)n_ub + 1, rocprim::plus<uint32_t>(), st) != hipSuccess ||
-            rocprim::exclusive_scan(c->d_segtmp.p, tb2, capv, cap_off, 0ull, (size_t)n_ub + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess)
-            return AGC_HIP_ENODEV;
-        HIPCHK(c, hipMemsetAsync(skey0, 0xFF, (size_t)n_ub * 4, st));
-        const PackedView pv = {pk->d_words, pk->d_esc_index, pk->d_esc_bytes, pk->n_symbols};
-        hipLaunchKernelGGL(known_emit_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, segs, counts, flag, known_rank, cap_off, n_ub, pv, d_ctg_off, descs, skey0, sval0);
-        rocprim::double_buffer<uint32_t> sk(skey0, skey1), sv(sval0, sval1);
-        tb = 0;
-        if (rocprim::radix_sort_pairs(nullptr, tb, sk, sv, (size_t)n_ub, 0, 32, st) != hipSuccess)
-            return AGC_HIP_ENODEV;
-        CHK(tmp_for(tb));
-        if (rocprim::radix_sort_pairs(c->d_segtmp.p, tb, sk, sv, (size_t)n_ub, 0, 32, st) != hipSuccess)
-            return AGC_HIP_ENODEV;
-        hipLaunchKernelGGL(known_order_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, descs, sv.current(), counts, (SegDesc *)c->l2.d_segs.p);
-        HIPCHK(c, hipGetLastError());
-        // the parse on the second lane, behind everything queued here
-        HIPCHK(c, hipEventRecord(c->l2.ready, st));
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->l2.ready, 0));
-        c->l2.timed = c->timing;
-        if (c->l2.timed)
-            (void)hipEventRecord(c->l2.e0, c->stream2);
-        CHK(launch_parse<MODE_ENCODE>(c, n_ub, (uint8_t *)c->l2.d_scratch.p, nullptr, true, &counts->n_known));
-        if (c->l2.timed)
-            (void)hipEventRecord(c->l2.e1, c->stream2);
-        HIPCHK(c, hipEventRecord(c->l2.done, c->stream2));
-        c->l2.done_valid = true;
-        HIPCHK(c, hipMemcpyAsync(c->l2.h_lens, c->l2.d_resv.p, (size_t)n_ub * 4, hipMemcpyDeviceToHost, c->stream2));
+    if (encode_known && S.valid) {
+        CHK(launch_known(c));
         launched = true;
+        LAP("encode queued");
     }
-    // ---- the segment table to the host
+    // ---- the segment table to the host (into pinned memory when the caller's buffer is: agc_hip_host_alloc)
     HIPCHK(c, hipMemcpyAsync(c->h_segcounts, counts, sizeof(SegCounts), hipMemcpyDeviceToHost, st));
     if (n_ub)
         HIPCHK(c, hipMemcpyAsync(h_segs, segs, (size_t)n_ub * sizeof(DevSeg), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    LAP("segments on the host");
     const SegCounts hc = *(const SegCounts *)c->h_segcounts;
     *h_n_segs = hc.n_segs;
     if (launched) {
-        c->l2.n = hc.n_known;
-        c->l2.pending = true;
+        // (the flags `encoded` were set before the copy: their number is the number of deltas; the device's own count arrives
+        // behind the parse and is what agc_hip_lz_encode_end goes by)
+        uint32_t ne = 0;
+        for (uint32_t i = 0; i < hc.n_segs; ++i)
+            ne += h_segs[i].encoded != 0;
         if (h_n_encoded)
-            *h_n_encoded = hc.n_known;
+            *h_n_encoded = ne;
+        if (!ne) { // (no group was known: the launch had nothing to do and nothing is in flight)
+            HIPCHK(c, hipStreamSynchronize(c->stream2));
+            c->l2.n_pinned = nullptr;
+            c->l2.pending = false;
+        }
     }
     if (from_pf)
         pf.valid = false;
     return AGC_HIP_OK;
+}
+
+// The same launch as a call of its own, for a caller that wants the segment table first (include/agc_hip.h)
+int agc_hip_segments_encode_known(agc_hip_ctx *c)
+{
+    if (!c)
+        return AGC_HIP_EINVAL;
+    if (!c->seg_state.valid) {
+        c->err = "segments_encode_known: no segments on the device (agc_hip_segments_packed comes first)";
+        return AGC_HIP_EINVAL;
+    }
+    if (c->l2.pending) {
+        c->err = "segments_encode_known: the previous encode was not collected (agc_hip_lz_encode_end)";
+        return AGC_HIP_EINVAL;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->seg_state.valid = false;
+    return launch_known(c);
 }
 
 } // extern "C"

@@ -204,6 +204,12 @@ typedef struct {
 int agc_hip_segments_packed(agc_hip_ctx *ctx, const agc_hip_packed *pk, const uint64_t *h_ctg_off, uint32_t n_ctg, uint32_t k,
                             int prefetched, int encode_known, uint64_t cap, agc_hip_segment *h_segs, uint64_t *h_n_segs,
                             uint32_t *h_n_encoded);
+/* The launch of encode_known as a call of its own, for a caller that wants the segment table first (its second lane may still
+ * be handing the previous sample's deltas over): the segments of the LAST agc_hip_segments_packed call (made with
+ * encode_known == 0) are still on the device; the ones whose group the table knew and whose reference is registered are
+ * encoded exactly as above -- these are the segments with two splitters and map_gid >= 16 (the caller tells them from its
+ * table).  Nothing is waited for. */
+int agc_hip_segments_encode_known(agc_hip_ctx *ctx);
 
 /* ---- S2: LZ-diff against group references (a10, a11, a6, a7) ---------- */
 /* A "slice" names one sequence inside a device buffer: symbols [off, off+len) of a packed sample *pk (the *_packed
@@ -269,6 +275,9 @@ int agc_hip_lz_encode_begin_dev(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_
 int agc_hip_lz_encode_begin_packed(agc_hip_ctx *ctx, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
                                    const uint32_t *h_len, const uint8_t *h_rc);
 int agc_hip_lz_encode_end(agc_hip_ctx *ctx, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
+/* number of deltas the encode in flight will deliver (0: none in flight); waits for the parse when the encode was launched from
+ * descriptors made on the device (agc_hip_segments_encode_known), whose number only the device knows until then. */
+int agc_hip_lz_encode_pending(agc_hip_ctx *ctx, uint32_t *h_n);
 
 /* Pinned host memory for result buffers (device-to-host copies into pageable memory go through a bounce buffer at a
  * fraction of the link rate).  Freed by agc_hip_host_free or with the context. */

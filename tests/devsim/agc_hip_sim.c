@@ -53,6 +53,11 @@ struct agc_hip_ctx {
     u64 *enc_eoff;
     /* the next sample ahead of its turn: the identity of what was announced */
     const void *pf_words;
+    /* what agc_hip_segments_packed left for agc_hip_segments_encode_known */
+    int sg_valid;
+    u32 sg_ne, *sg_gid, *sg_len;
+    u64 *sg_off;
+    u8 *sg_rc, *sg_codes;
     /* the mirrored (k-mer 1, k-mer 2) -> group table */
     agc_hip_group_slot *gmap;
     u64 gmap_slots;
@@ -118,6 +123,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
     free(c->sp_index);
     free(c->sp_esc);
     free(c->gmap);
+    free(c->sg_gid), free(c->sg_len), free(c->sg_off), free(c->sg_rc), free(c->sg_codes);
     free(c);
 }
 
@@ -359,6 +365,14 @@ int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid,
         break;
     }
     c->enc_pending = 1;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_encode_pending(agc_hip_ctx *c, uint32_t *h_n)
+{
+    if (!c || !h_n)
+        return AGC_HIP_EINVAL;
+    *h_n = c->enc_pending ? c->enc_n : 0;
     return AGC_HIP_OK;
 }
 
@@ -820,7 +834,12 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     }
     *h_n_segs = n;
     int r = AGC_HIP_OK;
-    if (encode_known && c->gmap_slots) {
+    free(c->sg_gid), free(c->sg_len), free(c->sg_off), free(c->sg_rc), free(c->sg_codes);
+    c->sg_gid = c->sg_len = NULL;
+    c->sg_off = NULL;
+    c->sg_rc = c->sg_codes = NULL;
+    c->sg_valid = 0;
+    if (c->gmap_slots) {
         u32 ne = 0;
         u32 *gid = (u32 *)malloc((n + 1) * 4), *len = (u32 *)malloc((n + 1) * 4);
         u64 *off = (u64 *)malloc((n + 1) * 8);
@@ -828,7 +847,8 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         for (u64 i = 0; i < n; ++i) {
             agc_hip_segment *s_ = &h_segs[i];
             if (s_->front_full && s_->back_full && s_->map_gid >= 16 && find_ref(c, (u32)s_->map_gid)) {
-                s_->encoded = 1;
+                if (encode_known)
+                    s_->encoded = 1;
                 gid[ne] = (u32)s_->map_gid;
                 off[ne] = h_ctg_off[s_->ctg] + s_->start;
                 len[ne] = s_->len;
@@ -836,15 +856,39 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
                 ++ne;
             }
         }
-        if (ne) {
-            r = agc_hip_lz_encode_begin_dev(c, ne, gid, codes, off, len, rc);
-            if (r == AGC_HIP_OK && h_n_encoded)
-                *h_n_encoded = ne;
+        if (encode_known) {
+            if (ne) {
+                r = agc_hip_lz_encode_begin_dev(c, ne, gid, codes, off, len, rc);
+                if (r == AGC_HIP_OK && h_n_encoded)
+                    *h_n_encoded = ne;
+            }
+            free(gid), free(len), free(off), free(rc);
+        } else { /* kept for agc_hip_segments_encode_known */
+            c->sg_gid = gid, c->sg_len = len, c->sg_off = off, c->sg_rc = rc, c->sg_codes = codes, c->sg_ne = ne, c->sg_valid = 1;
+            codes = NULL;
         }
-        free(gid), free(len), free(off), free(rc);
     }
     free(codes);
     return r;
+}
+
+/* the launch as a call of its own: the stand-in kept what it needs from the last agc_hip_segments_packed call */
+int agc_hip_segments_encode_known(agc_hip_ctx *c)
+{
+    if (!c || !c->sg_valid)
+        return fail(c, AGC_HIP_EINVAL, "segments_encode_known: no segments");
+    if (c->enc_pending)
+        return fail(c, AGC_HIP_EINVAL, "segments_encode_known: the previous encode was not collected");
+    c->sg_valid = 0;
+    if (!c->sg_ne) {
+        /* (nothing known: an empty encode is in flight, as on the device) */
+        c->enc_n = 0;
+        c->enc_eoff = (u64 *)calloc(1, 8);
+        c->enc_out = (u8 *)malloc(1);
+        c->enc_pending = 1;
+        return AGC_HIP_OK;
+    }
+    return agc_hip_lz_encode_begin_dev(c, c->sg_ne, c->sg_gid, c->sg_codes, c->sg_off, c->sg_len, c->sg_rc);
 }
 
 /* a1 on the stand-in: the oracle's preprocess_raw_contig */

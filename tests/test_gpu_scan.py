@@ -304,6 +304,12 @@ def test_segments_on_the_device_match_oracle(hip_ctx, oracle, k, prefetched, big
     assert eoff.size == n_known + 1
     for i, (key, t) in enumerate(texts):
         assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], oracle.LZ(refs[key], mml).encode(t)), i
+    # the launch as a call of its own (the table first, the encode when the caller's second lane is free): the same deltas
+    segs3, _ = hip_ctx.segments_packed(pk, off, k, cap=1 << 14)
+    m = hip_ctx.segments_encode_known(segs3, keys.values())
+    assert int(m.sum()) == n_known
+    enc3, eoff3 = hip_ctx.lz_encode_end()
+    assert np.array_equal(enc3, enc) and np.array_equal(eoff3, eoff)
     # single slots of the table replaced: a key moves to another group, the look-up follows
     key0 = next(iter(keys))
     tab = hip_ctx.group_map_set(keys, n_slots=(1 << 22) if big_table else 16)
@@ -315,3 +321,37 @@ def test_segments_on_the_device_match_oracle(hip_ctx, oracle, k, prefetched, big
     moved = [int(sg["map_gid"]) for sg in segs2 if sg["front_full"] and sg["back_full"] and
              (min(int(sg["front_dir"]), int(sg["front_rc"])), min(int(sg["back_dir"]), int(sg["back_rc"]))) in (key0, key0[::-1])]
     assert moved and all(g == -7 for g in moved)
+
+
+@pytest.mark.parametrize("seed", [9, 3, 14, 27])
+def test_segments_of_fuzz_collections_match_oracle(hip_ctx, oracle, seed, tmp_path):
+    """the cut on the device for the fuzzer's collections (tests/fuzz.py: tiny segment sizes -- hits closer than k --, contigs
+    shorter than k, repeats, N runs): every file's segments against the oracle's compress_contig"""
+    import torch
+    from agc_amd import fasta
+    from tests import fuzz
+    case = fuzz.make_case(seed, str(tmp_path / "in"))
+    k = int(case["args"][case["args"].index("-k") + 1])
+    seg = int(case["args"][case["args"].index("-s") + 1])
+    if k < 16:
+        pytest.skip("the packed scan needs k >= 16")
+    _n, rcodes, roff = fasta.read_codes(case["files"][0])
+    spl = oracle.determine_splitters([rcodes[int(roff[i]):int(roff[i + 1])] for i in range(len(roff) - 1)], k, seg)
+    hip_ctx.splitters_set(spl)
+    hip_ctx.group_map_set({})
+    for f in case["files"]:
+        _names, codes, off = fasta.read_codes(f)
+        if not codes.size:
+            continue
+        d = torch.from_numpy(np.concatenate([codes, np.zeros(64, np.uint8)])).cuda()
+        torch.cuda.synchronize()
+        pk, keep = hip_ctx.pack_dev(d, codes.size)
+        segs, _ = hip_ctx.segments_packed(pk, off, k, cap=8)
+        want = []
+        for ci in range(len(off) - 1):
+            s = oracle.scan_contig(codes[int(off[ci]):int(off[ci + 1])], k, spl)
+            for i in range(len(s["start"])):
+                want.append((ci, int(s["start"][i]), int(s["len"][i]), int(s["front_full"][i]), int(s["back_full"][i]),
+                             int(s["front_dir"][i]) if s["front_full"][i] else 0, int(s["back_dir"][i]) if s["back_full"][i] else 0))
+        got = [(int(g["ctg"]), int(g["start"]), int(g["len"]), int(g["front_full"]), int(g["back_full"]), int(g["front_dir"]), int(g["back_dir"])) for g in segs]
+        assert got == want, (f, len(got), len(want), next((i, a, b) for i, (a, b) in enumerate(zip(got + [None], want + [None])) if a != b))
