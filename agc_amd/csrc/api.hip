@@ -89,8 +89,7 @@ struct agc_hip_ctx {
         uint64_t total = 0;
         agc_hip_packed pk{};
         void *segs = nullptr, *counts = nullptr, *d_ctg_off = nullptr;
-        void *flag = nullptr, *capv = nullptr, *known_rank = nullptr, *cap_off = nullptr, *descs = nullptr, *skey0 = nullptr, *skey1 = nullptr, *sval0 = nullptr,
-             *sval1 = nullptr;
+        void *flag = nullptr, *capv = nullptr, *known_rank = nullptr, *cap_off = nullptr, *descs = nullptr, *lcnt = nullptr;
     } seg_state;
     DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
         d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_zdstoff, d_maybe, d_fjobs;
@@ -98,6 +97,11 @@ struct agc_hip_ctx {
     PackTemp pk1;        // byte-input entry points on the first stream
     PackTemp pk_sample;  // agc_hip_sample_pack
     std::mutex host_alloc_mtx; // host_allocs: agc_hip_host_alloc / _free may be called from the thread that collects an encode
+    // pinned staging ring of the small host -> device uploads (descriptors, offsets, tables): a copy from pageable memory makes the
+    // calling thread wait for the copy engine -- behind whatever else it is moving, e.g. the 22 MB of a sample's deltas
+    uint8_t *up_ring = nullptr;
+    size_t up_cap = 0, up_head = 0;
+    std::mutex up_mtx;
 
     // second LZ lane: agc_hip_lz_encode_begin_dev / _end run the encode of a whole sample on `stream2` with their own scratch,
     // beside the estimates / cost vectors / index builds the caller goes on with on `stream`
@@ -242,6 +246,39 @@ struct ZTimer {
 
 int ensure_z(agc_hip_ctx *c, DevBuf &b, size_t bytes) { return ensure(c, b, bytes, c->zstream); }
 
+// host -> device, without the calling thread waiting: through the context's pinned ring (a slot is reused a ring's length later:
+// tens of steps; the wrap waits for the LZ streams once to be sure).  Large copies go the ordinary way.
+int upload(agc_hip_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStream_t st)
+{
+    constexpr size_t RING = (size_t)64 << 20, MAX_PIECE = (size_t)8 << 20;
+    if (!bytes)
+        return AGC_HIP_OK;
+    if (bytes > MAX_PIECE) {
+        HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+        return AGC_HIP_OK;
+    }
+    uint8_t *slot;
+    {
+        std::lock_guard<std::mutex> lk(c->up_mtx);
+        if (!c->up_ring) {
+            HIPCHK(c, hipHostMalloc((void **)&c->up_ring, RING, hipHostMallocDefault));
+            c->up_cap = RING;
+        }
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (c->up_head + need > c->up_cap) {
+            for (hipStream_t s_ : {c->stream, c->stream2, c->pf.stream})
+                if (s_)
+                    HIPCHK(c, hipStreamSynchronize(s_));
+            c->up_head = 0;
+        }
+        slot = c->up_ring + c->up_head;
+        c->up_head += need;
+    }
+    std::memcpy(slot, h_src, bytes);
+    HIPCHK(c, hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, st));
+    return AGC_HIP_OK;
+}
+
 // the entropy stage's stream yields to the streams of the steps wherever the hardware queues let it
 hipError_t create_low_priority_stream(hipStream_t *s)
 {
@@ -259,8 +296,9 @@ int upload_refs(agc_hip_ctx *c)
         HIPCHK(c, hipStreamSynchronize(c->stream2)); // the encode in flight reads the table that is about to be replaced
     CHK(ensure(c, c->d_refs, std::max<size_t>(1, c->refs.size()) * sizeof(RefDesc)));
     if (!c->refs.empty())
-        HIPCHK(c, hipMemcpyAsync(c->d_refs.p, c->refs.data(), c->refs.size() * sizeof(RefDesc), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // refs vector may be reallocated by the caller's next register
+        CHK(upload(c, c->d_refs.p, c->refs.data(), c->refs.size() * sizeof(RefDesc), c->stream));
+    if (c->refs.size() * sizeof(RefDesc) > ((size_t)8 << 20))
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // (beyond upload()'s staging: the vector may be reallocated by the next register)
     c->refs_dirty = false;
     return AGC_HIP_OK;
 }
@@ -355,6 +393,8 @@ int agc_hip_create(agc_hip_ctx **out, int device)
         create_low_priority_stream(&c->zstream) != hipSuccess || create_low_priority_stream(&c->zstream2) != hipSuccess ||
         hipEventCreateWithFlags(&c->zev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->zev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->zev_wait, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
+        // (the second lane at the first stream's priority: measured with a low-priority lane the whole-sample encode is starved by
+        // the classification kernels until they are done and ends up on the critical path of the NEXT sample's launch)
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l2.e0) != hipSuccess ||
         hipEventCreate(&c->l2.e1) != hipSuccess || hipEventCreateWithFlags(&c->l2.ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->l2.done, hipEventDisableTiming) != hipSuccess ||
@@ -391,6 +431,8 @@ void agc_hip_destroy(agc_hip_ctx *c)
     }
     for (void *hp : c->host_allocs)
         (void)hipHostFree(hp);
+    if (c->up_ring)
+        (void)hipHostFree(c->up_ring);
     if (c->l2.h_lens)
         (void)hipHostFree(c->l2.h_lens);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_sbloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
@@ -737,7 +779,7 @@ int agc_hip_scan_contigs_dev(agc_hip_ctx *c, const uint8_t *d_codes, const uint6
         return AGC_HIP_EINVAL;
     CHK(ensure(c, c->d_ranges, ranges.size() * sizeof(ScanRange)));
     CHK(ensure(c, c->d_counter, 64));
-    HIPCHK(c, hipMemcpyAsync(c->d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), c->stream));
 
     uint32_t dev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(total / 2000 + 4096, c->d_hits.cap / sizeof(ScanHit)), 1u << 30);
     uint32_t n_found = 0;
@@ -911,7 +953,7 @@ static int packed_scan_raw(agc_hip_ctx *c, const agc_hip_packed *pk, const uint6
         return AGC_HIP_EINVAL;
     CHK(ensure(c, c->d_ranges, ranges.size() * sizeof(ScanRange)));
     CHK(ensure(c, c->d_counter, 64));
-    HIPCHK(c, hipMemcpyAsync(c->d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), c->stream));
     static bool lds_set = false;
     if (!lds_set) {
         HIPCHK(c, hipFuncSetAttribute((const void *)scan_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SBLOOM_WORDS * 4));
@@ -1019,7 +1061,7 @@ int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const 
         pf.dev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(total / 1000 + 4096, pf.d_hits.cap / sizeof(ScanHit)), 1u << 30);
         CHK(ensure(c, pf.d_hits, (size_t)pf.dev_cap * sizeof(ScanHit), pf.stream));
         // (the ranges go through a pageable vector: the copy is staged by the runtime before the call returns)
-        HIPCHK(c, hipMemcpyAsync(pf.d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), hipMemcpyHostToDevice, pf.stream));
+        CHK(upload(c, pf.d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), pf.stream));
         HIPCHK(c, hipMemsetAsync(pf.d_counter.p, 0, 4, pf.stream));
         static bool lds_set = false;
         if (!lds_set) {
@@ -1136,7 +1178,7 @@ static int ref_register_impl(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_
     CHK(ensure(c, c->d_jobs, (size_t)n_refs * sizeof(IdxBuild)));
     CHK(ensure(c, c->d_counts, (size_t)n_refs * 4));
     CHK(ensure(c, c->d_flags, (size_t)n_refs * 4));
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), c->stream));
     // few references per batch (steady state): spread each over several blocks to fill the chip
     const uint32_t split = n_refs >= 2048 ? 1u : std::min<uint32_t>(16u, 2048u / n_refs);
     HIPCHK(c, hipMemsetAsync(c->d_flags.p, 0, (size_t)n_refs * 4, c->stream));
@@ -1196,11 +1238,11 @@ static int ref_register_impl(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_
     }
     if (!ejobs.empty()) {
         CHK(ensure(c, c->d_esc_jobs, ejobs.size() * sizeof(EscJob)));
-        HIPCHK(c, hipMemcpyAsync(c->d_esc_jobs.p, ejobs.data(), ejobs.size() * sizeof(EscJob), hipMemcpyHostToDevice, c->stream));
+        CHK(upload(c, c->d_esc_jobs.p, ejobs.data(), ejobs.size() * sizeof(EscJob), c->stream));
         KTimer t(c, AGC_HIP_K_REFSTORE);
         hipLaunchKernelGGL(ref_esc_kernel, dim3((uint32_t)ejobs.size()), dim3(256), 0, c->stream, (const EscJob *)c->d_esc_jobs.p);
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_jobs.p, jobs.data(), (size_t)n_refs * sizeof(IdxBuild), c->stream));
     {
         KTimer t(c, AGC_HIP_K_INDEX);
         hipLaunchKernelGGL(idx_insert_kernel, dim3(n_refs * split), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p, split);
@@ -1427,17 +1469,16 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
     }
     if (!fjobs.empty()) {
         CHK(ensure(c, c->d_fjobs, fjobs.size() * sizeof(FilterJob)));
-        HIPCHK(c, hipMemcpyAsync(c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), hipMemcpyHostToDevice, L_stream));
+        CHK(upload(c, c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), L_stream));
         {
             KTimer t(c, AGC_HIP_K_FILTER);
             hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
         }
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(L_stream)); // (fjobs is a local)
+        HIPCHK(c, hipGetLastError()); // (fjobs is a local: upload() took its copy)
     }
     LAP("descriptors");
     CHK(ensure(c, L_segs, (size_t)n * sizeof(SegDesc), L_stream));
-    HIPCHK(c, hipMemcpyAsync(L_segs.p, b.segs.data(), (size_t)n * sizeof(SegDesc), hipMemcpyHostToDevice, L_stream));
+    CHK(upload(c, L_segs.p, b.segs.data(), (size_t)n * sizeof(SegDesc), L_stream));
     CHK(ensure(c, L_counter, 64, L_stream));
     HIPCHK(c, hipMemsetAsync(L_counter.p, 0, 4, L_stream));
     CHK(ensure(c, L_resv, (size_t)n * 4, L_stream));
@@ -1503,7 +1544,7 @@ static int lz_encode_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, con
         return AGC_HIP_EINVAL;
     CHK(ensure(c, c->d_dstoff, (size_t)n * 8));
     CHK(ensure(c, c->d_compact, tot));
-    HIPCHK(c, hipMemcpyAsync(c->d_dstoff.p, h_enc_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_dstoff.p, h_enc_off, (size_t)n * 8, c->stream));
     hipLaunchKernelGGL(gather_bytes_kernel, dim3(grid_for(n, 1, 8192)), dim3(256), 0, c->stream, (const uint8_t *)c->d_scratch.p,
                        (const SegDesc *)c->d_segs.p, (const uint32_t *)c->d_resv.p, (const uint64_t *)c->d_dstoff.p, n,
                        (uint8_t *)c->d_compact.p);
@@ -1681,23 +1722,45 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint
         (void)hipMemcpyToSymbol(HIP_SYMBOL(agc::g_phase_cnt), z, sizeof z);
     }
 #endif
+    static const bool laps = getenv("AGC_HIP_LAPS") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double lt = laps ? tnow() : 0;
+    auto LAP = [&](const char *what) {
+        if (laps && n > 10000) {
+            const double t = tnow();
+            fprintf(stderr, "    lz_encode_end lap %s %.3f ms\n", what, t - lt);
+            lt = t;
+        }
+    };
     for (uint32_t i = 0; i < n; ++i)
         h_enc_off[i + 1] = h_enc_off[i] + c->l2.h_lens[i];
     const uint64_t tot = h_enc_off[n];
     if (tot > enc_cap)
         return AGC_HIP_ECAP; // (still in flight: call again with a larger buffer)
+    LAP("offsets");
     if (tot) {
         if (!h_enc)
             return AGC_HIP_EINVAL;
         CHK(ensure(c, c->l2.d_dstoff, (size_t)n * 8, c->stream2));
-        CHK(ensure(c, c->l2.d_compact, tot, c->stream2));
-        HIPCHK(c, hipMemcpyAsync(c->l2.d_dstoff.p, h_enc_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream2));
+        CHK(upload(c, c->l2.d_dstoff.p, h_enc_off, (size_t)n * 8, c->stream2));
+        // a pinned result buffer (agc_hip_host_alloc) is written by the gather itself, over the link: no second buffer, no copy
+        // engine; anything else gets the deltas compacted in HBM and copied
+        void *d_host = nullptr;
+        if (hipHostGetDevicePointer(&d_host, h_enc, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            d_host = nullptr;
+        }
+        if (!d_host)
+            CHK(ensure(c, c->l2.d_compact, tot, c->stream2));
         hipLaunchKernelGGL(gather_bytes_kernel, dim3(grid_for(n, 1, 8192)), dim3(256), 0, c->stream2, (const uint8_t *)c->l2.d_scratch.p,
                            (const SegDesc *)c->l2.d_segs.p, (const uint32_t *)c->l2.d_resv.p, (const uint64_t *)c->l2.d_dstoff.p, n,
-                           (uint8_t *)c->l2.d_compact.p);
+                           d_host ? (uint8_t *)d_host : (uint8_t *)c->l2.d_compact.p);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(h_enc, c->l2.d_compact.p, tot, hipMemcpyDeviceToHost, c->stream2));
+        if (!d_host)
+            HIPCHK(c, hipMemcpyAsync(h_enc, c->l2.d_compact.p, tot, hipMemcpyDeviceToHost, c->stream2));
+        LAP("queued");
         HIPCHK(c, hipStreamSynchronize(c->stream2));
+        LAP("deltas on the host");
     }
     c->l2.pending = false;
     return AGC_HIP_OK;
@@ -1805,7 +1868,7 @@ static int lz_split_point_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid
     }
     CHK(ensure(c, c->d_jobs, (size_t)n * sizeof(SplitJob)));
     CHK(ensure(c, c->d_dstoff, (size_t)n * 8));
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs.p, jobs.data(), (size_t)n * sizeof(SplitJob), hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_jobs.p, jobs.data(), (size_t)n * sizeof(SplitJob), c->stream));
     uint32_t *d_pos = (uint32_t *)c->d_dstoff.p, *d_sum = d_pos + n;
     {
         KTimer t(c, AGC_HIP_K_COSTVEC);
@@ -1839,7 +1902,7 @@ static int fetch_slices_impl(agc_hip_ctx *c, uint32_t n, const PackedSrc &src, c
     for (uint32_t i = 0; i < n; ++i)
         sl[i] = {{src.words, src.esc_index, src.esc_bytes, h_off[i], h_len[i], h_rc ? (uint32_t)(h_rc[i] != 0) : 0u}, (uint8_t *)c->d_compact.p + h_out_off[i]};
     CHK(ensure(c, c->d_slices, (size_t)n * sizeof(ViewJob)));
-    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(ViewJob), hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_slices.p, sl.data(), (size_t)n * sizeof(ViewJob), c->stream));
     {
         KTimer t(c, AGC_HIP_K_REVCOMP);
         hipLaunchKernelGGL(slice_expand_kernel, dim3(grid_for(n, 1, 65536)), dim3(256), 0, c->stream, (const ViewJob *)c->d_slices.p, n);
@@ -1860,7 +1923,7 @@ static int ref_lag_counts_impl(agc_hip_ctx *c, uint32_t n, const PackedSrc &src,
         sl[i] = {{src.words, src.esc_index, src.esc_bytes, h_off[i], h_len[i], h_rc ? (uint32_t)(h_rc[i] != 0) : 0u}, nullptr};
     CHK(ensure(c, c->d_slices, (size_t)n * sizeof(ViewJob)));
     CHK(ensure(c, c->d_lag, (size_t)n * 28 * 4 * 2));
-    HIPCHK(c, hipMemcpyAsync(c->d_slices.p, sl.data(), (size_t)n * sizeof(ViewJob), hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->d_slices.p, sl.data(), (size_t)n * sizeof(ViewJob), c->stream));
     uint32_t *d_cnt = (uint32_t *)c->d_lag.p, *d_cur = d_cnt + (size_t)n * 28;
     const uint32_t split = n >= 2048 ? 1u : std::min<uint32_t>(32u, 2048u / n);
     HIPCHK(c, hipMemsetAsync(c->d_lag.p, 0, (size_t)n * 28 * 4 * 2, c->stream));

@@ -44,13 +44,109 @@ struct SegCounts { // device counters of one call
     unsigned long long enc_cap; // bytes of encode scratch the known segments take
 };
 
-// ---- 1. sort keys ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) hit_keys_kernel(const ScanHit *__restrict__ hits, uint32_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+// ---- small device-wide primitives.  The lists here hold a few ten thousand entries: one block scans them in microseconds, and
+// a library call (size query + launch, each asking the runtime for the device's properties) costs more host time than that.
+__device__ __forceinline__ uint32_t shfl_up_t(uint32_t v, uint32_t d) { return __shfl_up(v, d); }
+__device__ __forceinline__ unsigned long long shfl_up_t(unsigned long long v, uint32_t d)
+{
+    const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// out[i] = in[0] + ... + in[i - 1] for i < n (one block of 1024 threads, 8 entries per thread and trip)
+template <typename T> __global__ void __launch_bounds__(1024) scan_excl_kernel(const T *__restrict__ in, T *__restrict__ out, uint32_t n)
+{
+    constexpr uint32_t PER = 8;
+    __shared__ T wave_tot[16];
+    __shared__ T carry;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024 * PER) {
+        const uint32_t i0 = base + threadIdx.x * PER;
+        T v[PER], tsum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            v[j] = i0 + j < n ? in[i0 + j] : (T)0;
+            tsum += v[j];
+        }
+        T x = tsum; // inclusive scan over the wave
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const T y = shfl_up_t(x, o);
+            if (lane >= o)
+                x += y;
+        }
+        if (lane == 63)
+            wave_tot[w] = x;
+        __syncthreads();
+        if (w == 0) {
+            const T t = lane < 16 ? wave_tot[lane] : (T)0;
+            T e = t;
+            for (uint32_t o = 1; o < 16; o <<= 1) {
+                const T y = shfl_up_t(e, o);
+                if (lane >= o)
+                    e += y;
+            }
+            if (lane < 16)
+                wave_tot[lane] = e - t; // exclusive
+        }
+        __syncthreads();
+        T run = carry + wave_tot[w] + (x - tsum);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            if (i0 + j < n)
+                out[i0 + j] = run;
+            run += v[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry = run;
+        __syncthreads();
+    }
+}
+
+// ---- 1. the hits in position order.  The scan kernel appends hits as its waves find them.  Positions of splitter hits spread
+// over the sample, so a counting sort into about n / 2 position buckets leaves a handful per bucket, which one thread orders:
+// count -> exclusive scan -> scatter -> per-bucket insertion sort (a degenerate input -- every hit in a few buckets -- is slower,
+// never wrong).
+__global__ void __launch_bounds__(256) hb_count_kernel(const ScanHit *__restrict__ hits, uint32_t n, uint64_t base, uint32_t sh, uint32_t *__restrict__ cnt)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n)
+        atomicAdd(&cnt[(hits[j].pos - base) >> sh], 1u);
+}
+
+__global__ void __launch_bounds__(256) hb_scatter_kernel(const ScanHit *__restrict__ hits, uint32_t n, uint64_t base, uint32_t sh, const uint32_t *__restrict__ bstart,
+                                                         uint32_t *__restrict__ cur, uint64_t *__restrict__ pos, uint32_t *__restrict__ order)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
-        keys[j] = hits[j].pos;
-        vals[j] = j;
+        const uint64_t p = hits[j].pos;
+        const uint32_t b = (uint32_t)((p - base) >> sh);
+        const uint32_t slot = bstart[b] + atomicAdd(&cur[b], 1u);
+        pos[slot] = p;
+        order[slot] = j;
+    }
+}
+
+__global__ void __launch_bounds__(256) hb_sort_kernel(const uint32_t *__restrict__ bstart, uint32_t n_buckets, uint64_t *__restrict__ pos, uint32_t *__restrict__ order)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets)
+        return;
+    const uint32_t lo = bstart[b], hi = bstart[b + 1];
+    for (uint32_t i = lo + 1; i < hi; ++i) {
+        const uint64_t p = pos[i];
+        const uint32_t o = order[i];
+        uint32_t t = i;
+        while (t > lo && pos[t - 1] > p) {
+            pos[t] = pos[t - 1];
+            order[t] = order[t - 1];
+            --t;
+        }
+        pos[t] = p;
+        order[t] = o;
     }
 }
 
@@ -306,7 +402,7 @@ __global__ void __launch_bounds__(1024) group_lookup_kernel(const GroupSlot *__r
 }
 
 // ---- 7. encode descriptors of the segments whose group is known (and has its reference in HBM).  flag / cap hold n_ub + 1
-// entries (the last one 0) so that their exclusive scans end in the totals; sort keys ~len give the longest-first order.
+// entries (the last one 0) so that their exclusive scans end in the totals.
 __global__ void __launch_bounds__(256) known_flag_kernel(const DevSeg *__restrict__ segs, const SegCounts *__restrict__ counts, const RefDesc *__restrict__ refs,
                                                          uint32_t n_refs, uint32_t n_ub, uint32_t *__restrict__ flag, unsigned long long *__restrict__ cap)
 {
@@ -328,8 +424,7 @@ __global__ void __launch_bounds__(256) known_flag_kernel(const DevSeg *__restric
 
 __global__ void __launch_bounds__(256) known_emit_kernel(DevSeg *__restrict__ segs, SegCounts *__restrict__ counts, const uint32_t *__restrict__ flag,
                                                          const uint32_t *__restrict__ known_rank, const unsigned long long *__restrict__ cap_off, uint32_t n_ub,
-                                                         PackedView pv, const uint64_t *__restrict__ ctg_off, SegDesc *__restrict__ descs,
-                                                         uint32_t *__restrict__ sort_key, uint32_t *__restrict__ sort_val)
+                                                         PackedView pv, const uint64_t *__restrict__ ctg_off, SegDesc *__restrict__ descs)
 {
     const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
     if (si == 0) { // the totals
@@ -349,18 +444,34 @@ __global__ void __launch_bounds__(256) known_emit_kernel(DevSeg *__restrict__ se
     d.idx = r;
     d.pad = 0;
     descs[r] = d;
-    sort_key[r] = ~s.len; // (slots beyond the known segments keep the 0xFFFFFFFF they were preset to: they sort last)
-    sort_val[r] = r;
     segs[si].encoded = 1;
 }
 
-// descriptors in processing order (longest first): out[p] = descs[order[p]]; slots beyond n_known are never read
-__global__ void __launch_bounds__(256) known_order_kernel(const SegDesc *__restrict__ descs, const uint32_t *__restrict__ order, const SegCounts *__restrict__ counts,
-                                                          SegDesc *__restrict__ out)
+// descriptors in processing order: longest first, to the bucket of LEN_BUCKET symbols (the order only decides which waves start
+// first -- the long segments, so that the short ones fill the tail of the launch; results are indexed by SegDesc::idx)
+constexpr uint32_t LEN_BUCKET_SHIFT = 8, LEN_BUCKETS = 8192;
+__device__ __forceinline__ uint32_t len_bucket(uint32_t len)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < counts->n_known)
-        out[p] = descs[order[p]];
+    const uint32_t b = len >> LEN_BUCKET_SHIFT;
+    return LEN_BUCKETS - 1 - (b < LEN_BUCKETS ? b : LEN_BUCKETS - 1); // bucket 0 = the longest
+}
+
+__global__ void __launch_bounds__(256) known_len_count_kernel(const SegDesc *__restrict__ descs, const SegCounts *__restrict__ counts, uint32_t *__restrict__ cnt)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < counts->n_known)
+        atomicAdd(&cnt[len_bucket(descs[r].text.len)], 1u);
+}
+
+__global__ void __launch_bounds__(256) known_order_kernel(const SegDesc *__restrict__ descs, const SegCounts *__restrict__ counts, const uint32_t *__restrict__ bstart,
+                                                          uint32_t *__restrict__ cur, SegDesc *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < counts->n_known) {
+        const SegDesc d = descs[r];
+        const uint32_t b = len_bucket(d.text.len);
+        out[bstart[b] + atomicAdd(&cur[b], 1u)] = d;
+    }
 }
 
 } // namespace agc

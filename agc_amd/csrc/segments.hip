@@ -98,7 +98,6 @@ static int launch_known(agc_hip_ctx *c)
     uint32_t *flag = (uint32_t *)S.flag, *known_rank = (uint32_t *)S.known_rank;
     unsigned long long *capv = (unsigned long long *)S.capv, *cap_off = (unsigned long long *)S.cap_off;
     SegDesc *descs = (SegDesc *)S.descs;
-    uint32_t *skey0 = (uint32_t *)S.skey0, *skey1 = (uint32_t *)S.skey1, *sval0 = (uint32_t *)S.sval0, *sval1 = (uint32_t *)S.sval1;
     CHK(upload_refs(c));
     const size_t scratch_ub = (size_t)(S.total + 5 * S.total / 16) + 96 * (size_t)n_ub + 64;
     CHK(ensure(c, c->l2.d_segs, (size_t)n_ub * sizeof(SegDesc), c->stream2));
@@ -115,26 +114,17 @@ static int launch_known(agc_hip_ctx *c)
     }
     hipLaunchKernelGGL(known_flag_kernel, dim3((n_ub + 256) / 256), dim3(256), 0, st, segs, counts, (const RefDesc *)c->d_refs.p, (uint32_t)c->refs.size(), n_ub, flag,
                        capv);
-    size_t tb = 0, tb2 = 0;
-    if (rocprim::exclusive_scan(nullptr, tb, flag, known_rank, 0u, (size_t)n_ub + 1, rocprim::plus<uint32_t>(), st) != hipSuccess ||
-        rocprim::exclusive_scan(nullptr, tb2, capv, cap_off, 0ull, (size_t)n_ub + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess)
-        return AGC_HIP_ENODEV;
-    CHK(ensure(c, c->d_segtmp, std::max(tb, tb2) + 256));
-    if (rocprim::exclusive_scan(c->d_segtmp.p, tb, flag, known_rank, 0u, (size_t)n_ub + 1, rocprim::plus<uint32_t>(), st) != hipSuccess ||
-        rocprim::exclusive_scan(c->d_segtmp.p, tb2, capv, cap_off, 0ull, (size_t)n_ub + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess)
-        return AGC_HIP_ENODEV;
-    HIPCHK(c, hipMemsetAsync(skey0, 0xFF, (size_t)n_ub * 4, st));
+    hipLaunchKernelGGL(scan_excl_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, flag, known_rank, n_ub + 1);
+    hipLaunchKernelGGL(scan_excl_kernel<unsigned long long>, dim3(1), dim3(1024), 0, st, capv, cap_off, n_ub + 1);
     const PackedView pv = {S.pk.d_words, S.pk.d_esc_index, S.pk.d_esc_bytes, S.pk.n_symbols};
     hipLaunchKernelGGL(known_emit_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, segs, counts, flag, known_rank, cap_off, n_ub, pv, (const uint64_t *)S.d_ctg_off,
-                       descs, skey0, sval0);
-    rocprim::double_buffer<uint32_t> sk(skey0, skey1), sv(sval0, sval1);
-    tb = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tb, sk, sv, (size_t)n_ub, 0, 32, st) != hipSuccess)
-        return AGC_HIP_ENODEV;
-    CHK(ensure(c, c->d_segtmp, tb + 256));
-    if (rocprim::radix_sort_pairs(c->d_segtmp.p, tb, sk, sv, (size_t)n_ub, 0, 32, st) != hipSuccess)
-        return AGC_HIP_ENODEV;
-    hipLaunchKernelGGL(known_order_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, descs, sv.current(), counts, (SegDesc *)c->l2.d_segs.p);
+                       descs);
+    // longest first (to the length bucket): count, scan, scatter
+    uint32_t *lcnt = (uint32_t *)S.lcnt, *lstart = lcnt + (LEN_BUCKETS + 1), *lcur = lstart + (LEN_BUCKETS + 1);
+    HIPCHK(c, hipMemsetAsync(lcnt, 0, (size_t)(3 * (LEN_BUCKETS + 1)) * 4, st));
+    hipLaunchKernelGGL(known_len_count_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, descs, counts, lcnt);
+    hipLaunchKernelGGL(scan_excl_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, lcnt, lstart, LEN_BUCKETS + 1);
+    hipLaunchKernelGGL(known_order_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, descs, counts, lstart, lcur, (SegDesc *)c->l2.d_segs.p);
     HIPCHK(c, hipGetLastError());
     // the parse on the second lane, behind everything queued here
     HIPCHK(c, hipEventRecord(c->l2.ready, st));
@@ -243,17 +233,14 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         take_(&S.known_rank, ((size_t)n_ub + 1) * 4);
         take_(&S.cap_off, ((size_t)n_ub + 1) * 8);
         take_(&S.descs, (size_t)n_ub * sizeof(SegDesc));
-        take_(&S.skey0, (size_t)n_ub * 4);
-        take_(&S.skey1, (size_t)n_ub * 4);
-        take_(&S.sval0, (size_t)n_ub * 4);
-        take_(&S.sval1, (size_t)n_ub * 4);
+        take_(&S.lcnt, (size_t)(3 * (LEN_BUCKETS + 1)) * 4);
         return (size_t)(p - p0);
     };
     const size_t fixed_bytes = layout(nullptr, false);
     size_t hit_bytes = 0;
     {
         uint8_t *p = nullptr;
-        carve<uint64_t>(p, n), carve<uint64_t>(p, n), carve<uint32_t>(p, n), carve<uint32_t>(p, n);                 // sort buffers of the hits
+        carve<uint64_t>(p, n), carve<uint32_t>(p, n), carve<uint32_t>(p, 3 * ((size_t)2 * n + 1030));                 // sorted hits, the sort's buckets
         carve<uint32_t>(p, n), carve<uint32_t>(p, (size_t)n + 1), carve<uint32_t>(p, (size_t)n + 1), carve<uint32_t>(p, n); // ctg, take, acc_rank, acc_idx
         carve<uint32_t>(p, (size_t)n_ctg + 1), carve<uint32_t>(p, (size_t)n_ctg + 1);
         hit_bytes = (size_t)(p - (uint8_t *)nullptr);
@@ -262,42 +249,40 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
     layout((uint8_t *)c->d_segwork.p, true);
     agc_hip_ctx::SegState &S = c->seg_state;
     uint8_t *p = (uint8_t *)c->d_segwork.p + fixed_bytes;
-    uint64_t *keys0 = carve<uint64_t>(p, n), *keys1 = carve<uint64_t>(p, n);
-    uint32_t *vals0 = carve<uint32_t>(p, n), *vals1 = carve<uint32_t>(p, n);
+    uint64_t *keys0 = carve<uint64_t>(p, n);
+    uint32_t *vals0 = carve<uint32_t>(p, n), *bwork = carve<uint32_t>(p, 3 * ((size_t)2 * n + 1030));
     uint32_t *ctg = carve<uint32_t>(p, n), *take = carve<uint32_t>(p, (size_t)n + 1), *acc_rank = carve<uint32_t>(p, (size_t)n + 1), *acc_idx = carve<uint32_t>(p, n);
     uint32_t *hits_before = carve<uint32_t>(p, (size_t)n_ctg + 1), *tails_before = carve<uint32_t>(p, (size_t)n_ctg + 1);
     DevSeg *segs = (DevSeg *)S.segs;
     SegCounts *counts = (SegCounts *)S.counts;
     uint64_t *d_ctg_off = (uint64_t *)S.d_ctg_off;
     const hipStream_t st = c->stream;
-    auto tmp_for = [&](size_t bytes) -> int { return ensure(c, c->d_segtmp, bytes + 256); };
 
-    HIPCHK(c, hipMemcpyAsync(d_ctg_off, h_ctg_off, ((size_t)n_ctg + 1) * 8, hipMemcpyHostToDevice, st));
+    CHK(upload(c, d_ctg_off, h_ctg_off, ((size_t)n_ctg + 1) * 8, st));
     HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(SegCounts), st));
     const uint64_t *pos_sorted = keys0;
     const uint32_t *order = vals0;
     KTimer tm(c, AGC_HIP_K_SEGMENTS);
     if (n) {
-        hipLaunchKernelGGL(hit_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_hits, n, keys0, vals0);
-        rocprim::double_buffer<uint64_t> dk(keys0, keys1);
-        rocprim::double_buffer<uint32_t> dv(vals0, vals1);
-        size_t tb = 0;
-        // (positions lie below 2^40: five 8-bit passes)
-        if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, (size_t)n, 0, 40, st) != hipSuccess)
-            return AGC_HIP_ENODEV;
-        CHK(tmp_for(tb));
-        if (rocprim::radix_sort_pairs(c->d_segtmp.p, tb, dk, dv, (size_t)n, 0, 40, st) != hipSuccess)
-            return AGC_HIP_ENODEV;
-        pos_sorted = dk.current();
-        order = dv.current();
+        // position order: counting sort into ~n / 2 position buckets, a handful of hits each (seg_kernels.hip)
+        const uint64_t base = h_ctg_off[0], span = h_ctg_off[n_ctg] - base;
+        uint64_t nb_target = 1024;
+        while (nb_target < n / 2)
+            nb_target <<= 1;
+        uint32_t sh = 0;
+        while ((span >> sh) >= nb_target)
+            ++sh;
+        const uint32_t n_buckets = (uint32_t)(span >> sh) + 1; // <= nb_target <= max(1024, n)
+        uint32_t *bcnt = bwork, *bstart = bwork + ((size_t)2 * n + 1030), *bcur = bstart + ((size_t)2 * n + 1030);
+        HIPCHK(c, hipMemsetAsync(bcnt, 0, ((size_t)n_buckets + 1) * 4, st));
+        HIPCHK(c, hipMemsetAsync(bcur, 0, ((size_t)n_buckets + 1) * 4, st));
+        hipLaunchKernelGGL(hb_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_hits, n, base, sh, bcnt);
+        hipLaunchKernelGGL(scan_excl_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, bcnt, bstart, n_buckets + 1);
+        hipLaunchKernelGGL(hb_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_hits, n, base, sh, bstart, bcur, keys0, vals0);
+        hipLaunchKernelGGL(hb_sort_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, st, bstart, n_buckets, keys0, vals0);
         hipLaunchKernelGGL(hit_contig_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pos_sorted, n, d_ctg_off, n_ctg, ctg);
         hipLaunchKernelGGL(hit_accept_kernel, dim3((n + 256) / 256), dim3(256), 0, st, pos_sorted, ctg, n, k, take);
-        tb = 0;
-        if (rocprim::exclusive_scan(nullptr, tb, take, acc_rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess)
-            return AGC_HIP_ENODEV;
-        CHK(tmp_for(tb));
-        if (rocprim::exclusive_scan(c->d_segtmp.p, tb, take, acc_rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess)
-            return AGC_HIP_ENODEV;
+        hipLaunchKernelGGL(scan_excl_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, take, acc_rank, n + 1);
         hipLaunchKernelGGL(hit_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, st, take, acc_rank, n, acc_idx);
     }
     hipLaunchKernelGGL(contig_sums_kernel, dim3(1), dim3(1024), 0, st, d_ctg_off, n_ctg, k, pos_sorted, ctg, acc_idx, acc_rank, n, hits_before, tails_before, counts);
