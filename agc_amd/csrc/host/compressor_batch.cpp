@@ -296,7 +296,10 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         // references: only when there are many of them (the reference sample), tuple-packed here (bytes2tuples is a byte loop)
         size_t n_refs = 0;
         for (const ZJob &j : jobs)
-            n_refs += j.kind == 0 && !j.data.empty();
+            n_refs += j.kind == 0 && !j.data.empty() && j.data.size() <= 65536; // (tuple-packed: <= 16 KiB, the lane-group kernel's class)
+        // references: to the device when a call brings many of the size a group of lanes codes (the reference sample of a
+        // collection with the default segment size); the few long ones -- contigs without a splitter, -s in the hundreds of kb:
+        // level 13 above 16 KiB is the one-lane kernel, a launch as long as its longest frame -- stay with the host pool
         const bool refs_too = gpu_zstd && gpu_zstd_refs_min && n_refs >= gpu_zstd_refs_min;
         if (refs_too)
             zpool->parallel_for(jobs.size(), [&](size_t i, unsigned) {
@@ -316,14 +319,31 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         for (uint32_t i = 0; i < jobs.size(); ++i) {
             const ZJob &j = jobs[i];
             const size_t src_n = j.staged.empty() ? j.data.size() : j.staged.size();
-            if (gpu_zstd && !j.data.empty() && src_n <= dev_max && (j.kind == 1 || (j.kind == 0 && refs_too)))
+            if (gpu_zstd && !j.data.empty() && src_n <= dev_max && (j.kind == 1 || (j.kind == 0 && refs_too && src_n <= 16384)))
                 dev_jobs.push_back(i);
             else
                 host_jobs.push_back(i);
         }
     }
+    // A launch lasts about as long as the serial chain of its longest frame however few frames it has (measured: ~48 us per input
+    // byte for the two-pass class <= 16 KiB, ~24 us beyond, a third of that for level 13), while the host pool finishes a small
+    // batch in bytes / (threads x ~5 MB/s): the device only takes a batch the pool would need longer for than that.
+    bool dev_pays = true;
+    if (!ext && !dev_jobs.empty() && !getenv("AGC_AMD_GPU_ZSTD_SHARE") && gpu_zstd_min > 1) {
+        uint64_t tot = 0;
+        double longest = 0;
+        for (uint32_t i : dev_jobs) {
+            const uint64_t sz = jobs[i].staged.empty() ? jobs[i].data.size() : jobs[i].staged.size();
+            tot += sz;
+            double t = (sz <= 16384 ? 48e-6 : 24e-6) * (double)sz;
+            if (jobs[i].kind == 0 && jobs[i].level == 13)
+                t *= 0.3;
+            longest = std::max(longest, t);
+        }
+        dev_pays = (double)tot / ((double)zpool->size() * 5e6) > longest;
+    }
     if (ext) {
-    } else if (dev_jobs.size() < gpu_zstd_min) { // not worth a launch
+    } else if (dev_jobs.size() < gpu_zstd_min || !dev_pays) { // not worth a launch
         host_jobs.insert(host_jobs.end(), dev_jobs.begin(), dev_jobs.end());
         std::sort(host_jobs.begin(), host_jobs.end());
         dev_jobs.clear();
@@ -460,7 +480,8 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     uint64_t all_bytes = 0;
     for (const ZJob &j : jobs)
         all_bytes += j.data.size();
-    const unsigned host_workers = all_bytes < (64u << 20) ? std::max(2u, zpool->size() / 4) : zpool->size();
+    // (... when that thread has human-size samples to drive; a collection of small genomes leaves it idle most of the time)
+    const unsigned host_workers = all_bytes < (64u << 20) && heavy_steps && !z_caller_waits.load() ? std::max(2u, zpool->size() / 4) : zpool->size();
     zpool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
         ZJob &j = jobs[host_jobs[hi]];
         ZstdCtx &z = *zctx[tid];
@@ -672,6 +693,12 @@ bool CAGCCompressor::Impl::batch_prepare(BatchState &b, std::vector<Contig> &ctg
     b.n_ctg = (uint32_t)ctgs.size();
     b.base_owned = next_base_owned;
     b.pk = packed_sample; // (n_symbols != 0: the LZ entry points read the sample's 2-bit words where they lie)
+    {
+        uint64_t bases = 0;
+        for (const Contig &ct : ctgs)
+            bases += ct.len;
+        heavy_steps = bases >= 100000000ull; // (what the entropy thread sizes its share of the host pool by)
+    }
     b.t0 = now();
     b.dev0 = st.t_device;
     b.lap_t = b.t0;

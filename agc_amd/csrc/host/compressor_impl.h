@@ -768,6 +768,7 @@ struct CAGCCompressor::Impl {
     bool z_busy = false, z_stop = false;
     std::atomic<bool> z_caller_waits{false}; // the caller stands still for the stage (Close, Drain): its launches may take the LDS
     bool sync_entropy = false;
+    std::atomic<bool> heavy_steps{false};    // the windows being driven are human-size: the entropy thread takes a quarter of the pool for small batches
     size_t par_min = 4096; // lists shorter than this are walked by the calling thread (AGC_AMD_PAR_MIN: tests force the pool paths)
     void z_submit(std::vector<ZJob> &&jobs);
     void z_wait_all();
@@ -976,11 +977,11 @@ struct CAGCCompressor::Impl {
     // ratio measured on MI355X + 16 host threads (0.7 GB/s against 0.1 GB/s), every call with real work on both sides updates it
     double gpu_zstd_share = 0.88;
     uint32_t gpu_zstd_min = 64;        // fewer packs than this in one call stay on the host (AGC_AMD_GPU_ZSTD_MIN)
-    // references (level 13 on their tuples, level 19 for repetitive ones) on the device too when a call brings at least this many
-    // (AGC_AMD_GPU_ZSTD_REFS=512: the reference sample's ~50 k references take 0.41 s instead of 0.95 s on 16 host threads).
-    // 0 = never, the default: the path is parity-tested frame by frame (CPU build, GPU kernels, whole archives on the stand-in)
-    // but no full-size archive has been compared with the reference CLI's with it on yet
-    uint32_t gpu_zstd_refs_min = 0;
+    // references (level 13 on their tuples, level 19 for repetitive ones) on the device too when a call brings at least this many:
+    // the reference sample's ~50 k references take 0.41 s instead of 0.95 s on 16 host threads.  On since round 4: configs[2] at
+    // full size with 5 samples is byte-identical to the reference CLI's archive with it (profiles/r4/c3_full_size_identity_5_samples_
+    // refs_on_device.log: 741 MB of the 3.2 GB of entropy input on the device).  AGC_AMD_GPU_ZSTD_REFS=0 keeps them on the host pool.
+    uint32_t gpu_zstd_refs_min = 512;
     PinnedBytes zsrc_buf, zdst_buf;    // staging of the device entropy stage (plain malloc: no zero fill of hundreds of MB)
     bool defer_stream_reg = false;     // parallel bookkeeping: pack jobs leave a missing delta stream to the merging thread
     bool minted_since_prepare = false; // a group of any key (also one-sided) was minted while a sample was prepared

@@ -59,6 +59,25 @@ def test_archive_with_the_encode_on_the_second_stream(name, mode, tmp_path, monk
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"], r.stderr[-1500:]
 
 
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_c3_twin", "syn_c4_twin"])
+def test_archive_with_every_reference_on_the_device_entropy_stage(name, tmp_path, monkeypatch):
+    """AGC_AMD_GPU_ZSTD_REFS=1: every call that brings a reference hands it to the device encoder (levels 13 on the tuple-packed
+    symbols / 19 for repetitive ones, agc_hip_zstd_batch) -- the default only does so for calls with 512 references and more, which
+    these small collections never bring -- and AGC_AMD_GPU_ZSTD_MIN=1 sends every delta pack there too: the archive must still be
+    the reference CLI's."""
+    from agc_amd import build
+    build.build_host()
+    monkeypatch.setenv("AGC_AMD_GPU_ZSTD_REFS", "1")
+    monkeypatch.setenv("AGC_AMD_GPU_ZSTD_MIN", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "amd.agc")
+    r = subprocess.run([AGC_AMD, "create"] + args + ["-t", "8", "-v", "1", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    assert os.path.exists(out), r.stderr[-2000:]
+    assert "entropy stage: device" in r.stderr, r.stderr[-1500:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"], r.stderr[-1500:]
+
+
 GOLD_APPEND = json.load(open(os.path.join(ROOT, "tests", "golden", "archives_append.json")))
 
 
