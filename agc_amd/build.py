@@ -15,7 +15,11 @@ class _Locked:
         import hashlib
         import tempfile
         self.f = open(os.path.join(tempfile.gettempdir(), "agc_amd_build_%s.lock" % hashlib.sha1(HERE.encode()).hexdigest()[:12]), "w")
-        fcntl.flock(self.f, fcntl.LOCK_EX)
+        try:
+            fcntl.flock(self.f, fcntl.LOCK_EX)
+        except BaseException:
+            self.f.close()
+            raise
 
     def __exit__(self, *a):
         import fcntl
@@ -65,10 +69,11 @@ def build_read(force=False, verbose=False):
     with _Locked():
         if not force and os.path.exists(READ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(READ_LIB) for d in deps):
             return READ_LIB
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB, "-ldl", "-pthread"]
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared"] + srcs + ["-o", READ_LIB + ".tmp", "-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(READ_LIB + ".tmp", READ_LIB)  # (never a half-written library under the final name)
         return READ_LIB
 
 
@@ -86,14 +91,19 @@ def build_host(force=False, verbose=False):
         os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
         cxx = os.environ.get("CXX", "g++")
         common = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
-        cmd1 = common + ["-shared"] + [os.path.join(HOST, s) for s in HOST_LIB_SOURCES] + ["-o", HOST_LIB,
-                         "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl"]
-        cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN, "-L" + HERE, "-lagc_host", "-lagc_hip",
+        # (linked under a temporary name and renamed: a process that only loads / executes never meets a half-written file)
+        cmd1 = common + ["-shared"] + [os.path.join(HOST, s) for s in HOST_LIB_SOURCES] + ["-o", HOST_LIB + ".tmp",
+                         "-L" + HERE, "-lagc_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-soname,libagc_host.so", "-lz", "-ldl"]
+        if verbose:
+            print(" ".join(cmd1), file=sys.stderr)
+        subprocess.check_call(cmd1)
+        os.replace(HOST_LIB + ".tmp", HOST_LIB)
+        cmd2 = common + [os.path.join(HOST, "main.cpp"), "-o", HOST_BIN + ".tmp", "-L" + HERE, "-lagc_host", "-lagc_hip",
                          "-Wl,-rpath,$ORIGIN/..", "-lz", "-ldl"]
-        for cmd in (cmd1, cmd2):
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+        if verbose:
+            print(" ".join(cmd2), file=sys.stderr)
+        subprocess.check_call(cmd2)
+        os.replace(HOST_BIN + ".tmp", HOST_BIN)
         return HOST_LIB
 
 

@@ -691,6 +691,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
     I.prep.base_owned = I.next_base_owned;
     I.prep.deferred = false;
     I.prep.spl_version = I.spl_version;
+    I.prep.st_before = I.st;
     I.prepared->no_new_splitters = ahead && I.adaptive;
     if (!I.batch_prepare(*I.prepared, I.prepared_ctgs, d_codes, nullptr, ahead)) {
         I.prepared.reset();
@@ -700,6 +701,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
         I.prepared.reset();
         I.prep.deferred = true;
     }
+    I.prep.st_after = I.st;
     return true;
 }
 
@@ -716,6 +718,16 @@ bool CAGCCompressor::CommitPreparedHead()
     if (I.dist_world > 1 && I.adaptive && (I.prep.deferred || (I.prepared && I.prep.spl_version != I.spl_version))) {
         // adaptive mode, the sample's turn: the speculative prepare did not stand (new splitters needed, or brought by the samples
         // in front) -- the plain prepare, against the state as it is now
+        // (what the dropped prepare counted -- bases, texts handed to the LZ kernels, deltas -- is taken back: the sample is
+        // counted once, by the prepare that stands)
+        if (I.prepared) {
+            const CompressorStats &a = I.prep.st_after, &b0 = I.prep.st_before;
+            for (uint64_t CompressorStats::*f : {&CompressorStats::bases, &CompressorStats::one_splitter, &CompressorStats::middle_tried,
+                                                 &CompressorStats::middle_split, &CompressorStats::lz_encoded, &CompressorStats::delta_bytes,
+                                                 &CompressorStats::enc_text, &CompressorStats::enc_ref, &CompressorStats::est_text, &CompressorStats::est_ref,
+                                                 &CompressorStats::cv_text, &CompressorStats::cv_ref, &CompressorStats::windows})
+                I.st.*f -= a.*f - b0.*f;
+        }
         ++I.st.reprepared;
         I.prepared.reset(new Impl::BatchState());
         I.changed_log.clear();

@@ -158,7 +158,7 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
 
 // The body: every delta item of the head, in the same order: u32 length + bytes.  ~22 MB per human-size sample, gathered by the
 // worker pool into pinned memory (its next stop is the writer's GPU or socket).
-void CAGCCompressor::Impl::make_record_body(const CommitData &cd)
+bool CAGCCompressor::Impl::make_record_body(const CommitData &cd)
 {
     const std::vector<Placed> &placed = *cd.placed;
     std::vector<uint32_t> pos_enc(placed.size());
@@ -171,7 +171,7 @@ void CAGCCompressor::Impl::make_record_body(const CommitData &cd)
     dist_body_n = 0;
     if (!dist_body_buf.resize(body_off[nb] + body_off[nb] / 8 + 64, false)) {
         err("out of memory (commit record)");
-        return;
+        return false;
     }
     uint8_t *const dst = dist_body_buf.data();
     auto copy_range = [&](size_t from, size_t to) {
@@ -189,6 +189,7 @@ void CAGCCompressor::Impl::make_record_body(const CommitData &cd)
     } else
         copy_range(0, nb);
     dist_body_n = body_off[nb];
+    return true;
 }
 
 // the record of a sample without contigs: nothing to register anywhere

@@ -959,6 +959,7 @@ struct CAGCCompressor::Impl {
         bool base_owned = false;
         bool deferred = false;      // no prepared state: prepare at the turn
         uint64_t spl_version = 0;   // splitter set the prepared state was scanned with
+        CompressorStats st_before, st_after; // the counters around the prepare (its share is taken back when the prepared state is dropped)
     } prep;
     uint64_t spl_version = 0;       // bumped whenever splitters are added (own samples, applied records)
     std::vector<Contig> prepared_ctgs;
@@ -1008,7 +1009,7 @@ struct CAGCCompressor::Impl {
     std::unique_ptr<PinnedBytes> body_recv; // handed out by RecordBodyBuffer, adopted by the next apply_record
     std::vector<uint32_t> dist_body_items; // the record's delta items (placed indices) in list order: head and body agree on it
     void make_record_head(BatchState &b);
-    void make_record_body(const CommitData &cd);
+    bool make_record_body(const CommitData &cd);
     void make_empty_record();
     bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n);
     void note_new_group(const pk_t &pk, uint32_t gid);

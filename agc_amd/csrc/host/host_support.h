@@ -630,11 +630,23 @@ public:
     // direct access for the compressor (avoids the linear contig search per segment)
     SampleDesc &sample_by_name(const std::string &stored) { return samples[sample_ids.at(stored)]; }
 
-    // store_contig_batch (collection_v3.cpp:660-680): names (zstd 18) then details (5 x zstd 19)
+    // store_contig_batch (collection_v3.cpp:660-680): names (zstd 18) then details (5 x zstd 19).  In two halves for a caller that
+    // shares the sample table with another thread: serialize_contig_batch reads (and clears) the samples' records -- short, under
+    // the caller's lock --, store_serialized_batch compresses (0.4 s at human scale) and adds the parts -- outside it.
+    struct SerializedBatch {
+        bytes_t names;
+        std::array<bytes_t, 5> details;
+    };
     void store_contig_batch(uint32_t id_from, uint32_t id_to)
     {
+        SerializedBatch sb;
+        serialize_contig_batch(id_from, id_to, sb);
+        store_serialized_batch(sb);
+    }
+    void serialize_contig_batch(uint32_t id_from, uint32_t id_to, SerializedBatch &sb)
+    {
         // ---- contig names, collection_v3.cpp:468-495
-        bytes_t v;
+        bytes_t &v = sb.names;
         app_num(v, id_to - id_from);
         for (uint32_t s = id_from; s < id_to; ++s) {
             app_num(v, (uint32_t)samples[s].contigs.size());
@@ -648,10 +660,8 @@ public:
                 prev = std::move(cur);
             }
         }
-        ar->add_part_buffered(id_contigs, zstd(v, 18), v.size());
-
         // ---- details, collection_v3.cpp:539-586 + 230-267
-        std::array<bytes_t, 5> d;
+        std::array<bytes_t, 5> &d = sb.details;
         app_num(d[0], id_to - id_from);
         in_group_ids.clear();
         auto get_igid = [&](uint32_t pos) -> int { return pos >= in_group_ids.size() ? -1 : in_group_ids[pos]; };
@@ -685,6 +695,15 @@ public:
                 }
             }
         }
+        for (uint32_t s = id_from; s < id_to; ++s) {
+            samples[s].contigs.clear();
+            samples[s].contigs.shrink_to_fit();
+        }
+    }
+    void store_serialized_batch(SerializedBatch &sb)
+    {
+        ar->add_part_buffered(id_contigs, zstd(sb.names, 18), sb.names.size());
+        std::array<bytes_t, 5> &d = sb.details;
         std::array<bytes_t, 5> pk;
         for (int i = 0; i < 5; ++i)
             pk[i] = zstd(d[i], 19);
@@ -696,11 +715,6 @@ public:
         for (int i = 0; i < 5; ++i)
             stream.insert(stream.end(), pk[i].begin(), pk[i].end());
         ar->add_part_buffered(id_details, std::move(stream), 0);
-
-        for (uint32_t s = id_from; s < id_to; ++s) {
-            samples[s].contigs.clear();
-            samples[s].contigs.shrink_to_fit();
-        }
     }
     // complete_serialization -> store_batch_sample_names (collection_v3.cpp:122-165, 329-335)
     void complete_serialization()

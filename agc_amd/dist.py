@@ -46,6 +46,45 @@ class DistCompressor:
         # order-dependent half up to the record's head), head (head size + head broadcast), finish (the owner's rest: new references
         # indexed, leftover deltas, the body), body (finish + delta body to the writer), apply (the other ranks' records applied here)
         self.seconds = {"prepare": 0.0, "commit": 0.0, "head": 0.0, "finish": 0.0, "body": 0.0, "apply": 0.0}
+        self._check_placement()
+        self.warm_up()
+
+    def _check_placement(self):
+        """one process per GPU: a world larger than the visible devices (or two ranks on one device) is a launch mistake that RCCL
+        reports as a hang or an obscure error much later -- said here, clearly, before the first collective"""
+        if self.hbm is None or self.dist.get_backend() != "nccl":
+            return
+        n_dev = self.torch.cuda.device_count()
+        if self.world > n_dev:
+            raise RuntimeError(f"{self.world} ranks but only {n_dev} visible GPU(s): the RCCL mode runs one process per GPU "
+                               f"(AGC_BENCH_ONE_GPU=1 with the gloo backend shares one device for functional runs)")
+        mine = self.torch.tensor([self.hbm.index if self.hbm.index is not None else self.torch.cuda.current_device()], dtype=self.torch.int64, device=self.comm)
+        every = [self.torch.zeros(1, dtype=self.torch.int64, device=self.comm) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        devs = [int(x[0]) for x in every]
+        if len(set(devs)) != len(devs):
+            raise RuntimeError(f"ranks share a GPU under the nccl backend: devices per rank {devs}")
+
+    def warm_up(self):
+        """every communication pattern of the run once, with a few bytes: a broadcast from every rank (the record heads), a
+        point-to-point message from every rank to the writer (the record bodies; RCCL sets a pair's channel up on its first use --
+        seconds, which would otherwise land in the first timed sample of that pair), an all_gather and a gather (Close)"""
+        torch, dist = self.torch, self.dist
+        t = torch.zeros(8, dtype=torch.uint8, device=self.comm)
+        for src in range(self.world):
+            dist.broadcast(t, src=src)
+        for r in range(self.world):
+            if r == self.writer:
+                continue
+            if self.rank == r:
+                dist.send(t, dst=self.writer)
+            elif self.rank == self.writer:
+                dist.recv(t, src=r)
+        dist.all_gather([torch.zeros(8, dtype=torch.uint8, device=self.comm) for _ in range(self.world)], t)
+        dist.gather(t, [torch.zeros(8, dtype=torch.uint8, device=self.comm) for _ in range(self.world)] if self.rank == self.writer else None,
+                    dst=self.writer)
+        if self.comm.type == "cuda":
+            torch.cuda.synchronize(self.comm)
 
     def owner_of(self, i):
         return i % self.world
@@ -197,19 +236,27 @@ class DistCompressor:
         t1 = time.perf_counter()
         b_view, bsize = None, 0
         if self.rank == owner:
+            failure = None
             if callable(body):
                 tf = time.perf_counter()
-                body = body()
+                try:
+                    body = body()
+                except Exception as e:  # the writer waits for a size: it gets one that says "the owner failed", then everybody stops
+                    failure, body = e, None
                 self.seconds["finish"] += time.perf_counter() - tf
             if owner != self.writer:
-                bsize = int(body.size)
+                bsize = int(body.size) if failure is None else -1
                 dist.send(torch.tensor([bsize], dtype=torch.int64, device=self.comm), dst=self.writer)
-                if bsize:
+                if bsize > 0:
                     dist.send(torch.from_numpy(body).to(self.comm), dst=self.writer)
+            if failure is not None:
+                raise failure
         elif self.rank == self.writer:
             nb = torch.zeros(1, dtype=torch.int64, device=self.comm)
             dist.recv(nb, src=owner)
             bsize = int(nb[0])
+            if bsize < 0:
+                raise RuntimeError(f"rank {owner} failed while finishing the commit of sample {self.next_sample - 1} (its message is on its stderr)")
             if bsize:
                 # straight into the pinned buffer the bookkeeping will read (no staging copy on the host)
                 b_view = self.cmp.record_body_buffer(bsize)

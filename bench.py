@@ -368,11 +368,17 @@ def main():
     # AGC_BENCH_ONE_GPU=1 (testing aid, a box with one GPU): every rank on cuda:0, records over gloo -- the N > 1 code path of
     # this file end to end on real kernels; the driver's runs use one GPU per rank and RCCL
     one_gpu = world > 1 and os.environ.get("AGC_BENCH_ONE_GPU") == "1"
+    import datetime
+    # (a collective that does not complete in ten minutes is a rank that died or a launch that does not match the node: the job
+    # stops with RCCL's message instead of hanging until the driver's limit)
     if one_gpu:
         local = 0
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
     elif world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if world > torch.cuda.device_count() or local >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py --gpus {world}: {torch.cuda.device_count()} GPU(s) visible to rank {rank} (LOCAL_RANK {local}); one process per GPU "
+                             "(AGC_BENCH_ONE_GPU=1 runs all ranks on cuda:0 over gloo for a functional check)")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), timeout=datetime.timedelta(seconds=600))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     red_dev = torch.device("cpu") if one_gpu else dev  # where the small reductions of the timings live
