@@ -1428,6 +1428,13 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
             std::memcpy(order.data(), src, (size_t)n * 4);
     }
     LAP("sort");
+    if (laps && mode == MODE_COSTVEC && n) {
+        uint64_t tot = 0;
+        for (uint32_t i = 0; i < n; ++i)
+            tot += h_len[i];
+        fprintf(stderr, "    cost-vector batch: %u parses, %.1f Mb of text, longest %u %u %u %u, median %u\n", n, tot / 1e6, h_len[order[0]], h_len[order[n > 1 ? 1 : 0]],
+                h_len[order[n > 2 ? 2 : 0]], h_len[order[n > 3 ? 3 : 0]], h_len[order[n / 2]]);
+    }
     std::vector<uint64_t> ooff(n);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < n; ++i) {

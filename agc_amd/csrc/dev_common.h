@@ -25,7 +25,11 @@ constexpr uint32_t MIN_NRUN_LEN = 4;     // lz_diff.h:36
 // for the estimate / cost-vector parses, whose texts are mostly literal runs (the non-matching half of a missing-middle
 // segment, wrong one-splitter candidates): the parse then skips from one candidate position to the next instead of probing
 // the index table in HBM at every position.
-constexpr uint32_t KEY_BLOOM_WORDS = 4096; // 32 KiB: 0.4 % false positives for the 15 k keys of a 60 kb reference
+// Two such filters with independent hashes, KEY_BLOOM_HALF words each (2 x 32 KiB): a key passes when both hold it.  One filter
+// lets 0.4 % of the foreign keys through for the 15 k keys of a 60 kb reference -- 240 exact steps (a table row from HBM each) in
+// the 60 kb of a missing-middle segment that belong to the OTHER reference, more than its matching half costs; two: 0.002 %.
+constexpr uint32_t KEY_BLOOM_HALF = 4096;
+constexpr uint32_t KEY_BLOOM_WORDS = 2 * KEY_BLOOM_HALF;
 __host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t &word, uint64_t &mask)
 {
     const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
@@ -34,6 +38,15 @@ __host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t &word, uin
     const uint32_t h2 = h1 * 0xC2B2AE35u;
     word = h1 >> 20; // 12 bits
     mask = (1ULL << (h2 >> 26)) | (1ULL << ((h2 >> 20) & 63)) | (1ULL << ((h2 >> 14) & 63));
+}
+__host__ __device__ inline void key_bloom_slot2(uint64_t key, uint32_t &word, uint64_t &mask)
+{
+    const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
+    uint32_t h1 = ((a * 0xCC9E2D51u) ^ (b + 0x7F4A7C15u)) * 0x1B873593u;
+    h1 ^= h1 >> 13;
+    const uint32_t h2 = h1 * 0x27D4EB2Fu;
+    word = KEY_BLOOM_HALF + (h1 >> 20);
+    mask = (1ULL << (h2 >> 26)) | (1ULL << ((h2 >> 19) & 63)) | (1ULL << ((h2 >> 12) & 63));
 }
 
 struct RefDesc {

@@ -978,7 +978,7 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__rest
 // multiplies for the filter hash, one LDS read.  Bit = 1 ("may match / let the exact step decide") when the key is in the
 // filter, contains a symbol outside ACGT, or runs past the end of the text.
 // ---------------------------------------------------------------------------
-constexpr uint32_t FILTER_CHUNK = 16384;
+constexpr uint32_t FILTER_CHUNK = 32768;
 
 struct FilterJob {
     SymView text;
@@ -1011,11 +1011,12 @@ __device__ __forceinline__ void pack16(const SymView &tv, uint32_t pos, uint32_t
 __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__restrict__ jobs)
 {
     const FilterJob jb = jobs[blockIdx.x];
-    __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[KEY_BLOOM_WORDS];
+    // (the first filter in LDS; the second one is consulted for the 0.4 % of foreign keys that pass it, from HBM / L2)
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[KEY_BLOOM_HALF];
     {
         const uint4 *src = (const uint4 *)jb.bloom;
         uint4 *dst = (uint4 *)s_bloom;
-        for (uint32_t t = threadIdx.x; t < KEY_BLOOM_WORDS / 2; t += blockDim.x)
+        for (uint32_t t = threadIdx.x; t < KEY_BLOOM_HALF / 2; t += blockDim.x)
             dst[t] = src[t];
     }
     __syncthreads();
@@ -1051,7 +1052,11 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
             uint32_t bw;
             uint64_t bm;
             key_bloom_slot(key, bw, bm);
-            const bool in_f = (s_bloom[bw] & bm) == bm;
+            bool in_f = (s_bloom[bw] & bm) == bm;
+            if (in_f && !bad) { // (0.4 % of the foreign keys get this far)
+                key_bloom_slot2(key, bw, bm);
+                in_f = (jb.bloom[bw] & bm) == bm;
+            }
             const bool past = !(pos + j + k < len);
             bits |= (uint32_t)(bad || in_f || past) << j;
         }
@@ -1189,6 +1194,8 @@ __device__ void idx_insert_one(const IdxBuild &jb, const SymView &rv, uint32_t t
         uint32_t bw;
         uint64_t bm;
         key_bloom_slot(x, bw, bm);
+        atomicOr(&jb.bloom[bw], (unsigned long long)bm);
+        key_bloom_slot2(x, bw, bm);
         atomicOr(&jb.bloom[bw], (unsigned long long)bm);
     }
     const E fp = FPBITS == 16 ? (E)(h >> 48) : (E)(h >> 32);
