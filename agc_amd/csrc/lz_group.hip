@@ -188,59 +188,9 @@ __device__ uint32_t lz_encode_group(const GrpRef &rd, GrpText &g, uint8_t *__res
 
     uint32_t i = 0, pred_pos = 0, npl = 0, o = 0;
     bool force_exact = false; // the grouped probe could not settle position i: 16 slots a round for this position
-    // literal runs (an insertion, the half of a missing-middle segment that belongs to the other reference): after WIDE_AFTER
-    // literal steps in a row the lanes look at 16 positions at once, each walking its own probe chain
-    constexpr uint32_t WIDE_AFTER = 4;
-    uint32_t lit_streak = 0;
-    bool try_wide = false;
     while (i + key_len < n) {
-        if (!grp_has(g, i, 48))
+        if (!grp_has(g, i, 36))
             grp_fill(g, i);
-        if (try_wide) {
-            const uint32_t q = i + gl;
-            const uint64_t P = grp_text32(g, q);
-            bool stop = true;
-            if (q + key_len < n) {
-                const uint64_t hx = murmur64(sv_key_from_packed(P, key_len));
-                uint32_t sl = (uint32_t)hx & ht_mask;
-                stop = false;
-                bool done = false;
-                // (a chain ends at its first empty slot: one or two loads settle almost every lane; a fingerprint hit or a chain
-                // beyond the probe budget makes the position a "stop" the exact rounds resolve -- the result is unchanged)
-                for (uint32_t t = 0; t < MAX_NO_TRIES && !done; ++t) {
-                    if (rd.is_short) {
-                        const uint32_t e = rd.table[sl];
-                        if (e == 0xFFFFFFFFu)
-                            done = true;
-                        else if ((e & 0xFFFFu) == (uint32_t)(hx >> 48))
-                            stop = done = true;
-                    } else {
-                        const uint64_t e = ((glb_u64 *)rd.table)[sl];
-                        if (e == ~0ULL)
-                            done = true;
-                        else if ((uint32_t)e == (uint32_t)(hx >> 32))
-                            stop = done = true;
-                    }
-                    sl = (sl + 1) & ht_mask;
-                }
-                stop = stop || !done;
-            }
-            const uint32_t sm = grp_ballot(stop);
-            const uint32_t f = sm ? (uint32_t)__builtin_ctz(sm) : GRP;
-            if (f) {
-                const uint32_t lits = grp_bcast((uint32_t)P, 0); // 16 symbols from position i
-                if (writer)
-                    for (uint32_t t = 0; t < f; ++t)
-                        out[o + t] = (uint8_t)('A' + ((lits >> (2u * t)) & 3u));
-                o += f;
-                i += f;
-                pred_pos += f;
-                npl += f;
-                try_wide = f == GRP; // a stop position was seen: on to its grouped / exact probe
-                continue;
-            }
-            try_wide = false;
-        }
         // ---- grouped probe: positions i .. i+3, four slots each.  A position whose chain ends (an empty slot) within its four
         // slots without a fingerprint hit is a literal; the first position with hits before the empty slot goes to the
         // verification with exactly the candidates the reference's probe loop would visit, in its order; a chain longer than
@@ -295,14 +245,11 @@ __device__ uint32_t lz_encode_group(const GrpRef &rd, GrpText &g, uint8_t *__res
                 i += f;
                 pred_pos += f;
                 npl += f;
-                lit_streak += f;
             }
             if (!have_cands) {
                 force_exact = to_exact;
-                if (f) {
-                    try_wide = !to_exact && lit_streak >= WIDE_AFTER;
+                if (f)
                     continue;
-                }
             }
         }
         const uint32_t max_len = n - i;
@@ -388,12 +335,9 @@ __device__ uint32_t lz_encode_group(const GrpRef &rd, GrpText &g, uint8_t *__res
             ++i;
             ++pred_pos;
             ++npl;
-            try_wide = ++lit_streak >= WIDE_AFTER;
             continue;
         }
 
-        try_wide = false;
-        lit_streak = 0;
         const uint32_t len = len_bck + len_fwd;
         // roll the back extension back (lz_diff.cpp:756-766)
         o -= len_bck;
@@ -458,7 +402,7 @@ __device__ uint32_t lz_encode_group(const GrpRef &rd, GrpText &g, uint8_t *__res
 
 // Group q of the launch parses segment q of the longest-first list; segments the group parse does not take (an escaped block in
 // the text, a reference with symbols outside ACGT) are appended to defer_list for lz_parse_kernel<MODE_ENCODE>.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) lz_encode_grp_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs, uint32_t n_segs,
+__global__ void __launch_bounds__(256) lz_encode_grp_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs, uint32_t n_segs,
                                                             uint8_t *__restrict__ out_bytes, uint32_t *__restrict__ res_value,
                                                             const uint32_t *__restrict__ n_segs_dev, uint32_t *__restrict__ defer_list,
                                                             uint32_t *__restrict__ defer_count)
