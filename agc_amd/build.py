@@ -26,7 +26,7 @@ class _Locked:
         fcntl.flock(self.f, fcntl.LOCK_UN)
         self.f.close()
 LIB = os.path.join(HERE, "libagc_hip.so")
-SOURCES = ["api.hip", "scan_kernels.hip", "lz_kernels.hip", "lz_group.hip", "splitters.hip", "zstd_kernels.hip", "seg_kernels.hip", "segments.hip", "dev_common.h", "sym_view.h",
+SOURCES = ["api.hip", "scan_kernels.hip", "lz_kernels.hip", "splitters.hip", "zstd_kernels.hip", "seg_kernels.hip", "segments.hip", "dev_common.h", "sym_view.h",
            "zstd/zs_common.h", "zstd/zs_opt.h", "zstd/zs_opt_sm.h", "zstd/zs_opt_grp.h", "zstd/zs_entropy.h", "zstd/zs_frame.h", "zstd/zs_params.h"]
 
 

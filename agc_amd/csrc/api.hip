@@ -16,7 +16,6 @@
 
 #include "scan_kernels.hip"
 #include "lz_kernels.hip"
-#include "lz_group.hip"
 #include "seg_kernels.hip"
 #include "zstd_kernels.hip"
 
@@ -92,10 +91,9 @@ struct agc_hip_ctx {
         void *segs = nullptr, *counts = nullptr, *d_ctg_off = nullptr;
         void *flag = nullptr, *capv = nullptr, *known_rank = nullptr, *cap_off = nullptr, *descs = nullptr, *lcnt = nullptr;
     } seg_state;
-    DevBuf d_ranges, d_hits, d_counter, d_segs, d_defer, d_slices, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
+    DevBuf d_ranges, d_hits, d_counter, d_segs, d_slices, d_scratch, d_resv, d_resp, d_dstoff, d_compact,
         d_jobs, d_counts, d_in, d_pp_cnt, d_pp_off, d_pp_total, d_lag, d_sample, d_zsrc, d_zdst, d_zws, d_zjobs, d_zsize, d_zout, d_zdstoff, d_maybe, d_fjobs;
 
-    bool grp_encode = getenv("AGC_HIP_LZ_WAVE") == nullptr; // the encode parse with 16 lanes per segment (lz_group.hip); unset for A/B only
     PackTemp pk1;        // byte-input entry points on the first stream
     PackTemp pk_sample;  // agc_hip_sample_pack
     std::mutex host_alloc_mtx; // host_allocs: agc_hip_host_alloc / _free may be called from the thread that collects an encode
@@ -108,7 +106,7 @@ struct agc_hip_ctx {
     // second LZ lane: agc_hip_lz_encode_begin_dev / _end run the encode of a whole sample on `stream2` with their own scratch,
     // beside the estimates / cost vectors / index builds the caller goes on with on `stream`
     struct Lane2 {
-        DevBuf d_segs, d_defer, d_counter, d_resv, d_resp, d_scratch, d_dstoff, d_compact;
+        DevBuf d_segs, d_counter, d_resv, d_resp, d_scratch, d_dstoff, d_compact;
         PackTemp pk;
         uint32_t *h_lens = nullptr; // pinned (a device-to-host copy into pageable memory would make begin wait for the kernel)
         size_t h_lens_cap = 0;
@@ -441,7 +439,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
                       &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
                       &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs,
-                      &c->l2.d_segs, &c->l2.d_defer, &c->d_defer, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
+                      &c->l2.d_segs, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
                       &c->l2.d_compact, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
     if (c->h_segcounts)
         (void)hipHostFree(c->h_segcounts);
@@ -1500,25 +1498,11 @@ template <int MODE>
 int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, bool lane2 = false, const uint32_t *n_dev = nullptr)
 {
     const uint32_t grid = (n + 3) / 4; // one wave per segment, 4 waves per block
-    hipStream_t st = lane2 ? c->stream2 : c->stream;
-    const RefDesc *refs = (const RefDesc *)c->d_refs.p;
-    const SegDesc *segs = (const SegDesc *)(lane2 ? c->l2.d_segs.p : c->d_segs.p);
-    uint32_t *resv = (uint32_t *)(lane2 ? c->l2.d_resv.p : c->d_resv.p), *resp = (uint32_t *)(lane2 ? c->l2.d_resp.p : c->d_resp.p);
-    if (MODE == MODE_ENCODE && c->grp_encode) {
-        // 16 lanes per segment (lz_group.hip); what that parse does not take -- escaped blocks, references with symbols outside
-        // ACGT -- comes back as a list for the wave kernel, whose grid covers the upper bound and ends at the list's length
-        DevBuf &defer = lane2 ? c->l2.d_defer : c->d_defer;
-        CHK(ensure(c, defer, (size_t)n * 4 + 64, st));
-        uint32_t *list = (uint32_t *)defer.p + 16, *count = (uint32_t *)defer.p;
-        HIPCHK(c, hipMemsetAsync(count, 0, 4, st));
-        KTimer t(c, lane2 ? -1 : AGC_HIP_K_ENCODE);
-        hipLaunchKernelGGL(lz_encode_grp_kernel, dim3((n + 15) / 16), dim3(256), 0, st, refs, segs, n, out_bytes, resv, n_dev, list, count);
-        hipLaunchKernelGGL(lz_parse_kernel<MODE_ENCODE>, dim3(grid), dim3(256), 0, st, refs, segs, n, out_bytes, out_u32, resv, resp,
-                           (const uint32_t *)count, (const uint32_t *)list);
-    } else {
+    {
         KTimer t(c, lane2 ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
-        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, st, refs, segs, n, out_bytes, out_u32, resv, resp, n_dev,
-                           (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, lane2 ? c->stream2 : c->stream, (const RefDesc *)c->d_refs.p,
+                           (const SegDesc *)(lane2 ? c->l2.d_segs.p : c->d_segs.p), n, out_bytes, out_u32,
+                           (uint32_t *)(lane2 ? c->l2.d_resv.p : c->d_resv.p), (uint32_t *)(lane2 ? c->l2.d_resp.p : c->d_resp.p), n_dev);
     }
     HIPCHK(c, hipGetLastError());
     return AGC_HIP_OK;

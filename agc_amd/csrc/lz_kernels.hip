@@ -899,21 +899,21 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
 // One wavefront per segment: wave w of block b parses segment 4*b + w of the host's
 // longest-first list (the dispatcher hands blocks out in order, so the long segments start
 // first and the short ones fill the tail).
+// One wavefront per segment: wave w of block b parses segment 4*b + w of the host's
+// longest-first list (the dispatcher hands blocks out in order, so the long segments start
+// first and the short ones fill the tail).
 template <int MODE>
 __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs,
                                                        uint32_t n_segs, uint8_t *__restrict__ out_bytes,
                                                        uint32_t *__restrict__ out_u32, uint32_t *__restrict__ res_value,
-                                                       uint32_t *__restrict__ res_peak, const uint32_t *__restrict__ n_segs_dev,
-                                                       const uint32_t *__restrict__ seg_list)
+                                                       uint32_t *__restrict__ res_peak, const uint32_t *__restrict__ n_segs_dev)
 {
-    uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     AGC_TRACE(1, idx);
-    // (n_segs_dev: the number of descriptors is known on the device only -- they were made there, seg_kernels.hip, or it is the
-    // length of seg_list, the segments lz_encode_grp_kernel left to this kernel -- and the grid covers an upper bound)
+    // (n_segs_dev: the number of descriptors is known on the device only -- they were made there, seg_kernels.hip -- and the grid
+    // covers an upper bound)
     if (idx >= (n_segs_dev ? *n_segs_dev : n_segs))
         return;
-    if (seg_list)
-        idx = uniform_u32(seg_list[idx]);
     const SegDesc &sdm = segs[idx];
     const RefDesc &rdm = refs[uniform_u32(sdm.ref_slot)];
     // (everything in the two descriptors is the same for the whole wave: scalar registers)
@@ -951,9 +951,9 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
     }
 }
 
-template __global__ void lz_parse_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint32_t *);
-template __global__ void lz_parse_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint32_t *);
-template __global__ void lz_parse_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint32_t *);
+template __global__ void lz_parse_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
+template __global__ void lz_parse_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
+template __global__ void lz_parse_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
 
 // gathers the per-segment deltas (scratch slots) into one contiguous buffer
 __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__restrict__ scratch, const SegDesc *__restrict__ segs,
