@@ -27,6 +27,7 @@ SYMBOLS = [
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
     "agc_hip_ref_register", "agc_hip_ref_register_batch_dev", "agc_hip_ref_get", "agc_hip_ref_index_get",
     "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch", "agc_hip_lz_encode_begin_dev", "agc_hip_lz_encode_end", "agc_hip_lz_encode_pending",
+    "agc_hip_lz_encode_begin_packed_on", "agc_hip_lz_encode_end_on", "agc_hip_lz_encode_pending_on",
     "agc_hip_host_alloc", "agc_hip_host_free",
     "agc_hip_lz_estimate_batch_dev", "agc_hip_lz_estimate_batch",
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
@@ -154,6 +155,9 @@ def load():
     L.agc_hip_ref_register_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, C.c_uint32]
     L.agc_hip_lz_encode_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]
     L.agc_hip_lz_encode_begin_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p]
+    L.agc_hip_lz_encode_begin_packed_on.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, pkp, u64p, u32p, u8p]
+    L.agc_hip_lz_encode_end_on.argtypes = [vp, C.c_uint32, u8p, C.c_uint64, u64p]
+    L.agc_hip_lz_encode_pending_on.argtypes = [vp, C.c_uint32, u32p]
     L.agc_hip_lz_estimate_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_lz_cost_vector_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u8p, u32p]
     L.agc_hip_lz_split_point_batch_packed.argtypes = [vp, C.c_uint32, u32p, u32p, pkp, u64p, u32p, u8p, u8p, u8p, u8p, u32p, u32p]
@@ -449,10 +453,36 @@ class Context:
     def lz_encode_batch_packed(self, pk, gids, off, length, rc=None, enc_cap=None):
         return self._encode(self.L.agc_hip_lz_encode_batch_packed, C.byref(pk), gids, off, length, rc, enc_cap)
 
-    def lz_encode_begin_packed(self, pk, gids, off, length, rc=None):
+    def lz_encode_begin_packed(self, pk, gids, off, length, rc=None, lane=None):
+        """first half of an encode on lane `lane` (None: the entry point without a lane, which is lane 0)"""
         g, o, l, r = self._batch(gids, off, length, rc)
-        self._enc_pending = (g, o, l, r)
-        self._chk(self.L.agc_hip_lz_encode_begin_packed(self.h, g.size, _p(g, u32p), C.byref(pk), _p(o, u64p), _p(l, u32p), _p(r, u8p)))
+        if lane is None:
+            self._enc_pending = (g, o, l, r)
+            self._chk(self.L.agc_hip_lz_encode_begin_packed(self.h, g.size, _p(g, u32p), C.byref(pk), _p(o, u64p), _p(l, u32p), _p(r, u8p)))
+        else:
+            if not hasattr(self, "_enc_pending_on"):
+                self._enc_pending_on = {}
+            self._enc_pending_on[lane] = (g, o, l, r)
+            self._chk(self.L.agc_hip_lz_encode_begin_packed_on(self.h, lane, g.size, _p(g, u32p), C.byref(pk), _p(o, u64p), _p(l, u32p), _p(r, u8p)))
+
+    def lz_encode_end_on(self, lane, enc_cap=None):
+        """second half on a lane: -> (enc bytes, enc_off[n+1])"""
+        g, o, l, r = self._enc_pending_on[lane]
+        n_dev = C.c_uint32()
+        self._chk(self.L.agc_hip_lz_encode_pending_on(self.h, lane, C.byref(n_dev)))
+        assert n_dev.value == g.size, (n_dev.value, g.size)
+        if enc_cap is None:
+            enc_cap = int(l.astype(np.uint64).sum()) * 21 // 16 + 64 * g.size + 64
+        enc = np.empty(enc_cap, np.uint8)
+        eoff = np.zeros(g.size + 1, np.uint64)
+        rc_ = self.L.agc_hip_lz_encode_end_on(self.h, lane, _p(enc, u8p), enc_cap, _p(eoff, u64p))
+        if rc_ == ECAP:
+            enc_cap = int(eoff[-1]) + 64
+            enc = np.empty(enc_cap, np.uint8)
+            rc_ = self.L.agc_hip_lz_encode_end_on(self.h, lane, _p(enc, u8p), enc_cap, _p(eoff, u64p))
+        self._chk(rc_)
+        del self._enc_pending_on[lane]
+        return enc[:int(eoff[-1])], eoff
 
     def lz_estimate_batch_packed(self, pk, gids, off, length, rc=None):
         return self._estimate(self.L.agc_hip_lz_estimate_batch_packed, C.byref(pk), gids, off, length, rc)

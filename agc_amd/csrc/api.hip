@@ -119,8 +119,11 @@ struct agc_hip_ctx {
         // the parse reads -- the sample staging buffers -- waits for the event on its own stream (sample_buffer, prefetch)
         hipEvent_t done = nullptr;
         bool done_valid = false;
-    } l2;
-    hipStream_t stream2 = nullptr;
+        hipStream_t s = nullptr; // the lane's stream
+    } l2, l3; // (l3: a second encode in flight -- the segments of a sample whose group was minted by that very sample, launched at
+              // commit time behind the whole-sample encode of l2 and collected by the same bookkeeping task)
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    Lane2 &lane(int which) { return which == 2 ? l3 : l2; }
 
     // the NEXT sample, started ahead of its turn (agc_hip_prefetch_packed_dev): expansion into one of two staging buffers and the
     // packed splitter scan, on a stream of their own with their own scratch -- they fill the gaps the sample in front leaves on the
@@ -266,7 +269,7 @@ int upload(agc_hip_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStre
         }
         const size_t need = (bytes + 255) & ~(size_t)255;
         if (c->up_head + need > c->up_cap) {
-            for (hipStream_t s_ : {c->stream, c->stream2, c->pf.stream})
+            for (hipStream_t s_ : {c->stream, c->stream2, c->stream3, c->pf.stream})
                 if (s_)
                     HIPCHK(c, hipStreamSynchronize(s_));
             c->up_head = 0;
@@ -292,8 +295,9 @@ int upload_refs(agc_hip_ctx *c)
 {
     if (!c->refs_dirty)
         return AGC_HIP_OK;
-    if (c->l2.pending)
-        HIPCHK(c, hipStreamSynchronize(c->stream2)); // the encode in flight reads the table that is about to be replaced
+    for (auto *ln : {&c->l2, &c->l3})
+        if (ln->pending)
+            HIPCHK(c, hipStreamSynchronize(ln->s)); // the encode in flight reads the table that is about to be replaced
     CHK(ensure(c, c->d_refs, std::max<size_t>(1, c->refs.size()) * sizeof(RefDesc)));
     if (!c->refs.empty())
         CHK(upload(c, c->d_refs.p, c->refs.data(), c->refs.size() * sizeof(RefDesc), c->stream));
@@ -398,11 +402,16 @@ int agc_hip_create(agc_hip_ctx **out, int device)
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l2.e0) != hipSuccess ||
         hipEventCreate(&c->l2.e1) != hipSuccess || hipEventCreateWithFlags(&c->l2.ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->l2.done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->l3.e0) != hipSuccess ||
+        hipEventCreate(&c->l3.e1) != hipSuccess || hipEventCreateWithFlags(&c->l3.ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->l3.done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->zev0) != hipSuccess || hipEventCreate(&c->zev1) != hipSuccess) {
         delete c;
         return AGC_HIP_ENODEV;
     }
+    c->l2.s = c->stream2;
+    c->l3.s = c->stream3;
     *out = c;
     return AGC_HIP_OK;
 }
@@ -417,8 +426,9 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipStreamSynchronize(c->zstream);
     if (c->zstream2)
         (void)hipStreamSynchronize(c->zstream2);
-    if (c->stream2)
-        (void)hipStreamSynchronize(c->stream2);
+    for (hipStream_t s_ : {c->stream2, c->stream3})
+        if (s_)
+            (void)hipStreamSynchronize(s_);
     if (c->pf.stream) {
         (void)hipStreamSynchronize(c->pf.stream);
         (void)hipStreamDestroy(c->pf.stream);
@@ -433,21 +443,23 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipHostFree(hp);
     if (c->up_ring)
         (void)hipHostFree(c->up_ring);
-    if (c->l2.h_lens)
-        (void)hipHostFree(c->l2.h_lens);
+    for (auto *ln : {&c->l2, &c->l3})
+        if (ln->h_lens)
+            (void)hipHostFree(ln->h_lens);
     DevBuf *bufs[] = {&c->d_table, &c->d_bloom, &c->d_bloom2, &c->d_sbloom, &c->d_refs, &c->d_ranges, &c->d_hits, &c->d_counter, &c->d_segs, &c->d_slices,
                       &c->d_scratch, &c->d_resv, &c->d_resp, &c->d_dstoff, &c->d_compact, &c->d_jobs, &c->d_counts,
                       &c->d_in, &c->d_pp_cnt, &c->d_pp_off, &c->d_pp_total, &c->d_lag, &c->d_sample, &c->d_zsrc, &c->d_zdst, &c->d_zws,
                       &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs,
                       &c->l2.d_segs, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
-                      &c->l2.d_compact, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
+                      &c->l2.d_compact, &c->l3.d_segs, &c->l3.d_counter, &c->l3.d_resv, &c->l3.d_resp, &c->l3.d_scratch, &c->l3.d_dstoff,
+                      &c->l3.d_compact, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
     if (c->h_segcounts)
         (void)hipHostFree(c->h_segcounts);
     if (c->h_gmap_stage)
         (void)hipHostFree(c->h_gmap_stage);
     if (c->gmap_ev)
         (void)hipEventDestroy(c->gmap_ev);
-    for (PackTemp *t : {&c->pk1, &c->pk_sample, &c->l2.pk})
+    for (PackTemp *t : {&c->pk1, &c->pk_sample, &c->l2.pk, &c->l3.pk})
         for (DevBuf *b : {&t->words, &t->index, &t->esc, &t->cnt})
             if (b->p)
                 (void)hipFree(b->p);
@@ -473,11 +485,12 @@ void agc_hip_destroy(agc_hip_ctx *c)
     for (hipEvent_t e : {c->zev_a, c->zev_b, c->zev_wait})
         if (e)
             (void)hipEventDestroy(e);
-    for (hipEvent_t e : {c->l2.e0, c->l2.e1, c->l2.ready, c->l2.done})
+    for (hipEvent_t e : {c->l2.e0, c->l2.e1, c->l2.ready, c->l2.done, c->l3.e0, c->l3.e1, c->l3.ready, c->l3.done})
         if (e)
             (void)hipEventDestroy(e);
-    if (c->stream2)
-        (void)hipStreamDestroy(c->stream2);
+    for (hipStream_t s_ : {c->stream2, c->stream3})
+        if (s_)
+            (void)hipStreamDestroy(s_);
     delete c;
 }
 
@@ -527,12 +540,13 @@ int agc_hip_sample_buffer(agc_hip_ctx *c, uint64_t bytes, uint8_t **d_ptr)
         return AGC_HIP_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     // (the encode of the previous sample may still be reading the buffer on the second lane: see Lane2::done)
-    if (c->l2.done_valid) {
-        if (bytes + 4096 > c->d_sample.cap)
-            HIPCHK(c, hipEventSynchronize(c->l2.done)); // the buffer is about to be replaced
-        else
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->l2.done, 0));
-    }
+    for (auto *ln : {&c->l2, &c->l3})
+        if (ln->done_valid) {
+            if (bytes + 4096 > c->d_sample.cap)
+                HIPCHK(c, hipEventSynchronize(ln->done)); // the buffer is about to be replaced
+            else
+                HIPCHK(c, hipStreamWaitEvent(c->stream, ln->done, 0));
+        }
     CHK(ensure(c, c->d_sample, bytes + 4096));
     *d_ptr = (uint8_t *)c->d_sample.p;
     return AGC_HIP_OK;
@@ -556,8 +570,9 @@ int agc_hip_sample_pack(agc_hip_ctx *c, const uint8_t *d_codes, uint64_t n_symbo
         return AGC_HIP_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     // (the encode of the previous sample may still be reading these buffers on the second lane: see Lane2::done)
-    if (c->l2.done_valid)
-        HIPCHK(c, hipEventSynchronize(c->l2.done));
+    for (auto *ln : {&c->l2, &c->l3})
+        if (ln->done_valid)
+            HIPCHK(c, hipEventSynchronize(ln->done));
     PackedSrc src;
     {
         KTimer t(c, AGC_HIP_K_PREPROCESS);
@@ -1378,12 +1393,13 @@ struct Batch {
 
 // Builds descriptors: every text is a view into the packed buffer (either orientation -- nothing is copied or staged).
 int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off,
-                  const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix, Batch &b, bool lane2 = false)
+                  const uint32_t *h_len, const uint8_t *h_rc, const uint8_t *h_prefix, Batch &b, int lane = 0)
 {
     // (lane 2: encode only -- no filter bitmaps; its own scratch and stream)
-    DevBuf &L_segs = lane2 ? c->l2.d_segs : c->d_segs, &L_counter = lane2 ? c->l2.d_counter : c->d_counter,
-           &L_resv = lane2 ? c->l2.d_resv : c->d_resv, &L_resp = lane2 ? c->l2.d_resp : c->d_resp;
-    const hipStream_t L_stream = lane2 ? c->stream2 : c->stream;
+    // (lane: 0 = the first stream and its buffers; 1, 2 = an encode lane of its own, agc_hip_ctx::lane)
+    DevBuf &L_segs = lane ? c->lane(lane).d_segs : c->d_segs, &L_counter = lane ? c->lane(lane).d_counter : c->d_counter,
+           &L_resv = lane ? c->lane(lane).d_resv : c->d_resv, &L_resp = lane ? c->lane(lane).d_resp : c->d_resp;
+    const hipStream_t L_stream = lane ? c->lane(lane).s : c->stream;
     static const bool laps = getenv("AGC_HIP_LAPS") != nullptr;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double lt = laps ? tnow() : 0;
@@ -1495,14 +1511,14 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
 }
 
 template <int MODE>
-int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, bool lane2 = false, const uint32_t *n_dev = nullptr)
+int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, int lane = 0, const uint32_t *n_dev = nullptr)
 {
     const uint32_t grid = (n + 3) / 4; // one wave per segment, 4 waves per block
     {
-        KTimer t(c, lane2 ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
-        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, lane2 ? c->stream2 : c->stream, (const RefDesc *)c->d_refs.p,
-                           (const SegDesc *)(lane2 ? c->l2.d_segs.p : c->d_segs.p), n, out_bytes, out_u32,
-                           (uint32_t *)(lane2 ? c->l2.d_resv.p : c->d_resv.p), (uint32_t *)(lane2 ? c->l2.d_resp.p : c->d_resp.p), n_dev);
+        KTimer t(c, lane ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, lane ? c->lane(lane).s : c->stream, (const RefDesc *)c->d_refs.p,
+                           (const SegDesc *)(lane ? c->lane(lane).d_segs.p : c->d_segs.p), n, out_bytes, out_u32,
+                           (uint32_t *)(lane ? c->lane(lane).d_resv.p : c->d_resv.p), (uint32_t *)(lane ? c->lane(lane).d_resp.p : c->d_resp.p), n_dev);
     }
     HIPCHK(c, hipGetLastError());
     return AGC_HIP_OK;
@@ -1564,49 +1580,51 @@ static int lz_encode_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, con
 // The encode in two halves (include/agc_hip.h): begin queues the parse and the copy of the delta lengths on the context's second
 // stream and returns; end waits, lays the deltas out back to back and brings them over.  Between the two the caller may use every
 // other entry point (they run on the first stream with their own scratch).
-static int lz_encode_begin_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off, const uint32_t *h_len,
-                                const uint8_t *h_rc)
+static int lz_encode_begin_impl(agc_hip_ctx *c, int lane, uint32_t n, const uint32_t *h_gid, const PackedSrc &src, const uint64_t *h_off,
+                                const uint32_t *h_len, const uint8_t *h_rc)
 {
+    agc_hip_ctx::Lane2 &L = c->lane(lane);
     static thread_local Batch b; // (its descriptors are read by an asynchronous upload: they outlive this call)
-    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, src, h_off, h_len, h_rc, nullptr, b, true));
-    CHK(ensure(c, c->l2.d_scratch, b.out_total + 64, c->stream2));
-    if (c->l2.h_lens_cap < n) {
-        if (c->l2.h_lens)
-            HIPCHK(c, hipHostFree(c->l2.h_lens));
-        c->l2.h_lens = nullptr;
-        c->l2.h_lens_cap = 0;
-        HIPCHK(c, hipHostMalloc((void **)&c->l2.h_lens, ((size_t)n + n / 4 + 1024) * 4, hipHostMallocDefault));
-        c->l2.h_lens_cap = (size_t)n + n / 4 + 1024;
+    CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, src, h_off, h_len, h_rc, nullptr, b, lane));
+    CHK(ensure(c, L.d_scratch, b.out_total + 64, L.s));
+    if (L.h_lens_cap < n) {
+        if (L.h_lens)
+            HIPCHK(c, hipHostFree(L.h_lens));
+        L.h_lens = nullptr;
+        L.h_lens_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&L.h_lens, ((size_t)n + n / 4 + 1024) * 4, hipHostMallocDefault));
+        L.h_lens_cap = (size_t)n + n / 4 + 1024;
     }
-    c->l2.timed = c->timing;
-    if (c->l2.timed)
-        (void)hipEventRecord(c->l2.e0, c->stream2);
-    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)c->l2.d_scratch.p, nullptr, true));
-    if (c->l2.timed)
-        (void)hipEventRecord(c->l2.e1, c->stream2);
-    HIPCHK(c, hipEventRecord(c->l2.done, c->stream2));
-    c->l2.done_valid = true;
-    HIPCHK(c, hipMemcpyAsync(c->l2.h_lens, c->l2.d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream2));
-    c->l2.pending = true;
+    L.timed = c->timing;
+    if (L.timed)
+        (void)hipEventRecord(L.e0, L.s);
+    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)L.d_scratch.p, nullptr, lane));
+    if (L.timed)
+        (void)hipEventRecord(L.e1, L.s);
+    HIPCHK(c, hipEventRecord(L.done, L.s));
+    L.done_valid = true;
+    HIPCHK(c, hipMemcpyAsync(L.h_lens, L.d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, L.s));
+    L.pending = true;
     return AGC_HIP_OK;
 }
 
 // common start of the two begin entry points: an abandoned encode is dropped, the first stream's work so far comes first
-static int lz_encode_begin_enter(agc_hip_ctx *c, uint32_t n)
+static int lz_encode_begin_enter(agc_hip_ctx *c, int lane, uint32_t n)
 {
-    if (c->l2.pending) { // (an abandoned encode: a caller that failed between the two halves) -- dropped
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->l2.pending = false;
+    agc_hip_ctx::Lane2 &L = c->lane(lane);
+    if (L.pending) { // (an abandoned encode: a caller that failed between the two halves) -- dropped
+        HIPCHK(c, hipStreamSynchronize(L.s));
+        L.pending = false;
     }
-    c->l2.n = n;
+    L.n = n;
     if (!n) {
-        c->l2.pending = true;
+        L.pending = true;
         return 1; // nothing to launch
     }
     HIPCHK(c, hipSetDevice(c->device));
     // everything queued on the first stream so far (index builds, a sample being packed) comes first
-    HIPCHK(c, hipEventRecord(c->l2.ready, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->l2.ready, 0));
+    HIPCHK(c, hipEventRecord(L.ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(L.s, L.ready, 0));
     return AGC_HIP_OK;
 }
 
@@ -1639,15 +1657,21 @@ int agc_hip_lz_encode_batch_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gi
     return lz_encode_impl(c, n, h_gid, src, off2.data(), h_len, h_rc, h_enc, enc_cap, h_enc_off);
 }
 
+int agc_hip_lz_encode_begin_packed_on(agc_hip_ctx *c, uint32_t lane, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
+                                      const uint32_t *h_len, const uint8_t *h_rc)
+{
+    if (!c || lane >= AGC_HIP_ENCODE_LANES || (n && (!h_gid || !h_off || !h_len || !pk || !pk->d_words)))
+        return AGC_HIP_EINVAL;
+    const int e = lz_encode_begin_enter(c, (int)lane + 1, n);
+    if (e)
+        return e > 0 ? AGC_HIP_OK : e;
+    return lz_encode_begin_impl(c, (int)lane + 1, n, h_gid, src_of(pk), h_off, h_len, h_rc);
+}
+
 int agc_hip_lz_encode_begin_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,
                                    const uint32_t *h_len, const uint8_t *h_rc)
 {
-    if (!c || (n && (!h_gid || !h_off || !h_len || !pk || !pk->d_words)))
-        return AGC_HIP_EINVAL;
-    const int e = lz_encode_begin_enter(c, n);
-    if (e)
-        return e > 0 ? AGC_HIP_OK : e;
-    return lz_encode_begin_impl(c, n, h_gid, src_of(pk), h_off, h_len, h_rc);
+    return agc_hip_lz_encode_begin_packed_on(c, 0, n, h_gid, pk, h_off, h_len, h_rc);
 }
 
 int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const uint8_t *d_base, const uint64_t *h_off,
@@ -1655,61 +1679,71 @@ int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gi
 {
     if (!c || (n && (!h_gid || !h_off || !h_len || !d_base)))
         return AGC_HIP_EINVAL;
-    const int e = lz_encode_begin_enter(c, n);
+    const int e = lz_encode_begin_enter(c, 1, n);
     if (e)
         return e > 0 ? AGC_HIP_OK : e;
+    agc_hip_ctx::Lane2 &L = c->lane(1);
     PackedSrc src;
     std::vector<uint64_t> off2;
-    CHK(pack_range(c, d_base, n, h_off, h_len, c->l2.pk, c->stream2, src, off2)); // (the lane's own packed copy: it lives until end)
-    return lz_encode_begin_impl(c, n, h_gid, src, off2.data(), h_len, h_rc);
+    CHK(pack_range(c, d_base, n, h_off, h_len, L.pk, L.s, src, off2)); // (the lane's own packed copy: it lives until end)
+    return lz_encode_begin_impl(c, 1, n, h_gid, src, off2.data(), h_len, h_rc);
 }
 
-int agc_hip_lz_encode_pending(agc_hip_ctx *c, uint32_t *h_n)
+int agc_hip_lz_encode_pending(agc_hip_ctx *c, uint32_t *h_n) { return agc_hip_lz_encode_pending_on(c, 0, h_n); }
+
+int agc_hip_lz_encode_pending_on(agc_hip_ctx *c, uint32_t lane, uint32_t *h_n)
 {
-    if (!c || !h_n)
+    if (!c || !h_n || lane >= AGC_HIP_ENCODE_LANES)
         return AGC_HIP_EINVAL;
+    agc_hip_ctx::Lane2 &L = c->lane((int)lane + 1);
     *h_n = 0;
-    if (!c->l2.pending)
+    if (!L.pending)
         return AGC_HIP_OK;
-    if (c->l2.n_pinned) { // (launched from descriptors made on the device: the count was copied behind the parse)
+    if (L.n_pinned) { // (launched from descriptors made on the device: the count was copied behind the parse)
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->l2.n = *c->l2.n_pinned;
-        c->l2.n_pinned = nullptr;
+        HIPCHK(c, hipStreamSynchronize(L.s));
+        L.n = *L.n_pinned;
+        L.n_pinned = nullptr;
     }
-    *h_n = c->l2.n;
+    *h_n = L.n;
     return AGC_HIP_OK;
 }
 
 int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
 {
-    if (!c || !h_enc_off)
+    return agc_hip_lz_encode_end_on(c, 0, h_enc, enc_cap, h_enc_off);
+}
+
+int agc_hip_lz_encode_end_on(agc_hip_ctx *c, uint32_t lane, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off || lane >= AGC_HIP_ENCODE_LANES)
         return AGC_HIP_EINVAL;
-    if (!c->l2.pending) {
+    agc_hip_ctx::Lane2 &L = c->lane((int)lane + 1);
+    if (!L.pending) {
         c->err = "lz_encode_end: no encode in flight";
         return AGC_HIP_EINVAL;
     }
     h_enc_off[0] = 0;
-    if (c->l2.n_pinned) { // (launched by agc_hip_segments_encode_known: the count was copied behind the parse)
+    if (L.n_pinned) { // (launched by agc_hip_segments_encode_known: the count was copied behind the parse)
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->l2.n = *c->l2.n_pinned;
-        c->l2.n_pinned = nullptr;
+        HIPCHK(c, hipStreamSynchronize(L.s));
+        L.n = *L.n_pinned;
+        L.n_pinned = nullptr;
     }
-    const uint32_t n = c->l2.n;
+    const uint32_t n = L.n;
     if (!n) {
-        c->l2.pending = false;
+        L.pending = false;
         return AGC_HIP_OK;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
-    if (c->l2.timed) {
+    HIPCHK(c, hipStreamSynchronize(L.s));
+    if (L.timed) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->l2.e0, c->l2.e1) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, L.e0, L.e1) == hipSuccess) {
             c->ms[AGC_HIP_K_ENCODE] += ms;
             c->launches[AGC_HIP_K_ENCODE] += 1;
         }
-        c->l2.timed = false; // (a second call after AGC_HIP_ECAP must not count the launch twice)
+        L.timed = false; // (a second call after AGC_HIP_ECAP must not count the launch twice)
     }
 #ifdef AGC_PHASES
     {
@@ -1740,7 +1774,7 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint
         }
     };
     for (uint32_t i = 0; i < n; ++i)
-        h_enc_off[i + 1] = h_enc_off[i] + c->l2.h_lens[i];
+        h_enc_off[i + 1] = h_enc_off[i] + L.h_lens[i];
     const uint64_t tot = h_enc_off[n];
     if (tot > enc_cap)
         return AGC_HIP_ECAP; // (still in flight: call again with a larger buffer)
@@ -1748,8 +1782,8 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint
     if (tot) {
         if (!h_enc)
             return AGC_HIP_EINVAL;
-        CHK(ensure(c, c->l2.d_dstoff, (size_t)n * 8, c->stream2));
-        CHK(upload(c, c->l2.d_dstoff.p, h_enc_off, (size_t)n * 8, c->stream2));
+        CHK(ensure(c, L.d_dstoff, (size_t)n * 8, L.s));
+        CHK(upload(c, L.d_dstoff.p, h_enc_off, (size_t)n * 8, L.s));
         // a pinned result buffer (agc_hip_host_alloc) is written by the gather itself, over the link: no second buffer, no copy
         // engine; anything else gets the deltas compacted in HBM and copied
         void *d_host = nullptr;
@@ -1758,18 +1792,18 @@ int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t enc_cap, uint
             d_host = nullptr;
         }
         if (!d_host)
-            CHK(ensure(c, c->l2.d_compact, tot, c->stream2));
-        hipLaunchKernelGGL(gather_bytes_kernel, dim3(grid_for(n, 1, 8192)), dim3(256), 0, c->stream2, (const uint8_t *)c->l2.d_scratch.p,
-                           (const SegDesc *)c->l2.d_segs.p, (const uint32_t *)c->l2.d_resv.p, (const uint64_t *)c->l2.d_dstoff.p, n,
-                           d_host ? (uint8_t *)d_host : (uint8_t *)c->l2.d_compact.p);
+            CHK(ensure(c, L.d_compact, tot, L.s));
+        hipLaunchKernelGGL(gather_bytes_kernel, dim3(grid_for(n, 1, 8192)), dim3(256), 0, L.s, (const uint8_t *)L.d_scratch.p,
+                           (const SegDesc *)L.d_segs.p, (const uint32_t *)L.d_resv.p, (const uint64_t *)L.d_dstoff.p, n,
+                           d_host ? (uint8_t *)d_host : (uint8_t *)L.d_compact.p);
         HIPCHK(c, hipGetLastError());
         if (!d_host)
-            HIPCHK(c, hipMemcpyAsync(h_enc, c->l2.d_compact.p, tot, hipMemcpyDeviceToHost, c->stream2));
+            HIPCHK(c, hipMemcpyAsync(h_enc, L.d_compact.p, tot, hipMemcpyDeviceToHost, L.s));
         LAP("queued");
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        HIPCHK(c, hipStreamSynchronize(L.s));
         LAP("deltas on the host");
     }
-    c->l2.pending = false;
+    L.pending = false;
     return AGC_HIP_OK;
 }
 

@@ -150,51 +150,63 @@ void CAGCCompressor::Impl::book_main()
         const double t0 = now();
         bool ok = true;
         uint64_t delta_bytes = 0;
-        if (t->enc_pending) {
-            // the registration's LZ encode was left in flight on the device's second lane: collect it (only that lane is touched)
-            const size_t ne = t->enc_todo.size();
+        // the registration's LZ encodes were left in flight on the device's lanes: collect them (only a lane's own state is touched)
+        auto collect = [&](uint32_t lane, const std::vector<uint32_t> &todo, uint64_t text, PinnedBytes &enc) {
+            const size_t ne = todo.size();
             std::vector<uint64_t> eoff(ne + 1, 0);
-            PinnedBytes &enc = *t->enc_dst;
             {
                 uint32_t n_dev = 0;
-                ok = hip_ok(agc_hip_lz_encode_pending(hip, &n_dev), "lz_encode_pending");
+                ok = hip_ok(agc_hip_lz_encode_pending_on(hip, lane, &n_dev), "lz_encode_pending");
                 if (ok && n_dev != ne) {
                     err("internal: the device's encode delivers another number of deltas than the host expects");
                     ok = false;
                 }
             }
             if (ok) {
-            uint64_t cap = std::max<uint64_t>(enc.size(), t->enc_text / 64 + (1u << 16));
-            for (;;) {
-                if (!enc.resize(cap, false)) {
-                    err("out of memory (delta buffer)");
-                    ok = false;
+                uint64_t cap = std::max<uint64_t>(enc.size(), text / 64 + (1u << 16));
+                for (;;) {
+                    if (!enc.resize(cap, false)) {
+                        err("out of memory (delta buffer)");
+                        ok = false;
+                        break;
+                    }
+                    const int r = agc_hip_lz_encode_end_on(hip, lane, enc.data(), cap, eoff.data());
+                    if (r == AGC_HIP_ECAP) {
+                        cap = eoff[ne] + eoff[ne] / 8 + 4096; // (headroom: the next sample's deltas are a little longer)
+                        continue;
+                    }
+                    ok = hip_ok(r, "lz_encode_end");
                     break;
                 }
-                const int r = agc_hip_lz_encode_end(hip, enc.data(), cap, eoff.data());
-                if (r == AGC_HIP_ECAP) {
-                    cap = eoff[ne] + eoff[ne] / 8 + 4096; // (headroom: the next sample's deltas are a little longer)
-                    continue;
-                }
-                ok = hip_ok(r, "lz_encode_end");
-                break;
             }
-            }
-            lane2_release(); // (the thread that drives the steps may launch the next sample's encode)
+            lane2_release((int)lane); // (the thread that drives the steps may launch the next sample's encode)
             if (ok) {
                 for (size_t i = 0; i < ne; ++i) {
-                    if (t->enc_todo[i] == ~0u)
+                    if (todo[i] == ~0u)
                         continue; // (a delta the device made ahead of the classification and the placement did not use)
-                    t->cd.enc_ptr[t->enc_todo[i]] = enc.data() + eoff[i];
-                    t->cd.enc_len[t->enc_todo[i]] = (uint32_t)(eoff[i + 1] - eoff[i]);
+                    t->cd.enc_ptr[todo[i]] = enc.data() + eoff[i];
+                    t->cd.enc_len[todo[i]] = (uint32_t)(eoff[i + 1] - eoff[i]);
                 }
-                delta_bytes = eoff[ne];
+                delta_bytes += eoff[ne];
             }
+        };
+        if (t->enc_pending)
+            collect(0, t->enc_todo, t->enc_text, *t->enc_dst);
+        const double t_c0 = now();
+        if (t->enc2_pending) {
+            if (ok)
+                collect(1, t->enc2_todo, t->enc2_text, *t->enc2_dst);
+            else
+                lane2_release(1);
         }
+        const double t_c1 = now();
         book_on_thread = true;
         ok = ok && book_and_store(t->cd);
         book_on_thread = false;
         t.reset();
+        static const bool book_laps = getenv("AGC_AMD_LAPS") != nullptr;
+        if (book_laps)
+            std::cerr << "    book task: collect lane 0 " << (t_c0 - t0) * 1e3 << " ms, lane 1 " << (t_c1 - t_c0) * 1e3 << " ms, books " << (now() - t_c1) * 1e3 << " ms\n";
         {
             std::lock_guard<std::mutex> lk(book_mtx);
             book_busy = false;
@@ -245,18 +257,18 @@ void CAGCCompressor::Impl::book_shutdown()
 }
 
 // the device's second LZ lane: one encode at a time
-void CAGCCompressor::Impl::lane2_acquire()
+void CAGCCompressor::Impl::lane2_acquire(int lane)
 {
     std::unique_lock<std::mutex> lk(book_mtx);
-    book_idle_cv.wait(lk, [&] { return !lane2_inflight; });
-    lane2_inflight = true;
+    book_idle_cv.wait(lk, [&] { return !lane_inflight[lane]; });
+    lane_inflight[lane] = true;
 }
 
-void CAGCCompressor::Impl::lane2_release()
+void CAGCCompressor::Impl::lane2_release(int lane)
 {
     {
         std::lock_guard<std::mutex> lk(book_mtx);
-        lane2_inflight = false;
+        lane_inflight[lane] = false;
     }
     book_idle_cv.notify_all();
 }
@@ -2057,6 +2069,8 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
     LAP("encode_end");
     std::vector<uint32_t> enc_later; // per result of the encode in flight on the second lane: its position in enc_items (~0u: unused)
     uint64_t enc_later_text = 0;
+    std::vector<uint32_t> enc_later2; // ... and of the one launched below on lane 1 while lane 0 still holds the whole-sample encode
+    uint64_t enc_later2_text = 0;
     const bool bulk = b.dev_enc_n != 0; // the device launched the encode of the segments whose group it knew (stage_scan_dev)
     if (bulk)
         enc_later.assign(b.dev_enc_n, ~0u);
@@ -2095,7 +2109,8 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             // The encode is only LAUNCHED here when its result is first read by the bookkeeping task: the task collects it (second
             // device lane) while this thread goes on with the next sample.  Needs a sample in a staging buffer the device context
             // owns (it outlives the call) and nothing else on that lane.
-            if (!bulk && hand_over && async_encode && dist_world == 1 && b.base_owned && b.pk.n_symbols && overlap_mode == 0 && !b.enc_in_flight && b.spec_bytes == 0) {
+            const bool later = hand_over && async_encode && dist_world == 1 && b.base_owned && b.pk.n_symbols && overlap_mode == 0 && !b.enc_in_flight && b.spec_bytes == 0;
+            if (!bulk && later) {
                 lane2_acquire();
                 if (!hip_ok(DEVT(agc_hip_lz_encode_begin_packed(hip, (uint32_t)ne, gid.data(), &b.pk, off.data(), len.data(), rc.data())), "lz_encode_begin")) {
                     lane2_release();
@@ -2103,6 +2118,17 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
                 }
                 enc_later.swap(todo);
                 enc_later_text = tot;
+                st.lz_encoded += ne;
+            } else if (bulk && later) {
+                // (lane 0 carries the encode of the segments the device knew; these -- followers of the groups this sample minted,
+                // whose references were indexed a moment ago -- go to lane 1 and are collected by the same task)
+                lane2_acquire(1);
+                if (!hip_ok(DEVT(agc_hip_lz_encode_begin_packed_on(hip, 1, (uint32_t)ne, gid.data(), &b.pk, off.data(), len.data(), rc.data())), "lz_encode_begin")) {
+                    lane2_release(1);
+                    return false;
+                }
+                enc_later2.swap(todo);
+                enc_later2_text = tot;
                 st.lz_encoded += ne;
             } else {
             PinnedBytes &enc = enc_buf2;
@@ -2131,7 +2157,7 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             }
         }
     }
-    LAP(enc_later.empty() ? "encode" : "encode (in flight)");
+    LAP(enc_later.empty() && enc_later2.empty() ? "encode" : "encode (in flight)");
     if (bulk && !hand_over) {
         // the synchronous path after all: the device's encode is collected here
         const size_t ne = enc_later.size();
@@ -2204,6 +2230,12 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
             // (the deltas encoded at commit time sit in enc_alt2 now; the device-launched encode of the whole sample is collected
             // into the other buffer of the set, which holds nothing in this mode: spec_bytes == 0)
             t->enc_dst = bulk ? &enc_alt : &enc_alt2;
+        }
+        if (!enc_later2.empty()) {
+            t->enc2_pending = true;
+            t->enc2_todo = std::move(enc_later2);
+            t->enc2_text = enc_later2_text;
+            t->enc2_dst = &enc_alt2;
         }
         last_own_seq = book_submit(std::move(t));
         LAP("book_and_store (queued)");

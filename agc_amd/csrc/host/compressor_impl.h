@@ -807,6 +807,12 @@ struct CAGCCompressor::Impl {
         std::vector<uint32_t> enc_todo;
         uint64_t enc_text = 0;
         PinnedBytes *enc_dst = nullptr;
+        // ... and a second one on lane 1 (agc_hip_lz_encode_begin_packed_on): the segments the sample's own new groups took,
+        // launched at commit time behind the whole-sample encode of lane 0
+        bool enc2_pending = false;
+        std::vector<uint32_t> enc2_todo;
+        uint64_t enc2_text = 0;
+        PinnedBytes *enc2_dst = nullptr;
         Impl *owner = nullptr;
         ~BookTask()
         {
@@ -928,9 +934,9 @@ struct CAGCCompressor::Impl {
     PinnedBytes dev_seg_buf;           // (pinned: the segment table of a human sample is 3 MB per step)
     // the device's second LZ lane carries one encode at a time: launched by the thread that drives the steps, collected by the
     // bookkeeping thread (or by the driver itself on the synchronous path)
-    bool lane2_inflight = false;       // (guarded by book_mtx)
-    void lane2_acquire();
-    void lane2_release();
+    bool lane_inflight[2] = {false, false}; // (guarded by book_mtx) device lanes 0 / 1 (AGC_HIP_ENCODE_LANES)
+    void lane2_acquire(int lane = 0);
+    void lane2_release(int lane = 0);
     bool stage_classify(BatchState &b);
     bool stage_place(BatchState &b);
     bool stage_register(BatchState &b);

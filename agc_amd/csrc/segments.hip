@@ -132,7 +132,7 @@ static int launch_known(agc_hip_ctx *c)
     c->l2.timed = c->timing;
     if (c->l2.timed)
         (void)hipEventRecord(c->l2.e0, c->stream2);
-    CHK(launch_parse<MODE_ENCODE>(c, n_ub, (uint8_t *)c->l2.d_scratch.p, nullptr, true, &counts->n_known));
+    CHK(launch_parse<MODE_ENCODE>(c, n_ub, (uint8_t *)c->l2.d_scratch.p, nullptr, 1, &counts->n_known));
     if (c->l2.timed)
         (void)hipEventRecord(c->l2.e1, c->stream2);
     HIPCHK(c, hipEventRecord(c->l2.done, c->stream2));

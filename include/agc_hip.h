@@ -278,6 +278,16 @@ int agc_hip_lz_encode_end(agc_hip_ctx *ctx, uint8_t *h_enc, uint64_t enc_cap, ui
 /* number of deltas the encode in flight will deliver (0: none in flight); waits for the parse when the encode was launched from
  * descriptors made on the device (agc_hip_segments_encode_known), whose number only the device knows until then. */
 int agc_hip_lz_encode_pending(agc_hip_ctx *ctx, uint32_t *h_n);
+/* The same three on a named lane.  A context has AGC_HIP_ENCODE_LANES encode lanes (streams with their own scratch), each with
+ * one encode in flight; the entry points above are lane 0, which is also the lane agc_hip_segments_encode_known launches on.
+ * A host that commits a sample while its whole-sample encode is still on lane 0 puts the remaining segments -- those whose group
+ * the sample itself minted (the reference's followers of a new group, agc_compressor.cpp:1275-1330) -- on lane 1 and lets the
+ * thread that collects lane 0 collect lane 1 after it, instead of waiting for them.  The rules of begin / end hold per lane. */
+#define AGC_HIP_ENCODE_LANES 2
+int agc_hip_lz_encode_begin_packed_on(agc_hip_ctx *ctx, uint32_t lane, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk,
+                                      const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc);
+int agc_hip_lz_encode_end_on(agc_hip_ctx *ctx, uint32_t lane, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
+int agc_hip_lz_encode_pending_on(agc_hip_ctx *ctx, uint32_t lane, uint32_t *h_n);
 
 /* Pinned host memory for result buffers (device-to-host copies into pageable memory go through a bounce buffer at a
  * fraction of the link rate).  Freed by agc_hip_host_free or with the context. */

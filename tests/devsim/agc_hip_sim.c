@@ -47,10 +47,12 @@ struct agc_hip_ctx {
     void **lz; /* by gid */
     u32 n_lz;
     /* encode in two halves: parsed at begin (see agc_hip_lz_encode_begin_dev), handed out by end */
-    int enc_pending;
-    u32 enc_n;
-    u8 *enc_out;
-    u64 *enc_eoff;
+    struct {
+        int pending;
+        u32 n;
+        u8 *out;
+        u64 *eoff;
+    } enc[AGC_HIP_ENCODE_LANES]; /* one per lane (agc_hip_lz_encode_*_on) */
     /* the next sample ahead of its turn: the identity of what was announced */
     const void *pf_words;
     /* what agc_hip_segments_packed left for agc_hip_segments_encode_known */
@@ -124,6 +126,8 @@ void agc_hip_destroy(agc_hip_ctx *c)
     free(c->sp_esc);
     free(c->gmap);
     free(c->sg_gid), free(c->sg_len), free(c->sg_off), free(c->sg_rc), free(c->sg_codes);
+    for (u32 l = 0; l < AGC_HIP_ENCODE_LANES; ++l)
+        free(c->enc[l].out), free(c->enc[l].eoff);
     free(c);
 }
 
@@ -324,74 +328,86 @@ static void *dup_mem(const void *p, size_t n)
     return q;
 }
 
-static void enc_clear(agc_hip_ctx *c)
+static void enc_clear(agc_hip_ctx *c, uint32_t lane)
 {
-    free(c->enc_out);
-    free(c->enc_eoff);
-    c->enc_out = NULL;
-    c->enc_eoff = NULL;
-    c->enc_pending = 0;
+    free(c->enc[lane].out);
+    free(c->enc[lane].eoff);
+    c->enc[lane].out = NULL;
+    c->enc[lane].eoff = NULL;
+    c->enc[lane].pending = 0;
 }
 
 /* The device runs the parse in stream order behind `begin` and makes whatever overwrites the sample buffer wait for it (api.hip,
  * Lane2::done); the stand-in has no streams, so it models the same thing by parsing AT begin into a buffer of its own.  `_end`
  * (possibly on another thread: it only touches the enc_* fields) hands the result out. */
-int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off, const uint32_t *len,
-                                const uint8_t *rc)
+static int encode_begin_on(agc_hip_ctx *c, uint32_t lane, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off,
+                           const uint32_t *len, const uint8_t *rc)
 {
-    if (!c || (n && (!gid || !d || !off || !len)))
+    if (!c || lane >= AGC_HIP_ENCODE_LANES || (n && (!gid || !d || !off || !len)))
         return AGC_HIP_EINVAL;
-    if (c->enc_pending)
-        enc_clear(c); /* an abandoned encode is dropped */
-    c->enc_n = n;
-    c->enc_eoff = (u64 *)calloc((size_t)n + 1, 8);
+    if (c->enc[lane].pending)
+        enc_clear(c, lane); /* an abandoned encode is dropped */
+    c->enc[lane].n = n;
+    c->enc[lane].eoff = (u64 *)calloc((size_t)n + 1, 8);
     u64 cap = 1u << 16;
     for (u32 i = 0; i < n; ++i)
         cap += len[i] / 64 + 16;
     for (;;) {
-        free(c->enc_out);
-        c->enc_out = (u8 *)malloc(cap ? cap : 1);
-        if (!c->enc_out || !c->enc_eoff)
+        free(c->enc[lane].out);
+        c->enc[lane].out = (u8 *)malloc(cap ? cap : 1);
+        if (!c->enc[lane].out || !c->enc[lane].eoff)
             return AGC_HIP_ENOMEM;
-        const int r = agc_hip_lz_encode_batch_dev(c, n, gid, d, off, len, rc, c->enc_out, cap, c->enc_eoff);
+        const int r = agc_hip_lz_encode_batch_dev(c, n, gid, d, off, len, rc, c->enc[lane].out, cap, c->enc[lane].eoff);
         if (r == AGC_HIP_ECAP) {
-            cap = c->enc_eoff[n] + 64;
+            cap = c->enc[lane].eoff[n] + 64;
             continue;
         }
         if (r != AGC_HIP_OK) {
-            enc_clear(c);
+            enc_clear(c, lane);
             return r;
         }
         break;
     }
-    c->enc_pending = 1;
+    c->enc[lane].pending = 1;
     return AGC_HIP_OK;
 }
 
-int agc_hip_lz_encode_pending(agc_hip_ctx *c, uint32_t *h_n)
+int agc_hip_lz_encode_begin_dev(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const uint8_t *d, const uint64_t *off, const uint32_t *len,
+                                const uint8_t *rc)
 {
-    if (!c || !h_n)
-        return AGC_HIP_EINVAL;
-    *h_n = c->enc_pending ? c->enc_n : 0;
-    return AGC_HIP_OK;
+    return encode_begin_on(c, 0, n, gid, d, off, len, rc);
 }
 
+int agc_hip_lz_encode_pending(agc_hip_ctx *c, uint32_t *h_n) { return agc_hip_lz_encode_pending_on(c, 0, h_n); }
 int agc_hip_lz_encode_end(agc_hip_ctx *c, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
 {
-    if (!c || !h_enc_off)
+    return agc_hip_lz_encode_end_on(c, 0, h_enc, cap, h_enc_off);
+}
+
+int agc_hip_lz_encode_pending_on(agc_hip_ctx *c, uint32_t lane, uint32_t *h_n)
+{
+    if (!c || !h_n || lane >= AGC_HIP_ENCODE_LANES)
         return AGC_HIP_EINVAL;
-    if (!c->enc_pending)
+    *h_n = c->enc[lane].pending ? c->enc[lane].n : 0;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_encode_end_on(agc_hip_ctx *c, uint32_t lane, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
+{
+    if (!c || !h_enc_off || lane >= AGC_HIP_ENCODE_LANES)
+        return AGC_HIP_EINVAL;
+    if (!c->enc[lane].pending)
         return fail(c, AGC_HIP_EINVAL, "encode_end: no encode in flight");
-    const u32 n = c->enc_n;
-    memcpy(h_enc_off, c->enc_eoff, ((size_t)n + 1) * 8);
-    if (c->enc_eoff[n] > cap)
+    const u32 n = c->enc[lane].n;
+    memcpy(h_enc_off, c->enc[lane].eoff, ((size_t)n + 1) * 8);
+    if (c->enc[lane].eoff[n] > cap)
         return AGC_HIP_ECAP; /* (still in flight: call again with a larger buffer) */
-    if (c->enc_eoff[n]) {
+    if (c->enc[lane].eoff[n]) {
         if (!h_enc)
             return AGC_HIP_EINVAL;
-        memcpy(h_enc, c->enc_out, c->enc_eoff[n]);
+        memcpy(h_enc, c->enc[lane].out, c->enc[lane].eoff[n]);
     }
-    enc_clear(c);
+    enc_clear(c, lane);
     return AGC_HIP_OK;
 }
 
@@ -672,12 +688,17 @@ int agc_hip_lz_encode_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *g
         return AGC_HIP_EINVAL;
     WITH_SPAN(agc_hip_lz_encode_batch_dev(c, n, gid, buf, off2, len, rc, h_enc, cap, h_enc_off))
 }
+int agc_hip_lz_encode_begin_packed_on(agc_hip_ctx *c, uint32_t lane, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
+                                      const uint32_t *len, const uint8_t *rc)
+{
+    if (!c || lane >= AGC_HIP_ENCODE_LANES || (n && (!gid || !pk || !off || !len)))
+        return AGC_HIP_EINVAL;
+    WITH_SPAN(encode_begin_on(c, lane, n, gid, buf, off2, len, rc))
+}
 int agc_hip_lz_encode_begin_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
                                    const uint32_t *len, const uint8_t *rc)
 {
-    if (!c || (n && (!gid || !pk || !off || !len)))
-        return AGC_HIP_EINVAL;
-    WITH_SPAN(agc_hip_lz_encode_begin_dev(c, n, gid, buf, off2, len, rc))
+    return agc_hip_lz_encode_begin_packed_on(c, 0, n, gid, pk, off, len, rc);
 }
 int agc_hip_lz_estimate_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *gid, const agc_hip_packed *pk, const uint64_t *off,
                                      const uint32_t *len, const uint8_t *rc, uint32_t *h_cost, uint32_t *h_peak)
@@ -773,7 +794,7 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         return AGC_HIP_EINVAL;
     if (prefetched && c->pf_words != pk->d_words)
         return AGC_HIP_EINVAL;
-    if (encode_known && c->enc_pending)
+    if (encode_known && c->enc[0].pending)
         return fail(c, AGC_HIP_EINVAL, "segments_packed: the previous encode was not collected");
     *h_n_segs = 0;
     if (h_n_encoded)
@@ -875,17 +896,18 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
 /* the launch as a call of its own: the stand-in kept what it needs from the last agc_hip_segments_packed call */
 int agc_hip_segments_encode_known(agc_hip_ctx *c)
 {
+    const uint32_t lane = 0;
     if (!c || !c->sg_valid)
         return fail(c, AGC_HIP_EINVAL, "segments_encode_known: no segments");
-    if (c->enc_pending)
+    if (c->enc[lane].pending)
         return fail(c, AGC_HIP_EINVAL, "segments_encode_known: the previous encode was not collected");
     c->sg_valid = 0;
     if (!c->sg_ne) {
         /* (nothing known: an empty encode is in flight, as on the device) */
-        c->enc_n = 0;
-        c->enc_eoff = (u64 *)calloc(1, 8);
-        c->enc_out = (u8 *)malloc(1);
-        c->enc_pending = 1;
+        c->enc[lane].n = 0;
+        c->enc[lane].eoff = (u64 *)calloc(1, 8);
+        c->enc[lane].out = (u8 *)malloc(1);
+        c->enc[lane].pending = 1;
         return AGC_HIP_OK;
     }
     return agc_hip_lz_encode_begin_dev(c, c->sg_ne, c->sg_gid, c->sg_codes, c->sg_off, c->sg_len, c->sg_rc);

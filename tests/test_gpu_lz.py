@@ -282,6 +282,16 @@ def test_packed_entry_points_match_oracle(hip_ctx, oracle, registered, gap_fill)
     enc2, eoff2 = hip_ctx.lz_encode_end()
     one, ooff = hip_ctx.lz_encode_batch_packed(pk, gids, off, ln)
     assert np.array_equal(enc2, one) and np.array_equal(eoff2, ooff)
+    # two encodes in flight, one per lane (AGC_HIP_ENCODE_LANES), collected in the other order; lane 1 with every other segment
+    half = np.arange(0, len(registered), 2)
+    hip_ctx.lz_encode_begin_packed(pk, gids, off, ln, lane=0)
+    hip_ctx.lz_encode_begin_packed(pk, gids[half], off[half], ln[half], rc=np.ones(half.size, np.uint8), lane=1)
+    cost2, _ = hip_ctx.lz_estimate_batch_packed(pk, gids, off, ln)
+    enc_b, eoff_b = hip_ctx.lz_encode_end_on(1)
+    enc_a, eoff_a = hip_ctx.lz_encode_end_on(0)
+    assert np.array_equal(enc_a, one) and np.array_equal(eoff_a, ooff)
+    want_b, woff_b = hip_ctx.lz_encode_batch_packed(pk, gids[half], off[half], ln[half], rc=np.ones(half.size, np.uint8))
+    assert np.array_equal(enc_b, want_b) and np.array_equal(eoff_b, woff_b)
     for i, (_m, _r, text) in enumerate(registered):
         assert np.array_equal(back[int(boff[i]):int(boff[i + 1])], oracle.rev_comp(text) if i % 2 else text), i
     cnt, cur = hip_ctx.ref_lag_counts_packed(pk, off, ln)
