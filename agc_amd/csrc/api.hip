@@ -2306,7 +2306,7 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
                                  zs_));
         {
             ZTimer t(c);
-            const uint32_t dbg = (uint32_t)(getenv("AGC_HIP_ZSTD_DEBUG") ? atoi(getenv("AGC_HIP_ZSTD_DEBUG")) : 0);
+            const uint32_t dbg = 0; // (the kernels' trace word: a debugging build sets it)
             const dim3 block(64);
             if (m_one) {
                 // frames per wave: fewer = fewer distinct parser states per trip of the micro-step loop, but every wave of the
@@ -2319,8 +2319,6 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
                             lanes = cand;
                             break;
                         }
-                if (const char *e = getenv("AGC_HIP_ZSTD_LANES"))
-                    lanes = (uint32_t)std::min(64, std::max(1, atoi(e)));
                 const dim3 grid((m_one + lanes - 1) / lanes);
                 const ZFrameJob *dj = (const ZFrameJob *)c->d_zjobs.p + done;
                 if (c->zstd_background)

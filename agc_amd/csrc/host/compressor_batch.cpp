@@ -367,8 +367,8 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         for (uint32_t i : dev_jobs)
             total += src_size(i);
         // (length of a frame's serial chain: level 17 parses inputs of up to 16 KB twice -- btultra2 -- and larger ones once,
-        // with a deeper search; AGC_AMD_ZSTD_CHAIN_W: relative cost of a position of the larger class, in percent)
-        static const uint64_t w_big = getenv("AGC_AMD_ZSTD_CHAIN_W") ? strtoull(getenv("AGC_AMD_ZSTD_CHAIN_W"), nullptr, 10) : 150;
+        // with a deeper search: 150 against 200 per position, from the measured launch times of the two classes)
+        const uint64_t w_big = 150;
         auto chain = [&](uint32_t i) -> uint64_t {
             const uint64_t sz = src_size(i);
             if (jobs[i].kind == 0 && jobs[i].level == 13) // one pass, a shallow search (searchLog 5 / 3)
@@ -381,10 +381,9 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         // frame whatever their number (a frame is a serial chain; a second round would last as long as the first): when there are
         // more packs than that, the host pool takes the SMALLEST ones (the fewest bytes per frame taken off the device); then the
         // largest ones move over until the device's byte share is the one that lets both sides finish together.
-        // (AGC_AMD_ZSTD_EXTRA_FRAMES: frames beyond one resident round.  The launch is sorted longest first, so the waves of the
-        // smallest frames retire early and the extra ones -- smaller still -- take their slots while the largest are still at work)
-        static const uint32_t extra_frames = getenv("AGC_AMD_ZSTD_EXTRA_FRAMES") ? (uint32_t)strtoul(getenv("AGC_AMD_ZSTD_EXTRA_FRAMES"), nullptr, 10) : 0u;
-        const uint32_t resident = std::max<uint32_t>(1u, agc_hip_zstd17_resident_frames(hip)) + extra_frames;
+        // (frames beyond one resident round were measured in round 3: +2 500 of the 50 k packs of a human Close() take the device
+        // from 0.64 to 0.99 s -- profiles/r3/bookkeeping_thread_and_extra_frames.txt)
+        const uint32_t resident = std::max<uint32_t>(1u, agc_hip_zstd17_resident_frames(hip));
         size_t lo = 0, hi = by_size.size();
         // (a handful of packs beyond 16 KiB -- the one-lane kernel's class, a launch of its own that lasts as long as a whole
         // launch of small frames -- is the host pool's: by_size ends with them)

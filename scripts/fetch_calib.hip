@@ -6,6 +6,10 @@
 //   calib_probe_row   the exact-step probe: 64 lanes read 64 consecutive 4-B slots at a random 4-B aligned row start
 //   calib_probe16     the wide literal probe: every lane one 16-B load at its own random 4-B aligned address
 //   calib_byte16      the match compare: every lane one 16-B load, lanes consecutive, base address byte-aligned (odd)
+//   calib_probe4      the zstd match finder's pattern: every lane one 4-B load at its own random 64-B aligned address
+//   calib_probe4_pair the same plus the 4 bytes 64 B further in the same 128-B aligned line: FETCH_SIZE per lane equal to
+//                     calib_probe4's means the memory side moves 128-B lines (and the counter's unit is to be read accordingly);
+//                     twice calib_probe4's means 64-B requests, counted as they are
 // The program prints the bytes each kernel asks for; FETCH_SIZE (KB) of the same dispatch is the other half of the ratio.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -63,6 +67,31 @@ __global__ void calib_byte16(const uint8_t *t, uint64_t nbytes, uint32_t *sink)
     if (acc == 0x12345678u) *sink = acc;
 }
 
+__global__ void calib_probe4(const uint8_t *t, uint64_t nbytes, uint32_t iters, uint32_t pair, uint32_t *sink)
+{
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t a = (mix((tid << 20) | it | 0x80000ull) % (nbytes >> 7)) << 7; // a 128-B aligned line of its own
+        acc ^= *(const uint32_t *)(t + a);
+        if (pair)
+            acc ^= *(const uint32_t *)(t + a + 64);
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+__global__ void calib_probe4_pair(const uint8_t *t, uint64_t nbytes, uint32_t iters, uint32_t pair, uint32_t *sink)
+{
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t a = (mix((tid << 20) | it | 0x80000ull) % (nbytes >> 7)) << 7;
+        acc ^= *(const uint32_t *)(t + a);
+        if (pair)
+            acc ^= *(const uint32_t *)(t + a + 64);
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
 int main()
 {
     const uint64_t nbytes = 4ull << 30;
@@ -89,6 +118,14 @@ int main()
     hipLaunchKernelGGL(calib_byte16, dim3(grid), dim3(block), 0, 0, (const uint8_t *)t, nbytes, sink);
     hipDeviceSynchronize();
     printf("calib_byte16     asks for %llu bytes (16 B per lane, coalesced, base + 3)\n", (unsigned long long)((nbytes - 64) / 16 * 16));
+    hipLaunchKernelGGL(calib_probe4, dim3(grid), dim3(block), 0, 0, (const uint8_t *)t, nbytes, iters, 0u, sink);
+    hipDeviceSynchronize();
+    printf("calib_probe4     asks for %llu bytes = %llu loads of 4 B, each in a 128-B line of its own (4 GiB table)\n",
+           (unsigned long long)grid * block * iters * 4ull, (unsigned long long)grid * block * iters);
+    hipLaunchKernelGGL(calib_probe4_pair, dim3(grid), dim3(block), 0, 0, (const uint8_t *)t, nbytes, iters, 1u, sink);
+    hipDeviceSynchronize();
+    printf("calib_probe4_pair asks for %llu bytes = %llu pairs of 4-B loads 64 B apart in one 128-B line\n",
+           (unsigned long long)grid * block * iters * 8ull, (unsigned long long)grid * block * iters);
     hipFree(t);
     hipFree(sink);
     return 0;
