@@ -109,15 +109,23 @@ def pmc_table():
     return tab
 
 
+# Kernels whose loads are narrow and scattered (one 4-byte word per lane in a line of its own: the zstd match finder's hash /
+# chain / tree tables).  profiles/r4/fetch_calibration.txt: calib_probe4 (134 M such loads in a 4 GiB table) counts 63.9 B per
+# load, calib_probe4_pair (the same plus the word 64 B further in the same 128-B line) 1.71 x that -- the memory side serves them
+# as 64-B requests and FETCH_SIZE counts those as they are; the x2 of the guide belongs to wide coalesced loads (calib_stream:
+# 0.50 of the bytes asked for).
+NARROW_LOADS = {"zstd"}
+
+
 def pmc_traffic(tab, name):
     """HBM bytes per launch: FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies the 128-B requests of wide coalesced
-    loads as 64 B; profiles/r2/fetch_calibration.txt holds this repo's own calibration incl. the 16-B table probes) + WRITE_SIZE.
-    The x2 is calibrated for wide coalesced reads only: for kernels whose reads are narrow and scattered (the zstd match finder)
-    the true figure lies between the uncorrected and the corrected sum -- pmc_traffic_range() states both."""
+    loads as 64 B) + WRITE_SIZE -- except for the kernels of NARROW_LOADS, whose requests the counter tallies as they are
+    (this repo's calibration, see above): FETCH_SIZE + WRITE_SIZE.  pmc_traffic_range() states both sums for every kernel: a
+    kernel that mixes streaming reads with table probes (the LZ parses) lies in between."""
     c = tab.get(KERNEL_SYMBOL[name])
     if not c or "FETCH_SIZE" not in c:
         return None
-    return int((2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
+    return int(((1.0 if name in NARROW_LOADS else 2.0) * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
 
 
 def pmc_traffic_range(tab, name):
@@ -530,6 +538,7 @@ def main():
                             "frac": round(ach / HBM_PEAK_GBS, 5)}
             tr = pmc_traffic(tab, name)
             row["traffic"] = tr
+            row["traffic_range"] = pmc_traffic_range(tab, name)
             row["waste"] = round(tr / row["as_built"]["algorithmic_bytes"], 2) if tr and row["as_built"]["algorithmic_bytes"] else None
             kern[name] = row
         # the entropy stage's kernel (zstd level 17 of the delta packs, one group of lanes per frame): its launches belong to
@@ -599,7 +608,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("as_built", {}).get("frac"),
                          "frac_packed_2bit": dom.get("packed_2bit", {}).get("frac"),
                          "traffic": dom.get("traffic"), "traffic_range": dom.get("traffic_range"), "waste": dom.get("waste"),
-                         "traffic_source": PMC_SUMMARY + " (2 x FETCH_SIZE + WRITE_SIZE, max over dispatches, per launch)" if dom.get("traffic") else None,
+                         "traffic_source": (PMC_SUMMARY + " (max over dispatches, per launch; traffic_range = [FETCH_SIZE + WRITE_SIZE, 2 x FETCH_SIZE "
+                                            "+ WRITE_SIZE]; traffic = the upper end for streaming kernels, the lower end for the zstd kernels, whose "
+                                            "4-byte scattered loads the counter tallies as 64-B requests: profiles/r4/fetch_calibration.txt)") if dom.get("traffic") else None,
                          "algorithmic_bytes_per_launch": dom.get("as_built", {}).get("algorithmic_bytes"),
                          "avg_launch_ms": dom.get("avg_launch_ms", dom.get("ms_per_step")),
                          "dominant_by": "largest kernel time per step among ALL kernels of the path (scan, encode, estimate, cost vectors, "

@@ -13,7 +13,7 @@ B="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 # the PMC passes run the driver's own shape (25 samples: the packs of Close() are what the entropy kernel really sees)
 BP="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/ktrace -o kt -- $BP > $ROOT/$OUT/ktrace.log 2>&1)
-if ! ls $OUT/ktrace/*kernel_stats.csv $OUT/ktrace/*/*kernel_stats.csv >/dev/null 2>&1; then
+if [ -z "$(find $OUT/ktrace -name "*kernel_stats.csv" 2>/dev/null)" ]; then
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/ktrace_qb -o kt -- python $ROOT/scripts/quick_bench.py 3e9 > $ROOT/$OUT/ktrace_qb.log 2>&1)
 fi
 (cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv --kernel-include-regex agc -d $ROOT/$OUT/pmc_fetch -o pf -- $BP > $ROOT/$OUT/pmc_fetch.log 2>&1)

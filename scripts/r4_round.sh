@@ -24,7 +24,7 @@ if [ "$PART" = a ]; then
   for cfg in c1 c4twin c5twin; do timeout 600 python bench.py --config $cfg > $OUT/bench_config_$cfg.json 2> $OUT/bench_config_$cfg.err; tail -c 600 $OUT/bench_config_$cfg.json; echo; done
   AGC_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks.json 2> $OUT/bench_one_gpu_2_ranks.err; show $OUT/bench_one_gpu_2_ranks.json
   AGC_BENCH_ONE_GPU=1 AGC_BENCH_SERIAL_PREPARE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks_serial_prepare.json 2> $OUT/bench_one_gpu_2_ranks_serial_prepare.err; show $OUT/bench_one_gpu_2_ranks_serial_prepare.json
-  timeout 900 python scripts/c3_full_identity.py > $OUT/c3_full_size_identity_5_samples.log 2>&1; tail -4 $OUT/c3_full_size_identity_5_samples.log
+  timeout 900 python scripts/c3_full_identity.py 3.0 5 87fa6261593cd046a4ec7ecc8ec216686e6d82cd39b62edb2c031141e83517fa > $OUT/c3_full_size_identity_5_samples.log 2>&1; tail -4 $OUT/c3_full_size_identity_5_samples.log
 else
   bash scripts/profile_round.sh r4
   LZ_PMC_KERNELS="lz_parse_kernel|scan_packed|key_filter|split_point|idx_|known_|group_lookup" bash scripts/lz_pmc_probe.sh r4 > $OUT/lz_pmc_probe.log 2>&1; tail -5 $OUT/lz_pmc_probe.log
