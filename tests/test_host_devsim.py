@@ -168,11 +168,55 @@ def test_bookkeeping_beside_the_next_registration_gives_the_same_archive(cli, na
         assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("env", [{"AGC_AMD_ASYNC_ENCODE": "0", "AGC_AMD_WINDOW_MAX": "1"},
+                                 {"AGC_AMD_ASYNC_ENCODE": "0", "AGC_AMD_ASYNC_BOOK": "0", "AGC_AMD_WINDOW_MAX": "1"},
+                                 {"AGC_AMD_DEV_SEGMENTS": "0", "AGC_AMD_ASYNC_ENCODE": "0", "AGC_AMD_WINDOW_MAX": "1", "AGC_AMD_SYNC_ENTROPY": "1"},
+                                 {"AGC_ZSTD_LIB": "libzstd.so.1"},
+                                 {"AGC_AMD_GPU_ZSTD": "0"}], ids=lambda e: "+".join(f"{k[8:] if k.startswith('AGC_AMD_') else k}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_c4_twin"])
+def test_switch_combinations_keep_the_archive(cli, name, env, tmp_path, monkeypatch):
+    """the behaviour switches of DESIGN.md 11 that no other test sets, alone and combined with the ones that gate the threads:
+    the encode collected by the calling thread, with and without the bookkeeping thread, on top of host-cut segments and a
+    synchronous entropy stage; libzstd named explicitly; the device entropy stage off -- the reference's bytes every time"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
+def test_producer_tag_changes_one_stream_only(cli, tmp_path, monkeypatch):
+    """AGC_AMD_PRODUCER_TAG=1: an honest producer string in file_type_info -- the archive differs from the reference's, its
+    samples do not"""
+    args, _ = C.CONFIGS["syn_mixed"]
+    files = C.build("syn_mixed", str(tmp_path / "in"))
+    plain = _create(cli, args, files, str(tmp_path / "a.agc"))
+    monkeypatch.setenv("AGC_AMD_PRODUCER_TAG", "1")
+    tagged = _create(cli, args, files, str(tmp_path / "b.agc"))
+    assert hashlib.sha256(plain).hexdigest() == GOLD["syn_mixed"]["sha256"] and tagged != plain
+    assert abs(len(tagged) - len(plain)) < 256
+    monkeypatch.delenv("AGC_AMD_PRODUCER_TAG")
+    names = subprocess.run([cli, "listset", str(tmp_path / "a.agc")], capture_output=True, timeout=60).stdout
+    assert names and subprocess.run([cli, "listset", str(tmp_path / "b.agc")], capture_output=True, timeout=60).stdout == names
+    for sn in names.decode().split()[:3]:
+        a = subprocess.run([cli, "getset", str(tmp_path / "a.agc"), sn], capture_output=True, timeout=60).stdout
+        # (the streamed reader too: AGC_AMD_NO_MMAP=1 reads the archive whole instead of mapping it)
+        monkeypatch.setenv("AGC_AMD_NO_MMAP", "1")
+        b = subprocess.run([cli, "getset", str(tmp_path / "b.agc"), sn], capture_output=True, timeout=60).stdout
+        monkeypatch.delenv("AGC_AMD_NO_MMAP")
+        assert a and a == b, sn
+
+
+@pytest.mark.parametrize("defer_mb", [None, "0"])
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_adaptive"])
-def test_two_ranks_in_one_process_write_the_reference_archive(name, tmp_path):
+def test_two_ranks_in_one_process_write_the_reference_archive(name, defer_mb, tmp_path, monkeypatch):
     """the multi-GPU protocol without torch: two compressors in one process (tests/devsim/two_ranks_one_process.cpp) -- prepare
     ahead, commit in two steps (head out first, then finish + body), the writer applying records into its bookkeeping queue --
-    give the reference's archive.  scripts/tsan_check.sh runs the same tool under ThreadSanitizer."""
+    give the reference's archive.  scripts/tsan_check.sh runs the same tool under ThreadSanitizer.
+    AGC_AMD_DEFER_MAX_MB=0: the writer keeps no full pack for the distributed Close, its own entropy stage takes them as they fill."""
+    if defer_mb is not None:
+        monkeypatch.setenv("AGC_AMD_DEFER_MAX_MB", defer_mb)
     exe = simbuild.build_two_ranks()
     args, _ = C.CONFIGS[name]
     opt = {"-k": 31, "-l": 20, "-s": 60000, "-b": 50}
