@@ -642,6 +642,20 @@ void CAGCCompressor::Impl::launch_prefetch()
     pf_live.valid = true;
 }
 
+namespace {
+constexpr uint64_t CompressorStats::*PREPARE_STATS[] = {&CompressorStats::bases, &CompressorStats::one_splitter, &CompressorStats::middle_tried,
+                                                         &CompressorStats::middle_split, &CompressorStats::lz_encoded, &CompressorStats::delta_bytes,
+                                                         &CompressorStats::enc_text, &CompressorStats::enc_ref, &CompressorStats::est_text,
+                                                         &CompressorStats::est_ref, &CompressorStats::cv_text, &CompressorStats::cv_ref,
+                                                         &CompressorStats::windows};
+void snapshot_prepare_stats(const CompressorStats &st, uint64_t *out)
+{
+    size_t t = 0;
+    for (uint64_t CompressorStats::*f : PREPARE_STATS)
+        out[t++] = st.*f;
+}
+} // namespace
+
 // scan + classification + speculative encode of a sample, against the state this process has NOW; nothing is registered
 // yet.  d_codes must stay untouched until CommitPrepared.  In the multi-GPU mode a rank calls this for its next sample
 // while earlier samples are still being committed elsewhere (agc_amd/dist.py).
@@ -691,7 +705,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
     I.prep.base_owned = I.next_base_owned;
     I.prep.deferred = false;
     I.prep.spl_version = I.spl_version;
-    I.prep.st_before = I.st;
+    snapshot_prepare_stats(I.st, I.prep.st_before);
     I.prepared->no_new_splitters = ahead && I.adaptive;
     if (!I.batch_prepare(*I.prepared, I.prepared_ctgs, d_codes, nullptr, ahead)) {
         I.prepared.reset();
@@ -701,7 +715,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
         I.prepared.reset();
         I.prep.deferred = true;
     }
-    I.prep.st_after = I.st;
+    snapshot_prepare_stats(I.st, I.prep.st_after);
     return true;
 }
 
@@ -721,12 +735,9 @@ bool CAGCCompressor::CommitPreparedHead()
         // (what the dropped prepare counted -- bases, texts handed to the LZ kernels, deltas -- is taken back: the sample is
         // counted once, by the prepare that stands)
         if (I.prepared) {
-            const CompressorStats &a = I.prep.st_after, &b0 = I.prep.st_before;
-            for (uint64_t CompressorStats::*f : {&CompressorStats::bases, &CompressorStats::one_splitter, &CompressorStats::middle_tried,
-                                                 &CompressorStats::middle_split, &CompressorStats::lz_encoded, &CompressorStats::delta_bytes,
-                                                 &CompressorStats::enc_text, &CompressorStats::enc_ref, &CompressorStats::est_text, &CompressorStats::est_ref,
-                                                 &CompressorStats::cv_text, &CompressorStats::cv_ref, &CompressorStats::windows})
-                I.st.*f -= a.*f - b0.*f;
+            size_t t = 0;
+            for (uint64_t CompressorStats::*f : PREPARE_STATS)
+                I.st.*f -= I.prep.st_after[t] - I.prep.st_before[t], ++t;
         }
         ++I.st.reprepared;
         I.prepared.reset(new Impl::BatchState());

@@ -965,7 +965,10 @@ struct CAGCCompressor::Impl {
         bool base_owned = false;
         bool deferred = false;      // no prepared state: prepare at the turn
         uint64_t spl_version = 0;   // splitter set the prepared state was scanned with
-        CompressorStats st_before, st_after; // the counters around the prepare (its share is taken back when the prepared state is dropped)
+        // the counters a prepare adds to, around the prepare (its share is taken back when the prepared state is dropped).  Only the
+        // fields the thread that drives the steps owns: a copy of the whole struct would read what the entropy thread is writing
+        static constexpr size_t N_PREP_STATS = 13;
+        uint64_t st_before[N_PREP_STATS] = {}, st_after[N_PREP_STATS] = {};
     } prep;
     uint64_t spl_version = 0;       // bumped whenever splitters are added (own samples, applied records)
     std::vector<Contig> prepared_ctgs;
