@@ -70,7 +70,7 @@ uint8_t *CAGCCompressor::RecordBodyBuffer(size_t n)
 }
 bool CAGCCompressor::ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record, const uint8_t *body, size_t body_n)
 {
-    if (!p->created || p->dist_world < 2 || p->appending || p->concatenated)
+    if (!p->created || p->dist_world < 2 || p->appending)
         return false;
     return p->apply_record(record, n, d_record, body, body_n);
 }
@@ -663,7 +663,9 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
                                          const uint64_t *ctg_off)
 {
     Impl &I = *p;
-    if (!I.created || I.concatenated || I.prepared || I.committing || I.prep.deferred)
+    // (-c mode: the caller hands over the reference's registration units -- runs of pack_cardinality contigs, sample name empty:
+    // every contig is a sample of its own -- and, at the end, the empty one the reference always sends, agc_compressor.cpp:2231-2238)
+    if (!I.created || I.prepared || I.committing || I.prep.deferred)
         return false;
     // a sample handed over one byte per symbol is packed first (context-owned buffers: they outlive this call)
     struct Unpack {
@@ -769,7 +771,7 @@ bool CAGCCompressor::CommitPreparedHead()
                 return false; // (AddSampleFiles skips such contigs; a device-resident sample is all or nothing)
             }
     }
-    if (I.prepared_ctgs.empty()) {
+    if (I.prepared_ctgs.empty() && !I.concatenated) {
         // a sample without contigs registers nothing (the reference warns and skips such a file, agc_compressor.cpp:2187-2195);
         // the other ranks still expect one record per sample: an empty one
         if (I.dist_world > 1)

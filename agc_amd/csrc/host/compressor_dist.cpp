@@ -228,8 +228,9 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
         err("truncated commit record");
         return false;
     }
-    if (n_ctg == 0 && n_lists == 0 && n_spl == 0 && n_new == 0)
-        return rr.p == rr.e; // empty sample: skipped on every rank
+    if (n_ctg == 0 && n_lists == 0 && n_spl == 0 && n_new == 0 && !concatenated)
+        return rr.p == rr.e; // empty sample: skipped on every rank (-c: the registration without contigs the reference sends at the end
+                             // still moves the sample counters on the writer: after_registration)
     const bool writer = dist_rank == dist_writer;
     size_t body_pos = 0; // (a record without deltas has no body: every kind-2 payload is checked against body_n below)
     // the body came in through RecordBodyBuffer: the bookkeeping reads it where it is

@@ -19,11 +19,32 @@ The head carries the symbols of every new reference (the "all-gather of newly-mi
 star -- a broadcast from the minting rank, since exactly one rank mints at a time) and the raw segments: ~3 MB per human-size
 sample; the body the deltas (~16 B per SNP): ~22 MB.  The archive is byte-identical to the single-GPU / reference one.
 
-Not covered in this mode: -c (concatenated) and append.
+-c (concatenated genomes): the unit that is dealt round-robin is the reference's own registration unit -- a run of pack_cardinality
+contigs across the input files, each contig a sample of its own -- followed by the empty registration the reference always sends at
+the end (agc_compressor.cpp:2155-2238); concatenated_units() below cuts them.  Not covered in this mode: append.
 """
 import time
 
 import numpy as np
+
+
+def concatenated_units(contig_names_per_file, pack_cardinality):
+    """-c mode.  contig_names_per_file: for every input file, in command-line order, the names of its contigs.
+    -> list of units; a unit = list of (file index, contig index) in order.  A contig whose name was seen before is skipped as the
+    reference skips it ("already in the archive", agc_compressor.cpp:2201-2205); the last unit is what is left (possibly empty):
+    the registration token the reference sends after the last file."""
+    units, cur, seen = [], [], set()
+    for fi, names in enumerate(contig_names_per_file):
+        for ci, name in enumerate(names):
+            if name in seen:
+                continue
+            seen.add(name)
+            cur.append((fi, ci))
+            if len(cur) >= pack_cardinality:
+                units.append(cur)
+                cur = []
+    units.append(cur)
+    return units
 
 
 class DistCompressor:

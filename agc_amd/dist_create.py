@@ -1,9 +1,10 @@
 """`agc create` on N GPUs into ONE archive (agc_amd/dist.py).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-        -m agc_amd.dist_create [-k 31] [-l 20] [-s 60000] [-b 50] [-a] [-t threads] -o out.agc ref.fa s1.fa s2.fa.gz ...
+        -m agc_amd.dist_create [-k 31] [-l 20] [-s 60000] [-b 50] [-a] [-c] [-t threads] -o out.agc ref.fa s1.fa s2.fa.gz ...
 
-Options as `agc create` (no -c).  Rank r reads, uploads and classifies the files r, r+N, ...; rank 0 writes the archive, which is
+Options as `agc create`.  Rank r reads, uploads and classifies the files r, r+N, ... (-c: the registration units r, r+N, ... --
+runs of -b contigs across the files); rank 0 writes the archive, which is
 byte-identical to what the single-GPU `agc_amd create` and the reference CLI write for the same command line."""
 import argparse
 import os
@@ -17,6 +18,7 @@ def main(argv=None):
     ap.add_argument("-s", type=int, default=60000)
     ap.add_argument("-b", type=int, default=50)
     ap.add_argument("-a", action="store_true")
+    ap.add_argument("-c", action="store_true", help="concatenated genomes: every contig is a sample")
     ap.add_argument("-t", type=int, default=0)
     ap.add_argument("-o", required=True)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (ranks may share a GPU)")
@@ -27,7 +29,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from agc_amd import fasta, host
-    from agc_amd.dist import DistCompressor
+    from agc_amd.dist import DistCompressor, concatenated_units
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
@@ -46,7 +48,7 @@ def main(argv=None):
     cmp_ = host.Compressor(local)
     cmp_.set_distributed(rank, world, 0)
     cmp_.create(a.o if rank == 0 else "", pack_cardinality=a.b, k=a.k, ref_file=files[0], segment_size=a.s, min_match_len=a.l,
-                adaptive=a.a, n_threads=threads if rank == 0 else 2)
+                concatenated=a.c, adaptive=a.a, n_threads=threads if rank == 0 else 2)
     dc = DistCompressor(cmp_, dist, rank, world, device=dev)
     keep = {}
 
@@ -57,7 +59,28 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
         return fasta.sample_name(files[i]), names, keep[i].data_ptr(), off
 
-    dc.compress(len(files), get_sample, prefetch=True)  # (-a too: a sample that needs new splitters is prepared again at its turn)
+    n_units = len(files)
+    if a.c:
+        # the reference's registration units: runs of -b contigs across the files, every contig a sample of its own (sample name "")
+        units = concatenated_units([fasta.read_codes(f)[0] for f in files], a.b)
+        n_units = len(units)
+
+        def get_sample(i):  # noqa: F811
+            keep.pop(i - world, None)
+            names, parts, off, cache = [], [], [0], {}
+            for fi, ci in units[i]:
+                if fi not in cache:
+                    cache = {fi: fasta.read_codes(files[fi])}
+                fn, fc, fo = cache[fi]
+                names.append(fn[ci])
+                parts.append(fc[int(fo[ci]):int(fo[ci + 1])])
+                off.append(off[-1] + parts[-1].size)
+            codes = np.concatenate(parts + [np.full(4096, 4, np.uint8)])
+            keep[i] = torch.from_numpy(codes).to(dev)
+            torch.cuda.synchronize(dev)
+            return "", names, keep[i].data_ptr(), np.asarray(off, np.uint64)
+
+    dc.compress(n_units, get_sample, prefetch=True)  # (-a too: a sample that needs new splitters is prepared again at its turn)
     dc.close(n_threads=threads if rank == 0 else 2)  # the delta packs are entropy-coded on every rank's GPU
     cmp_.close_handle()
     dist.barrier()

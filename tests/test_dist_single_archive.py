@@ -64,13 +64,27 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
         cmp_ = host.Compressor(lib=lib)
         cmp_.set_distributed(rank, world, 0)
         cmp_.create(out_path if rank == 0 else "", pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"],
-                    min_match_len=opt["-l"], adaptive="-a" in args, n_threads=2)
+                    min_match_len=opt["-l"], concatenated="-c" in args, adaptive="-a" in args, n_threads=2)
         dc = DistCompressor(cmp_, dist, rank, world, device=device)
         keep = {}
+        units = None
+        if "-c" in args:  # the reference's registration units: runs of -b contigs across the files, sample name ""
+            from agc_amd.dist import concatenated_units
+            units = concatenated_units([fasta_codes(f)[0] for f in files], opt["-b"])
 
         def get_sample(i):
-            names, codes, off = fasta_codes(files[i])
-            sn = os.path.basename(files[i])
+            if units is not None:
+                names, parts, off = [], [], [0]
+                for fi, ci in units[i]:
+                    fn, fc, fo = fasta_codes(files[fi])
+                    names.append(fn[ci])
+                    parts.append(fc[int(fo[ci]):int(fo[ci + 1])])
+                    off.append(off[-1] + parts[-1].size)
+                codes = np.concatenate(parts + [np.full(4096, 4, np.uint8)])
+                sn, off = "", np.asarray(off, np.uint64)
+            else:
+                names, codes, off = fasta_codes(files[i])
+                sn = os.path.basename(files[i])
             for suf in (".gz", ".fa", ".fasta", ".fna"):
                 sn = sn[:-len(suf)] if sn.endswith(suf) else sn
             if on_gpu:
@@ -80,9 +94,9 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
             keep[i] = codes
             return sn, names, codes.ctypes.data, off
 
-        if prefetch:
-            dc.compress(len(files), get_sample, prefetch=True)  # (also in adaptive mode: a prepare that needs new splitters waits for its turn)
-        for i, f in enumerate(files if not prefetch else []):
+        if prefetch or units is not None:
+            dc.compress(len(files) if units is None else len(units), get_sample, prefetch=prefetch)  # (also in adaptive mode: a prepare that needs new splitters waits for its turn)
+        for i, f in enumerate(files if not prefetch and units is None else []):
             if dc.owner_of(i) == rank:
                 names, codes, off = fasta_codes(f)
                 sn = os.path.basename(f)
@@ -161,6 +175,15 @@ def test_prefetching_ranks_still_write_the_reference_archive(name, world, tmp_pa
         assert sum(r[5] for r in res) == 0
 
 
+@pytest.mark.parametrize("name,world,prefetch", [("syn_viral_c", 2, False), ("syn_viral_c", 3, True), ("syn_adaptive_c", 2, True)])
+def test_concatenated_mode_from_n_ranks_equals_the_reference(name, world, prefetch, tmp_path):
+    """-c: the units dealt round-robin are the reference's registration units (runs of -b contigs across the files, every contig
+    a sample of its own, then the empty registration the reference sends at the end) -- agc_amd.dist.concatenated_units"""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    _run(name, world, tmp_path, on_gpu=False, prefetch=prefetch)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 3)])
 def test_prefetching_ranks_on_the_gpu(name, world, tmp_path):
@@ -181,13 +204,14 @@ def test_one_archive_from_n_ranks_on_the_gpu(name, world, tmp_path):
 
 
 @pytest.mark.gpu
-def test_dist_create_front_end_on_the_gpu(tmp_path):
-    """python -m agc_amd.dist_create under torch.distributed.run, two ranks sharing cuda:0 (gloo): the user-facing multi-GPU create"""
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_viral_c"])
+def test_dist_create_front_end_on_the_gpu(name, tmp_path):
+    """python -m agc_amd.dist_create under torch.distributed.run, two ranks sharing cuda:0 (gloo): the user-facing multi-GPU create
+    (syn_viral_c: -c, the registration units of the concatenated mode dealt over the ranks)"""
     import subprocess
     import sys
     from agc_amd import build
     build.build_host()
-    name = "syn_mixed"
     args, _ = COLL.CONFIGS[name]
     files = COLL.build(name, str(tmp_path / "in"))
     out = str(tmp_path / "d.agc")
