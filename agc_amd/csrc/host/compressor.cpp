@@ -70,7 +70,7 @@ uint8_t *CAGCCompressor::RecordBodyBuffer(size_t n)
 }
 bool CAGCCompressor::ApplyRecord(const uint8_t *record, size_t n, const uint8_t *d_record, const uint8_t *body, size_t body_n)
 {
-    if (!p->created || p->dist_world < 2 || p->appending)
+    if (!p->created || p->dist_world < 2)
         return false;
     return p->apply_record(record, n, d_record, body, body_n);
 }
@@ -504,6 +504,10 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     for (auto &t : I.terminators)
         std::sort(t.second.begin(), t.second.end());
     I.coll.reset_prev_sample_name();
+    // (the sample counters of a session that adds through the device API / commit records; AddSampleFiles sets them itself,
+    // agc_compressor.cpp:2150-2153)
+    I.processed_samples = (uint32_t)I.coll.no_samples();
+    I.stored_samples = I.processed_samples / I.pack_cardinality * I.pack_cardinality;
     return true;
 }
 
@@ -707,6 +711,7 @@ bool CAGCCompressor::PrepareSampleDevice(const std::string &sample_name, const s
     I.prep.base_owned = I.next_base_owned;
     I.prep.deferred = false;
     I.prep.spl_version = I.spl_version;
+    I.prep.ahead = ahead;
     snapshot_prepare_stats(I.st, I.prep.st_before);
     I.prepared->no_new_splitters = ahead && I.adaptive;
     if (!I.batch_prepare(*I.prepared, I.prepared_ctgs, d_codes, nullptr, ahead)) {
@@ -731,7 +736,9 @@ bool CAGCCompressor::CommitPreparedHead()
     Impl &I = *p;
     if (I.committing)
         return false;
-    if (I.dist_world > 1 && I.adaptive && (I.prep.deferred || (I.prepared && I.prep.spl_version != I.spl_version))) {
+    // (only a prepare made AHEAD of the turn can be stale: one made at its turn -- append mode -- mined its own new splitters, which is
+    // what moved spl_version)
+    if (I.dist_world > 1 && I.adaptive && I.prep.ahead && (I.prep.deferred || (I.prepared && I.prep.spl_version != I.spl_version))) {
         // adaptive mode, the sample's turn: the speculative prepare did not stand (new splitters needed, or brought by the samples
         // in front) -- the plain prepare, against the state as it is now
         // (what the dropped prepare counted -- bases, texts handed to the LZ kernels, deltas -- is taken back: the sample is

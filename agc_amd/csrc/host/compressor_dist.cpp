@@ -280,6 +280,10 @@ bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint
     std::vector<uint64_t> reg_off; // payload offsets inside the record (device copy)
     for (uint32_t li = 0; li < n_lists && rr.ok; ++li) {
         const uint32_t gid = rr.u32(), cnt = rr.u32();
+        // append mode: the first add to a group of the input archive unpacks it -- on every rank, as on the owner (stage_register;
+        // segment.cpp:19-20, 39-40): the reference goes to this rank's HBM, the group stops answering as a packed one
+        if (appending && gid < groups.size() && groups[gid].packed && !unpack_group(gid))
+            return false;
         sl.gids.push_back(gid);
         sl.begin.push_back((uint32_t)sl.items.size());
         for (uint32_t i = 0; i < cnt && rr.ok; ++i) {

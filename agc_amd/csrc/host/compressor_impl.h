@@ -967,6 +967,7 @@ struct CAGCCompressor::Impl {
         uint64_t spl_version = 0;   // splitter set the prepared state was scanned with
         // the counters a prepare adds to, around the prepare (its share is taken back when the prepared state is dropped).  Only the
         // fields the thread that drives the steps owns: a copy of the whole struct would read what the entropy thread is writing
+        bool ahead = false; // prepared before its turn (N-rank mode outside append): the only kind of prepare that can go stale
         static constexpr size_t N_PREP_STATS = 13;
         uint64_t st_before[N_PREP_STATS] = {}, st_after[N_PREP_STATS] = {};
     } prep;

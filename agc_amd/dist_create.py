@@ -1,10 +1,11 @@
-"""`agc create` on N GPUs into ONE archive (agc_amd/dist.py).
+"""`agc create` / `agc append` on N GPUs into ONE archive (agc_amd/dist.py).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         -m agc_amd.dist_create [-k 31] [-l 20] [-s 60000] [-b 50] [-a] [-c] [-t threads] -o out.agc ref.fa s1.fa s2.fa.gz ...
 
 Options as `agc create`.  Rank r reads, uploads and classifies the files r, r+N, ... (-c: the registration units r, r+N, ... --
 runs of -b contigs across the files); rank 0 writes the archive, which is
+(--append in.agc: every rank loads in.agc, all files are new samples, k / l / s / b come from the archive, as `agc append`)
 byte-identical to what the single-GPU `agc_amd create` and the reference CLI write for the same command line."""
 import argparse
 import os
@@ -21,9 +22,12 @@ def main(argv=None):
     ap.add_argument("-c", action="store_true", help="concatenated genomes: every contig is a sample")
     ap.add_argument("-t", type=int, default=0)
     ap.add_argument("-o", required=True)
+    ap.add_argument("--append", default=None, metavar="IN.agc", help="append the files to this archive (as `agc append`); every rank reads it")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (ranks may share a GPU)")
     ap.add_argument("files", nargs="+")
     a = ap.parse_args(argv)
+    if a.append and a.c:
+        ap.error("--append with -c: the registration units continue the input archive's last batch; use the single-GPU `agc_amd append -c`")
 
     import numpy as np
     import torch
@@ -47,8 +51,11 @@ def main(argv=None):
     threads = a.t or max(1, (os.cpu_count() or 2) // 2)
     cmp_ = host.Compressor(local)
     cmp_.set_distributed(rank, world, 0)
-    cmp_.create(a.o if rank == 0 else "", pack_cardinality=a.b, k=a.k, ref_file=files[0], segment_size=a.s, min_match_len=a.l,
-                concatenated=a.c, adaptive=a.a, n_threads=threads if rank == 0 else 2)
+    if a.append:
+        cmp_.append(a.append, a.o if rank == 0 else "", concatenated=a.c, adaptive=a.a, n_threads=threads if rank == 0 else 2)
+    else:
+        cmp_.create(a.o if rank == 0 else "", pack_cardinality=a.b, k=a.k, ref_file=files[0], segment_size=a.s, min_match_len=a.l,
+                    concatenated=a.c, adaptive=a.a, n_threads=threads if rank == 0 else 2)
     dc = DistCompressor(cmp_, dist, rank, world, device=dev)
     keep = {}
 
@@ -80,7 +87,9 @@ def main(argv=None):
             torch.cuda.synchronize(dev)
             return "", names, keep[i].data_ptr(), np.asarray(off, np.uint64)
 
-    dc.compress(n_units, get_sample, prefetch=True)  # (-a too: a sample that needs new splitters is prepared again at its turn)
+    # (-a too: a sample that needs new splitters is prepared again at its turn; append: a packed group answers Estimate with 0 until a
+    # record unpacks it, so nothing can be classified ahead of its turn)
+    dc.compress(n_units, get_sample, prefetch=not a.append)
     dc.close(n_threads=threads if rank == 0 else 2)  # the delta packs are entropy-coded on every rank's GPU
     cmp_.close_handle()
     dist.barrier()

@@ -41,7 +41,7 @@ def _sim_zstd_batch():
     return run
 
 
-def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=False):
+def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=False, append_to=None):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -63,8 +63,11 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
                 opt[args[i]] = int(args[i + 1])
         cmp_ = host.Compressor(lib=lib)
         cmp_.set_distributed(rank, world, 0)
-        cmp_.create(out_path if rank == 0 else "", pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"],
-                    min_match_len=opt["-l"], concatenated="-c" in args, adaptive="-a" in args, n_threads=2)
+        if append_to is not None:  # every rank loads the input archive; the writer copies it into the new one
+            cmp_.append(append_to, out_path if rank == 0 else "", concatenated="-c" in args, adaptive="-a" in args, n_threads=2)
+        else:
+            cmp_.create(out_path if rank == 0 else "", pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"],
+                        min_match_len=opt["-l"], concatenated="-c" in args, adaptive="-a" in args, n_threads=2)
         dc = DistCompressor(cmp_, dist, rank, world, device=device)
         keep = {}
         units = None
@@ -122,8 +125,8 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
         q.put((rank, "error: %r" % (e,), 0, 0, 0, 0, 0))
 
 
-def _run(name, world, tmp_path, on_gpu, prefetch=False):
-    files = COLL.build(name, str(tmp_path / "in"))
+def _run(name, world, tmp_path, on_gpu, prefetch=False, files=None, append_to=None, want=None):
+    files = COLL.build(name, str(tmp_path / "in")) if files is None else files
     out = str(tmp_path / "dist.agc")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -131,14 +134,15 @@ def _run(name, world, tmp_path, on_gpu, prefetch=False):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, name, files, out, q, on_gpu, prefetch)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, name, files, out, q, on_gpu, prefetch, append_to)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted(q.get(timeout=300) for _ in ps)
     [p.join(timeout=60) for p in ps]
     assert all(r[1] == "ok" for r in res), res
     got = open(out, "rb").read()
-    assert len(got) == GOLD[name]["size"]
-    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+    want = GOLD[name] if want is None else want
+    assert len(got) == want["size"]
+    assert hashlib.sha256(got).hexdigest() == want["sha256"]
     # every rank saw every record and minted the same groups
     assert len({r[2] for r in res}) == 1 and res[0][2] > 0
     assert len({r[3] for r in res}) == 1
@@ -184,6 +188,25 @@ def test_concatenated_mode_from_n_ranks_equals_the_reference(name, world, prefet
     _run(name, world, tmp_path, on_gpu=False, prefetch=prefetch)
 
 
+@pytest.mark.parametrize("plan,world", [("snp_4_3", 2), ("mixed_3_3", 2), ("viral_25_15", 3), ("shuffled_2_4", 2), ("adaptive_3_4", 2)])
+def test_append_from_n_ranks_equals_the_reference(plan, world, tmp_path):
+    """`append` in the N-rank mode: every rank loads the input archive (groups packed, references decoded into its own HBM when a
+    record first adds to a group -- apply_record unpacks exactly where the owner's registration does), samples are prepared at
+    their turn (a packed group answers Estimate with 0 until it is unpacked: nothing can be classified ahead), the writer copies
+    the old parts and appends.  Step 0 (`create`) is made by the CLI; the appended archive must be the reference CLI's."""
+    from tests.devsim import build as simbuild
+    cli = simbuild.build()
+    coll, steps = COLL.APPEND_PLANS[plan]
+    args, _ = COLL.CONFIGS[coll]
+    files = COLL.build(coll, str(tmp_path / "in"))
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "archives_append.json")))[plan]
+    import subprocess
+    step0 = str(tmp_path / "step0.agc")
+    subprocess.run([cli, "create"] + args + ["-t", "4", "-o", step0] + files[:steps[0]], check=True, capture_output=True, timeout=300)
+    assert hashlib.sha256(open(step0, "rb").read()).hexdigest() == gold[0]["sha256"]
+    _run(coll, world, tmp_path, on_gpu=False, files=files[steps[0]:steps[0] + steps[1]], append_to=step0, want=gold[1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 3)])
 def test_prefetching_ranks_on_the_gpu(name, world, tmp_path):
@@ -204,27 +227,41 @@ def test_one_archive_from_n_ranks_on_the_gpu(name, world, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["syn_mixed", "syn_viral_c"])
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_viral_c", "append:mixed_3_3"])
 def test_dist_create_front_end_on_the_gpu(name, tmp_path):
     """python -m agc_amd.dist_create under torch.distributed.run, two ranks sharing cuda:0 (gloo): the user-facing multi-GPU create
-    (syn_viral_c: -c, the registration units of the concatenated mode dealt over the ranks)"""
+    (syn_viral_c: -c, the registration units of the concatenated mode dealt over the ranks; append:<plan>: --append onto the archive
+    the single-GPU CLI made of the plan's first step)"""
     import subprocess
     import sys
     from agc_amd import build
     build.build_host()
+    extra, want = [], None
+    if name.startswith("append:"):
+        plan = name.split(":")[1]
+        name, steps = COLL.APPEND_PLANS[plan]
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "archives_append.json")))[plan]
+        want = gold[1]["sha256"]
     args, _ = COLL.CONFIGS[name]
     files = COLL.build(name, str(tmp_path / "in"))
+    if want is not None:
+        step0 = str(tmp_path / "step0.agc")
+        subprocess.run([build.HOST_BIN, "create"] + args + ["-t", "4", "-o", step0] + files[:steps[0]], check=True, capture_output=True, timeout=300)
+        assert hashlib.sha256(open(step0, "rb").read()).hexdigest() == gold[0]["sha256"]
+        extra, files = ["--append", step0], files[steps[0]:steps[0] + steps[1]]
+    else:
+        want = GOLD[name]["sha256"]
     out = str(tmp_path / "d.agc")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "agc_amd.dist_create", "--backend", "gloo"] + args + ["-t", "4", "-o", out] + files
+           "--master-port", str(port), "-m", "agc_amd.dist_create", "--backend", "gloo"] + extra + args + ["-t", "4", "-o", out] + files
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert os.path.exists(out), r.stderr[-3000:]
     got = open(out, "rb").read()
-    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"], r.stderr[-2000:]
+    assert hashlib.sha256(got).hexdigest() == want, r.stderr[-2000:]
 
 
 # ---- edge cases of the prepare / commit split (ADVICE round 1) ------------------------------------------------------------
