@@ -21,7 +21,9 @@ sample; the body the deltas (~16 B per SNP): ~22 MB.  The archive is byte-identi
 
 -c (concatenated genomes): the unit that is dealt round-robin is the reference's own registration unit -- a run of pack_cardinality
 contigs across the input files, each contig a sample of its own -- followed by the empty registration the reference always sends at
-the end (agc_compressor.cpp:2155-2238); concatenated_units() below cuts them.  Not covered in this mode: append.
+the end (agc_compressor.cpp:2155-2238); concatenated_units() below cuts them.
+append: every rank loads the input archive (host.Compressor.append); compress(prefetch=False) -- a packed group answers Estimate with
+0 until a record unpacks it, on every rank, so samples are prepared at their turn.  Not covered: append together with -c.
 """
 import time
 
