@@ -86,8 +86,32 @@ __device__ __forceinline__ SymView uniform_view(const SymView &v)
     return u;
 }
 
+// A view whose pointers name the global address space.  A pointer that reaches a kernel through a descriptor loaded from memory is a
+// generic pointer to the compiler: every access becomes a FLAT instruction, which counts against the LDS / scalar-memory counter as
+// well -- a read of the text window in LDS then waits for every table row and reference word still in flight.  The parse converts
+// its views once (the sym_view.h accessors are templates over the view type).
+typedef const __attribute__((address_space(1))) uint32_t g_u32;
+typedef const __attribute__((address_space(1))) int32_t g_i32;
+typedef const __attribute__((address_space(1))) uint8_t g_u8;
+typedef const __attribute__((address_space(1))) uint64_t g_u64;
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) __attribute__((aligned(4))) v4u32 g_v4u32_a4; // (16 bytes at a 4-byte aligned address)
+typedef __attribute__((address_space(1))) __attribute__((aligned(8))) v2u64 g_v2u64_a8;
+struct SymViewG {
+    g_u32 *words;
+    g_i32 *esc_index;
+    g_u8 *esc_bytes;
+    uint64_t start;
+    uint32_t len, rc;
+};
+__device__ __forceinline__ SymViewG global_view(const SymView &v)
+{
+    return {(g_u32 *)v.words, (g_i32 *)v.esc_index, (g_u8 *)v.esc_bytes, v.start, v.len, v.rc};
+}
+
 // no block the sequence touches is escaped (whole wave; one index entry per lane and step)
-__device__ bool wave_view_clean(const SymView &v)
+template <class V> __device__ bool wave_view_clean(const V &v)
 {
     if (!v.esc_index || !v.len)
         return true;
@@ -99,8 +123,8 @@ __device__ bool wave_view_clean(const SymView &v)
 }
 
 // a lane's chunk (N = 16 or 32 symbols: P, I as sv_fetch delivers them; cnt of them valid) as bytes at dst (LDS, N-byte aligned)
-template <uint32_t N>
-__device__ __forceinline__ void store_syms(uint8_t *dst, const SymView &v, uint32_t pos, uint32_t cnt, uint64_t P, uint32_t I)
+template <uint32_t N, class V>
+__device__ __forceinline__ void store_syms(uint8_t *dst, const V &v, uint32_t pos, uint32_t cnt, uint64_t P, uint32_t I)
 {
     if (cnt == N && I == 0) {
         const uint32_t lo = (uint32_t)P, hi = (uint32_t)(P >> 32);
@@ -136,7 +160,7 @@ __device__ __forceinline__ bool win_has(const TextWin &w, uint32_t pos, uint32_t
     return pos >= w.base && pos + cnt <= w.base + w.len;
 }
 
-__device__ __forceinline__ void win_fill(TextWin &w, const SymView &tv, bool t_clean, uint32_t n, uint32_t pos)
+template <class V> __device__ __forceinline__ void win_fill(TextWin &w, const V &tv, bool t_clean, uint32_t n, uint32_t pos)
 {
     const uint32_t lane = lane_id();
     const uint32_t len = n - pos < WIN_SYMS ? n - pos : WIN_SYMS;
@@ -158,7 +182,8 @@ __device__ __forceinline__ void win_fill(TextWin &w, const SymView &tv, bool t_c
 // 64-bit XOR; symbols outside ACGT (escaped blocks) are compared by value, one at a time.
 // Semantics of refresh::matching_length (3rd_party/refresh/string_operations/lib/string_operations.h:18-69) as used by
 // compare_fwd (lz_diff.h:264-266).  When `win` is given the text chunk of the final step is captured into the window.
-__device__ uint32_t wave_match_fwd(const SymView &tv, uint32_t tp, bool t_clean, const SymView &rv, uint32_t rp, bool r_clean, uint32_t max_len,
+template <class V>
+__device__ uint32_t wave_match_fwd(const V &tv, uint32_t tp, bool t_clean, const V &rv, uint32_t rp, bool r_clean, uint32_t max_len,
                                    TextWin *win = nullptr)
 {
     const uint32_t lane = lane_id();
@@ -206,7 +231,7 @@ __device__ uint32_t wave_match_fwd(const SymView &tv, uint32_t tp, bool t_clean,
 }
 
 // Backward extension (lz_diff.cpp:308-311): number of equal symbols walking left from text[tp - 1] / ref[rp - 1], at most lim.
-__device__ uint32_t wave_common_suffix(const SymView &tv, uint32_t tp, const SymView &rv, uint32_t rp, uint32_t lim)
+template <class V> __device__ uint32_t wave_common_suffix(const V &tv, uint32_t tp, const V &rv, uint32_t rp, uint32_t lim)
 {
     const uint32_t lane = lane_id();
     for (uint32_t base = 0; base < lim; base += WAVE) {
@@ -333,8 +358,8 @@ struct ParseOut {
 // maybe: one bit per text position from key_filter_kernel (0 = the key at this position is valid and not in the reference's
 // index: a certain literal); nullptr: literal runs are found by probing the table (wide probe)
 template <int MODE>
-__device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__restrict__ out, cost_t *__restrict__ costs,
-                             const bool prefix_costs, uint8_t *win_lds, const unsigned long long *__restrict__ maybe)
+__device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__restrict__ out, cost_t *__restrict__ costs,
+                             const bool prefix_costs, uint8_t *win_lds, const unsigned long long *__restrict__ maybe_generic)
 {
     const uint32_t lane = lane_id();
     const bool writer = lane == 0;
@@ -343,7 +368,10 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
     const uint32_t mml = rd.min_match_len;
     const uint32_t ref_size = rd.ref_size;
     const uint32_t ht_mask = rd.ht_mask;
-    const SymView rv = {rd.words, rd.esc_index, rd.esc_bytes, 0, ref_size, 0};
+    const SymViewG rv = {(g_u32 *)rd.words, (g_i32 *)rd.esc_index, (g_u8 *)rd.esc_bytes, 0, ref_size, 0};
+    g_u64 *maybe = (g_u64 *)maybe_generic;
+    g_u32 *tab32 = (g_u32 *)rd.table;
+    g_u64 *tab64 = (g_u64 *)rd.table;
     const bool r_clean = rd.esc_index == nullptr; // (a reference has an escape index only when it holds a symbol outside ACGT)
     const bool t_clean = wave_view_clean(tv);
     ParseOut res{0, 0};
@@ -451,13 +479,12 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
                 // end at the first empty slot, so one or two round trips settle almost every lane
                 if (rd.is_short) {
                     const uint32_t fp = (uint32_t)(hx >> 48);
-                    const uint32_t *tab = (const uint32_t *)rd.table;
+                    g_u32 *tab = tab32;
                     bool done = false;
                     for (uint32_t t = 0; t < WIDE_MAX_SLOTS && !done; t += 4) {
                         uint32_t e[4];
                         if (sl + 3 <= ht_mask) {
-                            uint4 v;
-                            __builtin_memcpy(&v, tab + sl, 16);
+                            const v4u32 v = *(const g_v4u32_a4 *)(tab + sl);
                             e[0] = v.x, e[1] = v.y, e[2] = v.z, e[3] = v.w;
                         } else {
 #pragma unroll
@@ -480,13 +507,12 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
                     stop = stop || !done; // chain longer than the probe budget: let the exact step decide
                 } else {
                     const uint32_t fp = (uint32_t)(hx >> 32);
-                    const uint64_t *tab = (const uint64_t *)rd.table;
+                    g_u64 *tab = tab64;
                     bool done = false;
                     for (uint32_t t = 0; t < WIDE_MAX_SLOTS && !done; t += 2) {
                         uint64_t e[2];
                         if (sl + 1 <= ht_mask) {
-                            ulonglong2 v;
-                            __builtin_memcpy(&v, tab + sl, 16);
+                            const v2u64 v = *(const g_v2u64_a8 *)(tab + sl);
                             e[0] = v.x, e[1] = v.y;
                         } else {
                             e[0] = tab[sl & ht_mask];
@@ -558,12 +584,12 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
                 const uint64_t hx = murmur64(spread_bits(r0) | (spread_bits(r1) << 1));
                 const uint32_t sl = ((uint32_t)hx + (lane % MP_S)) & ht_mask;
                 if (rd.is_short) {
-                    const uint32_t e = ((const uint32_t *)rd.table)[sl];
+                    const uint32_t e = tab32[sl];
                     is_empty = e == 0xFFFFFFFFu;
                     epos = e >> 16;
                     fp_ok = (e & 0xFFFFu) == (uint32_t)(hx >> 48);
                 } else {
-                    const uint64_t e = ((const uint64_t *)rd.table)[sl];
+                    const uint64_t e = tab64[sl];
                     is_empty = e == ~0ULL;
                     epos = (uint32_t)(e >> 32);
                     fp_ok = (uint32_t)e == (uint32_t)(hx >> 32);
@@ -699,12 +725,12 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymView &tv, uint8_t *__re
         // ---- find_best_match: 64 lanes = 64 probes ----
         bool is_empty, fp_ok;
         if (rd.is_short) {
-            const uint32_t e = ((const uint32_t *)rd.table)[(slot + lane) & ht_mask];
+            const uint32_t e = tab32[(slot + lane) & ht_mask];
             is_empty = e == 0xFFFFFFFFu;
             epos = e >> 16;
             fp_ok = (e & 0xFFFFu) == (uint32_t)(h >> 48);
         } else {
-            const uint64_t e = ((const uint64_t *)rd.table)[(slot + lane) & ht_mask];
+            const uint64_t e = tab64[(slot + lane) & ht_mask];
             is_empty = e == ~0ULL;
             epos = (uint32_t)(e >> 32);
             fp_ok = (uint32_t)e == (uint32_t)(h >> 32);
@@ -929,7 +955,7 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
     rd.min_match_len = uniform_u32(rdm.min_match_len);
     rd.is_short = uniform_u32(rdm.is_short);
     rd.valid = 1;
-    const SymView tv = uniform_view(sdm.text);
+    const SymViewG tv = global_view(uniform_view(sdm.text));
     const uint64_t out_off = uniform_u64(sdm.out_off);
     const unsigned long long *maybe = uniform_ptr(sdm.maybe);
     const uint32_t flags = uniform_u32(sdm.flags), oidx = uniform_u32(sdm.idx);
@@ -988,7 +1014,7 @@ struct FilterJob {
     uint32_t chunk;            // first position of this block's chunk
 };
 
-__device__ __forceinline__ void pack16(const SymView &tv, uint32_t pos, uint32_t &P, uint32_t &I)
+template <class V> __device__ __forceinline__ void pack16(const V &tv, uint32_t pos, uint32_t &P, uint32_t &I)
 {
     // 16 symbols at pos: P = 2-bit codes (first symbol most significant), I = mask of symbols > 3 (first symbol = bit 15);
     // positions at or after len count as invalid
@@ -1011,30 +1037,29 @@ __device__ __forceinline__ void pack16(const SymView &tv, uint32_t pos, uint32_t
 __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__restrict__ jobs)
 {
     const FilterJob jb = jobs[blockIdx.x];
+    const SymViewG text = global_view(jb.text); // (global loads instead of FLAT ones: see SymViewG)
+    g_u64 *bloom = (g_u64 *)jb.bloom;
+    unsigned long long __attribute__((address_space(1))) *out = (unsigned long long __attribute__((address_space(1))) *)jb.out;
     // (the first filter in LDS; the second one is consulted for the 0.4 % of foreign keys that pass it, from HBM / L2)
     __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[KEY_BLOOM_HALF];
-    {
-        const uint4 *src = (const uint4 *)jb.bloom;
-        uint4 *dst = (uint4 *)s_bloom;
-        for (uint32_t t = threadIdx.x; t < KEY_BLOOM_HALF / 2; t += blockDim.x)
-            dst[t] = src[t];
-    }
+    for (uint32_t t = threadIdx.x; t < KEY_BLOOM_HALF; t += blockDim.x)
+        s_bloom[t] = bloom[t];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t k = jb.key_len;
     const uint64_t kmask = (1ULL << (2 * k)) - 1ULL;     // key_len <= 29
     const uint32_t imask = (1u << k) - 1u;
-    const uint32_t len = jb.text.len;
+    const uint32_t len = text.len;
     const uint32_t end = min(len, jb.chunk + FILTER_CHUNK);
     for (uint32_t base = jb.chunk + wave * 1024; base < end; base += 4 * 1024) {
         const uint32_t pos = base + lane * 16;
         uint32_t P, I;
-        pack16(jb.text, pos, P, I);
+        pack16(text, pos, P, I);
         uint32_t P1 = __shfl_down(P, 1), I1 = __shfl_down(I, 1), P2 = __shfl_down(P, 2), I2 = __shfl_down(I, 2);
         if (lane >= 62) { // the followers of the last two lanes belong to the next step
             if (lane == 63)
-                pack16(jb.text, pos + 16, P1, I1);
-            pack16(jb.text, pos + 32, P2, I2);
+                pack16(text, pos + 16, P1, I1);
+            pack16(text, pos + 32, P2, I2);
         }
         // 96-bit window: symbols 0..15 (P), 16..31 (P1), 32..47 (P2); symbol s at bits [94 - 2s, 95 - 2s]
         const uint64_t hi = ((uint64_t)P << 32) | P1;            // symbols 0..31
@@ -1055,7 +1080,7 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
             bool in_f = (s_bloom[bw] & bm) == bm;
             if (in_f && !bad) { // (0.4 % of the foreign keys get this far)
                 key_bloom_slot2(key, bw, bm);
-                in_f = (jb.bloom[bw] & bm) == bm;
+                in_f = (bloom[bw] & bm) == bm;
             }
             const bool past = !(pos + j + k < len);
             bits |= (uint32_t)(bad || in_f || past) << j;
@@ -1065,7 +1090,7 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
         uint64_t word = mine | __shfl_xor(mine, 1);
         word |= __shfl_xor(word, 2);
         if ((lane & 3) == 0 && pos < len)
-            jb.out[pos >> 6] = word;
+            out[pos >> 6] = word;
     }
 }
 

@@ -62,10 +62,13 @@ SV_HD uint64_t sv_rev2_64(uint64_t x)
 
 SV_HD uint32_t sv_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 
+// (The accessors are templates over the view type V -- any struct with SymView's members -- and over the word pointer type: a kernel
+// that has loaded a view out of a descriptor holds GENERIC pointers as far as the compiler can tell and would get FLAT loads for
+// every access; it converts the view once into one whose pointers name the global address space, lz_kernels.hip: SymViewG.)
 // 32 stored symbols starting at buffer index s (symbol s + j at bits [2j, 2j+1]); reads words s/16 .. s/16 + 2
-SV_HD uint64_t sv_raw64(const uint32_t *__restrict__ words, uint64_t s)
+template <class W> SV_HD uint64_t sv_raw64(W words, uint64_t s)
 {
-    const uint32_t *p = words + (s >> 4);
+    const W p = words + (s >> 4);
     const uint32_t sh = 2u * (uint32_t)(s & 15u);
     const uint32_t a = p[0], b = p[1], c = p[2];
     uint64_t x = (((uint64_t)b << 32) | a) >> sh;
@@ -75,7 +78,7 @@ SV_HD uint64_t sv_raw64(const uint32_t *__restrict__ words, uint64_t s)
 }
 
 // one symbol of the buffer (full code, escapes looked up)
-SV_HD uint32_t sv_buf_sym(const SymView &v, uint64_t s, bool clean)
+template <class V> SV_HD uint32_t sv_buf_sym(const V &v, uint64_t s, bool clean)
 {
     if (!clean && v.esc_index) {
         const int32_t slot = v.esc_index[s / SV_BLOCK];
@@ -86,7 +89,7 @@ SV_HD uint32_t sv_buf_sym(const SymView &v, uint64_t s, bool clean)
 }
 
 // symbol at position p of the sequence (p < len); clean = the caller knows that no block of the sequence is escaped
-SV_HD uint32_t sv_sym(const SymView &v, uint32_t p, bool clean = false)
+template <class V> SV_HD uint32_t sv_sym(const V &v, uint32_t p, bool clean = false)
 {
     if (v.rc) {
         const uint32_t c = sv_buf_sym(v, v.start + (v.len - 1u - p), clean);
@@ -98,7 +101,7 @@ SV_HD uint32_t sv_sym(const SymView &v, uint32_t p, bool clean = false)
 // cnt (1..32) symbols from position p (p + cnt <= len): P = their 2-bit codes (position p + j at bits [2j, 2j+1]; symbols
 // outside ACGT leave two arbitrary bits), I = bit j set where the symbol is outside ACGT.  Bits of positions >= cnt are
 // unspecified in P and clear in I.
-SV_HD void sv_fetch32(const SymView &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
+template <class V> SV_HD void sv_fetch32(const V &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
 {
     I = 0;
     uint64_t s0, s1; // first / last buffer index touched
@@ -132,9 +135,9 @@ SV_HD void sv_fetch32(const SymView &v, uint32_t p, uint32_t cnt, bool clean, ui
 }
 
 // the same for cnt (1..16) symbols: two dwords per fetch instead of three (P in the low 32 bits)
-SV_HD uint32_t sv_raw32(const uint32_t *__restrict__ words, uint64_t s)
+template <class W> SV_HD uint32_t sv_raw32(W words, uint64_t s)
 {
-    const uint32_t *p = words + (s >> 4);
+    const W p = words + (s >> 4);
     const uint32_t sh = 2u * (uint32_t)(s & 15u);
     return (uint32_t)(((((uint64_t)p[1]) << 32) | p[0]) >> sh);
 }
@@ -143,7 +146,7 @@ SV_HD uint32_t sv_rev2_32(uint32_t x)
     x = sv_brev32(x);
     return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
 }
-SV_HD void sv_fetch16(const SymView &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
+template <class V> SV_HD void sv_fetch16(const V &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
 {
     I = 0;
     uint64_t s0, s1;
@@ -174,7 +177,7 @@ SV_HD void sv_fetch16(const SymView &v, uint32_t p, uint32_t cnt, bool clean, ui
         I |= (uint32_t)(c > 3u) << j;
     }
 }
-template <uint32_t N> SV_HD void sv_fetch(const SymView &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
+template <uint32_t N, class V> SV_HD void sv_fetch(const V &v, uint32_t p, uint32_t cnt, bool clean, uint64_t &P, uint32_t &I)
 {
     if (N == 16)
         sv_fetch16(v, p, cnt, clean, P, I);
