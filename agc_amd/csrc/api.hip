@@ -72,6 +72,9 @@ struct agc_hip_ctx {
     bool refs_dirty = true;
     std::vector<ArenaChunk> arena;
 
+    // the > 64 KiB dynamic-LDS attribute of a kernel is a property of the device the context runs on: set once per context
+    bool lds_scan_set = false, lds_lookup_set = false;
+
     // scratch
     DevBuf d_esc_jobs, d_flags;
     // the (k1, k2) -> group table (mirror of the host's map_segments) and the work area of agc_hip_segments_packed
@@ -107,6 +110,7 @@ struct agc_hip_ctx {
     // beside the estimates / cost vectors / index builds the caller goes on with on `stream`
     struct Lane2 {
         DevBuf d_segs, d_counter, d_resv, d_resp, d_scratch, d_dstoff, d_compact;
+        DevBuf d_n; // the lane's own copy of a segment count made on the device (the work area it came from is re-laid-out by the next sample)
         PackTemp pk;
         uint32_t *h_lens = nullptr; // pinned (a device-to-host copy into pageable memory would make begin wait for the kernel)
         size_t h_lens_cap = 0;
@@ -452,7 +456,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
                       &c->d_zjobs, &c->d_zsize, &c->d_zout, &c->d_zdstoff, &c->d_maybe, &c->d_fjobs,
                       &c->l2.d_segs, &c->l2.d_counter, &c->l2.d_resv, &c->l2.d_resp, &c->l2.d_scratch, &c->l2.d_dstoff,
                       &c->l2.d_compact, &c->l3.d_segs, &c->l3.d_counter, &c->l3.d_resv, &c->l3.d_resp, &c->l3.d_scratch, &c->l3.d_dstoff,
-                      &c->l3.d_compact, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
+                      &c->l3.d_compact, &c->l2.d_n, &c->l3.d_n, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
     if (c->h_segcounts)
         (void)hipHostFree(c->h_segcounts);
     if (c->h_gmap_stage)
@@ -969,10 +973,9 @@ static int packed_scan_raw(agc_hip_ctx *c, const agc_hip_packed *pk, const uint6
     CHK(ensure(c, c->d_ranges, ranges.size() * sizeof(ScanRange)));
     CHK(ensure(c, c->d_counter, 64));
     CHK(upload(c, c->d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), c->stream));
-    static bool lds_set = false;
-    if (!lds_set) {
+    if (!c->lds_scan_set) {
         HIPCHK(c, hipFuncSetAttribute((const void *)scan_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SBLOOM_WORDS * 4));
-        lds_set = true;
+        c->lds_scan_set = true;
     }
     uint32_t dev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(total / 2000 + 4096, c->d_hits.cap / sizeof(ScanHit)), 1u << 30);
     uint32_t n_found = 0;
@@ -1078,10 +1081,9 @@ int agc_hip_prefetch_packed_dev(agc_hip_ctx *c, const agc_hip_packed *pk, const 
         // (the ranges go through a pageable vector: the copy is staged by the runtime before the call returns)
         CHK(upload(c, pf.d_ranges.p, ranges.data(), ranges.size() * sizeof(ScanRange), pf.stream));
         HIPCHK(c, hipMemsetAsync(pf.d_counter.p, 0, 4, pf.stream));
-        static bool lds_set = false;
-        if (!lds_set) {
+        if (!c->lds_scan_set) {
             HIPCHK(c, hipFuncSetAttribute((const void *)scan_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SBLOOM_WORDS * 4));
-            lds_set = true;
+            c->lds_scan_set = true;
         }
         ScanPackedArgs a;
         a.pv = pv;
@@ -1622,6 +1624,10 @@ static int lz_encode_begin_enter(agc_hip_ctx *c, int lane, uint32_t n)
         return 1; // nothing to launch
     }
     HIPCHK(c, hipSetDevice(c->device));
+    // the group descriptors of references registered a moment ago travel on the first stream: their copy has to be queued BEFORE the
+    // event the lane waits for, or the lane's parse could read a table the copy has not reached yet (prepare_batch would queue it
+    // behind the event)
+    CHK(upload_refs(c));
     // everything queued on the first stream so far (index builds, a sample being packed) comes first
     HIPCHK(c, hipEventRecord(L.ready, c->stream));
     HIPCHK(c, hipStreamWaitEvent(L.s, L.ready, 0));

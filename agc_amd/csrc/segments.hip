@@ -99,11 +99,14 @@ static int launch_known(agc_hip_ctx *c)
     unsigned long long *capv = (unsigned long long *)S.capv, *cap_off = (unsigned long long *)S.cap_off;
     SegDesc *descs = (SegDesc *)S.descs;
     CHK(upload_refs(c));
-    const size_t scratch_ub = (size_t)(S.total + 5 * S.total / 16) + 96 * (size_t)n_ub + 64;
+    // a slot = len + 5 len / 16 + 64, rounded up to 16 (known_flag_kernel), and neighbouring segments share k <= 32 symbols:
+    // per segment 32 * 21 / 16 + 64 + 15 < 128 bytes beyond its share of the sample
+    const size_t scratch_ub = (size_t)(S.total + 5 * S.total / 16) + 128 * (size_t)n_ub + 64;
     CHK(ensure(c, c->l2.d_segs, (size_t)n_ub * sizeof(SegDesc), c->stream2));
     CHK(ensure(c, c->l2.d_resv, (size_t)n_ub * 4, c->stream2));
     CHK(ensure(c, c->l2.d_resp, (size_t)n_ub * 4, c->stream2));
     CHK(ensure(c, c->l2.d_scratch, scratch_ub, c->stream2));
+    CHK(ensure(c, c->l2.d_n, 64, c->stream2));
     if (c->l2.h_lens_cap < n_ub) {
         if (c->l2.h_lens)
             HIPCHK(c, hipHostFree(c->l2.h_lens));
@@ -126,20 +129,24 @@ static int launch_known(agc_hip_ctx *c)
     hipLaunchKernelGGL(scan_excl_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, lcnt, lstart, LEN_BUCKETS + 1);
     hipLaunchKernelGGL(known_order_kernel, dim3((n_ub + 255) / 256), dim3(256), 0, st, descs, counts, lstart, lcur, (SegDesc *)c->l2.d_segs.p);
     HIPCHK(c, hipGetLastError());
+    // the number of descriptors moves into a word the lane owns: the next sample's agc_hip_segments_packed clears and re-lays-out
+    // the work area on the first stream while this parse (and the copy of the count behind it) may still be running
+    uint32_t *d_n_known = (uint32_t *)c->l2.d_n.p;
+    HIPCHK(c, hipMemcpyAsync(d_n_known, &counts->n_known, 4, hipMemcpyDeviceToDevice, st));
     // the parse on the second lane, behind everything queued here
     HIPCHK(c, hipEventRecord(c->l2.ready, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->l2.ready, 0));
     c->l2.timed = c->timing;
     if (c->l2.timed)
         (void)hipEventRecord(c->l2.e0, c->stream2);
-    CHK(launch_parse<MODE_ENCODE>(c, n_ub, (uint8_t *)c->l2.d_scratch.p, nullptr, 1, &counts->n_known));
+    CHK(launch_parse<MODE_ENCODE>(c, n_ub, (uint8_t *)c->l2.d_scratch.p, nullptr, 1, d_n_known));
     if (c->l2.timed)
         (void)hipEventRecord(c->l2.e1, c->stream2);
     HIPCHK(c, hipEventRecord(c->l2.done, c->stream2));
     c->l2.done_valid = true;
     HIPCHK(c, hipMemcpyAsync(c->l2.h_lens, c->l2.d_resv.p, (size_t)n_ub * 4, hipMemcpyDeviceToHost, c->stream2));
     uint32_t *n_pinned = (uint32_t *)((uint8_t *)c->h_segcounts + 64);
-    HIPCHK(c, hipMemcpyAsync(n_pinned, &counts->n_known, 4, hipMemcpyDeviceToHost, c->stream2));
+    HIPCHK(c, hipMemcpyAsync(n_pinned, d_n_known, 4, hipMemcpyDeviceToHost, c->stream2));
     c->l2.n_pinned = n_pinned;
     c->l2.n = 0;
     c->l2.pending = true;
@@ -297,10 +304,9 @@ int agc_hip_segments_packed(agc_hip_ctx *c, const agc_hip_packed *pk, const uint
         const uint64_t n_ranges = c->gmap_slots / range_slots;
         const bool staged = n_ranges <= 65535 && (uint64_t)n_ub * 8 >= c->gmap_slots;
         if (staged) {
-            static bool lds_set = false;
-            if (!lds_set) {
+            if (!c->lds_lookup_set) {
                 HIPCHK(c, hipFuncSetAttribute((const void *)group_lookup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GM_RANGE_SLOTS * sizeof(GroupSlot)));
-                lds_set = true;
+                c->lds_lookup_set = true;
             }
             hipLaunchKernelGGL(group_lookup_kernel, dim3((uint32_t)n_ranges), dim3(1024), range_slots * sizeof(GroupSlot), st, (const GroupSlot *)c->d_gmap.p, mask, segs,
                                counts, 1u);
