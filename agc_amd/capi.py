@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libagc_hip.so")
 
 OK, ENODEV, EINVAL, ENOMEM, ECAP, ENOREF = 0, -1, -2, -3, -4, -5
 K_SCAN, K_INDEX, K_ENCODE, K_ESTIMATE, K_COSTVEC, K_REVCOMP, K_PREPROCESS, K_REFSTORE = range(8)
-K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd", "filter", "segments"]
+K_NAMES = ["scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd", "filter", "segments", "pack"]
 
 # every symbol include/agc_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -27,7 +27,7 @@ SYMBOLS = [
     "agc_hip_scan_contigs_dev", "agc_hip_scan_contigs",
     "agc_hip_ref_register", "agc_hip_ref_register_batch_dev", "agc_hip_ref_get", "agc_hip_ref_index_get",
     "agc_hip_lz_encode_batch_dev", "agc_hip_lz_encode_batch", "agc_hip_lz_encode_begin_dev", "agc_hip_lz_encode_end", "agc_hip_lz_encode_pending",
-    "agc_hip_lz_encode_begin_packed_on", "agc_hip_lz_encode_end_on", "agc_hip_lz_encode_pending_on",
+    "agc_hip_lz_encode_begin_packed_on", "agc_hip_lz_encode_end_on", "agc_hip_lz_encode_pending_on", "agc_hip_lz_encode_drop_on",
     "agc_hip_host_alloc", "agc_hip_host_free",
     "agc_hip_lz_estimate_batch_dev", "agc_hip_lz_estimate_batch",
     "agc_hip_lz_cost_vector_batch_dev", "agc_hip_lz_cost_vector_batch",
@@ -38,6 +38,7 @@ SYMBOLS = [
     "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched", "agc_hip_sample_pack",
     "agc_hip_ref_register_batch_packed", "agc_hip_lz_encode_batch_packed", "agc_hip_lz_encode_begin_packed", "agc_hip_lz_estimate_batch_packed",
     "agc_hip_lz_cost_vector_batch_packed", "agc_hip_lz_split_point_batch_packed", "agc_hip_fetch_slices_packed", "agc_hip_ref_lag_counts_packed",
+    "agc_hip_pack_fasta_begin", "agc_hip_pack_fasta_end", "agc_hip_pack_fasta_dev",
     "agc_hip_group_hash", "agc_hip_group_map_set", "agc_hip_group_map_update", "agc_hip_segments_packed", "agc_hip_segments_encode_known",
 ]
 
@@ -147,6 +148,9 @@ def load():
     L.agc_hip_packed_index_bytes.restype = C.c_uint64
     L.agc_hip_packed_index_bytes.argtypes = [C.c_uint64]
     L.agc_hip_pack_dev.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
+    L.agc_hip_pack_fasta_begin.argtypes = [vp, vp, C.c_uint64, u64p, u64p, C.c_uint32, vp, vp, vp, C.c_uint64]
+    L.agc_hip_pack_fasta_end.argtypes = [vp, u64p, u64p]
+    L.agc_hip_pack_fasta_dev.argtypes = [vp, vp, C.c_uint64, u64p, u64p, C.c_uint32, vp, vp, vp, C.c_uint64, u64p, u64p]
     L.agc_hip_expand_dev.argtypes = [vp, C.POINTER(Packed), vp]
     L.agc_hip_scan_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u32p, u64p, u64p, u64p]
     L.agc_hip_prefetch_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32]
@@ -158,6 +162,7 @@ def load():
     L.agc_hip_lz_encode_begin_packed_on.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, pkp, u64p, u32p, u8p]
     L.agc_hip_lz_encode_end_on.argtypes = [vp, C.c_uint32, u8p, C.c_uint64, u64p]
     L.agc_hip_lz_encode_pending_on.argtypes = [vp, C.c_uint32, u32p]
+    L.agc_hip_lz_encode_drop_on.argtypes = [vp, C.c_uint32]
     L.agc_hip_lz_estimate_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u32p, u32p]
     L.agc_hip_lz_cost_vector_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u8p, u32p]
     L.agc_hip_lz_split_point_batch_packed.argtypes = [vp, C.c_uint32, u32p, u32p, pkp, u64p, u32p, u8p, u8p, u8p, u8p, u32p, u32p]
@@ -313,6 +318,46 @@ class Context:
             break
         pk = Packed(words.data_ptr(), index.data_ptr(), esc.data_ptr(), n)
         return pk, (words, index, esc)
+
+    def pack_fasta_begin(self, d_raw_tensor, n_raw, raw_begin, raw_end, esc_cap=64, bufs=None):
+        """raw FASTA bodies in HBM (torch uint8 tensor; contig c = bytes [raw_begin[c], raw_end[c])) -> the packed sample, queued on
+        the library's pack stream.  Returns the pending handle pack_fasta_end() takes.  `bufs` = (words, index, esc) of an earlier
+        pack to write into (their sizes must fit)."""
+        import torch
+        dev = d_raw_tensor.device
+        rb, re_ = _a(raw_begin, np.uint64), _a(raw_end, np.uint64)
+        ub = int((re_ - rb).sum())  # kept bytes <= the ranges' lengths
+        if bufs is None:
+            words = torch.empty(int(self.L.agc_hip_packed_words_bytes(ub)) // 4 + 4, dtype=torch.int32, device=dev)
+            index = torch.empty(int(self.L.agc_hip_packed_index_bytes(ub)) // 4 + 1, dtype=torch.int32, device=dev)
+            esc = torch.empty(max(esc_cap, 1) * 1024, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)  # (torch's allocations / the raw bytes come from torch's stream)
+        else:
+            words, index, esc = bufs
+            esc_cap = esc.numel() // 1024
+        self._chk(self.L.agc_hip_pack_fasta_begin(self.h, d_raw_tensor.data_ptr(), int(n_raw), _p(rb, u64p), _p(re_, u64p), rb.size, words.data_ptr(),
+                                                  index.data_ptr(), esc.data_ptr(), esc_cap))
+        return {"raw": d_raw_tensor, "n_raw": int(n_raw), "rb": rb, "re": re_, "bufs": (words, index, esc)}
+
+    def pack_fasta_end(self, pending):
+        """-> (Packed, backing tensors, symbol offsets of the contigs); grows the escape buffer and packs again when it was too small"""
+        import torch
+        while True:
+            off = np.zeros(pending["rb"].size + 1, np.uint64)
+            cnt = np.zeros(1, np.uint64)
+            rc = self.L.agc_hip_pack_fasta_end(self.h, _p(off, u64p), _p(cnt, u64p))
+            if rc == ECAP:
+                words, index, _esc = pending["bufs"]
+                esc = torch.empty((int(cnt[0]) + 16) * 1024, dtype=torch.uint8, device=words.device)
+                torch.cuda.synchronize(words.device)
+                pending = self.pack_fasta_begin(pending["raw"], pending["n_raw"], pending["rb"], pending["re"], bufs=(words, index, esc))
+                continue
+            self._chk(rc)
+            words, index, esc = pending["bufs"]
+            return Packed(words.data_ptr(), index.data_ptr(), esc.data_ptr(), int(off[-1])), pending["bufs"], off
+
+    def pack_fasta_dev(self, d_raw_tensor, n_raw, raw_begin, raw_end, esc_cap=64):
+        return self.pack_fasta_end(self.pack_fasta_begin(d_raw_tensor, n_raw, raw_begin, raw_end, esc_cap))
 
     def expand_dev(self, pk, d_codes_ptr):
         self._chk(self.L.agc_hip_expand_dev(self.h, C.byref(pk), d_codes_ptr))

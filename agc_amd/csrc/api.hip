@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "scan_kernels.hip"
+#include "pack_kernels.hip"
 #include "lz_kernels.hip"
 #include "seg_kernels.hip"
 #include "zstd_kernels.hip"
@@ -145,6 +146,19 @@ struct agc_hip_ctx {
         bool timed = false;
     } pf;
 
+    // agc_hip_pack_fasta_begin / _end: raw FASTA bodies -> the packed sample on a stream of its own (pack_kernels.hip)
+    struct PackFasta {
+        hipStream_t stream = nullptr;
+        DevBuf d_state, d_rng, d_off; // look-back words + the three counters; the ranges; n_ctg + 1 symbol offsets + the total
+        uint64_t *h_res = nullptr;    // pinned: offsets, total, escaped-block count
+        size_t h_res_cap = 0;
+        uint32_t n_ctg = 0;
+        uint64_t n_raw = 0, esc_cap = 0;
+        std::vector<uint64_t> rng_begin;
+        bool pending = false, timed = false;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+    } pfa;
+
     // pinned host allocations handed out by agc_hip_host_alloc
     std::vector<void *> host_allocs;
 
@@ -273,7 +287,7 @@ int upload(agc_hip_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStre
         }
         const size_t need = (bytes + 255) & ~(size_t)255;
         if (c->up_head + need > c->up_cap) {
-            for (hipStream_t s_ : {c->stream, c->stream2, c->stream3, c->pf.stream})
+            for (hipStream_t s_ : {c->stream, c->stream2, c->stream3, c->pf.stream, c->pfa.stream})
                 if (s_)
                     HIPCHK(c, hipStreamSynchronize(s_));
             c->up_head = 0;
@@ -433,6 +447,19 @@ void agc_hip_destroy(agc_hip_ctx *c)
     for (hipStream_t s_ : {c->stream2, c->stream3})
         if (s_)
             (void)hipStreamSynchronize(s_);
+    if (c->pfa.stream) {
+        (void)hipStreamSynchronize(c->pfa.stream);
+        (void)hipStreamDestroy(c->pfa.stream);
+        for (DevBuf *b : {&c->pfa.d_state, &c->pfa.d_rng, &c->pfa.d_off})
+            if (b->p)
+                (void)hipFree(b->p);
+        if (c->pfa.h_res)
+            (void)hipHostFree(c->pfa.h_res);
+        if (c->pfa.e0)
+            (void)hipEventDestroy(c->pfa.e0);
+        if (c->pfa.e1)
+            (void)hipEventDestroy(c->pfa.e1);
+    }
     if (c->pf.stream) {
         (void)hipStreamSynchronize(c->pf.stream);
         (void)hipStreamDestroy(c->pf.stream);
@@ -901,6 +928,124 @@ int agc_hip_expand_dev(agc_hip_ctx *c, const agc_hip_packed *pk, uint8_t *d_code
     }
     HIPCHK(c, hipGetLastError());
     return AGC_HIP_OK;
+}
+
+// raw FASTA bodies (device) -> the packed sample, one pass (pack_kernels.hip), on a stream of its own
+int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *h_raw_begin, const uint64_t *h_raw_end, uint32_t n_ctg,
+                             uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks)
+{
+    if (!c || (n_ctg && (!h_raw_begin || !h_raw_end)) || (n_raw && n_ctg && (!d_raw || !d_words || !d_esc_index)) || (esc_cap_blocks && !d_esc_bytes) ||
+        ((uintptr_t)d_raw & 15) || ((uintptr_t)d_words & 15))
+        return AGC_HIP_EINVAL;
+    uint64_t prev = 0;
+    for (uint32_t i = 0; i < n_ctg; ++i) {
+        if (h_raw_begin[i] < prev || h_raw_end[i] < h_raw_begin[i] || h_raw_end[i] > n_raw)
+            return AGC_HIP_EINVAL;
+        prev = h_raw_end[i];
+    }
+    const uint64_t n_tiles64 = (n_raw + PF_TILE - 1) / PF_TILE;
+    if (n_tiles64 > 0x7fffffffULL)
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    agc_hip_ctx::PackFasta &P = c->pfa;
+    if (!P.stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreate(&P.e0));
+        HIPCHK(c, hipEventCreate(&P.e1));
+    }
+    if (P.pending) { // (a pack nobody collected: dropped)
+        HIPCHK(c, hipStreamSynchronize(P.stream));
+        P.pending = false;
+    }
+    P.n_ctg = n_ctg;
+    P.n_raw = n_raw;
+    P.esc_cap = esc_cap_blocks;
+    P.rng_begin.assign(h_raw_begin, h_raw_begin + n_ctg);
+    const size_t res_words = (size_t)n_ctg + 4;
+    if (P.h_res_cap < res_words) {
+        if (P.h_res)
+            HIPCHK(c, hipHostFree(P.h_res));
+        P.h_res = nullptr;
+        P.h_res_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&P.h_res, (res_words + 1024) * 8, hipHostMallocDefault));
+        P.h_res_cap = res_words + 1024;
+    }
+    const uint32_t n_tiles = (uint32_t)n_tiles64;
+    // [0, 64): ticket, escaped-block count, total; then one look-back word per tile
+    CHK(ensure(c, P.d_state, 64 + (size_t)n_tiles * 8, P.stream));
+    CHK(ensure(c, P.d_rng, std::max<size_t>(16, (size_t)n_ctg * 16), P.stream));
+    CHK(ensure(c, P.d_off, ((size_t)n_ctg + 2) * 8, P.stream));
+    HIPCHK(c, hipMemsetAsync(P.d_state.p, 0, 64 + (size_t)n_tiles * 8, P.stream));
+    HIPCHK(c, hipMemsetAsync(P.d_off.p, 0xFF, ((size_t)n_ctg + 1) * 8, P.stream));
+    if (n_ctg) {
+        CHK(upload(c, P.d_rng.p, h_raw_begin, (size_t)n_ctg * 8, P.stream));
+        CHK(upload(c, (uint8_t *)P.d_rng.p + (size_t)n_ctg * 8, h_raw_end, (size_t)n_ctg * 8, P.stream));
+    }
+    P.timed = c->timing;
+    if (P.timed)
+        (void)hipEventRecord(P.e0, P.stream);
+    if (n_tiles && n_ctg) {
+        PackFastaArgs a;
+        a.raw = d_raw;
+        a.n_raw = n_raw;
+        a.rng_begin = (const uint64_t *)P.d_rng.p;
+        a.rng_end = a.rng_begin + n_ctg;
+        a.n_rng = n_ctg;
+        a.n_tiles = n_tiles;
+        a.ticket = (uint32_t *)P.d_state.p;
+        a.esc_count = (uint32_t *)P.d_state.p + 1;
+        a.total = (unsigned long long *)P.d_state.p + 1;
+        a.state = (unsigned long long *)P.d_state.p + 8;
+        a.words = d_words;
+        a.esc_index = d_esc_index;
+        a.esc_bytes = d_esc_bytes;
+        a.esc_cap = (uint32_t)std::min<uint64_t>(esc_cap_blocks, 0x7fffffffu);
+        a.ctg_off = (unsigned long long *)P.d_off.p;
+        hipLaunchKernelGGL(pack_fasta_kernel, dim3(n_tiles), dim3(256), 0, P.stream, a);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (P.timed)
+        (void)hipEventRecord(P.e1, P.stream);
+    HIPCHK(c, hipMemcpyAsync(P.h_res, P.d_off.p, ((size_t)n_ctg + 1) * 8, hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(c, hipMemcpyAsync(P.h_res + n_ctg + 1, P.d_state.p, 16, hipMemcpyDeviceToHost, P.stream));
+    P.pending = true;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_pack_fasta_end(agc_hip_ctx *c, uint64_t *h_ctg_off, uint64_t *h_n_esc_blocks)
+{
+    if (!c || !h_ctg_off || !h_n_esc_blocks)
+        return AGC_HIP_EINVAL;
+    agc_hip_ctx::PackFasta &P = c->pfa;
+    if (!P.pending)
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(P.stream));
+    P.pending = false;
+    if (P.timed) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, P.e0, P.e1);
+        c->ms[AGC_HIP_K_PACK] += ms;
+        c->launches[AGC_HIP_K_PACK] += 1;
+        P.timed = false;
+    }
+    const uint32_t n = P.n_ctg;
+    const uint32_t *cnt = (const uint32_t *)(P.h_res + n + 1); // ticket, escaped blocks; the total in the next 8 bytes
+    const uint64_t total = (P.n_raw && n) ? P.h_res[n + 2] : 0;
+    for (uint32_t i = 0; i < n; ++i) // (a contig whose first byte no tile holds -- it begins at the end of the buffer -- is empty and begins at the total)
+        h_ctg_off[i] = P.h_res[i] == ~0ULL ? total : P.h_res[i];
+    h_ctg_off[n] = total;
+    *h_n_esc_blocks = (P.n_raw && n) ? cnt[1] : 0;
+    return *h_n_esc_blocks > P.esc_cap ? AGC_HIP_ECAP : AGC_HIP_OK;
+}
+
+int agc_hip_pack_fasta_dev(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *h_raw_begin, const uint64_t *h_raw_end, uint32_t n_ctg,
+                           uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks, uint64_t *h_ctg_off, uint64_t *h_n_esc_blocks)
+{
+    if (!h_ctg_off || !h_n_esc_blocks)
+        return AGC_HIP_EINVAL;
+    CHK(agc_hip_pack_fasta_begin(c, d_raw, n_raw, h_raw_begin, h_raw_end, n_ctg, d_words, d_esc_index, d_esc_bytes, esc_cap_blocks));
+    return agc_hip_pack_fasta_end(c, h_ctg_off, h_n_esc_blocks);
 }
 
 // filter over the last 16 symbols of every splitter and of its reverse complement, for k-mer length k (cached per k)
@@ -1712,6 +1857,22 @@ int agc_hip_lz_encode_pending_on(agc_hip_ctx *c, uint32_t lane, uint32_t *h_n)
         L.n_pinned = nullptr;
     }
     *h_n = L.n;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_lz_encode_drop_on(agc_hip_ctx *c, uint32_t lane)
+{
+    if (!c || lane >= AGC_HIP_ENCODE_LANES)
+        return AGC_HIP_EINVAL;
+    agc_hip_ctx::Lane2 &L = c->lane((int)lane + 1);
+    if (L.pending) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(L.s));
+    }
+    L.pending = false;
+    L.n_pinned = nullptr;
+    L.timed = false;
+    L.n = 0;
     return AGC_HIP_OK;
 }
 

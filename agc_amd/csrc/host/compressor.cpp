@@ -749,6 +749,11 @@ bool CAGCCompressor::CommitPreparedHead()
                 I.st.*f -= I.prep.st_after[t] - I.prep.st_before[t], ++t;
         }
         ++I.st.reprepared;
+        if (I.prepared && I.prepared->dev_enc_n) { // (its whole-sample encode is on the device's first lane: given up)
+            if (!I.hip_ok(agc_hip_lz_encode_drop_on(I.hip, 0), "lz_encode_drop"))
+                return false;
+            I.lane2_release();
+        }
         I.prepared.reset(new Impl::BatchState());
         I.changed_log.clear();
         I.minted_since_prepare = false;

@@ -959,13 +959,18 @@ void CAGCCompressor::Impl::lap(BatchState &b, const char *what)
 // compress_contig for every contig of the window: splitter hits from the GPU, adaptive-mode re-scan, segments
 // the device delivers segments, not hits: scan (or its prefetched result), reset rule, cut, keys and their look-up in the group
 // table all run there (agc_hip_segments_packed), and the encode of every segment whose group is known is launched from there
+// Every mode takes it (round 5): windows of several registrations and -c (the keys the device looked up are those of the window's
+// first classification; a revalidation reads the host's map), append (a group that is still packed has no reference in HBM: the
+// device does not launch its encode, the host does not expect it), adaptive mode (a contig without any splitter is looked at on
+// the host; only when the splitter set really has to grow does the window go the host's way, stage_scan_host) and the N-rank
+// mode (the prepare ahead of the turn).
 bool CAGCCompressor::Impl::use_dev_segments(const BatchState &b) const
 {
-    return dev_segments && b.pk.n_symbols && k >= 16 && !adaptive && !appending && !concatenated && dist_world == 1 && b.n_ctg &&
-           (*b.ctgs).back().sample_idx == 0 && overlap_mode == 0;
+    return dev_segments && b.pk.n_symbols && k >= 16 && b.n_ctg && overlap_mode == 0;
 }
 
-bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
+// -> 1 done, 0 failed, 2 the window goes the host's way (adaptive mode: new splitters were mined; they wait in b.mined_*)
+int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
 {
     const std::vector<Contig> &ctgs = *b.ctgs;
     const uint32_t n_ctg = b.n_ctg;
@@ -976,13 +981,13 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
         st.bases += ctgs[i].len;
         if (i + 1 < n_ctg && ctgs[i].off + ctgs[i].len != ctgs[i + 1].off) {
             err("internal: contigs of a batch must be contiguous in HBM");
-            return false;
+            return 0;
         }
     }
     ctg_off[n_ctg] = ctgs.back().off + ctgs.back().len;
     // the groups minted since the last sample go to the device's table first
     if (!hip_ok(DEVT(map_segments.sync_device(hip)), "group_map"))
-        return false;
+        return 0;
     lap(b, "group map -> device");
     if (!dev_seg_buf.ctx)
         dev_seg_buf.ctx = hip;
@@ -991,7 +996,7 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
     for (;;) {
         if (!dev_seg_buf.resize(cap * sizeof(agc_hip_segment), false)) {
             err("out of memory (segment table)");
-            return false;
+            return 0;
         }
         const int rc = DEVT(agc_hip_segments_packed(hip, &b.pk, ctg_off.data(), n_ctg, k, scan_from_prefetch ? 1 : 0, 0, dev_seg_buf.size() / sizeof(agc_hip_segment),
                                                     (agc_hip_segment *)dev_seg_buf.data(), &n_segs, nullptr));
@@ -1000,7 +1005,7 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             continue;
         }
         if (!hip_ok(rc, "segments_packed"))
-            return false;
+            return 0;
         break;
     }
     b.dev_keys = true;
@@ -1013,7 +1018,7 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
     segs.resize(n_segs);
     // the encode of the segments whose group the table knew is launched on the device's second lane when its deltas can be
     // collected beside the next sample (bookkeeping thread); otherwise the commit encodes as before
-    const bool enc = async_encode && book_can_async(1) && b.base_owned;
+    const bool enc = async_encode && book_can_async(1) && b.base_owned && ctgs.back().sample_idx == 0;
     std::vector<uint8_t> is_known(enc ? n_segs : 0, 0);
     {
         const size_t n_chunks = n_segs >= par_min ? std::min<size_t>(std::max<size_t>(n_segs / 2048, 2), (size_t)pool->size() * 4) : 1;
@@ -1043,6 +1048,55 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             conv(0, 0);
     }
     lap(b, "segments -> host records");
+    // ---- adaptive mode: contigs without any splitter look for new ones (agc_compressor.cpp:2038-2044, 2054-2081).  When they
+    // find none -- nearly always: a sample that resembles the collection has splitters in every contig -- the device's segments
+    // stand; when the set has to grow the window goes the host's way (only those contigs take the second scan's hits,
+    // :1187-1237), with what was mined here
+    if (adaptive) {
+        std::vector<uint32_t> need;
+        for (size_t i = 0; i < n_segs; ++i)
+            if ((i == 0 || dsegs[i - 1].ctg != dsegs[i].ctg) && !dsegs[i].back_full && ctgs[dsegs[i].ctg].len >= segment_size)
+                need.push_back(dsegs[i].ctg);
+        if (!need.empty()) {
+            const std::vector<bytes_t> *host_data = b.host_data;
+            std::vector<bytes_t> fetched_ctg(need.size());
+            if (!host_data) {
+                std::vector<uint64_t> off(need.size()), ooff(need.size() + 1);
+                std::vector<uint32_t> len(need.size());
+                uint64_t tot = 0;
+                for (size_t i = 0; i < need.size(); ++i) {
+                    off[i] = ctgs[need[i]].off;
+                    len[i] = (uint32_t)ctgs[need[i]].len;
+                    tot += len[i];
+                }
+                bytes_t buf(tot);
+                if (!hip_ok(DEVT(agc_hip_fetch_slices_packed(hip, (uint32_t)need.size(), &b.pk, off.data(), len.data(), nullptr, buf.data(), tot, ooff.data())),
+                            "fetch_slices"))
+                    return 0;
+                for (size_t i = 0; i < need.size(); ++i)
+                    fetched_ctg[i].assign(buf.begin() + ooff[i], buf.begin() + ooff[i + 1]);
+            }
+            std::vector<std::vector<uint64_t>> found(need.size());
+            pool->parallel_for(need.size(), [&](size_t i, unsigned) { find_new_splitters(host_data ? (*host_data)[need[i]] : fetched_ctg[i], found[i]); });
+            size_t n_new = 0;
+            for (auto &f : found)
+                n_new += f.size();
+            if (n_new) {
+                for (uint32_t i = 0; i < n_ctg; ++i)
+                    st.bases -= ctgs[i].len; // (counted again by whoever scans the window next)
+                b.dev_keys = false;
+                if (b.no_new_splitters) { // prepared ahead of its turn: the set is not this sample's to extend yet
+                    b.needs_turn = true;
+                    return 1;
+                }
+                b.mined_valid = true;
+                b.mined_need.swap(need);
+                b.mined_found.swap(found);
+                return 2;
+            }
+        }
+        lap(b, "contigs without a splitter: nothing new");
+    }
     uint32_t n_enc = 0;
     if (enc) {
         if (b.spec.size() != 2 * segs.size()) {
@@ -1071,20 +1125,23 @@ bool CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             lap(b, "second lane free");
             if (!hip_ok(DEVT(agc_hip_segments_encode_known(hip)), "segments_encode_known")) {
                 lane2_release();
-                return false;
+                return 0;
             }
             st.lz_encoded += n_enc;
         }
         lap(b, "encode of the known segments launched");
     }
     b.dev_enc_n = n_enc;
-    return true;
+    return 1;
 }
 
 bool CAGCCompressor::Impl::stage_scan(BatchState &b)
 {
-    if (use_dev_segments(b))
-        return stage_scan_dev(b);
+    if (use_dev_segments(b)) {
+        const int r = stage_scan_dev(b);
+        if (r != 2)
+            return r == 1;
+    }
     const std::vector<Contig> &ctgs = *b.ctgs;
     const uint8_t *d_base = b.d_base;
     const uint32_t n_ctg = b.n_ctg;
@@ -1129,7 +1186,7 @@ bool CAGCCompressor::Impl::stage_scan(BatchState &b)
                 if (ctgs[c].len >= segment_size)
                     need.push_back(c);
             std::vector<bytes_t> fetched_ctg(need.size());
-            if (!need.empty() && !host_data) {
+            if (!need.empty() && !host_data && !(b.mined_valid && b.mined_need == need)) {
                 std::vector<uint64_t> off(need.size()), ooff(need.size() + 1);
                 std::vector<uint32_t> len(need.size());
                 uint64_t tot = 0;
@@ -1147,9 +1204,13 @@ bool CAGCCompressor::Impl::stage_scan(BatchState &b)
                     fetched_ctg[i].assign(buf.begin() + ooff[i], buf.begin() + ooff[i + 1]);
             }
             std::vector<std::vector<uint64_t>> found(need.size());
-            pool->parallel_for(need.size(), [&](size_t i, unsigned) {
-                find_new_splitters(host_data ? (*host_data)[need[i]] : fetched_ctg[i], found[i]);
-            });
+            if (b.mined_valid && b.mined_need == need) // (the device path looked already: stage_scan_dev)
+                found.swap(b.mined_found);
+            else
+                pool->parallel_for(need.size(), [&](size_t i, unsigned) {
+                    find_new_splitters(host_data ? (*host_data)[need[i]] : fetched_ctg[i], found[i]);
+                });
+            b.mined_valid = false;
             size_t n_new = 0;
             for (auto &f : found)
                 n_new += f.size();
@@ -2070,7 +2131,43 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
     uint64_t enc_later_text = 0;
     std::vector<uint32_t> enc_later2; // ... and of the one launched below on lane 1 while lane 0 still holds the whole-sample encode
     uint64_t enc_later2_text = 0;
-    const bool bulk = b.dev_enc_n != 0; // the device launched the encode of the segments whose group it knew (stage_scan_dev)
+    // the device launched the encode of the segments whose group it knew (stage_scan_dev).  Its deltas are first read by the
+    // bookkeeping task, which then collects them beside the next sample -- unless there is no such task (several registrations in
+    // the window do not reach here with one in flight; -c, append, AGC_AMD_ASYNC_BOOK=0) or this is the N-rank mode, where the
+    // record's body is made below and holds every delta: then they are collected now, behind the window's other speculative
+    // deltas, and are ordinary speculative deltas from here on
+    if (b.dev_enc_n != 0 && (!hand_over || dist_world > 1)) {
+        const size_t ne = b.dev_enc_n;
+        std::vector<uint64_t> eoff(ne + 1, 0);
+        const uint64_t base = b.spec_bytes;
+        uint64_t cap = std::max<uint64_t>(enc_buf.size() > base ? enc_buf.size() - base : 0, (uint64_t)1 << 16);
+        for (;;) {
+            if (!enc_buf.resize(base + cap)) {
+                err("out of memory (delta buffer)");
+                return false;
+            }
+            const int r = DEVT(agc_hip_lz_encode_end(hip, enc_buf.data() + base, cap, eoff.data()));
+            if (r == AGC_HIP_ECAP) {
+                cap = eoff[ne] + eoff[ne] / 8 + 4096;
+                continue;
+            }
+            lane2_release();
+            if (!hip_ok(r, "lz_encode_end"))
+                return false;
+            break;
+        }
+        for (BatchState::Spec &sp : b.spec)
+            if (sp.valid && sp.pending >= 0) {
+                sp.enc_off = base + eoff[(size_t)sp.pending];
+                sp.enc_len = (uint32_t)(eoff[(size_t)sp.pending + 1] - eoff[(size_t)sp.pending]);
+                sp.pending = -1;
+            }
+        b.spec_bytes = base + eoff[ne];
+        st.delta_bytes += eoff[ne];
+        b.dev_enc_n = 0;
+        LAP("encode of the known segments collected");
+    }
+    const bool bulk = b.dev_enc_n != 0;
     if (bulk)
         enc_later.assign(b.dev_enc_n, ~0u);
     {
@@ -2157,34 +2254,6 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
         }
     }
     LAP(enc_later.empty() && enc_later2.empty() ? "encode" : "encode (in flight)");
-    if (bulk && !hand_over) {
-        // the synchronous path after all: the device's encode is collected here
-        const size_t ne = enc_later.size();
-        std::vector<uint64_t> eoff(ne + 1, 0);
-        uint64_t cap = std::max<uint64_t>(enc_buf.size(), enc_later_text / 64 + (1u << 16));
-        for (;;) {
-            if (!enc_buf.resize(cap, false)) {
-                err("out of memory (delta buffer)");
-                return false;
-            }
-            const int r = DEVT(agc_hip_lz_encode_end(hip, enc_buf.data(), cap, eoff.data()));
-            if (r == AGC_HIP_ECAP) {
-                cap = eoff[ne] + eoff[ne] / 8 + 4096;
-                continue;
-            }
-            lane2_release();
-            if (!hip_ok(r, "lz_encode_end"))
-                return false;
-            break;
-        }
-        for (size_t i = 0; i < ne; ++i)
-            if (enc_later[i] != ~0u) {
-                enc_ptr[enc_later[i]] = enc_buf.data() + eoff[i];
-                enc_len[enc_later[i]] = (uint32_t)(eoff[i + 1] - eoff[i]);
-            }
-        st.delta_bytes += eoff[ne];
-        enc_later.clear();
-    }
     stage_end(st.t_encode, st.h_encode, t0, dev0);
     t0 = now();
 

@@ -899,6 +899,11 @@ struct CAGCCompressor::Impl {
         // adaptive mode, a sample prepared ahead of its turn (multi-GPU mode): the scan must not extend the splitter set; when it
         // would have to, it only says so (needs_turn) and the sample is prepared again at its turn
         bool no_new_splitters = false, needs_turn = false;
+        // adaptive mode, device segments: the contigs without a splitter and what find_new_splitters made of them, handed to the
+        // host's scan when the set has to grow (stage_scan_dev -> stage_scan)
+        bool mined_valid = false;
+        std::vector<uint32_t> mined_need;
+        std::vector<std::vector<uint64_t>> mined_found;
         struct Spec {                              // speculative delta of a placed item (by Placed::key)
             uint64_t off = 0, enc_off = 0;
             uint32_t gid = 0, len = 0, enc_len = 0;
@@ -928,7 +933,7 @@ struct CAGCCompressor::Impl {
         } sto;
     };
     bool stage_scan(BatchState &b);
-    bool stage_scan_dev(BatchState &b);
+    int stage_scan_dev(BatchState &b);
     bool use_dev_segments(const BatchState &b) const;
     bool dev_segments = true;          // AGC_AMD_DEV_SEGMENTS=0: scan hits to the host, cut and key look-up there (the round-3 path)
     PinnedBytes dev_seg_buf;           // (pinned: the segment table of a human sample is 3 MB per step)

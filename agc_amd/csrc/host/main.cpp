@@ -3,6 +3,7 @@
 // commands getcol / getset / getctg / listref / listset / listctg (src/app/main.cpp:171-368) on the host decoder.
 // Exit code 0 always, messages on stderr, as the reference.
 #include "compressor.h"
+#include "../../../include/agc_hip.h"
 #include "reader.h"
 #include <algorithm>
 #include <cstdio>
@@ -298,6 +299,11 @@ int main(int argc, char **argv)
         std::cerr << "Cannot create archive " << out << std::endl;
         return 0;
     }
+    // AGC_AMD_KERNEL_TIMES=1 (a measuring aid, `bench.py --config`): HIP events around every kernel of the run, summed per
+    // kernel family on stderr with the symbols each was asked to look at -- the rows of a roofline table
+    const bool kernel_times = getenv("AGC_AMD_KERNEL_TIMES") != nullptr;
+    if (kernel_times && c.HipContext())
+        agc_hip_timing_enable(c.HipContext(), 1);
     std::vector<std::pair<std::string, std::string>> v;
     for (auto &fn : inputs) {
         std::string sn = std::filesystem::path(fn).stem().string();
@@ -315,6 +321,21 @@ int main(int argc, char **argv)
                   << " register " << s.t_register << " encode " << s.t_encode << " store " << s.t_store << " zstd " << s.t_zstd << " (inside the device library: " << s.t_device << ")\n"
                   << "host-only part: scan " << s.h_scan << " classify " << s.h_classify << " gpu-aux " << s.h_gpu_aux << " register " << s.h_register
                   << " encode " << s.h_encode << " store " << s.h_store << "\n";
+    }
+    if (kernel_times && c.HipContext()) {
+        static const char *names[AGC_HIP_K_COUNT] = {"scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd", "filter",
+                                                     "segments", "pack"};
+        const auto &s = c.Stats();
+        std::cerr << "kernel-ms:";
+        for (int w = 0; w < AGC_HIP_K_COUNT; ++w) {
+            double ms = 0;
+            uint64_t n = 0;
+            if (agc_hip_timing_get(c.HipContext(), w, &ms, &n) == AGC_HIP_OK && n)
+                std::cerr << " " << names[w] << " " << ms << " " << n;
+        }
+        std::cerr << "\nkernel-symbols: scan " << s.bases << " encode " << s.enc_text + s.enc_ref << " estimate " << s.est_text + s.est_ref << " costvec "
+                  << s.cv_text + s.cv_ref << " filter " << s.est_text + s.cv_text << " zstd_dev_in " << s.zstd_dev_in << " zstd_dev_out " << s.zstd_dev_out
+                  << " zstd_in " << s.zstd_in << "\n";
     }
     return 0;
 }

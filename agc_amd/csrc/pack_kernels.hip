@@ -1,0 +1,392 @@
+// pack_kernels.hip -- raw FASTA bodies in HBM -> the 2-bit packed sample, in ONE pass over the input.
+//
+// What it replaces: CAGCCompressor::preprocess_raw_contig (src/core/agc_compressor.cpp:907-951: every byte < 64 is dropped -- line
+// ends --, the others go through cnv_num, src/common/agc_basic.h:39-49) followed by the packing of the codes (pack_codes_kernel):
+// two kernels that read and write one byte per symbol three times over (count, scatter, pack).  Here the raw bytes are read once
+// (1 + 1 / line_width bytes per symbol) and 0.25 bytes per symbol are written.
+//
+// Shape: a compaction needs every tile's output offset = the number of symbols kept in front of it.  The tiles are handed out in
+// ticket order and publish their counts through a chained scan with decoupled look-back (one 64-bit word per tile: 2 flag bits +
+// the count or the inclusive prefix), so a tile knows its offset a few hundred cycles after it has counted its own bytes, which
+// are still in registers.  A tile of 16 KiB of input then writes WHOLE 1024-symbol blocks only: it owns the blocks whose first
+// symbol it holds, leaves the symbols in front of its first block to the tile before it and reads on into the next tiles'
+// bytes (<= 1023 symbols, L2 hits for the neighbour) to finish its last block -- words, escape index and escaped bytes of a block
+// have one writer, nothing is zeroed beforehand and no atomics touch the output.
+#pragma once
+
+namespace agc {
+
+constexpr uint32_t PF_TILE = 16384;                    // input bytes per tile: 256 threads x 4 chunks x 16 B
+constexpr uint32_t PF_MAX_BLOCKS = PF_TILE / PACK_BLOCK + 1; // blocks a tile can own (16; + 1 of slack)
+constexpr uint64_t PF_FLAG_AGG = 1ULL << 62, PF_FLAG_INCL = 2ULL << 62, PF_VALUE = (1ULL << 62) - 1;
+
+struct PackFastaArgs {
+    const uint8_t *raw;
+    uint64_t n_raw;
+    const uint64_t *rng_begin, *rng_end; // contig c = raw bytes [rng_begin[c], rng_end[c]); ascending, disjoint
+    uint32_t n_rng;
+    uint32_t n_tiles;
+    uint32_t *ticket;                    // zeroed
+    unsigned long long *state;           // n_tiles words, zeroed
+    uint32_t *words;
+    int32_t *esc_index;
+    uint8_t *esc_bytes;
+    uint32_t *esc_count;                 // zeroed
+    uint32_t esc_cap;
+    unsigned long long *ctg_off;         // n_rng + 1 symbol offsets (all-ones where no tile holds the contig's first byte: host)
+    unsigned long long *total;           // symbols in all
+};
+
+// one chunk of 16 raw bytes: which of them are symbols, their 2-bit codes squeezed together, whether any lies outside ACGT
+struct PfChunk {
+    uint32_t bits;  // 2 bits per KEPT symbol, first symbol lowest
+    uint32_t cnt;   // kept symbols (<= 16)
+    uint32_t keep;  // bit j: raw byte j is a symbol
+    bool other;     // a kept symbol outside ACGT
+};
+
+// byte j of the four words (a select chain: a dynamic index would send the words to scratch memory)
+__device__ __forceinline__ uint8_t pf_byte(const uint32_t w[4], uint32_t j)
+{
+    const uint32_t q = j >> 2, x = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
+    return (uint8_t)(x >> (8 * (j & 3)));
+}
+
+// per byte of w: 1 where the byte is >= 64
+__device__ __forceinline__ uint32_t pf_ge64(uint32_t w) { return ((w >> 6) | (w >> 7)) & 0x01010101u; }
+
+// the bytes of [p, p + 16) that lie inside a contig range -> 16-bit mask.  [cb, ce) is a range the caller knows (the one its tile
+// starts in); only chunks that leave it walk the list.
+__device__ __forceinline__ uint32_t pf_range_mask(const PackFastaArgs &a, uint64_t p, uint64_t cb, uint64_t ce, uint32_t r_first)
+{
+    if (p >= cb && p + 16 <= ce)
+        return 0xFFFFu;
+    uint32_t m = 0;
+    uint32_t r = r_first;
+    while (r < a.n_rng && a.rng_end[r] <= p)
+        ++r;
+    for (; r < a.n_rng && a.rng_begin[r] < p + 16; ++r) {
+        const uint64_t b = a.rng_begin[r] > p ? a.rng_begin[r] - p : 0, e = a.rng_end[r] < p + 16 ? a.rng_end[r] - p : 16;
+        if (e > b)
+            m |= ((1u << e) - 1u) & ~((1u << b) - 1u);
+    }
+    return m;
+}
+
+__device__ __forceinline__ PfChunk pf_chunk(const PackFastaArgs &a, uint64_t p, uint64_t cb, uint64_t ce, uint32_t r_first, uint32_t w[4])
+{
+    PfChunk c;
+    c.bits = 0;
+    c.cnt = 0;
+    c.keep = 0;
+    c.other = false;
+    if (p >= a.n_raw) {
+        w[0] = w[1] = w[2] = w[3] = 0;
+        return c;
+    }
+    if (p + 16 <= a.n_raw) {
+        const uint4 v = *(const uint4 *)(a.raw + p); // (p is a multiple of 16, the buffer 16-byte aligned)
+        w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) // (static indices: the words stay in registers)
+            if (p + j < a.n_raw)
+                w[j >> 2] |= (uint32_t)a.raw[p + j] << (8 * (j & 3));
+    }
+    uint32_t keep = 0, bits = 0, bad = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t x = w[q];
+        const uint32_t g = pf_ge64(x);                                 // 0x01 per byte >= 64
+        keep |= (((g * 0x01020408u) >> 24) & 0xFu) << (4 * q);         // the four flags, byte 0's lowest
+        // ACGT / acgt: the code is bits 1..2 of the letter, with G and T exchanged (A 0x41 C 0x43 G 0x47 T 0x54 -> 0 1 3 2 -> 0 1 2 3)
+        const uint32_t t = (x >> 1) & 0x03030303u;
+        const uint32_t code = t ^ ((t >> 1) & 0x01010101u);
+        bits |= (((code * 0x00041041u) >> 18) & 0xFFu) << (8 * q);      // the four 2-bit codes side by side, byte 0's lowest
+        // is it one of the four letters?  the letter the two bits stand for, against the byte with its case bit cleared
+        const uint32_t b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u;
+        const uint32_t expect = 0x41414141u + 2u * b0 + 0x13u * b1 - 0x0Fu * (b0 & b1);
+        const uint32_t diff = (x & 0xDFDFDFDFu) ^ expect;
+        const uint32_t nz = ((diff | ((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u; // 0x01 per byte that differs
+        bad |= ((((nz & g) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+    }
+    keep &= pf_range_mask(a, p, cb, ce, r_first);
+    bad &= keep;
+    if (bad) { // a symbol outside ACGT: its code's two low bits stand in the word (nobody reads them: the block is escaped)
+        c.other = true;
+        for (uint32_t m = bad; m; m &= m - 1) {
+            const uint32_t j = __builtin_ctz(m);
+            bits = (bits & ~(3u << (2 * j))) | ((uint32_t)(cnv_symbol(pf_byte(w, j)) & 3u) << (2 * j));
+        }
+    }
+    // squeeze the dropped bytes' fields out, highest first
+    for (uint32_t m = ~keep & 0xFFFFu; m;) {
+        const uint32_t j = 31 - __builtin_clz(m);
+        m &= ~(1u << j);
+        const uint32_t low = j ? (0xFFFFFFFFu >> (32 - 2 * j)) : 0u;
+        bits = (bits & low) | ((bits >> 2) & ~low);
+    }
+    c.bits = bits;
+    c.keep = keep;
+    c.cnt = __popc(keep);
+    if (c.cnt < 16)
+        c.bits &= c.cnt ? (0xFFFFFFFFu >> (32 - 2 * c.cnt)) : 0u;
+    return c;
+}
+
+// inclusive scan of v over the 64 lanes
+__device__ __forceinline__ uint32_t pf_wave_incl(uint32_t v)
+{
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(v, o);
+        if (lane >= (uint32_t)o)
+            v += u;
+    }
+    return v;
+}
+
+// symbols [g, g + cnt) with the 2-bit fields `bits` -> the tile's word stage in LDS, as far as they lie in [s0, s1)
+__device__ __forceinline__ void pf_stage(uint32_t *lds_words, uint32_t *lds_flag, uint64_t g, uint32_t cnt, uint32_t bits, bool other, uint64_t s0, uint64_t s1)
+{
+    if (!cnt || g + cnt <= s0 || g >= s1)
+        return;
+    if (g < s0) {
+        const uint32_t d = (uint32_t)(s0 - g);
+        bits >>= 2 * d;
+        cnt -= d;
+        g = s0;
+    }
+    if (g + cnt > s1) {
+        cnt = (uint32_t)(s1 - g);
+        bits &= 0xFFFFFFFFu >> (32 - 2 * cnt);
+    }
+    const uint32_t li = (uint32_t)(g - s0), sh = 2 * (li & 15);
+    atomicOr(&lds_words[li >> 4], bits << sh);
+    if (sh && (li & 15) + cnt > 16)
+        atomicOr(&lds_words[(li >> 4) + 1], bits >> (32 - sh));
+    if (other) { // (to the block: whether the symbol outside ACGT is among the clipped ones is not worth telling apart -- it is, nearly always)
+        lds_flag[li / PACK_BLOCK] = 1;
+        if ((li + cnt - 1) / PACK_BLOCK != li / PACK_BLOCK)
+            lds_flag[(li + cnt - 1) / PACK_BLOCK] = 1;
+    }
+}
+
+// the escaped form of the same symbols: one byte each, cnv_num's codes
+__device__ __forceinline__ void pf_escape(const PackFastaArgs &a, const int32_t *lds_slot, uint64_t g, uint32_t keep, const uint32_t w[4], uint64_t s0, uint64_t s1)
+{
+    for (uint32_t m = keep; m; m &= m - 1, ++g) {
+        if (g < s0 || g >= s1)
+            continue;
+        const int32_t slot = lds_slot[(g - s0) / PACK_BLOCK];
+        if (slot >= 0)
+            a.esc_bytes[(uint64_t)slot * PACK_BLOCK + ((g - s0) & (PACK_BLOCK - 1))] = cnv_symbol(pf_byte(w, __builtin_ctz(m)));
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
+{
+    __shared__ uint32_t s_words[PF_MAX_BLOCKS * (PACK_BLOCK / 16)];
+    __shared__ uint32_t s_flag[PF_MAX_BLOCKS];
+    __shared__ int32_t s_slot[PF_MAX_BLOCKS];
+    __shared__ uint32_t s_wsum[4 * 4]; // [chunk row j][wave]
+    __shared__ uint32_t s_tile, s_rfirst;
+    __shared__ unsigned long long s_excl, s_cb, s_ce;
+    __shared__ uint32_t s_ra[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    if (tid == 0)
+        s_tile = atomicAdd(a.ticket, 1u);
+    for (uint32_t i = tid; i < PF_MAX_BLOCKS * (PACK_BLOCK / 16); i += 256)
+        s_words[i] = 0;
+    if (tid < PF_MAX_BLOCKS) {
+        s_flag[tid] = 0;
+        s_slot[tid] = -1;
+    }
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= a.n_tiles)
+        return;
+    const uint64_t t_begin = (uint64_t)tile * PF_TILE, t_end = t_begin + PF_TILE < a.n_raw ? t_begin + PF_TILE : a.n_raw;
+    if (tid == 0) {
+        // the first range that ends behind the tile's first byte
+        uint32_t lo = 0, hi = a.n_rng;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.rng_end[mid] <= t_begin)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        s_rfirst = lo;
+        s_cb = lo < a.n_rng ? a.rng_begin[lo] : ~0ULL;
+        s_ce = lo < a.n_rng ? a.rng_end[lo] : 0;
+    }
+    __syncthreads();
+    const uint32_t r_first = s_rfirst;
+    const uint64_t cb = s_cb, ce = s_ce;
+
+    // ---- own tile: four rows of 64 x 16 bytes per wave, every load coalesced
+    uint32_t w[4][4];
+    PfChunk ch[4];
+    uint32_t rank[4]; // exclusive rank of the chunk's first symbol inside the tile
+    uint32_t wave_tot = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t p = t_begin + (uint64_t)wv * 4096 + j * 1024 + lane * 16;
+        ch[j] = pf_chunk(a, p, cb, ce, r_first, w[j]);
+        const uint32_t incl = pf_wave_incl(ch[j].cnt);
+        rank[j] = wave_tot + incl - ch[j].cnt;
+        wave_tot += (uint32_t)__shfl((int)incl, 63);
+    }
+    if (lane == 0)
+        s_wsum[wv] = wave_tot;
+    __syncthreads();
+    uint32_t wbase = 0, cnt_tile = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < 4; ++x) {
+        if (x < wv)
+            wbase += s_wsum[x];
+        cnt_tile += s_wsum[x];
+    }
+
+    // ---- the tile's offset: publish the count, look back
+    if (wv == 0) {
+        unsigned long long excl = 0;
+        if (tile) {
+            if (lane == 0)
+                __hip_atomic_store(&a.state[tile], PF_FLAG_AGG | cnt_tile, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t look = (int64_t)tile - 1;
+            for (;;) {
+                const int64_t idx = look - lane;
+                unsigned long long s = PF_FLAG_INCL; // (in front of tile 0: nothing)
+                if (idx >= 0)
+                    s = __hip_atomic_load(&a.state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t inv = __ballot((s >> 62) == 0), inc = __ballot((s >> 62) == 2);
+                const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u, first_inv = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
+                if (first_inv < first_inc) { // a tile in front has not counted yet
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                unsigned long long v = lane <= first_inc ? (s & PF_VALUE) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    v += __shfl_xor(v, o);
+                excl += v;
+                if (first_inc < 64)
+                    break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&a.state[tile], PF_FLAG_INCL | (excl + cnt_tile), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+    }
+    __syncthreads();
+    const uint64_t o = s_excl;
+
+    // ---- contigs that start in this tile: their symbol offset (the lane whose chunk holds the first byte)
+    if (cb >= t_begin || (r_first + 1 < a.n_rng && a.rng_begin[r_first + 1] < t_end)) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint64_t p = t_begin + (uint64_t)wv * 4096 + j * 1024 + lane * 16;
+            for (uint32_t r = r_first; r < a.n_rng && a.rng_begin[r] < p + 16; ++r)
+                if (a.rng_begin[r] >= p && a.rng_begin[r] < a.n_raw)
+                    a.ctg_off[r] = o + wbase + rank[j] + __popc(ch[j].keep & ((1u << (a.rng_begin[r] - p)) - 1u));
+        }
+    }
+    if (tile == a.n_tiles - 1 && tid == 0)
+        *a.total = o + cnt_tile;
+
+    // ---- the blocks this tile owns: those whose first symbol it holds
+    const uint64_t s0 = (o + PACK_BLOCK - 1) / PACK_BLOCK * PACK_BLOCK;
+    if (s0 >= o + cnt_tile)
+        return; // (none: its symbols belong to the last block of a tile in front)
+    const uint64_t s1 = (o + cnt_tile - 1) / PACK_BLOCK * PACK_BLOCK + PACK_BLOCK;
+    const uint32_t n_own = (uint32_t)((s1 - s0) / PACK_BLOCK);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        pf_stage(s_words, s_flag, o + wbase + rank[j], ch[j].cnt, ch[j].bits, ch[j].other, s0, s1);
+    // ---- the rest of the last block, from the bytes behind the tile (rounds of 256 x 16 bytes)
+    // (a round looks at as many bytes as the missing symbols need at a line width of 16 or more, not at 4 KiB: what lies behind the
+    // tile is another tile's input, quite possibly in another XCD's L2)
+    uint64_t g_next = o + cnt_tile, p_next = t_begin + PF_TILE;
+    uint32_t n_rounds = 0;
+    while (g_next < s1 && p_next < a.n_raw) {
+        uint32_t wr[4];
+        const uint32_t need = (uint32_t)(s1 - g_next), span = min(4096u, (need + need / 16 + 47) & ~15u);
+        const PfChunk c = pf_chunk(a, tid * 16 < span ? p_next + tid * 16 : a.n_raw, cb, ce, r_first, wr);
+        const uint32_t incl = pf_wave_incl(c.cnt);
+        __syncthreads(); // (s_ra of the round before has been read)
+        if (lane == 63)
+            s_ra[wv] = incl;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < 4; ++x) {
+            if (x < wv)
+                base += s_ra[x];
+            tot += s_ra[x];
+        }
+        pf_stage(s_words, s_flag, g_next + base + incl - c.cnt, c.cnt, c.bits, c.other, s0, s1);
+        g_next += tot;
+        p_next += span;
+        ++n_rounds;
+    }
+    __syncthreads();
+    // ---- escaped blocks: a slot each
+    if (tid < n_own) {
+        int32_t slot = -1;
+        if (s_flag[tid]) {
+            const uint32_t s = atomicAdd(a.esc_count, 1u);
+            slot = s < a.esc_cap ? (int32_t)s : -2; // (over capacity: the caller comes again with a larger buffer)
+        }
+        s_slot[tid] = slot;
+        a.esc_index[s0 / PACK_BLOCK + tid] = slot;
+    }
+    // ---- the words
+    {
+        uint32_t *out = a.words + s0 / 16;
+        const uint32_t n_words = n_own * (PACK_BLOCK / 16);
+        for (uint32_t i = tid * 4; i < n_words; i += 1024)
+            *(uint4 *)(out + i) = make_uint4(s_words[i], s_words[i + 1], s_words[i + 2], s_words[i + 3]); // (s0 / 16 is a multiple of 64 words)
+    }
+    __syncthreads();
+    bool any = false;
+    for (uint32_t i = 0; i < n_own; ++i)
+        any |= s_slot[i] >= 0;
+    if (!any)
+        return;
+    // ---- ... and their symbols one byte each: the same walk again (rare: N runs, IUPAC codes)
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        pf_escape(a, s_slot, o + wbase + rank[j], ch[j].keep, w[j], s0, s1);
+    g_next = o + cnt_tile;
+    p_next = t_begin + PF_TILE;
+    for (uint32_t r = 0; r < n_rounds; ++r) {
+        uint32_t wr[4];
+        const uint32_t need = (uint32_t)(s1 - g_next), span = min(4096u, (need + need / 16 + 47) & ~15u);
+        const PfChunk c = pf_chunk(a, tid * 16 < span ? p_next + tid * 16 : a.n_raw, cb, ce, r_first, wr);
+        const uint32_t incl = pf_wave_incl(c.cnt);
+        __syncthreads();
+        if (lane == 63)
+            s_ra[wv] = incl;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < 4; ++x) {
+            if (x < wv)
+                base += s_ra[x];
+            tot += s_ra[x];
+        }
+        pf_escape(a, s_slot, g_next + base + incl - c.cnt, c.keep, wr, s0, s1);
+        g_next += tot;
+        p_next += span;
+    }
+    // (the tail of a last, partial block in an escaped slot stays as it is: nobody reads beyond n_symbols)
+}
+
+} // namespace agc

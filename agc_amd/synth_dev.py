@@ -89,3 +89,49 @@ def positional_splitters(ref, ctg_off, k, segment_size):
     ends_t = torch.tensor(ends, dtype=torch.int64, device=ref.device)
     can, _d, _rc = kmers_ending_at(ref, ends_t, k)
     return np.unique(can)
+
+
+_LETTERS = None
+
+
+def make_fasta(codes, ctg_off, names, width=60):
+    """codes (uint8 tensor in HBM, contigs back to back at ctg_off) -> the bytes of the FASTA FILE that holds them, resident in
+    HBM: a header line per contig, `width` letters per line, '\\n' line ends.  Returns (raw uint8 tensor with 64 bytes of slack,
+    n_raw, raw_begin, raw_end): contig c's sequence lines are raw[raw_begin[c]:raw_end[c]] -- what genome_io hands to the
+    reference's workers (src/core/agc_compressor.cpp:2160-2228), what agc_hip_pack_fasta_* takes."""
+    global _LETTERS
+    dev = codes.device
+    if _LETTERS is None or _LETTERS.device != dev:
+        _LETTERS = torch.tensor(list(b"ACGTNRYSWKMBDHVU"), dtype=torch.uint8, device=dev)
+    n_ctg = len(ctg_off) - 1
+    heads = [(">%s\n" % names[c]).encode() for c in range(n_ctg)]
+    lens = [int(ctg_off[c + 1]) - int(ctg_off[c]) for c in range(n_ctg)]
+    body = [ln + (ln + width - 1) // width for ln in lens]
+    n_raw = sum(len(h) for h in heads) + sum(body)
+    raw = torch.empty(n_raw + 64, dtype=torch.uint8, device=dev)
+    raw[n_raw:] = 0
+    rb, re_ = np.zeros(n_ctg, np.uint64), np.zeros(n_ctg, np.uint64)
+    o = 0
+    step = (1 << 26) // width * width
+    for c in range(n_ctg):
+        raw[o:o + len(heads[c])] = torch.tensor(list(heads[c]), dtype=torch.uint8, device=dev)
+        o += len(heads[c])
+        rb[c] = o
+        b0 = int(ctg_off[c])
+        for b in range(0, lens[c], step):
+            e = min(lens[c], b + step)
+            letters = _LETTERS[codes[b0 + b:b0 + e].to(torch.int64)]
+            full = (e - b) // width
+            if full:
+                blk = raw[o:o + full * (width + 1)].view(full, width + 1)
+                blk[:, :width] = letters[:full * width].view(full, width)
+                blk[:, width] = 10
+                o += full * (width + 1)
+            rest = (e - b) - full * width
+            if rest:  # (only the contig's last line)
+                raw[o:o + rest] = letters[full * width:]
+                raw[o + rest] = 10
+                o += rest + 1
+        re_[c] = o
+    assert o == n_raw
+    return raw, n_raw, rb, re_

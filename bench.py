@@ -62,6 +62,11 @@ def parse():
                          "SARS-CoV-2-size genomes (30 kb, 1 %% SNP from one reference), default parameters, from FASTA files through the product "
                          "CLI path; the reference CLI is timed beside it on the same files and the two archives are compared.  c4twin / c5twin: the "
                          "1/100 twins of configs[3] / configs[4] the parity tests use, the same way; all three with a stage breakdown")
+    ap.add_argument("--prepacked", action="store_true",
+                    help="round-4 input: every sample packed into the 2-bit layout BEFORE the timer starts.  Default since round 5: the "
+                         "samples are resident in HBM as the bytes of their FASTA files and the timed step turns them into the 2-bit layout "
+                         "(agc_hip_pack_fasta_*: preprocess_raw_contig + packing in one pass), two samples ahead on a stream of its own")
+    ap.add_argument("--fasta-width", type=int, default=60, help="letters per FASTA line of the HBM-resident inputs")
     ap.add_argument("--no-prefetch", action="store_true", help="do not announce the next sample (its scan then runs inside its own step)")
     ap.add_argument("--verify-entropy", action="store_true",
                     help="CHECKING RUN, not a measurement: every frame the device entropy stage returns (all the packs of this run's Close) is "
@@ -86,11 +91,12 @@ def host_cpus():
 PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r4", "r3"))
                     if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r4", "pmc_summary.csv"))
 KERNEL_SYMBOL = {"scan": "agc::scan_packed_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
-                 "costvec": "agc::lz_parse_kernel<2>", "filter": "agc::key_filter_kernel",
+                 "costvec": "agc::lz_parse_kernel<2>", "filter": "agc::key_filter_kernel", "pack": "agc::pack_fasta_kernel",
                  "zstd": "agc::zstd_frames_grp_kernel<3, 2>"}
 # bytes per symbol each kernel reads in the layout AS BUILT = SURVEY 8d's 2-bit column since round 4: scan, key filter and the
 # three LZ parses read texts and references as 2-bit words where they lie (no expansion, no reverse-complement staging)
-AS_BUILT_BPS = {"scan": 0.25, "encode": 0.25, "estimate": 0.25, "costvec": 0.25, "filter": 0.25}
+# (pack: the FASTA bytes of a symbol, 1 + 1 / line width, read once + its 0.25 B written: filled in by main() for --fasta-width)
+AS_BUILT_BPS = {"scan": 0.25, "encode": 0.25, "estimate": 0.25, "costvec": 0.25, "filter": 0.25, "pack": 1.0 + 1.0 / 60 + 0.25}
 PACKED_BPS = AS_BUILT_BPS
 
 
@@ -433,7 +439,7 @@ def main():
             if i == 0:
                 return "ref", names, ref.data_ptr(), off
             s_ = (i - rank) // world - (1 if rank == 0 else 0)
-            return f"s{rank}_{s_}", names, samples[s_][0], off
+            return f"s{rank}_{s_}", names, packed_sample(s_)[0], sample_off[s_]
 
         dc.compress(1, get_sample)  # sample 0: minted on rank 0, its record (the whole reference set) broadcast
     else:
@@ -447,9 +453,17 @@ def main():
             # the next sample is known (as a reader that runs ahead of the compressor knows its next file): its
             # splitter scan is queued on the device beside this sample's classification / encode / registration.  Not across
             # the warm-up / timed boundary: every timed sample's scan runs inside the timed region.
-            if s + 1 < n_steps and s + 1 != args.warmup and not args.no_prefetch:
-                cmp_.set_next_sample_packed_dev(samples[s + 1][0], off)
-            cmp_.add_sample_packed_dev(f"{tag}{rank}_{s}", names, samples[s][0], off)
+            # FASTA bytes -> 2-bit layout: this sample's and the next one's packs were queued one and two steps ago (at the start of
+            # the warm-up and of the timed region: here, and waited for); the one after next is queued now and runs beside this step
+            packed_sample(s)
+            nxt = s + 1 < n_steps and s + 1 != args.warmup
+            if nxt:
+                packed_sample(s + 1)
+            if s + 2 < n_steps and (s + 2 < args.warmup) == (s < args.warmup):
+                start_pack(s + 2)
+            if nxt and not args.no_prefetch:
+                cmp_.set_next_sample_packed_dev(samples[s + 1][0], sample_off[s + 1])
+            cmp_.add_sample_packed_dev(f"{tag}{rank}_{s}", names, samples[s][0], sample_off[s])
             return
         # (each step: the N samples prepared in parallel.  AGC_BENCH_SERIAL_PREPARE=1, a measuring aid for ranks that SHARE one GPU:
         # every rank prepares at its own turn, so the per-stage times of config.single_archive_ms_per_sample_rank0 are those of an
@@ -462,12 +476,41 @@ def main():
     # packed, and the codes dropped.  Inside a step every kernel reads the packed words where they lie.
     from agc_amd import capi
     hctx = capi.Context.from_handle(cmp_.hip_ctx())
-    samples = []
+    # Default (round 5): a sample is resident as THE BYTES OF ITS FASTA FILE (header lines, --fasta-width letters per line, line
+    # ends: 1 + 1 / width bytes per base) and the timed step makes the 2-bit layout from them (agc_hip_pack_fasta_begin / _end: the
+    # reference's preprocess_raw_contig + the packing, one pass; its output buffers are allocated here, its work is timed).
+    # --prepacked: packed before the timer starts, as in round 4.
+    samples = [None] * n_steps      # (Packed, backing tensors) once packed
+    sample_off = [off] * n_steps    # the contigs' symbol offsets as the pack returns them
+    fasta = []                      # per sample: (raw bytes in HBM, n_raw, raw_begin, raw_end, (words, index, esc))
+    pack_pending = {}
+    AS_BUILT_BPS["pack"] = 1.0 + 1.0 / args.fasta_width + 0.25
     for s in range(n_steps):
         codes = synth_dev.make_sample(ref, tot, args.div, shard.sample_seed(1000, s, rank, world), dev)
-        samples.append(hctx.pack_dev(codes, tot))
+        if args.prepacked:
+            samples[s] = hctx.pack_dev(codes, tot)
+        else:
+            raw, n_raw, rb, re_ = synth_dev.make_fasta(codes, off, names, args.fasta_width)
+            bufs = (torch.empty(int(hctx.L.agc_hip_packed_words_bytes(tot)) // 4 + 4, dtype=torch.int32, device=dev),
+                    torch.empty(int(hctx.L.agc_hip_packed_index_bytes(tot)) // 4 + 1, dtype=torch.int32, device=dev),
+                    torch.empty(64 * 1024, dtype=torch.uint8, device=dev))
+            fasta.append((raw, n_raw, rb, re_, bufs))
         del codes
     torch.cuda.synchronize()
+
+    def start_pack(s):
+        if samples[s] is None and s not in pack_pending:
+            raw, n_raw, rb, re_, bufs = fasta[s]
+            pack_pending[s] = hctx.pack_fasta_begin(raw, n_raw, rb, re_, bufs=bufs)
+
+    def packed_sample(s):
+        if samples[s] is None:
+            start_pack(s)
+            pk, keep, o_ = hctx.pack_fasta_end(pack_pending.pop(s))
+            if not np.array_equal(o_, np.asarray(off, np.uint64)):
+                raise SystemExit(f"bench.py: the pack of sample {s} returned other contig offsets than the generator's")
+            samples[s], sample_off[s] = (pk, keep), o_
+        return samples[s]
 
     def barrier():
         torch.cuda.synchronize()
@@ -519,12 +562,12 @@ def main():
         # key-filter kernel that writes the "may match" bitmaps of the estimate / cost-vector parses: it reads every text once;
         # there is no expansion kernel any more: every row's time is that kernel's alone).
         n_rank_steps = max(args.steps * world, 1)
-        sym = {"scan": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"],
+        sym = {"scan": stats["bases"], "pack": stats["bases"], "encode": stats["enc_text"] + stats["enc_ref"],
                "estimate": stats["est_text"] + stats["est_ref"], "costvec": stats["cv_text"] + stats["cv_ref"],
                "filter": stats["est_text"] + stats["cv_text"]}
         tab = pmc_table()
         kern = {}
-        for name in ("scan", "encode", "estimate", "costvec", "filter"):
+        for name in ("pack", "scan", "encode", "estimate", "costvec", "filter"):
             ms_, n_ = tm[name]
             if not n_:
                 continue
@@ -565,14 +608,17 @@ def main():
         dom = kern.get(dominant, {})
         per = lambda x: x / max(args.steps * world, 1)
         out = {
-            "metric": "input Gbp/s compressed (create), hot path scan + match + encode + zstd packing",
+            "metric": "input Gbp/s compressed (create), hot path " + ("" if args.prepacked else "FASTA bytes in HBM -> 2-bit pack + ") + "scan + match + encode + zstd packing",
             "value": round(value, 3), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: GRCh38-shaped {args.gbp:g} Gbp reference (24 contigs), one {args.gbp:g} Gbp sample per GPU per step, "
                                    f"d={args.div:g}, k={K} l={MML} b={pack_card} s={SEG}"
                                    + (" (OVERLAP VARIANT: packs fill during the steps)" if pack_card != PACK else ""),
-                       "stages_timed": "per step: splitter-scan kernel, hit fix-up, add_segment classification (one-splitter estimates and "
+                       "input": ("samples packed into the 2-bit layout before the timer (--prepacked)" if args.prepacked else
+                                 f"samples resident in HBM as the bytes of their FASTA files ({args.fasta_width} letters per line); every timed sample's "
+                                 "conversion + 2-bit packing (agc_hip_pack_fasta_*, one pass) runs inside the timed region, two samples ahead on its own stream"),
+                       "stages_timed": "per step: " + ("" if args.prepacked else "FASTA bytes -> 2-bit words (one-pass kernel), ") + "splitter-scan kernel, hit fix-up, add_segment classification (one-splitter estimates and "
                                        "missing-middle split points on the GPU), group registration, index build of new references, LZ-diff "
                                        "encode kernel, delta D2H, pack bookkeeping, collection records (a sample's encode is collected and its "
                                        "bookkeeping done on a second thread beside the next sample's scan and classification; the next sample's "

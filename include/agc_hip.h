@@ -59,7 +59,8 @@ enum {
     AGC_HIP_K_ZSTD = 8,
     AGC_HIP_K_FILTER = 9, /* key_filter_kernel: the "may match" bitmaps of the estimate / cost-vector parses */
     AGC_HIP_K_SEGMENTS = 10, /* agc_hip_segments_packed: hits -> segments -> group look-up -> encode descriptors (seg_kernels.hip) */
-    AGC_HIP_K_COUNT = 11
+    AGC_HIP_K_PACK = 11,     /* agc_hip_pack_fasta_*: raw FASTA bodies -> the 2-bit packed sample in one pass (pack_kernels.hip) */
+    AGC_HIP_K_COUNT = 12
 };
 int agc_hip_timing_enable(agc_hip_ctx *ctx, int on);
 int agc_hip_timing_reset(agc_hip_ctx *ctx);
@@ -141,6 +142,22 @@ uint64_t agc_hip_packed_index_bytes(uint64_t n_symbols);
  * esc_cap_blocks blocks have to be escaped. */
 int agc_hip_pack_dev(agc_hip_ctx *ctx, const uint8_t *d_codes, uint64_t n_symbols, uint32_t *d_words, int32_t *d_esc_index,
                      uint8_t *d_esc_bytes, uint64_t esc_cap_blocks, uint64_t *h_n_esc_blocks);
+/* Raw FASTA bodies (device) -> packed, in ONE pass over the input: preprocess_raw_contig (src/core/agc_compressor.cpp:907-951 --
+ * every byte < 64, i.e. the line ends, dropped; the others through cnv_num, src/common/agc_basic.h:39-49) fused with the packing,
+ * no intermediate one-byte-per-symbol buffer.  Contig c = the raw bytes [h_raw_begin[c], h_raw_end[c]) of d_raw -- its sequence
+ * lines as the file holds them, what genome_io hands to the reference's workers (src/core/agc_compressor.cpp:2160-2228); the
+ * ranges ascend and do not overlap, whatever lies between them (header lines) is skipped.  The contigs land back to back in the
+ * packed buffer; h_ctg_off[0..n_ctg] receives their symbol offsets (h_ctg_off[n_ctg] = n_symbols).  The output buffers must hold
+ * agc_hip_packed_words_bytes / _index_bytes of an upper bound of the symbol count (the kept bytes: <= the sum of the range
+ * lengths); d_raw and d_words 16-byte aligned.  AGC_HIP_ECAP (+ the needed count) when more than esc_cap_blocks blocks are escaped.
+ * begin queues the work on a stream of its own and returns; end waits and delivers (one pack in flight per context; the buffers
+ * must not be touched in between).  Every other entry point may be used meanwhile. */
+int agc_hip_pack_fasta_begin(agc_hip_ctx *ctx, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *h_raw_begin, const uint64_t *h_raw_end,
+                             uint32_t n_ctg, uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks);
+int agc_hip_pack_fasta_end(agc_hip_ctx *ctx, uint64_t *h_ctg_off, uint64_t *h_n_esc_blocks);
+int agc_hip_pack_fasta_dev(agc_hip_ctx *ctx, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *h_raw_begin, const uint64_t *h_raw_end,
+                           uint32_t n_ctg, uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks,
+                           uint64_t *h_ctg_off, uint64_t *h_n_esc_blocks);
 /* packed -> codes (d_codes: n_symbols bytes, 16-byte aligned).  Nothing on the create path needs it (the LZ kernels read the
  * packed form); a utility for callers and tests.  Asynchronous on the context's stream (ordered before every later call). */
 int agc_hip_expand_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, uint8_t *d_codes);
@@ -288,6 +305,9 @@ int agc_hip_lz_encode_begin_packed_on(agc_hip_ctx *ctx, uint32_t lane, uint32_t 
                                       const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc);
 int agc_hip_lz_encode_end_on(agc_hip_ctx *ctx, uint32_t lane, uint8_t *h_enc, uint64_t enc_cap, uint64_t *h_enc_off);
 int agc_hip_lz_encode_pending_on(agc_hip_ctx *ctx, uint32_t lane, uint32_t *h_n);
+/* gives up the encode in flight on a lane (waits for its kernels, delivers nothing): a host that prepared a sample ahead of its
+ * turn and has to prepare it again (adaptive mode in the N-rank mode: the splitter set grew meanwhile) */
+int agc_hip_lz_encode_drop_on(agc_hip_ctx *ctx, uint32_t lane);
 
 /* Pinned host memory for result buffers (device-to-host copies into pageable memory go through a bounce buffer at a
  * fraction of the link rate).  Freed by agc_hip_host_free or with the context. */

@@ -392,6 +392,15 @@ int agc_hip_lz_encode_pending_on(agc_hip_ctx *c, uint32_t lane, uint32_t *h_n)
     return AGC_HIP_OK;
 }
 
+int agc_hip_lz_encode_drop_on(agc_hip_ctx *c, uint32_t lane)
+{
+    if (!c || lane >= AGC_HIP_ENCODE_LANES)
+        return AGC_HIP_EINVAL;
+    if (c->enc[lane].pending)
+        enc_clear(c, lane);
+    return AGC_HIP_OK;
+}
+
 int agc_hip_lz_encode_end_on(agc_hip_ctx *c, uint32_t lane, uint8_t *h_enc, uint64_t cap, uint64_t *h_enc_off)
 {
     if (!c || !h_enc_off || lane >= AGC_HIP_ENCODE_LANES)

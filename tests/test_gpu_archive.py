@@ -201,3 +201,26 @@ def test_baseline_config1_full_size(tmp_path, concat):
     got = _run_amd(args, files, str(tmp_path / "amd.agc"))
     if got != want:
         pytest.fail("\n".join(agc_container.diff(want, got)))
+
+
+# sha256 / size of the archive the reference CLI (oracle/_ref/agc, libzstd 1.4.9) wrote for BASELINE configs[2] at FULL size --
+# the seeded 3 Gbp GRCh38-shaped reference + ONE 3 Gbp sample at d = 1e-3, -k 31 -l 15 -b 100 -- recorded by
+# scripts/c3_full_identity.py on the GPU box (profiles/r4/c3_full_size_identity_1_sample_against_reference_cli_run.log: 256 s of
+# reference-CLI time, which is why the test compares with the recorded hash instead of running the CLI again)
+C3_FULL_1_SAMPLE = ("46b81e041ac68005a743d229bca09bf1d809d161fc3a145f6f97cba7858e6d9f", 767396631)
+
+
+def test_configs2_at_full_size_equals_the_reference_archive():
+    """BASELINE configs[2] at full contig size through the product path bench.py times (samples resident in the 2-bit layout,
+    agc_cmp_add_sample_packed_dev, device segments, two encode lanes, GPU entropy stage): the archive has the reference CLI's
+    recorded sha256, and every frame the device entropy stage returned equals libzstd's (AGC_AMD_VERIFY_DEV_FRAMES=1)."""
+    import re
+    import sys
+    env = dict(os.environ, AGC_AMD_VERIFY_DEV_FRAMES="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "c3_full_identity.py"), "3.0", "1", C3_FULL_1_SAMPLE[0]],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    assert f"agc_amd {C3_FULL_1_SAMPLE[1]} {C3_FULL_1_SAMPLE[0]}" in r.stdout
+    checks = re.findall(r"verify: (\d+) device frames .*?: (\d+) differ", r.stderr)
+    assert checks and sum(int(n) for n, _ in checks) > 10000, r.stderr[-1500:]  # (the reference sample's 50 k references go through levels 13 / 19 there)
+    assert all(int(bad) == 0 for _, bad in checks), checks

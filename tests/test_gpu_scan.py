@@ -94,6 +94,123 @@ def test_preprocess(hip_ctx, oracle):
     assert np.array_equal(d_out[:n].cpu().numpy(), want)
 
 
+def _fasta_case(rng, contigs, width, eol=b"\n", lower=0.0, junk=0.0):
+    """contigs (arrays of letters) -> (raw file bytes, raw_begin, raw_end): header lines between the bodies, `width` letters per
+    line, optional lower-case letters and bytes < 64 sprinkled into the lines"""
+    raw = bytearray()
+    rb, re_ = [], []
+    for i, c in enumerate(contigs):
+        raw += b">ctg%d some description\n" % i
+        rb.append(len(raw))
+        c = c.copy()
+        if lower:
+            m = rng.random(c.size) < lower
+            c[m] |= 0x20
+        for a in range(0, c.size, width):
+            line = bytes(c[a:a + width])
+            if junk and rng.random() < junk:
+                q = int(rng.integers(0, len(line) + 1))
+                line = line[:q] + bytes(rng.choice(np.frombuffer(b" \t0123456789*-.;", np.uint8), size=int(rng.integers(1, 5)))) + line[q:]
+            raw += line + eol
+        re_.append(len(raw))
+    return np.frombuffer(bytes(raw), np.uint8), np.array(rb, np.uint64), np.array(re_, np.uint64)
+
+
+def _check_pack_fasta(hip_ctx, oracle, raw, rb, re_, esc_cap=64):
+    import torch
+    d_raw = torch.from_numpy(np.concatenate([raw, np.zeros(64, np.uint8)])).cuda()
+    torch.cuda.synchronize()
+    pk, keep, off = hip_ctx.pack_fasta_dev(d_raw, raw.size, rb, re_, esc_cap=esc_cap)
+    want = [oracle.preprocess(raw[int(b):int(e)]) for b, e in zip(rb, re_)]
+    woff = np.zeros(len(want) + 1, np.uint64)
+    woff[1:] = np.cumsum([w.size for w in want])
+    assert np.array_equal(off, woff), (off[:8], woff[:8])
+    n = int(woff[-1])
+    assert pk.n_symbols == n
+    if n:
+        out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        hip_ctx.expand_dev(pk, out.data_ptr())
+        got = out[:n].cpu().numpy()
+        exp = np.concatenate(want)
+        if not np.array_equal(got, exp):
+            bad = np.nonzero(got != exp)[0]
+            raise AssertionError(f"{bad.size} symbols differ, first at {bad[:5]}: got {got[bad[:5]]} want {exp[bad[:5]]}")
+    return pk, keep, off
+
+
+@pytest.mark.parametrize("width,eol", [(60, b"\n"), (80, b"\r\n"), (17, b"\n"), (1, b"\n"), (100000, b"\n")])
+def test_pack_fasta_matches_oracle_preprocess(hip_ctx, oracle, width, eol):
+    """agc_hip_pack_fasta_dev (raw FASTA bodies -> the 2-bit layout in one pass) against the oracle's preprocess_raw_contig of every
+    contig: symbol offsets and, through agc_hip_expand_dev, every symbol -- header lines between the bodies, several line widths and
+    line ends, lower case, N runs and IUPAC codes (escaped blocks), stray bytes < 64, empty and tiny contigs"""
+    rng = np.random.default_rng(5000 + width)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    sizes = [70_001, 0, 5, 16_384, 1023, 1024, 1025, 200_000 if width > 1 else 20_000, 1, 33_333]
+    contigs = []
+    for i, n in enumerate(sizes):
+        c = rng.choice(letters, size=n)
+        if i in (0, 7) and n > 5000:
+            c[2000:2000 + 1500] = ord("N")                       # an N run: whole escaped blocks
+            c[n // 2] = ord("R")
+            c[n - 3] = ord("y")
+            c[n // 3:n // 3 + 3] = np.frombuffer(b"@`U", np.uint8)  # cnv_num's odd corners
+        contigs.append(c)
+    raw, rb, re_ = _fasta_case(rng, contigs, width, eol, lower=0.3, junk=0.01)
+    _check_pack_fasta(hip_ctx, oracle, raw, rb, re_, esc_cap=2)  # (2: the first attempt overflows, the binding grows the buffer)
+
+
+def test_pack_fasta_edge_cases(hip_ctx, oracle):
+    """no contigs, an empty buffer, ranges that skip most of the buffer, a body that is nearly all line ends (the read-ahead of a
+    tile runs over several rounds), ranges that begin / end on tile and chunk boundaries, a contig of non-ACGT symbols only"""
+    rng = np.random.default_rng(6001)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    z = np.zeros(0, np.uint64)
+    _check_pack_fasta(hip_ctx, oracle, np.zeros(0, np.uint8), z, z)
+    _check_pack_fasta(hip_ctx, oracle, rng.choice(letters, size=5000), z, z)
+    body = rng.choice(letters, size=100_000)
+    _check_pack_fasta(hip_ctx, oracle, body, np.array([0], np.uint64), np.array([body.size], np.uint64))
+    _check_pack_fasta(hip_ctx, oracle, body, np.array([16384, 32768, 49152 + 16, 70_000, 100_000], np.uint64),
+                      np.array([16384 + 16, 49152, 49152 + 32, 70_000, 100_000], np.uint64))
+    sparse = np.full(300_000, 10, np.uint8)
+    sparse[rng.choice(sparse.size, size=4000, replace=False)] = ord("G")
+    sparse[150_000:151_100] = rng.choice(letters, size=1100)
+    _check_pack_fasta(hip_ctx, oracle, sparse, np.array([0, 200_000], np.uint64), np.array([200_000, 300_000], np.uint64))
+    only_n = np.full(50_000, ord("N"), np.uint8)
+    _check_pack_fasta(hip_ctx, oracle, only_n, np.array([3], np.uint64), np.array([49_999], np.uint64))
+
+
+def test_pack_fasta_equals_preprocess_and_pack_on_a_big_sample(hip_ctx, oracle):
+    """size-independent property at a larger size (120 MB of FASTA, 9 contigs): the one-pass kernel gives what the three-pass
+    preprocess + the packing of its codes give, and the packed scan reports the same hits on both"""
+    import torch
+    rng = np.random.default_rng(6100)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    ref = rng.choice(letters, size=2_000_000)
+    contigs = []
+    for i in range(9):
+        c = np.tile(ref, 6)[: 11_000_000 + 77_777 * i].copy()
+        m = rng.random(c.size) < 0.001
+        c[m] = rng.choice(letters, size=int(m.sum()))
+        if i % 3 == 0:
+            c[5_000_000:5_003_000] = ord("N")
+        contigs.append(c)
+    raw, rb, re_ = _fasta_case(rng, contigs, 60)
+    pk, keep, off = _check_pack_fasta(hip_ctx, oracle, raw, rb, re_)
+    codes = np.concatenate([oracle.preprocess(raw[int(b):int(e)]) for b, e in zip(rb, re_)])
+    d = torch.from_numpy(codes).cuda()
+    torch.cuda.synchronize()
+    pk2, keep2 = hip_ctx.pack_dev(d)
+    k = 31
+    spl = oracle.determine_splitters([oracle.preprocess(ref)], k, 20_000)
+    hip_ctx.splitters_set(spl)
+    a = hip_ctx.scan_packed_dev(pk, off, k, cap=1 << 18)
+    b = hip_ctx.scan_packed_dev(pk2, off, k, cap=1 << 18)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[0].size > 1000
+
+
 @pytest.mark.parametrize("k,seg", [(31, 1000), (21, 500), (17, 3000), (32, 700)])
 def test_determine_splitters_matches_oracle(hip_ctx, oracle, k, seg):
     """reference preprocessing on the GPU (agc_hip_determine_splitters_dev) vs the oracle's restatement of
