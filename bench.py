@@ -57,11 +57,14 @@ def parse():
                     help="N > 1: one independent archive shard per rank (no collective) instead of the default: all ranks feed ONE "
                          "archive (ordered commit from broadcast commit records, entropy stage spread over the ranks' GPUs; agc_amd/dist.py)")
     ap.add_argument("--single-archive", action="store_true", help="(the default for N > 1; kept for older command lines)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c1", "c4twin", "c5twin"],
+    ap.add_argument("--c5-samples", type=int, default=256, help="--config c5slice: number of 5 Mbp genomes")
+    ap.add_argument("--config", default="c2", choices=["c2", "c1", "c4twin", "c5twin", "c5slice"],
                     help="c2 (default): BASELINE configs[2], the headline (HBM-resident 3 Gbp samples).  c1: BASELINE configs[1] -- 1000 "
                          "SARS-CoV-2-size genomes (30 kb, 1 %% SNP from one reference), default parameters, from FASTA files through the product "
                          "CLI path; the reference CLI is timed beside it on the same files and the two archives are compared.  c4twin / c5twin: the "
-                         "1/100 twins of configs[3] / configs[4] the parity tests use, the same way; all three with a stage breakdown")
+                         "1/100 twins of configs[3] / configs[4] the parity tests use, the same way; c5slice: a slice of configs[4] at FULL contig size -- "
+                         "--c5-samples (256) bacterial-size genomes of 5 Mbp, 5 %% pairwise divergence, plasmid families without a splitter of the "
+                         "reference, adaptive mode (-a), default parameters.  All with a stage breakdown and per-kernel roofline rows")
     ap.add_argument("--prepacked", action="store_true",
                     help="round-4 input: every sample packed into the 2-bit layout BEFORE the timer starts.  Default since round 5: the "
                          "samples are resident in HBM as the bytes of their FASTA files and the timed step turns them into the 2-bit layout "
@@ -100,16 +103,17 @@ AS_BUILT_BPS = {"scan": 0.25, "encode": 0.25, "estimate": 0.25, "costvec": 0.25,
 PACKED_BPS = AS_BUILT_BPS
 
 
-def pmc_table():
+def pmc_table(path=None):
     """{kernel symbol: {counter: max KB per dispatch}} from the committed rocprofv3 PMC summary of this workload
     (scripts/pmc_summary.py over separate --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1`; max over
     dispatches = the full-size launches).  Empty when the summary is absent."""
     tab = {}
     try:
-        for line in open(os.path.join(ROOT, PMC_SUMMARY)):
+        for line in open(os.path.join(ROOT, path or PMC_SUMMARY)):
             f = line.strip().rsplit(",", 4)  # (a kernel name may hold commas: template arguments)
             if len(f) >= 5 and f[0] != "kernel":
                 tab.setdefault(f[0], {})[f[1]] = float(f[4])
+                tab.setdefault(f[0], {})[f[1] + ":sum"] = float(f[3]) * float(f[2])  # (mean x dispatches)
     except OSError:
         pass
     return tab
@@ -123,7 +127,7 @@ def pmc_table():
 NARROW_LOADS = {"zstd"}
 
 
-def pmc_traffic(tab, name):
+def pmc_traffic(tab, name, per_run=False):
     """HBM bytes per launch: FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies the 128-B requests of wide coalesced
     loads as 64 B) + WRITE_SIZE -- except for the kernels of NARROW_LOADS, whose requests the counter tallies as they are
     (this repo's calibration, see above): FETCH_SIZE + WRITE_SIZE.  pmc_traffic_range() states both sums for every kernel: a
@@ -131,6 +135,8 @@ def pmc_traffic(tab, name):
     c = tab.get(KERNEL_SYMBOL[name])
     if not c or "FETCH_SIZE" not in c:
         return None
+    if per_run:  # (the --config rows: all dispatches of a run together, like their time)
+        return int(((1.0 if name in NARROW_LOADS else 2.0) * c["FETCH_SIZE:sum"] + c.get("WRITE_SIZE:sum", 0.0)) * 1024)
     return int(((1.0 if name in NARROW_LOADS else 2.0) * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
 
 
@@ -246,6 +252,25 @@ def config_cli(args):
                 files.append(fn)
             what = ("BASELINE configs[1]: 1000 synthetic SARS-CoV-2-size genomes (30 kb, 1 % SNP from one reference), k=31 l=20 s=60000 b=50, "
                     "one FASTA file each (tmpfs)")
+        elif args.config == "c5slice":
+            # configs[4] at full contig size, a slice of its 50 k genomes: every genome = the ancestor's 5 Mbp chromosome at 2.5 %
+            # (5 % between two genomes) + 0-2 plasmids of 12 families the reference genome has no splitter for (adaptive mode mines them)
+            n = max(2, args.c5_samples)
+            rng = np.random.default_rng(5)
+            anc = synth.random_seq(rng, 5_000_000)
+            plasmids = [synth.random_seq(rng, int(rng.integers(20_000, 90_000))) for _ in range(12)]
+            files, cli_args = [], ["-a"]
+            for i in range(n):
+                ctg, nm = [synth.mutate(rng, anc, 0.025)], [f"NZ_CP{i:06d}.1 strain {i} chromosome"]
+                if i:
+                    for pi in rng.permutation(12)[: int(rng.integers(0, 3))]:
+                        ctg.append(synth.mutate(rng, plasmids[int(pi)], 0.025))
+                        nm.append(f"NZ_CP{i:06d}p{int(pi)}.1 strain {i} plasmid p{int(pi)}")
+                fn = os.path.join(td, f"GCF_{i:09d}.fa")
+                synth.to_fasta(fn, ctg, nm)
+                files.append(fn)
+            what = (f"slice of BASELINE configs[4] at full contig size: {n} synthetic bacterial genomes (5 Mbp chromosome at 2.5 % from one ancestor = 5 % "
+                    "pairwise, 0-2 plasmids of 12 families), adaptive mode `-a`, k=31 l=20 s=60000 b=50, one FASTA file each (tmpfs)")
         else:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from tests import collections as C
@@ -255,10 +280,11 @@ def config_cli(args):
             what = (f"twin of BASELINE configs[{3 if args.config == 'c4twin' else 4}] at 1/100 size (tests/collections.py: {name}, "
                     f"`{' '.join(cli_args) or 'default parameters'}`), {len(files)} FASTA files (tmpfs)")
         bases = 0
-        for fn in files:
-            for line in open(fn, "rb"):
-                if not line.startswith(b">"):
-                    bases += len(line.strip())
+        for fn in files:  # (letters = bytes - line ends - header lines)
+            raw = np.fromfile(fn, np.uint8)
+            nl = np.flatnonzero(raw == 10)
+            hdr = sum(int(nl[np.searchsorted(nl, st_)]) - int(st_) for st_ in np.flatnonzero(raw == ord(">")))
+            bases += int(raw.size - nl.size - (raw == 13).sum()) - hdr
         tiny = os.path.join(td, "tiny.fa")
         synth.to_fasta(tiny, [synth.random_seq(np.random.default_rng(1), 2000)], ["tiny"])
 
@@ -287,13 +313,40 @@ def config_cli(args):
             stages["entropy_device_s"] = round(sum(float(x[1]) for x in m), 3)
             stages["entropy_host_mb"] = round(sum(float(x[2]) for x in m), 2)
             stages["entropy_host_s"] = round(sum(float(x[3]) for x in m), 3)
+        # per-kernel rows: one more run with HIP events around every kernel (AGC_AMD_KERNEL_TIMES=1: every launch is waited for,
+        # so this run's wall time is not a measurement; the rows' times are the kernels' own)
+        kern, dominant = {}, None
+        _t, kerr = run(amd, os.path.join(td, "k.agc"), files, ("-v", "1"), env=dict(os.environ, AGC_AMD_KERNEL_TIMES="1"))
+        mk = re.search(r"kernel-ms:(.*)", kerr)
+        ms_ = re.search(r"kernel-symbols:(.*)", kerr)
+        if mk and ms_:
+            t_ = mk.group(1).split()
+            kms = {t_[i]: (float(t_[i + 1]), int(t_[i + 2])) for i in range(0, len(t_) - 2, 3)}
+            y_ = ms_.group(1).split()
+            sym = {y_[i]: int(y_[i + 1]) for i in range(0, len(y_) - 1, 2)}
+            tab = pmc_table(os.path.join("profiles", "r5", f"pmc_summary_{args.config}.csv"))
+            for name in ("scan", "encode", "estimate", "costvec", "filter", "zstd"):
+                if name not in kms or not kms[name][0]:
+                    continue
+                ms, n_l = kms[name]
+                alg = (sym["zstd_dev_in"] + sym["zstd_dev_out"]) if name == "zstd" else 0.25 * sym.get(name, 0)
+                ach = alg / (ms * 1e-3) / 1e9
+                tr = pmc_traffic(tab, name, per_run=True)
+                kern[name] = {"ms_per_run": round(ms, 3), "launches": n_l, "kernel": KERNEL_SYMBOL.get(name),
+                              "algorithmic_bytes": int(alg), "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
+                              "traffic": tr, "waste": round(tr / alg, 2) if tr and alg else None}
+            other = {k_: round(v[0], 3) for k_, v in kms.items() if k_ not in kern and v[0]}
+            if kern:
+                dominant = max(kern, key=lambda k_: kern[k_]["ms_per_run"])
+            kern["_other_ms_per_run"] = other  # (index build, segments, reference store, preprocess: latency-bound helpers)
         cpu = None
         if os.path.exists(refbin) and not args.no_cpu_baseline:
-            rt = sorted(run(refbin, os.path.join(td, "r.agc"), files, env=ref_env)[0] for _ in range(3))[1]
+            ref_reps = 1 if args.config == "c5slice" else 3  # (c5slice: minutes of reference-CLI time per run)
+            rt = sorted(run(refbin, os.path.join(td, "r.agc"), files, env=ref_env)[0] for _ in range(ref_reps))[ref_reps // 2]
             rt_fixed = sorted(run(refbin, os.path.join(td, "rt.agc"), [tiny], env=ref_env)[0] for _ in range(3))[1]
             same = hashlib.sha256(open(os.path.join(td, "a.agc"), "rb").read()).digest() == hashlib.sha256(open(os.path.join(td, "r.agc"), "rb").read()).digest()
             cpu = {"value": round(bases / rt / 1e9, 4), "unit": "Gbp/s", "cores": threads, "kind": "reference",
-                   "sample": f"oracle/_ref/agc create -t {threads} on the same {len(files)} files: median of 3 = {rt:.3f} s (a one-contig archive: {rt_fixed:.3f} s)",
+                   "sample": f"oracle/_ref/agc create -t {threads} on the same {len(files)} files: median of {ref_reps} = {rt:.3f} s (a one-contig archive: {rt_fixed:.3f} s)",
                    "value_without_start": round(bases / max(rt - rt_fixed, 1e-9) / 1e9, 4), "archives_identical": same}
         out = {"metric": f"input Gbp/s compressed (create), {args.config}: whole CLI run from FASTA files", "value": round(bases / t_amd / 1e9, 4),
                "unit": "Gbp/s", "n_gpus": 1, "steps": reps, "warmup": 1, "ms_per_step": round(t_amd * 1e3, 1), "higher_is_better": True,
@@ -302,8 +355,13 @@ def config_cli(args):
                           "bases": bases, "host_threads": threads, "fixed_cost_s": round(t_fixed, 3),
                           "fixed_cost_is": "the wall time of `agc_amd create` of one 2 kb contig: process start, HIP context and streams, dlopen of libzstd, archive",
                           "value_without_start": round(bases / max(t_amd - t_fixed, 1e-9) / 1e9, 4),
-                          "stage_seconds": stages},
-               "roofline": None}
+                          "stage_seconds": stages,
+                          "host_entropy_share_of_wall": round(stages.get("entropy_host_s", 0.0) / t_amd, 3) if stages.get("entropy_host_s") is not None else None},
+               "roofline": ({"bound": "hbm", "kernel": kern[dominant]["kernel"], "achieved": kern[dominant]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": kern[dominant]["frac"], "traffic": kern[dominant]["traffic"],
+                             "dominant_by": "largest kernel time per run (HIP events around every launch, a separate run with AGC_AMD_KERNEL_TIMES=1)",
+                             "algorithmic_bytes": "0.25 B per symbol a kernel was asked to look at (text once + reference once for the parses); zstd: packs in + frames out",
+                             "kernels": kern} if dominant else None)}
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

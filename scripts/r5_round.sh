@@ -1,0 +1,34 @@
+#!/bin/bash
+# scripts/r5_round.sh PART -- the GPU runs of round 5, written under gpurun_out/r5/ on the GPU box
+#   PART=a: the new one-pass pack kernel's tests first (under a short timeout: a look-back that never ends must not hold the box),
+#           then the GPU test suite, the driver's bench command (FASTA bytes in HBM) and its --prepacked control, configs c1 / c5twin / c5slice
+#   PART=b: rocprofv3 passes (kernel trace + stats, FETCH_SIZE, WRITE_SIZE) of the bench and of the divergent configs, laps, --verify-entropy
+#   PART=c: end of round: tests, smoke, bench lines, two ranks on one GPU, fuzz through the real kernels
+PART=${1:-a}
+OUT=gpurun_out/r5
+mkdir -p $OUT
+export TMPDIR=/tmp
+show() { python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+    print(sys.argv[1], "no line:", e); sys.exit(0)
+c = d.get("config", {})
+k = (d.get("roofline") or {}).get("kernels") or {}
+print(sys.argv[1].split("/")[-1], "value", d.get("value"), "ms_per_step", d.get("ms_per_step"), "steps_only", c.get("steps_only_ms"), "close", c.get("close_ms"),
+      "| kernels ms:", {n: (v.get("ms_per_step") or v.get("ms_per_run")) for n, v in k.items() if isinstance(v, dict) and ("ms_per_step" in v or "ms_per_run" in v)},
+      "| cpu", (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline") or {}).get("archives_identical"), "fixed", c.get("fixed_cost_s"))
+PY
+}
+if [ "$PART" = a ]; then
+  timeout 300 python -m pytest tests/test_gpu_scan.py -m gpu -x -q -k "pack_fasta" > $OUT/pack_fasta_tests.log 2>&1; PF=$?; tail -15 $OUT/pack_fasta_tests.log
+  timeout 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_scan.py::test_pack_fasta_matches_oracle_preprocess > $OUT/gpu_tests.log 2>&1; tail -12 $OUT/gpu_tests.log
+  if [ $PF = 0 ]; then
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd_steps20_warmup5_no_cpu_baseline.json 2> $OUT/bench_driver_cmd.err; show $OUT/bench_driver_cmd_steps20_warmup5_no_cpu_baseline.json; tail -3 $OUT/bench_driver_cmd.err
+  fi
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --prepacked > $OUT/bench_prepacked_steps20_warmup5.json 2> $OUT/bench_prepacked.err; show $OUT/bench_prepacked_steps20_warmup5.json
+  for cfg in c1 c5twin; do timeout 600 python bench.py --config $cfg > $OUT/bench_config_$cfg.json 2> $OUT/bench_config_$cfg.err; show $OUT/bench_config_$cfg.json; done
+  timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/bench_config_c5slice.json 2> $OUT/bench_config_c5slice.err; show $OUT/bench_config_c5slice.json; tail -3 $OUT/bench_config_c5slice.err
+fi
+ls $OUT | head -60
