@@ -56,9 +56,16 @@ int agc_cmp_set_distributed(void *h, uint32_t rank, uint32_t world_size, uint32_
 }
 int agc_cmp_last_record(void *h, const uint8_t **ptr, uint64_t *n)
 {
-    const std::vector<uint8_t> &r = ((CAGCCompressor *)h)->LastRecord();
-    *ptr = r.data();
-    *n = r.size();
+    size_t m = 0;
+    *ptr = ((CAGCCompressor *)h)->LastRecord(&m);
+    *n = m;
+    return 1;
+}
+int agc_cmp_last_record_framed(void *h, uint8_t **ptr, uint64_t *n)
+{
+    size_t m = 0;
+    *ptr = ((CAGCCompressor *)h)->LastRecordFramed(&m);
+    *n = m;
     return 1;
 }
 int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record, const uint8_t *body, uint64_t body_n)

@@ -42,7 +42,16 @@ bool CAGCCompressor::SetDistributed(uint32_t rank, uint32_t world_size, uint32_t
     p->dist_writer = writer_rank;
     return true;
 }
-const std::vector<uint8_t> &CAGCCompressor::LastRecord() const { return p->dist_record; }
+const uint8_t *CAGCCompressor::LastRecord(size_t *n) const
+{
+    *n = p->dist_record_n;
+    return p->dist_record_n ? p->dist_record_ptr() : nullptr;
+}
+uint8_t *CAGCCompressor::LastRecordFramed(size_t *n)
+{
+    *n = p->dist_record_n ? p->dist_record_n + Impl::DIST_FRAME : 0;
+    return p->dist_record_n ? p->dist_record_buf.data() : nullptr;
+}
 const uint8_t *CAGCCompressor::LastRecordBody(size_t *n) const
 {
     *n = p->dist_body_n;
@@ -154,7 +163,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
-    I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.hip;
+    I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.dist_record_buf.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_PAR_MIN"))
         I.par_min = (size_t)std::max(1LL, atoll(e));
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
@@ -341,7 +350,7 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
-    I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.hip;
+    I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.dist_record_buf.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_PAR_MIN"))
         I.par_min = (size_t)std::max(1LL, atoll(e));
     if (const char *e = getenv("AGC_AMD_ENCODE_OVERLAP"))
@@ -772,7 +781,7 @@ bool CAGCCompressor::CommitPreparedHead()
     if (!I.prepared)
         return false;
     std::unique_ptr<Impl::BatchState> b = std::move(I.prepared); // (note_new_group stops logging)
-    I.dist_record.clear();
+    I.dist_record_n = 0;
     I.dist_body_n = 0;
     {
         std::lock_guard<std::mutex> coll_lk(I.coll_mtx); // (the bookkeeping of the previous sample may be looking its contigs up)

@@ -86,7 +86,10 @@ public:
     // need), ApplyRecord everywhere else.  d_record = optional copy of the record in this rank's HBM (e.g. the buffer an
     // RCCL broadcast delivered): the newly minted references are then registered from there without a host round trip.
     bool SetDistributed(uint32_t rank, uint32_t world_size, uint32_t writer_rank);
-    const std::vector<uint8_t> &LastRecord() const;     // the head: every rank
+    const uint8_t *LastRecord(size_t *n) const;         // the head: every rank (pinned host memory, valid until this rank's next commit)
+    // the same with 64 bytes in front of it that belong to the caller's transport (a fixed-size message header: head and header
+    // then travel as one message); *n counts them
+    uint8_t *LastRecordFramed(size_t *n);
     const uint8_t *LastRecordBody(size_t *n) const;     // the LZ deltas: the writer rank only (pinned host memory)
     // writer rank: where the next record's body should be received (pinned host memory, n bytes); an ApplyRecord whose `body` is
     // this pointer takes the buffer over instead of copying it (any other pointer is copied)

@@ -72,8 +72,8 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
     const std::vector<Contig> &ctgs = *b.ctgs;
     const std::vector<Placed> &placed = placed_buf;
     const BatchState::Store &sto = b.sto;
-    bytes_t &r = dist_record;
     dist_body_n = 0;
+    dist_record_n = 0;
     dist_body_items.clear();
     const SampleLists &sl = b.per_sample.at(0); // one registration per record
     std::vector<uint32_t> pos_newref(placed.size()), pos_raw(placed.size());
@@ -91,8 +91,11 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
     for (auto &c : ctgs)
         need += c.sample.size() + c.name.size() + 2;
     need += 21 * sto.new_ref_items.size() + 4 * sto.raw_items.size() + (sto.fetched_off.empty() ? 0 : sto.fetched_off.back());
-    r.resize(need);
-    uint8_t *w = r.data();
+    if (!dist_record_buf.resize(DIST_FRAME + need + need / 8 + 64, false)) {
+        err("out of memory (commit record)");
+        return;
+    }
+    uint8_t *w = dist_record_ptr();
     auto w32 = [&](uint32_t x) {
         w[0] = (uint8_t)x, w[1] = (uint8_t)(x >> 8), w[2] = (uint8_t)(x >> 16), w[3] = (uint8_t)(x >> 24);
         w += 4;
@@ -153,7 +156,7 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
             w += n;
         }
     }
-    r.resize((size_t)(w - r.data()));
+    dist_record_n = (size_t)(w - dist_record_ptr());
 }
 
 // The body: every delta item of the head, in the same order: u32 length + bytes.  ~22 MB per human-size sample, gathered by the
@@ -195,15 +198,17 @@ bool CAGCCompressor::Impl::make_record_body(const CommitData &cd)
 // the record of a sample without contigs: nothing to register anywhere
 void CAGCCompressor::Impl::make_empty_record()
 {
-    bytes_t &r = dist_record;
-    r.clear();
     dist_body_n = 0;
-    r.insert(r.end(), {'A', 'G', 'C', 'R'});
-    put32(r, 0);
-    put32(r, 0);
-    put32(r, 0);
-    put32(r, ~0u);
-    put32(r, 0);
+    dist_record_n = 0;
+    if (!dist_record_buf.resize(DIST_FRAME + 64, false))
+        return;
+    uint8_t *w = dist_record_ptr();
+    memcpy(w, "AGCR", 4);
+    const uint32_t f[5] = {0, 0, 0, ~0u, 0};
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 4; ++j)
+            w[4 + 4 * i + j] = (uint8_t)(f[i] >> (8 * j));
+    dist_record_n = 24;
 }
 
 bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n)

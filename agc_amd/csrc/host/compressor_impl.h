@@ -1014,7 +1014,13 @@ struct CAGCCompressor::Impl {
     }
     // multi-GPU single-archive mode: one registration at a time, committed on every rank from the owner's record
     uint32_t dist_rank = 0, dist_world = 1, dist_writer = 0;
-    bytes_t dist_record;        // head of the commit record (every rank): compressor_dist.cpp
+    // head of the commit record (every rank; compressor_dist.cpp), in pinned host memory: its next stop is a collective, i.e. a copy
+    // engine.  DIST_FRAME bytes in front of it belong to the transport (agc_amd/dist.py writes its fixed-size message header there,
+    // so that header and head travel as ONE message)
+    static constexpr size_t DIST_FRAME = 64;
+    PinnedBytes dist_record_buf;
+    size_t dist_record_n = 0;
+    uint8_t *dist_record_ptr() { return dist_record_buf.data() ? dist_record_buf.data() + DIST_FRAME : nullptr; }
     PinnedBytes dist_body_buf;  // its delta body (the writer only), dist_body_n bytes
     size_t dist_body_n = 0;
     // writer rank: receive buffers for the bodies of the other ranks' records (pinned; a queued bookkeeping task keeps its

@@ -8,7 +8,9 @@ first-come in sample order, agc_compressor.cpp:954-1050): samples are therefore 
 
     owner:   prepare + commit (head)     scan + classification + speculative LZ-encode on its GPU ahead of its turn; at its turn
                                          the order-dependent registration and the HEAD of the commit record
-    all:     broadcast(record head)      one collective per sample: length, then the bytes (uint8 tensor on the backend's device)
+    all:     broadcast(record head)      ONE collective per sample: a 64-byte message header (sizes) + the head, in a buffer of a
+                                         capacity every rank derives from the sizes seen so far (a head that does not fit announces
+                                         its size in the header and its rest follows in a second broadcast: the reference sample)
     owner:   commit (finish)             new references indexed on its GPU, leftover deltas, the record's BODY -- after the head is out
     owner -> writer: send(record body)   the LZ deltas, point to point: only the writer needs them
     others:  apply_record(head)          same group ids / map / terminator updates; the newly minted reference segments inside the
@@ -69,8 +71,49 @@ class DistCompressor:
         # order-dependent half up to the record's head), head (head size + head broadcast), finish (the owner's rest: new references
         # indexed, leftover deltas, the body), body (finish + delta body to the writer), apply (the other ranks' records applied here)
         self.seconds = {"prepare": 0.0, "commit": 0.0, "head": 0.0, "finish": 0.0, "body": 0.0, "apply": 0.0}
+        self.n_records = 0          # samples published (sample 0, the reference, included)
+        self.bytes_head_last = 0    # head size of the last record (a typical sample's: the reference sample's is the collection)
+        self.n_collectives = 0      # broadcasts spent on record heads
+        # transport buffers of the record heads, reused for every sample: the message = 64-byte header + head.  Under nccl the
+        # broadcast runs HBM -> HBM (`_dmsg`), the owner fills it from the compressor's pinned record with one async copy and the other
+        # ranks read header + head back into a pinned host buffer (`_hmsg`) -- no pageable staging, no allocation per sample; under gloo
+        # the broadcast runs on `_hmsg` itself
+        import os
+        # (AGC_AMD_DIST_MSG_CAP0 / _MAX: the tests shrink the message so that the second broadcast of a long head and the capacity's
+        # adaptation are walked through by small collections)
+        self.MSG_CAP0 = max(self.MSG_HDR + 8, int(os.environ.get("AGC_AMD_DIST_MSG_CAP0", self.MSG_CAP0)))
+        self.MSG_CAP_MAX = max(self.MSG_CAP0, int(os.environ.get("AGC_AMD_DIST_MSG_CAP_MAX", self.MSG_CAP_MAX)))
+        self._cap = self.MSG_CAP0
+        self._hmsg = self._host_buffer(self._cap)
+        self._dmsg = torch.empty(self._cap, dtype=torch.uint8, device=self.comm) if self.comm.type == "cuda" else None
+        self._dapply = None         # (gloo with a GPU: the head's copy in this rank's HBM the new references are registered from)
         self._check_placement()
         self.warm_up()
+
+    MSG_CAP0 = 4 << 20      # capacity of the head message before any head has been seen
+    MSG_CAP_MAX = 64 << 20  # ... and the most a typical head may claim (a larger one takes the second broadcast)
+    MSG_HDR = 64            # bytes of the message header in front of the head (Impl::DIST_FRAME)
+
+    def _host_buffer(self, n):
+        torch = self.torch
+        try:
+            return torch.empty(n, dtype=torch.uint8, pin_memory=self.hbm is not None)
+        except RuntimeError:
+            return torch.empty(n, dtype=torch.uint8)
+
+    def _next_cap(self, msg_bytes):
+        """capacity of the NEXT head message, from the size of this one: every rank sees every size, so every rank derives the same"""
+        want = (msg_bytes * 3 // 2 + (1 << 20) - 1) >> 20 << 20
+        return min(self.MSG_CAP_MAX, max(self.MSG_CAP0, want))
+
+    def _set_cap(self, cap):
+        if cap == self._cap:
+            return
+        self._cap = cap
+        if self._hmsg.numel() < cap:
+            self._hmsg = self._host_buffer(cap)
+        if self._dmsg is not None and self._dmsg.numel() < cap:
+            self._dmsg = self.torch.empty(cap, dtype=self.torch.uint8, device=self.comm)
 
     def _check_placement(self):
         """one process per GPU: a world larger than the visible devices (or two ranks on one device) is a launch mistake that RCCL
@@ -91,7 +134,7 @@ class DistCompressor:
     def warm_up(self):
         """every communication pattern of the run once, with a few bytes: a broadcast from every rank (the record heads), a
         point-to-point message from every rank to the writer (the record bodies; RCCL sets a pair's channel up on its first use --
-        seconds, which would otherwise land in the first timed sample of that pair), an all_gather and a gather (Close)"""
+        seconds, which would otherwise land in the first timed sample of that pair) and one back (Close: the packs)"""
         torch, dist = self.torch, self.dist
         t = torch.zeros(8, dtype=torch.uint8, device=self.comm)
         for src in range(self.world):
@@ -103,9 +146,13 @@ class DistCompressor:
                 dist.send(t, dst=self.writer)
             elif self.rank == self.writer:
                 dist.recv(t, src=r)
-        dist.all_gather([torch.zeros(8, dtype=torch.uint8, device=self.comm) for _ in range(self.world)], t)
-        dist.gather(t, [torch.zeros(8, dtype=torch.uint8, device=self.comm) for _ in range(self.world)] if self.rank == self.writer else None,
-                    dst=self.writer)
+        for r in range(self.world):  # ... and back: Close hands every rank its share of the packs point to point
+            if r == self.writer:
+                continue
+            if self.rank == self.writer:
+                dist.send(t, dst=r)
+            elif self.rank == r:
+                dist.recv(t, src=self.writer)
         if self.comm.type == "cuda":
             torch.cuda.synchronize(self.comm)
 
@@ -123,7 +170,7 @@ class DistCompressor:
             t0 = time.perf_counter()
             self.cmp.add_sample_dev(sample_name, contig_names, d_codes, ctg_off)
             self.seconds["commit"] += time.perf_counter() - t0
-            rec, body = self.cmp.last_record(copy=False), self.cmp.last_record_body(copy=False)
+            rec, body = self.cmp.last_record_framed(), self.cmp.last_record_body(copy=False)
         self._publish(owner, rec, body)
         return owner
 
@@ -166,9 +213,9 @@ class DistCompressor:
         self.seconds["prepare"] += time.perf_counter() - t0
 
     def close(self, zstd_raw=None, n_threads=8):
-        """Close() with the entropy stage of the delta packs spread over all ranks: the writer hands the pending packs out
-        (one broadcast), rank r compresses a contiguous run of them -- the runs hold about the same number of bytes -- on its own
-        GPU (agc_hip_zstd17_batch), the frames go back to the writer (gather), which finishes the archive.  No per-pack Python
+        """Close() with the entropy stage of the delta packs spread over all ranks: the writer hands every rank ITS run of the pending
+        packs (point to point; the runs hold about the same number of bytes), rank r compresses it on its own GPU
+        (agc_hip_zstd17_batch_dev), the frames go back to the writer as long as they are, which finishes the archive.  No per-pack Python
         work anywhere (a human collection closes 50 k packs).
         zstd_raw(src uint8 array, off uint64[n + 1]) -> (frames uint8 array, foff uint64[n + 1]); default: this rank's GPU.
         Every rank must call this instead of Compressor.close()."""
@@ -180,81 +227,145 @@ class DistCompressor:
             ctx = capi.Context.from_handle(self.cmp.hip_ctx())
             zstd_raw = ctx.zstd17_batch_raw
         writer = self.rank == self.writer
+        W = self.world
+        src = off = None
         if writer:
             src, off = self.cmp.close_collect_packs()
-            meta = torch.tensor([off.size - 1, int(off[-1])], dtype=torch.int64, device=self.comm)
+            n, total = off.size - 1, int(off[-1])
+            # rank r takes packs [cut[r], cut[r + 1]): equal shares of the bytes
+            cut = np.searchsorted(off, (np.arange(W + 1, dtype=np.float64) * total / W).astype(np.uint64), side="left")
+            cut[0], cut[-1] = 0, n
+            cut = np.maximum.accumulate(np.minimum(cut, n)).astype(np.int64)
+            plan = np.zeros((W, 2), np.int64)  # per rank: packs, bytes
+            for r in range(W):
+                plan[r] = (cut[r + 1] - cut[r], int(off[cut[r + 1]]) - int(off[cut[r]]))
+            d_plan = torch.from_numpy(plan.reshape(-1)).to(self.comm)
         else:
-            meta = torch.zeros(2, dtype=torch.int64, device=self.comm)
-        dist.broadcast(meta, src=self.writer)
-        n, total = int(meta[0]), int(meta[1])
-        if n == 0:
+            d_plan = torch.zeros(2 * W, dtype=torch.int64, device=self.comm)
+        dist.broadcast(d_plan, src=self.writer)  # (one small collective: who gets how much)
+        plan = d_plan.cpu().numpy().reshape(W, 2)
+        if int(plan[:, 0].sum()) == 0:
             if writer:
                 self.cmp.close_provide_frames(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
             self.cmp.close(n_threads)
             return
-        d_off = torch.from_numpy(off.astype(np.int64)).to(self.comm) if writer else torch.zeros(n + 1, dtype=torch.int64, device=self.comm)
-        d_src = torch.from_numpy(src).to(self.comm) if writer else torch.empty(total, dtype=torch.uint8, device=self.comm)
-        dist.broadcast(d_off, src=self.writer)
-        dist.broadcast(d_src, src=self.writer)   # (nccl: HBM -> HBM over xGMI)
-        h_off = d_off.cpu().numpy().astype(np.uint64)
-        # the packs stay where the broadcast put them: with a GPU the kernel reads them from HBM (RCCL delivered them there; under
-        # gloo they are uploaded once) -- no HBM -> host -> HBM round trip of the inputs
+        my_n, my_bytes = int(plan[self.rank, 0]), int(plan[self.rank, 1])
+        # ---- the packs: every rank receives ITS OWN byte range only, point to point (round 4 broadcast all of them to all ranks:
+        # 4.4 GB at N = 8 where a rank needs an eighth); the writer's share stays where it is
         dev_path = self.hbm is not None and default_raw
-        if dev_path:
-            d_hbm = d_src if d_src.is_cuda else d_src.to(self.hbm)
-            torch.cuda.synchronize(self.hbm)
-        else:
-            h_src = d_src.cpu().numpy()
-        # rank r takes packs [cut[r], cut[r + 1]): equal shares of the bytes
-        cut = np.searchsorted(h_off, (np.arange(self.world + 1, dtype=np.float64) * total / self.world).astype(np.uint64), side="left")
-        cut[0], cut[-1] = 0, n
-        cut = np.maximum.accumulate(np.minimum(cut, n))
-        a, b = int(cut[self.rank]), int(cut[self.rank + 1])
-        if b > a:
+        if writer:
+            sends = []
+            for r in range(W):
+                if r == self.writer or plan[r, 0] == 0:
+                    continue
+                a_, b_ = int(cut[r]), int(cut[r + 1])
+                o_ = torch.from_numpy((off[a_:b_ + 1] - off[a_]).astype(np.int64)).to(self.comm)
+                x_ = torch.from_numpy(src[int(off[a_]):int(off[b_])]).to(self.comm)
+                sends.append(dist.isend(o_, dst=r))
+                sends.append(dist.isend(x_, dst=r))
+            a_, b_ = int(cut[self.rank]), int(cut[self.rank + 1])
+            my_off = (off[a_:b_ + 1] - off[a_]).astype(np.uint64)
+            my_src = src[int(off[a_]):int(off[b_])]
+            d_mine = torch.from_numpy(my_src).to(self.hbm) if (dev_path and my_n) else None
+            for w_ in sends:
+                w_.wait()
+        elif my_n:
+            d_o = torch.empty(my_n + 1, dtype=torch.int64, device=self.comm)
+            d_x = torch.empty(my_bytes, dtype=torch.uint8, device=self.comm)
+            dist.recv(d_o, src=self.writer)
+            dist.recv(d_x, src=self.writer)   # (nccl: HBM -> HBM over xGMI, and the kernel reads the packs where they landed)
+            my_off = d_o.cpu().numpy().astype(np.uint64)
             if dev_path:
-                frames, foff = ctx.zstd17_batch_raw_dev(d_hbm.data_ptr(), h_off[a:b + 1])
+                d_mine = d_x if d_x.is_cuda else d_x.to(self.hbm)
             else:
-                frames, foff = zstd_raw(h_src[int(h_off[a]):int(h_off[b])], h_off[a:b + 1] - h_off[a])
+                my_src = d_x.cpu().numpy()
+        if my_n:
+            if dev_path:
+                torch.cuda.synchronize(self.hbm)
+                frames, foff = ctx.zstd17_batch_raw_dev(d_mine.data_ptr(), my_off)
+            else:
+                frames, foff = zstd_raw(my_src, my_off)
             frames = np.ascontiguousarray(frames, dtype=np.uint8)
             sizes = np.diff(foff.astype(np.int64))
         else:
             frames, sizes = np.zeros(0, np.uint8), np.zeros(0, np.int64)
-        # every rank's frame sizes (padded to the longest run), then the bytes (padded to the largest total)
-        per = int(np.max(np.diff(cut))) if n else 0
-        sz = torch.zeros(max(per, 1), dtype=torch.int64, device=self.comm)
-        if sizes.size:
-            sz[:sizes.size] = torch.from_numpy(sizes).to(self.comm)
-        all_sz = [torch.zeros(max(per, 1), dtype=torch.int64, device=self.comm) for _ in range(self.world)]
-        dist.all_gather(all_sz, sz)
-        tot = [int(x.sum()) for x in all_sz]
-        cap = max(max(tot), 1)
-        buf = torch.zeros(cap, dtype=torch.uint8, device=self.comm)
-        if frames.size:
-            buf[:frames.size] = torch.from_numpy(frames).to(self.comm)
-        gathered = [torch.zeros(cap, dtype=torch.uint8, device=self.comm) for _ in range(self.world)] if writer else None
-        dist.gather(buf, gathered, dst=self.writer)
+        # ---- the frames back to the writer, as long as they are (sizes first: the writer knows every rank's pack count)
         if writer:
-            sizes_all = np.concatenate([all_sz[r].cpu().numpy()[:int(cut[r + 1] - cut[r])] for r in range(self.world)]).astype(np.uint64)
-            foff_all = np.zeros(n + 1, np.uint64)
+            all_sizes, all_frames = [None] * W, [None] * W
+            all_sizes[self.rank], all_frames[self.rank] = sizes, frames
+            for r in range(W):
+                if r == self.writer or plan[r, 0] == 0:
+                    continue
+                d_s = torch.empty(int(plan[r, 0]), dtype=torch.int64, device=self.comm)
+                dist.recv(d_s, src=r)
+                s_ = d_s.cpu().numpy()
+                d_f = torch.empty(int(s_.sum()), dtype=torch.uint8, device=self.comm)
+                if d_f.numel():
+                    dist.recv(d_f, src=r)
+                all_sizes[r], all_frames[r] = s_, d_f.cpu().numpy()
+            order = [r for r in range(W) if plan[r, 0]]
+            sizes_all = np.concatenate([all_sizes[r] for r in order]).astype(np.uint64)
+            foff_all = np.zeros(sizes_all.size + 1, np.uint64)
             foff_all[1:] = np.cumsum(sizes_all)
-            out = np.concatenate([gathered[r].cpu().numpy()[:tot[r]] for r in range(self.world)]) if n else np.zeros(0, np.uint8)
+            out = np.concatenate([all_frames[r] for r in order])
             self.cmp.close_provide_frames(out, foff_all)
+        elif my_n:
+            dist.send(torch.from_numpy(sizes).to(self.comm), dst=self.writer)
+            if frames.size:
+                dist.send(torch.from_numpy(frames).to(self.comm), dst=self.writer)
         self.cmp.close(n_threads)
 
     def _publish(self, owner, rec, body):
-        """one sample's commit record: the head to every rank (broadcast), the delta body to the writer only (point to point);
-        ranks other than the owner apply it.  rec: the owner's head (numpy uint8 view into its compressor), None elsewhere.
+        """one sample's commit record: the head to every rank (one broadcast), the delta body to the writer only (point to point);
+        ranks other than the owner apply it.  rec: the owner's head as the compressor frames it (numpy uint8 view of its pinned
+        buffer: 64 bytes for the message header + the head), None elsewhere.
         body: the owner's body, or a function that finishes the commit and returns it -- called AFTER the head is out, so the
         other ranks go on while the owner indexes its new references, encodes what is left and builds the body."""
         torch, dist = self.torch, self.dist
         t0 = time.perf_counter()
-        n = torch.zeros(1, dtype=torch.int64, device=self.comm)
+        H, cap = self.MSG_HDR, self._cap
+        on_dev = self._dmsg is not None
+        msg = self._dmsg if on_dev else self._hmsg
         if rec is not None:
-            n[0] = rec.size
-        dist.broadcast(n, src=owner)
-        size = int(n[0])
-        buf = torch.from_numpy(rec).to(self.comm) if rec is not None else torch.empty(size, dtype=torch.uint8, device=self.comm)
-        dist.broadcast(buf, src=owner)
+            if rec.size < H:
+                raise RuntimeError("the compressor has no commit record for this sample")
+            hdr = rec[:H].view(np.uint64)
+            hdr[:] = 0
+            hdr[0], hdr[1] = 0x4D434741, rec.size - H  # "AGCM", bytes of the head
+            first = min(rec.size, cap)
+            msg[:first].copy_(torch.from_numpy(rec[:first]), non_blocking=True)  # (pinned -> HBM: one async copy; gloo: a memcpy)
+        dist.broadcast(msg[:cap], src=owner)
+        self.n_collectives += 1
+        hm = self._hmsg
+        if rec is None:
+            if on_dev:
+                # header + what a head of the usual size needs, in one copy and one wait; the rest only if this head is longer
+                guess = min(cap, max(H, ((self.bytes_head_last + H) * 9 // 8 + 4095) & ~4095))
+                hm[:guess].copy_(msg[:guess], non_blocking=True)
+                torch.cuda.current_stream(self.comm).synchronize()
+            h = hm[:H].numpy().view(np.uint64)
+            if int(h[0]) != 0x4D434741:
+                raise RuntimeError(f"rank {self.rank}: bad record message from rank {owner}")
+            size = int(h[1])
+            if on_dev and min(size + H, cap) > guess:
+                hm[guess:min(size + H, cap)].copy_(msg[guess:min(size + H, cap)], non_blocking=True)
+                torch.cuda.current_stream(self.comm).synchronize()
+        else:
+            size = rec.size - H
+        rest = size + H - cap
+        big = None
+        if rest > 0:
+            # a head beyond the message's capacity (the reference sample: every reference segment of the collection): the rest in a
+            # second broadcast, sized by the header everybody has by now
+            if rec is not None:
+                big = torch.from_numpy(rec[cap:]).to(self.comm)
+            else:
+                big = torch.empty(rest, dtype=torch.uint8, device=self.comm)
+            dist.broadcast(big, src=owner)
+            self.n_collectives += 1
+        self._set_cap(self._next_cap(min(size + H, self.MSG_CAP_MAX)))
+        self.n_records += 1
+        self.bytes_head_last = size
         self.bytes_broadcast += size
         t1 = time.perf_counter()
         b_view, bsize = None, 0
@@ -292,13 +403,30 @@ class DistCompressor:
         self.bytes_p2p += bsize
         t2 = time.perf_counter()
         if self.rank != owner:
-            # the head is parsed on the host; the new references are registered from the copy in this rank's HBM when there is one
-            host = np.ascontiguousarray(buf.cpu().numpy())
-            d_buf = buf if buf.is_cuda else (buf.to(self.hbm) if self.hbm is not None else None)
-            if d_buf is not None:
-                torch.cuda.synchronize(self.hbm)
-            self.cmp.apply_record(host.ctypes.data, size, d_buf.data_ptr() if d_buf is not None else None,
-                                  b_view.ctypes.data if b_view is not None else None, bsize if b_view is not None else 0)
+            # the head is parsed where it lies in pinned host memory; the new references are registered from its copy in this rank's
+            # HBM (the broadcast buffer under nccl; uploaded once under gloo with a GPU)
+            if big is None:
+                host = hm[H:H + size].numpy()
+                d_ptr = None
+                if on_dev:
+                    d_ptr = msg.data_ptr() + H
+                elif self.hbm is not None:
+                    if self._dapply is None or self._dapply.numel() < size:
+                        self._dapply = torch.empty(max(size * 5 // 4, 1 << 20), dtype=torch.uint8, device=self.hbm)
+                    self._dapply[:size].copy_(hm[H:H + size], non_blocking=True)
+                    torch.cuda.synchronize(self.hbm)
+                    d_ptr = self._dapply.data_ptr()
+            else:
+                # (the two pieces side by side, once per archive)
+                whole = torch.empty(size, dtype=torch.uint8, device=self.comm)
+                whole[:cap - H].copy_(msg[H:cap])
+                whole[cap - H:].copy_(big)
+                host = np.ascontiguousarray(whole.cpu().numpy())
+                d_whole = whole if whole.is_cuda else (whole.to(self.hbm) if self.hbm is not None else None)
+                if d_whole is not None:
+                    torch.cuda.synchronize(self.hbm)
+                d_ptr = d_whole.data_ptr() if d_whole is not None else None
+            self.cmp.apply_record(host.ctypes.data, size, d_ptr, b_view.ctypes.data if b_view is not None else None, bsize if b_view is not None else 0)
         t3 = time.perf_counter()
         self.seconds["head"] += t1 - t0
         self.seconds["body"] += t2 - t1
@@ -308,7 +436,7 @@ class DistCompressor:
         t0 = time.perf_counter()
         self.cmp.commit_prepared_head()
         self.seconds["commit"] += time.perf_counter() - t0
-        self._publish(self.rank, self.cmp.last_record(copy=False), self._finish_commit)
+        self._publish(self.rank, self.cmp.last_record_framed(), self._finish_commit)
         self.next_sample = i + 1
 
     def _finish_commit(self):

@@ -43,6 +43,7 @@ def bind(L):
     L.agc_cmp_stats.argtypes = [vp, C.POINTER(C.c_double), C.c_uint32]
     L.agc_cmp_set_distributed.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.agc_cmp_last_record.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+    L.agc_cmp_last_record_framed.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
     L.agc_cmp_apply_record.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64]
     L.agc_cmp_last_record_body.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
     L.agc_cmp_record_body_buffer.argtypes = [vp, C.c_uint64, C.POINTER(C.POINTER(C.c_uint8))]
@@ -175,6 +176,16 @@ class Compressor:
             return np.zeros(0, np.uint8)
         a = np.ctypeslib.as_array(p, shape=(n.value,))
         return a.copy() if copy else a
+
+    def last_record_framed(self):
+        """the same record as a view into the compressor's pinned buffer WITH the 64 bytes in front of it that belong to the transport
+        (agc_amd.dist writes its message header there); empty when there is no record"""
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        self.L.agc_cmp_last_record_framed(self.h, C.byref(p), C.byref(n))
+        if not n.value:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
 
     def last_record_body(self, copy=True):
         """the LZ deltas of the sample just added (the part of its commit record only the writer rank needs; pinned host memory)"""

@@ -583,11 +583,15 @@ def main():
     cmp_.hip_timing(True)  # HIP events on the library's stream around every kernel of the timed region
     barrier()
     sec0 = dict(dc.seconds) if dc is not None else None
+    bytes0 = (dc.bytes_broadcast, dc.bytes_p2p, dc.n_records) if dc is not None else None
     t0 = time.perf_counter()
     for s in range(args.warmup, n_steps):
         add_step(s, "s")
     t_steps = time.perf_counter() - t0
     sec1 = dict(dc.seconds) if dc is not None else None
+    # (per TIMED sample: the reference sample's record -- the whole collection's references -- is setup and not averaged in)
+    head_timed_mb = (dc.bytes_broadcast - bytes0[0]) / max(dc.n_records - bytes0[2], 1) / 1e6 if dc is not None else 0.0
+    body_timed_mb = (dc.bytes_p2p - bytes0[1]) / max((dc.n_records - bytes0[2]) * (world - 1) // world, 1) / 1e6 if dc is not None else 0.0
     # Close(): zstd of every pending delta pack + metadata + footer -- the deferred part of the steps' work
     if single:
         dc.close(n_threads=threads)  # packs handed out to every rank's GPU, frames gathered by the writer
@@ -703,10 +707,12 @@ def main():
                        # own samples (prepare runs beside the other ranks'), head / body / apply of every sample's record (serial)
                        "single_archive_ms_per_sample_rank0": ({k_: round((sec1[k_] - sec0[k_]) * 1e3 / max(args.steps * (1 if k_ in ("prepare", "commit", "finish") else world), 1), 3)
                                                                for k_ in sec1} if sec1 is not None else None),
-                       "parallelism": (f"samples round-robin over {world} GPUs into ONE archive: ordered commit, one RCCL broadcast of the commit "
-                                       f"record's head (ids, keys, new reference segments) per sample, {dc.bytes_broadcast / max(dc.next_sample, 1) / 1e6:.1f} MB each, "
-                                       f"its delta body point to point to the writer ({dc.bytes_p2p / max(dc.next_sample, 1) / 1e6:.1f} MB per sample on average); "
-                                       "at Close the pending packs are broadcast, every rank's GPU compresses its share, rank 0 gathers and writes") if single else
+                       "parallelism": (f"samples round-robin over {world} GPUs into ONE archive: ordered commit, one {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} "
+                                       f"broadcast per sample (64-byte message header + the commit record's head: ids, keys, new reference segments; "
+                                       f"{dc.n_collectives} broadcasts for {dc.n_records} records), {head_timed_mb:.2f} MB per timed sample, "
+                                       f"its delta body point to point to the writer ({body_timed_mb:.1f} MB per timed sample that is not the writer's own); "
+                                       "at Close every rank receives its own byte range of the pending packs point to point, its GPU compresses it, "
+                                       "rank 0 receives the frames as long as they are and writes") if single else
                                       f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dominant), "achieved": dom.get("as_built", {}).get("achieved"),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("as_built", {}).get("frac"),

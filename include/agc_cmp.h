@@ -72,6 +72,9 @@ int agc_cmp_close_provide_frames(void *h, const uint8_t *frames, const uint64_t 
  * must pass to agc_cmp_apply_record (d_record: optional copy in that rank's HBM, or NULL). */
 int agc_cmp_set_distributed(void *h, uint32_t rank, uint32_t world_size, uint32_t writer_rank);
 int agc_cmp_last_record(void *h, const uint8_t **ptr, uint64_t *n);
+/* the same bytes (pinned host memory) with 64 bytes in front of them that belong to the caller's transport: a fixed-size message
+ * header written there lets header and head travel as ONE message (agc_amd/dist.py).  *n counts the 64 bytes. */
+int agc_cmp_last_record_framed(void *h, uint8_t **ptr, uint64_t *n);
 /* the record has a HEAD every rank applies (group ids, keys, the newly minted reference segments) and a BODY (the LZ deltas) only
  * the writer rank needs: body / body_n = NULL / 0 on the other ranks */
 int agc_cmp_apply_record(void *h, const uint8_t *record, uint64_t n, const uint8_t *d_record, const uint8_t *body, uint64_t body_n);

@@ -80,7 +80,9 @@ int main(int argc, char **argv)
             return 7;
         if (!cmp[o].CommitPreparedHead())
             return 8;
-        const std::vector<uint8_t> head = cmp[o].LastRecord(); // ("broadcast")
+        size_t hn = 0;
+        const uint8_t *hp = cmp[o].LastRecord(&hn);
+        const std::vector<uint8_t> head(hp, hp + hn); // ("broadcast")
         if (!cmp[o].CommitPreparedFinish())
             return 9;
         prepared[o] = -1;

@@ -179,6 +179,19 @@ def test_prefetching_ranks_still_write_the_reference_archive(name, world, tmp_pa
         assert sum(r[5] for r in res) == 0
 
 
+@pytest.mark.parametrize("name,world,cap0,cap_max", [("syn_mixed", 2, 128, 4096), ("syn_snp", 3, 4096, 1 << 20), ("syn_adaptive", 2, 72, 72),
+                                                     ("syn_c5_twin", 3, 1000, 30000)])
+def test_record_heads_longer_than_the_message_take_a_second_broadcast(name, world, cap0, cap_max, tmp_path, monkeypatch):
+    """the head travels as ONE message (64-byte header + head) whose capacity every rank derives from the sizes seen so far; a head
+    that does not fit announces its size and sends its rest in a second broadcast.  With the capacities shrunk (72 bytes: room for
+    the header and 8 bytes of head) every path of that is walked through, prefetching ranks included; same archive."""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    monkeypatch.setenv("AGC_AMD_DIST_MSG_CAP0", str(cap0))
+    monkeypatch.setenv("AGC_AMD_DIST_MSG_CAP_MAX", str(cap_max))
+    _run(name, world, tmp_path, on_gpu=False, prefetch=True)
+
+
 @pytest.mark.parametrize("name,world,prefetch", [("syn_viral_c", 2, False), ("syn_viral_c", 3, True), ("syn_adaptive_c", 2, True)])
 def test_concatenated_mode_from_n_ranks_equals_the_reference(name, world, prefetch, tmp_path):
     """-c: the units dealt round-robin are the reference's registration units (runs of -b contigs across the files, every contig
