@@ -145,7 +145,7 @@ int agc_cmp_stats(void *h, double *out, uint32_t n)
                         (double)s.zstd_out, (double)s.archive_bytes, s.t_scan, s.t_classify, s.t_gpu_aux, s.t_register, s.t_encode,
                         s.t_store, s.t_zstd, s.t_io, s.t_device, s.h_scan, s.h_classify, s.h_gpu_aux, s.h_register, s.h_encode, s.h_store,
                         (double)s.windows, (double)s.commit_runs, (double)s.revalidated,
-                        (double)s.enc_text, (double)s.enc_ref, (double)s.est_text, (double)s.est_ref, (double)s.cv_text, (double)s.cv_ref, (double)s.zstd_dev_in, s.t_zstd_dev, s.t_zstd_host, s.t_zstd_stage, s.t_zstd_wait, (double)s.reprepared, (double)s.zstd_dev_out};
+                        (double)s.enc_text, (double)s.enc_ref, (double)s.est_text, (double)s.est_ref, (double)s.cv_text, (double)s.cv_ref, (double)s.zstd_dev_in, s.t_zstd_dev, s.t_zstd_host, s.t_zstd_stage, s.t_zstd_wait, (double)s.reprepared, (double)s.zstd_dev_out, (double)s.windows_cut};
     const uint32_t m = sizeof(v) / sizeof(v[0]);
     for (uint32_t i = 0; i < n && i < m; ++i)
         out[i] = v[i];

@@ -857,7 +857,9 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     const uint64_t WINDOW_BYTES = 64ull << 20;
     // (AGC_AMD_WINDOW_MAX: tests pin the window, e.g. to 1 = every registration on its own, bookkeeping beside the next one)
     static const uint32_t window_cap = getenv("AGC_AMD_WINDOW_MAX") ? (uint32_t)std::max(1, atoi(getenv("AGC_AMD_WINDOW_MAX"))) : 256u;
-    const uint32_t WINDOW_MAX = I.adaptive ? 1u : window_cap; // new splitters change later scans: no speculation in -a mode
+    // (adaptive mode: new splitters change later scans -- a window is cut at the registration that brings some, stage_scan_dev;
+    // without the device's segments there is no such cut and no speculation)
+    const uint32_t WINDOW_MAX = I.adaptive && !I.adaptive_windows() ? 1u : window_cap;
     uint32_t window = 1; // grows while whole windows commit, shrinks to what did commit otherwise
 
     auto run_window = [&]() -> bool {

@@ -38,6 +38,7 @@ struct CompressorStats {
     uint64_t zstd_dev_in = 0;      // bytes entropy-coded on the GPU (part of zstd_in)
     uint64_t zstd_dev_out = 0;     // bytes of the frames it wrote (counted, not estimated)
     uint64_t enc_text = 0, enc_ref = 0, est_text = 0, est_ref = 0, cv_text = 0, cv_ref = 0;
+    uint64_t windows_cut = 0; // adaptive mode: windows cut at a registration that had to extend the splitter set
     uint64_t windows = 0, commit_runs = 0, revalidated = 0; // process_batch calls, commit runs inside them, segments classified again
     uint64_t reprepared = 0;       // multi-GPU + adaptive mode: samples whose prepare ahead of the turn did not stand (prepared again at the turn)
     double t_scan = 0, t_classify = 0, t_gpu_aux = 0, t_register = 0, t_encode = 0, t_store = 0, t_zstd = 0, t_io = 0;

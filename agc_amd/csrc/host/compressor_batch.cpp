@@ -745,9 +745,10 @@ bool CAGCCompressor::Impl::batch_commit(BatchState &b, uint32_t &n_committed)
         if (!stage_register(b) || !stage_store(b))
             return false;
         n_committed = b.commit_upto;
-        // append / adaptive mode: the caller classifies the rest again (unpacked groups and new splitters change more than
-        // the dependencies revalidate() follows; their windows hold one registration anyway)
-        if (b.commit_upto >= b.n_samples || appending || adaptive)
+        // append mode: the caller classifies the rest again (unpacked groups change more than the dependencies revalidate()
+        // follows; its windows hold one registration anyway).  Adaptive mode: a window never holds a registration that extends
+        // the splitter set behind another one (stage_scan_dev cuts it there), so what revalidate() follows is all that changes
+        if (b.commit_upto >= b.n_samples || appending || (adaptive && !adaptive_windows()))
             break;
         b.s_from = b.commit_upto;
         if (!revalidate(b))
@@ -1078,20 +1079,53 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             }
             std::vector<std::vector<uint64_t>> found(need.size());
             pool->parallel_for(need.size(), [&](size_t i, unsigned) { find_new_splitters(host_data ? (*host_data)[need[i]] : fetched_ctg[i], found[i]); });
-            size_t n_new = 0;
-            for (auto &f : found)
-                n_new += f.size();
-            if (n_new) {
-                for (uint32_t i = 0; i < n_ctg; ++i)
-                    st.bases -= ctgs[i].len; // (counted again by whoever scans the window next)
+            // the first registration of the window that has to extend the set.  A window of several registrations (round 5: adaptive
+            // mode speculates too) is valid as far as the set it was scanned with is: the registrations in front of that one
+            // stand, the one itself and everything behind it come again -- it as the first of its window, where the set is its
+            // to extend (agc_compressor.cpp:1187-1237: new splitters take effect for the contigs that come after)
+            uint32_t first_bad = ~0u;
+            for (size_t i = 0; i < need.size(); ++i)
+                if (!found[i].empty())
+                    first_bad = std::min(first_bad, ctgs[need[i]].sample_idx);
+            if (first_bad != ~0u) {
+                const uint32_t keep = first_bad == 0 ? 1u : first_bad; // registrations that stay in this window
+                if (ctgs.back().sample_idx >= keep) {
+                    uint32_t nc = 0;
+                    while (nc < n_ctg && ctgs[nc].sample_idx < keep)
+                        ++nc;
+                    for (uint32_t i = nc; i < n_ctg; ++i)
+                        st.bases -= ctgs[i].len;
+                    size_t ns = 0;
+                    while (ns < n_segs && dsegs[ns].ctg < nc)
+                        ++ns;
+                    b.ctgs->resize(nc);
+                    b.n_ctg = nc;
+                    segs.resize(ns);
+                    ++st.windows_cut;
+                    if (first_bad != 0) { // nothing new in what is left: the device's segments stand
+                        lap(b, "window cut at the registration that brings new splitters");
+                        b.dev_enc_n = 0;
+                        return 1;
+                    }
+                }
+                // the window's first registration extends the set (the window is that registration alone by now)
+                for (uint32_t i = 0; i < b.n_ctg; ++i)
+                    st.bases -= (*b.ctgs)[i].len; // (counted again by whoever scans the window next)
                 b.dev_keys = false;
                 if (b.no_new_splitters) { // prepared ahead of its turn: the set is not this sample's to extend yet
                     b.needs_turn = true;
                     return 1;
                 }
+                std::vector<uint32_t> need0;
+                std::vector<std::vector<uint64_t>> found0;
+                for (size_t i = 0; i < need.size(); ++i)
+                    if (need[i] < b.n_ctg) {
+                        need0.push_back(need[i]);
+                        found0.emplace_back(std::move(found[i]));
+                    }
                 b.mined_valid = true;
-                b.mined_need.swap(need);
-                b.mined_found.swap(found);
+                b.mined_need.swap(need0);
+                b.mined_found.swap(found0);
                 return 2;
             }
         }

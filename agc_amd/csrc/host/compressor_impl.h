@@ -935,6 +935,9 @@ struct CAGCCompressor::Impl {
     bool stage_scan(BatchState &b);
     int stage_scan_dev(BatchState &b);
     bool use_dev_segments(const BatchState &b) const;
+    // adaptive mode with windows of several registrations: only where the device delivers the segments (the cut of a window at
+    // the registration that brings new splitters lives there)
+    bool adaptive_windows() const { return adaptive && dev_segments && k >= 16 && overlap_mode == 0 && !appending; }
     bool dev_segments = true;          // AGC_AMD_DEV_SEGMENTS=0: scan hits to the host, cut and key look-up there (the round-3 path)
     PinnedBytes dev_seg_buf;           // (pinned: the segment table of a human sample is 3 MB per step)
     // the device's second LZ lane carries one encode at a time: launched by the thread that drives the steps, collected by the

@@ -316,7 +316,7 @@ int main(int argc, char **argv)
         const auto &s = c.Stats();
         std::cerr << "bases " << s.bases << " segments " << s.segments << " groups " << s.new_groups << " one-splitter " << s.one_splitter
                   << " middle " << s.middle_tried << "/" << s.middle_split << " windows " << s.windows << " commit-runs " << s.commit_runs
-                  << " revalidated " << s.revalidated << " zstd " << c.ZstdVersion() << "\n"
+                  << " revalidated " << s.revalidated << " windows-cut " << s.windows_cut << " zstd " << c.ZstdVersion() << "\n"
                   << "seconds: io " << s.t_io << " scan " << s.t_scan << " classify " << s.t_classify << " gpu-aux " << s.t_gpu_aux
                   << " register " << s.t_register << " encode " << s.t_encode << " store " << s.t_store << " zstd " << s.t_zstd << " (inside the device library: " << s.t_device << ")\n"
                   << "host-only part: scan " << s.h_scan << " classify " << s.h_classify << " gpu-aux " << s.h_gpu_aux << " register " << s.h_register

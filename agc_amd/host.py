@@ -14,7 +14,7 @@ STAT_NAMES = ["bases", "segments", "new_groups", "one_splitter", "middle_tried",
               "ref_bytes", "zstd_in", "zstd_out", "archive_bytes",
               "t_scan", "t_classify", "t_gpu_aux", "t_register", "t_encode", "t_store", "t_zstd", "t_io", "t_device",
               "h_scan", "h_classify", "h_gpu_aux", "h_register", "h_encode", "h_store", "windows", "commit_runs", "revalidated",
-              "enc_text", "enc_ref", "est_text", "est_ref", "cv_text", "cv_ref", "zstd_dev_in", "t_zstd_dev", "t_zstd_host", "t_zstd_stage", "t_zstd_wait", "reprepared", "zstd_dev_out"]
+              "enc_text", "enc_ref", "est_text", "est_ref", "cv_text", "cv_ref", "zstd_dev_in", "t_zstd_dev", "t_zstd_host", "t_zstd_stage", "t_zstd_wait", "reprepared", "zstd_dev_out", "windows_cut"]
 
 _lib = None
 

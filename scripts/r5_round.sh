@@ -31,4 +31,21 @@ if [ "$PART" = a ]; then
   for cfg in c1 c5twin; do timeout 600 python bench.py --config $cfg > $OUT/bench_config_$cfg.json 2> $OUT/bench_config_$cfg.err; show $OUT/bench_config_$cfg.json; done
   timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/bench_config_c5slice.json 2> $OUT/bench_config_c5slice.err; show $OUT/bench_config_c5slice.json; tail -3 $OUT/bench_config_c5slice.err
 fi
-ls $OUT | head -60
+if [ "$PART" = b ]; then
+  timeout 300 python -m pytest tests/test_gpu_scan.py tests/test_dist_single_archive.py -m gpu -x -q -k "pack_fasta or on_the_gpu" > $OUT/b_pack_and_dist_tests.log 2>&1; tail -4 $OUT/b_pack_and_dist_tests.log
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/b_bench_driver_cmd_no_cpu_baseline.json 2> $OUT/b_bench_driver_cmd.err; show $OUT/b_bench_driver_cmd_no_cpu_baseline.json; tail -2 $OUT/b_bench_driver_cmd.err
+  for cfg in c5twin c1; do timeout 600 python bench.py --config $cfg > $OUT/b_bench_config_$cfg.json 2> $OUT/b_bench_config_$cfg.err; show $OUT/b_bench_config_$cfg.json; grep -h "^bases" $OUT/b_bench_config_$cfg.err | tail -1; done
+  timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/b_bench_config_c5slice.json 2> $OUT/b_bench_config_c5slice.err; show $OUT/b_bench_config_c5slice.json; grep -h "^bases\|^seconds" $OUT/b_bench_config_c5slice.err | tail -2
+  AGC_BENCH_ONE_GPU=1 AGC_BENCH_SERIAL_PREPARE=1 AGC_AMD_LAPS=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/b_bench_one_gpu_2_ranks_serial_prepare.json 2> $OUT/b_bench_one_gpu_2_ranks_serial_prepare.err; show $OUT/b_bench_one_gpu_2_ranks_serial_prepare.json
+  python - $OUT/b_bench_one_gpu_2_ranks_serial_prepare.json <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("ms per sample rank0:", d["config"].get("single_archive_ms_per_sample_rank0"))
+    print(d["config"].get("parallelism"))
+except Exception as e:
+    print("no line", e)
+PY
+  tail -5 $OUT/b_bench_one_gpu_2_ranks_serial_prepare.err
+fi
+ls $OUT | head -80
