@@ -149,7 +149,8 @@ struct agc_hip_ctx {
     // agc_hip_pack_fasta_begin / _end: raw FASTA bodies -> the packed sample on a stream of its own (pack_kernels.hip)
     struct PackFasta {
         hipStream_t stream = nullptr;
-        DevBuf d_state, d_rng, d_off; // look-back words + the three counters; the ranges; n_ctg + 1 symbol offsets + the total
+        DevBuf d_state, d_rng, d_off; // the three counters (+ look-back words); the ranges; n_ctg + 1 symbol offsets + the total
+        DevBuf d_tcnt, d_toff;        // two-pass variant: symbols per tile, symbols in front of every tile
         uint64_t *h_res = nullptr;    // pinned: offsets, total, escaped-block count
         size_t h_res_cap = 0;
         uint32_t n_ctg = 0;
@@ -450,7 +451,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
     if (c->pfa.stream) {
         (void)hipStreamSynchronize(c->pfa.stream);
         (void)hipStreamDestroy(c->pfa.stream);
-        for (DevBuf *b : {&c->pfa.d_state, &c->pfa.d_rng, &c->pfa.d_off})
+        for (DevBuf *b : {&c->pfa.d_state, &c->pfa.d_rng, &c->pfa.d_off, &c->pfa.d_tcnt, &c->pfa.d_toff})
             if (b->p)
                 (void)hipFree(b->p);
         if (c->pfa.h_res)
@@ -1001,7 +1002,19 @@ int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_ra
         a.esc_bytes = d_esc_bytes;
         a.esc_cap = (uint32_t)std::min<uint64_t>(esc_cap_blocks, 0x7fffffffu);
         a.ctg_off = (unsigned long long *)P.d_off.p;
-        hipLaunchKernelGGL(pack_fasta_kernel, dim3(n_tiles), dim3(256), 0, P.stream, a);
+        static const bool lookback = getenv("AGC_HIP_PACK_LOOKBACK") != nullptr;
+        if (lookback) {
+            a.tile_off = nullptr;
+            hipLaunchKernelGGL(pack_fasta_kernel<true>, dim3(n_tiles), dim3(256), 0, P.stream, a);
+        } else {
+            CHK(ensure(c, P.d_tcnt, (size_t)n_tiles * 4 + 64, P.stream));
+            CHK(ensure(c, P.d_toff, (size_t)n_tiles * 8 + 64, P.stream));
+            a.tile_off = (const uint64_t *)P.d_toff.p;
+            hipLaunchKernelGGL(pack_fasta_count_kernel, dim3(n_tiles), dim3(256), 0, P.stream, a, (uint32_t *)P.d_tcnt.p);
+            hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(1024), 0, P.stream, (const uint32_t *)P.d_tcnt.p, n_tiles, (uint64_t *)P.d_toff.p,
+                               (uint64_t *)((uint8_t *)P.d_state.p + 32)); // (its total: unused, the last tile writes a.total)
+            hipLaunchKernelGGL(pack_fasta_kernel<false>, dim3(n_tiles), dim3(256), 0, P.stream, a);
+        }
         HIPCHK(c, hipGetLastError());
     }
     if (P.timed)

@@ -5,10 +5,14 @@
 // two kernels that read and write one byte per symbol three times over (count, scatter, pack).  Here the raw bytes are read once
 // (1 + 1 / line_width bytes per symbol) and 0.25 bytes per symbol are written.
 //
-// Shape: a compaction needs every tile's output offset = the number of symbols kept in front of it.  The tiles are handed out in
-// ticket order and publish their counts through a chained scan with decoupled look-back (one 64-bit word per tile: 2 flag bits +
-// the count or the inclusive prefix), so a tile knows its offset a few hundred cycles after it has counted its own bytes, which
-// are still in registers.  A tile of 16 KiB of input then writes WHOLE 1024-symbol blocks only: it owns the blocks whose first
+// Shape: a compaction needs every tile's output offset = the number of symbols kept in front of it.  Two variants of that:
+//  * LOOKBACK = false (the default): a counting pass over the raw bytes first (pack_fasta_count_kernel: one count per tile, then
+//    the one-block scan of pp_scan_kernel), i.e. the input is read twice -- 2 (1 + 1 / width) + 0.25 bytes per symbol of traffic;
+//  * LOOKBACK = true (AGC_HIP_PACK_LOOKBACK=1): one pass -- the tiles are handed out in ticket order and publish their counts
+//    through a chained scan with decoupled look-back (one 64-bit word per tile: 2 flag bits + the count or the inclusive prefix).
+//    Measured on MI355X: 19.7 ms per 3 Gbp against ~1 for the two passes -- 186 k tiles, each behind one same-address atomic and
+//    a look-back that advances 64 tiles per round trip of device-scope loads through eight L2s; kept for the record.
+// Either way a tile of 16 KiB of input then writes WHOLE 1024-symbol blocks only: it owns the blocks whose first
 // symbol it holds, leaves the symbols in front of its first block to the tile before it and reads on into the next tiles'
 // bytes (<= 1023 symbols, L2 hits for the neighbour) to finish its last block -- words, escape index and escaped bytes of a block
 // have one writer, nothing is zeroed beforehand and no atomics touch the output.
@@ -26,8 +30,9 @@ struct PackFastaArgs {
     const uint64_t *rng_begin, *rng_end; // contig c = raw bytes [rng_begin[c], rng_end[c]); ascending, disjoint
     uint32_t n_rng;
     uint32_t n_tiles;
-    uint32_t *ticket;                    // zeroed
-    unsigned long long *state;           // n_tiles words, zeroed
+    uint32_t *ticket;                    // zeroed                 (look-back variant)
+    unsigned long long *state;           // n_tiles words, zeroed  (look-back variant)
+    const uint64_t *tile_off;            // symbols in front of every tile (two-pass variant: pack_fasta_count_kernel + pp_scan_kernel)
     uint32_t *words;
     int32_t *esc_index;
     uint8_t *esc_bytes;
@@ -186,7 +191,63 @@ __device__ __forceinline__ void pf_escape(const PackFastaArgs &a, const int32_t 
     }
 }
 
-__global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
+// symbols (bytes >= 64 inside a contig range) per tile
+__global__ void __launch_bounds__(256) pack_fasta_count_kernel(PackFastaArgs a, uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t s_part[4], s_rfirst;
+    __shared__ unsigned long long s_cb, s_ce;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x;
+    const uint64_t t_begin = (uint64_t)tile * PF_TILE;
+    if (tid == 0) {
+        uint32_t lo = 0, hi = a.n_rng;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.rng_end[mid] <= t_begin)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        s_rfirst = lo;
+        s_cb = lo < a.n_rng ? a.rng_begin[lo] : ~0ULL;
+        s_ce = lo < a.n_rng ? a.rng_end[lo] : 0;
+    }
+    __syncthreads();
+    const uint32_t r_first = s_rfirst;
+    const uint64_t cb = s_cb, ce = s_ce;
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t p = t_begin + (uint64_t)wv * 4096 + j * 1024 + lane * 16;
+        if (p >= a.n_raw)
+            continue;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (p + 16 <= a.n_raw) {
+            const uint4 v = *(const uint4 *)(a.raw + p);
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+        } else {
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t)
+                if (p + t < a.n_raw)
+                    w[t >> 2] |= (uint32_t)a.raw[p + t] << (8 * (t & 3));
+        }
+        uint32_t keep = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q)
+            keep |= (((pf_ge64(w[q]) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+        keep &= pf_range_mask(a, p, cb, ce, r_first);
+        c += __popc(keep);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        c += __shfl_down(c, o);
+    if (lane == 0)
+        s_part[wv] = c;
+    __syncthreads();
+    if (tid == 0)
+        tile_cnt[tile] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
 {
     __shared__ uint32_t s_words[PF_MAX_BLOCKS * (PACK_BLOCK / 16)];
     __shared__ uint32_t s_flag[PF_MAX_BLOCKS];
@@ -198,7 +259,7 @@ __global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     if (tid == 0)
-        s_tile = atomicAdd(a.ticket, 1u);
+        s_tile = LOOKBACK ? atomicAdd(a.ticket, 1u) : blockIdx.x;
     for (uint32_t i = tid; i < PF_MAX_BLOCKS * (PACK_BLOCK / 16); i += 256)
         s_words[i] = 0;
     if (tid < PF_MAX_BLOCKS) {
@@ -255,7 +316,10 @@ __global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
     // ---- the tile's offset: publish the count, look back.  The state word is all that travels between tiles (flag and value in one
     // 64-bit word), so the atomics are RELAXED: an agent-scope release / acquire pair would write back and invalidate the XCD's L2
     // around every one of them (buffer_wbl2 / buffer_inv on gfx950) -- measured: 19.7 ms per 3 Gbp instead of < 1
-    if (wv == 0) {
+    if (!LOOKBACK) {
+        if (tid == 0)
+            s_excl = a.tile_off[tile];
+    } else if (wv == 0) {
         unsigned long long excl = 0;
         if (tile) {
             if (lane == 0)
@@ -390,5 +454,8 @@ __global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
     }
     // (the tail of a last, partial block in an escaped slot stays as it is: nobody reads beyond n_symbols)
 }
+
+template __global__ void pack_fasta_kernel<false>(PackFastaArgs);
+template __global__ void pack_fasta_kernel<true>(PackFastaArgs);
 
 } // namespace agc
