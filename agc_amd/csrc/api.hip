@@ -160,6 +160,11 @@ struct agc_hip_ctx {
         hipEvent_t e0 = nullptr, e1 = nullptr;
     } pfa;
 
+    // the parse in chunks (launch_parse): chunk list, logs and per-chunk output of the first stream and of the two encode lanes
+    struct ChunkBufs {
+        DevBuf d_jobs, d_seg0, d_logs, d_logn, d_out;
+    } chunk_bufs[3];
+
     // pinned host allocations handed out by agc_hip_host_alloc
     std::vector<void *> host_allocs;
 
@@ -448,6 +453,10 @@ void agc_hip_destroy(agc_hip_ctx *c)
     for (hipStream_t s_ : {c->stream2, c->stream3})
         if (s_)
             (void)hipStreamSynchronize(s_);
+    for (auto &cb : c->chunk_bufs)
+        for (DevBuf *b : {&cb.d_jobs, &cb.d_seg0, &cb.d_logs, &cb.d_logn, &cb.d_out})
+            if (b->p)
+                (void)hipFree(b->p);
     if (c->pfa.stream) {
         (void)hipStreamSynchronize(c->pfa.stream);
         (void)hipStreamDestroy(c->pfa.stream);
@@ -1670,15 +1679,70 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
     return AGC_HIP_OK;
 }
 
+// A launch with few, long texts is a handful of dependent chains on an empty GPU: such batches are parsed in chunks (lz_kernels.hip:
+// ChunkCtl) -- a wavefront per 4096-symbol chunk, then a wavefront per text that joins them.  AGC_HIP_LZ_CHUNK=<symbols> forces a chunk
+// length for every launch the host has descriptors of (the tests run the whole LZ suite that way), 0 switches the path off.
 template <int MODE>
-int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, int lane = 0, const uint32_t *n_dev = nullptr)
+int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u32, int lane = 0, const uint32_t *n_dev = nullptr, const Batch *b = nullptr)
 {
     const uint32_t grid = (n + 3) / 4; // one wave per segment, 4 waves per block
+    const hipStream_t st = lane ? c->lane(lane).s : c->stream;
+    const RefDesc *d_refs = (const RefDesc *)c->d_refs.p;
+    const SegDesc *d_segs = (const SegDesc *)(lane ? c->lane(lane).d_segs.p : c->d_segs.p);
+    uint32_t *d_resv = (uint32_t *)(lane ? c->lane(lane).d_resv.p : c->d_resv.p), *d_resp = (uint32_t *)(lane ? c->lane(lane).d_resp.p : c->d_resp.p);
+    static const int forced = getenv("AGC_HIP_LZ_CHUNK") ? atoi(getenv("AGC_HIP_LZ_CHUNK")) : -1;
+    uint32_t chunk_len = 0;
+    if (b && !n_dev && n && forced != 0 && b->segs.size() == n) {
+        if (forced > 0)
+            chunk_len = (uint32_t)std::max(64, forced);
+        else if (n < 1024 && b->segs[0].text.len >= 16384) // (longest first)
+            chunk_len = 4096;
+    }
+    if (chunk_len) {
+        agc_hip_ctx::ChunkBufs &cb = c->chunk_bufs[lane];
+        std::vector<ChunkJob> jobs;
+        std::vector<uint32_t> seg0(n + 1);
+        for (uint32_t i = 0; i < n; ++i) {
+            seg0[i] = (uint32_t)jobs.size();
+            const uint32_t len = (uint32_t)b->segs[i].text.len, nc = std::max<uint32_t>(1, (len + chunk_len - 1) / chunk_len);
+            for (uint32_t ch = 0; ch < nc; ++ch)
+                jobs.push_back({i, ch});
+        }
+        seg0[n] = (uint32_t)jobs.size();
+        if (jobs.size() <= (1u << 22)) {
+            ChunkPlan pl;
+            pl.n_jobs = (uint32_t)jobs.size();
+            pl.chunk_len = chunk_len;
+            pl.cap = chunk_len / 8 + 4;
+            pl.chunk_stride = MODE == MODE_ENCODE ? ((chunk_len + 5 * chunk_len / 16 + 160 + 15) & ~15u) : 0;
+            CHK(ensure(c, cb.d_jobs, jobs.size() * sizeof(ChunkJob), st));
+            CHK(ensure(c, cb.d_seg0, seg0.size() * 4, st));
+            CHK(ensure(c, cb.d_logs, jobs.size() * (size_t)pl.cap * sizeof(ChunkState), st));
+            CHK(ensure(c, cb.d_logn, jobs.size() * 4, st));
+            if (MODE == MODE_ENCODE)
+                CHK(ensure(c, cb.d_out, jobs.size() * (size_t)pl.chunk_stride + 64, st));
+            // (the two lists go through the pinned ring in pieces: a window of diverged genomes has a few 10 k chunks)
+            for (size_t o = 0; o < jobs.size(); o += 1u << 19)
+                CHK(upload(c, (ChunkJob *)cb.d_jobs.p + o, jobs.data() + o, std::min<size_t>(jobs.size() - o, 1u << 19) * sizeof(ChunkJob), st));
+            for (size_t o = 0; o < seg0.size(); o += 1u << 20)
+                CHK(upload(c, (uint32_t *)cb.d_seg0.p + o, seg0.data() + o, std::min<size_t>(seg0.size() - o, 1u << 20) * 4, st));
+            pl.jobs = (const ChunkJob *)cb.d_jobs.p;
+            pl.seg_chunk0 = (const uint32_t *)cb.d_seg0.p;
+            pl.logs = (ChunkState *)cb.d_logs.p;
+            pl.log_n = (uint32_t *)cb.d_logn.p;
+            pl.chunk_out = (uint8_t *)cb.d_out.p;
+            {
+                KTimer t(c, lane ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+                hipLaunchKernelGGL(lz_chunk_kernel<MODE>, dim3((pl.n_jobs + 3) / 4), dim3(256), 0, st, d_refs, d_segs, pl, out_u32);
+                hipLaunchKernelGGL(lz_hop_kernel<MODE>, dim3(grid), dim3(256), 0, st, d_refs, d_segs, n, pl, out_bytes, out_u32, d_resv, d_resp);
+            }
+            HIPCHK(c, hipGetLastError());
+            return AGC_HIP_OK;
+        }
+    }
     {
         KTimer t(c, lane ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
-        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, lane ? c->lane(lane).s : c->stream, (const RefDesc *)c->d_refs.p,
-                           (const SegDesc *)(lane ? c->lane(lane).d_segs.p : c->d_segs.p), n, out_bytes, out_u32,
-                           (uint32_t *)(lane ? c->lane(lane).d_resv.p : c->d_resv.p), (uint32_t *)(lane ? c->lane(lane).d_resp.p : c->d_resp.p), n_dev);
+        hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, st, d_refs, d_segs, n, out_bytes, out_u32, d_resv, d_resp, n_dev);
     }
     HIPCHK(c, hipGetLastError());
     return AGC_HIP_OK;
@@ -1712,7 +1776,7 @@ static int lz_encode_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, con
     Batch b;
     CHK(prepare_batch(c, MODE_ENCODE, n, h_gid, src, h_off, h_len, h_rc, nullptr, b));
     CHK(ensure(c, c->d_scratch, b.out_total + 64));
-    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)c->d_scratch.p, nullptr));
+    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)c->d_scratch.p, nullptr, 0, nullptr, &b));
     std::vector<uint32_t> lens(n);
     HIPCHK(c, hipMemcpyAsync(lens.data(), c->d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1758,7 +1822,7 @@ static int lz_encode_begin_impl(agc_hip_ctx *c, int lane, uint32_t n, const uint
     L.timed = c->timing;
     if (L.timed)
         (void)hipEventRecord(L.e0, L.s);
-    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)L.d_scratch.p, nullptr, lane));
+    CHK(launch_parse<MODE_ENCODE>(c, n, (uint8_t *)L.d_scratch.p, nullptr, lane, nullptr, &b));
     if (L.timed)
         (void)hipEventRecord(L.e1, L.s);
     HIPCHK(c, hipEventRecord(L.done, L.s));
@@ -2029,7 +2093,7 @@ static int lz_estimate_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, c
 {
     Batch b;
     CHK(prepare_batch(c, MODE_ESTIMATE, n, h_gid, src, h_off, h_len, h_rc, nullptr, b));
-    CHK(launch_parse<MODE_ESTIMATE>(c, n, nullptr, nullptr));
+    CHK(launch_parse<MODE_ESTIMATE>(c, n, nullptr, nullptr, 0, nullptr, &b));
     HIPCHK(c, hipMemcpyAsync(h_cost, c->d_resv.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (h_peak)
         HIPCHK(c, hipMemcpyAsync(h_peak, c->d_resp.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2043,7 +2107,7 @@ static int lz_cost_vector_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid
     Batch b;
     CHK(prepare_batch(c, MODE_COSTVEC, n, h_gid, src, h_off, h_len, h_rc, h_prefix_costs, b));
     CHK(ensure(c, c->d_scratch, b.out_total + 64)); // (one byte per position on the device: lz_kernels.hip, cost_t)
-    CHK(launch_parse<MODE_COSTVEC>(c, n, nullptr, (uint32_t *)c->d_scratch.p));
+    CHK(launch_parse<MODE_COSTVEC>(c, n, nullptr, (uint32_t *)c->d_scratch.p, 0, nullptr, &b));
     std::vector<uint8_t> tmp(b.out_total);
     if (b.out_total)
         HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_scratch.p, b.out_total, hipMemcpyDeviceToHost, c->stream));
@@ -2075,7 +2139,7 @@ static int lz_split_point_impl(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid
     Batch b;
     CHK(prepare_batch(c, MODE_COSTVEC, m, gid.data(), src, off.data(), len.data(), rc.data(), pf.data(), b));
     CHK(ensure(c, c->d_scratch, b.out_total + 64));
-    CHK(launch_parse<MODE_COSTVEC>(c, m, nullptr, (uint32_t *)c->d_scratch.p));
+    CHK(launch_parse<MODE_COSTVEC>(c, m, nullptr, (uint32_t *)c->d_scratch.p, 0, nullptr, &b));
     std::vector<SplitJob> jobs(n);
     uint64_t o = 0;
     for (uint32_t s = 0; s < n; ++s) {

@@ -355,11 +355,38 @@ struct ParseOut {
     uint32_t peak;  // estimate: largest cost seen at a loop-top check
 };
 
+// ---- a parse in chunks (round 5) ----
+// One wavefront per text is a chain of dependent steps: ~7 us per edit, so a 500 kb text at 2.5 % divergence keeps ONE wavefront busy
+// for 90 ms however empty the GPU is -- the shape of adaptive collections of diverged genomes, where a launch holds a few dozen long
+// texts.  The state of the reference's loop at the top of an iteration is (i, pred_pos, no_prev_literals) (lz_diff.cpp:669-798), and
+// right after a match it is (i, pred_pos, 0): nothing in front of a match end is read or re-written again (back extension and the
+// '!' patch stop at the literals since the last match).  So a parser that starts somewhere in the text with a guessed state produces
+// the reference's tokens from the first match end on that it shares with the true parse -- same position, same pred_pos -- and in
+// similar sequences that is its first or second match.
+//   ROLE 1 (lz_chunk_kernel): one wavefront per CHUNK of a text, started at the chunk's first symbol with pred_pos = 0; it stops at the
+//          chunk's end and logs the state after every match (position, pred_pos, bytes written, running cost).
+//   ROLE 2 (lz_hop_kernel): one wavefront per text walks from chunk to chunk: it is the true parse, but wherever its state after a match
+//          is in the log of the chunk it has reached, it takes that chunk's tokens from there to the chunk's last match end as they are
+//          (copies the bytes / adds the costs) and goes on behind them -- it parses only the few tokens around every chunk boundary.
+//   ROLE 0: the whole text by one wavefront, as before (launches with thousands of texts: the GPU is full anyway).
+struct ChunkState {
+    uint32_t i, pred, o, est; // after a match: text position, pred_pos, output cursor (estimate: the peak), running cost
+};
+struct ChunkCtl {
+    uint32_t i0, i_stop;          // ROLE 1: the chunk [i0, i_stop)
+    ChunkState *log;              // ROLE 1: this chunk's log; ROLE 2: the logs of the text's chunks, `cap` entries apart
+    uint32_t *log_n;              // ... and their entry counts
+    uint32_t cap, chunk_len, n_chunks;
+    const uint8_t *chunk_out;     // ROLE 2, encode: chunk c's bytes at chunk_out + c * chunk_stride
+    uint32_t chunk_stride;
+};
+
 // maybe: one bit per text position from key_filter_kernel (0 = the key at this position is valid and not in the reference's
 // index: a certain literal); nullptr: literal runs are found by probing the table (wide probe)
-template <int MODE>
+template <int MODE, int ROLE = 0>
 __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__restrict__ out, cost_t *__restrict__ costs,
-                             const bool prefix_costs, uint8_t *win_lds, const unsigned long long *__restrict__ maybe_generic)
+                             const bool prefix_costs, uint8_t *win_lds, const unsigned long long *__restrict__ maybe_generic,
+                             const ChunkCtl cc = ChunkCtl())
 {
     const uint32_t lane = lane_id();
     const bool writer = lane == 0;
@@ -376,15 +403,22 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
     const bool t_clean = wave_view_clean(tv);
     ParseOut res{0, 0};
 
-    if (MODE != MODE_COSTVEC) {
+    if (MODE != MODE_COSTVEC && ROLE != 1) {
         // identical sequence (lz_diff.cpp:678-680 / 849-851)
         if (n == ref_size && wave_match_fwd(tv, 0, t_clean, rv, 0, r_clean, n) == n)
             return res;
     }
 
-    uint32_t i = 0, pred_pos = 0, npl = 0; // npl = no_prev_literals
-    uint32_t o = 0;                        // output cursor (bytes or costs)
+    uint32_t i = ROLE == 1 ? cc.i0 : 0, pred_pos = 0, npl = 0; // npl = no_prev_literals
+    uint32_t o = ROLE == 1 && MODE == MODE_COSTVEC ? cc.i0 : 0; // output cursor (bytes or costs; a cost's index is its position)
     uint32_t est = 0, peak = 0;
+    const uint32_t i_stop = ROLE == 1 ? cc.i_stop : 0xFFFFFFFFu; // a chunk parser writes no cost at or beyond its chunk's end
+    uint32_t n_log = 0;                                          // ROLE 1: entries logged
+#define PUT_COST(idx, v)                                                                           \
+    do {                                                                                           \
+        if (ROLE != 1 || (idx) < i_stop)                                                           \
+            costs[(idx)] = (v);                                                                    \
+    } while (0)
 
     AGC_TRACE(3, n);
     const uint64_t keybits = (1ULL << key_len) - 1ULL;
@@ -401,8 +435,73 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
     bool try_wide = false;
     bool force_exact = false; // the grouped probe could not settle position i: the next step is the exact one
     TextWin win{win_lds, 0, 0};
+    // ROLE 2: chunk x's tokens from its logged state `from` (== this parser's state) to its last logged state are taken as they are
+    auto hop = [&](uint32_t x, const ChunkState from) {
+        const ChunkState last = cc.log[(size_t)x * cc.cap + cc.log_n[x] - 1];
+        if (MODE == MODE_ENCODE) {
+            const uint8_t *src = cc.chunk_out + (size_t)x * cc.chunk_stride + from.o;
+            const uint32_t cnt = last.o - from.o;
+            for (uint32_t t = lane; t < cnt; t += WAVE)
+                out[o + t] = src[t];
+            o += cnt;
+            coop_out = true;
+        } else if (MODE == MODE_ESTIMATE) {
+            const uint32_t base = est - from.est;
+            if (base + last.o > peak)
+                peak = base + last.o; // (.o of an estimate's log entry: the chunk parser's peak at that point)
+            est = base + last.est;
+        } else
+            o = last.i; // (the chunk parser wrote its costs where they belong)
+        i = last.i;
+        pred_pos = last.pred;
+        npl = 0;
+        lit_streak = 0;
+        try_wide = false;
+        force_exact = false;
+    };
+    // ROLE 2, after a match: is this state (position, pred_pos) in the log of the chunk the position lies in?
+    auto try_hop = [&]() {
+        if (!i)
+            return;
+        const uint32_t x = (i - 1) / cc.chunk_len;
+        if (x >= cc.n_chunks)
+            return;
+        const uint32_t nl = cc.log_n[x];
+        for (uint32_t b0 = 0; b0 < nl; b0 += WAVE) {
+            ChunkState e{0xFFFFFFFFu, 0, 0, 0};
+            if (b0 + lane < nl)
+                e = cc.log[(size_t)x * cc.cap + b0 + lane];
+            const uint64_t hit = __ballot(e.i == i && e.pred == pred_pos);
+            if (hit) {
+                const uint32_t l = ctz64(hit);
+                if (b0 + l + 1 < nl) { // (the chunk's last entry: nothing behind it to take)
+                    ChunkState from;
+                    from.i = i;
+                    from.pred = pred_pos;
+                    from.o = bcast_u32(e.o, l);
+                    from.est = bcast_u32(e.est, l);
+                    hop(x, from);
+                }
+                return;
+            }
+            if (__ballot(b0 + lane < nl && e.i > i))
+                return; // (entries ascend by position)
+        }
+    };
+    if (ROLE == 2 && cc.n_chunks && cc.log_n[0])
+        hop(0, ChunkState{0, 0, 0, 0}); // the first chunk's parser started with the true state
+#define LOG_STATE()                                                                                \
+    do {                                                                                           \
+        if (ROLE == 1 && i <= i_stop && n_log < cc.cap) {                                          \
+            if (writer)                                                                            \
+                cc.log[n_log] = ChunkState{i, pred_pos, MODE == MODE_ESTIMATE ? peak : o, est};    \
+            ++n_log;                                                                               \
+        }                                                                                          \
+        if (ROLE == 2)                                                                             \
+            try_hop();                                                                             \
+    } while (0)
     PH_DECL
-    while (i + key_len < n) {
+    while (i + key_len < n && (ROLE != 1 || i < i_stop)) {
         AGC_TRACE(4, i);
         PH(0) // everything after the previous iteration's last mark (emission of a match / literal)
         {
@@ -435,6 +534,8 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
             const uint32_t lim = n - key_len; // i + key_len < n holds here, so lim > i
             if (stop_pos > lim)
                 stop_pos = lim;
+            if (ROLE == 1 && stop_pos > i_stop)
+                stop_pos = i_stop; // (i < i_stop here: the loop condition)
             const uint32_t f = stop_pos - i;
             if (f) {
                 if (MODE == MODE_ESTIMATE) {
@@ -443,7 +544,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                     est += f;
                 } else {
                     for (uint32_t t = lane; t < f; t += WAVE)
-                        costs[o + t] = 1;
+                        PUT_COST(o + t, 1);
                 }
                 o += f;
                 i += f;
@@ -535,7 +636,9 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                 }
             }
             const uint64_t sm = __ballot(stop);
-            const uint32_t f = sm ? ctz64(sm) : WAVE;
+            uint32_t f = sm ? ctz64(sm) : WAVE;
+            if (ROLE == 1 && f > i_stop - i)
+                f = i_stop - i;
             if (f) {
                 if (MODE == MODE_ENCODE) {
                     if (stale_out) {
@@ -553,7 +656,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                     // (no drain: positions at or after `o` hold no pending store -- a roll-back is always followed by a match
                     // that covers the rolled-back positions and drains around its own stores)
                     if (lane < f)
-                        costs[o + lane] = 1;
+                        PUT_COST(o + lane, 1);
                 }
                 o += f;
                 i += f;
@@ -628,7 +731,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                         peak = est + f - 1; // loop-top checks of these f literal steps
                     est += f;
                 } else if (lane < f)
-                    costs[o + lane] = 1;
+                    PUT_COST(o + lane, 1);
                 o += f;
                 i += f;
                 pred_pos += f;
@@ -688,10 +791,10 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                 } else {
                     const uint32_t tc = 2 + base_int_len(nrun - MIN_NRUN_LEN);
                     for (uint32_t t = lane; t < nrun; t += WAVE)
-                        costs[o + t] = 0;
+                        PUT_COST(o + t, 0);
                     __builtin_amdgcn_s_waitcnt(0); // the run's zeros land before lane 0 stores its cost
                     if (writer)
-                        costs[prefix_costs ? o : o + nrun - 1] = (cost_t)tc;
+                        PUT_COST(prefix_costs ? o : o + nrun - 1, (cost_t)tc);
                     o += nrun;
                 }
                 i += nrun;
@@ -705,7 +808,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                 } else if (MODE == MODE_ESTIMATE)
                     ++est;
                 else if (writer)
-                    costs[o] = 1;
+                    PUT_COST(o, 1);
                 ++o;
                 ++i;
                 ++pred_pos;
@@ -792,7 +895,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
             } else if (MODE == MODE_ESTIMATE)
                 ++est;
             else if (writer)
-                costs[o] = 1;
+                PUT_COST(o, 1);
             ++o;
             ++i;
             ++pred_pos;
@@ -813,6 +916,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
             pred_pos = match_pos + len;
             i += len;
             npl = 0;
+            LOG_STATE();
             continue;
         }
 
@@ -879,15 +983,21 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
             // and the zero fill before lane 0's match cost: drain the wave's stores in between
             __builtin_amdgcn_s_waitcnt(0);
             for (uint32_t t = lane; t < len; t += WAVE)
-                costs[o + t] = 0;
+                PUT_COST(o + t, 0);
             __builtin_amdgcn_s_waitcnt(0);
             if (writer)
-                costs[prefix_costs ? o : o + len - 1] = (cost_t)tc;
+                PUT_COST(prefix_costs ? o : o + len - 1, (cost_t)tc);
             o += len;
         }
         pred_pos = match_pos + len;
         i += len;
         npl = 0;
+        LOG_STATE();
+    }
+    if (ROLE == 1) { // a chunk ends where its range does: the tail of the text is the hop parser's
+        if (writer)
+            *cc.log_n = n_log;
+        return res;
     }
 
 #ifdef AGC_PHASES
@@ -920,6 +1030,8 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
     }
     res.value = o;
     return res;
+#undef PUT_COST
+#undef LOG_STATE
 }
 
 // One wavefront per segment: wave w of block b parses segment 4*b + w of the host's
@@ -980,6 +1092,122 @@ __global__ void __launch_bounds__(256) lz_parse_kernel(const RefDesc *__restrict
 template __global__ void lz_parse_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
 template __global__ void lz_parse_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
 template __global__ void lz_parse_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
+
+// ---- the parse in chunks (see ChunkCtl): a wavefront per chunk, then a wavefront per text that hops from chunk to chunk ----
+struct ChunkJob {
+    uint32_t seg;   // index into the descriptor array
+    uint32_t chunk; // chunk of that text
+};
+struct ChunkPlan {
+    const ChunkJob *jobs;        // every chunk of every text (lz_chunk_kernel: one wavefront each)
+    const uint32_t *seg_chunk0;  // per descriptor: index of its first chunk in `jobs`, n_segs + 1 entries
+    uint32_t n_jobs, chunk_len, cap;
+    ChunkState *logs;            // n_jobs x cap
+    uint32_t *log_n;             // n_jobs
+    uint8_t *chunk_out;          // encode: n_jobs x chunk_stride bytes
+    uint32_t chunk_stride;
+};
+
+__device__ __forceinline__ void load_descs(const RefDesc *refs, const SegDesc &sdm, RefDesc &rd, SymViewG &tv)
+{
+    const RefDesc &rdm = refs[uniform_u32(sdm.ref_slot)];
+    rd.words = uniform_ptr(rdm.words);
+    rd.esc_index = uniform_ptr(rdm.esc_index);
+    rd.esc_bytes = uniform_ptr(rdm.esc_bytes);
+    rd.table = uniform_ptr(rdm.table);
+    rd.bloom = uniform_ptr(rdm.bloom);
+    rd.ref_size = uniform_u32(rdm.ref_size);
+    rd.ht_mask = uniform_u32(rdm.ht_mask);
+    rd.key_len = uniform_u32(rdm.key_len);
+    rd.min_match_len = uniform_u32(rdm.min_match_len);
+    rd.is_short = uniform_u32(rdm.is_short);
+    rd.valid = 1;
+    tv = global_view(uniform_view(sdm.text));
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) lz_chunk_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs, ChunkPlan pl,
+                                                       uint32_t *__restrict__ out_u32)
+{
+    const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= pl.n_jobs)
+        return;
+    const uint32_t seg = uniform_u32(pl.jobs[j].seg), ch = uniform_u32(pl.jobs[j].chunk);
+    const SegDesc &sdm = segs[seg];
+    RefDesc rd;
+    SymViewG tv;
+    load_descs(refs, sdm, rd, tv);
+    const uint64_t out_off = uniform_u64(sdm.out_off);
+    const unsigned long long *maybe = uniform_ptr(sdm.maybe);
+    const uint32_t flags = uniform_u32(sdm.flags);
+    __shared__ __attribute__((aligned(32))) uint8_t s_win[4][WIN_SYMS];
+    uint8_t *win_lds = s_win[threadIdx.x >> 6];
+    ChunkCtl cc;
+    cc.i0 = ch * pl.chunk_len;
+    cc.i_stop = cc.i0 + pl.chunk_len < tv.len ? cc.i0 + pl.chunk_len : tv.len;
+    cc.log = pl.logs + (size_t)j * pl.cap;
+    cc.log_n = pl.log_n + j;
+    cc.cap = pl.cap;
+    cc.chunk_len = pl.chunk_len;
+    cc.n_chunks = 0;
+    cc.chunk_out = nullptr;
+    cc.chunk_stride = 0;
+    if (MODE == MODE_ENCODE)
+        (void)lz_parse<MODE, 1>(rd, tv, pl.chunk_out + (size_t)j * pl.chunk_stride, nullptr, false, win_lds, nullptr, cc);
+    else if (MODE == MODE_ESTIMATE)
+        (void)lz_parse<MODE, 1>(rd, tv, nullptr, nullptr, false, win_lds, maybe, cc);
+    else
+        (void)lz_parse<MODE, 1>(rd, tv, nullptr, (cost_t *)out_u32 + out_off, (flags & 1u) != 0, win_lds, maybe, cc);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) lz_hop_kernel(const RefDesc *__restrict__ refs, const SegDesc *__restrict__ segs, uint32_t n_segs, ChunkPlan pl,
+                                                     uint8_t *__restrict__ out_bytes, uint32_t *__restrict__ out_u32, uint32_t *__restrict__ res_value,
+                                                     uint32_t *__restrict__ res_peak)
+{
+    const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= n_segs)
+        return;
+    const SegDesc &sdm = segs[idx];
+    RefDesc rd;
+    SymViewG tv;
+    load_descs(refs, sdm, rd, tv);
+    const uint64_t out_off = uniform_u64(sdm.out_off);
+    const unsigned long long *maybe = uniform_ptr(sdm.maybe);
+    const uint32_t flags = uniform_u32(sdm.flags), oidx = uniform_u32(sdm.idx);
+    __shared__ __attribute__((aligned(32))) uint8_t s_win[4][WIN_SYMS];
+    uint8_t *win_lds = s_win[threadIdx.x >> 6];
+    const uint32_t j0 = uniform_u32(pl.seg_chunk0[idx]), j1 = uniform_u32(pl.seg_chunk0[idx + 1]);
+    ChunkCtl cc;
+    cc.i0 = 0;
+    cc.i_stop = 0xFFFFFFFFu;
+    cc.log = pl.logs + (size_t)j0 * pl.cap;
+    cc.log_n = pl.log_n + j0;
+    cc.cap = pl.cap;
+    cc.chunk_len = pl.chunk_len;
+    cc.n_chunks = j1 - j0;
+    cc.chunk_out = pl.chunk_out + (size_t)j0 * pl.chunk_stride;
+    cc.chunk_stride = pl.chunk_stride;
+    ParseOut r;
+    if (MODE == MODE_ENCODE)
+        r = lz_parse<MODE, 2>(rd, tv, out_bytes + out_off, nullptr, false, win_lds, nullptr, cc);
+    else if (MODE == MODE_ESTIMATE)
+        r = lz_parse<MODE, 2>(rd, tv, nullptr, nullptr, false, win_lds, maybe, cc);
+    else
+        r = lz_parse<MODE, 2>(rd, tv, nullptr, (cost_t *)out_u32 + out_off, (flags & 1u) != 0, win_lds, maybe, cc);
+    if (lane_id() == 0) {
+        res_value[oidx] = r.value;
+        if (MODE == MODE_ESTIMATE)
+            res_peak[oidx] = r.peak;
+    }
+}
+
+template __global__ void lz_chunk_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, ChunkPlan, uint32_t *);
+template __global__ void lz_chunk_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, ChunkPlan, uint32_t *);
+template __global__ void lz_chunk_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, ChunkPlan, uint32_t *);
+template __global__ void lz_hop_kernel<MODE_ENCODE>(const RefDesc *, const SegDesc *, uint32_t, ChunkPlan, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
+template __global__ void lz_hop_kernel<MODE_ESTIMATE>(const RefDesc *, const SegDesc *, uint32_t, ChunkPlan, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
+template __global__ void lz_hop_kernel<MODE_COSTVEC>(const RefDesc *, const SegDesc *, uint32_t, ChunkPlan, uint8_t *, uint32_t *, uint32_t *, uint32_t *);
 
 // gathers the per-segment deltas (scratch slots) into one contiguous buffer
 __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__restrict__ scratch, const SegDesc *__restrict__ segs,

@@ -307,6 +307,9 @@ def config_cli(args):
             toks = m.group(1).split()
             stages = {toks[i]: float(toks[i + 1]) for i in range(0, len(toks) - 1, 2)}
             stages["inside_device_library"] = float(m.group(2))
+        m = re.search(r"windows (\d+) commit-runs (\d+) revalidated (\d+) windows-cut (\d+)", err)
+        if m:
+            stages["windows"], stages["commit_runs"], stages["revalidated_segments"], stages["windows_cut"] = (int(x) for x in m.groups())
         m = re.findall(r"entropy stage: device ([0-9.e+-]+) MB in ([0-9.e+-]+) s, host ([0-9.e+-]+) MB in ([0-9.e+-]+) s", err)
         if m:
             stages["entropy_device_mb"] = round(sum(float(x[0]) for x in m), 2)

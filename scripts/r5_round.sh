@@ -48,4 +48,13 @@ except Exception as e:
 PY
   tail -5 $OUT/b_bench_one_gpu_2_ranks_serial_prepare.err
 fi
+if [ "$PART" = c ]; then
+  timeout 200 python -m pytest tests/test_gpu_scan.py -m gpu -x -q -k "pack_fasta" > $OUT/c_pack_tests.log 2>&1; tail -3 $OUT/c_pack_tests.log
+  timeout 300 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "not every_launch" > $OUT/c_lz_tests.log 2>&1; tail -15 $OUT/c_lz_tests.log
+  timeout 900 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "every_launch" > $OUT/c_lz_forced_chunks.log 2>&1; tail -25 $OUT/c_lz_forced_chunks.log
+  timeout 300 python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/c_bench_steps10.json 2> $OUT/c_bench_steps10.err; show $OUT/c_bench_steps10.json
+  AGC_HIP_PACK_LOOKBACK=1 timeout 300 python bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/c_bench_lookback.json 2> /dev/null; show $OUT/c_bench_lookback.json
+  timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/c_bench_config_c5slice.json 2> $OUT/c_bench_config_c5slice.err; show $OUT/c_bench_config_c5slice.json
+  timeout 300 python bench.py --config c5twin > $OUT/c_bench_config_c5twin.json 2> /dev/null; show $OUT/c_bench_config_c5twin.json
+fi
 ls $OUT | head -80

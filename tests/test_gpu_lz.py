@@ -325,3 +325,79 @@ def test_packed_references_out_of_a_sample(hip_ctx, oracle):
     for i, r in enumerate(refs):
         stored = oracle.rev_comp(r) if rc[i] else r
         assert np.array_equal(enc[int(eoff[i]):int(eoff[i + 1])], oracle.LZ(stored, mml).encode(texts[i])), i
+
+
+# ---- the parse in chunks (lz_kernels.hip: ChunkCtl; launch_parse picks it for launches of few, long texts) --------------------------
+def _long_cases(oracle):
+    """few, long, diverged texts -- the launches the chunked parse is made for: 2.5 % substitutions with indels, a text whose second
+    half belongs to another reference (the shape of a missing-middle candidate), N runs, a text identical to its reference, a
+    low-complexity reference, a text with a novel insertion of 30 kb (no match end for several chunks)"""
+    rng = np.random.default_rng(515)
+    out = []
+    ra, rb = synth.random_seq(rng, 260_000), synth.random_seq(rng, 240_000)
+    out.append((20, ra, synth.mutate(rng, ra, 0.025, indels=12)))
+    out.append((15, rb, synth.mutate(rng, rb, 0.05, n_runs=6, iupac=5, indels=6)))
+    half = np.concatenate([synth.mutate(rng, ra[:130_000], 0.025), synth.mutate(rng, rb[100_000:220_000], 0.025)])
+    out.append((20, ra, half))
+    out.append((20, rb, half))
+    out.append((20, ra, ra.copy()))
+    unit = synth.random_seq(rng, 7)
+    low = np.tile(unit, 20_000)[:120_000].copy()
+    out.append((17, low, synth.mutate(rng, low, 0.01)))
+    ins = synth.mutate(rng, ra[:200_000], 0.01)
+    out.append((20, ra, np.concatenate([ins[:90_000], synth.random_seq(rng, 30_000), ins[90_000:]])))
+    big = synth.mutate(rng, rb, 0.002)
+    big[50_000:58_000] = 4
+    out.append((24, rb, big))
+    return out
+
+
+def test_chunked_parse_of_few_long_texts(hip_ctx, oracle):
+    """encode, estimate + peak and both cost vectors of launches the library parses in chunks (a wavefront per 4096-symbol chunk,
+    then one per text that joins them at the match ends both parses share) against the oracle's sequential parse"""
+    cases = _long_cases(oracle)
+    for i, (mml, ref, _t) in enumerate(cases):
+        hip_ctx.ref_register(3000 + i, ref, mml)
+    buf, off, ln = _concat(cases)
+    gids = 3000 + np.arange(len(cases))
+    for rc in (None, np.ones(len(cases), np.uint8)):
+        enc, eoff = hip_ctx.lz_encode_batch(buf, gids, off, ln, rc=rc)
+        for i, (mml, ref, text) in enumerate(cases):
+            t = text if rc is None else oracle.rev_comp(text)
+            want = oracle.LZ(ref, mml).encode(t)
+            got = enc[int(eoff[i]):int(eoff[i + 1])]
+            if not np.array_equal(got, want):
+                d = int(np.argmax(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])) if min(got.size, want.size) else 0
+                raise AssertionError(f"case {i} rc={rc is not None}: {got.size} / {want.size} bytes, first difference at {d}: "
+                                     f"{got[max(d - 20, 0):d + 20].tobytes()} / {want[max(d - 20, 0):d + 20].tobytes()}")
+    cost, peak = hip_ctx.lz_estimate_batch(buf, gids, off, ln)
+    for i, (mml, ref, text) in enumerate(cases):
+        want, wpeak = oracle.LZ(ref, mml).estimate(text, want_peak=True)
+        assert (int(cost[i]), int(peak[i])) == (want, wpeak), f"case {i}"
+    for prefix in (0, 1):
+        costs = hip_ctx.lz_cost_vector_batch(buf, gids, off, ln, None, np.full(len(cases), prefix, np.uint8))
+        p = 0
+        for i, (mml, ref, text) in enumerate(cases):
+            want = oracle.LZ(ref, mml).cost_vector(text, prefix)
+            got = costs[p:p + text.size]
+            if not np.array_equal(got, want):
+                d = int(np.argmax(got != want))
+                raise AssertionError(f"case {i} prefix={prefix}: first difference at {d}: {got[max(d - 8, 0):d + 8]} / {want[max(d - 8, 0):d + 8]}")
+            p += text.size
+
+
+@pytest.mark.parametrize("chunk", [64, 300, 1024])
+def test_lz_suite_with_every_launch_parsed_in_chunks(chunk):
+    """AGC_HIP_LZ_CHUNK=<symbols> forces the chunked parse onto every launch the host holds descriptors of: this file's other tests
+    and the archive tests (one-splitter estimates, missing-middle cost vectors, encodes of every collection) run again that way,
+    with chunks from 64 symbols (a chunk boundary every few tokens) to 1024"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AGC_HIP_LZ_CHUNK=str(chunk))
+    sel = ["tests/test_gpu_lz.py", "-k", "not every_launch_parsed_in_chunks"]
+    if chunk == 300:
+        sel = ["tests/test_gpu_lz.py", "tests/test_gpu_archive.py", "-k", "not every_launch_parsed_in_chunks and not full_size"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q"] + sel, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:]
