@@ -1695,8 +1695,15 @@ int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u
     if (b && !n_dev && n && forced != 0 && b->segs.size() == n) {
         if (forced > 0)
             chunk_len = (uint32_t)std::max(64, forced);
-        else if (n < 1024 && b->segs[0].text.len >= 16384) // (longest first)
-            chunk_len = 4096;
+        else if (b->segs[0].text.len >= 16384) { // (longest first)
+            // worth it when the longest text's chain outlasts the launch's work spread over the chip (~6 k wavefronts in flight):
+            // the diverged collections' few long texts, not the 3 000 cost-vector parses of a human sample
+            uint64_t total = 0;
+            for (const SegDesc &sd : b->segs)
+                total += sd.text.len;
+            if ((uint64_t)b->segs[0].text.len * 6144 > 4 * total)
+                chunk_len = 4096;
+        }
     }
     if (chunk_len) {
         agc_hip_ctx::ChunkBufs &cb = c->chunk_bufs[lane];

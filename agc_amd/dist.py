@@ -103,7 +103,7 @@ class DistCompressor:
 
     def _next_cap(self, msg_bytes):
         """capacity of the NEXT head message, from the size of this one: every rank sees every size, so every rank derives the same"""
-        want = (msg_bytes * 3 // 2 + (1 << 20) - 1) >> 20 << 20
+        want = (msg_bytes * 9 // 8 + (1 << 18) - 1) >> 18 << 18  # (heads of consecutive samples differ by a few percent)
         return min(self.MSG_CAP_MAX, max(self.MSG_CAP0, want))
 
     def _set_cap(self, cap):
@@ -267,8 +267,6 @@ class DistCompressor:
             my_off = (off[a_:b_ + 1] - off[a_]).astype(np.uint64)
             my_src = src[int(off[a_]):int(off[b_])]
             d_mine = torch.from_numpy(my_src).to(self.hbm) if (dev_path and my_n) else None
-            for w_ in sends:
-                w_.wait()
         elif my_n:
             d_o = torch.empty(my_n + 1, dtype=torch.int64, device=self.comm)
             d_x = torch.empty(my_bytes, dtype=torch.uint8, device=self.comm)
@@ -289,6 +287,9 @@ class DistCompressor:
             sizes = np.diff(foff.astype(np.int64))
         else:
             frames, sizes = np.zeros(0, np.uint8), np.zeros(0, np.int64)
+        if writer:
+            for w_ in sends:  # (the other ranks' packs left while this rank's own share was being compressed)
+                w_.wait()
         # ---- the frames back to the writer, as long as they are (sizes first: the writer knows every rank's pack count)
         if writer:
             all_sizes, all_frames = [None] * W, [None] * W

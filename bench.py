@@ -545,6 +545,7 @@ def main():
     sample_off = [off] * n_steps    # the contigs' symbol offsets as the pack returns them
     fasta = []                      # per sample: (raw bytes in HBM, n_raw, raw_begin, raw_end, (words, index, esc))
     pack_pending = {}
+    pack_ms_each = []
     AS_BUILT_BPS["pack"] = 1.0 + 1.0 / args.fasta_width + 0.25
     for s in range(n_steps):
         codes = synth_dev.make_sample(ref, tot, args.div, shard.sample_seed(1000, s, rank, world), dev)
@@ -568,6 +569,7 @@ def main():
         if samples[s] is None:
             start_pack(s)
             pk, keep, o_ = hctx.pack_fasta_end(pack_pending.pop(s))
+            pack_ms_each.append(round(hctx.timing_get()["pack"][0], 3))  # (cumulative while timing is on: differences = each pack)
             if not np.array_equal(o_, np.asarray(off, np.uint64)):
                 raise SystemExit(f"bench.py: the pack of sample {s} returned other contig offsets than the generator's")
             samples[s], sample_off[s] = (pk, keep), o_
@@ -694,6 +696,7 @@ def main():
                        "setup_not_timed": f"determine_splitters ({'positional shortcut' if args.positional_splitters else 'GPU: enumerate + radix sort + singletons'}): "
                                           f"{t_spl:.2f} s; reference genome as first sample (mints ~{int(st0['new_groups'])} groups): {t_ref:.2f} s",
                        "steps_only_ms": round(t_steps / max(args.steps, 1) * 1e3, 3),
+                       "pack_ms_cumulative_after_each_pack": pack_ms_each[-(args.steps + 2):],
                        **({"archive_sha256": _sha256_file(archive_path), "archive_bytes": os.path.getsize(archive_path)} if archive_path else {}),
                        "close_ms": round((elapsed - t_steps) * 1e3, 1),
                        "segments_per_step": int(per(stats["segments"])), "lz_encoded_per_step": int(per(stats["lz_encoded"])),

@@ -57,4 +57,22 @@ if [ "$PART" = c ]; then
   timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/c_bench_config_c5slice.json 2> $OUT/c_bench_config_c5slice.err; show $OUT/c_bench_config_c5slice.json
   timeout 300 python bench.py --config c5twin > $OUT/c_bench_config_c5twin.json 2> /dev/null; show $OUT/c_bench_config_c5twin.json
 fi
+if [ "$PART" = d ]; then
+  timeout 300 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "not every_launch" > $OUT/d_lz_tests.log 2>&1; tail -15 $OUT/d_lz_tests.log
+  timeout 1200 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "every_launch" > $OUT/d_lz_forced_chunks.log 2>&1; tail -25 $OUT/d_lz_forced_chunks.log
+  timeout 200 python scripts/pack_alone.py 3.0 0 > $OUT/d_pack_alone.log 2>&1; tail -6 $OUT/d_pack_alone.log
+  AGC_HIP_PACK_LOOKBACK=1 timeout 200 python scripts/pack_alone.py 3.0 0 >> $OUT/d_pack_alone.log 2>&1; tail -6 $OUT/d_pack_alone.log
+  timeout 300 python scripts/pack_alone.py 3.0 120 >> $OUT/d_pack_alone.log 2>&1; tail -6 $OUT/d_pack_alone.log
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/d_bench_driver_cmd_no_cpu_baseline.json 2> $OUT/d_bench_driver_cmd.err; show $OUT/d_bench_driver_cmd_no_cpu_baseline.json
+  python - $OUT/d_bench_driver_cmd_no_cpu_baseline.json <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    v = d["config"].get("pack_ms_cumulative_after_each_pack") or []
+    print("pack ms each:", [round(b - a, 2) for a, b in zip([0] + v[:-1], v)])
+except Exception as e:
+    print("no line", e)
+PY
+  timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/d_bench_config_c5slice.json 2> $OUT/d_bench_config_c5slice.err; show $OUT/d_bench_config_c5slice.json
+fi
 ls $OUT | head -80

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+from agc_amd import synth
 from tests.cases import lz_cases
 
 pytestmark = pytest.mark.gpu
