@@ -1738,18 +1738,62 @@ int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u
             pl.logs = (ChunkState *)cb.d_logs.p;
             pl.log_n = (uint32_t *)cb.d_logn.p;
             pl.chunk_out = (uint8_t *)cb.d_out.p;
+            static const bool chunk_log = getenv("AGC_HIP_CHUNK_LOG") != nullptr; // (a measuring aid: every chunked launch on stderr)
+            hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+            if (chunk_log)
+                for (auto &e : ev)
+                    (void)hipEventCreate(&e);
             {
                 KTimer t(c, lane ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+                if (chunk_log)
+                    (void)hipEventRecord(ev[0], st);
                 hipLaunchKernelGGL(lz_chunk_kernel<MODE>, dim3((pl.n_jobs + 3) / 4), dim3(256), 0, st, d_refs, d_segs, pl, out_u32);
+                if (chunk_log)
+                    (void)hipEventRecord(ev[1], st);
                 hipLaunchKernelGGL(lz_hop_kernel<MODE>, dim3(grid), dim3(256), 0, st, d_refs, d_segs, n, pl, out_bytes, out_u32, d_resv, d_resp);
+                if (chunk_log)
+                    (void)hipEventRecord(ev[2], st);
             }
             HIPCHK(c, hipGetLastError());
+            if (chunk_log) {
+                (void)hipEventSynchronize(ev[2]);
+                float a = 0, b2 = 0;
+                (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+                (void)hipEventElapsedTime(&b2, ev[1], ev[2]);
+                uint64_t total = 0;
+                for (const SegDesc &sd : b->segs)
+                    total += sd.text.len;
+                fprintf(stderr, "    chunked launch mode %d: %u texts, %.2f Mb, longest %u, %u chunks of %u: chunk kernel %.3f ms, hop kernel %.3f ms\n", MODE, n, total / 1e6,
+                        (uint32_t)b->segs[0].text.len, pl.n_jobs, chunk_len, a, b2);
+                for (auto &e : ev)
+                    (void)hipEventDestroy(e);
+            }
             return AGC_HIP_OK;
         }
     }
+    static const bool chunk_log2 = getenv("AGC_HIP_CHUNK_LOG") != nullptr;
+    hipEvent_t pe[2] = {nullptr, nullptr};
+    if (chunk_log2 && b)
+        for (auto &e : pe)
+            (void)hipEventCreate(&e);
     {
         KTimer t(c, lane ? -1 : MODE == MODE_ENCODE ? AGC_HIP_K_ENCODE : MODE == MODE_ESTIMATE ? AGC_HIP_K_ESTIMATE : AGC_HIP_K_COSTVEC);
+        if (pe[0])
+            (void)hipEventRecord(pe[0], st);
         hipLaunchKernelGGL(lz_parse_kernel<MODE>, dim3(grid), dim3(256), 0, st, d_refs, d_segs, n, out_bytes, out_u32, d_resv, d_resp, n_dev);
+        if (pe[0])
+            (void)hipEventRecord(pe[1], st);
+    }
+    if (pe[0]) {
+        (void)hipEventSynchronize(pe[1]);
+        float a = 0;
+        (void)hipEventElapsedTime(&a, pe[0], pe[1]);
+        uint64_t total = 0;
+        for (const SegDesc &sd : b->segs)
+            total += sd.text.len;
+        fprintf(stderr, "    whole-text launch mode %d: %u texts, %.2f Mb, longest %u: %.3f ms\n", MODE, n, total / 1e6, n ? (uint32_t)b->segs[0].text.len : 0u, a);
+        for (auto &e : pe)
+            (void)hipEventDestroy(e);
     }
     HIPCHK(c, hipGetLastError());
     return AGC_HIP_OK;

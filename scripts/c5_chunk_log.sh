@@ -1,0 +1,18 @@
+#!/bin/bash
+# every LZ launch of a small slice of configs[4] on stderr (AGC_HIP_CHUNK_LOG): texts, sizes, chunked or not, kernel times
+OUT=gpurun_out/r5; mkdir -p $OUT
+python - <<'PY'
+import os, sys, subprocess, numpy as np
+sys.path.insert(0, os.getcwd())
+from agc_amd import synth
+td = "/dev/shm/c5log"; os.makedirs(td, exist_ok=True)
+rng = np.random.default_rng(5)
+anc = synth.random_seq(rng, 5_000_000)
+files = []
+for i in range(10):
+    fn = os.path.join(td, f"g{i}.fa"); synth.to_fasta(fn, [synth.mutate(rng, anc, 0.025)], [f"chr{i}"]); files.append(fn)
+env = dict(os.environ, AGC_HIP_CHUNK_LOG="1")
+r = subprocess.run(["agc_amd/bin/agc_amd", "create", "-a", "-v", "1", "-t", "16", "-o", td + "/o.agc"] + files, capture_output=True, text=True, env=env)
+open("gpurun_out/r5/e_c5_chunk_log.txt", "w").write(r.stderr)
+PY
+grep -c "launch mode" $OUT/e_c5_chunk_log.txt; grep "launch mode" $OUT/e_c5_chunk_log.txt | sort -t: -k3 | awk '{print}' | head -60; grep "^bases\|^seconds" $OUT/e_c5_chunk_log.txt
