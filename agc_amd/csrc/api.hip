@@ -1400,16 +1400,21 @@ static int ref_register_impl(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_
     uint8_t *tbase = nullptr;
     CHK(arena_alloc(c, tab_bytes, &tbase));
     HIPCHK(c, hipMemsetAsync(tbase, 0xFF, tab_bytes, c->stream));
-    // key filters (KEY_BLOOM_WORDS x 8 bytes each, zeroed; the insert kernel sets the bits)
+    // key filters (two per reference, sized by its length: dev_common.h; zeroed; the insert kernel sets the bits)
     uint8_t *bbase = nullptr;
-    const size_t bloom_bytes = (size_t)n_refs * KEY_BLOOM_WORDS * 8;
+    std::vector<size_t> boff(n_refs);
+    size_t bloom_bytes = 0;
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        boff[i] = bloom_bytes;
+        bloom_bytes += (size_t)2 * key_bloom_half_words(key_bloom_shift(jobs[i].ref_size)) * 8;
+    }
     CHK(arena_alloc(c, bloom_bytes, &bbase));
     HIPCHK(c, hipMemsetAsync(bbase, 0, bloom_bytes, c->stream));
     // references that hold a symbol outside ACGT: escape index + one byte per symbol for the blocks that need it
     std::vector<EscJob> ejobs;
     for (uint32_t i = 0; i < n_refs; ++i) {
         jobs[i].table = tbase + toff[i];
-        jobs[i].bloom = (unsigned long long *)(bbase + (size_t)i * KEY_BLOOM_WORDS * 8);
+        jobs[i].bloom = (unsigned long long *)(bbase + boff[i]);
         if (flags[i]) {
             const uint32_t nb = (h_len[i] + PACK_BLOCK - 1) / PACK_BLOCK;
             uint8_t *eb = nullptr;
@@ -1656,7 +1661,7 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         if (mode != MODE_ENCODE && rd.bloom && h_len[i] > 4 * WAVE) { // (short texts: not worth a block)
             s.maybe = (const unsigned long long *)c->d_maybe.p + moff[i];
             for (uint32_t ch = 0; ch < h_len[i]; ch += FILTER_CHUNK)
-                fjobs.push_back({s.text, rd.bloom, (unsigned long long *)c->d_maybe.p + moff[i], rd.key_len, ch});
+                fjobs.push_back({s.text, rd.bloom, (unsigned long long *)c->d_maybe.p + moff[i], rd.key_len, ch, key_bloom_shift(rd.ref_size), 0u});
         }
     }
     if (!fjobs.empty()) {
@@ -1767,6 +1772,14 @@ int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u
                         (uint32_t)b->segs[0].text.len, pl.n_jobs, chunk_len, a, b2);
                 for (auto &e : ev)
                     (void)hipEventDestroy(e);
+                if (MODE != MODE_ESTIMATE) { // (the hop parser left its counters where an estimate's peak goes)
+                    std::vector<uint32_t> dbg(n);
+                    (void)hipMemcpy(dbg.data(), d_resp, (size_t)n * 4, hipMemcpyDeviceToHost);
+                    for (uint32_t i = 0; i < n && i < 12; ++i)
+                        fprintf(stderr, "        text %u: %u symbols, %u chunks, ref %u: %u chunks taken over, %u matches parsed by the hop wavefront\n", i,
+                                (uint32_t)b->segs[i].text.len, ((uint32_t)b->segs[i].text.len + chunk_len - 1) / chunk_len, c->refs[b->segs[i].ref_slot].ref_size,
+                                dbg[b->segs[i].idx] >> 16, dbg[b->segs[i].idx] & 0xFFFFu);
+                }
             }
             return AGC_HIP_OK;
         }

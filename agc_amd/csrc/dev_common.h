@@ -28,24 +28,37 @@ constexpr uint32_t MIN_NRUN_LEN = 4;     // lz_diff.h:36
 // Two such filters with independent hashes, KEY_BLOOM_HALF words each (2 x 32 KiB): a key passes when both hold it.  One filter
 // lets 0.4 % of the foreign keys through for the 15 k keys of a 60 kb reference -- 240 exact steps (a table row from HBM each) in
 // the 60 kb of a missing-middle segment that belong to the OTHER reference, more than its matching half costs; two: 0.002 %.
+// Round 5: the filters grow with the reference -- KEY_BLOOM_HALF words each up to 16 k keys (a 60 kb reference: what a human
+// collection has, and what fits the LDS of key_filter_kernel), then the next power of two of keys / 4 words (>= 16 bits per key): the
+// 600 kb references of a diverged bacterial collection filled the fixed-size filters to 82 % and 30 % of the foreign positions
+// passed both -- a foreign stretch then costs an exact step every third position, tens of milliseconds per text.
 constexpr uint32_t KEY_BLOOM_HALF = 4096;
-constexpr uint32_t KEY_BLOOM_WORDS = 2 * KEY_BLOOM_HALF;
-__host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t &word, uint64_t &mask)
+constexpr uint32_t KEY_BLOOM_SHIFT0 = 20; // word index = 32 - shift bits of the hash: 12 bits for KEY_BLOOM_HALF words
+__host__ __device__ inline uint32_t key_bloom_shift(uint32_t ref_size)
+{
+    const uint32_t keys = ref_size / HASHING_STEP + 1;
+    uint32_t sh = KEY_BLOOM_SHIFT0;
+    while (sh > 8 && (1u << (32 - sh)) < keys / 4)
+        --sh;
+    return sh;
+}
+__host__ __device__ inline uint32_t key_bloom_half_words(uint32_t shift) { return 1u << (32 - shift); }
+__host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t shift, uint32_t &word, uint64_t &mask)
 {
     const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
     uint32_t h1 = (a ^ (b * 0x9E3779B1u)) * 0x85EBCA6Bu;
     h1 ^= h1 >> 15;
     const uint32_t h2 = h1 * 0xC2B2AE35u;
-    word = h1 >> 20; // 12 bits
+    word = h1 >> shift;
     mask = (1ULL << (h2 >> 26)) | (1ULL << ((h2 >> 20) & 63)) | (1ULL << ((h2 >> 14) & 63));
 }
-__host__ __device__ inline void key_bloom_slot2(uint64_t key, uint32_t &word, uint64_t &mask)
+__host__ __device__ inline void key_bloom_slot2(uint64_t key, uint32_t shift, uint32_t &word, uint64_t &mask)
 {
     const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
     uint32_t h1 = ((a * 0xCC9E2D51u) ^ (b + 0x7F4A7C15u)) * 0x1B873593u;
     h1 ^= h1 >> 13;
     const uint32_t h2 = h1 * 0x27D4EB2Fu;
-    word = KEY_BLOOM_HALF + (h1 >> 20);
+    word = key_bloom_half_words(shift) + (h1 >> shift);
     mask = (1ULL << (h2 >> 26)) | (1ULL << ((h2 >> 19) & 63)) | (1ULL << ((h2 >> 12) & 63));
 }
 
@@ -59,7 +72,7 @@ struct RefDesc {
     const int32_t *esc_index;
     const uint8_t *esc_bytes;
     const void *table;    // ht_mask+1 entries
-    const unsigned long long *bloom; // KEY_BLOOM_WORDS words (nullptr: none)
+    const unsigned long long *bloom; // two filters of key_bloom_half_words(key_bloom_shift(ref_size)) words each (nullptr: none)
     uint32_t ref_size;
     uint32_t ht_mask;
     uint32_t key_len;

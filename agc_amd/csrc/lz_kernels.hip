@@ -414,6 +414,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
     uint32_t est = 0, peak = 0;
     const uint32_t i_stop = ROLE == 1 ? cc.i_stop : 0xFFFFFFFFu; // a chunk parser writes no cost at or beyond its chunk's end
     uint32_t n_log = 0;                                          // ROLE 1: entries logged
+    uint32_t dbg_hops = 0, dbg_own = 0;                          // ROLE 2: chunks taken over / matches parsed by this wavefront itself
 #define PUT_COST(idx, v)                                                                           \
     do {                                                                                           \
         if (ROLE != 1 || (idx) < i_stop)                                                           \
@@ -481,6 +482,7 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                     from.o = bcast_u32(e.o, l);
                     from.est = bcast_u32(e.est, l);
                     hop(x, from);
+                    ++dbg_hops;
                 }
                 return;
             }
@@ -497,8 +499,10 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
                 cc.log[n_log] = ChunkState{i, pred_pos, MODE == MODE_ESTIMATE ? peak : o, est};    \
             ++n_log;                                                                               \
         }                                                                                          \
-        if (ROLE == 2)                                                                             \
+        if (ROLE == 2) {                                                                           \
+            ++dbg_own;                                                                             \
             try_hop();                                                                             \
+        }                                                                                          \
     } while (0)
     PH_DECL
     while (i + key_len < n && (ROLE != 1 || i < i_stop)) {
@@ -1029,6 +1033,8 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
         o += cnt;
     }
     res.value = o;
+    if (ROLE == 2)
+        res.peak = (dbg_hops << 16) | (dbg_own < 65535u ? dbg_own : 65535u); // (cost vectors / encode: a debugging aid, AGC_HIP_CHUNK_LOG)
     return res;
 #undef PUT_COST
 #undef LOG_STATE
@@ -1197,8 +1203,7 @@ __global__ void __launch_bounds__(256) lz_hop_kernel(const RefDesc *__restrict__
         r = lz_parse<MODE, 2>(rd, tv, nullptr, (cost_t *)out_u32 + out_off, (flags & 1u) != 0, win_lds, maybe, cc);
     if (lane_id() == 0) {
         res_value[oidx] = r.value;
-        if (MODE == MODE_ESTIMATE)
-            res_peak[oidx] = r.peak;
+        res_peak[oidx] = r.peak;
     }
 }
 
@@ -1240,6 +1245,8 @@ struct FilterJob {
     unsigned long long *out;   // (len + 63) / 64 words
     uint32_t key_len;
     uint32_t chunk;            // first position of this block's chunk
+    uint32_t bloom_shift;      // key_bloom_shift of the reference
+    uint32_t pad;
 };
 
 template <class V> __device__ __forceinline__ void pack16(const V &tv, uint32_t pos, uint32_t &P, uint32_t &I)
@@ -1269,9 +1276,13 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
     g_u64 *bloom = (g_u64 *)jb.bloom;
     unsigned long long __attribute__((address_space(1))) *out = (unsigned long long __attribute__((address_space(1))) *)jb.out;
     // (the first filter in LDS; the second one is consulted for the 0.4 % of foreign keys that pass it, from HBM / L2)
+    // (a filter of more than KEY_BLOOM_HALF words -- a reference of more than 64 k symbols -- is read where it lies: L2)
     __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[KEY_BLOOM_HALF];
-    for (uint32_t t = threadIdx.x; t < KEY_BLOOM_HALF; t += blockDim.x)
-        s_bloom[t] = bloom[t];
+    const uint32_t bshift = jb.bloom_shift;
+    const bool in_lds = bshift == KEY_BLOOM_SHIFT0;
+    if (in_lds)
+        for (uint32_t t = threadIdx.x; t < KEY_BLOOM_HALF; t += blockDim.x)
+            s_bloom[t] = bloom[t];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t k = jb.key_len;
@@ -1304,10 +1315,10 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
             const bool bad = ((uint32_t)(inv >> (48 - j - k)) & imask) != 0;
             uint32_t bw;
             uint64_t bm;
-            key_bloom_slot(key, bw, bm);
-            bool in_f = (s_bloom[bw] & bm) == bm;
+            key_bloom_slot(key, bshift, bw, bm);
+            bool in_f = ((in_lds ? s_bloom[bw] : bloom[bw]) & bm) == bm;
             if (in_f && !bad) { // (0.4 % of the foreign keys get this far)
-                key_bloom_slot2(key, bw, bm);
+                key_bloom_slot2(key, bshift, bw, bm);
                 in_f = (bloom[bw] & bm) == bm;
             }
             const bool past = !(pos + j + k < len);
@@ -1446,9 +1457,10 @@ __device__ void idx_insert_one(const IdxBuild &jb, const SymView &rv, uint32_t t
     if (jb.bloom) {
         uint32_t bw;
         uint64_t bm;
-        key_bloom_slot(x, bw, bm);
+        const uint32_t bshift = key_bloom_shift(jb.ref_size);
+        key_bloom_slot(x, bshift, bw, bm);
         atomicOr(&jb.bloom[bw], (unsigned long long)bm);
-        key_bloom_slot2(x, bw, bm);
+        key_bloom_slot2(x, bshift, bw, bm);
         atomicOr(&jb.bloom[bw], (unsigned long long)bm);
     }
     const E fp = FPBITS == 16 ? (E)(h >> 48) : (E)(h >> 32);

@@ -15,4 +15,4 @@ env = dict(os.environ, AGC_HIP_CHUNK_LOG="1")
 r = subprocess.run(["agc_amd/bin/agc_amd", "create", "-a", "-v", "1", "-t", "16", "-o", td + "/o.agc"] + files, capture_output=True, text=True, env=env)
 open("gpurun_out/r5/e_c5_chunk_log.txt", "w").write(r.stderr)
 PY
-grep -c "launch mode" $OUT/e_c5_chunk_log.txt; grep "launch mode" $OUT/e_c5_chunk_log.txt | sort -t: -k3 | awk '{print}' | head -60; grep "^bases\|^seconds" $OUT/e_c5_chunk_log.txt
+grep -c "launch mode" $OUT/e_c5_chunk_log.txt; grep -A12 "launch mode 2" $OUT/e_c5_chunk_log.txt | head -150; grep "^bases\|^seconds" $OUT/e_c5_chunk_log.txt

@@ -75,4 +75,12 @@ except Exception as e:
 PY
   timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/d_bench_config_c5slice.json 2> $OUT/d_bench_config_c5slice.err; show $OUT/d_bench_config_c5slice.json
 fi
+if [ "$PART" = e ]; then
+  timeout 300 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "not every_launch" > $OUT/e_lz_tests.log 2>&1; tail -5 $OUT/e_lz_tests.log
+  timeout 600 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "every_launch and 300" > $OUT/e_lz_forced_chunks.log 2>&1; tail -5 $OUT/e_lz_forced_chunks.log
+  bash scripts/c5_chunk_log.sh > $OUT/e_c5_chunk_log_summary.txt 2>&1; grep "launch mode" $OUT/e_c5_chunk_log.txt | awk '{print $3, $NF, $(NF-1), $(NF-5), $(NF-4)}' | sort | uniq -c | sort -k1nr | head -5; grep "launch mode [12]" $OUT/e_c5_chunk_log.txt | sed 's/.*chunk kernel/chunk kernel/' | sort -k7n | tail -5
+  timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/e_bench_config_c5slice.json 2> $OUT/e_bench_config_c5slice.err; show $OUT/e_bench_config_c5slice.json
+  timeout 300 python bench.py --config c5twin > $OUT/e_bench_config_c5twin.json 2> /dev/null; show $OUT/e_bench_config_c5twin.json
+  timeout 300 python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/e_bench_steps10.json 2> /dev/null; show $OUT/e_bench_steps10.json
+fi
 ls $OUT | head -80
