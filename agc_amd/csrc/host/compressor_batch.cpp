@@ -1019,7 +1019,9 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
     segs.resize(n_segs);
     // the encode of the segments whose group the table knew is launched on the device's second lane when its deltas can be
     // collected beside the next sample (bookkeeping thread); otherwise the commit encodes as before
-    const bool enc = async_encode && book_can_async(1) && b.base_owned && ctgs.back().sample_idx == 0;
+    // (... and when the sample is large enough to fill the GPU with one wavefront per segment: the few dozen segments of a bacterial
+    // genome are encoded from the host's descriptors at commit time instead, where the library parses them in chunks)
+    const bool enc = async_encode && book_can_async(1) && b.base_owned && ctgs.back().sample_idx == 0 && n_segs >= dev_encode_min;
     std::vector<uint8_t> is_known(enc ? n_segs : 0, 0);
     {
         const size_t n_chunks = n_segs >= par_min ? std::min<size_t>(std::max<size_t>(n_segs / 2048, 2), (size_t)pool->size() * 4) : 1;

@@ -934,6 +934,7 @@ struct CAGCCompressor::Impl {
     };
     bool stage_scan(BatchState &b);
     int stage_scan_dev(BatchState &b);
+    uint32_t dev_encode_min = 2048;    // segments a sample needs for the device-launched whole-sample encode (AGC_AMD_DEV_ENCODE_MIN: tests)
     bool use_dev_segments(const BatchState &b) const;
     // adaptive mode with windows of several registrations: only where the device delivers the segments (the cut of a window at
     // the registration that brings new splitters lives there)

@@ -99,7 +99,8 @@ __device__ __forceinline__ PfChunk pf_chunk(const PackFastaArgs &a, uint64_t p, 
             if (p + j < a.n_raw)
                 w[j >> 2] |= (uint32_t)a.raw[p + j] << (8 * (j & 3));
     }
-    uint32_t keep = 0, bits = 0, bad = 0;
+    uint32_t keep = 0, bits = 0, bad = 0, odd = 0;
+    uint32_t diffs[4];
 #pragma unroll
     for (uint32_t q = 0; q < 4; ++q) {
         const uint32_t x = w[q];
@@ -112,9 +113,17 @@ __device__ __forceinline__ PfChunk pf_chunk(const PackFastaArgs &a, uint64_t p, 
         // is it one of the four letters?  the letter the two bits stand for, against the byte with its case bit cleared
         const uint32_t b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u;
         const uint32_t expect = 0x41414141u + 2u * b0 + 0x13u * b1 - 0x0Fu * (b0 & b1);
-        const uint32_t diff = (x & 0xDFDFDFDFu) ^ expect;
-        const uint32_t nz = ((diff | ((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u; // 0x01 per byte that differs
-        bad |= ((((nz & g) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+        diffs[q] = ((x & 0xDFDFDFDFu) ^ expect) & ((g << 8) - g);      // (only bytes >= 64 count: 0xFF per such byte)
+        odd |= diffs[q];
+    }
+    // which bytes they are is worked out only when some lane of the wavefront met one (N runs, IUPAC codes: rare)
+    if (__ballot(odd != 0)) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t diff = diffs[q];
+            const uint32_t nz = ((diff | ((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u; // 0x01 per byte that differs
+            bad |= (((nz * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+        }
     }
     keep &= pf_range_mask(a, p, cb, ce, r_first);
     bad &= keep;
@@ -298,9 +307,14 @@ template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kerne
     for (uint32_t j = 0; j < 4; ++j) {
         const uint64_t p = t_begin + (uint64_t)wv * 4096 + j * 1024 + lane * 16;
         ch[j] = pf_chunk(a, p, cb, ce, r_first, w[j]);
-        const uint32_t incl = pf_wave_incl(ch[j].cnt);
-        rank[j] = wave_tot + incl - ch[j].cnt;
-        wave_tot += (uint32_t)__shfl((int)incl, 63);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j += 2) { // (two rows per scan: a row's counts add up to 1024 at most, 16 bits each)
+        const uint32_t incl = pf_wave_incl(ch[j].cnt | (ch[j + 1].cnt << 16));
+        const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+        rank[j] = wave_tot + (incl & 0xFFFFu) - ch[j].cnt;
+        rank[j + 1] = wave_tot + (tot & 0xFFFFu) + (incl >> 16) - ch[j + 1].cnt;
+        wave_tot += (tot & 0xFFFFu) + (tot >> 16);
     }
     if (lane == 0)
         s_wsum[wv] = wave_tot;

@@ -35,7 +35,14 @@ def main():
         d = tempfile.mkdtemp(prefix=f"fuzz{seed}_")
         case = fuzz.make_case(seed, os.path.join(d, "in"), big=a.big, many=a.many)
         want, e1 = fuzz.run_case(ref, case, d, "ref", threads="1", env=env)
-        got, e2 = fuzz.run_case(cli, case, d, "amd")
+        # (every third seed: the whole-sample encode launched from the device's descriptors for every sample however small, every
+        # registration a window of its own -- the path 3 Gbp samples take; every third: the LZ parses in 300-symbol chunks)
+        amd_env = None
+        if seed % 3 == 1:
+            amd_env = dict(os.environ, AGC_AMD_DEV_ENCODE_MIN="0", AGC_AMD_WINDOW_MAX="1")
+        elif seed % 3 == 2:
+            amd_env = dict(os.environ, AGC_HIP_LZ_CHUNK="300")
+        got, e2 = fuzz.run_case(cli, case, d, "amd", env=amd_env)
         # the reference itself dies on some inputs (e.g. `append -c` onto a partly filled batch): compare up to there
         n_cmp = len(want) - 1 if want and want[-1] is None else len(want)
         crashed = n_cmp != len(want)

@@ -83,4 +83,11 @@ if [ "$PART" = e ]; then
   timeout 300 python bench.py --config c5twin > $OUT/e_bench_config_c5twin.json 2> /dev/null; show $OUT/e_bench_config_c5twin.json
   timeout 300 python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/e_bench_steps10.json 2> /dev/null; show $OUT/e_bench_steps10.json
 fi
+if [ "$PART" = f ]; then
+  timeout 300 python -m pytest tests/test_gpu_scan.py tests/test_gpu_archive.py -m gpu -x -q -k "pack_fasta or small_samples_too" > $OUT/f_tests.log 2>&1; tail -4 $OUT/f_tests.log
+  timeout 200 python scripts/pack_alone.py 3.0 0 > $OUT/f_pack_alone.log 2>&1; tail -3 $OUT/f_pack_alone.log
+  timeout 300 python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/f_bench_steps10.json 2> /dev/null; show $OUT/f_bench_steps10.json
+  timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/f_bench_config_c5slice.json 2> $OUT/f_bench_config_c5slice.err; show $OUT/f_bench_config_c5slice.json
+  for cfg in c5twin c1; do timeout 300 python bench.py --config $cfg > $OUT/f_bench_config_$cfg.json 2> /dev/null; show $OUT/f_bench_config_$cfg.json; done
+fi
 ls $OUT | head -80

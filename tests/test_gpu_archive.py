@@ -203,6 +203,23 @@ def test_baseline_config1_full_size(tmp_path, concat):
         pytest.fail("\n".join(agc_container.diff(want, got)))
 
 
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_adaptive", "syn_c5_twin", "syn_c3_twin", "syn_viral"])
+def test_whole_sample_encode_from_the_device_descriptors_for_small_samples_too(name, tmp_path, monkeypatch):
+    """AGC_AMD_DEV_ENCODE_MIN=0 + AGC_AMD_WINDOW_MAX=1: every sample, however small, has its encode launched from the descriptors
+    the device made (agc_hip_segments_encode_known) and collected by the bookkeeping thread -- the path of the 3 Gbp samples, on
+    the real kernels; by default small samples are encoded from the host's descriptors at commit time"""
+    from agc_amd import build
+    build.build_host()
+    monkeypatch.setenv("AGC_AMD_DEV_ENCODE_MIN", "0")
+    monkeypatch.setenv("AGC_AMD_WINDOW_MAX", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "amd.agc")
+    r = subprocess.run([AGC_AMD, "create"] + args + ["-t", "8", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    assert os.path.exists(out), r.stderr[-2000:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"], r.stderr[-1500:]
+
+
 # sha256 / size of the archive the reference CLI (oracle/_ref/agc, libzstd 1.4.9) wrote for BASELINE configs[2] at FULL size --
 # the seeded 3 Gbp GRCh38-shaped reference + ONE 3 Gbp sample at d = 1e-3, -k 31 -l 15 -b 100 -- recorded by
 # scripts/c3_full_identity.py on the GPU box (profiles/r4/c3_full_size_identity_1_sample_against_reference_cli_run.log: 256 s of

@@ -186,6 +186,19 @@ def test_switch_combinations_keep_the_archive(cli, name, env, tmp_path, monkeypa
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_adaptive", "syn_c5_twin", "syn_c3_twin"])
+def test_whole_sample_encode_from_the_device_descriptors_for_small_samples_too(cli, name, tmp_path, monkeypatch):
+    """AGC_AMD_DEV_ENCODE_MIN=0 + AGC_AMD_WINDOW_MAX=1: every sample, however few segments it has, takes the path the 3 Gbp samples
+    take -- its encode launched from the descriptors the device made, collected by the bookkeeping thread (by default samples of
+    fewer than 2048 segments are encoded from the host's descriptors at commit time, where the library can parse in chunks)"""
+    monkeypatch.setenv("AGC_AMD_DEV_ENCODE_MIN", "0")
+    monkeypatch.setenv("AGC_AMD_WINDOW_MAX", "1")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
 def test_producer_tag_changes_one_stream_only(cli, tmp_path, monkeypatch):
     """AGC_AMD_PRODUCER_TAG=1: an honest producer string in file_type_info -- the archive differs from the reference's, its
     samples do not"""
