@@ -91,8 +91,8 @@ def host_cpus():
     return n
 
 
-PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r4", "r3"))
-                    if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r4", "pmc_summary.csv"))
+PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r5", "r4", "r3"))
+                    if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r5", "pmc_summary.csv"))
 KERNEL_SYMBOL = {"scan": "agc::scan_packed_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
                  "costvec": "agc::lz_parse_kernel<2>", "filter": "agc::key_filter_kernel", "pack": "agc::pack_fasta_kernel<false>",
                  "zstd": "agc::zstd_frames_grp_kernel<3, 2>"}

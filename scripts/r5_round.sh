@@ -90,4 +90,51 @@ if [ "$PART" = f ]; then
   timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/f_bench_config_c5slice.json 2> $OUT/f_bench_config_c5slice.err; show $OUT/f_bench_config_c5slice.json
   for cfg in c5twin c1; do timeout 300 python bench.py --config $cfg > $OUT/f_bench_config_$cfg.json 2> /dev/null; show $OUT/f_bench_config_$cfg.json; done
 fi
-ls $OUT | head -80
+if [ "$PART" = g ]; then
+  # ---- end of round, part 1: tests, smoke, the driver's command (with the CPU baseline), controls, configs, two ranks on one GPU, fuzz
+  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd_steps20_warmup5.json 2> $OUT/bench_driver_cmd.err; show $OUT/bench_driver_cmd_steps20_warmup5.json
+  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd_steps20_warmup5_run2.json 2>/dev/null; show $OUT/bench_driver_cmd_steps20_warmup5_run2.json
+  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --prepacked > $OUT/bench_prepacked_control_steps20_warmup5.json 2>/dev/null; show $OUT/bench_prepacked_control_steps20_warmup5.json
+  for cfg in c1 c4twin c5twin; do timeout 400 python bench.py --config $cfg > $OUT/bench_config_$cfg.json 2> /dev/null; show $OUT/bench_config_$cfg.json; done
+  timeout 900 python bench.py --config c5slice --c5-samples 192 > $OUT/bench_config_c5slice.json 2> /dev/null; show $OUT/bench_config_c5slice.json
+  AGC_BENCH_ONE_GPU=1 AGC_BENCH_SERIAL_PREPARE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks_serial_prepare.json 2> $OUT/bench_one_gpu_2_ranks_serial_prepare.err; show $OUT/bench_one_gpu_2_ranks_serial_prepare.json
+  AGC_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks.json 2> $OUT/bench_one_gpu_2_ranks.err; show $OUT/bench_one_gpu_2_ranks.json
+  # a Close of 6 300 full packs of 44 KB: what one of 8 GPUs holds when 200 human-size samples close: 104 samples of 378 Mbp, b = 100
+  timeout 600 python bench.py --gbp 0.378 --steps 100 --warmup 4 --prepacked --no-cpu-baseline > $OUT/bench_6300_groups_104_samples_full_packs.json 2>/dev/null; show $OUT/bench_6300_groups_104_samples_full_packs.json
+  timeout 900 python scripts/fuzz_archives.py --from 70000 --count 120 > $OUT/fuzz_gpu_120_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_120_cases.log
+  timeout 600 python scripts/fuzz_archives.py --many --from 71000 --count 30 > $OUT/fuzz_gpu_many_30_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_many_30_cases.log
+  timeout 600 python scripts/fuzz_archives.py --big --from 72000 --count 20 > $OUT/fuzz_gpu_big_20_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_big_20_cases.log
+fi
+if [ "$PART" = h ]; then
+  # ---- end of round, part 2: rocprofv3 passes of the driver's command and of the c5slice CLI run, laps, --verify-entropy
+  bash scripts/profile_round.sh r5 > $OUT/profile_round.log 2>&1; tail -3 $OUT/profile_round.log
+  python - <<'PY'
+import os, sys, subprocess, numpy as np
+sys.path.insert(0, os.getcwd())
+from agc_amd import synth
+td = "/dev/shm/c5prof"; os.makedirs(td, exist_ok=True)
+rng = np.random.default_rng(5)
+anc = synth.random_seq(rng, 5_000_000)
+plasmids = [synth.random_seq(rng, int(rng.integers(20_000, 90_000))) for _ in range(12)]
+with open(td + "/files.txt", "w") as fl:
+    for i in range(48):
+        ctg, nm = [synth.mutate(rng, anc, 0.025)], [f"NZ_CP{i:06d}.1 strain {i} chromosome"]
+        if i:
+            for pi in rng.permutation(12)[: int(rng.integers(0, 3))]:
+                ctg.append(synth.mutate(rng, plasmids[int(pi)], 0.025)); nm.append(f"NZ_CP{i:06d}p{int(pi)}.1 plasmid")
+        fn = f"{td}/GCF_{i:09d}.fa"; synth.to_fasta(fn, ctg, nm); fl.write(fn + "\n")
+PY
+  C5="agc_amd/bin/agc_amd create -a -t 16 -o /dev/shm/c5prof/o.agc $(cat /dev/shm/c5prof/files.txt | tr '\n' ' ')"
+  ROOT=$(pwd)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/c5_ktrace -o kt -- $ROOT/$C5 > $ROOT/$OUT/c5_ktrace.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv --kernel-include-regex agc -d $ROOT/$OUT/c5_pmc_fetch -o pf -- $ROOT/$C5 > $ROOT/$OUT/c5_pmc_fetch.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv --kernel-include-regex agc -d $ROOT/$OUT/c5_pmc_write -o pw -- $ROOT/$C5 > $ROOT/$OUT/c5_pmc_write.log 2>&1)
+  python scripts/pmc_summary.py $OUT/pmc_summary_c5slice.csv $OUT/c5_pmc_fetch $OUT/c5_pmc_write > $OUT/pmc_summary_c5slice.log 2>&1
+  find $OUT -name '*counter_collection.csv' -size +4M -delete; find $OUT -name '*kernel_trace.csv' -size +8M -delete
+  AGC_AMD_LAPS=1 AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $OUT/bench_laps_steps20_warmup5.txt; grep -c lap $OUT/bench_laps_steps20_warmup5.txt
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --verify-entropy > $OUT/bench_verify_entropy.json 2> $OUT/bench_verify_entropy.log; grep -h "verify" $OUT/bench_verify_entropy.log | tail -3
+  find $OUT -name "*kernel_stats.csv" | head; find $OUT -name "*kernel_stats.csv" -exec head -12 {} \;
+fi
+ls $OUT | head -100
