@@ -84,6 +84,7 @@ class DistCompressor:
         self.MSG_CAP0 = max(self.MSG_HDR + 8, int(os.environ.get("AGC_AMD_DIST_MSG_CAP0", self.MSG_CAP0)))
         self.MSG_CAP_MAX = max(self.MSG_CAP0, int(os.environ.get("AGC_AMD_DIST_MSG_CAP_MAX", self.MSG_CAP_MAX)))
         self._cap = self.MSG_CAP0
+        self._prev_msg_bytes = 0
         self._hmsg = self._host_buffer(self._cap)
         self._dmsg = torch.empty(self._cap, dtype=torch.uint8, device=self.comm) if self.comm.type == "cuda" else None
         self._dapply = None         # (gloo with a GPU: the head's copy in this rank's HBM the new references are registered from)
@@ -103,7 +104,11 @@ class DistCompressor:
 
     def _next_cap(self, msg_bytes):
         """capacity of the NEXT head message, from the size of this one: every rank sees every size, so every rank derives the same"""
-        want = (msg_bytes * 9 // 8 + (1 << 18) - 1) >> 18 << 18  # (heads of consecutive samples differ by a few percent)
+        # (heads of consecutive samples differ by ten or twenty percent -- a sample mints 40 to 90 groups: a quarter above the larger
+        # of the last two keeps the second broadcast for the reference sample)
+        big = max(msg_bytes, self._prev_msg_bytes)
+        self._prev_msg_bytes = msg_bytes
+        want = (big * 5 // 4 + (1 << 18) - 1) >> 18 << 18
         return min(self.MSG_CAP_MAX, max(self.MSG_CAP0, want))
 
     def _set_cap(self, cap):

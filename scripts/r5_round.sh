@@ -133,6 +133,9 @@ PY
   (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv --kernel-include-regex agc -d $ROOT/$OUT/c5_pmc_write -o pw -- $ROOT/$C5 > $ROOT/$OUT/c5_pmc_write.log 2>&1)
   python scripts/pmc_summary.py $OUT/pmc_summary_c5slice.csv $OUT/c5_pmc_fetch $OUT/c5_pmc_write > $OUT/pmc_summary_c5slice.log 2>&1
   find $OUT -name '*counter_collection.csv' -size +4M -delete; find $OUT -name '*kernel_trace.csv' -size +8M -delete
+  # a Close that holds 6 300 nearly full packs (99 samples, b = 100): the device's launch on what ONE of 8 GPUs closes when 200 samples end
+  timeout 600 python bench.py --gbp 0.378 --steps 95 --warmup 4 --prepacked --no-cpu-baseline > $OUT/bench_6300_groups_99_samples_close_holds_full_packs.json 2>/dev/null; show $OUT/bench_6300_groups_99_samples_close_holds_full_packs.json
+  AGC_AMD_GPU_ZSTD_SHARE=1.0 timeout 600 python bench.py --gbp 0.378 --steps 95 --warmup 4 --prepacked --no-cpu-baseline > $OUT/bench_6300_groups_99_samples_all_packs_on_the_device.json 2>/dev/null; show $OUT/bench_6300_groups_99_samples_all_packs_on_the_device.json
   AGC_AMD_LAPS=1 AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $OUT/bench_laps_steps20_warmup5.txt; grep -c lap $OUT/bench_laps_steps20_warmup5.txt
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --verify-entropy > $OUT/bench_verify_entropy.json 2> $OUT/bench_verify_entropy.log; grep -h "verify" $OUT/bench_verify_entropy.log | tail -3
   find $OUT -name "*kernel_stats.csv" | head; find $OUT -name "*kernel_stats.csv" -exec head -12 {} \;
