@@ -26,7 +26,7 @@ class _Locked:
         fcntl.flock(self.f, fcntl.LOCK_UN)
         self.f.close()
 LIB = os.path.join(HERE, "libagc_hip.so")
-SOURCES = ["api.hip", "scan_kernels.hip", "lz_kernels.hip", "splitters.hip", "zstd_kernels.hip", "seg_kernels.hip", "segments.hip", "dev_common.h", "sym_view.h",
+SOURCES = ["api.hip", "scan_kernels.hip", "pack_kernels.hip", "lz_kernels.hip", "splitters.hip", "zstd_kernels.hip", "seg_kernels.hip", "segments.hip", "dev_common.h", "sym_view.h",
            "zstd/zs_common.h", "zstd/zs_opt.h", "zstd/zs_opt_sm.h", "zstd/zs_opt_grp.h", "zstd/zs_entropy.h", "zstd/zs_frame.h", "zstd/zs_params.h"]
 
 
@@ -107,6 +107,33 @@ def build_host(force=False, verbose=False):
         return HOST_LIB
 
 
+def write_build_log():
+    """agc_amd/build.log: what was built with what -- compiler versions, the command lines' flags, size and sha256 of every
+    artefact (the .so files are git-ignored and ship prebuilt with a snapshot: this is their record)"""
+    import hashlib
+    import time
+    lines = ["# agc_amd build record (agc_amd/build.py: write_build_log)", "written: " + time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime())]
+    for tool, arg in ((os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"), (os.environ.get("CXX", "g++"), "--version")):
+        try:
+            out = subprocess.run([tool, arg], capture_output=True, text=True, timeout=60).stdout.strip().splitlines()
+            lines.append(f"{tool}: " + " | ".join(x.strip() for x in out[:3]))
+        except Exception as e:  # noqa: BLE001
+            lines.append(f"{tool}: {e}")
+    lines.append("libagc_hip.so: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wall csrc/api.hip (one translation unit: it includes the *.hip files)")
+    lines.append("libagc_host.so / bin/agc_amd / libagc_read.so: g++ -O2 -std=c++17 -fPIC -Wall -pthread csrc/host/*.cpp, linked against libagc_hip.so ($ORIGIN rpath), -lz -ldl")
+    for path in (LIB, HOST_LIB, READ_LIB, HOST_BIN):
+        if os.path.exists(path):
+            h = hashlib.sha256(open(path, "rb").read()).hexdigest()
+            lines.append(f"{os.path.relpath(path, HERE)}: {os.path.getsize(path)} bytes, sha256 {h}, mtime {time.strftime('%Y-%m-%d %H:%M:%S', time.gmtime(os.path.getmtime(path)))}")
+    srcs = [os.path.join(CSRC, s_) for s_ in SOURCES] + [os.path.join(HOST, s_) for s_ in HOST_SOURCES]
+    hs = hashlib.sha256()
+    for p_ in sorted(srcs):
+        hs.update(open(p_, "rb").read())
+    lines.append(f"sources ({len(srcs)} files under csrc/): sha256 of their concatenation in name order {hs.hexdigest()}")
+    open(os.path.join(HERE, "build.log"), "w").write("\n".join(lines) + "\n")
+
+
 if __name__ == "__main__":
     build_host(force="--force" in sys.argv, verbose=True)
     print(build(force="--force" in sys.argv, verbose=True))
+    write_build_log()

@@ -1013,14 +1013,23 @@ int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_ra
         a.ctg_off = (unsigned long long *)P.d_off.p;
         static const bool lookback = getenv("AGC_HIP_PACK_LOOKBACK") != nullptr;
         if (lookback) {
-            a.tile_off = nullptr;
+            a.tile_local = nullptr;
+            a.block_off = nullptr;
             hipLaunchKernelGGL(pack_fasta_kernel<true>, dim3(n_tiles), dim3(256), 0, P.stream, a);
         } else {
-            CHK(ensure(c, P.d_tcnt, (size_t)n_tiles * 4 + 64, P.stream));
-            CHK(ensure(c, P.d_toff, (size_t)n_tiles * 8 + 64, P.stream));
-            a.tile_off = (const uint64_t *)P.d_toff.p;
-            hipLaunchKernelGGL(pack_fasta_count_kernel, dim3(n_tiles), dim3(256), 0, P.stream, a, (uint32_t *)P.d_tcnt.p);
-            hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(1024), 0, P.stream, (const uint32_t *)P.d_tcnt.p, n_tiles, (uint64_t *)P.d_toff.p,
+            const uint32_t n_sb = (n_tiles + PF_SCAN_TILES - 1) / PF_SCAN_TILES;
+            // d_tcnt: counts per tile, then the scan blocks' totals; d_toff: offsets inside a scan block (u32), then the blocks' offsets (u64)
+            const size_t tl_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255;
+            CHK(ensure(c, P.d_tcnt, tl_bytes + (size_t)n_sb * 4 + 64, P.stream));
+            CHK(ensure(c, P.d_toff, tl_bytes + (size_t)n_sb * 8 + 64, P.stream));
+            uint32_t *d_cnt = (uint32_t *)P.d_tcnt.p, *d_tot = (uint32_t *)((uint8_t *)P.d_tcnt.p + tl_bytes);
+            uint32_t *d_local = (uint32_t *)P.d_toff.p;
+            uint64_t *d_boff = (uint64_t *)((uint8_t *)P.d_toff.p + tl_bytes);
+            a.tile_local = d_local;
+            a.block_off = d_boff;
+            hipLaunchKernelGGL(pack_fasta_count_kernel, dim3(n_tiles), dim3(256), 0, P.stream, a, d_cnt);
+            hipLaunchKernelGGL(pack_fasta_scan_kernel, dim3(n_sb), dim3(1024), 0, P.stream, (const uint32_t *)d_cnt, n_tiles, d_local, d_tot);
+            hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(1024), 0, P.stream, (const uint32_t *)d_tot, n_sb, d_boff,
                                (uint64_t *)((uint8_t *)P.d_state.p + 32)); // (its total: unused, the last tile writes a.total)
             hipLaunchKernelGGL(pack_fasta_kernel<false>, dim3(n_tiles), dim3(256), 0, P.stream, a);
         }
@@ -1775,10 +1784,16 @@ int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u
                 if (MODE != MODE_ESTIMATE) { // (the hop parser left its counters where an estimate's peak goes)
                     std::vector<uint32_t> dbg(n);
                     (void)hipMemcpy(dbg.data(), d_resp, (size_t)n * 4, hipMemcpyDeviceToHost);
-                    for (uint32_t i = 0; i < n && i < 12; ++i)
-                        fprintf(stderr, "        text %u: %u symbols, %u chunks, ref %u: %u chunks taken over, %u matches parsed by the hop wavefront\n", i,
-                                (uint32_t)b->segs[i].text.len, ((uint32_t)b->segs[i].text.len + chunk_len - 1) / chunk_len, c->refs[b->segs[i].ref_slot].ref_size,
-                                dbg[b->segs[i].idx] >> 16, dbg[b->segs[i].idx] & 0xFFFFu);
+                    uint32_t shown = 0;
+                    for (uint32_t i = 0; i < n && shown < 16; ++i) {
+                        const uint32_t nch = ((uint32_t)b->segs[i].text.len + chunk_len - 1) / chunk_len, hops = dbg[b->segs[i].idx] >> 16;
+                        if (i >= 4 && (hops * 2 >= nch || nch < 4))
+                            continue; // (the first few, and every text the hop wavefront had to parse mostly by itself)
+                        ++shown;
+                        fprintf(stderr, "        text %u: %u symbols (rc %u), %u chunks, ref %u (gid %u): %u chunks taken over, %u matches parsed by the hop wavefront\n", i,
+                                (uint32_t)b->segs[i].text.len, (uint32_t)b->segs[i].text.rc, nch, c->refs[b->segs[i].ref_slot].ref_size, b->segs[i].ref_slot, hops,
+                                dbg[b->segs[i].idx] & 0xFFFFu);
+                    }
                 }
             }
             return AGC_HIP_OK;

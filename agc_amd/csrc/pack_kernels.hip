@@ -32,7 +32,8 @@ struct PackFastaArgs {
     uint32_t n_tiles;
     uint32_t *ticket;                    // zeroed                 (look-back variant)
     unsigned long long *state;           // n_tiles words, zeroed  (look-back variant)
-    const uint64_t *tile_off;            // symbols in front of every tile (two-pass variant: pack_fasta_count_kernel + pp_scan_kernel)
+    const uint32_t *tile_local;          // two-pass variant: symbols in front of a tile inside its scan block (pack_fasta_scan_kernel) ...
+    const uint64_t *block_off;           // ... and in front of that scan block (pp_scan_kernel over the blocks' totals)
     uint32_t *words;
     int32_t *esc_index;
     uint8_t *esc_bytes;
@@ -256,6 +257,44 @@ __global__ void __launch_bounds__(256) pack_fasta_count_kernel(PackFastaArgs a, 
         tile_cnt[tile] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
+// tile counts -> the symbols in front of every tile, in two levels (a single block walking 186 k counts took 0.44 ms -- as long as
+// the counting pass itself): block b scans the counts of tiles [8192 b, 8192 (b + 1)) and leaves its total; the few totals are
+// scanned by pp_scan_kernel; the pack kernel adds the two
+constexpr uint32_t PF_SCAN_TILES = 8192; // tiles per scan block: 1024 threads x 8
+__global__ void __launch_bounds__(1024) pack_fasta_scan_kernel(const uint32_t *__restrict__ tile_cnt, uint32_t n_tiles, uint32_t *__restrict__ tile_local,
+                                                              uint32_t *__restrict__ block_total)
+{
+    __shared__ uint32_t s_w[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t t0 = blockIdx.x * PF_SCAN_TILES + tid * 8;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        v[j] = t0 + j < n_tiles ? tile_cnt[t0 + j] : 0u;
+        sum += v[j];
+    }
+    const uint32_t incl = pf_wave_incl(sum);
+    if (lane == 63)
+        s_w[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < 16; ++x) {
+        if (x < wv)
+            base += s_w[x];
+        total += s_w[x];
+    }
+    uint32_t run = base + incl - sum;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        if (t0 + j < n_tiles)
+            tile_local[t0 + j] = run;
+        run += v[j];
+    }
+    if (tid == 0)
+        block_total[blockIdx.x] = total;
+}
+
 template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
 {
     __shared__ uint32_t s_words[PF_MAX_BLOCKS * (PACK_BLOCK / 16)];
@@ -332,7 +371,7 @@ template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kerne
     // around every one of them (buffer_wbl2 / buffer_inv on gfx950) -- measured: 19.7 ms per 3 Gbp instead of < 1
     if (!LOOKBACK) {
         if (tid == 0)
-            s_excl = a.tile_off[tile];
+            s_excl = a.block_off[tile / PF_SCAN_TILES] + a.tile_local[tile];
     } else if (wv == 0) {
         unsigned long long excl = 0;
         if (tile) {
