@@ -140,4 +140,19 @@ PY
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --verify-entropy > $OUT/bench_verify_entropy.json 2> $OUT/bench_verify_entropy.log; grep -h "verify" $OUT/bench_verify_entropy.log | tail -3
   find $OUT -name "*kernel_stats.csv" | head; find $OUT -name "*kernel_stats.csv" -exec head -12 {} \;
 fi
+if [ "$PART" = i ]; then
+  # ---- the last pass on the final build: tests, smoke, the driver's command, its control, the profiles, the configs
+  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd_steps20_warmup5.json 2> $OUT/bench_driver_cmd.err; show $OUT/bench_driver_cmd_steps20_warmup5.json
+  for i in 2 3; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd_steps20_warmup5_run$i.json 2>/dev/null; show $OUT/bench_driver_cmd_steps20_warmup5_run$i.json; done
+  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --prepacked > $OUT/bench_prepacked_control_steps20_warmup5.json 2>/dev/null; show $OUT/bench_prepacked_control_steps20_warmup5.json
+  timeout 400 python bench.py --no-cpu-baseline > $OUT/bench_default_no_cpu_baseline.json 2>/dev/null; show $OUT/bench_default_no_cpu_baseline.json
+  timeout 200 python scripts/pack_alone.py 3.0 0 > $OUT/pack_alone.log 2>&1; tail -2 $OUT/pack_alone.log
+  bash scripts/profile_round.sh r5 > $OUT/profile_round.log 2>&1
+  for cfg in c1 c4twin c5twin; do timeout 400 python bench.py --config $cfg > $OUT/bench_config_$cfg.json 2> /dev/null; show $OUT/bench_config_$cfg.json; done
+  timeout 900 python bench.py --config c5slice --c5-samples 192 > $OUT/bench_config_c5slice.json 2> /dev/null; show $OUT/bench_config_c5slice.json
+  AGC_BENCH_ONE_GPU=1 AGC_BENCH_SERIAL_PREPARE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks_serial_prepare.json 2> $OUT/bench_one_gpu_2_ranks_serial_prepare.err; show $OUT/bench_one_gpu_2_ranks_serial_prepare.json
+  find $OUT -name "*kernel_stats.csv" | head -3
+fi
 ls $OUT | head -100
