@@ -155,7 +155,6 @@ struct agc_hip_ctx {
         size_t h_res_cap = 0;
         uint32_t n_ctg = 0;
         uint64_t n_raw = 0, esc_cap = 0;
-        std::vector<uint64_t> rng_begin;
         bool pending = false, timed = false;
         hipEvent_t e0 = nullptr, e1 = nullptr;
     } pfa;
@@ -970,7 +969,6 @@ int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_ra
     P.n_ctg = n_ctg;
     P.n_raw = n_raw;
     P.esc_cap = esc_cap_blocks;
-    P.rng_begin.assign(h_raw_begin, h_raw_begin + n_ctg);
     const size_t res_words = (size_t)n_ctg + 4;
     if (P.h_res_cap < res_words) {
         if (P.h_res)
