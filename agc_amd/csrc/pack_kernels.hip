@@ -377,26 +377,46 @@ template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kerne
         if (tile) {
             if (lane == 0)
                 __hip_atomic_store(&a.state[tile], PF_FLAG_AGG | cnt_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (four rounds of 64 predecessors per trip, their loads in flight together: the chain of tiles advances 256 tiles per
+            // device-scope round trip instead of 64)
             int64_t look = (int64_t)tile - 1;
             for (;;) {
-                const int64_t idx = look - lane;
-                unsigned long long s = PF_FLAG_INCL; // (in front of tile 0: nothing)
-                if (idx >= 0)
-                    s = __hip_atomic_load(&a.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t inv = __ballot((s >> 62) == 0), inc = __ballot((s >> 62) == 2);
-                const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u, first_inv = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
-                if (first_inv < first_inc) { // a tile in front has not counted yet
+                unsigned long long st[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t idx = look - (q * 64 + (int64_t)lane);
+                    st[q] = PF_FLAG_INCL; // (in front of tile 0: nothing)
+                    if (idx >= 0)
+                        st[q] = __hip_atomic_load(&a.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool again = false, done = false;
+                unsigned long long add = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (again || done)
+                        continue;
+                    const unsigned long long sq = st[q];
+                    const uint64_t inv = __ballot((sq >> 62) == 0), inc = __ballot((sq >> 62) == 2);
+                    const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u, first_inv = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
+                    if (first_inv < first_inc) { // a tile in front has not counted yet
+                        again = true;
+                        continue;
+                    }
+                    unsigned long long v = lane <= first_inc ? (sq & PF_VALUE) : 0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1)
+                        v += __shfl_xor(v, o);
+                    add += v;
+                    done = first_inc < 64;
+                }
+                if (again) {
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
-                unsigned long long v = lane <= first_inc ? (s & PF_VALUE) : 0;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-                    v += __shfl_xor(v, o);
-                excl += v;
-                if (first_inc < 64)
+                excl += add;
+                if (done)
                     break;
-                look -= 64;
+                look -= 256;
             }
         }
         if (lane == 0) {
