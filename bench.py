@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- AGC `create` hot path on MI355X: input Gbp/s compressed.
 
-One "step" = one pass of the hot path (splitter scan -> add_segment classification ->
-LZ-diff encode of every placed segment against its group reference -> pack bookkeeping)
-over one synthetic human-scale sample that is already resident in HBM
-(BASELINE.json configs[2]: GRCh38-shaped reference, 0.1 % divergence, k=31 l=15 b=100);
+One "step" = one pass of the hot path (FASTA bytes -> 2-bit words -> splitter scan -> add_segment
+classification -> LZ-diff encode of every placed segment against its group reference -> pack
+bookkeeping) over one synthetic human-scale sample that is resident in HBM as the bytes of its
+FASTA file (BASELINE.json configs[2]: GRCh38-shaped reference, 0.1 % divergence, k=31 l=15 b=100;
+--prepacked: already in the 2-bit layout when the timer starts, round 4's region);
 the zstd packing the steps defer (packs flush every b samples) runs in Close(), which is
 inside the timed region.  The step is the same code path `agc_amd create` runs and whose
 archives are byte-identical to the reference's (tests/test_gpu_archive.py).
