@@ -180,6 +180,20 @@ def test_pack_fasta_edge_cases(hip_ctx, oracle):
     _check_pack_fasta(hip_ctx, oracle, only_n, np.array([3], np.uint64), np.array([49_999], np.uint64))
 
 
+def test_pack_fasta_many_tiny_contigs(hip_ctx, oracle):
+    """20 000 contigs of 1-400 letters (a fragmented assembly: several contigs per 16-byte chunk, hundreds per tile): every range
+    boundary falls somewhere else in a chunk, headers are longer than the bodies"""
+    import time
+    rng = np.random.default_rng(6200)
+    letters = np.frombuffer(b"ACGTacgtN", np.uint8)
+    contigs = [rng.choice(letters, size=int(n)) for n in rng.integers(1, 400, size=20_000)]
+    contigs[7] = np.zeros(0, np.uint8)
+    raw, rb, re_ = _fasta_case(rng, contigs, 70)
+    t0 = time.time()
+    _check_pack_fasta(hip_ctx, oracle, raw, rb, re_, esc_cap=4096)
+    assert time.time() - t0 < 60
+
+
 def test_pack_fasta_equals_preprocess_and_pack_on_a_big_sample(hip_ctx, oracle):
     """size-independent property at a larger size (120 MB of FASTA, 9 contigs): the one-pass kernel gives what the three-pass
     preprocess + the packing of its codes give, and the packed scan reports the same hits on both"""
