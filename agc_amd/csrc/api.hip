@@ -1676,7 +1676,11 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         CHK(upload(c, c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), L_stream));
         {
             KTimer t(c, AGC_HIP_K_FILTER);
-            hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
+            static const bool filter_lds = !(getenv("AGC_HIP_FILTER_LDS") && atoi(getenv("AGC_HIP_FILTER_LDS")) == 0);
+            if (filter_lds)
+                hipLaunchKernelGGL(key_filter_kernel<true>, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
+            else
+                hipLaunchKernelGGL(key_filter_kernel<false>, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
         }
         HIPCHK(c, hipGetLastError()); // (fjobs is a local: upload() took its copy)
     }
