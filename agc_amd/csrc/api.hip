@@ -149,7 +149,7 @@ struct agc_hip_ctx {
     // agc_hip_pack_fasta_begin / _end: raw FASTA bodies -> the packed sample on a stream of its own (pack_kernels.hip)
     struct PackFasta {
         hipStream_t stream = nullptr;
-        DevBuf d_state, d_rng, d_off; // the three counters (+ look-back words); the ranges; n_ctg + 1 symbol offsets + the total
+        DevBuf d_state, d_rng, d_off; // the three counters; the ranges; n_ctg + 1 symbol offsets + the total
         DevBuf d_tcnt, d_toff;        // two-pass variant: symbols per tile, symbols in front of every tile
         uint64_t *h_res = nullptr;    // pinned: offsets, total, escaped-block count
         size_t h_res_cap = 0;
@@ -979,11 +979,11 @@ int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_ra
         P.h_res_cap = res_words + 1024;
     }
     const uint32_t n_tiles = (uint32_t)n_tiles64;
-    // [0, 64): ticket, escaped-block count, total; then one look-back word per tile
-    CHK(ensure(c, P.d_state, 64 + (size_t)n_tiles * 8, P.stream));
+    // the counters: [4, 8) escaped blocks, [8, 16) the total
+    CHK(ensure(c, P.d_state, 64, P.stream));
     CHK(ensure(c, P.d_rng, std::max<size_t>(16, (size_t)n_ctg * 16), P.stream));
     CHK(ensure(c, P.d_off, ((size_t)n_ctg + 2) * 8, P.stream));
-    HIPCHK(c, hipMemsetAsync(P.d_state.p, 0, 64 + (size_t)n_tiles * 8, P.stream));
+    HIPCHK(c, hipMemsetAsync(P.d_state.p, 0, 64, P.stream));
     HIPCHK(c, hipMemsetAsync(P.d_off.p, 0xFF, ((size_t)n_ctg + 1) * 8, P.stream));
     if (n_ctg) {
         CHK(upload(c, P.d_rng.p, h_raw_begin, (size_t)n_ctg * 8, P.stream));
@@ -1000,21 +1000,14 @@ int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_ra
         a.rng_end = a.rng_begin + n_ctg;
         a.n_rng = n_ctg;
         a.n_tiles = n_tiles;
-        a.ticket = (uint32_t *)P.d_state.p;
         a.esc_count = (uint32_t *)P.d_state.p + 1;
         a.total = (unsigned long long *)P.d_state.p + 1;
-        a.state = (unsigned long long *)P.d_state.p + 8;
         a.words = d_words;
         a.esc_index = d_esc_index;
         a.esc_bytes = d_esc_bytes;
         a.esc_cap = (uint32_t)std::min<uint64_t>(esc_cap_blocks, 0x7fffffffu);
         a.ctg_off = (unsigned long long *)P.d_off.p;
-        static const bool lookback = getenv("AGC_HIP_PACK_LOOKBACK") != nullptr;
-        if (lookback) {
-            a.tile_local = nullptr;
-            a.block_off = nullptr;
-            hipLaunchKernelGGL(pack_fasta_kernel<true>, dim3(n_tiles), dim3(256), 0, P.stream, a);
-        } else {
+        {
             const uint32_t n_sb = (n_tiles + PF_SCAN_TILES - 1) / PF_SCAN_TILES;
             // d_tcnt: counts per tile, then the scan blocks' totals; d_toff: offsets inside a scan block (u32), then the blocks' offsets (u64)
             const size_t tl_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255;
@@ -1029,7 +1022,7 @@ int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_ra
             hipLaunchKernelGGL(pack_fasta_scan_kernel, dim3(n_sb), dim3(1024), 0, P.stream, (const uint32_t *)d_cnt, n_tiles, d_local, d_tot);
             hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(1024), 0, P.stream, (const uint32_t *)d_tot, n_sb, d_boff,
                                (uint64_t *)((uint8_t *)P.d_state.p + 32)); // (its total: unused, the last tile writes a.total)
-            hipLaunchKernelGGL(pack_fasta_kernel<false>, dim3(n_tiles), dim3(256), 0, P.stream, a);
+            hipLaunchKernelGGL(pack_fasta_kernel, dim3(n_tiles), dim3(256), 0, P.stream, a);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -1059,7 +1052,7 @@ int agc_hip_pack_fasta_end(agc_hip_ctx *c, uint64_t *h_ctg_off, uint64_t *h_n_es
         P.timed = false;
     }
     const uint32_t n = P.n_ctg;
-    const uint32_t *cnt = (const uint32_t *)(P.h_res + n + 1); // ticket, escaped blocks; the total in the next 8 bytes
+    const uint32_t *cnt = (const uint32_t *)(P.h_res + n + 1); // (unused), escaped blocks; the total in the next 8 bytes
     const uint64_t total = (P.n_raw && n) ? P.h_res[n + 2] : 0;
     for (uint32_t i = 0; i < n; ++i) // (a contig whose first byte no tile holds -- it begins at the end of the buffer -- is empty and begins at the total)
         h_ctg_off[i] = P.h_res[i] == ~0ULL ? total : P.h_res[i];
@@ -1676,11 +1669,7 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         CHK(upload(c, c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), L_stream));
         {
             KTimer t(c, AGC_HIP_K_FILTER);
-            static const bool filter_lds = !(getenv("AGC_HIP_FILTER_LDS") && atoi(getenv("AGC_HIP_FILTER_LDS")) == 0);
-            if (filter_lds)
-                hipLaunchKernelGGL(key_filter_kernel<true>, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
-            else
-                hipLaunchKernelGGL(key_filter_kernel<false>, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
+            hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
         }
         HIPCHK(c, hipGetLastError()); // (fjobs is a local: upload() took its copy)
     }

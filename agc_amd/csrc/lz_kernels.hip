@@ -1269,9 +1269,7 @@ template <class V> __device__ __forceinline__ void pack16(const V &tv, uint32_t 
     }
 }
 
-// USE_LDS = false: an instance without the 32 KiB of LDS -- every filter read from L2 (the experiment of VERDICT r4 item 7,
-// AGC_HIP_FILTER_LDS=0: does the filter run better beside the whole-sample encode when it does not compete for LDS?)
-template <bool USE_LDS> __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__restrict__ jobs)
+__global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__restrict__ jobs)
 {
     const FilterJob jb = jobs[blockIdx.x];
     const SymViewG text = global_view(jb.text); // (global loads instead of FLAT ones: see SymViewG)
@@ -1279,9 +1277,9 @@ template <bool USE_LDS> __global__ void __launch_bounds__(256) key_filter_kernel
     unsigned long long __attribute__((address_space(1))) *out = (unsigned long long __attribute__((address_space(1))) *)jb.out;
     // (the first filter in LDS; the second one is consulted for the 0.4 % of foreign keys that pass it, from HBM / L2)
     // (a filter of more than KEY_BLOOM_HALF words -- a reference of more than 64 k symbols -- is read where it lies: L2)
-    __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[USE_LDS ? KEY_BLOOM_HALF : 1];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[KEY_BLOOM_HALF];
     const uint32_t bshift = jb.bloom_shift;
-    const bool in_lds = USE_LDS && bshift == KEY_BLOOM_SHIFT0;
+    const bool in_lds = bshift == KEY_BLOOM_SHIFT0;
     if (in_lds)
         for (uint32_t t = threadIdx.x; t < KEY_BLOOM_HALF; t += blockDim.x)
             s_bloom[t] = bloom[t];
@@ -1334,9 +1332,6 @@ template <bool USE_LDS> __global__ void __launch_bounds__(256) key_filter_kernel
             out[pos >> 6] = word;
     }
 }
-
-template __global__ void key_filter_kernel<true>(const FilterJob *);
-template __global__ void key_filter_kernel<false>(const FilterJob *);
 
 // ---------------------------------------------------------------------------
 // Index build.

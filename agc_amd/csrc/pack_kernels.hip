@@ -1,18 +1,18 @@
-// pack_kernels.hip -- raw FASTA bodies in HBM -> the 2-bit packed sample, in ONE pass over the input.
+// pack_kernels.hip -- raw FASTA bodies in HBM -> the 2-bit packed sample without an intermediate one-byte-per-symbol form.
 //
 // What it replaces: CAGCCompressor::preprocess_raw_contig (src/core/agc_compressor.cpp:907-951: every byte < 64 is dropped -- line
 // ends --, the others go through cnv_num, src/common/agc_basic.h:39-49) followed by the packing of the codes (pack_codes_kernel):
-// two kernels that read and write one byte per symbol three times over (count, scatter, pack).  Here the raw bytes are read once
-// (1 + 1 / line_width bytes per symbol) and 0.25 bytes per symbol are written.
+// two kernels that read and write one byte per symbol three times over (count, scatter, pack).  Here the raw bytes (1 + 1 / line_width
+// per symbol) are read twice and 0.25 bytes per symbol are written.
 //
-// Shape: a compaction needs every tile's output offset = the number of symbols kept in front of it.  Two variants of that:
-//  * LOOKBACK = false (the default): a counting pass over the raw bytes first (pack_fasta_count_kernel: one count per tile, then
-//    the one-block scan of pp_scan_kernel), i.e. the input is read twice -- 2 (1 + 1 / width) + 0.25 bytes per symbol of traffic;
-//  * LOOKBACK = true (AGC_HIP_PACK_LOOKBACK=1): one pass -- the tiles are handed out in ticket order and publish their counts
-//    through a chained scan with decoupled look-back (one 64-bit word per tile: 2 flag bits + the count or the inclusive prefix).
-//    Measured on MI355X: 19.7 ms per 3 Gbp against ~1 for the two passes -- 186 k tiles, each behind one same-address atomic and
-//    a look-back that advances 64 tiles per round trip of device-scope loads through eight L2s; kept for the record.
-// Either way a tile of 16 KiB of input then writes WHOLE 1024-symbol blocks only: it owns the blocks whose first
+// Shape: a compaction needs every tile's output offset = the number of symbols kept in front of it: a counting pass over the raw
+// bytes first (pack_fasta_count_kernel: one count per tile), a two-level scan of the counts (pack_fasta_scan_kernel + pp_scan_kernel
+// over the scan blocks' totals), then the pack pass -- the input is read twice, 2 (1 + 1 / width) + 0.25 bytes per symbol of traffic.
+// (A ONE-pass variant -- tiles in ticket order publishing their counts through a chained scan with decoupled look-back, relaxed
+// device-scope atomics -- was built first and measured slower on MI355X: 3.1 ms per 3 Gbp against 1.9, 0.5 ms of it the 186 k
+// same-address ticket atomics, the rest the chain of round trips through eight L2s; with an acquire / release pair per tile, which
+// writes back and invalidates the XCD's L2 each time, 19.7 ms.  It lived behind AGC_HIP_PACK_LOOKBACK until commit 9ace5d7.)
+// A tile of 16 KiB of input then writes WHOLE 1024-symbol blocks only: it owns the blocks whose first
 // symbol it holds, leaves the symbols in front of its first block to the tile before it and reads on into the next tiles'
 // bytes (<= 1023 symbols, L2 hits for the neighbour) to finish its last block -- words, escape index and escaped bytes of a block
 // have one writer, nothing is zeroed beforehand and no atomics touch the output.
@@ -22,7 +22,6 @@ namespace agc {
 
 constexpr uint32_t PF_TILE = 16384;                    // input bytes per tile: 256 threads x 4 chunks x 16 B
 constexpr uint32_t PF_MAX_BLOCKS = PF_TILE / PACK_BLOCK + 1; // blocks a tile can own (16; + 1 of slack)
-constexpr uint64_t PF_FLAG_AGG = 1ULL << 62, PF_FLAG_INCL = 2ULL << 62, PF_VALUE = (1ULL << 62) - 1;
 
 struct PackFastaArgs {
     const uint8_t *raw;
@@ -30,8 +29,6 @@ struct PackFastaArgs {
     const uint64_t *rng_begin, *rng_end; // contig c = raw bytes [rng_begin[c], rng_end[c]); ascending, disjoint
     uint32_t n_rng;
     uint32_t n_tiles;
-    uint32_t *ticket;                    // zeroed                 (look-back variant)
-    unsigned long long *state;           // n_tiles words, zeroed  (look-back variant)
     const uint32_t *tile_local;          // two-pass variant: symbols in front of a tile inside its scan block (pack_fasta_scan_kernel) ...
     const uint64_t *block_off;           // ... and in front of that scan block (pp_scan_kernel over the blocks' totals)
     uint32_t *words;
@@ -295,7 +292,7 @@ __global__ void __launch_bounds__(1024) pack_fasta_scan_kernel(const uint32_t *_
         block_total[blockIdx.x] = total;
 }
 
-template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
+__global__ void __launch_bounds__(256) pack_fasta_kernel(PackFastaArgs a)
 {
     __shared__ uint32_t s_words[PF_MAX_BLOCKS * (PACK_BLOCK / 16)];
     __shared__ uint32_t s_flag[PF_MAX_BLOCKS];
@@ -307,7 +304,7 @@ template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kerne
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     if (tid == 0)
-        s_tile = LOOKBACK ? atomicAdd(a.ticket, 1u) : blockIdx.x;
+        s_tile = blockIdx.x;
     for (uint32_t i = tid; i < PF_MAX_BLOCKS * (PACK_BLOCK / 16); i += 256)
         s_words[i] = 0;
     if (tid < PF_MAX_BLOCKS) {
@@ -369,61 +366,8 @@ template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kerne
     // ---- the tile's offset: publish the count, look back.  The state word is all that travels between tiles (flag and value in one
     // 64-bit word), so the atomics are RELAXED: an agent-scope release / acquire pair would write back and invalidate the XCD's L2
     // around every one of them (buffer_wbl2 / buffer_inv on gfx950) -- measured: 19.7 ms per 3 Gbp instead of < 1
-    if (!LOOKBACK) {
-        if (tid == 0)
-            s_excl = a.block_off[tile / PF_SCAN_TILES] + a.tile_local[tile];
-    } else if (wv == 0) {
-        unsigned long long excl = 0;
-        if (tile) {
-            if (lane == 0)
-                __hip_atomic_store(&a.state[tile], PF_FLAG_AGG | cnt_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (four rounds of 64 predecessors per trip, their loads in flight together: the chain of tiles advances 256 tiles per
-            // device-scope round trip instead of 64)
-            int64_t look = (int64_t)tile - 1;
-            for (;;) {
-                unsigned long long st[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t idx = look - (q * 64 + (int64_t)lane);
-                    st[q] = PF_FLAG_INCL; // (in front of tile 0: nothing)
-                    if (idx >= 0)
-                        st[q] = __hip_atomic_load(&a.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                bool again = false, done = false;
-                unsigned long long add = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (again || done)
-                        continue;
-                    const unsigned long long sq = st[q];
-                    const uint64_t inv = __ballot((sq >> 62) == 0), inc = __ballot((sq >> 62) == 2);
-                    const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u, first_inv = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
-                    if (first_inv < first_inc) { // a tile in front has not counted yet
-                        again = true;
-                        continue;
-                    }
-                    unsigned long long v = lane <= first_inc ? (sq & PF_VALUE) : 0;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1)
-                        v += __shfl_xor(v, o);
-                    add += v;
-                    done = first_inc < 64;
-                }
-                if (again) {
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                excl += add;
-                if (done)
-                    break;
-                look -= 256;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(&a.state[tile], PF_FLAG_INCL | (excl + cnt_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_excl = excl;
-        }
-    }
+    if (tid == 0)
+        s_excl = a.block_off[tile / PF_SCAN_TILES] + a.tile_local[tile];
     __syncthreads();
     const uint64_t o = s_excl;
 
@@ -527,8 +471,5 @@ template <bool LOOKBACK> __global__ void __launch_bounds__(256) pack_fasta_kerne
     }
     // (the tail of a last, partial block in an escaped slot stays as it is: nobody reads beyond n_symbols)
 }
-
-template __global__ void pack_fasta_kernel<false>(PackFastaArgs);
-template __global__ void pack_fasta_kernel<true>(PackFastaArgs);
 
 } // namespace agc

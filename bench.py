@@ -95,7 +95,7 @@ def host_cpus():
 PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r5", "r4", "r3"))
                     if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r5", "pmc_summary.csv"))
 KERNEL_SYMBOL = {"scan": "agc::scan_packed_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
-                 "costvec": "agc::lz_parse_kernel<2>", "filter": "agc::key_filter_kernel<true>", "pack": "agc::pack_fasta_kernel<false>",
+                 "costvec": "agc::lz_parse_kernel<2>", "filter": "agc::key_filter_kernel", "pack": "agc::pack_fasta_kernel",
                  "zstd": "agc::zstd_frames_grp_kernel<3, 2>"}
 # bytes per symbol each kernel reads in the layout AS BUILT = SURVEY 8d's 2-bit column since round 4: scan, key filter and the
 # three LZ parses read texts and references as 2-bit words where they lie (no expansion, no reverse-complement staging)

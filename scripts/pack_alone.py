@@ -1,4 +1,4 @@
-"""agc_hip_pack_fasta_* alone on an idle GPU: 3 Gbp of FASTA bytes in HBM -> 2-bit words, both variants (AGC_HIP_PACK_LOOKBACK), a few
+"""agc_hip_pack_fasta_* alone on an idle GPU: 3 Gbp of FASTA bytes in HBM -> 2-bit words, a few
 repetitions, with and without other large allocations resident (the bench keeps 25 samples = ~95 GB beside it).
     python scripts/pack_alone.py [gbp=3.0] [extra_gb=0]"""
 import os, sys, time
@@ -26,8 +26,7 @@ for it in range(6):
     pk, keep, o_ = ctx.pack_fasta_dev(raw, n_raw, rb, re_)
     wall = (time.perf_counter() - t0) * 1e3
     ms = ctx.timing_get()["pack"][0]
-    print(f"pack {it}: kernel {ms - last:.3f} ms, call {wall:.2f} ms, {n_raw / 1e9:.2f} GB of FASTA, {tot / 1e9:.2f} Gbp, extra {extra_gb:.0f} GB resident, "
-          f"lookback={bool(os.environ.get('AGC_HIP_PACK_LOOKBACK'))}", flush=True)
+    print(f"pack {it}: kernel {ms - last:.3f} ms, call {wall:.2f} ms, {n_raw / 1e9:.2f} GB of FASTA, {tot / 1e9:.2f} Gbp, extra {extra_gb:.0f} GB resident", flush=True)
     last = ms
     assert np.array_equal(o_, np.asarray(off, np.uint64))
 ctx.close()

@@ -53,7 +53,7 @@ if [ "$PART" = c ]; then
   timeout 300 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "not every_launch" > $OUT/c_lz_tests.log 2>&1; tail -15 $OUT/c_lz_tests.log
   timeout 900 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "every_launch" > $OUT/c_lz_forced_chunks.log 2>&1; tail -25 $OUT/c_lz_forced_chunks.log
   timeout 300 python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/c_bench_steps10.json 2> $OUT/c_bench_steps10.err; show $OUT/c_bench_steps10.json
-  AGC_HIP_PACK_LOOKBACK=1 timeout 300 python bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/c_bench_lookback.json 2> /dev/null; show $OUT/c_bench_lookback.json
+  # (the run with AGC_HIP_PACK_LOOKBACK=1 recorded as c_bench_lookback.json used the one-pass variant removed after commit 9ace5d7)
   timeout 900 python bench.py --config c5slice --c5-samples ${C5N:-128} > $OUT/c_bench_config_c5slice.json 2> $OUT/c_bench_config_c5slice.err; show $OUT/c_bench_config_c5slice.json
   timeout 300 python bench.py --config c5twin > $OUT/c_bench_config_c5twin.json 2> /dev/null; show $OUT/c_bench_config_c5twin.json
 fi
@@ -61,7 +61,7 @@ if [ "$PART" = d ]; then
   timeout 300 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "not every_launch" > $OUT/d_lz_tests.log 2>&1; tail -15 $OUT/d_lz_tests.log
   timeout 1200 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "every_launch" > $OUT/d_lz_forced_chunks.log 2>&1; tail -25 $OUT/d_lz_forced_chunks.log
   timeout 200 python scripts/pack_alone.py 3.0 0 > $OUT/d_pack_alone.log 2>&1; tail -6 $OUT/d_pack_alone.log
-  AGC_HIP_PACK_LOOKBACK=1 timeout 200 python scripts/pack_alone.py 3.0 0 >> $OUT/d_pack_alone.log 2>&1; tail -6 $OUT/d_pack_alone.log
+  tail -6 $OUT/d_pack_alone.log
   timeout 300 python scripts/pack_alone.py 3.0 120 >> $OUT/d_pack_alone.log 2>&1; tail -6 $OUT/d_pack_alone.log
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/d_bench_driver_cmd_no_cpu_baseline.json 2> $OUT/d_bench_driver_cmd.err; show $OUT/d_bench_driver_cmd_no_cpu_baseline.json
   python - $OUT/d_bench_driver_cmd_no_cpu_baseline.json <<'PY'
@@ -156,3 +156,11 @@ if [ "$PART" = i ]; then
   find $OUT -name "*kernel_stats.csv" | head -3
 fi
 ls $OUT | head -100
+if [ "$PART" = z ]; then
+  # the last build of the round (experiment variants removed): tests, smoke, pack alone, the profile passes, the driver's bench line
+  timeout 700 python -m pytest tests -m gpu -x -q -k "not every_launch" > $OUT/z_gpu_tests.log 2>&1; tail -4 $OUT/z_gpu_tests.log
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/z_smoke.log 2>&1; tail -2 $OUT/z_smoke.log
+  timeout 200 python scripts/pack_alone.py 3.0 0 > $OUT/z_pack_alone.log 2>&1; tail -4 $OUT/z_pack_alone.log
+  bash scripts/profile_round.sh r5/z_prof > $OUT/z_profile_round.log 2>&1; tail -3 $OUT/z_profile_round.log
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/z_bench_driver_cmd.json 2> $OUT/z_bench_driver_cmd.err; show $OUT/z_bench_driver_cmd.json
+fi
