@@ -163,6 +163,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
+    if (const char *e = getenv("AGC_AMD_ENTROPY_STREAM"))
+        I.entropy_stream = atoi(e) != 0;
     I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.dist_record_buf.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_PAR_MIN"))
         I.par_min = (size_t)std::max(1LL, atoll(e));
@@ -352,6 +354,8 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
     I.sync_entropy = getenv("AGC_AMD_SYNC_ENTROPY") != nullptr;
+    if (const char *e = getenv("AGC_AMD_ENTROPY_STREAM"))
+        I.entropy_stream = atoi(e) != 0;
     I.enc_buf.ctx = I.enc_buf2.ctx = I.dist_body_buf.ctx = I.dist_record_buf.ctx = I.hip;
     if (const char *e = getenv("AGC_AMD_PAR_MIN"))
         I.par_min = (size_t)std::max(1LL, atoll(e));
@@ -989,19 +993,39 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     };
     const size_t READ_AHEAD = std::max<size_t>(1, std::min<size_t>(8, no_threads)); // files in flight
     const uint64_t READ_AHEAD_BYTES = 8ull << 30;                                    // (estimated) bytes of sequence in flight
-    std::deque<std::future<FileData>> inflight;
+    // (small genomes -- a file per virus -- are mostly the latency of opening them and of starting a task: up to 8 of them per
+    // task, four times as many files in flight)
+    const uint64_t SMALL_FILE = 1u << 20;
+    std::deque<std::future<std::vector<FileData>>> inflight;
     std::deque<uint64_t> inflight_sz;
+    std::deque<size_t> inflight_n;
+    std::deque<FileData> ready;
     uint64_t inflight_bytes = 0;
-    size_t next_launch = 0;
+    size_t inflight_files = 0, next_launch = 0;
     auto launch = [&]() {
         while (next_launch < files.size()) {
-            const uint64_t sz = file_bytes(files[next_launch].second);
-            if (!inflight.empty() && (inflight.size() >= READ_AHEAD || inflight_bytes + sz > READ_AHEAD_BYTES))
+            uint64_t sz = file_bytes(files[next_launch].second);
+            const bool small = sz < SMALL_FILE;
+            if (!inflight.empty() && (inflight_files + ready.size() >= (small ? 4 * READ_AHEAD : READ_AHEAD) || inflight_bytes + sz > READ_AHEAD_BYTES))
                 break;
-            inflight.emplace_back(std::async(std::launch::async, read_file, files[next_launch].second));
+            std::vector<std::string> paths{files[next_launch++].second};
+            while (small && paths.size() < 8 && next_launch < files.size()) {
+                const uint64_t s2 = file_bytes(files[next_launch].second);
+                if (s2 >= SMALL_FILE)
+                    break;
+                sz += s2;
+                paths.push_back(files[next_launch++].second);
+            }
+            inflight_n.push_back(paths.size());
+            inflight_files += paths.size();
+            inflight.emplace_back(std::async(std::launch::async, [read_file](std::vector<std::string> ps) {
+                std::vector<FileData> v;
+                for (auto &p_ : ps)
+                    v.emplace_back(read_file(p_));
+                return v;
+            }, std::move(paths)));
             inflight_sz.push_back(sz);
             inflight_bytes += sz;
-            ++next_launch;
         }
     };
 
@@ -1013,10 +1037,17 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         }
         double t0 = now();
         launch();
-        FileData fd = inflight.front().get();
-        inflight.pop_front();
-        inflight_bytes -= inflight_sz.front();
-        inflight_sz.pop_front();
+        if (ready.empty()) {
+            for (FileData &f_ : inflight.front().get())
+                ready.emplace_back(std::move(f_));
+            inflight.pop_front();
+            inflight_bytes -= inflight_sz.front();
+            inflight_sz.pop_front();
+            inflight_files -= inflight_n.front();
+            inflight_n.pop_front();
+        }
+        FileData fd = std::move(ready.front());
+        ready.pop_front();
         launch();
         if (!fd.opened) {
             I.err("Cannot open file: " + sf.second);

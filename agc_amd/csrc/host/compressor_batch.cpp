@@ -72,8 +72,13 @@ void CAGCCompressor::Impl::z_main()
             }
             z_busy = true;
         }
-        agc_hip_zstd17_background(hip, z_caller_waits.load() ? 0 : 1); // beside the steps: leave the LDS to the scan
-        run_jobs_round(batch);
+        if (entropy_stream && !heavy_steps.load() && host_only_batch(batch)) {
+            run_host_stream(std::move(batch)); // (publishes every part as it is finished)
+            batch.clear();
+        } else {
+            agc_hip_zstd17_background(hip, z_caller_waits.load() ? 0 : 1); // beside the steps: leave the LDS to the scan
+            run_jobs_round(batch);
+        }
         for (ZJob &j : batch) {
             st.zstd_in += j.data.size();
             st.zstd_out += j.out.size();
@@ -88,6 +93,121 @@ void CAGCCompressor::Impl::z_main()
         }
         z_idle_cv.notify_all();
     }
+}
+
+// A batch run_jobs_round would hand to the host pool whole: no device entropy stage, or fewer device-size jobs than a launch is
+// worth (the rule of run_jobs_round: dev_jobs.size() < gpu_zstd_min).
+bool CAGCCompressor::Impl::host_only_batch(const std::vector<ZJob> &jobs) const
+{
+    if (!gpu_zstd)
+        return true;
+    const uint32_t dev_max = agc_hip_zstd17_max_input();
+    size_t n_refs = 0, n_packs = 0;
+    for (const ZJob &j : jobs) {
+        n_refs += j.kind == 0 && !j.data.empty() && j.data.size() <= 65536;
+        n_packs += j.kind == 1 && !j.data.empty() && j.data.size() <= dev_max;
+    }
+    const bool refs_too = gpu_zstd_refs_min && n_refs >= gpu_zstd_refs_min;
+    return n_packs + (refs_too ? n_refs : 0) < gpu_zstd_min;
+}
+
+// add_to_archive / add_to_archive_tuples / store_in_archive(ref) on the host (segment.h:172-255): one job, libzstd
+void CAGCCompressor::Impl::host_compress(ZJob &j, unsigned tid)
+{
+    ZstdCtx &z = *zctx[tid];
+    const bytes_t *src = &j.data;
+    bytes_t tuples;
+    int level = 17;
+    uint8_t marker = 0;
+    if (j.kind == 0) {
+        if (!j.repetitive) {
+            if (!j.staged.empty())
+                src = &j.staged; // (packed for the device, which then left it to the pool)
+            else {
+                bytes2tuples(j.data, tuples);
+                src = &tuples;
+            }
+            level = 13;
+            marker = 1;
+        } else
+            level = 19;
+    }
+    const size_t bound = zstd.compressBound(src->size());
+    bytes_t packed(bound + 1);
+    const uint32_t ps = (uint32_t)z.compress(packed.data(), bound, src->data(), src->size(), level);
+    packed[ps] = marker;
+    if (ps + 1u < (uint32_t)j.data.size()) {
+        packed.resize((size_t)ps + 1);
+        j.out = std::move(packed);
+        j.meta = j.data.size();
+    } else {
+        j.out = j.data;
+        j.meta = 0;
+    }
+}
+
+// Host-only batches (collections of small genomes, packs beyond one zstd block): a pack of a few hundred KB is a few tenths of a
+// second of level 17 for ONE thread, and a registration fills only a few packs -- a parallel_for per batch leaves most of the
+// pool idle behind its longest job while the next batches queue up (configs[1]: 6 batches of 1, 3, 5, 6, 21 jobs one after the
+// other).  Here the pool's threads take jobs from one list that later batches join as they are submitted; the stream ends when
+// every thread is idle and the queue holds nothing for it.  The parts were given their places in the archive at submission
+// (PartSlot), so the order of completion is free.
+void CAGCCompressor::Impl::run_host_stream(std::vector<ZJob> &&first)
+{
+    const double t0 = now();
+    std::deque<ZJob> pending;
+    const unsigned nw = zpool->size();
+    unsigned waiting = 0;
+    bool done = false, stop_pulling = false;
+    auto push_batch = [&](std::vector<ZJob> &b) { // longest jobs first (the tail is then made of short ones)
+        std::stable_sort(b.begin(), b.end(), [](const ZJob &x, const ZJob &y) { return x.data.size() > y.data.size(); });
+        for (ZJob &j : b)
+            pending.emplace_back(std::move(j));
+        b.clear();
+    };
+    push_batch(first);
+    zpool->parallel_for(nw, [&](size_t, unsigned tid) {
+        std::unique_lock<std::mutex> lk(z_mtx);
+        for (;;) {
+            while (!stop_pulling && !z_queue.empty()) {
+                if (!host_only_batch(z_queue.front())) { // the device's: the stream ends first
+                    stop_pulling = true;
+                    break;
+                }
+                push_batch(z_queue.front());
+                z_queue.pop_front();
+                z_cv.notify_all();
+            }
+            if (!pending.empty()) {
+                ZJob j = std::move(pending.front());
+                pending.pop_front();
+                lk.unlock();
+                host_compress(j, tid);
+                const uint64_t n_in = j.data.size(), n_out = j.out.size();
+                j.slot->out = std::move(j.out);
+                j.slot->meta = j.meta;
+                j.slot->ready.store(true, std::memory_order_release);
+                bytes_t().swap(j.data);
+                lk.lock();
+                st.zstd_in += n_in;
+                st.zstd_out += n_out;
+                continue;
+            }
+            if (done)
+                return;
+            if (waiting + 1 == nw) { // everybody else is idle too
+                done = true;
+                z_cv.notify_all();
+                return;
+            }
+            ++waiting;
+            z_cv.wait(lk, [&] { return done || !pending.empty() || (!stop_pulling && !z_queue.empty()); });
+            --waiting;
+        }
+    });
+    const double dt = now() - t0;
+    st.t_zstd_host += dt;
+    st.t_zstd += dt;
 }
 
 void CAGCCompressor::Impl::z_wait_all()
@@ -279,7 +399,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     static const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
     double lt = t0;
     auto LAP = [&](const char *what) {
-        if (laps && jobs.size() > 1000)
+        if (laps && jobs.size() > 0)
             std::cerr << "    entropy lap " << what << " " << (now() - lt) * 1e3 << " ms\n";
         lt = now();
     };
@@ -416,7 +536,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         if (jobs[i].kind == 1)
             host_bytes += jobs[i].data.size();
     double t_dev = 0, t_host = 0;
-    if (laps && jobs.size() > 1000) {
+    if (laps && jobs.size() > 0) {
         uint64_t nb[4] = {0, 0, 0, 0}, nc[4] = {0, 0, 0, 0};
         for (const ZJob &j : jobs) {
             const int c = j.kind == 0 ? 0 : j.data.size() > dev_max ? 1 : j.data.size() > 16384 ? 2 : 3;
@@ -494,29 +614,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     // (... when that thread has human-size samples to drive; a collection of small genomes leaves it idle most of the time)
     const unsigned host_workers = all_bytes < (64u << 20) && heavy_steps && !z_caller_waits.load() ? std::max(2u, zpool->size() / 4) : zpool->size();
     zpool->parallel_for(host_jobs.size(), [&](size_t hi, unsigned tid) {
-        ZJob &j = jobs[host_jobs[hi]];
-        ZstdCtx &z = *zctx[tid];
-        const bytes_t *src = &j.data;
-        bytes_t tuples;
-        int level = 17;
-        uint8_t marker = 0;
-        if (j.kind == 0) {
-            if (!j.repetitive) {
-                if (!j.staged.empty())
-                    src = &j.staged; // (packed for the device, which then left it to the pool)
-                else {
-                    bytes2tuples(j.data, tuples);
-                    src = &tuples;
-                }
-                level = 13;
-                marker = 1;
-            } else
-                level = 19;
-        }
-        size_t bound = zstd.compressBound(src->size());
-        bytes_t packed(bound + 1);
-        uint32_t ps = (uint32_t)z.compress(packed.data(), bound, src->data(), src->size(), level);
-        finish(j, packed, ps, marker);
+        host_compress(jobs[host_jobs[hi]], tid);
     }, host_workers);
     t_host = now() - th0;
     st.t_zstd_host += t_host;

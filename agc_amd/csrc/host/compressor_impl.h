@@ -478,13 +478,16 @@ public:
         // a regular file that does not start with the gzip magic is read directly
         struct stat st;
         int h = ::open(fn.c_str(), O_RDONLY);
+        uint64_t gz_size = ~0ull; // (the size of a regular file that turns out to be gzip)
         if (h >= 0 && fstat(h, &st) == 0 && S_ISREG(st.st_mode)) {
+            gz_size = (uint64_t)st.st_size;
             uint8_t magic[2] = {0, 0};
             const ssize_t r = ::pread(h, magic, 2, 0);
             if (!(r == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
                 fd = h;
                 remaining = (uint64_t)st.st_size;
-                buf.resize(16 << 20);
+                // (the block buffer is zero-filled memory: 16 MiB of it for a 30 kb genome was most of the time to read one)
+                buf.resize((size_t)std::min<uint64_t>(16u << 20, std::max<uint64_t>(remaining + 1, 4096)));
                 pos = filled = 0;
                 return true;
             }
@@ -494,8 +497,8 @@ public:
         f = gzopen(fn.c_str(), "rb");
         if (!f)
             return false;
-        gzbuffer(f, 1 << 20);
-        buf.resize(16 << 20);
+        gzbuffer(f, (unsigned)std::min<uint64_t>(1u << 20, std::max<uint64_t>(gz_size, 8192)));
+        buf.resize((size_t)std::min<uint64_t>(16u << 20, std::max<uint64_t>(gz_size < (1u << 20) ? gz_size * 8 : ~0ull, 65536)));
         pos = filled = 0;
         return true;
     }
@@ -1041,6 +1044,10 @@ struct CAGCCompressor::Impl {
     void finish_groups();
     void run_jobs(std::vector<ZJob> &jobs, bool add_parts = true);
     void run_jobs_round(std::vector<ZJob> &jobs);
+    bool host_only_batch(const std::vector<ZJob> &jobs) const; // run_jobs_round would leave every job of it to the host pool
+    void host_compress(ZJob &j, unsigned tid);                 // one job through libzstd (zctx[tid])
+    void run_host_stream(std::vector<ZJob> &&first);           // z_main: host-only batches without a barrier between them
+    bool entropy_stream = true;                                // (AGC_AMD_ENTROPY_STREAM=0: a parallel_for per batch, as before)
     void build_close_jobs(std::vector<ZJob> &jobs);
     void store_open_batch(bool flush = true);
     // Close in steps (multi-GPU entropy stage, compressor.h: CloseCollectPacks / CloseProvideFrames)

@@ -164,3 +164,15 @@ if [ "$PART" = z ]; then
   bash scripts/profile_round.sh r5/z_prof > $OUT/z_profile_round.log 2>&1; tail -3 $OUT/z_profile_round.log
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/z_bench_driver_cmd.json 2> $OUT/z_bench_driver_cmd.err; show $OUT/z_bench_driver_cmd.json
 fi
+if [ "$PART" = y ]; then
+  # the host entropy stage without a barrier between batches (AGC_AMD_ENTROPY_STREAM), configs[1]; where the fixed start goes
+  timeout 120 python scripts/start_cost.py > $OUT/y_start_cost.log 2>&1; cat $OUT/y_start_cost.log
+  AGC_AMD_ENTROPY_STREAM=0 timeout 300 python bench.py --config c1 > $OUT/y_bench_config_c1_batches.json 2> /dev/null; show $OUT/y_bench_config_c1_batches.json
+  timeout 300 python bench.py --config c1 > $OUT/y_bench_config_c1.json 2> /dev/null; show $OUT/y_bench_config_c1.json
+  timeout 300 python bench.py --config c4twin > $OUT/y_bench_config_c4twin.json 2> /dev/null; show $OUT/y_bench_config_c4twin.json
+fi
+if [ "$PART" = x ]; then
+  # the config lines again: host entropy stream, small read buffers, grouped small files
+  for c in c1 c4twin c5twin; do timeout 300 python bench.py --config $c > $OUT/x_bench_config_$c.json 2> /dev/null; show $OUT/x_bench_config_$c.json; done
+  timeout 900 python bench.py --config c5slice > $OUT/x_bench_config_c5slice.json 2> $OUT/x_bench_config_c5slice.err; show $OUT/x_bench_config_c5slice.json
+fi

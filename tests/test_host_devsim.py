@@ -188,6 +188,21 @@ def test_switch_combinations_keep_the_archive(cli, name, env, tmp_path, monkeypa
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
+@pytest.mark.parametrize("stream", ["1", "0"])
+@pytest.mark.parametrize("name", ["syn_c5_twin", "syn_snp"])
+def test_entropy_batches_with_and_without_the_stream(cli, name, stream, tmp_path, monkeypatch):
+    """host-only entropy batches (a few packs per window of a small collection) are streamed through the pool without a barrier
+    between them (run_host_stream: later batches join the list while earlier jobs are still being compressed, parts finish in
+    any order); AGC_AMD_ENTROPY_STREAM=0 is the parallel_for per batch of before.  Windows of two files: many small batches.
+    The many files of these collections also go through the grouped small-file reader (eight per task)."""
+    monkeypatch.setenv("AGC_AMD_ENTROPY_STREAM", stream)
+    monkeypatch.setenv("AGC_AMD_WINDOW_MAX", "2")
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_adaptive", "syn_c5_twin"])  # (+ the configs[2] twin on the GPU: tests/test_gpu_archive.py)
 def test_whole_sample_encode_from_the_device_descriptors_for_small_samples_too(cli, name, tmp_path, monkeypatch):
     """AGC_AMD_DEV_ENCODE_MIN=0 + AGC_AMD_WINDOW_MAX=1: every sample, however few segments it has, takes the path the 3 Gbp samples
