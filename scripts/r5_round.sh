@@ -176,3 +176,10 @@ if [ "$PART" = x ]; then
   for c in c1 c4twin c5twin; do timeout 300 python bench.py --config $c > $OUT/x_bench_config_$c.json 2> /dev/null; show $OUT/x_bench_config_$c.json; done
   timeout 900 python bench.py --config c5slice > $OUT/x_bench_config_c5slice.json 2> $OUT/x_bench_config_c5slice.err; show $OUT/x_bench_config_c5slice.json
 fi
+if [ "$PART" = w ]; then
+  # the round's last host code: every GPU test, smoke, fuzz through the real kernels, the driver's bench line
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/w_gpu_tests.log 2>&1; tail -n 3 $OUT/w_gpu_tests.log
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/w_smoke.log 2>&1; tail -n 2 $OUT/w_smoke.log
+  timeout 400 python scripts/fuzz_archives.py --from 9500 --count 60 > $OUT/w_fuzz_gpu_60_cases.log 2>&1; tail -n 2 $OUT/w_fuzz_gpu_60_cases.log
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/w_bench_driver_cmd.json 2> $OUT/w_bench_driver_cmd.err; show $OUT/w_bench_driver_cmd.json
+fi
