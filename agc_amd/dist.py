@@ -32,23 +32,42 @@ import time
 import numpy as np
 
 
-def concatenated_units(contig_names_per_file, pack_cardinality):
+def concatenated_units(contig_names_per_file, pack_cardinality, already=0, seen=()):
     """-c mode.  contig_names_per_file: for every input file, in command-line order, the names of its contigs.
     -> list of units; a unit = list of (file index, contig index) in order.  A contig whose name was seen before is skipped as the
     reference skips it ("already in the archive", agc_compressor.cpp:2201-2205); the last unit is what is left (possibly empty):
-    the registration token the reference sends after the last file."""
-    units, cur, seen = [], [], set()
+    the registration token the reference sends after the last file.
+    append: `already` = samples of the input archive modulo the pack cardinality -- the first unit completes the batch the archive
+    ended in (agc_compressor.cpp:2150-2153: processed_samples starts at the collection's sample count) -- and `seen` = the contig
+    names it holds (archive_contig_names)."""
+    units, cur, seen = [], [], set(seen)
+    fill = int(already) % pack_cardinality
     for fi, names in enumerate(contig_names_per_file):
         for ci, name in enumerate(names):
             if name in seen:
                 continue
             seen.add(name)
             cur.append((fi, ci))
-            if len(cur) >= pack_cardinality:
+            fill += 1
+            if fill >= pack_cardinality:
                 units.append(cur)
-                cur = []
+                cur, fill = [], 0
     units.append(cur)
     return units
+
+
+def archive_contig_names(path):
+    """(number of samples, names of all contigs, pack cardinality) of an archive: what `append -c` continues from
+    (concatenated_units)"""
+    from . import reader
+    f = reader.CAGCFile()
+    if not f.Open(path, False):
+        raise RuntimeError("cannot open " + path)
+    samples = f.ListSample()
+    names = [c for s in samples for c in f.ListCtg(s)]
+    b = (f.GetParams() or {}).get("pack_cardinality")
+    f.Close()
+    return len(samples), names, b
 
 
 class DistCompressor:

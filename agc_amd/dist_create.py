@@ -5,7 +5,8 @@
 
 Options as `agc create`.  Rank r reads, uploads and classifies the files r, r+N, ... (-c: the registration units r, r+N, ... --
 runs of -b contigs across the files); rank 0 writes the archive, which is
-(--append in.agc: every rank loads in.agc, all files are new samples, k / l / s / b come from the archive, as `agc append`)
+(--append in.agc: every rank loads in.agc, all files are new samples, k / l / s / b come from the archive, as `agc append`;
+with -c the first unit completes the batch in.agc ended in)
 byte-identical to what the single-GPU `agc_amd create` and the reference CLI write for the same command line."""
 import argparse
 import os
@@ -26,14 +27,11 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (ranks may share a GPU)")
     ap.add_argument("files", nargs="+")
     a = ap.parse_args(argv)
-    if a.append and a.c:
-        ap.error("--append with -c: the registration units continue the input archive's last batch; use the single-GPU `agc_amd append -c`")
-
     import numpy as np
     import torch
     import torch.distributed as dist
     from agc_amd import fasta, host
-    from agc_amd.dist import DistCompressor, concatenated_units
+    from agc_amd.dist import DistCompressor, archive_contig_names, concatenated_units
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
@@ -69,7 +67,9 @@ def main(argv=None):
     n_units = len(files)
     if a.c:
         # the reference's registration units: runs of -b contigs across the files, every contig a sample of its own (sample name "")
-        units = concatenated_units([fasta.read_codes(f)[0] for f in files], a.b)
+        # (append: the first unit completes the batch the input archive ended in; its contigs are not taken again)
+        n0, names0, b0 = archive_contig_names(a.append) if a.append else (0, (), None)
+        units = concatenated_units([fasta.read_codes(f)[0] for f in files], b0 or a.b, already=n0, seen=names0)
         n_units = len(units)
 
         def get_sample(i):  # noqa: F811

@@ -72,8 +72,9 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
         keep = {}
         units = None
         if "-c" in args:  # the reference's registration units: runs of -b contigs across the files, sample name ""
-            from agc_amd.dist import concatenated_units
-            units = concatenated_units([fasta_codes(f)[0] for f in files], opt["-b"])
+            from agc_amd.dist import archive_contig_names, concatenated_units
+            n0, names0, b0 = archive_contig_names(append_to) if append_to is not None else (0, (), None)
+            units = concatenated_units([fasta_codes(f)[0] for f in files], b0 or opt["-b"], already=n0, seen=names0)
 
         def get_sample(i):
             if units is not None:
@@ -201,7 +202,8 @@ def test_concatenated_mode_from_n_ranks_equals_the_reference(name, world, prefet
     _run(name, world, tmp_path, on_gpu=False, prefetch=prefetch)
 
 
-@pytest.mark.parametrize("plan,world", [("snp_4_3", 2), ("mixed_3_3", 2), ("viral_25_15", 3), ("shuffled_2_4", 2), ("adaptive_3_4", 2)])
+@pytest.mark.parametrize("plan,world", [("snp_4_3", 2), ("mixed_3_3", 2), ("viral_25_15", 3), ("shuffled_2_4", 2), ("adaptive_3_4", 2),
+                                        ("viral_c_1_1", 2), ("adaptive_c_4_3", 2)])  # (the last two: append together with -c)
 def test_append_from_n_ranks_equals_the_reference(plan, world, tmp_path):
     """`append` in the N-rank mode: every rank loads the input archive (groups packed, references decoded into its own HBM when a
     record first adds to a group -- apply_record unpacks exactly where the owner's registration does), samples are prepared at
