@@ -242,7 +242,7 @@ def test_one_archive_from_n_ranks_on_the_gpu(name, world, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["syn_mixed", "syn_viral_c", "append:mixed_3_3"])
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_viral_c", "append:mixed_3_3", "append:viral_c_1_1"])
 def test_dist_create_front_end_on_the_gpu(name, tmp_path):
     """python -m agc_amd.dist_create under torch.distributed.run, two ranks sharing cuda:0 (gloo): the user-facing multi-GPU create
     (syn_viral_c: -c, the registration units of the concatenated mode dealt over the ranks; append:<plan>: --append onto the archive
