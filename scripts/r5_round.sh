@@ -183,3 +183,9 @@ if [ "$PART" = w ]; then
   timeout 400 python scripts/fuzz_archives.py --from 9500 --count 60 > $OUT/w_fuzz_gpu_60_cases.log 2>&1; tail -n 2 $OUT/w_fuzz_gpu_60_cases.log
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/w_bench_driver_cmd.json 2> $OUT/w_bench_driver_cmd.err; show $OUT/w_bench_driver_cmd.json
 fi
+if [ "$PART" = v ]; then
+  # last evidence on the round's last code: every device frame of the bench's Close against libzstd; fuzz flavours through the real kernels
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --verify-entropy > $OUT/v_bench_verify_entropy.json 2> $OUT/v_bench_verify_entropy.log; grep -h "verify" $OUT/v_bench_verify_entropy.log | tail -n 3
+  timeout 240 python scripts/fuzz_archives.py --many --from 9700 --count 20 > $OUT/v_fuzz_gpu_many_20_cases.log 2>&1; tail -n 1 $OUT/v_fuzz_gpu_many_20_cases.log
+  timeout 240 python scripts/fuzz_archives.py --big --from 9800 --count 15 > $OUT/v_fuzz_gpu_big_15_cases.log 2>&1; tail -n 1 $OUT/v_fuzz_gpu_big_15_cases.log
+fi
