@@ -189,3 +189,10 @@ if [ "$PART" = v ]; then
   timeout 240 python scripts/fuzz_archives.py --many --from 9700 --count 20 > $OUT/v_fuzz_gpu_many_20_cases.log 2>&1; tail -n 1 $OUT/v_fuzz_gpu_many_20_cases.log
   timeout 240 python scripts/fuzz_archives.py --big --from 9800 --count 15 > $OUT/v_fuzz_gpu_big_15_cases.log 2>&1; tail -n 1 $OUT/v_fuzz_gpu_big_15_cases.log
 fi
+if [ "$PART" = u ]; then
+  # the FASTA conversion's stream at the lowest priority (it runs two samples ahead: only idle slots), alternating with the default
+  for i in 1 2; do
+    AGC_HIP_PACK_LOW_PRIORITY=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/u_bench_pack_low_priority_$i.json 2> /dev/null; show $OUT/u_bench_pack_low_priority_$i.json
+    timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/u_bench_pack_default_priority_$i.json 2> /dev/null; show $OUT/u_bench_pack_default_priority_$i.json
+  done
+fi
