@@ -196,3 +196,10 @@ if [ "$PART" = u ]; then
     timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/u_bench_pack_default_priority_$i.json 2> /dev/null; show $OUT/u_bench_pack_default_priority_$i.json
   done
 fi
+if [ "$PART" = t ]; then
+  # kernel timeline of the driver's command: start / end of every kernel, for the busy / idle accounting of a step (scripts/step_timeline.py)
+  export TMPDIR=/tmp; ROOT=$(pwd)
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/t_ktrace -o kt -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/$OUT/t_ktrace.log 2>&1)
+  tail -n 1 $OUT/t_ktrace.log | cut -c1-200
+  find $OUT/t_ktrace -name "*kernel_trace.csv" -exec ls -la {} \;
+fi
