@@ -190,7 +190,7 @@ if [ "$PART" = v ]; then
   timeout 240 python scripts/fuzz_archives.py --big --from 9800 --count 15 > $OUT/v_fuzz_gpu_big_15_cases.log 2>&1; tail -n 1 $OUT/v_fuzz_gpu_big_15_cases.log
 fi
 if [ "$PART" = u ]; then
-  # the FASTA conversion's stream at the lowest priority (it runs two samples ahead: only idle slots), alternating with the default
+  # the FASTA conversion's stream at the lowest priority (AGC_HIP_PACK_LOW_PRIORITY existed for this call only: profiles/EXPERIMENTS.md; not kept)
   for i in 1 2; do
     AGC_HIP_PACK_LOW_PRIORITY=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/u_bench_pack_low_priority_$i.json 2> /dev/null; show $OUT/u_bench_pack_low_priority_$i.json
     timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/u_bench_pack_default_priority_$i.json 2> /dev/null; show $OUT/u_bench_pack_default_priority_$i.json
@@ -202,4 +202,12 @@ if [ "$PART" = t ]; then
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/t_ktrace -o kt -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/$OUT/t_ktrace.log 2>&1)
   tail -n 1 $OUT/t_ktrace.log | cut -c1-200
   find $OUT/t_ktrace -name "*kernel_trace.csv" -exec ls -la {} \;
+fi
+if [ "$PART" = s ]; then
+  # the conversion as a few blocks per CU walking the tiles (AGC_HIP_PACK_BLOCKS_PER_CU existed for this call only: profiles/EXPERIMENTS.md; reverted)
+  timeout 200 python -m pytest tests/test_gpu_scan.py -m gpu -x -q -k "pack_fasta" > $OUT/s_pack_tests.log 2>&1; tail -n 2 $OUT/s_pack_tests.log
+  for n in 2 1000; do AGC_HIP_PACK_BLOCKS_PER_CU=$n timeout 100 python scripts/pack_alone.py 3.0 0 > $OUT/s_pack_alone_$n.log 2>&1; echo "per CU $n:"; tail -n 2 $OUT/s_pack_alone_$n.log; done
+  for i in 1 2; do for n in 2 1000 1 4; do
+    AGC_HIP_PACK_BLOCKS_PER_CU=$n timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/s_bench_pack_${n}_per_cu_$i.json 2> /dev/null; show $OUT/s_bench_pack_${n}_per_cu_$i.json
+  done; done
 fi
