@@ -383,3 +383,16 @@ def test_one_sided_groups_minted_between_prepare_and_commit_and_an_empty_sample(
     got, n2 = _edge_run(world, tmp_path, True, f"w{world}")
     assert n2 == n_groups
     assert got == want
+
+
+def test_concatenated_units_continue_the_input_archive():
+    """-c mode, pure bookkeeping: units of -b contigs across the files, duplicates skipped, the closing (possibly empty) unit; with an
+    input archive (append) the first unit completes the batch it ended in and its contigs are not taken again
+    (agc_compressor.cpp:2150-2153, 2201-2205)"""
+    from agc_amd.dist import concatenated_units
+    names = [["a", "b", "c"], ["d", "b", "e", "f"], ["g"]]
+    assert concatenated_units(names, 3) == [[(0, 0), (0, 1), (0, 2)], [(1, 0), (1, 2), (1, 3)], [(2, 0)]]
+    assert concatenated_units(names, 7) == [[(0, 0), (0, 1), (0, 2), (1, 0), (1, 2), (1, 3), (2, 0)], []]
+    # five samples in the archive, -b 3: two more complete its second batch; "c" is in the archive already
+    assert concatenated_units(names, 3, already=5, seen=["c", "x"]) == [[(0, 0)], [(0, 1), (1, 0), (1, 2)], [(1, 3), (2, 0)]]
+    assert concatenated_units([[]], 4, already=8) == [[]]
