@@ -411,6 +411,12 @@ int agc_hip_create(agc_hip_ctx **out, int device)
     if (!out)
         return AGC_HIP_EINVAL;
     *out = nullptr;
+    // The ROCm runtime maps the HIP streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context has eight
+    // streams (steps, two encode lanes, scan prefetch, FASTA pack, two entropy streams + the caller's): on four queues they share, and a
+    // wait on an idle stream lasts until the kernels of the stream it shares a queue with are done (measured: pack_fasta_end's
+    // hipStreamSynchronize 1 ms behind the followers' encode, profiles/r6/).  Only effective when this is the process's first HIP call
+    // (the CLI); a Python caller that initialises HIP first sets the variable itself (bench.py does).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
         return AGC_HIP_ENODEV;

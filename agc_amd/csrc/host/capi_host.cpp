@@ -117,6 +117,12 @@ int agc_cmp_set_next_sample_packed_dev(void *h, const void *packed, const uint64
 {
     return ((CAGCCompressor *)h)->SetNextSamplePackedDevice(packed, ctg_off, n_ctg) ? 1 : 0;
 }
+int agc_cmp_set_next_fasta_dev(void *h, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *raw_begin, const uint64_t *raw_end, uint32_t n_ctg,
+                               uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks)
+{
+    return ((CAGCCompressor *)h)->SetNextFastaDevice(d_raw, n_raw, raw_begin, raw_end, n_ctg, d_words, d_esc_index, d_esc_bytes, esc_cap_blocks) ? 1 : 0;
+}
+int agc_cmp_finish_fasta_dev(void *h, uint64_t *ctg_off, uint64_t *n_esc_blocks) { return ((CAGCCompressor *)h)->FinishFastaDevice(ctg_off, n_esc_blocks); }
 int agc_cmp_commit_prepared(void *h) { return ((CAGCCompressor *)h)->CommitPrepared() ? 1 : 0; }
 int agc_cmp_commit_prepared_head(void *h) { return ((CAGCCompressor *)h)->CommitPreparedHead() ? 1 : 0; }
 int agc_cmp_commit_prepared_finish(void *h) { return ((CAGCCompressor *)h)->CommitPreparedFinish() ? 1 : 0; }

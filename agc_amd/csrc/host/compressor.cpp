@@ -159,6 +159,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         I.async_book = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_ASYNC_ENCODE"))
         I.async_encode = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_EARLY_COLLECT"))
+        I.early_collect = atoi(e) != 0;
     I.enc_alt.ctx = I.enc_alt2.ctx = I.hip;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
@@ -350,6 +352,8 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         I.async_book = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_ASYNC_ENCODE"))
         I.async_encode = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_EARLY_COLLECT"))
+        I.early_collect = atoi(e) != 0;
     I.enc_alt.ctx = I.enc_alt2.ctx = I.hip;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
@@ -650,9 +654,51 @@ bool CAGCCompressor::Impl::pack_sample(const uint8_t *d_codes, uint64_t n_symbol
     return hip_ok(DEVT(agc_hip_sample_pack(hip, d_codes, n_symbols, &packed_sample)), "sample_pack");
 }
 
+bool CAGCCompressor::SetNextFastaDevice(const uint8_t *d_raw, uint64_t n_raw, const uint64_t *raw_begin, const uint64_t *raw_end, uint32_t n_ctg,
+                                        uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks)
+{
+    Impl &I = *p;
+    if (!I.created || I.fasta_next.live || (n_ctg && (!raw_begin || !raw_end)))
+        return false;
+    Impl::FastaNext &f = I.fasta_next;
+    f.d_raw = d_raw;
+    f.n_raw = n_raw;
+    f.rb.assign(raw_begin, raw_begin + n_ctg);
+    f.re.assign(raw_end, raw_end + n_ctg);
+    f.d_words = d_words;
+    f.d_idx = d_esc_index;
+    f.d_esc = d_esc_bytes;
+    f.esc_cap = esc_cap_blocks;
+    f.valid = true;
+    return true;
+}
+
+bool CAGCCompressor::Impl::launch_fasta()
+{
+    FastaNext &f = fasta_next;
+    if (!f.valid)
+        return true;
+    f.valid = false;
+    const int rc = agc_hip_pack_fasta_begin(hip, f.d_raw, f.n_raw, f.rb.data(), f.re.data(), (uint32_t)f.rb.size(), f.d_words, f.d_idx, f.d_esc, f.esc_cap);
+    f.live = rc == AGC_HIP_OK;
+    return hip_ok(rc, "pack_fasta_begin");
+}
+
+int CAGCCompressor::FinishFastaDevice(uint64_t *ctg_off, uint64_t *n_esc_blocks)
+{
+    Impl &I = *p;
+    if (!I.created || (!I.fasta_next.valid && !I.fasta_next.live))
+        return AGC_HIP_EINVAL;
+    if (I.fasta_next.valid && !I.launch_fasta())
+        return AGC_HIP_EINVAL;
+    I.fasta_next.live = false;
+    return agc_hip_pack_fasta_end(I.hip, ctg_off, n_esc_blocks);
+}
+
 // queues the announced sample's scan on the device (called once the current sample's own classification kernels are in)
 void CAGCCompressor::Impl::launch_prefetch()
 {
+    (void)launch_fasta(); // (a conversion that does not start is reported by FinishFastaDevice)
     if (!pf_next.valid)
         return;
     pf_next.valid = false;
@@ -804,7 +850,7 @@ bool CAGCCompressor::CommitPreparedHead()
         // a sample without contigs registers nothing (the reference warns and skips such a file, agc_compressor.cpp:2187-2195);
         // the other ranks still expect one record per sample: an empty one
         if (I.dist_world > 1)
-            I.make_empty_record();
+            return I.make_empty_record();
         return true;
     }
     // Any group minted since PrepareSampleDevice -- also one keyed (k-mer, NO_KMER), which has no terminator entry and is

@@ -122,6 +122,17 @@ public:
     // from the queue while earlier ones register (agc_compressor.cpp:1093-1272).  The announced sample must then be the next one
     // added (otherwise the work is dropped); not used in adaptive mode (new splitters change later scans).
     bool SetNextSamplePackedDevice(const void *packed, const uint64_t *ctg_off, uint32_t n_ctg);
+    // A sample that is still the bytes of its FASTA file in HBM (contig c = raw bytes [raw_begin[c], raw_end[c]): its sequence
+    // lines), to become a packed sample in the caller's buffers (include/agc_hip.h: agc_hip_pack_fasta_begin -- the reference's
+    // preprocess_raw_contig, agc_compressor.cpp:907-951, fused with the 2-bit packing).  The conversion is QUEUED BY THE COMPRESSOR at
+    // the point of the sample in progress where the GPU has room for it (with the announced scan: after the classification
+    // kernels, beside the registration's host work) -- the reference's reader thread likewise runs ahead of its workers
+    // (agc_compressor.cpp:2155-2238).  FinishFastaDevice waits for it (and queues it first when no sample call came in between)
+    // and returns the contigs' symbol offsets (n_ctg + 1) and the number of escaped blocks; its result is agc_hip_pack_fasta_end's
+    // (AGC_HIP_OK, AGC_HIP_ECAP: announce again with an escape buffer of *n_esc_blocks blocks, ...).  One conversion at a time.
+    bool SetNextFastaDevice(const uint8_t *d_raw, uint64_t n_raw, const uint64_t *raw_begin, const uint64_t *raw_end, uint32_t n_ctg, uint32_t *d_words,
+                            int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks);
+    int FinishFastaDevice(uint64_t *ctg_off, uint64_t *n_esc_blocks);
 
     // src/core/agc_compressor.cpp:2094-2115 (close_compression) + ~CArchive
     bool Close(uint32_t no_threads);

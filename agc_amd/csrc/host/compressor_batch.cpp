@@ -283,7 +283,7 @@ void CAGCCompressor::Impl::book_main()
                 }
             }
             if (ok) {
-                uint64_t cap = std::max<uint64_t>(enc.size(), text / 64 + (1u << 16));
+                uint64_t cap = std::max<uint64_t>(enc.size(), text / 64 + text / 512 + (1u << 16));
                 for (;;) {
                     if (!enc.resize(cap, false)) {
                         err("out of memory (delta buffer)");
@@ -310,7 +310,64 @@ void CAGCCompressor::Impl::book_main()
                 delta_bytes += eoff[ne];
             }
         };
-        if (t->enc_pending)
+        if (t->early_only) {
+            // lane 0's deltas as they are, nothing mapped: the registration's own task does that (enc_collected)
+            const size_t ne = t->enc_n;
+            std::vector<uint64_t> eoff(ne + 1, 0);
+            uint32_t n_dev = 0;
+            ok = hip_ok(agc_hip_lz_encode_pending_on(hip, 0, &n_dev), "lz_encode_pending");
+            if (ok && n_dev != ne) {
+                err("internal: the device's encode delivers another number of deltas than the host expects");
+                ok = false;
+            }
+            if (ok) {
+                PinnedBytes &enc = *t->enc_dst;
+                uint64_t cap = std::max<uint64_t>(enc.size(), t->enc_text / 64 + t->enc_text / 512 + (1u << 16));
+                for (;;) {
+                    if (!enc.resize(cap, false)) {
+                        err("out of memory (delta buffer)");
+                        ok = false;
+                        break;
+                    }
+                    const int r = agc_hip_lz_encode_end_on(hip, 0, enc.data(), cap, eoff.data());
+                    if (r == AGC_HIP_ECAP) {
+                        cap = eoff[ne] + eoff[ne] / 8 + 4096;
+                        continue;
+                    }
+                    ok = hip_ok(r, "lz_encode_end");
+                    break;
+                }
+            }
+            lane2_release(0);
+            static const bool early_laps = getenv("AGC_AMD_LAPS") != nullptr;
+            if (early_laps)
+                std::cerr << "    book task (early): lane 0 collected in " << (now() - t0) * 1e3 << " ms\n";
+            t.reset();
+            {
+                std::lock_guard<std::mutex> lk(book_mtx);
+                early_enc.ok = ok;
+                early_enc.eoff.swap(eoff);
+                book_busy = false;
+                ++book_seq_done;
+                book_seconds += now() - t0;
+                if (ok)
+                    book_delta_bytes += early_enc.eoff[ne];
+                else
+                    book_failed = true;
+            }
+            book_idle_cv.notify_all();
+            continue;
+        }
+        if (t->enc_collected) {
+            const std::vector<uint32_t> &todo = t->enc_todo;
+            const uint8_t *base = t->enc_dst->data();
+            for (size_t i = 0; i < todo.size(); ++i) {
+                if (todo[i] == ~0u)
+                    continue;
+                t->cd.enc_ptr[todo[i]] = base + t->enc_eoff[i];
+                t->cd.enc_len[todo[i]] = (uint32_t)(t->enc_eoff[i + 1] - t->enc_eoff[i]);
+            }
+        } else if (t->enc_pending)
             collect(0, t->enc_todo, t->enc_text, *t->enc_dst);
         const double t_c0 = now();
         if (t->enc2_pending) {
@@ -1262,6 +1319,25 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
                 return 0;
             }
             st.lz_encoded += n_enc;
+            // The deltas are collected as soon as the kernel is done -- an early task of the bookkeeping thread, queued now -- when
+            // it is certain already that the registration's books are that thread's too (stage_store_finish: hand_over).  The lane
+            // is then free long before the next sample's launch asks for it (it used to be released by the registration's own
+            // task, a whole step later: 0.9 ms of "second lane free" per human-size sample) and that task starts with its deltas
+            // on the host.  enc_buf is nobody's until the hand-over swaps the buffer sets (bulk mode: spec_bytes == 0).
+            if (early_collect && dist_world == 1 && book_can_async(1) && b.spec_bytes == 0) {
+                uint64_t text = 0;
+                for (size_t i = 0; i < n_segs; ++i)
+                    if (is_known[i])
+                        text += dsegs[i].len;
+                std::unique_ptr<BookTask> t(new BookTask());
+                t->early_only = true;
+                t->enc_n = n_enc;
+                t->enc_text = text;
+                if (!enc_buf.ctx)
+                    enc_buf.ctx = hip;
+                t->enc_dst = &enc_buf;
+                b.early_seq = book_submit(std::move(t));
+            }
         }
         lap(b, "encode of the known segments launched");
     }
@@ -2209,7 +2285,8 @@ bool CAGCCompressor::Impl::stage_store_head(BatchState &b)
     }
     LAP("fetch_slices");
     if (dist_world > 1) {
-        make_record_head(b);
+        if (!make_record_head(b))
+            return false;
         LAP("record head");
     }
     return true;
@@ -2229,6 +2306,10 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
     // the previous registration's task is done with the second buffer set and with the device's second lane (long ago: it was
     // queued a whole step earlier)
     if (!book_wait_seq(last_own_seq))
+        return false;
+    // ... and the early collection of this sample's whole-sample encode (done since the kernel ended, a few ms ago)
+    const bool early_done = b.early_seq != 0 && b.dev_enc_n != 0;
+    if (b.early_seq != 0 && (!book_wait_seq(b.early_seq) || !early_enc.ok))
         return false;
     const bool hand_over = book_can_async(b.n_samples) && (dist_world == 1 || dist_rank == dist_writer);
     {
@@ -2275,7 +2356,14 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
         std::vector<uint64_t> eoff(ne + 1, 0);
         const uint64_t base = b.spec_bytes;
         uint64_t cap = std::max<uint64_t>(enc_buf.size() > base ? enc_buf.size() - base : 0, (uint64_t)1 << 16);
-        for (;;) {
+        if (early_done) { // (collected already, at the start of enc_buf: an early task is only queued with spec_bytes == 0)
+            if (base != 0 || early_enc.eoff.size() != ne + 1) {
+                err("internal: early collection of the encode does not match the registration");
+                return false;
+            }
+            eoff = early_enc.eoff;
+        }
+        for (; !early_done;) {
             if (!enc_buf.resize(base + cap)) {
                 err("out of memory (delta buffer)");
                 return false;
@@ -2297,7 +2385,8 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
                 sp.pending = -1;
             }
         b.spec_bytes = base + eoff[ne];
-        st.delta_bytes += eoff[ne];
+        if (!early_done) // (an early task's bytes are counted by the book thread)
+            st.delta_bytes += eoff[ne];
         b.dev_enc_n = 0;
         LAP("encode of the known segments collected");
     }
@@ -2427,6 +2516,15 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
         t->cd.fetched = &fetch_alt;
         if (!enc_later.empty()) {
             t->enc_pending = true;
+            if (bulk && early_done) { // the deltas are in enc_buf (enc_alt since the swap above) already
+                if (early_enc.eoff.size() != enc_later.size() + 1) {
+                    err("internal: early collection of the encode does not match the registration");
+                    return false;
+                }
+                t->enc_pending = false;
+                t->enc_collected = true;
+                t->enc_eoff.swap(early_enc.eoff);
+            }
             t->enc_todo = std::move(enc_later);
             t->enc_text = enc_later_text;
             // (the deltas encoded at commit time sit in enc_alt2 now; the device-launched encode of the whole sample is collected

@@ -67,7 +67,7 @@ struct RecReader {
 
 // The head: built in the first half of store_segments (stage_store_head) -- before the new references are indexed on this GPU and
 // before any leftover delta is encoded -- so that the other ranks can go on as early as possible.
-void CAGCCompressor::Impl::make_record_head(BatchState &b)
+bool CAGCCompressor::Impl::make_record_head(BatchState &b)
 {
     const std::vector<Contig> &ctgs = *b.ctgs;
     const std::vector<Placed> &placed = placed_buf;
@@ -93,7 +93,7 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
     need += 21 * sto.new_ref_items.size() + 4 * sto.raw_items.size() + (sto.fetched_off.empty() ? 0 : sto.fetched_off.back());
     if (!dist_record_buf.resize(DIST_FRAME + need + need / 8 + 64, false)) {
         err("out of memory (commit record)");
-        return;
+        return false;
     }
     uint8_t *w = dist_record_ptr();
     auto w32 = [&](uint32_t x) {
@@ -157,6 +157,7 @@ void CAGCCompressor::Impl::make_record_head(BatchState &b)
         }
     }
     dist_record_n = (size_t)(w - dist_record_ptr());
+    return true;
 }
 
 // The body: every delta item of the head, in the same order: u32 length + bytes.  ~22 MB per human-size sample, gathered by the
@@ -196,12 +197,14 @@ bool CAGCCompressor::Impl::make_record_body(const CommitData &cd)
 }
 
 // the record of a sample without contigs: nothing to register anywhere
-void CAGCCompressor::Impl::make_empty_record()
+bool CAGCCompressor::Impl::make_empty_record()
 {
     dist_body_n = 0;
     dist_record_n = 0;
-    if (!dist_record_buf.resize(DIST_FRAME + 64, false))
-        return;
+    if (!dist_record_buf.resize(DIST_FRAME + 64, false)) {
+        err("out of memory (commit record)");
+        return false;
+    }
     uint8_t *w = dist_record_ptr();
     memcpy(w, "AGCR", 4);
     const uint32_t f[5] = {0, 0, 0, ~0u, 0};
@@ -209,6 +212,7 @@ void CAGCCompressor::Impl::make_empty_record()
         for (int j = 0; j < 4; ++j)
             w[4 + 4 * i + j] = (uint8_t)(f[i] >> (8 * j));
     dist_record_n = 24;
+    return true;
 }
 
 bool CAGCCompressor::Impl::apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n)

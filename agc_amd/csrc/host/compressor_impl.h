@@ -324,6 +324,10 @@ struct PinnedBytes {
     {
         if (m <= n)
             return true;
+        // (a buffer that has to grow grows by a quarter at least: the deltas of two human samples differ by a fraction of a percent,
+        // and every new maximum used to cost a hipHostFree + hipHostMalloc of tens of MB -- 6 + 6 ms -- on the thread that holds a lane)
+        if (n)
+            m = std::max(m, n + n / 4);
         if (!keep)
             release();
         void *q = nullptr;
@@ -812,6 +816,13 @@ struct CAGCCompressor::Impl {
         PinnedBytes *enc_dst = nullptr;
         // ... and a second one on lane 1 (agc_hip_lz_encode_begin_packed_on): the segments the sample's own new groups took,
         // launched at commit time behind the whole-sample encode of lane 0
+        // early_only: nothing but the raw collection of lane 0 into *enc_dst (enc_n deltas, offsets -> Impl::early_enc): queued right
+        // behind the launch of the whole-sample encode, so that the lane is free and the deltas are on the host long before the
+        // registration's own task comes.  enc_collected: this (full) task finds lane 0's deltas in *enc_dst already, at enc_eoff
+        bool early_only = false;
+        uint32_t enc_n = 0;
+        bool enc_collected = false;
+        std::vector<uint64_t> enc_eoff;
         bool enc2_pending = false;
         std::vector<uint32_t> enc2_todo;
         uint64_t enc2_text = 0;
@@ -831,8 +842,13 @@ struct CAGCCompressor::Impl {
     std::deque<std::unique_ptr<BookTask>> book_queue;
     bool book_busy = false, book_stop = false, book_failed = false;
     bool async_book = true, async_encode = true;
+    bool early_collect = true; // the whole-sample encode is collected by an early task of the book thread (AGC_AMD_EARLY_COLLECT=0: by the registration's own)
     uint64_t book_seq_submitted = 0, book_seq_done = 0; // tasks are numbered; they complete in order
     uint64_t last_own_seq = 0;          // the last task that points into this object's buffers (the *_alt set below)
+    struct EarlyEnc {                   // result of an early_only task (written by the book thread, read after book_wait_seq)
+        bool ok = false;
+        std::vector<uint64_t> eoff;
+    } early_enc;
     double book_seconds = 0;            // the book thread's own time (added to st.t_store / h_store by book_wait)
     uint64_t book_delta_bytes = 0;      // deltas collected by the book thread (added to st.delta_bytes by book_wait)
     std::unique_ptr<ThreadPool> bpool;  // the stage's own workers (`pool` belongs to the thread that drives the steps)
@@ -922,6 +938,7 @@ struct CAGCCompressor::Impl {
         // delivered; dev_enc_n != 0: the encode of the segments whose group was known is in flight on the device's second lane
         bool dev_keys = false;
         uint32_t dev_enc_n = 0;
+        uint64_t early_seq = 0; // != 0: the book thread's early task that collects that encode (Impl::early_enc takes its result)
         std::vector<uint32_t> flight_keys, flight_gid, flight_len;
         std::vector<uint64_t> flight_off;
         std::vector<uint8_t> flight_rc;
@@ -993,6 +1010,17 @@ struct CAGCCompressor::Impl {
         bool valid = false;
     } pf_next, pf_live;
     bool scan_from_prefetch = false;   // the sample being prepared is pf_live: its first scan is collected, not launched
+    // a FASTA -> 2-bit conversion announced by SetNextFastaDevice: queued by launch_prefetch (or by FinishFastaDevice, whichever comes first)
+    struct FastaNext {
+        bool valid = false, live = false;
+        const uint8_t *d_raw = nullptr;
+        uint64_t n_raw = 0, esc_cap = 0;
+        std::vector<uint64_t> rb, re;
+        uint32_t *d_words = nullptr;
+        int32_t *d_idx = nullptr;
+        uint8_t *d_esc = nullptr;
+    } fasta_next;
+    bool launch_fasta();
     void launch_prefetch();
     agc_hip_packed packed_sample{};    // the sample being prepared is resident in the 2-bit layout (n_symbols != 0): scans read it
     bool gpu_zstd = false;             // delta packs are entropy-coded on the GPU (libzstd 1.4.x frames; AGC_AMD_HOST_ZSTD=1 turns it off)
@@ -1036,9 +1064,9 @@ struct CAGCCompressor::Impl {
     std::vector<std::unique_ptr<PinnedBytes>> body_pool;
     std::unique_ptr<PinnedBytes> body_recv; // handed out by RecordBodyBuffer, adopted by the next apply_record
     std::vector<uint32_t> dist_body_items; // the record's delta items (placed indices) in list order: head and body agree on it
-    void make_record_head(BatchState &b);
+    bool make_record_head(BatchState &b);
     bool make_record_body(const CommitData &cd);
-    void make_empty_record();
+    bool make_empty_record();
     bool apply_record(const uint8_t *rec, size_t n, const uint8_t *d_rec, const uint8_t *body, size_t body_n);
     void note_new_group(const pk_t &pk, uint32_t gid);
     void finish_groups();

@@ -442,6 +442,10 @@ __device__ ParseOut lz_parse(const RefDesc &rd, const SymViewG &tv, uint8_t *__r
         if (MODE == MODE_ENCODE) {
             const uint8_t *src = cc.chunk_out + (size_t)x * cc.chunk_stride + from.o;
             const uint32_t cnt = last.o - from.o;
+            if (stale_out) {
+                __builtin_amdgcn_s_waitcnt(0); // lane 0's rolled-back bytes land before the copied chunk bytes overwrite them
+                stale_out = false;
+            }
             for (uint32_t t = lane; t < cnt; t += WAVE)
                 out[o + t] = src[t];
             o += cnt;

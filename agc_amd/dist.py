@@ -286,7 +286,8 @@ class DistCompressor:
                 o_ = torch.from_numpy((off[a_:b_ + 1] - off[a_]).astype(np.int64)).to(self.comm)
                 x_ = torch.from_numpy(src[int(off[a_]):int(off[b_])]).to(self.comm)
                 sends.append(dist.isend(o_, dst=r))
-                sends.append(dist.isend(x_, dst=r))
+                if x_.numel():  # (packs that are all empty: nothing but their offsets travels, as on the frames leg)
+                    sends.append(dist.isend(x_, dst=r))
             a_, b_ = int(cut[self.rank]), int(cut[self.rank + 1])
             my_off = (off[a_:b_ + 1] - off[a_]).astype(np.uint64)
             my_src = src[int(off[a_]):int(off[b_])]
@@ -295,7 +296,8 @@ class DistCompressor:
             d_o = torch.empty(my_n + 1, dtype=torch.int64, device=self.comm)
             d_x = torch.empty(my_bytes, dtype=torch.uint8, device=self.comm)
             dist.recv(d_o, src=self.writer)
-            dist.recv(d_x, src=self.writer)   # (nccl: HBM -> HBM over xGMI, and the kernel reads the packs where they landed)
+            if my_bytes:
+                dist.recv(d_x, src=self.writer)   # (nccl: HBM -> HBM over xGMI, and the kernel reads the packs where they landed)
             my_off = d_o.cpu().numpy().astype(np.uint64)
             if dev_path:
                 d_mine = d_x if d_x.is_cuda else d_x.to(self.hbm)

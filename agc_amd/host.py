@@ -51,6 +51,8 @@ def bind(L):
     L.agc_cmp_prepare_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_add_sample_packed_dev.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_uint64)]
     L.agc_cmp_set_next_sample_packed_dev.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_uint32]
+    L.agc_cmp_set_next_fasta_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32, vp, vp, vp, C.c_uint64]
+    L.agc_cmp_finish_fasta_dev.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.agc_cmp_commit_prepared.argtypes = [vp]
     L.agc_cmp_commit_prepared_head.argtypes = [vp]
     L.agc_cmp_commit_prepared_finish.argtypes = [vp]
@@ -127,6 +129,38 @@ class Compressor:
         """the packed sample that will be added after the next add call: its expansion + scan run ahead on the device"""
         off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
         return bool(self.L.agc_cmp_set_next_sample_packed_dev(self.h, C.byref(packed), off.ctypes.data_as(C.POINTER(C.c_uint64)), off.size - 1))
+
+    def set_next_fasta_dev(self, d_raw_tensor, n_raw, raw_begin, raw_end, bufs):
+        """announces a sample that is still the bytes of its FASTA file in HBM (torch uint8 tensor; contig c = bytes
+        [raw_begin[c], raw_end[c])); bufs = (words, index, esc) tensors the packed sample is written into.  The compressor queues
+        the conversion where the sample call in progress leaves the GPU room for it.  -> the pending handle finish_fasta_dev takes"""
+        rb = np.ascontiguousarray(raw_begin, dtype=np.uint64)
+        re_ = np.ascontiguousarray(raw_end, dtype=np.uint64)
+        words, index, esc = bufs
+        u64p = C.POINTER(C.c_uint64)
+        if not self.L.agc_cmp_set_next_fasta_dev(self.h, d_raw_tensor.data_ptr(), int(n_raw), rb.ctypes.data_as(u64p), re_.ctypes.data_as(u64p), rb.size,
+                                                 words.data_ptr(), index.data_ptr(), esc.data_ptr(), esc.numel() // 1024):
+            raise RuntimeError("SetNextFastaDevice refused (a conversion is pending)")
+        return {"raw": d_raw_tensor, "n_raw": int(n_raw), "rb": rb, "re": re_, "bufs": bufs}
+
+    def finish_fasta_dev(self, pending):
+        """-> (Packed, backing tensors, the contigs' symbol offsets); grows the escape buffer and converts again when it was too small"""
+        import torch
+        from .capi import ECAP, OK, Packed
+        while True:
+            off = np.zeros(pending["rb"].size + 1, np.uint64)
+            cnt = np.zeros(1, np.uint64)
+            u64p = C.POINTER(C.c_uint64)
+            rc = self.L.agc_cmp_finish_fasta_dev(self.h, off.ctypes.data_as(u64p), cnt.ctypes.data_as(u64p))
+            words, index, esc = pending["bufs"]
+            if rc == ECAP:
+                esc = torch.empty((int(cnt[0]) + 16) * 1024, dtype=torch.uint8, device=words.device)
+                torch.cuda.synchronize(words.device)
+                pending = self.set_next_fasta_dev(pending["raw"], pending["n_raw"], pending["rb"], pending["re"], (words, index, esc))
+                continue
+            if rc != OK:
+                raise RuntimeError(f"FinishFastaDevice failed ({rc})")
+            return Packed(words.data_ptr(), index.data_ptr(), esc.data_ptr(), int(off[-1])), pending["bufs"], off
 
     def prepare_sample_packed_dev(self, sample_name, contig_names, packed, ctg_off):
         n = len(contig_names)

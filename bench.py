@@ -26,6 +26,10 @@ import sys
 import tempfile
 import time
 
+# (before anything initialises HIP: the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, default 4; the
+# library has eight -- agc_amd/csrc/api.hip: agc_hip_create -- and on four they wait for one another)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -562,14 +566,17 @@ def main():
     torch.cuda.synchronize()
 
     def start_pack(s):
+        # announced to the compressor, which queues the conversion where the sample call in progress leaves the GPU room for it
+        # (behind its classification kernels, beside the registration's host work and the announced scan) -- or at once, in
+        # packed_sample(), when no sample call comes in between (the first two samples of the warm-up and of the timed region)
         if samples[s] is None and s not in pack_pending:
             raw, n_raw, rb, re_, bufs = fasta[s]
-            pack_pending[s] = hctx.pack_fasta_begin(raw, n_raw, rb, re_, bufs=bufs)
+            pack_pending[s] = cmp_.set_next_fasta_dev(raw, n_raw, rb, re_, bufs)
 
     def packed_sample(s):
         if samples[s] is None:
             start_pack(s)
-            pk, keep, o_ = hctx.pack_fasta_end(pack_pending.pop(s))
+            pk, keep, o_ = cmp_.finish_fasta_dev(pack_pending.pop(s))
             pack_ms_each.append(round(hctx.timing_get()["pack"][0], 3))  # (cumulative while timing is on: differences = each pack)
             if not np.array_equal(o_, np.asarray(off, np.uint64)):
                 raise SystemExit(f"bench.py: the pack of sample {s} returned other contig offsets than the generator's")
@@ -591,8 +598,11 @@ def main():
     sec0 = dict(dc.seconds) if dc is not None else None
     bytes0 = (dc.bytes_broadcast, dc.bytes_p2p, dc.n_records) if dc is not None else None
     t0 = time.perf_counter()
+    step_ms_each = []
     for s in range(args.warmup, n_steps):
+        ts_ = time.perf_counter()
         add_step(s, "s")
+        step_ms_each.append(round((time.perf_counter() - ts_) * 1e3, 2))
     t_steps = time.perf_counter() - t0
     sec1 = dict(dc.seconds) if dc is not None else None
     # (per TIMED sample: the reference sample's record -- the whole collection's references -- is setup and not averaged in)
@@ -685,7 +695,7 @@ def main():
                                    + (" (OVERLAP VARIANT: packs fill during the steps)" if pack_card != PACK else ""),
                        "input": ("samples packed into the 2-bit layout before the timer (--prepacked)" if args.prepacked else
                                  f"samples resident in HBM as the bytes of their FASTA files ({args.fasta_width} letters per line); every timed sample's "
-                                 "conversion + 2-bit packing (agc_hip_pack_fasta_*, one pass) runs inside the timed region, two samples ahead on its own stream"),
+                                 "conversion + 2-bit packing (agc_cmp_set_next_fasta_dev -> agc_hip_pack_fasta_*) runs inside the timed region, two samples ahead on its own stream, queued by the compressor"),
                        "stages_timed": "per step: " + ("" if args.prepacked else "FASTA bytes -> 2-bit words (one-pass kernel), ") + "splitter-scan kernel, hit fix-up, add_segment classification (one-splitter estimates and "
                                        "missing-middle split points on the GPU), group registration, index build of new references, LZ-diff "
                                        "encode kernel, delta D2H, pack bookkeeping, collection records (a sample's encode is collected and its "
@@ -697,6 +707,7 @@ def main():
                        "setup_not_timed": f"determine_splitters ({'positional shortcut' if args.positional_splitters else 'GPU: enumerate + radix sort + singletons'}): "
                                           f"{t_spl:.2f} s; reference genome as first sample (mints ~{int(st0['new_groups'])} groups): {t_ref:.2f} s",
                        "steps_only_ms": round(t_steps / max(args.steps, 1) * 1e3, 3),
+                       "step_ms_each_rank0": step_ms_each,
                        "pack_ms_cumulative_after_each_pack": pack_ms_each[-(args.steps + 2):],
                        **({"archive_sha256": _sha256_file(archive_path), "archive_bytes": os.path.getsize(archive_path)} if archive_path else {}),
                        "close_ms": round((elapsed - t_steps) * 1e3, 1),

@@ -54,6 +54,17 @@ int agc_cmp_prepare_sample_packed_dev(void *h, const char *sample_name, uint32_t
  * added in between (the reference's workers take later contigs from the queue while earlier ones register,
  * agc_compressor.cpp:1093-1272); 0 when not applicable (adaptive / append / -c mode): the sample then goes the ordinary way */
 int agc_cmp_set_next_sample_packed_dev(void *h, const void *packed, const uint64_t *ctg_off, uint32_t n_ctg);
+/* announces a sample that is still THE BYTES OF ITS FASTA FILE in HBM (contig c = the sequence lines raw[raw_begin[c] .. raw_end[c]),
+ * as genome_io hands them to the reference's workers, agc_compressor.cpp:2160-2228): preprocess_raw_contig (agc_compressor.cpp:907-951)
+ * + the 2-bit packing into the caller's buffers (sizes: agc_hip_packed_words_bytes / _index_bytes; agc_hip_pack_fasta_begin's
+ * arguments).  The compressor queues the conversion itself, at the point of the sample call in progress where the GPU has room for
+ * it -- the reference's reader runs ahead of its workers the same way (agc_compressor.cpp:2155-2238) --, or inside
+ * agc_cmp_finish_fasta_dev when no sample call came in between.  agc_cmp_finish_fasta_dev waits for it: the contigs' symbol
+ * offsets (n_ctg + 1) and the number of escaped blocks; returns agc_hip_pack_fasta_end's code (AGC_HIP_OK; AGC_HIP_ECAP: announce
+ * again with room for *n_esc_blocks escaped blocks).  One conversion at a time; 1 / 0 from the first call. */
+int agc_cmp_set_next_fasta_dev(void *h, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *raw_begin, const uint64_t *raw_end, uint32_t n_ctg,
+                               uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks);
+int agc_cmp_finish_fasta_dev(void *h, uint64_t *ctg_off, uint64_t *n_esc_blocks);
 /* CAGCCompressor::Close (agc_compressor.cpp:2094-2115, 2386-2400) */
 int agc_cmp_close(void *h, uint32_t n_threads);
 /* The entropy stage runs beside the add calls (the reference's workers compress a pack when it fills while the others go on,

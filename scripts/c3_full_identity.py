@@ -1,5 +1,6 @@
 """BASELINE configs[2] at FULL contig size, asserted: one 3 Gbp GRCh38-shaped reference + N samples (d = 1e-3), -k 31 -l 15 -b 100.
-agc_amd through the product path of bench.py (samples resident in the 2-bit layout, packed scan, GPU entropy stage) against the
+agc_amd through the product path of bench.py (samples resident in HBM as the bytes of their FASTA files -> agc_hip_pack_fasta_* -> the
+2-bit layout, packed scan, GPU entropy stage; AGC_IDENTITY_PREPACKED=1: packed from the codes, as before round 6) against the
 reference CLI (oracle/_ref/agc) on the same data written as FASTA: the two archives must be byte-identical.
 
     python scripts/c3_full_identity.py [gbp=3.0] [n_samples=1] [sha256]   (needs a GPU, oracle/_ref/agc and ~7 GB per genome of scratch)
@@ -47,13 +48,39 @@ with tempfile.TemporaryDirectory(dir=scratch) as td:
     cmp_.create(out_amd, 100, 31, None, 60000, 15, n_threads=16)
     cmp_.set_reference_dev(ref.data_ptr(), off)
     hctx = capi.Context.from_handle(cmp_.hip_ctx())
-    pk, keep = hctx.pack_dev(ref, tot)
-    cmp_.add_sample_packed_dev("ref", names, pk, off)
-    packed = [hctx.pack_dev(smp, tot) for smp in samples]
+
+    def packed_from_fasta(codes, what):
+        """the bench's own front stage (bench.py: start_pack / packed_sample): the sample as the bytes of its FASTA file in HBM ->
+        agc_hip_pack_fasta_begin / _end.  Every word of the 2-bit layout, the escape index and the contig offsets are compared with
+        the pack of the codes themselves (agc_hip_pack_dev), at full size."""
+        if os.environ.get("AGC_IDENTITY_PREPACKED"):
+            return hctx.pack_dev(codes, tot), off
+        raw, n_raw, rb, re_ = synth_dev.make_fasta(codes, off, names, int(os.environ.get("AGC_IDENTITY_FASTA_WIDTH", "60")))
+        pk_f, keep_f, off_f = hctx.pack_fasta_dev(raw, n_raw, rb, re_)
+        del raw
+        assert np.array_equal(off_f, np.asarray(off, np.uint64)), "pack_fasta: contig offsets differ from the generator's"
+        pk_c, keep_c = hctx.pack_dev(codes, tot)
+        n_words, n_blocks = (tot + 15) // 16, (tot + 1023) // 1024
+        wf, wc = keep_f[0][:n_words], keep_c[0][:n_words]
+        if tot % 16:  # (bits beyond the last symbol of the last word are nobody's)
+            m = (1 << (2 * (tot % 16))) - 1
+            assert (int(wf[-1]) & m) == (int(wc[-1]) & m), "pack_fasta: last word differs"
+            wf, wc = wf[:-1], wc[:-1]
+        same_w = bool(torch.equal(wf, wc))
+        same_i = bool(torch.equal(keep_f[1][:n_blocks], keep_c[1][:n_blocks]))
+        print(f"pack_fasta of {what}: {n_raw} FASTA bytes -> {n_words} words; words {'==' if same_w else '!='} pack_dev(codes), "
+              f"escape index {'==' if same_i else '!='}", flush=True)
+        assert same_w and same_i, "pack_fasta: the packed sample differs from the pack of the codes"
+        del pk_c, keep_c
+        return (pk_f, keep_f), off_f
+
+    (pk, keep), off_r = packed_from_fasta(ref, "the reference")
+    cmp_.add_sample_packed_dev("ref", names, pk, off_r)
+    packed = [packed_from_fasta(smp, f"sample {s}") for s, smp in enumerate(samples)]
     for s in range(len(samples)):
         if announce and s + 1 < len(samples):
-            cmp_.set_next_sample_packed_dev(packed[s + 1][0], off)
-        cmp_.add_sample_packed_dev(f"s{s}", names, packed[s][0], off)
+            cmp_.set_next_sample_packed_dev(packed[s + 1][0][0], packed[s + 1][1])
+        cmp_.add_sample_packed_dev(f"s{s}", names, packed[s][0][0], packed[s][1])
     cmp_.close(16)
     st = cmp_.stats()
     cmp_.close_handle()
