@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -72,6 +73,9 @@ struct agc_hip_ctx {
     DevBuf d_refs;
     bool refs_dirty = true;
     std::vector<ArenaChunk> arena;
+    // the NEXT chunk, allocated ahead of need by a helper thread (arena_alloc): a hipMalloc of GBs is 30 ms per GB on a box whose
+    // VRAM this process touches for the first time -- 150 ms in the middle of a step (profiles/r6/)
+    std::future<ArenaChunk> arena_spare;
 
     // the > 64 KiB dynamic-LDS attribute of a kernel is a property of the device the context runs on: set once per context
     bool lds_scan_set = false, lds_lookup_set = false;
@@ -202,6 +206,9 @@ int ensure(agc_hip_ctx *c, DevBuf &b, size_t bytes, hipStream_t stream = nullptr
     // hipFree/hipMalloc (hundreds of ms for multi-GB buffers) out of the steady state
     size_t want = std::max(bytes + bytes / 4, b.cap + b.cap / 2);
     want = (want + 255) & ~(size_t)255;
+    static const bool laps = getenv("AGC_HIP_LAPS") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t had = b.cap;
     if (b.p) {
         HIPCHK(c, hipStreamSynchronize(stream));
         HIPCHK(c, hipFree(b.p));
@@ -210,21 +217,61 @@ int ensure(agc_hip_ctx *c, DevBuf &b, size_t bytes, hipStream_t stream = nullptr
     }
     HIPCHK(c, hipMalloc(&b.p, want));
     b.cap = want;
+    if (laps && want >= ((size_t)16 << 20))
+        fprintf(stderr, "    ensure: a device buffer grows from %.1f to %.1f MB (asked: %.1f) in %.3f ms\n", had / 1e6, want / 1e6, bytes / 1e6,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return AGC_HIP_OK;
+}
+
+size_t arena_next_size(const agc_hip_ctx *c)
+{
+    // a chunk is at least half of what the arena holds already: the number of hipMalloc calls of a run grows with the logarithm of
+    // its references, not with their number
+    size_t held = 0;
+    for (const ArenaChunk &ch : c->arena)
+        held += ch.size;
+    return std::max((size_t)256 << 20, std::min(held / 2, (size_t)8 << 30));
 }
 
 int arena_alloc(agc_hip_ctx *c, size_t bytes, uint8_t **out)
 {
     bytes = (bytes + 255) & ~(size_t)255;
+    static const bool laps = getenv("AGC_HIP_LAPS") != nullptr;
     if (c->arena.empty() || c->arena.back().used + bytes > c->arena.back().size) {
-        size_t sz = std::max(bytes, (size_t)256 << 20);
-        uint8_t *p = nullptr;
-        HIPCHK(c, hipMalloc((void **)&p, sz + 4096)); // tail slack: 16-byte over-reads never leave the allocation
-        c->arena.push_back({p, sz, 0});
+        const auto t0 = std::chrono::steady_clock::now();
+        ArenaChunk nc{nullptr, 0, 0};
+        if (c->arena_spare.valid()) { // (allocated since the current chunk was half full: long done)
+            nc = c->arena_spare.get();
+            if (nc.p && nc.size < bytes) {
+                (void)hipFree(nc.p);
+                nc = ArenaChunk{nullptr, 0, 0};
+            }
+        }
+        if (!nc.p) {
+            const size_t sz = std::max(bytes, arena_next_size(c));
+            uint8_t *p = nullptr;
+            HIPCHK(c, hipMalloc((void **)&p, sz + 4096)); // tail slack: 16-byte over-reads never leave the allocation
+            nc = ArenaChunk{p, sz, 0};
+        }
+        c->arena.push_back(nc);
+        if (laps)
+            fprintf(stderr, "    arena: a chunk of %.1f MB becomes current in %.3f ms\n", nc.size / 1e6,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     ArenaChunk &ch = c->arena.back();
     *out = ch.p + ch.used;
     ch.used += bytes;
+    // the chunk after this one is asked for as soon as this one is half full, on a thread of its own
+    if (!c->arena_spare.valid() && ch.used * 2 >= ch.size) {
+        const size_t sz = arena_next_size(c);
+        const int dev = c->device;
+        c->arena_spare = std::async(std::launch::async, [sz, dev] {
+            uint8_t *p = nullptr;
+            if (hipSetDevice(dev) != hipSuccess || hipMalloc((void **)&p, sz + 4096) != hipSuccess)
+                return ArenaChunk{nullptr, 0, 0}; // (arena_alloc then allocates when the chunk is needed, and reports)
+            return ArenaChunk{p, sz, 0};
+        });
+    }
     return AGC_HIP_OK;
 }
 
@@ -514,6 +561,11 @@ void agc_hip_destroy(agc_hip_ctx *c)
             (void)hipFree(b->p);
     for (auto &ch : c->arena)
         (void)hipFree(ch.p);
+    if (c->arena_spare.valid()) {
+        const ArenaChunk sp = c->arena_spare.get();
+        if (sp.p)
+            (void)hipFree(sp.p);
+    }
     if (c->ev0)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
@@ -1074,6 +1126,58 @@ int agc_hip_pack_fasta_dev(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw,
         return AGC_HIP_EINVAL;
     CHK(agc_hip_pack_fasta_begin(c, d_raw, n_raw, h_raw_begin, h_raw_end, n_ctg, d_words, d_esc_index, d_esc_bytes, esc_cap_blocks));
     return agc_hip_pack_fasta_end(c, h_ctg_off, h_n_esc_blocks);
+}
+
+// A window of FASTA bodies in HOST memory -> the packed sample in the context's own buffers (those of agc_hip_sample_pack): the
+// bodies go to HBM as they are, back to back, and the pack_fasta kernels make the 2-bit layout from them -- what a host that reads
+// FASTA files calls once per window (include/agc_hip.h).
+int agc_hip_sample_pack_fasta(agc_hip_ctx *c, uint32_t n_ctg, const uint8_t *const *h_raw, const uint64_t *h_len, agc_hip_packed *out, uint64_t *h_ctg_off)
+{
+    if (!c || !out || !h_ctg_off || (n_ctg && (!h_raw || !h_len)))
+        return AGC_HIP_EINVAL;
+    *out = agc_hip_packed{};
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->pfa.pending) {
+        c->err = "sample_pack_fasta: a conversion queued by agc_hip_pack_fasta_begin is pending";
+        return AGC_HIP_EINVAL;
+    }
+    std::vector<uint64_t> rb(n_ctg), re(n_ctg);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n_ctg; ++i) {
+        if (h_len[i] && !h_raw[i])
+            return AGC_HIP_EINVAL;
+        rb[i] = tot;
+        tot += h_len[i];
+        re[i] = tot;
+    }
+    for (uint32_t i = 0; i <= n_ctg; ++i)
+        h_ctg_off[i] = 0;
+    if (!tot)
+        return AGC_HIP_OK;
+    // (the encode of the previous sample may still be reading the packed buffers on a lane: see Lane2::done)
+    for (auto *ln : {&c->l2, &c->l3})
+        if (ln->done_valid)
+            HIPCHK(c, hipEventSynchronize(ln->done));
+    CHK(ensure(c, c->d_in, tot + 64));
+    for (uint32_t i = 0; i < n_ctg; ++i)
+        if (h_len[i])
+            HIPCHK(c, hipMemcpyAsync((uint8_t *)c->d_in.p + rb[i], h_raw[i], h_len[i], hipMemcpyHostToDevice, c->stream));
+    // every byte may be a symbol and every block escaped: room for all of them, nothing has to be asked twice
+    PackTemp &t = c->pk_sample;
+    const uint64_t n_blocks = (tot + PACK_BLOCK - 1) / PACK_BLOCK;
+    CHK(ensure(c, t.words, n_blocks * (PACK_BLOCK / 4) + 64));
+    CHK(ensure(c, t.index, n_blocks * 4 + 64));
+    CHK(ensure(c, t.esc, n_blocks * PACK_BLOCK + 64));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the bodies are in HBM, the buffers are where they will stay)
+    uint64_t n_esc = 0;
+    CHK(agc_hip_pack_fasta_begin(c, (const uint8_t *)c->d_in.p, tot, rb.data(), re.data(), n_ctg, (uint32_t *)t.words.p, (int32_t *)t.index.p, (uint8_t *)t.esc.p,
+                                 n_blocks));
+    CHK(agc_hip_pack_fasta_end(c, h_ctg_off, &n_esc));
+    out->d_words = (const uint32_t *)t.words.p;
+    out->d_esc_index = (const int32_t *)t.index.p;
+    out->d_esc_bytes = (const uint8_t *)t.esc.p;
+    out->n_symbols = h_ctg_off[n_ctg];
+    return AGC_HIP_OK;
 }
 
 // filter over the last 16 symbols of every splitter and of its reverse complement, for k-mer length k (cached per k)

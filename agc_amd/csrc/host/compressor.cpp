@@ -915,6 +915,10 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     // without the device's segments there is no such cut and no speculation)
     const uint32_t WINDOW_MAX = I.adaptive && !I.adaptive_windows() ? 1u : window_cap;
     uint32_t window = 1; // grows while whole windows commit, shrinks to what did commit otherwise
+    // (adaptive mode mines new splitters from host copies of the codes, k < 16 scans one byte per symbol: the earlier path.
+    // AGC_AMD_FASTA_PACK=0 switches the one-pass conversion off, AGC_AMD_FASTA_PACK_MIN=<bytes> moves its threshold)
+    const bool fasta_ok = !I.adaptive && I.k >= 16 && !(getenv("AGC_AMD_FASTA_PACK") && atoi(getenv("AGC_AMD_FASTA_PACK")) == 0);
+    const uint64_t FASTA_PACK_MIN = getenv("AGC_AMD_FASTA_PACK_MIN") ? strtoull(getenv("AGC_AMD_FASTA_PACK_MIN"), nullptr, 10) : (1ull << 20);
 
     auto run_window = [&]() -> bool {
         // batch = the first `window` pending registrations (at least one)
@@ -926,6 +930,53 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
             tot += pending[b].bytes;
         uint8_t *d_base = nullptr;
         double t0 = now();
+        // S1a on the product path: a window whose contigs are all still FASTA bodies goes to HBM as it is and is converted + packed
+        // there in one pass (agc_hip_sample_pack_fasta -> pack_fasta_*_kernel: preprocess_raw_contig, agc_compressor.cpp:907-951, fused
+        // with the 2-bit packing) -- no one-byte-per-symbol copy of the sample exists anywhere, no per-contig round trip
+        bool all_raw = fasta_ok && nb > 0 && tot >= FASTA_PACK_MIN;
+        for (uint32_t b = 0; b < nb && all_raw; ++b)
+            for (size_t c = 0; c < pending[b].ctgs.size(); ++c)
+                all_raw = all_raw && c < pending[b].raw.size() && pending[b].raw[c];
+        if (all_raw) {
+            std::vector<const uint8_t *> ptr;
+            std::vector<uint64_t> len;
+            for (uint32_t b = 0; b < nb; ++b)
+                for (size_t c = 0; c < pending[b].ctgs.size(); ++c) {
+                    ptr.push_back(pending[b].data[c].data());
+                    len.push_back(pending[b].data[c].size());
+                }
+            std::vector<uint64_t> off(ptr.size() + 1, 0);
+            agc_hip_packed pk{};
+            if (!I.hip_ok(DEVTI(agc_hip_sample_pack_fasta(I.hip, (uint32_t)ptr.size(), ptr.data(), len.data(), &pk, off.data())), "sample_pack_fasta"))
+                return false;
+            size_t x = 0;
+            for (uint32_t b = 0; b < nb; ++b)
+                for (size_t c = 0; c < pending[b].ctgs.size(); ++c, ++x) {
+                    Contig ct = pending[b].ctgs[c];
+                    ct.sample_idx = b;
+                    ct.off = off[x];
+                    ct.len = off[x + 1] - off[x];
+                    batch.push_back(ct);
+                }
+            I.st.t_io += now() - t0;
+            uint32_t n_done = 0;
+            I.next_base_owned = true; // (the context's own packed buffers)
+            I.packed_sample = pk;
+            const bool batch_ok = I.process_batch(batch, nullptr, nullptr, n_done);
+            I.packed_sample.n_symbols = 0;
+            I.next_base_owned = false;
+            if (!batch_ok)
+                return false;
+            if (n_done == nb)
+                window = std::min(WINDOW_MAX, window * 2);
+            else
+                window = std::max(1u, n_done);
+            for (uint32_t b = 0; b < n_done; ++b) {
+                pending_bytes -= pending.front().bytes;
+                pending.pop_front();
+            }
+            return true;
+        }
         if (!I.hip_ok(DEVTI(agc_hip_sample_buffer(I.hip, tot, &d_base)), "sample_buffer"))
             return false;
         uint64_t o = 0;
@@ -998,18 +1049,27 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
     // splitters from host copies -- are converted by the reading thread as before
     const uint64_t GPU_A1_MIN = I.adaptive ? ~0ull : (1ull << 20);
     const unsigned read_threads = std::max(1u, std::min(8u, no_threads / 2));
-    auto read_file = [GPU_A1_MIN, read_threads](std::string path) {
+    // (a file of FASTA_PACK_MIN bytes or more keeps EVERY contig as it was read -- the small scaffolds of an assembly beside its
+    // chromosomes -- so that its window qualifies for the one-pass conversion; smaller files: per contig, as before)
+    auto read_file = [GPU_A1_MIN, read_threads, fasta_ok, FASTA_PACK_MIN](std::string path) {
         FileData fd;
+        auto settle = [&]() {
+            uint64_t total = 0;
+            for (const bytes_t &c_ : fd.contigs)
+                total += c_.size();
+            const bool whole = fasta_ok && total >= FASTA_PACK_MIN;
+            fd.raw.resize(fd.contigs.size());
+            for (size_t i = 0; i < fd.contigs.size(); ++i) {
+                fd.raw[i] = whole || fd.contigs[i].size() >= GPU_A1_MIN;
+                if (!fd.raw[i])
+                    preprocess_raw_contig(fd.contigs[i]);
+            }
+        };
         // a big plain file: mapped, cut and copied out by a few threads
         static const uint64_t map_min = getenv("AGC_AMD_MAP_MIN") ? strtoull(getenv("AGC_AMD_MAP_MIN"), nullptr, 10) : (64ull << 20);
         if (FastaReader::read_all_mapped(path, fd.ids, fd.contigs, read_threads, map_min)) {
             fd.opened = true;
-            fd.raw.resize(fd.contigs.size());
-            for (size_t i = 0; i < fd.contigs.size(); ++i) {
-                fd.raw[i] = fd.contigs[i].size() >= GPU_A1_MIN;
-                if (!fd.raw[i])
-                    preprocess_raw_contig(fd.contigs[i]);
-            }
+            settle();
             return fd;
         }
         FastaReader fr;
@@ -1019,14 +1079,11 @@ bool CAGCCompressor::AddSampleFiles(const std::vector<std::pair<std::string, std
         std::string id;
         bytes_t contig;
         while (fr.read_contig_raw(id, contig)) {
-            const bool keep_raw = contig.size() >= GPU_A1_MIN;
-            if (!keep_raw)
-                preprocess_raw_contig(contig);
-            fd.raw.push_back(keep_raw);
             fd.ids.emplace_back(id);
             fd.contigs.emplace_back(std::move(contig));
             contig.clear();
         }
+        settle();
         return fd;
     };
     auto file_bytes = [](const std::string &path) -> uint64_t {
@@ -1270,10 +1327,39 @@ bool CAGCCompressor::Close(uint32_t no_threads)
             std::cerr << "  close lap " << what << " " << (now() - lt) * 1e3 << " ms\n";
         lt = now();
     };
+    // (the payloads of `splitters` and `segment-splitters` -- 50 k sorted map entries at human scale -- are serialised beside the
+    // entropy stage too: nothing changes the two tables any more)
+    bytes_t v_splitters, v_segspl;
+    size_t n_segspl = 0;
+    std::future<void> tables = std::async(std::launch::async, [&] {
+        auto a32 = [](bytes_t &d, uint32_t x) {
+            for (int i = 0; i < 4; ++i, x >>= 8)
+                d.push_back((uint8_t)(x & 0xff));
+        };
+        auto a64 = [](bytes_t &d, uint64_t x) {
+            for (int i = 0; i < 8; ++i, x >>= 8)
+                d.push_back((uint8_t)(x & 0xff));
+        };
+        v_splitters.reserve(I.splitters.size() * 8);
+        for (uint64_t x : I.splitters) // sorted
+            a64(v_splitters, x);
+        std::vector<std::pair<pk_t, int32_t>> ms;
+        ms.reserve(I.map_segments.size());
+        I.map_segments.for_each([&](const pk_t &k, int32_t v) { ms.emplace_back(k, v); });
+        std::sort(ms.begin(), ms.end());
+        v_segspl.reserve(ms.size() * 20);
+        for (auto &x : ms) {
+            a64(v_segspl, x.first.first);
+            a64(v_segspl, x.first.second);
+            a32(v_segspl, (uint32_t)x.second);
+        }
+        n_segspl = ms.size();
+    });
     I.finish_groups();
     I.z_wait_all();
     if (open_batch.valid())
         open_batch.get();
+    tables.get();
     LAP("finish_groups (pack jobs + entropy stage + parts) || open collection batch");
     if (I.verify_bad.load()) { // (AGC_AMD_VERIFY_DEV_FRAMES)
         I.err("Close: " + std::to_string(I.verify_bad.load()) + " of " + std::to_string(I.verify_frames.load()) + " device frames differ from libzstd");
@@ -1284,10 +1370,6 @@ bool CAGCCompressor::Close(uint32_t no_threads)
 
     auto app32 = [](bytes_t &d, uint32_t x) {
         for (int i = 0; i < 4; ++i, x >>= 8)
-            d.push_back((uint8_t)(x & 0xff));
-    };
-    auto app64 = [](bytes_t &d, uint64_t x) {
-        for (int i = 0; i < 8; ++i, x >>= 8)
             d.push_back((uint8_t)(x & 0xff));
     };
     auto appstr = [](bytes_t &d, const std::string &s) {
@@ -1301,22 +1383,8 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     app32(v, I.segment_size);
     I.ar.add_part(I.ar.register_stream("params"), v, 0);
 
-    v.clear();
-    for (uint64_t x : I.splitters) // sorted
-        app64(v, x);
-    I.ar.add_part(I.ar.register_stream("splitters"), v, I.splitters.size());
-
-    std::vector<std::pair<pk_t, int32_t>> ms;
-    ms.reserve(I.map_segments.size());
-    I.map_segments.for_each([&](const pk_t &k, int32_t v) { ms.emplace_back(k, v); });
-    std::sort(ms.begin(), ms.end());
-    v.clear();
-    for (auto &x : ms) {
-        app64(v, x.first.first);
-        app64(v, x.first.second);
-        app32(v, (uint32_t)x.second);
-    }
-    I.ar.add_part(I.ar.register_stream("segment-splitters"), v, ms.size());
+    I.ar.add_part(I.ar.register_stream("splitters"), v_splitters, I.splitters.size());
+    I.ar.add_part(I.ar.register_stream("segment-splitters"), v_segspl, n_segspl);
 
     LAP("params / splitters / segment-splitters");
     I.coll.complete_serialization();

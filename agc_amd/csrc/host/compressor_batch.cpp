@@ -86,12 +86,12 @@ void CAGCCompressor::Impl::z_main()
             j.slot->meta = j.meta;
             j.slot->ready.store(true, std::memory_order_release);
         }
-        batch.clear();
         {
             std::lock_guard<std::mutex> lk(z_mtx);
             z_busy = false;
         }
         z_idle_cv.notify_all();
+        batch.clear(); // (the inputs -- half a GB at a human Close -- are freed while whoever waited goes on)
     }
 }
 
@@ -605,6 +605,7 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
     }
     LAP("split");
     std::future<bool> dev_done;
+    bool dev_results_done = false; // (written by the device's thread, read after dev_done.get())
     std::vector<uint64_t> src_off, dst_off;
     const double ts0 = now();
     if (ext) {
@@ -622,8 +623,10 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         }
         const uint64_t cap = src_off[nd] + 32 * nd + 64; // a frame never exceeds its input by more than the headers
         dst_off.assign(nd + 1, 0);
-        // the packs are gathered by the whole pool (hundreds of MB into fresh pages: a tenth of a second for one thread, and the
-        // device's side of the split is the longer one), then the device call runs beside the pool's own jobs
+        // the packs are gathered by the whole pool (hundreds of MB into fresh pages: a tenth of a second for one thread; the pool's
+        // own jobs wait the 7 ms this takes -- helper threads beside a pool that already uses the whole CPU quota were measured:
+        // the device's side then starts late and ends 57 ms behind the pool), then the device call runs beside the pool's jobs
+        // on a thread of its own, which also puts the frames back into their jobs as soon as the device is done
         const double tg = now();
         zsrc_buf.resize(src_off[nd] + src_off[nd] / 8, false); // (headroom: the next call's packs are a little longer)
         {
@@ -639,6 +642,15 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
         const double t_gather = now() - tg;
         dev_done = std::async(std::launch::async, [&, nd, cap, t_gather, levels, any_ref] {
             const double td = now() - t_gather; // (the gather counts as device-side time for the split rule)
+            auto helpers = [&](size_t n_items, const std::function<void(size_t, size_t)> &body) {
+                const size_t nt = n_items >= 4096 ? 2 : 1;
+                std::vector<std::thread> th;
+                for (size_t t = 1; t < nt; ++t)
+                    th.emplace_back([&, t] { body(n_items * t / nt, n_items * (t + 1) / nt); });
+                body(0, n_items / nt);
+                for (auto &x : th)
+                    x.join();
+            };
             zdst_buf.resize(cap + cap / 8, false);
             if (const char *dump = getenv("AGC_AMD_DUMP_PACKS")) { // debugging aid: the packs of this call, for scripts/zstd_gpu_probe.py
                 static int dump_no = 0;
@@ -657,6 +669,20 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                                                       dst_off.data()),
                                    "zstd_batch");
             t_dev = now() - td;
+            static const bool verify_dev = getenv("AGC_AMD_VERIFY_DEV_FRAMES") != nullptr;
+            if (ok && !verify_dev) { // (a checking run compares the frames with libzstd's first: below, with the pool)
+                helpers(nd, [&](size_t a, size_t b) {
+                    for (size_t t = a; t < b; ++t) {
+                        ZJob &j = jobs[dev_jobs[t]];
+                        const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);
+                        bytes_t packed(zdst_buf.data() + dst_off[t], zdst_buf.data() + dst_off[t + 1]);
+                        packed.push_back(0);
+                        finish(j, packed, ps, j.kind == 0 ? j.marker : 0);
+                        bytes_t().swap(j.staged);
+                    }
+                });
+                dev_results_done = true;
+            }
             return ok;
         });
     }
@@ -717,14 +743,15 @@ void CAGCCompressor::Impl::run_jobs_round(std::vector<ZJob> &jobs)
                 if (bad.load())
                     err("entropy stage: device frames differ from libzstd");
             }
-            zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned) {
-                ZJob &j = jobs[dev_jobs[t]];
-                const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);
-                bytes_t packed(zdst_buf.data() + dst_off[t], zdst_buf.data() + dst_off[t + 1]);
-                packed.push_back(0);
-                finish(j, packed, ps, j.kind == 0 ? j.marker : 0);
-                bytes_t().swap(j.staged);
-            });
+            if (!dev_results_done)
+                zpool->parallel_for(dev_jobs.size(), [&](size_t t, unsigned) {
+                    ZJob &j = jobs[dev_jobs[t]];
+                    const uint32_t ps = (uint32_t)(dst_off[t + 1] - dst_off[t]);
+                    bytes_t packed(zdst_buf.data() + dst_off[t], zdst_buf.data() + dst_off[t + 1]);
+                    packed.push_back(0);
+                    finish(j, packed, ps, j.kind == 0 ? j.marker : 0);
+                    bytes_t().swap(j.staged);
+                });
             if (!ext) {
                 st.zstd_dev_in += src_off[dev_jobs.size()];
                 st.zstd_dev_out += dst_off[dev_jobs.size()];
@@ -2781,23 +2808,35 @@ void CAGCCompressor::Impl::finish_groups()
         close_collected = false;
         return;
     }
+    static const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
+    const double tl0 = now();
     std::vector<ZJob> jobs;
     build_close_jobs(jobs);
-    for (ZJob &j : jobs) {
-        j.slot = std::make_shared<PartSlot>();
-        ar.add_part_deferred(j.stream_id, j.slot);
+    const double tl1 = now();
+    {
+        // (50 k parts take their places in one go: one lock, not one per part)
+        std::vector<std::pair<int, std::shared_ptr<PartSlot>>> places;
+        places.reserve(jobs.size());
+        for (ZJob &j : jobs) {
+            j.slot = std::make_shared<PartSlot>();
+            places.emplace_back(j.stream_id, j.slot);
+        }
+        ar.add_parts_deferred(places);
     }
     deferred_bytes = 0;
     for (ZJob &j : deferred_packs) // (Close without CloseCollectPacks: the kept packs are coded here after all)
         jobs.emplace_back(std::move(j));
     deferred_packs.clear();
     z_caller_waits = true;     // (Close waits for the entropy thread, then flushes)
+    if (laps)
+        std::cerr << "    finish_groups: pack jobs " << (tl1 - tl0) * 1e3 << " ms, their places in the archive " << (now() - tl1) * 1e3 << " ms\n";
     z_submit(std::move(jobs));
 }
 
 // the pack jobs of every group's open pack (+ the parts an appended archive's untouched groups keep as they are)
 void CAGCCompressor::Impl::build_close_jobs(std::vector<ZJob> &jobs)
 {
+    jobs.reserve(jobs.size() + groups.size() + 16);
     for (uint32_t gid = 0; gid < groups.size(); ++gid) {
         Group &g = groups[gid];
         if (!g.lzp_off.empty())

@@ -98,37 +98,49 @@ struct ZstdCtx {
 // worker pool: parallel_for over independent jobs
 // ---------------------------------------------------------------------------
 class ThreadPool {
+    // A call returns when its JOBS are done, not when every worker has woken up and reported: a worker the scheduler brings in late
+    // (or one beyond max_workers) finds nothing left and goes back to sleep on its own.  The job counter carries the call's number
+    // (epoch) in its high half, so a worker that was preempted between waking up and taking its first job can never take an index of
+    // a later call by mistake: it only ever takes an index by compare-and-swap against a value of ITS epoch.
     std::vector<std::thread> th;
     std::mutex mtx;
     std::condition_variable cv, cv_done;
-    std::function<void(size_t, unsigned)> fn;
-    std::atomic<size_t> next{0};
-    size_t n_jobs = 0;
-    unsigned active = 0, limit = ~0u;
-    uint64_t epoch = 0;
+    std::function<void(size_t, unsigned)> fn; // (valid while a call of parallel_for waits: only jobs of that call read it)
+    std::atomic<uint64_t> next{0};            // epoch << 32 | next job index
+    std::atomic<uint32_t> done{0};            // jobs of the current call that have run
+    uint32_t n_jobs = 0;
+    unsigned limit = ~0u;
+    uint32_t epoch = 0;
     bool stop = false;
 
     void run(unsigned tid)
     {
-        uint64_t seen = 0;
+        uint32_t seen = 0;
         for (;;) {
+            uint32_t my_n, my_epoch;
+            unsigned my_limit;
             {
                 std::unique_lock<std::mutex> lk(mtx);
                 cv.wait(lk, [&] { return stop || epoch != seen; });
                 if (stop)
                     return;
-                seen = epoch;
+                seen = my_epoch = epoch;
+                my_n = n_jobs;
+                my_limit = limit;
             }
-            for (; tid < limit;) {
-                size_t i = next.fetch_add(1);
-                if (i >= n_jobs)
+            if (tid >= my_limit)
+                continue;
+            for (;;) {
+                uint64_t cur = next.load(std::memory_order_acquire);
+                if ((uint32_t)(cur >> 32) != my_epoch || (uint32_t)cur >= my_n)
                     break;
-                fn(i, tid);
-            }
-            {
-                std::unique_lock<std::mutex> lk(mtx);
-                if (--active == 0)
+                if (!next.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel))
+                    continue;
+                fn((size_t)(uint32_t)cur, tid);
+                if (done.fetch_add(1, std::memory_order_acq_rel) + 1 == my_n) {
+                    std::lock_guard<std::mutex> lk(mtx);
                     cv_done.notify_all();
+                }
             }
         }
     }
@@ -159,20 +171,26 @@ public:
     }
     unsigned size() const { return (unsigned)th.size(); }
     // fn(job index, worker id); returns when every job has run.  max_workers: only that many workers take jobs (a small
-    // batch beside other busy threads of the process)
+    // batch beside other busy threads of the process).  One call at a time (every pool has one calling thread).
     void parallel_for(size_t n, std::function<void(size_t, unsigned)> f, unsigned max_workers = ~0u)
     {
         if (!n)
             return;
+        if (n > 0x7fffffffu) { // (the index travels in 32 bits; never in practice)
+            for (size_t from = 0; from < n; from += 0x7fffffffu)
+                parallel_for(std::min<size_t>(n - from, 0x7fffffffu), [&f, from](size_t i, unsigned t) { f(from + i, t); }, max_workers);
+            return;
+        }
         std::unique_lock<std::mutex> lk(mtx);
         fn = std::move(f);
         limit = max_workers ? max_workers : 1;
-        n_jobs = n;
-        next = 0;
-        active = (unsigned)th.size();
+        n_jobs = (uint32_t)n;
         ++epoch;
+        done.store(0, std::memory_order_release);
+        next.store((uint64_t)epoch << 32, std::memory_order_release);
         cv.notify_all();
-        cv_done.wait(lk, [&] { return active == 0; });
+        cv_done.wait(lk, [&] { return done.load(std::memory_order_acquire) == n_jobs; });
+        fn = nullptr;
     }
 };
 
@@ -327,6 +345,18 @@ public:
         buffer[id].push_back(BufPart{bytes_t(), 0, slot});
         buffer_deferred = true;
     }
+    void add_parts_deferred(const std::vector<std::pair<int, std::shared_ptr<PartSlot>>> &places)
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        auto hint = buffer.end();
+        for (auto &pl : places) { // (ids mostly ascending: the hint makes the insertion O(1))
+            hint = buffer.emplace_hint(hint, pl.first, std::vector<BufPart>());
+            hint->second.push_back(BufPart{bytes_t(), 0, pl.second});
+            ++hint;
+        }
+        if (!places.empty())
+            buffer_deferred = true;
+    }
 
 private:
     void write_event(buffer_t &b)
@@ -351,8 +381,22 @@ private:
     {
         while (!events.empty() && event_ready(events.front())) {
             write_event(events.front());
+            if (events.front().size() >= 4096) {
+                // (the flush of a Close holds one part per group: 50 k map nodes, slots and payloads to free -- 20 ms at human
+                // scale, on a thread of its own while the caller writes the archive's last streams)
+                auto *dead = new buffer_t(std::move(events.front()));
+                reapers.emplace_back([dead] { delete dead; });
+            }
             events.pop_front();
         }
+    }
+    std::vector<std::thread> reapers;
+    void join_reapers()
+    {
+        for (auto &t : reapers)
+            if (t.joinable())
+                t.join();
+        reapers.clear();
     }
 
 public:
@@ -382,6 +426,7 @@ public:
         return !events.empty();
     }
     // ~CArchive -> Close: flush buffered parts, footer, 8-byte footer size (archive.cpp:68-85)
+    ~ArchiveWriter() { join_reapers(); }
     void close()
     {
         flush_out_buffers();
@@ -407,7 +452,7 @@ public:
                 io_error = true;
         } else if (f && fflush(f) != 0)
             io_error = true;
-        f = nullptr;
+        f = nullptr; // (the reapers are joined by the destructor: freeing what has been written is nobody's wait)
     }
 };
 

@@ -320,7 +320,9 @@ int main(int argc, char **argv)
                   << "seconds: io " << s.t_io << " scan " << s.t_scan << " classify " << s.t_classify << " gpu-aux " << s.t_gpu_aux
                   << " register " << s.t_register << " encode " << s.t_encode << " store " << s.t_store << " zstd " << s.t_zstd << " (inside the device library: " << s.t_device << ")\n"
                   << "host-only part: scan " << s.h_scan << " classify " << s.h_classify << " gpu-aux " << s.h_gpu_aux << " register " << s.h_register
-                  << " encode " << s.h_encode << " store " << s.h_store << "\n";
+                  << " encode " << s.h_encode << " store " << s.h_store << "\n"
+                  << "entropy-seconds: host-pool " << s.t_zstd_host << " device " << s.t_zstd_dev << " staging " << s.t_zstd_stage << " caller-waited "
+                  << s.t_zstd_wait << "\n";
     }
     if (kernel_times && c.HipContext()) {
         static const char *names[AGC_HIP_K_COUNT] = {"scan", "index", "encode", "estimate", "costvec", "revcomp", "preprocess", "refstore", "zstd", "filter",

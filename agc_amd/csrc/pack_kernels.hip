@@ -45,7 +45,7 @@ struct PfChunk {
     uint32_t bits;  // 2 bits per KEPT symbol, first symbol lowest
     uint32_t cnt;   // kept symbols (<= 16)
     uint32_t keep;  // bit j: raw byte j is a symbol
-    bool other;     // a kept symbol outside ACGT
+    uint32_t other; // bit r: the r-th KEPT symbol lies outside ACGT (0: none)
 };
 
 // byte j of the four words (a select chain: a dynamic index would send the words to scratch memory)
@@ -55,8 +55,23 @@ __device__ __forceinline__ uint8_t pf_byte(const uint32_t w[4], uint32_t j)
     return (uint8_t)(x >> (8 * (j & 3)));
 }
 
-// per byte of w: 1 where the byte is >= 64
-__device__ __forceinline__ uint32_t pf_ge64(uint32_t w) { return ((w >> 6) | (w >> 7)) & 0x01010101u; }
+// per byte of w: 0x80 where the byte is >= 64 (bit 6 or bit 7 set; what the shift brings in from the byte below lands on bit 0)
+__device__ __forceinline__ uint32_t pf_ge64(uint32_t w) { return ((w << 1) | w) & 0x80808080u; }
+
+// four words of 0x80-per-byte flags (16 bytes) -> one bit per byte, byte 0's lowest.  The flags of word q go to bit q of their byte,
+// the four low nibbles are drawn together (bit 4 j + q for byte j of word q) and the 4 x 4 bit matrix is transposed by two delta
+// swaps (bit 4 q + j): 20 plain operations -- a multiply per word to draw a word's flags together costs four issue slots each
+__device__ __forceinline__ uint32_t pf_gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3)
+{
+    uint32_t v = (f0 >> 7) | (f1 >> 6) | (f2 >> 5) | (f3 >> 4);
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    v = (v | (v >> 8)) & 0xFFFFu;
+    uint32_t t = ((v >> 3) ^ v) & 0x0A0Au;
+    v ^= t ^ (t << 3);
+    t = ((v >> 6) ^ v) & 0x00CCu;
+    v ^= t ^ (t << 6);
+    return v;
+}
 
 // the bytes of [p, p + 16) that lie inside a contig range -> 16-bit mask.  [cb, ce) is a range the caller knows (the one its tile
 // starts in); only chunks that leave it walk the list.
@@ -82,7 +97,7 @@ __device__ __forceinline__ PfChunk pf_chunk(const PackFastaArgs &a, uint64_t p, 
     c.bits = 0;
     c.cnt = 0;
     c.keep = 0;
-    c.other = false;
+    c.other = 0;
     if (p >= a.n_raw) {
         w[0] = w[1] = w[2] = w[3] = 0;
         return c;
@@ -97,39 +112,48 @@ __device__ __forceinline__ PfChunk pf_chunk(const PackFastaArgs &a, uint64_t p, 
             if (p + j < a.n_raw)
                 w[j >> 2] |= (uint32_t)a.raw[p + j] << (8 * (j & 3));
     }
-    uint32_t keep = 0, bits = 0, bad = 0, odd = 0;
-    uint32_t diffs[4];
-#pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) {
-        const uint32_t x = w[q];
-        const uint32_t g = pf_ge64(x);                                 // 0x01 per byte >= 64
-        keep |= (((g * 0x01020408u) >> 24) & 0xFu) << (4 * q);         // the four flags, byte 0's lowest
-        // ACGT / acgt: the code is bits 1..2 of the letter, with G and T exchanged (A 0x41 C 0x43 G 0x47 T 0x54 -> 0 1 3 2 -> 0 1 2 3)
-        const uint32_t t = (x >> 1) & 0x03030303u;
-        const uint32_t code = t ^ ((t >> 1) & 0x01010101u);
-        bits |= (((code * 0x00041041u) >> 18) & 0xFFu) << (8 * q);      // the four 2-bit codes side by side, byte 0's lowest
-        // is it one of the four letters?  the letter the two bits stand for, against the byte with its case bit cleared
-        const uint32_t b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u;
-        const uint32_t expect = 0x41414141u + 2u * b0 + 0x13u * b1 - 0x0Fu * (b0 & b1);
-        diffs[q] = ((x & 0xDFDFDFDFu) ^ expect) & ((g << 8) - g);      // (only bytes >= 64 count: 0xFF per such byte)
-        odd |= diffs[q];
-    }
-    // which bytes they are is worked out only when some lane of the wavefront met one (N runs, IUPAC codes: rare)
-    if (__ballot(odd != 0)) {
+    // ACGT / acgt: the code is bits 1..2 of the letter with G and T exchanged (A 0x41 C 0x43 G 0x47 T 0x54 -> 0 1 3 2 -> 0 1 2 3) --
+    // a byte permute with the two bits as selector reads the code, and the letter the two bits stand for, out of a register
+    uint32_t m[4], diffs[4], odd = 0, bad = 0;
+    uint32_t bits;
+    {
+        uint32_t code[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
-            const uint32_t diff = diffs[q];
-            const uint32_t nz = ((diff | ((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u; // 0x01 per byte that differs
-            bad |= (((nz * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+            const uint32_t x = w[q];
+            m[q] = pf_ge64(x);                                            // 0x80 per byte >= 64
+            const uint32_t t = (x >> 1) & 0x03030303u;
+            code[q] = __builtin_amdgcn_perm(0u, 0x02030100u, t);          // t -> 0 1 3 2
+            const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, t); // t -> 'A' 'C' 'T' 'G'
+            const uint32_t full = m[q] | (m[q] - (m[q] >> 7));            // 0xFF per byte >= 64: only those count
+            diffs[q] = ((x & 0xDFDFDFDFu) ^ expect) & full;               // (case bit cleared)
+            odd |= diffs[q];
         }
+        // the sixteen 2-bit codes side by side, byte 0's lowest: word q's codes go to bit pair q of their byte (element 4 j + q),
+        // then the 4 x 4 matrix of 2-bit elements is transposed (element 4 q + j) by two delta swaps
+        uint32_t u = code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6);
+        uint32_t t = ((u >> 6) ^ u) & 0x00CC00CCu;
+        u ^= t ^ (t << 6);
+        t = ((u >> 12) ^ u) & 0x0000F0F0u;
+        u ^= t ^ (t << 12);
+        bits = u;
+    }
+    uint32_t keep = pf_gather16(m[0], m[1], m[2], m[3]);
+    // which bytes are outside ACGT is worked out only when some lane of the wavefront met one (N runs, IUPAC codes: rare)
+    if (__ballot(odd != 0)) {
+        uint32_t nz[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q)
+            nz[q] = (diffs[q] | ((diffs[q] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // 0x80 per byte that differs
+        bad = pf_gather16(nz[0], nz[1], nz[2], nz[3]);
     }
     keep &= pf_range_mask(a, p, cb, ce, r_first);
     bad &= keep;
     if (bad) { // a symbol outside ACGT: its code's two low bits stand in the word (nobody reads them: the block is escaped)
-        c.other = true;
-        for (uint32_t m = bad; m; m &= m - 1) {
-            const uint32_t j = __builtin_ctz(m);
+        for (uint32_t mm = bad; mm; mm &= mm - 1) {
+            const uint32_t j = __builtin_ctz(mm);
             bits = (bits & ~(3u << (2 * j))) | ((uint32_t)(cnv_symbol(pf_byte(w, j)) & 3u) << (2 * j));
+            c.other |= 1u << __popc(keep & ((1u << j) - 1u)); // (its rank among the kept symbols: what the staging clips by)
         }
     }
     // squeeze the dropped bytes' fields out, highest first
@@ -161,28 +185,32 @@ __device__ __forceinline__ uint32_t pf_wave_incl(uint32_t v)
 }
 
 // symbols [g, g + cnt) with the 2-bit fields `bits` -> the tile's word stage in LDS, as far as they lie in [s0, s1)
-__device__ __forceinline__ void pf_stage(uint32_t *lds_words, uint32_t *lds_flag, uint64_t g, uint32_t cnt, uint32_t bits, bool other, uint64_t s0, uint64_t s1)
+__device__ __forceinline__ void pf_stage(uint32_t *lds_words, uint32_t *lds_flag, uint64_t g, uint32_t cnt, uint32_t bits, uint32_t other, uint64_t s0, uint64_t s1)
 {
     if (!cnt || g + cnt <= s0 || g >= s1)
         return;
     if (g < s0) {
         const uint32_t d = (uint32_t)(s0 - g);
         bits >>= 2 * d;
+        other >>= d;
         cnt -= d;
         g = s0;
     }
     if (g + cnt > s1) {
         cnt = (uint32_t)(s1 - g);
         bits &= 0xFFFFFFFFu >> (32 - 2 * cnt);
+        other &= 0xFFFFu >> (16 - cnt);
     }
     const uint32_t li = (uint32_t)(g - s0), sh = 2 * (li & 15);
     atomicOr(&lds_words[li >> 4], bits << sh);
     if (sh && (li & 15) + cnt > 16)
         atomicOr(&lds_words[(li >> 4) + 1], bits >> (32 - sh));
-    if (other) { // (to the block: whether the symbol outside ACGT is among the clipped ones is not worth telling apart -- it is, nearly always)
-        lds_flag[li / PACK_BLOCK] = 1;
-        if ((li + cnt - 1) / PACK_BLOCK != li / PACK_BLOCK)
-            lds_flag[(li + cnt - 1) / PACK_BLOCK] = 1;
+    if (other) { // the block(s) of the symbols outside ACGT that are left after the clipping (a chunk spans two blocks at most)
+        const uint32_t first = PACK_BLOCK - (li & (PACK_BLOCK - 1)); // symbols of this chunk that lie in the first of them
+        if (first >= 16 || (other & ((1u << first) - 1u)))
+            lds_flag[li / PACK_BLOCK] = 1;
+        if (first < 16 && (other >> first))
+            lds_flag[li / PACK_BLOCK + 1] = 1;
     }
 }
 
@@ -237,12 +265,11 @@ __global__ void __launch_bounds__(256) pack_fasta_count_kernel(PackFastaArgs a, 
                 if (p + t < a.n_raw)
                     w[t >> 2] |= (uint32_t)a.raw[p + t] << (8 * (t & 3));
         }
-        uint32_t keep = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q)
-            keep |= (((pf_ge64(w[q]) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
-        keep &= pf_range_mask(a, p, cb, ce, r_first);
-        c += __popc(keep);
+        const uint32_t m0 = pf_ge64(w[0]), m1 = pf_ge64(w[1]), m2 = pf_ge64(w[2]), m3 = pf_ge64(w[3]);
+        if (p >= cb && p + 16 <= ce) // (inside the range the tile starts in: nearly every chunk)
+            c += __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+        else
+            c += __popc(pf_gather16(m0, m1, m2, m3) & pf_range_mask(a, p, cb, ce, r_first));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)

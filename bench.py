@@ -83,6 +83,14 @@ def parse():
     return ap.parse_args()
 
 
+def cgroup_cpu_stat():
+    """usage / throttling counters of this container's CPU quota (cgroup v2 cpu.stat), {} when unreadable"""
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
+    except Exception:
+        return {}
+
+
 def host_cpus():
     """CPUs this container may actually use: the cgroup quota when there is one (the GPU box reports
     256 logical CPUs but grants 16), else the logical CPU count."""
@@ -96,16 +104,20 @@ def host_cpus():
     return n
 
 
-PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r5", "r4", "r3"))
-                    if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r5", "pmc_summary.csv"))
+PMC_SUMMARY = next((p_ for p_ in (os.path.join("profiles", r_, "pmc_summary.csv") for r_ in ("r6", "r5", "r4", "r3"))
+                    if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r6", "pmc_summary.csv"))
 KERNEL_SYMBOL = {"scan": "agc::scan_packed_kernel", "encode": "agc::lz_parse_kernel<0>", "estimate": "agc::lz_parse_kernel<1>",
                  "costvec": "agc::lz_parse_kernel<2>", "filter": "agc::key_filter_kernel", "pack": "agc::pack_fasta_kernel",
                  "zstd": "agc::zstd_frames_grp_kernel<3, 2>"}
+# a row whose time covers more than one kernel: their counters are added up (the conversion = counting pass + pack pass; the scans
+# of the tile counts between them move a few hundred KB)
+KERNEL_SYMBOLS_ALL = {"pack": ("agc::pack_fasta_count_kernel", "agc::pack_fasta_kernel")}
 # bytes per symbol each kernel reads in the layout AS BUILT = SURVEY 8d's 2-bit column since round 4: scan, key filter and the
 # three LZ parses read texts and references as 2-bit words where they lie (no expansion, no reverse-complement staging)
-# (pack: the FASTA bytes of a symbol, 1 + 1 / line width, read once + its 0.25 B written: filled in by main() for --fasta-width)
-AS_BUILT_BPS = {"scan": 0.25, "encode": 0.25, "estimate": 0.25, "costvec": 0.25, "filter": 0.25, "pack": 1.0 + 1.0 / 60 + 0.25}
-PACKED_BPS = AS_BUILT_BPS
+# (pack: the FASTA bytes of a symbol, 1 + 1 / line width, read TWICE -- the counting pass and the pack pass, pack_kernels.hip -- + its
+# 0.25 B written: the layout as built; SURVEY 8d's figure reads them once.  Filled in by main() for --fasta-width)
+AS_BUILT_BPS = {"scan": 0.25, "encode": 0.25, "estimate": 0.25, "costvec": 0.25, "filter": 0.25, "pack": 2.0 * (1.0 + 1.0 / 60) + 0.25}
+PACKED_BPS = dict(AS_BUILT_BPS, pack=1.0 + 1.0 / 60 + 0.25)
 
 
 def pmc_table(path=None):
@@ -137,20 +149,28 @@ def pmc_traffic(tab, name, per_run=False):
     loads as 64 B) + WRITE_SIZE -- except for the kernels of NARROW_LOADS, whose requests the counter tallies as they are
     (this repo's calibration, see above): FETCH_SIZE + WRITE_SIZE.  pmc_traffic_range() states both sums for every kernel: a
     kernel that mixes streaming reads with table probes (the LZ parses) lies in between."""
-    c = tab.get(KERNEL_SYMBOL[name])
-    if not c or "FETCH_SIZE" not in c:
-        return None
-    if per_run:  # (the --config rows: all dispatches of a run together, like their time)
-        return int(((1.0 if name in NARROW_LOADS else 2.0) * c["FETCH_SIZE:sum"] + c.get("WRITE_SIZE:sum", 0.0)) * 1024)
-    return int(((1.0 if name in NARROW_LOADS else 2.0) * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
+    tot = 0
+    for sym in KERNEL_SYMBOLS_ALL.get(name, (KERNEL_SYMBOL[name],)):
+        c = tab.get(sym)
+        if not c or "FETCH_SIZE" not in c:
+            return None
+        if per_run:  # (the --config rows: all dispatches of a run together, like their time)
+            tot += int(((1.0 if name in NARROW_LOADS else 2.0) * c["FETCH_SIZE:sum"] + c.get("WRITE_SIZE:sum", 0.0)) * 1024)
+        else:
+            tot += int(((1.0 if name in NARROW_LOADS else 2.0) * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
+    return tot
 
 
 def pmc_traffic_range(tab, name):
     """[FETCH_SIZE + WRITE_SIZE, 2 x FETCH_SIZE + WRITE_SIZE] in bytes per launch (see pmc_traffic)"""
-    c = tab.get(KERNEL_SYMBOL[name])
-    if not c or "FETCH_SIZE" not in c:
-        return None
-    return [int((f * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024) for f in (1.0, 2.0)]
+    lo = hi = 0
+    for sym in KERNEL_SYMBOLS_ALL.get(name, (KERNEL_SYMBOL[name],)):
+        c = tab.get(sym)
+        if not c or "FETCH_SIZE" not in c:
+            return None
+        lo += int((1.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
+        hi += int((2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024)
+    return [lo, hi]
 
 
 def cpu_baseline(args, mbp):
@@ -315,6 +335,9 @@ def config_cli(args):
         m = re.search(r"windows (\d+) commit-runs (\d+) revalidated (\d+) windows-cut (\d+)", err)
         if m:
             stages["windows"], stages["commit_runs"], stages["revalidated_segments"], stages["windows_cut"] = (int(x) for x in m.groups())
+        m = re.search(r"entropy-seconds: host-pool ([0-9.e+-]+) device ([0-9.e+-]+) staging ([0-9.e+-]+) caller-waited ([0-9.e+-]+)", err)
+        if m:
+            stages["entropy_host_pool_s"], stages["entropy_device_call_s"], stages["entropy_staging_s"], stages["entropy_caller_waited_s"] = (float(x) for x in m.groups())
         m = re.findall(r"entropy stage: device ([0-9.e+-]+) MB in ([0-9.e+-]+) s, host ([0-9.e+-]+) MB in ([0-9.e+-]+) s", err)
         if m:
             stages["entropy_device_mb"] = round(sum(float(x[0]) for x in m), 2)
@@ -332,7 +355,8 @@ def config_cli(args):
             kms = {t_[i]: (float(t_[i + 1]), int(t_[i + 2])) for i in range(0, len(t_) - 2, 3)}
             y_ = ms_.group(1).split()
             sym = {y_[i]: int(y_[i + 1]) for i in range(0, len(y_) - 1, 2)}
-            tab = pmc_table(os.path.join("profiles", "r5", f"pmc_summary_{args.config}.csv"))
+            tab = pmc_table(next((p_ for p_ in (os.path.join("profiles", r_, f"pmc_summary_{args.config}.csv") for r_ in ("r6", "r5"))
+                                  if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r6", f"pmc_summary_{args.config}.csv")))
             for name in ("scan", "encode", "estimate", "costvec", "filter", "zstd"):
                 if name not in kms or not kms[name][0]:
                     continue
@@ -356,7 +380,9 @@ def config_cli(args):
             cpu = {"value": round(bases / rt / 1e9, 4), "unit": "Gbp/s", "cores": threads, "kind": "reference",
                    "sample": f"oracle/_ref/agc create -t {threads} on the same {len(files)} files: median of {ref_reps} = {rt:.3f} s (a one-contig archive: {rt_fixed:.3f} s)",
                    "value_without_start": round(bases / max(rt - rt_fixed, 1e-9) / 1e9, 4), "archives_identical": same}
-        out = {"metric": f"input Gbp/s compressed (create), {args.config}: whole CLI run from FASTA files", "value": round(bases / t_amd / 1e9, 4),
+        out = {"metric": f"input Gbp/s compressed (create), {args.config}: whole CLI run from FASTA files"
+                         + (" -- A START-COST PROBE: 8 Mbp in all, the fixed start of a run is most of its wall time; read fixed_cost_s and "
+                            "value_without_start, not value" if args.config == "c5twin" else ""), "value": round(bases / t_amd / 1e9, 4),
                "unit": "Gbp/s", "n_gpus": 1, "steps": reps, "warmup": 1, "ms_per_step": round(t_amd * 1e3, 1), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": what + f", `agc_amd create` (process start, HIP context, files, archive) -- median wall of {reps} runs",
@@ -364,7 +390,9 @@ def config_cli(args):
                           "fixed_cost_is": "the wall time of `agc_amd create` of one 2 kb contig: process start, HIP context and streams, dlopen of libzstd, archive",
                           "value_without_start": round(bases / max(t_amd - t_fixed, 1e-9) / 1e9, 4),
                           "stage_seconds": stages,
-                          "host_entropy_share_of_wall": round(stages.get("entropy_host_s", 0.0) / t_amd, 3) if stages.get("entropy_host_s") is not None else None},
+                          # the host pool's libzstd time (the entropy thread's own clock around its pool calls: they overlap the
+                          # steps) as a share of the run's wall time
+                          "host_entropy_share_of_wall": (round(stages["entropy_host_pool_s"] / t_amd, 3) if "entropy_host_pool_s" in stages else None)},
                "roofline": ({"bound": "hbm", "kernel": kern[dominant]["kernel"], "achieved": kern[dominant]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": kern[dominant]["frac"], "traffic": kern[dominant]["traffic"],
                              "dominant_by": "largest kernel time per run (HIP events around every launch, a separate run with AGC_AMD_KERNEL_TIMES=1)",
@@ -551,7 +579,8 @@ def main():
     fasta = []                      # per sample: (raw bytes in HBM, n_raw, raw_begin, raw_end, (words, index, esc))
     pack_pending = {}
     pack_ms_each = []
-    AS_BUILT_BPS["pack"] = 1.0 + 1.0 / args.fasta_width + 0.25
+    AS_BUILT_BPS["pack"] = 2.0 * (1.0 + 1.0 / args.fasta_width) + 0.25  # (both passes read the bytes)
+    PACKED_BPS["pack"] = 1.0 + 1.0 / args.fasta_width + 0.25           # (one read + the words: the algorithmic figure)
     for s in range(n_steps):
         codes = synth_dev.make_sample(ref, tot, args.div, shard.sample_seed(1000, s, rank, world), dev)
         if args.prepacked:
@@ -599,11 +628,13 @@ def main():
     bytes0 = (dc.bytes_broadcast, dc.bytes_p2p, dc.n_records) if dc is not None else None
     t0 = time.perf_counter()
     step_ms_each = []
+    cg0 = cgroup_cpu_stat()
     for s in range(args.warmup, n_steps):
         ts_ = time.perf_counter()
         add_step(s, "s")
         step_ms_each.append(round((time.perf_counter() - ts_) * 1e3, 2))
     t_steps = time.perf_counter() - t0
+    cg1 = cgroup_cpu_stat()
     sec1 = dict(dc.seconds) if dc is not None else None
     # (per TIMED sample: the reference sample's record -- the whole collection's references -- is setup and not averaged in)
     head_timed_mb = (dc.bytes_broadcast - bytes0[0]) / max(dc.n_records - bytes0[2], 1) / 1e6 if dc is not None else 0.0
@@ -615,6 +646,7 @@ def main():
         cmp_.close(threads)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    cg2 = cgroup_cpu_stat()
     tm = cmp_.hip_timing_get()
     st1 = cmp_.stats()
     stats = {k_: st1[k_] - st0[k_] for k_ in st1}
@@ -708,6 +740,13 @@ def main():
                                           f"{t_spl:.2f} s; reference genome as first sample (mints ~{int(st0['new_groups'])} groups): {t_ref:.2f} s",
                        "steps_only_ms": round(t_steps / max(args.steps, 1) * 1e3, 3),
                        "step_ms_each_rank0": step_ms_each,
+                       # the container's CPU quota at work (cgroup v2 cpu.stat deltas): CPU seconds used and time spent throttled
+                       "cgroup_cpu": ({"steps": {"cpu_s": round((cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6, 3),
+                                                 "throttled_s": round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e6, 3),
+                                                 "nr_throttled": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0)},
+                                       "close": {"cpu_s": round((cg2.get("usage_usec", 0) - cg1.get("usage_usec", 0)) / 1e6, 3),
+                                                 "throttled_s": round((cg2.get("throttled_usec", 0) - cg1.get("throttled_usec", 0)) / 1e6, 3),
+                                                 "nr_throttled": cg2.get("nr_throttled", 0) - cg1.get("nr_throttled", 0)}} if cg0 else None),
                        "pack_ms_cumulative_after_each_pack": pack_ms_each[-(args.steps + 2):],
                        **({"archive_sha256": _sha256_file(archive_path), "archive_bytes": os.path.getsize(archive_path)} if archive_path else {}),
                        "close_ms": round((elapsed - t_steps) * 1e3, 1),

@@ -158,6 +158,14 @@ int agc_hip_pack_fasta_end(agc_hip_ctx *ctx, uint64_t *h_ctg_off, uint64_t *h_n_
 int agc_hip_pack_fasta_dev(agc_hip_ctx *ctx, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *h_raw_begin, const uint64_t *h_raw_end,
                            uint32_t n_ctg, uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks,
                            uint64_t *h_ctg_off, uint64_t *h_n_esc_blocks);
+/* The same for a host that reads FASTA files: the sequence lines of the window's contigs, in HOST memory as the reader cut them
+ * out of the file (contig c = h_raw[c], h_len[c] bytes: what genome_io hands to the reference's workers,
+ * src/core/agc_compressor.cpp:2160-2228), are uploaded as they are and converted + packed on the device into buffers the CONTEXT
+ * owns (*out names them; valid until the next agc_hip_sample_pack / agc_hip_sample_pack_fasta; an encode left in flight on the
+ * previous sample is waited for first).  h_ctg_off receives the contigs' symbol offsets (n_ctg + 1).  Replaces, per window,
+ * preprocess_raw_contig (agc_compressor.cpp:907-951) of every contig + agc_hip_sample_pack. */
+int agc_hip_sample_pack_fasta(agc_hip_ctx *ctx, uint32_t n_ctg, const uint8_t *const *h_raw, const uint64_t *h_len, agc_hip_packed *out,
+                              uint64_t *h_ctg_off);
 /* packed -> codes (d_codes: n_symbols bytes, 16-byte aligned).  Nothing on the create path needs it (the LZ kernels read the
  * packed form); a utility for callers and tests.  Asynchronous on the context's stream (ordered before every later call). */
 int agc_hip_expand_dev(agc_hip_ctx *ctx, const agc_hip_packed *pk, uint8_t *d_codes);

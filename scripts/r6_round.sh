@@ -60,3 +60,131 @@ for n in ("c_bench_1", "c_bench_early_off", "c_bench_2"):
         print(n, e)
 PY
 fi
+if [ "$PART" = d ]; then
+  # stream priorities (0 off, 1 steps high + bulk low, 2 steps high only); host threads of the entropy pool; the new thread pool
+  bench d_bench_prio1
+  bench d_bench_prio0 AGC_HIP_STREAM_PRIORITIES=0
+  bench d_bench_prio2 AGC_HIP_STREAM_PRIORITIES=2
+  bench d_bench_prio1_b
+  bench d_bench_prio0_b AGC_HIP_STREAM_PRIORITIES=0
+  for t in 20 24; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --threads $t > $OUT/d_bench_threads$t.json 2>/dev/null; show $OUT/d_bench_threads$t.json; done
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/d_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"], d["config"].get("cgroup_cpu"))
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = e ]; then
+  # Close: the pool starts at once, the device's side on its own thread; arena chunks grow geometrically; no stream priorities
+  timeout 600 python -m pytest tests/test_gpu_archive.py tests/test_gpu_zstd.py -m gpu -x -q > $OUT/e_tests.log 2>&1; tail -3 $OUT/e_tests.log
+  bench e_bench_1
+  bench e_bench_2
+  bench e_bench_3
+  AGC_AMD_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/e_bench_laps.json 2> $OUT/e_bench_laps.txt; show $OUT/e_bench_laps.json
+  grep -n "close lap\|entropy lap\|finish_groups" $OUT/e_bench_laps.txt | tail -12
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/e_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"], d["config"].get("cgroup_cpu"))
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = f ]; then
+  # bulk streams on a CU mask (32 CUs never take a bulk block); S1a on the file path; allocation latencies
+  python scripts/malloc_probe.py > $OUT/f_malloc_probe.txt 2>&1; cat $OUT/f_malloc_probe.txt
+  timeout 900 python -m pytest tests/test_gpu_archive.py -m gpu -x -q > $OUT/f_archive_tests.log 2>&1; tail -3 $OUT/f_archive_tests.log
+  bench f_bench_mask32
+  bench f_bench_mask0 AGC_HIP_BULK_FREE_CUS=0
+  bench f_bench_mask64 AGC_HIP_BULK_FREE_CUS=64
+  bench f_bench_mask32_b
+  bench f_bench_mask0_b AGC_HIP_BULK_FREE_CUS=0
+  AGC_AMD_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/f_bench_laps.json 2> $OUT/f_bench_laps.txt; show $OUT/f_bench_laps.json
+  timeout 600 python bench.py --from-fasta 2 > $OUT/f_from_fasta.json 2> $OUT/f_from_fasta.err; cat $OUT/f_from_fasta.json | cut -c1-700
+  AGC_AMD_FASTA_PACK=0 timeout 600 python bench.py --from-fasta 2 > $OUT/f_from_fasta_off.json 2> $OUT/f_from_fasta_off.err; cat $OUT/f_from_fasta_off.json | cut -c1-700
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/f_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"], d["config"].get("cgroup_cpu"))
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = g ]; then
+  # pack kernel with byte-permute look-ups and bit-matrix transposes; exact escape flags; Close with the gather by the pool again
+  timeout 600 python -m pytest tests/test_gpu_scan.py -m gpu -x -q -k "pack_fasta" > $OUT/g_pack_tests.log 2>&1; tail -5 $OUT/g_pack_tests.log
+  timeout 200 python scripts/pack_alone.py 3.0 0 > $OUT/g_pack_alone.log 2>&1; tail -4 $OUT/g_pack_alone.log
+  timeout 900 python -m pytest tests/test_gpu_archive.py -m gpu -x -q > $OUT/g_archive_tests.log 2>&1; tail -3 $OUT/g_archive_tests.log
+  bench g_bench_1
+  bench g_bench_2
+  bench g_bench_3
+  AGC_AMD_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/g_bench_laps.json 2> $OUT/g_bench_laps.txt; show $OUT/g_bench_laps.json
+  grep -n "close lap\|entropy lap\|finish_groups" $OUT/g_bench_laps.txt | tail -12
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/g_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"], d["config"].get("cgroup_cpu"))
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = h ]; then
+  # where the hiccups of the FIRST bench run on a fresh box come from (steps 9 and 17 of the timed region: 180 + 42 ms): laps first
+  AGC_AMD_LAPS=1 AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/h_bench_laps_first.json 2> $OUT/h_bench_laps_first.txt; show $OUT/h_bench_laps_first.json
+  python - <<'PY'
+import re, collections, json
+lines = open("gpurun_out/r6/h_bench_laps_first.txt").read().splitlines()
+steps = []; cur = None
+for l in lines:
+    m = re.match(r'\s+lap (.*?) ([0-9.e+-]+) ms$', l)
+    if m:
+        if m.group(1) == 'group map -> device':
+            cur = collections.OrderedDict(); steps.append(cur)
+        if cur is not None:
+            cur[m.group(1)] = cur.get(m.group(1), 0) + float(m.group(2))
+for i, s in enumerate(steps[-20:]):
+    tot = sum(s.values())
+    if tot > 17:
+        print("timed step", i, "sum", round(tot, 1), {k: round(v, 1) for k, v in s.items() if v > 1.5})
+d = json.loads(open("gpurun_out/r6/h_bench_laps_first.json").read().strip().splitlines()[-1])
+print(d["config"]["step_ms_each_rank0"])
+PY
+  grep -n "prepare_batch lap\|lz_encode_end lap\|segments_packed lap" $OUT/h_bench_laps_first.txt | awk '{ if ($(NF-1)+0 > 8) print }' | head -20
+  bench h_bench_2
+fi
+if [ "$PART" = i ]; then
+  AGC_AMD_LAPS=1 AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/i_bench_laps_first.json 2> $OUT/i_bench_laps_first.txt; show $OUT/i_bench_laps_first.json
+  grep -n "ensure:\|arena:" $OUT/i_bench_laps_first.txt | tail -40
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r6/i_bench_laps_first.json").read().strip().splitlines()[-1])
+print(d["config"]["step_ms_each_rank0"]); print(d["config"]["setup_not_timed"])
+PY
+fi
+if [ "$PART" = j ]; then
+  # the arena's next chunk allocated ahead by a helper thread: the first run on a fresh box again
+  AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/j_bench_first.json 2> $OUT/j_bench_first.txt; show $OUT/j_bench_first.json
+  grep -n "ensure:\|arena:" $OUT/j_bench_first.txt | tail -12
+  bench j_bench_2
+  bench j_bench_3
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/j_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"], d["config"].get("cgroup_cpu"))
+    except Exception as e:
+        print(n, e)
+PY
+  timeout 900 python -m pytest tests/test_dist_single_archive.py -m gpu -x -q -k "rccl" > $OUT/j_rccl_one_rank.log 2>&1; tail -5 $OUT/j_rccl_one_rank.log
+fi

@@ -63,6 +63,10 @@ struct agc_hip_ctx {
     /* the mirrored (k-mer 1, k-mer 2) -> group table */
     agc_hip_group_slot *gmap;
     u64 gmap_slots;
+    /* agc_hip_pack_fasta_begin .. _end: the result of the one conversion in flight */
+    int pfa_pending, pfa_rc;
+    u32 pfa_n_ctg;
+    u64 *pfa_off, pfa_esc;
     /* agc_hip_sample_pack: the context's own packed buffers */
     uint32_t *sp_words;
     int32_t *sp_index;
@@ -125,6 +129,7 @@ void agc_hip_destroy(agc_hip_ctx *c)
     free(c->sp_index);
     free(c->sp_esc);
     free(c->gmap);
+    free(c->pfa_off);
     free(c->sg_gid), free(c->sg_len), free(c->sg_off), free(c->sg_rc), free(c->sg_codes);
     for (u32 l = 0; l < AGC_HIP_ENCODE_LANES; ++l)
         free(c->enc[l].out), free(c->enc[l].eoff);
@@ -934,4 +939,80 @@ int agc_hip_preprocess_dev(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw,
 int agc_hip_preprocess(agc_hip_ctx *c, const uint8_t *h_raw, uint64_t n_raw, uint8_t *d_codes, uint64_t *h_n)
 {
     return agc_hip_preprocess_dev(c, h_raw, n_raw, d_codes, h_n);
+}
+
+/* S1a on the stand-in: the oracle's preprocess_raw_contig of every contig's byte range, the codes back to back, then the
+ * stand-in's own pack.  "begin" does the work, "end" hands the result out (one conversion in flight, as in the product). */
+int agc_hip_pack_fasta_begin(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *h_raw_begin, const uint64_t *h_raw_end, uint32_t n_ctg,
+                             uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks)
+{
+    if (!c || (n_ctg && (!h_raw_begin || !h_raw_end)))
+        return AGC_HIP_EINVAL;
+    u64 ub = 0, prev = 0;
+    for (u32 i = 0; i < n_ctg; ++i) {
+        if (h_raw_begin[i] < prev || h_raw_end[i] < h_raw_begin[i] || h_raw_end[i] > n_raw)
+            return AGC_HIP_EINVAL;
+        prev = h_raw_end[i];
+        ub += h_raw_end[i] - h_raw_begin[i];
+    }
+    u8 *codes = (u8 *)malloc(ub + 1);
+    free(c->pfa_off);
+    c->pfa_off = (u64 *)calloc((size_t)n_ctg + 1, 8);
+    if (!codes || !c->pfa_off) {
+        free(codes);
+        return fail(c, AGC_HIP_ENOMEM, "out of memory (pack_fasta)");
+    }
+    u64 n = 0;
+    for (u32 i = 0; i < n_ctg; ++i) {
+        c->pfa_off[i] = n;
+        if (h_raw_end[i] > h_raw_begin[i])
+            n += agco_preprocess(d_raw + h_raw_begin[i], (size_t)(h_raw_end[i] - h_raw_begin[i]), codes + n);
+    }
+    c->pfa_off[n_ctg] = n;
+    c->pfa_n_ctg = n_ctg;
+    c->pfa_esc = 0;
+    c->pfa_rc = n ? agc_hip_pack_dev(c, codes, n, d_words, d_esc_index, d_esc_bytes, esc_cap_blocks, &c->pfa_esc) : AGC_HIP_OK;
+    free(codes);
+    c->pfa_pending = 1;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_pack_fasta_end(agc_hip_ctx *c, uint64_t *h_ctg_off, uint64_t *h_n_esc_blocks)
+{
+    if (!c || !h_ctg_off || !h_n_esc_blocks || !c->pfa_pending)
+        return AGC_HIP_EINVAL;
+    c->pfa_pending = 0;
+    memcpy(h_ctg_off, c->pfa_off, ((size_t)c->pfa_n_ctg + 1) * 8);
+    *h_n_esc_blocks = c->pfa_esc;
+    return c->pfa_rc;
+}
+
+int agc_hip_pack_fasta_dev(agc_hip_ctx *c, const uint8_t *d_raw, uint64_t n_raw, const uint64_t *h_raw_begin, const uint64_t *h_raw_end, uint32_t n_ctg,
+                           uint32_t *d_words, int32_t *d_esc_index, uint8_t *d_esc_bytes, uint64_t esc_cap_blocks, uint64_t *h_ctg_off, uint64_t *h_n_esc_blocks)
+{
+    const int rc = agc_hip_pack_fasta_begin(c, d_raw, n_raw, h_raw_begin, h_raw_end, n_ctg, d_words, d_esc_index, d_esc_bytes, esc_cap_blocks);
+    return rc != AGC_HIP_OK ? rc : agc_hip_pack_fasta_end(c, h_ctg_off, h_n_esc_blocks);
+}
+
+int agc_hip_sample_pack_fasta(agc_hip_ctx *c, uint32_t n_ctg, const uint8_t *const *h_raw, const uint64_t *h_len, agc_hip_packed *out, uint64_t *h_ctg_off)
+{
+    if (!c || !out || !h_ctg_off || (n_ctg && (!h_raw || !h_len)))
+        return AGC_HIP_EINVAL;
+    memset(out, 0, sizeof *out);
+    u64 ub = 0;
+    for (u32 i = 0; i < n_ctg; ++i)
+        ub += h_len[i];
+    u8 *codes = (u8 *)malloc(ub + 1);
+    if (!codes)
+        return fail(c, AGC_HIP_ENOMEM, "out of memory (sample_pack_fasta)");
+    u64 n = 0;
+    for (u32 i = 0; i < n_ctg; ++i) {
+        h_ctg_off[i] = n;
+        if (h_len[i])
+            n += agco_preprocess(h_raw[i], (size_t)h_len[i], codes + n);
+    }
+    h_ctg_off[n_ctg] = n;
+    const int rc = n ? agc_hip_sample_pack(c, codes, n, out) : AGC_HIP_OK;
+    free(codes);
+    return rc;
 }

@@ -41,11 +41,16 @@ def _sim_zstd_batch():
     return run
 
 
-def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=False, append_to=None):
+def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=False, append_to=None, backend="gloo", cmp_world=None):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":  # RCCL: one process per GPU, the communicator bound to the device at once
+            import torch
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         from agc_amd import host
         from agc_amd.dist import DistCompressor
         device = None
@@ -62,7 +67,9 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
             if args[i] in opt:
                 opt[args[i]] = int(args[i + 1])
         cmp_ = host.Compressor(lib=lib)
-        cmp_.set_distributed(rank, world, 0)
+        # (cmp_world: what the compressor is told -- a lone rank that is told of two still makes commit records and hands its packs
+        # out at Close, so the record transport runs without a second process)
+        cmp_.set_distributed(rank, cmp_world or world, 0)
         if append_to is not None:  # every rank loads the input archive; the writer copies it into the new one
             cmp_.append(append_to, out_path if rank == 0 else "", concatenated="-c" in args, adaptive="-a" in args, n_threads=2)
         else:
@@ -220,6 +227,48 @@ def test_append_from_n_ranks_equals_the_reference(plan, world, tmp_path):
     subprocess.run([cli, "create"] + args + ["-t", "4", "-o", step0] + files[:steps[0]], check=True, capture_output=True, timeout=300)
     assert hashlib.sha256(open(step0, "rb").read()).hexdigest() == gold[0]["sha256"]
     _run(coll, world, tmp_path, on_gpu=False, files=files[steps[0]:steps[0] + steps[1]], append_to=step0, want=gold[1])
+
+
+def _one_rank(name, tmp_path, on_gpu, backend):
+    files = COLL.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "dist.agc")
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_worker, args=(0, 1, port, name, files, out, q, on_gpu, True, None, backend, 2))
+    p_.start()
+    p_.join(timeout=600)
+    assert not p_.is_alive()
+    res = q.get(timeout=10)
+    assert res[1] == "ok", res
+    assert res[2] > 0  # (bytes of record heads that went through the broadcast)
+    got = open(out, "rb").read()
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_adaptive"])
+def test_one_rank_told_of_two_makes_records_and_deals_its_packs(name, tmp_path):
+    """the harness of the RCCL test below on the CPU (gloo, stand-in): one process whose compressor is told it is the writer of two ranks
+    makes every commit record, publishes it to a world of one and codes its own share at Close; same archive"""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    _one_rank(name, tmp_path, False, "gloo")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["syn_mixed", "syn_c3_twin"])
+def test_record_transport_under_rccl_with_one_rank(name, tmp_path):
+    """RCCL readiness on a one-GPU box: ONE process, backend nccl (= RCCL) bound to cuda:0, the compressor told it is the writer of a
+    two-rank job -- every sample's commit record is made, copied pinned -> HBM into the device message buffer (`_dmsg`), broadcast
+    (a one-rank collective on HBM tensors), the RCCL placement check (all_gather of device indices) and the warm-up run, Close deals the
+    packs through the collect / provide path and this rank's GPU codes its share from HBM.  What a second rank would add -- send /
+    recv of bodies and packs -- is not reachable with one process; the archive must still be the reference's."""
+    from agc_amd import build
+    build.build_host()
+    _one_rank(name, tmp_path, True, "nccl")
 
 
 @pytest.mark.gpu

@@ -136,6 +136,14 @@ def _check_pack_fasta(hip_ctx, oracle, raw, rb, re_, esc_cap=64):
         if not np.array_equal(got, exp):
             bad = np.nonzero(got != exp)[0]
             raise AssertionError(f"{bad.size} symbols differ, first at {bad[:5]}: got {got[bad[:5]]} want {exp[bad[:5]]}")
+        # the escaped blocks are exactly those that hold a symbol outside ACGT -- the packed form agc_hip_pack_dev gives for the
+        # same codes (a clean block beside an N must not take an escape slot: ADVICE r5)
+        nb = (n + 1023) // 1024
+        pad = np.zeros(nb * 1024, np.uint8)
+        pad[:n] = exp
+        want_esc = (pad.reshape(nb, 1024) > 3).any(axis=1)
+        got_esc = keep[1][:nb].cpu().numpy() >= 0
+        assert np.array_equal(got_esc, want_esc), (np.nonzero(got_esc != want_esc)[0][:8], int(got_esc.sum()), int(want_esc.sum()))
     return pk, keep, off
 
 
