@@ -35,7 +35,7 @@ SYMBOLS = [
     "agc_hip_ref_lag_counts_dev",
     "agc_hip_zstd17_max_input", "agc_hip_zstd17_resident_frames", "agc_hip_zstd17_batch", "agc_hip_zstd17_batch_dev", "agc_hip_zstd17_background", "agc_hip_zstd17_cparams", "agc_hip_zstd_batch", "agc_hip_zstd_cparams",
     "agc_hip_packed_words_bytes", "agc_hip_packed_index_bytes", "agc_hip_pack_dev", "agc_hip_expand_dev", "agc_hip_scan_packed_dev",
-    "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched", "agc_hip_sample_pack", "agc_hip_sample_pack_fasta",
+    "agc_hip_prefetch_packed_dev", "agc_hip_scan_prefetched", "agc_hip_sample_pack", "agc_hip_sample_pack_fasta", "agc_hip_ref_store_begin_packed", "agc_hip_ref_store_end",
     "agc_hip_ref_register_batch_packed", "agc_hip_lz_encode_batch_packed", "agc_hip_lz_encode_begin_packed", "agc_hip_lz_estimate_batch_packed",
     "agc_hip_lz_cost_vector_batch_packed", "agc_hip_lz_split_point_batch_packed", "agc_hip_fetch_slices_packed", "agc_hip_ref_lag_counts_packed",
     "agc_hip_pack_fasta_begin", "agc_hip_pack_fasta_end", "agc_hip_pack_fasta_dev",
@@ -156,6 +156,8 @@ def load():
     L.agc_hip_prefetch_packed_dev.argtypes = [vp, C.POINTER(Packed), u64p, C.c_uint32, C.c_uint32]
     pkp = C.POINTER(Packed)
     L.agc_hip_sample_pack.argtypes = [vp, vp, C.c_uint64, pkp]
+    L.agc_hip_ref_store_begin_packed.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, pkp, u64p, C.POINTER(C.c_uint32), vp, vp, vp, vp, C.c_uint64, u64p]
+    L.agc_hip_ref_store_end.argtypes = [vp, C.c_uint32]
     L.agc_hip_sample_pack_fasta.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), u64p, pkp, u64p]
     L.agc_hip_ref_register_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, C.c_uint32]
     L.agc_hip_lz_encode_batch_packed.argtypes = [vp, C.c_uint32, u32p, pkp, u64p, u32p, u8p, u8p, C.c_uint64, u64p]

@@ -6,6 +6,7 @@
 #include "dev_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -73,6 +74,13 @@ struct agc_hip_ctx {
     DevBuf d_refs;
     bool refs_dirty = true;
     std::vector<ArenaChunk> arena;
+    // agc_hip_ref_store_begin_packed / _end: two slots, a stream and buffers of their own (the steps' stream never waits for them)
+    struct RefStore {
+        DevBuf d_slices, d_lag, d_out;
+        hipEvent_t done = nullptr;
+        std::atomic<bool> pending{false}; // (_end may run on the caller's bookkeeping thread)
+    } ref_store[2];
+    hipStream_t ref_store_stream = nullptr;
     // the NEXT chunk, allocated ahead of need by a helper thread (arena_alloc): a hipMalloc of GBs is 30 ms per GB on a box whose
     // VRAM this process touches for the first time -- 150 ms in the middle of a step (profiles/r6/)
     std::future<ArenaChunk> arena_spare;
@@ -339,7 +347,7 @@ int upload(agc_hip_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStre
         }
         const size_t need = (bytes + 255) & ~(size_t)255;
         if (c->up_head + need > c->up_cap) {
-            for (hipStream_t s_ : {c->stream, c->stream2, c->stream3, c->pf.stream, c->pfa.stream})
+            for (hipStream_t s_ : {c->stream, c->stream2, c->stream3, c->pf.stream, c->pfa.stream, c->ref_store_stream})
                 if (s_)
                     HIPCHK(c, hipStreamSynchronize(s_));
             c->up_head = 0;
@@ -561,6 +569,17 @@ void agc_hip_destroy(agc_hip_ctx *c)
             (void)hipFree(b->p);
     for (auto &ch : c->arena)
         (void)hipFree(ch.p);
+    for (auto &rs : c->ref_store) {
+        for (DevBuf *b : {&rs.d_slices, &rs.d_lag, &rs.d_out})
+            if (b->p)
+                (void)hipFree(b->p);
+        if (rs.done)
+            (void)hipEventDestroy(rs.done);
+    }
+    if (c->ref_store_stream) {
+        (void)hipStreamSynchronize(c->ref_store_stream);
+        (void)hipStreamDestroy(c->ref_store_stream);
+    }
     if (c->arena_spare.valid()) {
         const ArenaChunk sp = c->arena_spare.get();
         if (sp.p)
@@ -645,6 +664,9 @@ int agc_hip_sample_buffer(agc_hip_ctx *c, uint64_t bytes, uint8_t **d_ptr)
             else
                 HIPCHK(c, hipStreamWaitEvent(c->stream, ln->done, 0));
         }
+    for (auto &rs : c->ref_store) // (agc_hip_ref_store_begin_dev does not exist: only packed samples take that path -- kept for symmetry)
+        if (rs.pending)
+            HIPCHK(c, hipEventSynchronize(rs.done));
     CHK(ensure(c, c->d_sample, bytes + 4096));
     *d_ptr = (uint8_t *)c->d_sample.p;
     return AGC_HIP_OK;
@@ -667,10 +689,14 @@ int agc_hip_sample_pack(agc_hip_ctx *c, const uint8_t *d_codes, uint64_t n_symbo
     if (!c || !out || (n_symbols && !d_codes))
         return AGC_HIP_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    // (the encode of the previous sample may still be reading these buffers on the second lane: see Lane2::done)
+    // (the encode of the previous sample may still be reading these buffers on the second lane: see Lane2::done; and the copy of
+    // its new references on the reference-store stream)
     for (auto *ln : {&c->l2, &c->l3})
         if (ln->done_valid)
             HIPCHK(c, hipEventSynchronize(ln->done));
+    for (auto &rs : c->ref_store)
+        if (rs.pending)
+            HIPCHK(c, hipEventSynchronize(rs.done));
     PackedSrc src;
     {
         KTimer t(c, AGC_HIP_K_PREPROCESS);
@@ -1154,10 +1180,14 @@ int agc_hip_sample_pack_fasta(agc_hip_ctx *c, uint32_t n_ctg, const uint8_t *con
         h_ctg_off[i] = 0;
     if (!tot)
         return AGC_HIP_OK;
-    // (the encode of the previous sample may still be reading the packed buffers on a lane: see Lane2::done)
+    // (the encode of the previous sample may still be reading the packed buffers on a lane: see Lane2::done; and the copy of its new
+    // references on the reference-store stream)
     for (auto *ln : {&c->l2, &c->l3})
         if (ln->done_valid)
             HIPCHK(c, hipEventSynchronize(ln->done));
+    for (auto &rs : c->ref_store)
+        if (rs.pending)
+            HIPCHK(c, hipEventSynchronize(rs.done));
     CHK(ensure(c, c->d_in, tot + 64));
     for (uint32_t i = 0; i < n_ctg; ++i)
         if (h_len[i])
@@ -2404,6 +2434,78 @@ static int ref_lag_counts_impl(agc_hip_ctx *c, uint32_t n, const PackedSrc &src,
 }
 
 extern "C" {
+
+// The new references (and raw items) of a registration in ONE submission that nobody on the steps' stream waits for: the
+// repetitiveness counters of the first n_refs slices (agc_hip_ref_lag_counts_packed) and the symbols of all n slices
+// (agc_hip_fetch_slices_packed), on a stream and in buffers of their own; _end waits for the slot (include/agc_hip.h).
+int agc_hip_ref_store_begin_packed(agc_hip_ctx *c, uint32_t slot, uint32_t n_refs, uint32_t n, const agc_hip_packed *pk, const uint64_t *h_off, const uint32_t *h_len,
+                                   const uint8_t *h_rc, uint32_t *h_cnt, uint32_t *h_cur, uint8_t *h_out, uint64_t out_cap, uint64_t *h_out_off)
+{
+    if (!c || slot >= 2 || n_refs > n || !h_out_off || (n && (!pk || !pk->d_words || !h_off || !h_len)) || (n_refs && (!h_cnt || !h_cur)))
+        return AGC_HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    agc_hip_ctx::RefStore &R = c->ref_store[slot];
+    if (!c->ref_store_stream)
+        HIPCHK(c, hipStreamCreateWithFlags(&c->ref_store_stream, hipStreamNonBlocking));
+    if (!R.done)
+        HIPCHK(c, hipEventCreateWithFlags(&R.done, hipEventDisableTiming));
+    const hipStream_t st = c->ref_store_stream;
+    if (R.pending) { // (a slot nobody collected: its copies must have landed before its buffers are written again)
+        HIPCHK(c, hipEventSynchronize(R.done));
+        R.pending = false;
+    }
+    h_out_off[0] = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        h_out_off[i + 1] = h_out_off[i] + h_len[i];
+    const uint64_t tot = h_out_off[n];
+    if (tot > out_cap)
+        return AGC_HIP_ECAP;
+    if (!n)
+        return AGC_HIP_OK;
+    if (tot && !h_out)
+        return AGC_HIP_EINVAL;
+    const PackedSrc src = src_of(pk);
+    if (!slices_inside(src, n, h_off, h_len))
+        return AGC_HIP_EINVAL;
+    CHK(ensure(c, R.d_out, tot + 64, st));
+    CHK(ensure(c, R.d_slices, (size_t)n * sizeof(ViewJob), st));
+    CHK(ensure(c, R.d_lag, std::max<size_t>(64, (size_t)n_refs * 28 * 4 * 2), st));
+    std::vector<ViewJob> sl(n);
+    for (uint32_t i = 0; i < n; ++i)
+        sl[i] = {{src.words, src.esc_index, src.esc_bytes, h_off[i], h_len[i], h_rc ? (uint32_t)(h_rc[i] != 0) : 0u}, (uint8_t *)R.d_out.p + h_out_off[i]};
+    CHK(upload(c, R.d_slices.p, sl.data(), (size_t)n * sizeof(ViewJob), st));
+    if (n_refs) {
+        uint32_t *d_cnt = (uint32_t *)R.d_lag.p, *d_cur = d_cnt + (size_t)n_refs * 28;
+        const uint32_t split = n_refs >= 2048 ? 1u : std::min<uint32_t>(32u, 2048u / n_refs);
+        HIPCHK(c, hipMemsetAsync(R.d_lag.p, 0, (size_t)n_refs * 28 * 4 * 2, st));
+        hipLaunchKernelGGL(lag_counts_kernel, dim3(n_refs * split), dim3(256), 0, st, (const ViewJob *)R.d_slices.p, d_cnt, d_cur, split);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, (size_t)n_refs * 28 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(h_cur, d_cur, (size_t)n_refs * 28 * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (tot) {
+        hipLaunchKernelGGL(slice_expand_kernel, dim3(grid_for(n, 1, 65536)), dim3(256), 0, st, (const ViewJob *)R.d_slices.p, n);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h_out, R.d_out.p, tot, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipEventRecord(R.done, st));
+    R.pending = true;
+    return AGC_HIP_OK;
+}
+
+int agc_hip_ref_store_end(agc_hip_ctx *c, uint32_t slot)
+{
+    if (!c || slot >= 2)
+        return AGC_HIP_EINVAL;
+    agc_hip_ctx::RefStore &R = c->ref_store[slot];
+    if (!R.pending)
+        return AGC_HIP_OK;
+    // (no hipSetDevice, no write to the shared error string: this may be the bookkeeping thread)
+    if (hipEventSynchronize(R.done) != hipSuccess)
+        return AGC_HIP_ENODEV;
+    R.pending = false;
+    return AGC_HIP_OK;
+}
 
 // ---- sequences in a 2-bit packed buffer -------------------------------------
 int agc_hip_lz_estimate_batch_packed(agc_hip_ctx *c, uint32_t n, const uint32_t *h_gid, const agc_hip_packed *pk, const uint64_t *h_off,

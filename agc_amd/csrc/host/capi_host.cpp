@@ -131,6 +131,16 @@ int agc_cmp_close_collect_packs(void *h, const uint8_t **src, const uint64_t **o
 {
     return ((CAGCCompressor *)h)->CloseCollectPacks(src, off, n) ? 1 : 0;
 }
+uint64_t agc_cmp_deferred_pack_bytes(void *h) { return ((CAGCCompressor *)h)->DeferredPackBytes(); }
+int agc_cmp_deal_collect_packs(void *h, uint32_t *deal_id, const uint8_t **src, const uint64_t **off, uint32_t *n)
+{
+    return ((CAGCCompressor *)h)->DealCollectPacks(deal_id, src, off, n) ? 1 : 0;
+}
+int agc_cmp_deal_keep_own(void *h, uint32_t deal_id, uint32_t first, uint32_t count) { return ((CAGCCompressor *)h)->DealKeepOwn(deal_id, first, count) ? 1 : 0; }
+int agc_cmp_deal_provide_frames(void *h, uint32_t deal_id, uint32_t first, uint32_t count, const uint8_t *frames, const uint64_t *off)
+{
+    return ((CAGCCompressor *)h)->DealProvideFrames(deal_id, first, count, frames, off) ? 1 : 0;
+}
 int agc_cmp_close_provide_frames(void *h, const uint8_t *frames, const uint64_t *off)
 {
     return ((CAGCCompressor *)h)->CloseProvideFrames(frames, off) ? 1 : 0;

@@ -106,6 +106,8 @@ bool CAGCCompressor::SetReferenceDevice(const uint8_t *d_codes, const uint64_t *
     return SetSplitters(spl.data(), n_spl);
 }
 
+void StartLap(const char *what) { start_lap(what); }
+
 bool CAGCCompressor::SetSplitters(const uint64_t *kmers, uint64_t n)
 {
     if (!p->created)
@@ -140,10 +142,12 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
     I.verbosity = verbosity;
 
     std::string e;
+    start_lap("Create");
     if (!I.zstd.load(e)) {
         I.err(e);
         return false;
     }
+    start_lap("libzstd opened");
     if (!I.hip) {
         int rc = agc_hip_create(&I.hip, I.device);
         if (rc != AGC_HIP_OK) {
@@ -151,6 +155,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
             return false;
         }
     }
+    start_lap("device context (runtime, streams, events)");
     unsigned nt = std::max(1u, no_threads);
     I.pool.reset(new ThreadPool(nt));
     I.zpool.reset(new ThreadPool(nt, 10));
@@ -161,6 +166,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         I.async_encode = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_EARLY_COLLECT"))
         I.early_collect = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_REF_STORE_ASYNC"))
+        I.ref_store_async = atoi(e) != 0;
     I.enc_alt.ctx = I.enc_alt2.ctx = I.hip;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
@@ -182,6 +189,7 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         return false;
     }
     I.created = true;
+    start_lap("pools, zstd contexts");
 
     if (!reference_file_name.empty()) {
         // the reference file: big plain files through the mapped reader; contigs of 1 MiB and more are converted to symbol
@@ -354,6 +362,8 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         I.async_encode = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_EARLY_COLLECT"))
         I.early_collect = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_REF_STORE_ASYNC"))
+        I.ref_store_async = atoi(e) != 0;
     I.enc_alt.ctx = I.enc_alt2.ctx = I.hip;
     for (unsigned i = 0; i < nt; ++i)
         I.zctx.emplace_back(new ZstdCtx(&I.zstd));
@@ -1227,6 +1237,7 @@ bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off
         return false;
     if (!I.book_wait())
         return false;
+    I.settle_deals_locally();
     I.z_wait_all(); // (the staging buffers below are the entropy thread's)
     I.store_open_batch();
     I.close_jobs.clear();
@@ -1258,6 +1269,128 @@ bool CAGCCompressor::CloseCollectPacks(const uint8_t **src, const uint64_t **off
     *n = (uint32_t)I.close_dev_jobs.size();
     I.close_collected = true;
     I.close_frames_off.clear();
+    return true;
+}
+
+// a pack's frame as add_to_archive stores it (segment.h:177-187: frame + a zero byte; the pack itself, metadata 0, when that is
+// not shorter), into the part's slot
+void CAGCCompressor::Impl::publish_frame(ZJob &j, const uint8_t *frame, size_t n)
+{
+    if (n + 1 < j.data.size()) {
+        j.out.assign(frame, frame + n);
+        j.out.push_back(0);
+        j.meta = j.data.size();
+    } else {
+        j.out = j.data;
+        j.meta = 0;
+    }
+    {
+        std::lock_guard<std::mutex> lk(z_mtx); // (the entropy thread adds to the same counters)
+        st.zstd_in += j.data.size();
+        st.zstd_out += j.out.size();
+    }
+    j.slot->out = std::move(j.out);
+    j.slot->meta = j.meta;
+    j.slot->ready.store(true, std::memory_order_release);
+}
+
+uint64_t CAGCCompressor::DeferredPackBytes()
+{
+    std::lock_guard<std::mutex> lk(p->deferred_mtx);
+    return p->deferred_bytes;
+}
+
+bool CAGCCompressor::DealCollectPacks(uint32_t *deal_id, const uint8_t **src, const uint64_t **off, uint32_t *n)
+{
+    Impl &I = *p;
+    if (!I.created || !deal_id || !src || !off || !n)
+        return false;
+    I.deals.emplace_back();
+    Impl::Deal &d = I.deals.back();
+    {
+        std::lock_guard<std::mutex> lk(I.deferred_mtx);
+        d.jobs.swap(I.deferred_packs);
+        I.deferred_bytes = 0;
+    }
+    d.id = I.next_deal_id++;
+    d.left = (uint32_t)d.jobs.size();
+    d.off.assign(d.jobs.size() + 1, 0);
+    for (size_t i = 0; i < d.jobs.size(); ++i)
+        d.off[i + 1] = d.off[i] + d.jobs[i].data.size();
+    d.src.resize(d.off.back());
+    I.pool->parallel_for(std::min<size_t>(d.jobs.size(), (size_t)I.pool->size() * 4), [&](size_t ci, unsigned) {
+        const size_t nc = std::min<size_t>(d.jobs.size(), (size_t)I.pool->size() * 4);
+        for (size_t t = d.jobs.size() * ci / nc; t < d.jobs.size() * (ci + 1) / nc; ++t)
+            memcpy(d.src.data() + d.off[t], d.jobs[t].data.data(), d.jobs[t].data.size());
+    });
+    *deal_id = d.id;
+    *src = d.src.data();
+    *off = d.off.data();
+    *n = (uint32_t)d.jobs.size();
+    if (d.jobs.empty())
+        I.deals.pop_back();
+    return true;
+}
+
+CAGCCompressor::Impl::Deal *CAGCCompressor::Impl::find_deal(uint32_t id)
+{
+    for (auto &d : deals)
+        if (d.id == id)
+            return &d;
+    return nullptr;
+}
+
+bool CAGCCompressor::DealKeepOwn(uint32_t deal_id, uint32_t first, uint32_t count)
+{
+    Impl &I = *p;
+    Impl::Deal *d = I.find_deal(deal_id);
+    if (!d || (uint64_t)first + count > d->jobs.size())
+        return false;
+    std::vector<ZJob> mine;
+    for (uint32_t t = first; t < first + count; ++t) {
+        if (!d->jobs[t].slot)
+            return false; // (handed out already)
+        mine.emplace_back(std::move(d->jobs[t]));
+        d->jobs[t].slot.reset();
+    }
+    d->left -= count;
+    I.z_submit(std::move(mine)); // this rank's own entropy stage, beside its steps
+    if (!d->left)
+        I.deals.remove_if([&](const Impl::Deal &x) { return x.id == deal_id; });
+    return true;
+}
+
+// a deal the caller never settled (Close came first): this rank's own entropy stage codes what is left of it
+void CAGCCompressor::Impl::settle_deals_locally()
+{
+    for (Deal &d : deals) {
+        std::vector<ZJob> mine;
+        for (ZJob &j : d.jobs)
+            if (j.slot)
+                mine.emplace_back(std::move(j));
+        z_submit(std::move(mine));
+    }
+    deals.clear();
+}
+
+bool CAGCCompressor::DealProvideFrames(uint32_t deal_id, uint32_t first, uint32_t count, const uint8_t *frames, const uint64_t *off)
+{
+    Impl &I = *p;
+    Impl::Deal *d = I.find_deal(deal_id);
+    if (!d || (uint64_t)first + count > d->jobs.size() || (count && (!frames || !off)))
+        return false;
+    for (uint32_t t = 0; t < count; ++t) {
+        ZJob &j = d->jobs[first + t];
+        if (!j.slot)
+            return false;
+        I.publish_frame(j, frames + off[t], (size_t)(off[t + 1] - off[t]));
+        j.slot.reset();
+        bytes_t().swap(j.data);
+    }
+    d->left -= count;
+    if (!d->left)
+        I.deals.remove_if([&](const Impl::Deal &x) { return x.id == deal_id; });
+    I.ar.try_drain(); // (the parts behind them may be written now)
     return true;
 }
 
@@ -1314,6 +1447,7 @@ bool CAGCCompressor::Close(uint32_t no_threads)
     }
     if (!I.book_wait()) // every registration is in the books
         return false;
+    I.settle_deals_locally();
     // the open collection batch (contig details of up to pack_cardinality samples: one thread of zstd-19 work, 0.4 s at human
     // scale) is serialised while the entropy stage of the delta packs runs; both only buffer parts, which are flushed below in
     // stream-id order whatever their arrival order

@@ -141,6 +141,16 @@ public:
     // has them compressed (agc_hip_zstd17_batch on any GPU) and returns the frames in the same order; Close then finishes with
     // them.  Without these two calls Close compresses everything itself.
     bool CloseCollectPacks(const uint8_t **src, const uint64_t **off, uint32_t *n);
+    // The same IN THE MIDDLE OF A RUN, for the delta packs that have filled (the reference's workers code a pack the moment it is
+    // full while the others go on, segment.cpp:34-80): the writer rank of an N-rank job parks them (their parts hold their places
+    // in the archive already); DeferredPackBytes says how much has piled up, DealCollectPacks hands them out as one DEAL -- inputs
+    // back to back, valid until every pack of the deal is settled --, the caller sends every rank its share, and the shares settle
+    // independently, in any order, samples later: DealProvideFrames(deal, first, count, frames, off) for packs [first, first + count)
+    // coded elsewhere (frame t = frames[off[t] .. off[t+1])), DealKeepOwn for a share this rank's own entropy stage takes.
+    uint64_t DeferredPackBytes();
+    bool DealCollectPacks(uint32_t *deal_id, const uint8_t **src, const uint64_t **off, uint32_t *n);
+    bool DealKeepOwn(uint32_t deal_id, uint32_t first, uint32_t count);
+    bool DealProvideFrames(uint32_t deal_id, uint32_t first, uint32_t count, const uint8_t *frames, const uint64_t *off);
     bool Drain(); // waits for the asynchronous entropy stage (every part handed over so far compressed and written)
     bool CloseProvideFrames(const uint8_t *frames, const uint64_t *off);
 
@@ -148,5 +158,8 @@ public:
     const char *ZstdVersion() const;
     agc_hip_ctx *HipContext();
 };
+
+// AGC_AMD_START_LAPS=1 (a measuring aid): milliseconds since the first call, on stderr, at the named points of a run's start
+void StartLap(const char *what);
 
 } // namespace agc

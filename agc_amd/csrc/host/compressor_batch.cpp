@@ -378,7 +378,7 @@ void CAGCCompressor::Impl::book_main()
         }
         const double t_c1 = now();
         book_on_thread = true;
-        ok = ok && book_and_store(t->cd);
+        ok = ok && finish_ref_store(t->cd, t->fetched) && book_and_store(t->cd);
         book_on_thread = false;
         t.reset();
         static const bool book_laps = getenv("AGC_AMD_LAPS") != nullptr;
@@ -2250,7 +2250,52 @@ bool CAGCCompressor::Impl::stage_store_head(BatchState &b)
     bytes_t &fetched = fetch_buf;
     std::vector<uint64_t> &fetched_off = b.sto.fetched_off;
     fetched_off.clear();
-    {
+    b.sto.ref_slot = -1;
+    // The steps' thread does not need any of this itself when the registration's books are another thread's (one registration, one
+    // GPU): counters and symbols are then asked for in ONE submission on a stream of their own and whoever does the books waits for
+    // them (finish_ref_store) -- a one-block kernel queued behind the announced scan and the FASTA conversion took 1.4 ms to come
+    // back, three round trips a step.  The reference sample's GBs of new references take the calls below as before.
+    bool ref_async = false;
+    if (ref_store_async && dist_world == 1 && book_can_async(b.n_samples) && b.pk.n_symbols && new_ref_items.size() + raw_items.size() > 0) {
+        const size_t nr = new_ref_items.size(), nf = nr + raw_items.size();
+        uint64_t tot = 0;
+        for (size_t i = 0; i < nf; ++i)
+            tot += placed[i < nr ? new_ref_items[i] : raw_items[i - nr]].len;
+        if (tot <= (64ull << 20)) {
+            std::vector<uint32_t> len(nf);
+            std::vector<uint64_t> off(nf);
+            std::vector<uint8_t> rc(nf);
+            for (size_t i = 0; i < nf; ++i) {
+                const Placed &pl = placed[i < nr ? new_ref_items[i] : raw_items[i - nr]];
+                off[i] = pl.off;
+                len[i] = pl.len;
+                rc[i] = pl.rc;
+                if (i < nr)
+                    st.ref_bytes += pl.len;
+            }
+            const uint32_t slot = ref_pin_next;
+            PinnedBytes &pin = ref_pin[slot];
+            if (!pin.ctx)
+                pin.ctx = hip;
+            const size_t cnt_bytes = nr * 28 * 4;
+            if (!pin.resize(2 * cnt_bytes + tot + 64, false)) {
+                err("out of memory (reference staging)");
+                return false;
+            }
+            fetched_off.resize(nf + 1);
+            if (!hip_ok(DEVT(agc_hip_ref_store_begin_packed(hip, slot, (uint32_t)nr, (uint32_t)nf, &b.pk, off.data(), len.data(), rc.data(), (uint32_t *)pin.data(),
+                                                            (uint32_t *)(pin.data() + cnt_bytes), pin.data() + 2 * cnt_bytes, tot, fetched_off.data())),
+                        "ref_store_begin"))
+                return false;
+            ref_pin_next ^= 1u;
+            b.sto.ref_slot = (int)slot;
+            b.sto.ref_nr = nr;
+            b.sto.ref_pin = &pin;
+            ref_async = true;
+            LAP("lag_counts + fetch_slices (queued)");
+        }
+    }
+    if (!ref_async) {
         const size_t nr = new_ref_items.size();
         if (nr) {
             std::vector<uint32_t> len(nr);
@@ -2519,6 +2564,10 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
     cdta.repetitive = std::move(b.sto.repetitive);
     cdta.fetched = &fetched;
     cdta.fetched_off = std::move(b.sto.fetched_off);
+    cdta.ref_slot = b.sto.ref_slot;
+    cdta.ref_nr = b.sto.ref_nr;
+    cdta.ref_pin = b.sto.ref_pin;
+    b.sto.ref_slot = -1;
     cdta.enc_ptr = std::move(enc_ptr);
     cdta.enc_len = std::move(enc_len);
     if (dist_world > 1) {
@@ -2568,9 +2617,42 @@ bool CAGCCompressor::Impl::stage_store_finish(BatchState &b)
         LAP("book_and_store (queued)");
         return true;
     }
-    const bool ok = book_wait() && book_and_store(cdta);
+    const bool ok = book_wait() && finish_ref_store(cdta, fetch_buf) && book_and_store(cdta);
     LAP("book_and_store");
     return ok;
+}
+
+// the second half of agc_hip_ref_store_begin_packed: waits for the slot, applies the reference's double-precision test to the lag
+// counters (segment.h:224-247) and puts the symbols where book_and_store reads them
+bool CAGCCompressor::Impl::finish_ref_store(CommitData &cd, bytes_t &fetched_dst)
+{
+    if (cd.ref_slot < 0)
+        return true;
+    if (!hip_ok(agc_hip_ref_store_end(hip, (uint32_t)cd.ref_slot), "ref_store_end"))
+        return false;
+    cd.ref_slot = -1;
+    const size_t nr = cd.ref_nr, cnt_bytes = nr * 28 * 4;
+    const uint32_t *lag_cnt = (const uint32_t *)cd.ref_pin->data(), *lag_cur = (const uint32_t *)(cd.ref_pin->data() + cnt_bytes);
+    cd.repetitive.assign(nr, 0);
+    for (size_t fi = 0; fi < nr; ++fi) {
+        double best_frac = 0.0;
+        for (uint32_t l = 0; l < 28; ++l) {
+            const uint32_t cnt = lag_cnt[fi * 28 + l], cur = lag_cur[fi * 28 + l];
+            double frac = 0.0;
+            if (cur)
+                frac = (double)cnt / cur;
+            if (frac > best_frac) {
+                best_frac = frac;
+                if (best_frac >= 0.5)
+                    break;
+            }
+        }
+        cd.repetitive[fi] = !(best_frac < 0.5);
+    }
+    const uint64_t tot = cd.fetched_off.empty() ? 0 : cd.fetched_off.back();
+    fetched_dst.assign(cd.ref_pin->data() + 2 * cnt_bytes, cd.ref_pin->data() + 2 * cnt_bytes + tot);
+    cd.fetched = &fetched_dst;
+    return true;
 }
 
 // store_segments, second half (agc_compressor.cpp:989-1050): per-group bookkeeping, zstd parts, collection records
@@ -2747,16 +2829,25 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
         // device can code are kept for the distributed Close (CloseCollectPacks), the rest (references) goes on now
         const uint32_t dev_max = agc_hip_zstd17_max_input();
         std::vector<ZJob> now_jobs;
+        std::lock_guard<std::mutex> dlk(deferred_mtx); // (DealCollectPacks takes them from the thread that drives the steps)
         for (ZJob &j : all_jobs)
             if (j.kind == 1 && !j.data.empty() && j.data.size() <= dev_max) {
                 deferred_bytes += j.data.size();
                 deferred_packs.emplace_back(std::move(j));
             } else
                 now_jobs.emplace_back(std::move(j));
-        // ... up to a ceiling: behind the first kept pack every later part of the archive waits in host memory (ArchiveWriter
-        // writes its events in order), so the writer's memory would grow with the collection.  Past the ceiling the writer's own
-        // entropy stage takes what has piled up (the same frames, only not spread over the ranks) and the archive flows again.
-        static const uint64_t defer_cap = (getenv("AGC_AMD_DEFER_MAX_MB") ? strtoull(getenv("AGC_AMD_DEFER_MAX_MB"), nullptr, 10) : 2048ull) << 20;
+        // The kept packs are dealt to the ranks in the middle of the run (agc_amd/dist.py: DealCollectPacks as soon as a few dozen MB
+        // have piled up) or at Close.  A safety net for a caller that never deals: behind the first kept pack every later part of
+        // the archive waits in host memory (ArchiveWriter writes its events in order) -- past the ceiling (a quarter of the
+        // machine's memory, 16 GiB at most; round 5: 2 GiB, which the first fill of 50 k human packs at -b 100 overran) the
+        // writer's own entropy stage takes what has piled up and the archive flows again.
+        static const uint64_t defer_cap = []() -> uint64_t {
+            if (const char *e = getenv("AGC_AMD_DEFER_MAX_MB"))
+                return (uint64_t)strtoull(e, nullptr, 10) << 20;
+            const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+            const uint64_t quarter = pages > 0 && psz > 0 ? (uint64_t)pages * (uint64_t)psz / 4 : (4ull << 30);
+            return std::min<uint64_t>(16ull << 30, std::max<uint64_t>(2ull << 30, quarter));
+        }();
         if (deferred_bytes > defer_cap) {
             for (ZJob &j : deferred_packs)
                 now_jobs.emplace_back(std::move(j));

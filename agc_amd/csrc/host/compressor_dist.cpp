@@ -21,11 +21,6 @@ namespace agc {
 // go on while the owner indexes its new references, encodes what is left and builds the body (CommitPreparedFinish).
 // ---------------------------------------------------------------------------
 namespace {
-void put32(bytes_t &d, uint32_t x)
-{
-    for (int i = 0; i < 4; ++i, x >>= 8)
-        d.push_back((uint8_t)(x & 0xff));
-}
 struct RecReader {
     const uint8_t *p, *e;
     bool ok = true;

@@ -4,6 +4,7 @@
 #pragma once
 #include "compressor.h"
 #include "host_support.h"
+#include <list>
 #include <cerrno>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -297,6 +298,7 @@ public:
     }
 };
 
+struct PinnedBytes;
 struct CommitData {
     const std::vector<Contig> *ctgs = nullptr;
     const std::vector<Placed> *placed = nullptr;
@@ -309,6 +311,11 @@ struct CommitData {
     std::vector<const uint8_t *> enc_ptr;                      // delta of every enc_items entry
     std::vector<uint32_t> enc_len;
     uint32_t sample_from = 0;                                  // the registrations [sample_from, commit_upto) of the window
+    // ref_slot >= 0: lag counters and symbols of the new references are still on their way (agc_hip_ref_store_begin_packed into
+    // *ref_pin: counters of ref_nr references, then the symbols); whoever does the books waits for the slot first (finish_ref_store)
+    int ref_slot = -1;
+    size_t ref_nr = 0;
+    const PinnedBytes *ref_pin = nullptr;
 };
 
 // result buffer in pinned host memory (agc_hip_host_alloc; plain malloc when that fails): grows, keeps its content, never shrinks
@@ -845,6 +852,10 @@ struct CAGCCompressor::Impl {
     bool early_collect = true; // the whole-sample encode is collected by an early task of the book thread (AGC_AMD_EARLY_COLLECT=0: by the registration's own)
     uint64_t book_seq_submitted = 0, book_seq_done = 0; // tasks are numbered; they complete in order
     uint64_t last_own_seq = 0;          // the last task that points into this object's buffers (the *_alt set below)
+    PinnedBytes ref_pin[2];             // staging of agc_hip_ref_store_begin_packed, alternating (the previous one is the queued task's)
+    uint32_t ref_pin_next = 0;
+    bool ref_store_async = true;        // AGC_AMD_REF_STORE_ASYNC=0: lag counters and symbols are waited for where they are asked for
+    bool finish_ref_store(CommitData &cd, bytes_t &fetched_dst); // waits for the slot, makes cd.repetitive and cd.fetched
     struct EarlyEnc {                   // result of an early_only task (written by the book thread, read after book_wait_seq)
         bool ok = false;
         std::vector<uint64_t> eoff;
@@ -950,6 +961,9 @@ struct CAGCCompressor::Impl {
             std::vector<uint32_t> new_ref_items, raw_items, enc_items; // placed indices
             std::vector<uint8_t> repetitive;
             std::vector<uint64_t> fetched_off;
+            int ref_slot = -1;                     // (see CommitData)
+            size_t ref_nr = 0;
+            const PinnedBytes *ref_pin = nullptr;
         } sto;
     };
     bool stage_scan(BatchState &b);
@@ -1083,7 +1097,24 @@ struct CAGCCompressor::Impl {
     // the archive) so that Close in steps can spread them over every rank's GPU together with the packs still open
     std::atomic<uint64_t> verify_frames{0}, verify_bad{0}; // AGC_AMD_VERIFY_DEV_FRAMES: device frames checked against libzstd / different
     std::vector<ZJob> deferred_packs;
-    uint64_t deferred_bytes = 0;       // their raw bytes (bounded: AGC_AMD_DEFER_MAX_MB, default 2 GiB -- compressor_batch.cpp)
+    uint64_t deferred_bytes = 0;       // their raw bytes (a safety net bounds them: AGC_AMD_DEFER_MAX_MB -- compressor_batch.cpp)
+    std::mutex deferred_mtx;           // (the bookkeeping thread parks packs, the thread that drives the steps takes them: DealCollectPacks)
+    // A DEAL: the parked packs handed out in the middle of a run (DealCollectPacks), their inputs back to back, so that the caller can
+    // send every rank its share; the shares' frames come back in any order, any time later (DealProvideFrames), or a share stays with
+    // this rank's own entropy stage (DealKeepOwn).  The reference's workers code a pack the moment it is full while the others go on
+    // (segment.cpp:34-80, segment.h:258-280): here the "workers" are the ranks' GPUs.
+    struct Deal {
+        uint32_t id = 0;
+        std::vector<ZJob> jobs;
+        bytes_t src;
+        std::vector<uint64_t> off;
+        uint32_t left = 0; // packs whose frame has not come back yet
+    };
+    std::list<Deal> deals;
+    uint32_t next_deal_id = 1;
+    void publish_frame(ZJob &j, const uint8_t *frame, size_t n);
+    Deal *find_deal(uint32_t id);
+    void settle_deals_locally();
     std::vector<ZJob> close_jobs;
     std::vector<uint32_t> close_dev_jobs;      // indices in close_jobs of the packs handed out
     std::vector<uint64_t> close_src_off, close_frames_off;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -93,6 +94,16 @@ struct ZstdCtx {
     // returns the frame size; dst must hold compressBound(n) + 1 bytes
     size_t compress(uint8_t *dst, size_t cap, const uint8_t *src, size_t n, int level) { return api->compressCCtx(cctx, dst, cap, src, n, level); }
 };
+
+// AGC_AMD_START_LAPS=1 (a measuring aid, scripts/start_cost.py): milliseconds since the first call at the named points of a run's start
+inline void start_lap(const char *what)
+{
+    static const bool on = getenv("AGC_AMD_START_LAPS") != nullptr;
+    if (!on)
+        return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "start lap %-44s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
 
 // ---------------------------------------------------------------------------
 // worker pool: parallel_for over independent jobs

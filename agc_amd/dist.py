@@ -27,6 +27,7 @@ the end (agc_compressor.cpp:2155-2238); concatenated_units() below cuts them.
 append: every rank loads the input archive (host.Compressor.append); compress(prefetch=False) -- a packed group answers Estimate with
 0 until a record unpacks it, on every rank, so samples are prepared at their turn.  Not covered: append together with -c.
 """
+import os
 import time
 
 import numpy as np
@@ -75,7 +76,7 @@ class DistCompressor:
     device: this rank's GPU (torch.device) or None (CPU tests).  The collectives run on the GPU when the backend is nccl
     (RCCL: the record never leaves HBM on its way between GPUs) and on host tensors otherwise (gloo)."""
 
-    def __init__(self, cmp_, dist, rank, world, device=None, writer=0):
+    def __init__(self, cmp_, dist, rank, world, device=None, writer=0, zstd_raw=None):
         import torch
         self.torch = torch
         self.cmp = cmp_
@@ -107,6 +108,24 @@ class DistCompressor:
         self._hmsg = self._host_buffer(self._cap)
         self._dmsg = torch.empty(self._cap, dtype=torch.uint8, device=self.comm) if self.comm.type == "cuda" else None
         self._dapply = None         # (gloo with a GPU: the head's copy in this rank's HBM the new references are registered from)
+        # ---- full delta packs dealt to the ranks' entropy stages IN THE MIDDLE of the run (_deal_step) ----
+        # AGC_AMD_DEAL_MIN_MB: the writer deals once that much has piled up (default 64; negative: only Close deals);
+        # AGC_AMD_DEAL_EVERY: a control step (one small all_gather) every that many samples (default 4)
+        import threading
+        import queue
+        self.deal_min = int(float(os.environ.get("AGC_AMD_DEAL_MIN_MB", "64")) * (1 << 20))
+        self.deal_every = max(1, int(os.environ.get("AGC_AMD_DEAL_EVERY", "4")))
+        self._zstd_raw = zstd_raw           # (src uint8 array, off uint64[n + 1]) -> (frames, foff); None: this rank's GPU
+        self._deal_q = queue.Queue()        # shares this rank has to code: (deal id, packs tensor / array, offsets)
+        self._deal_done = []                # ... and has coded: (deal id, frame sizes int64[n], frames uint8 array), oldest first
+        self._deal_lock = threading.Lock()
+        self._deal_thread = None
+        self._deal_error = None
+        self._deals_out = {}                # writer: (deal id, rank) -> (first pack, count) of the shares that are out
+        self._since_deal = 0
+        self.n_deals = 0                    # deals started (every rank counts the same)
+        self.bytes_dealt = 0                # pack bytes that left the writer in deals
+        self.seconds["deal"] = 0.0          # host seconds of this rank in control steps and transfers of deals
         self._check_placement()
         self.warm_up()
 
@@ -183,6 +202,150 @@ class DistCompressor:
     def owner_of(self, i):
         return i % self.world
 
+    # ---- deals: the reference's workers code a delta pack the moment it is full while the others go on (segment.cpp:34-80,
+    # segment.h:258-280); here the full packs pile up at the writer (their parts hold their places in the archive) and are DEALT to
+    # every rank's entropy stage a few samples later: a rank codes its share on a thread of its own, on its own GPU's entropy stream,
+    # beside the samples it goes on preparing, and the frames travel back at a later control step.  Close then has the packs still
+    # open left to deal, not every pack of the run.
+    def _code_share(self, packs, off):
+        if self._zstd_raw is not None:
+            src = packs.cpu().numpy() if hasattr(packs, "cpu") else packs
+            return self._zstd_raw(src, off)
+        from agc_amd import capi
+        ctx = capi.Context.from_handle(self.cmp.hip_ctx())
+        if self.hbm is not None:
+            d = packs if (hasattr(packs, "is_cuda") and packs.is_cuda) else self.torch.from_numpy(np.ascontiguousarray(packs)).to(self.hbm)
+            self.torch.cuda.synchronize(self.hbm)
+            return ctx.zstd17_batch_raw_dev(d.data_ptr(), off)
+        return ctx.zstd17_batch_raw(packs.numpy() if hasattr(packs, "numpy") else packs, off)
+
+    def _deal_main(self):
+        while True:
+            job = self._deal_q.get()
+            if job is None:
+                return
+            deal, packs, off = job
+            try:
+                frames, foff = self._code_share(packs, off)
+                with self._deal_lock:
+                    self._deal_done.append((deal, np.diff(foff.astype(np.int64)), np.ascontiguousarray(frames, dtype=np.uint8)))
+            except Exception as e:  # noqa: BLE001 -- reported at the next control step, on the thread that drives the ranks
+                self._deal_error = e
+            finally:
+                self._deal_q.task_done()
+
+    def _deal_step(self, final=False):
+        """SPMD, at the same sample boundaries on every rank: ONE small all_gather says whether the writer starts a deal (and every
+        rank's share of it) and which rank has a finished share to return; the transfers follow point to point."""
+        torch, dist = self.torch, self.dist
+        t0 = time.perf_counter()
+        W, writer = self.world, self.rank == self.writer
+        if self._deal_error is not None:
+            raise self._deal_error
+        v = np.zeros(2 + 2 * W, np.int64)
+        with self._deal_lock:
+            if self._deal_done and not writer:
+                v[0] = self._deal_done[0][0]
+        src = off = cut = None
+        if writer and not final and self.deal_min >= 0 and self.cmp.deferred_pack_bytes() >= max(self.deal_min, 1):
+            deal, src, off = self.cmp.deal_collect_packs()
+            if deal:
+                n, total = off.size - 1, int(off[-1])
+                cut = np.searchsorted(off, (np.arange(W + 1, dtype=np.float64) * total / W).astype(np.uint64), side="left")
+                cut[0], cut[-1] = 0, n
+                cut = np.maximum.accumulate(np.minimum(cut, n)).astype(np.int64)
+                v[1] = deal
+                for r in range(W):
+                    v[2 + 2 * r], v[3 + 2 * r] = cut[r + 1] - cut[r], int(off[cut[r + 1]]) - int(off[cut[r]])
+        mine = torch.from_numpy(v).to(self.comm)
+        every = [torch.zeros(2 + 2 * W, dtype=torch.int64, device=self.comm) for _ in range(W)]
+        dist.all_gather(every, mine)
+        every = [e.cpu().numpy() for e in every]
+        moved = False
+        # ---- a new deal: every rank's share leaves the writer
+        deal = int(every[self.writer][1])
+        if deal:
+            moved = True
+            self.n_deals += 1
+            plan = every[self.writer][2:].reshape(W, 2)
+            if writer:
+                sends = []
+                for r in range(W):
+                    a_, b_ = int(cut[r]), int(cut[r + 1])
+                    if b_ == a_:
+                        continue
+                    if r == self.writer:
+                        self.cmp.deal_keep_own(deal, a_, b_ - a_)  # (this rank's own entropy stage, beside its steps)
+                        continue
+                    self._deals_out[(deal, r)] = (a_, b_ - a_)
+                    sends.append(dist.isend(torch.from_numpy((off[a_:b_ + 1] - off[a_]).astype(np.int64)).to(self.comm), dst=r))
+                    if int(off[b_]) > int(off[a_]):
+                        sends.append(dist.isend(torch.from_numpy(src[int(off[a_]):int(off[b_])]).to(self.comm), dst=r))
+                    self.bytes_dealt += int(off[b_]) - int(off[a_])
+                for w_ in sends:
+                    w_.wait()
+            elif plan[self.rank, 0]:
+                n_, bytes_ = int(plan[self.rank, 0]), int(plan[self.rank, 1])
+                d_o = torch.empty(n_ + 1, dtype=torch.int64, device=self.comm)
+                d_x = torch.empty(bytes_, dtype=torch.uint8, device=self.comm)
+                dist.recv(d_o, src=self.writer)
+                if bytes_:
+                    dist.recv(d_x, src=self.writer)
+                if self._deal_thread is None:
+                    import threading
+                    self._deal_thread = threading.Thread(target=self._deal_main, daemon=True)
+                    self._deal_thread.start()
+                self._deal_q.put((deal, d_x, d_o.cpu().numpy().astype(np.uint64)))
+        # ---- finished shares travel back (one per rank and control step, oldest first)
+        for r in range(W):
+            back = int(every[r][0])
+            if not back or r == self.writer:
+                continue
+            moved = True
+            if writer:
+                first, count = self._deals_out.pop((back, r))
+                d_s = torch.empty(count, dtype=torch.int64, device=self.comm)
+                dist.recv(d_s, src=r)
+                sz = d_s.cpu().numpy()
+                d_f = torch.empty(int(sz.sum()), dtype=torch.uint8, device=self.comm)
+                if d_f.numel():
+                    dist.recv(d_f, src=r)
+                foff = np.zeros(count + 1, np.uint64)
+                foff[1:] = np.cumsum(sz)
+                self.cmp.deal_provide_frames(back, first, count, d_f.cpu().numpy(), foff)
+            elif r == self.rank:
+                with self._deal_lock:
+                    _d, sz, frames = self._deal_done.pop(0)
+                dist.send(torch.from_numpy(sz).to(self.comm), dst=self.writer)
+                if frames.size:
+                    dist.send(torch.from_numpy(frames).to(self.comm), dst=self.writer)
+        self.seconds["deal"] += time.perf_counter() - t0
+        return moved
+
+    def _after_sample(self):
+        self._since_deal += 1
+        if self.world > 1 and self._since_deal >= self.deal_every:
+            self._since_deal = 0
+            self._deal_step()
+
+    def _settle_deals(self):
+        """Close: every share that is out comes home first (each rank waits for its own coding thread, then control steps until none moves)"""
+        if self.world <= 1:
+            return
+        self._deal_q.join()
+        while True:
+            moved = self._deal_step(final=True)
+            flag = self.torch.tensor([1 if moved else 0], dtype=self.torch.int64, device=self.comm)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if not int(flag[0]):
+                break
+        if self._deal_thread is not None:
+            self._deal_q.put(None)
+            self._deal_thread.join()
+            self._deal_thread = None
+        if self._deal_error is not None:
+            raise self._deal_error
+
     def add_sample(self, sample_name=None, contig_names=None, d_codes=None, ctg_off=None):
         """SPMD: every rank calls this once per sample, in the same order; only the owner passes the data."""
         torch, dist = self.torch, self.dist
@@ -196,6 +359,7 @@ class DistCompressor:
             self.seconds["commit"] += time.perf_counter() - t0
             rec, body = self.cmp.last_record_framed(), self.cmp.last_record_body(copy=False)
         self._publish(owner, rec, body)
+        self._after_sample()
         return owner
 
     def compress(self, n_total, get_sample, prefetch=True, start=0):
@@ -225,6 +389,7 @@ class DistCompressor:
                 nxt = i + self.world if i + self.world < n_total else None
             else:
                 self._receive(owner)
+            self._after_sample()
 
     def _prepare(self, sample):
         """sample = (name, contig names, d_codes pointer | agc_amd.capi.Packed, ctg_off)"""
@@ -244,6 +409,9 @@ class DistCompressor:
         zstd_raw(src uint8 array, off uint64[n + 1]) -> (frames uint8 array, foff uint64[n + 1]); default: this rank's GPU.
         Every rank must call this instead of Compressor.close()."""
         torch, dist = self.torch, self.dist
+        if zstd_raw is not None and self._zstd_raw is None:
+            self._zstd_raw = zstd_raw
+        self._settle_deals()
         default_raw = zstd_raw is None
         ctx = None
         if zstd_raw is None:

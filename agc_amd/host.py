@@ -36,6 +36,11 @@ def bind(L):
     L.agc_cmp_drain.argtypes = [vp]
     L.agc_cmp_close_collect_packs.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32)]
     L.agc_cmp_close_provide_frames.argtypes = [vp, vp, vp]
+    L.agc_cmp_deferred_pack_bytes.argtypes = [vp]
+    L.agc_cmp_deferred_pack_bytes.restype = C.c_uint64
+    L.agc_cmp_deal_collect_packs.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32)]
+    L.agc_cmp_deal_keep_own.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.agc_cmp_deal_provide_frames.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.agc_cmp_zstd_version.argtypes = [vp]
     L.agc_cmp_zstd_version.restype = C.c_char_p
     L.agc_cmp_hip_ctx.argtypes = [vp]
@@ -258,6 +263,34 @@ class Compressor:
         off = np.ctypeslib.as_array(o, shape=(n.value + 1,)).copy()
         src = np.ctypeslib.as_array(p, shape=(int(off[-1]),)) if off[-1] else np.zeros(0, np.uint8)
         return src, off
+
+    # ---- full packs dealt to the ranks in the middle of a run (agc_amd/dist.py) ----
+    def deferred_pack_bytes(self):
+        return int(self.L.agc_cmp_deferred_pack_bytes(self.h))
+
+    def deal_collect_packs(self):
+        """-> (deal id, src bytes as a numpy view, offsets [n + 1]); the view stays valid until every pack of the deal is settled"""
+        d = C.c_uint32()
+        p = C.POINTER(C.c_uint8)()
+        o = C.POINTER(C.c_uint64)()
+        n = C.c_uint32()
+        if not self.L.agc_cmp_deal_collect_packs(self.h, C.byref(d), C.byref(p), C.byref(o), C.byref(n)):
+            raise RuntimeError("DealCollectPacks failed")
+        if not n.value:
+            return 0, np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+        off = np.ctypeslib.as_array(o, shape=(n.value + 1,)).copy()
+        src = np.ctypeslib.as_array(p, shape=(int(off[-1]),)) if off[-1] else np.zeros(0, np.uint8)
+        return int(d.value), src, off
+
+    def deal_keep_own(self, deal, first, count):
+        if not self.L.agc_cmp_deal_keep_own(self.h, deal, first, count):
+            raise RuntimeError("DealKeepOwn failed")
+
+    def deal_provide_frames(self, deal, first, count, frames, off):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        if not self.L.agc_cmp_deal_provide_frames(self.h, deal, first, count, frames.ctypes.data, off.ctypes.data):
+            raise RuntimeError("DealProvideFrames failed")
 
     def close_provide_frames(self, frames, off):
         frames = np.ascontiguousarray(frames, dtype=np.uint8)

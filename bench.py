@@ -768,8 +768,10 @@ def main():
                                        f"broadcast per sample (64-byte message header + the commit record's head: ids, keys, new reference segments; "
                                        f"{dc.n_collectives} broadcasts for {dc.n_records} records), {head_timed_mb:.2f} MB per timed sample, "
                                        f"its delta body point to point to the writer ({body_timed_mb:.1f} MB per timed sample that is not the writer's own); "
-                                       "at Close every rank receives its own byte range of the pending packs point to point, its GPU compresses it, "
-                                       "rank 0 receives the frames as long as they are and writes") if single else
+                                       f"full packs are dealt to the ranks' entropy stages in the middle of the run ({dc.n_deals} deals, {dc.bytes_dealt / 1e6:.1f} MB of "
+                                       "packs left the writer; a rank codes its share on a thread of its own beside its samples, the frames travel back at a "
+                                       "later control step); at Close every rank receives its own byte range of the packs still open point to point, its GPU "
+                                       "compresses it, rank 0 receives the frames as long as they are and writes") if single else
                                       f"samples round-robin over {world} GPU(s), one archive shard per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dominant), "achieved": dom.get("as_built", {}).get("achieved"),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("as_built", {}).get("frac"),

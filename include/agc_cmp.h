@@ -77,6 +77,17 @@ int agc_cmp_drain(void *h);
  * frames[off[i] .. off[i+1])), then agc_cmp_close.  The buffers returned by the first call stay valid until agc_cmp_close. */
 int agc_cmp_close_collect_packs(void *h, const uint8_t **src, const uint64_t **off, uint32_t *n);
 int agc_cmp_close_provide_frames(void *h, const uint8_t *frames, const uint64_t *off);
+/* the same in the middle of a run (writer rank of an N-rank job): the reference's workers code a delta pack the moment it is full
+ * while the others go on (segment.cpp:34-80, segment.h:258-280); here the full packs wait (their parts already hold their places
+ * in the archive) until the caller DEALS them to the ranks' entropy stages.  agc_cmp_deferred_pack_bytes: how much has piled up;
+ * agc_cmp_deal_collect_packs: all of it as one deal (inputs back to back, pack i = src[off[i] .. off[i+1]); valid until every pack
+ * of the deal is settled); a share [first, first + count) settles either with agc_cmp_deal_provide_frames (its level-17 frames,
+ * frame t = frames[off[t] .. off[t+1]), from whichever rank coded them, any number of samples later) or with agc_cmp_deal_keep_own
+ * (this rank's own entropy stage takes it, beside its steps).  Shares settle in any order; agc_cmp_close needs every deal settled. */
+uint64_t agc_cmp_deferred_pack_bytes(void *h);
+int agc_cmp_deal_collect_packs(void *h, uint32_t *deal_id, const uint8_t **src, const uint64_t **off, uint32_t *n);
+int agc_cmp_deal_keep_own(void *h, uint32_t deal_id, uint32_t first, uint32_t count);
+int agc_cmp_deal_provide_frames(void *h, uint32_t deal_id, uint32_t first, uint32_t count, const uint8_t *frames, const uint64_t *off);
 
 /* one archive from N ranks (before agc_cmp_create on every rank; protocol: agc_amd/dist.py, compressor_dist.cpp).
  * After agc_cmp_add_sample_dev / agc_cmp_commit_prepared on the owner, agc_cmp_last_record gives the bytes every other rank

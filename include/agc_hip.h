@@ -395,6 +395,17 @@ int agc_hip_ref_lag_counts_packed(agc_hip_ctx *ctx, uint32_t n, const agc_hip_pa
                                   const uint64_t *h_off, const uint32_t *h_len, const uint8_t *h_rc,
                                   uint32_t *h_cnt /* n*28 */, uint32_t *h_cur /* n*28 */);
 
+/* The two calls above for the new references of ONE registration, in one submission nobody has to wait for at once: slices
+ * [0, n_refs) are the new references (their counters go to h_cnt / h_cur, n_refs * 28 each), slices [0, n) -- references, then raw
+ * items -- are copied to h_out back to back (offsets in h_out_off, n + 1, filled at once).  _begin queues kernels and copies on a stream
+ * of the context's own and returns; _end(slot) waits for that slot (two slots: a caller that hands a registration's bookkeeping to
+ * another thread alternates them; _end may be called from that thread).  The host buffers must be pinned (agc_hip_host_alloc) and,
+ * like the packed sample, stay untouched until _end.  Replaces the same reference lines as the two calls it combines. */
+int agc_hip_ref_store_begin_packed(agc_hip_ctx *ctx, uint32_t slot, uint32_t n_refs, uint32_t n, const agc_hip_packed *pk, const uint64_t *h_off,
+                                   const uint32_t *h_len, const uint8_t *h_rc, uint32_t *h_cnt, uint32_t *h_cur, uint8_t *h_out, uint64_t out_cap,
+                                   uint64_t *h_out_off);
+int agc_hip_ref_store_end(agc_hip_ctx *ctx, uint32_t slot);
+
 /* ---- S3: entropy coding of delta packs (a14) -------------------------- */
 /* Replaces ZSTD_compressCCtx(cctx, dst, bound, src, n, 17) as CSegment::add_to_archive calls it for delta packs
  * (src/common/segment.h:199-201, store_in_archive(pack) :258-280), for a batch of independent inputs: frame i =

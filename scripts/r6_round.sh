@@ -188,3 +188,61 @@ for n in sorted(glob.glob("gpurun_out/r6/j_bench_*.json")):
 PY
   timeout 900 python -m pytest tests/test_dist_single_archive.py -m gpu -x -q -k "rccl" > $OUT/j_rccl_one_rank.log 2>&1; tail -5 $OUT/j_rccl_one_rank.log
 fi
+if [ "$PART" = k ]; then
+  # lag counters + symbols of the new references in one submission nobody on the steps' thread waits for
+  timeout 900 python -m pytest tests/test_gpu_archive.py -m gpu -x -q > $OUT/k_archive_tests.log 2>&1; tail -3 $OUT/k_archive_tests.log
+  bench k_bench_1
+  bench k_bench_off AGC_AMD_REF_STORE_ASYNC=0
+  bench k_bench_2
+  bench k_bench_3
+  AGC_AMD_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/k_bench_laps.json 2> $OUT/k_bench_laps.txt; show $OUT/k_bench_laps.json
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/k_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"])
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = l ]; then
+  # the same with the context's packed buffers protected from the next window's pack; where the start of a run goes
+  timeout 900 python -m pytest tests/test_gpu_archive.py -m gpu -x -q > $OUT/l_archive_tests.log 2>&1; tail -3 $OUT/l_archive_tests.log
+  timeout 900 python -m pytest tests/test_gpu_archive.py -m gpu -x -q > $OUT/l_archive_tests2.log 2>&1; tail -3 $OUT/l_archive_tests2.log
+  python - <<'PY'
+import os, subprocess, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from agc_amd import synth
+td = tempfile.mkdtemp(dir="/dev/shm")
+fn = td + "/tiny.fa"
+synth.to_fasta(fn, [synth.random_seq(np.random.default_rng(1), 2000)], ["tiny"])
+for rep in range(3):
+    t0 = time.perf_counter()
+    r = subprocess.run(["agc_amd/bin/agc_amd", "create", "-o", td + "/t.agc", fn], capture_output=True, text=True, env=dict(os.environ, AGC_AMD_START_LAPS="1"))
+    print(f"CLI wall {time.perf_counter() - t0:.3f} s"); print(r.stderr)
+PY
+  bench l_bench_1
+  bench l_bench_2
+  for cfg in c1; do timeout 400 python bench.py --config $cfg > $OUT/l_bench_config_$cfg.json 2> /dev/null; show $OUT/l_bench_config_$cfg.json; done
+fi
+if [ "$PART" = m ]; then
+  timeout 600 python scripts/c1_probe.py > $OUT/m_c1_probe.txt 2>&1; cat $OUT/m_c1_probe.txt
+fi
+if [ "$PART" = n ]; then
+  # deals in the middle of an N-rank run with the real kernels; two ranks on one GPU with packs that fill during the steps
+  timeout 900 python -m pytest tests/test_dist_single_archive.py -m gpu -x -q > $OUT/n_dist_gpu_tests.log 2>&1; tail -3 $OUT/n_dist_gpu_tests.log
+  for dm in -1 0; do
+    AGC_AMD_DEAL_MIN_MB=$dm AGC_AMD_DEAL_EVERY=2 AGC_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 2961$((dm+2)) bench.py --gpus 2 --steps 12 --warmup 2 --pack-cardinality 8 --no-cpu-baseline > $OUT/n_bench_2ranks_b8_deal$dm.json 2> $OUT/n_bench_2ranks_b8_deal$dm.err; show $OUT/n_bench_2ranks_b8_deal$dm.json
+    python - $OUT/n_bench_2ranks_b8_deal$dm.json <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("  ms per sample rank0:", d["config"].get("single_archive_ms_per_sample_rank0")); print("  ", d["config"].get("parallelism")[-420:]); print("  zstd", d["config"]["zstd"])
+except Exception as e:
+    print("no line", e)
+PY
+    tail -3 $OUT/n_bench_2ranks_b8_deal$dm.err
+  done
+fi

@@ -1016,3 +1016,20 @@ int agc_hip_sample_pack_fasta(agc_hip_ctx *c, uint32_t n_ctg, const uint8_t *con
     free(codes);
     return rc;
 }
+
+/* lag counters + symbols of a registration's new references in one call: done at begin, nothing to wait for at end */
+int agc_hip_ref_store_begin_packed(agc_hip_ctx *c, uint32_t slot, uint32_t n_refs, uint32_t n, const agc_hip_packed *pk, const uint64_t *h_off,
+                                   const uint32_t *h_len, const uint8_t *h_rc, uint32_t *h_cnt, uint32_t *h_cur, uint8_t *h_out, uint64_t out_cap,
+                                   uint64_t *h_out_off)
+{
+    if (!c || slot >= 2 || n_refs > n || !h_out_off)
+        return AGC_HIP_EINVAL;
+    if (n_refs) {
+        const int r = agc_hip_ref_lag_counts_packed(c, n_refs, pk, h_off, h_len, h_rc, h_cnt, h_cur);
+        if (r != AGC_HIP_OK)
+            return r;
+    }
+    h_out_off[0] = 0;
+    return n ? agc_hip_fetch_slices_packed(c, n, pk, h_off, h_len, h_rc, h_out, out_cap, h_out_off) : AGC_HIP_OK;
+}
+int agc_hip_ref_store_end(agc_hip_ctx *c, uint32_t slot) { return c && slot < 2 ? AGC_HIP_OK : AGC_HIP_EINVAL; }

@@ -75,7 +75,8 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
         else:
             cmp_.create(out_path if rank == 0 else "", pack_cardinality=opt["-b"], k=opt["-k"], ref_file=files[0], segment_size=opt["-s"],
                         min_match_len=opt["-l"], concatenated="-c" in args, adaptive="-a" in args, n_threads=2)
-        dc = DistCompressor(cmp_, dist, rank, world, device=device)
+        # (the stand-in's encoder from the start: full packs are dealt to the ranks in the middle of the run, not only at Close)
+        dc = DistCompressor(cmp_, dist, rank, world, device=device, zstd_raw=None if on_gpu else _sim_zstd_batch())
         keep = {}
         units = None
         if "-c" in args:  # the reference's registration units: runs of -b contigs across the files, sample name ""
@@ -127,10 +128,11 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
             dc.close(zstd_raw=_sim_zstd_batch())  # the stand-in's agc_hip_zstd17_batch (same encoder headers as the kernel)
         st = cmp_.stats()
         cmp_.close_handle()
-        q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"], st["revalidated"], st["reprepared"], sum(1 for i in range(len(files)) if i % world == rank)))
+        q.put((rank, "ok", dc.bytes_broadcast, st["new_groups"], st["revalidated"], st["reprepared"], sum(1 for i in range(len(files)) if i % world == rank),
+               dc.n_deals, dc.bytes_dealt))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
-        q.put((rank, "error: %r" % (e,), 0, 0, 0, 0, 0))
+        q.put((rank, "error: %r" % (e,), 0, 0, 0, 0, 0, 0, 0))
 
 
 def _run(name, world, tmp_path, on_gpu, prefetch=False, files=None, append_to=None, want=None):
@@ -185,6 +187,25 @@ def test_prefetching_ranks_still_write_the_reference_archive(name, world, tmp_pa
         assert 0 < again < own, (again, own)
     else:
         assert sum(r[5] for r in res) == 0
+
+
+@pytest.mark.parametrize("name,world,every", [("syn_viral", 2, 1), ("syn_viral", 3, 2), ("syn_snp", 3, 1), ("syn_mixed", 2, 1), ("syn_adaptive", 2, 1),
+                                              ("syn_adaptive", 3, 3), ("syn_viral_c", 2, 1)])
+def test_full_packs_are_dealt_to_the_ranks_in_the_middle_of_the_run(name, world, every, tmp_path, monkeypatch):
+    """the reference's workers code a delta pack the moment it is full while the others go on (segment.cpp:34-80); here the writer deals
+    the full packs to every rank's entropy stage a few samples after they filled (AGC_AMD_DEAL_MIN_MB=0: as soon as there is one;
+    AGC_AMD_DEAL_EVERY: control step every that many samples), the ranks code their shares on threads of their own while the samples
+    go on, the frames come back at later control steps -- and Close only deals what is still open.  Same archive; deals did happen."""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    monkeypatch.setenv("AGC_AMD_DEAL_MIN_MB", "0")
+    monkeypatch.setenv("AGC_AMD_DEAL_EVERY", str(every))
+    res = _run(name, world, tmp_path, on_gpu=False, prefetch=True)
+    assert len({r[7] for r in res}) == 1, [r[7] for r in res]   # every rank saw the same number of deals
+    if not name.startswith("syn_adaptive"):  # (7 samples, one fill at the fifth, parked by the bookkeeping thread: Close may come first)
+        assert res[0][7] > 0
+    if name in ("syn_snp", "syn_mixed"):  # (a fill of the 30 kb genomes is one pack: the writer's own share; syn_adaptive: see above)
+        assert sum(r[8] for r in res) > 0                                          # ... and pack bytes did leave the writer
 
 
 @pytest.mark.parametrize("name,world,cap0,cap_max", [("syn_mixed", 2, 128, 4096), ("syn_snp", 3, 4096, 1 << 20), ("syn_adaptive", 2, 72, 72),
@@ -288,6 +309,20 @@ def test_one_archive_from_n_ranks_on_the_gpu(name, world, tmp_path):
     from agc_amd import build
     build.build_host()
     _run(name, world, tmp_path, on_gpu=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("syn_snp", 2), ("syn_mixed", 3), ("syn_viral", 2)])
+def test_full_packs_dealt_in_the_middle_of_the_run_on_the_gpu(name, world, tmp_path, monkeypatch):
+    """the deals of test_full_packs_are_dealt_to_the_ranks_in_the_middle_of_the_run with the product libraries: a rank's share is coded by
+    its GPU's entropy stream (agc_hip_zstd17_batch_dev on a thread of its own) WHILE the same context prepares and commits the next
+    samples on the steps' streams; the frames travel back at a later control step.  Same archive."""
+    from agc_amd import build
+    build.build_host()
+    monkeypatch.setenv("AGC_AMD_DEAL_MIN_MB", "0")
+    monkeypatch.setenv("AGC_AMD_DEAL_EVERY", "1")
+    res = _run(name, world, tmp_path, on_gpu=True, prefetch=True)
+    assert len({r[7] for r in res}) == 1 and res[0][7] > 0, [r[7] for r in res]
 
 
 @pytest.mark.gpu
