@@ -1339,11 +1339,38 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             st.enc_ref += groups[(uint32_t)d.map_gid].ref_size ? groups[(uint32_t)d.map_gid].ref_size - 1 : 0;
         }
         if (n_enc) {
+            b.dev_enc_n = n_enc;
+            b.known_text = 0;
+            for (size_t i = 0; i < n_segs; ++i)
+                if (is_known[i])
+                    b.known_text += dsegs[i].len;
+            b.known_launch_due = true;
+            if (!launch_known_encode(b))
+                return 0;
+        }
+        lap(b, "encode of the known segments launched");
+    }
+    b.dev_enc_n = n_enc;
+    return 1;
+}
+
+// The launch of the whole-sample encode from the descriptors the device made (stage_scan_dev), queued at once: beside the estimates
+// and the cost vectors.  (Behind the estimates, or behind the whole classification -- beside the announced scan and the FASTA
+// conversion --, was measured in round 6: median step 13.7-15.5 ms against 12.6-13.2, profiles/EXPERIMENTS.md.)
+bool CAGCCompressor::Impl::launch_known_encode(BatchState &b)
+{
+    if (!b.known_launch_due)
+        return true;
+    b.known_launch_due = false;
+    const uint32_t n_enc = b.dev_enc_n;
+    {
+        {
             lane2_acquire(); // (the previous sample's deltas have been collected: they were while the table came over)
             lap(b, "second lane free");
             if (!hip_ok(DEVT(agc_hip_segments_encode_known(hip)), "segments_encode_known")) {
                 lane2_release();
-                return 0;
+                b.dev_enc_n = 0;
+                return false;
             }
             st.lz_encoded += n_enc;
             // The deltas are collected as soon as the kernel is done -- an early task of the bookkeeping thread, queued now -- when
@@ -1352,10 +1379,7 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             // task, a whole step later: 0.9 ms of "second lane free" per human-size sample) and that task starts with its deltas
             // on the host.  enc_buf is nobody's until the hand-over swaps the buffer sets (bulk mode: spec_bytes == 0).
             if (early_collect && dist_world == 1 && book_can_async(1) && b.spec_bytes == 0) {
-                uint64_t text = 0;
-                for (size_t i = 0; i < n_segs; ++i)
-                    if (is_known[i])
-                        text += dsegs[i].len;
+                const uint64_t text = b.known_text;
                 std::unique_ptr<BookTask> t(new BookTask());
                 t->early_only = true;
                 t->enc_n = n_enc;
@@ -1366,10 +1390,9 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
                 b.early_seq = book_submit(std::move(t));
             }
         }
-        lap(b, "encode of the known segments launched");
     }
-    b.dev_enc_n = n_enc;
-    return 1;
+    lap(b, "encode of the known segments launched");
+    return true;
 }
 
 bool CAGCCompressor::Impl::stage_scan(BatchState &b)

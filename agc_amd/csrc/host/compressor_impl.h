@@ -949,6 +949,8 @@ struct CAGCCompressor::Impl {
         // delivered; dev_enc_n != 0: the encode of the segments whose group was known is in flight on the device's second lane
         bool dev_keys = false;
         uint32_t dev_enc_n = 0;
+        bool known_launch_due = false; // the whole-sample encode has its descriptors on the device and is not launched yet (launch_known_encode)
+        uint64_t known_text = 0;       // symbols of its texts
         uint64_t early_seq = 0; // != 0: the book thread's early task that collects that encode (Impl::early_enc takes its result)
         std::vector<uint32_t> flight_keys, flight_gid, flight_len;
         std::vector<uint64_t> flight_off;
@@ -967,6 +969,7 @@ struct CAGCCompressor::Impl {
         } sto;
     };
     bool stage_scan(BatchState &b);
+    bool launch_known_encode(BatchState &b);
     int stage_scan_dev(BatchState &b);
     uint32_t dev_encode_min = 2048;    // segments a sample needs for the device-launched whole-sample encode (AGC_AMD_DEV_ENCODE_MIN: tests)
     bool use_dev_segments(const BatchState &b) const;

@@ -246,3 +246,55 @@ PY
     tail -3 $OUT/n_bench_2ranks_b8_deal$dm.err
   done
 fi
+if [ "$PART" = o ]; then
+  # the encode kernel with room for 7 / 8 waves per SIMD (71 / 64 VGPRs; default 78 -> 6 waves)
+  timeout 300 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "not every_launch" > $OUT/o_lz_tests_base.log 2>&1; tail -2 $OUT/o_lz_tests_base.log
+  for v in lz_w8 lz_w7; do
+    LD_PRELOAD=$PWD/scripts/variants/$v.so AGC_HIP_LIB=$PWD/scripts/variants/$v.so timeout 300 python -m pytest tests/test_gpu_lz.py -m gpu -x -q -k "not every_launch" > $OUT/o_lz_tests_$v.log 2>&1; tail -2 $OUT/o_lz_tests_$v.log
+  done
+  for rep in 1 2; do
+    bench o_bench_base_$rep
+    for v in lz_w8 lz_w7; do bench o_bench_${v}_$rep LD_PRELOAD=$PWD/scripts/variants/$v.so AGC_HIP_LIB=$PWD/scripts/variants/$v.so; done
+  done
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/o_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        e = d["config"]["step_ms_each_rank0"]
+        print(n.split("/")[-1], "median step", sorted(e)[len(e) // 2], e)
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = p ]; then
+  # where a registration queues its whole-sample encode: 0 at once (beside estimates + cost vectors), 1 behind the estimates, 2 behind the classification (beside scan + conversion)
+  for m in 1 2; do AGC_AMD_ENCODE_LAUNCH_AT=$m timeout 600 python -m pytest tests/test_gpu_archive.py -m gpu -x -q -k "c3_twin or small_samples or full_size" > $OUT/p_tests_at$m.log 2>&1; tail -1 $OUT/p_tests_at$m.log; done
+  for rep in 1 2; do for m in 0 1 2; do bench p_bench_at${m}_$rep AGC_AMD_ENCODE_LAUNCH_AT=$m; done; done
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/p_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        e = d["config"]["step_ms_each_rank0"]
+        print(n.split("/")[-1], "median step", sorted(e)[len(e) // 2], e)
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = z1 ]; then
+  # ---- end of round, part 1: tests, smoke, the driver's command (with the CPU baseline), controls, configs, two ranks on one GPU, fuzz
+  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd_steps20_warmup5.json 2> $OUT/bench_driver_cmd.err; show $OUT/bench_driver_cmd_steps20_warmup5.json
+  for i in 2 3; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd_steps20_warmup5_run$i.json 2>/dev/null; show $OUT/bench_driver_cmd_steps20_warmup5_run$i.json; done
+  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --prepacked > $OUT/bench_prepacked_control_steps20_warmup5.json 2>/dev/null; show $OUT/bench_prepacked_control_steps20_warmup5.json
+  timeout 400 python bench.py --no-cpu-baseline > $OUT/bench_default_no_cpu_baseline.json 2>/dev/null; show $OUT/bench_default_no_cpu_baseline.json
+  for cfg in c1 c4twin c5twin; do timeout 400 python bench.py --config $cfg > $OUT/bench_config_$cfg.json 2> /dev/null; show $OUT/bench_config_$cfg.json; done
+  timeout 900 python bench.py --config c5slice --c5-samples 192 > $OUT/bench_config_c5slice.json 2> /dev/null; show $OUT/bench_config_c5slice.json
+  AGC_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks.json 2> $OUT/bench_one_gpu_2_ranks.err; show $OUT/bench_one_gpu_2_ranks.json
+  timeout 900 python scripts/fuzz_archives.py --from 90000 --count 120 > $OUT/fuzz_gpu_120_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_120_cases.log
+  timeout 600 python scripts/fuzz_archives.py --many --from 91000 --count 30 > $OUT/fuzz_gpu_many_30_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_many_30_cases.log
+  timeout 600 python scripts/fuzz_archives.py --big --from 92000 --count 20 > $OUT/fuzz_gpu_big_20_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_big_20_cases.log
+  timeout 900 python scripts/fuzz_deals_gpu.py --from 93000 --count 24 > $OUT/fuzz_gpu_deals_24_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_deals_24_cases.log
+fi

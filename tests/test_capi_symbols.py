@@ -55,7 +55,7 @@ def test_host_compressor_header_matches_the_library_and_the_binding():
     h = open(os.path.join(ROOT, "include", "agc_cmp.h")).read()
     decl = sorted(set(re.findall(r"\b(agc_cmp_[a-z0-9_]+)\s*\(", h)))
     src = open(os.path.join(ROOT, "agc_amd", "csrc", "host", "capi_host.cpp")).read()
-    defined = sorted(set(re.findall(r"^(?:int|void|void \*|const char \*)\s*\*?(agc_cmp_[a-z0-9_]+)\(", src, re.M)))
+    defined = sorted(set(re.findall(r"^(?:int|void|uint64_t|void \*|const char \*)\s*\*?(agc_cmp_[a-z0-9_]+)\(", src, re.M)))
     assert decl == defined
     bound = sorted(set(re.findall(r"L\.(agc_cmp_[a-z0-9_]+)\.", open(host.__file__).read())))
     assert bound == decl

@@ -61,7 +61,7 @@ def _worker(rank, world, port, name, files, out_path, q, on_gpu=False, prefetch=
         else:       # host pipeline on the device stand-in (never the product library here)
             from tests.devsim import build as simbuild
             lib = host.bind(C.CDLL(simbuild.SIM_HOST))
-        args, _ = COLL.CONFIGS[name]
+        args = list(name) if isinstance(name, (list, tuple)) else COLL.CONFIGS[name][0]  # (a list: the CLI options themselves -- scripts/fuzz_deals.py)
         opt = {"-k": 31, "-l": 20, "-s": 60000, "-b": 50}
         for i in range(0, len(args) - 1):
             if args[i] in opt:

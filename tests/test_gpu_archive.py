@@ -222,6 +222,28 @@ def test_whole_sample_encode_from_the_device_descriptors_for_small_samples_too(n
 
 # sha256 / size of the archive the reference CLI (oracle/_ref/agc, libzstd 1.4.9) wrote for BASELINE configs[2] at FULL size --
 # the seeded 3 Gbp GRCh38-shaped reference + ONE 3 Gbp sample at d = 1e-3, -k 31 -l 15 -b 100 -- recorded by
+@pytest.mark.parametrize("env", [{"AGC_AMD_FASTA_PACK": "0"}, {"AGC_AMD_FASTA_PACK_MIN": "1", "AGC_AMD_WINDOW_MAX": "1"},
+                                 {"AGC_AMD_EARLY_COLLECT": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
+                                 {"AGC_AMD_REF_STORE_ASYNC": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"}],
+                         ids=["per_contig_conversion", "one_pass_conversion_of_every_file", "encode_collected_by_the_registrations_task", "reference_store_waited_for"])
+@pytest.mark.parametrize("name", ["syn_c3_twin", "syn_mixed", "syn_adaptive"])
+def test_round6_switches_keep_the_archive(name, env, tmp_path, monkeypatch):
+    """the file path with and without the one-pass FASTA conversion (agc_hip_sample_pack_fasta), the whole-sample encode collected by an
+    early task or by the registration's own, the reference store on a stream of its own or waited for: the real kernels, every sample on
+    the device-launched encode and a window of its own where that matters -- the reference's archive every time (syn_adaptive is the
+    collection that caught the packed buffers being packed again under the reference-store stream)"""
+    from agc_amd import build
+    build.build_host()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    out = str(tmp_path / "amd.agc")
+    r = subprocess.run([AGC_AMD, "create"] + args + ["-t", "8", "-o", out] + files, capture_output=True, text=True, timeout=300)
+    assert os.path.exists(out), r.stderr[-2000:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == GOLD[name]["sha256"], r.stderr[-1500:]
+
+
 # scripts/c3_full_identity.py on the GPU box (profiles/r4/c3_full_size_identity_1_sample_against_reference_cli_run.log: 256 s of
 # reference-CLI time, which is why the test compares with the recorded hash instead of running the CLI again)
 C3_FULL_1_SAMPLE = ("46b81e041ac68005a743d229bca09bf1d809d161fc3a145f6f97cba7858e6d9f", 767396631)

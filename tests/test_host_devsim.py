@@ -172,7 +172,12 @@ def test_bookkeeping_beside_the_next_registration_gives_the_same_archive(cli, na
                                  {"AGC_AMD_ASYNC_ENCODE": "0", "AGC_AMD_ASYNC_BOOK": "0", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_AMD_DEV_SEGMENTS": "0", "AGC_AMD_ASYNC_ENCODE": "0", "AGC_AMD_WINDOW_MAX": "1", "AGC_AMD_SYNC_ENTROPY": "1"},
                                  {"AGC_ZSTD_LIB": "libzstd.so.1"},
-                                 {"AGC_AMD_GPU_ZSTD": "0"}], ids=lambda e: "+".join(f"{k[8:] if k.startswith('AGC_AMD_') else k}={v}" for k, v in e.items()))
+                                 {"AGC_AMD_GPU_ZSTD": "0"},
+                                 # round 6: the whole-sample encode collected by the registration's own task / the reference store waited for
+                                 # where it is asked for, every sample on the device-launched encode and a window of its own
+                                 {"AGC_AMD_EARLY_COLLECT": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
+                                 {"AGC_AMD_REF_STORE_ASYNC": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
+                                 {"AGC_AMD_EARLY_COLLECT": "1", "AGC_AMD_REF_STORE_ASYNC": "1", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"}], ids=lambda e: "+".join(f"{k[8:] if k.startswith('AGC_AMD_') else k}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_c4_twin"])
 def test_switch_combinations_keep_the_archive(cli, name, env, tmp_path, monkeypatch):
     if name == "syn_c4_twin" and not ("AGC_AMD_DEV_SEGMENTS" in env or "AGC_AMD_ASYNC_BOOK" in env):
@@ -180,6 +185,21 @@ def test_switch_combinations_keep_the_archive(cli, name, env, tmp_path, monkeypa
     """the behaviour switches of DESIGN.md 11 that no other test sets, alone and combined with the ones that gate the threads:
     the encode collected by the calling thread, with and without the bookkeeping thread, on top of host-cut segments and a
     synchronous entropy stage; libzstd named explicitly; the device entropy stage off -- the reference's bytes every time"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    args, _ = C.CONFIGS[name]
+    files = C.build(name, str(tmp_path / "in"))
+    got = _create(cli, args, files, str(tmp_path / "o.agc"))
+    assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
+
+
+@pytest.mark.parametrize("name", ["syn_c3_twin", "syn_c4_twin", "syn_mixed"])
+@pytest.mark.parametrize("env", [{"AGC_AMD_FASTA_PACK": "0"}, {"AGC_AMD_FASTA_PACK_MIN": "1"}, {"AGC_AMD_FASTA_PACK_MIN": "1", "AGC_AMD_WINDOW_MAX": "1"}],
+                         ids=["per_contig", "every_window", "every_file_its_own_window"])
+def test_file_path_with_and_without_the_one_pass_conversion(cli, name, env, tmp_path, monkeypatch):
+    """AddSampleFiles: a window of raw contigs goes to the device as it is and is converted + packed there (agc_hip_sample_pack_fasta) --
+    for every window however small (AGC_AMD_FASTA_PACK_MIN=1), or never (AGC_AMD_FASTA_PACK=0: preprocess_raw_contig per contig and a
+    pack of the codes, the path before round 6); the 30 Mbp files of the twins take the one-pass conversion by default.  Same archives."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     args, _ = C.CONFIGS[name]
