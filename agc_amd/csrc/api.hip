@@ -174,6 +174,11 @@ struct agc_hip_ctx {
     // the parse in chunks (launch_parse): chunk list, logs and per-chunk output of the first stream and of the two encode lanes
     struct ChunkBufs {
         DevBuf d_jobs, d_seg0, d_logs, d_logn, d_out;
+        // the chunk logs of a human-size batch are 0.7 GB: a launch of thousands of parses that is NOT parsed in chunks has a helper
+        // thread allocate them, so that the first batch that is -- one text of a few hundred kb among 3 000, twice in twenty samples --
+        // does not pay a hipMalloc inside a step (27-41 ms on a box whose VRAM the process touches for the first time)
+        std::future<DevBuf> logs_ahead;
+        bool logs_asked = false;
     } chunk_bufs[3];
 
     // pinned host allocations handed out by agc_hip_host_alloc
@@ -569,6 +574,12 @@ void agc_hip_destroy(agc_hip_ctx *c)
             (void)hipFree(b->p);
     for (auto &ch : c->arena)
         (void)hipFree(ch.p);
+    for (auto &cbufs : c->chunk_bufs)
+        if (cbufs.logs_ahead.valid()) {
+            const DevBuf ahead = cbufs.logs_ahead.get();
+            if (ahead.p)
+                (void)hipFree(ahead.p);
+        }
     for (auto &rs : c->ref_store) {
         for (DevBuf *b : {&rs.d_slices, &rs.d_lag, &rs.d_out})
             if (b->p)
@@ -1869,6 +1880,17 @@ int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u
             pl.chunk_stride = MODE == MODE_ENCODE ? ((chunk_len + 5 * chunk_len / 16 + 160 + 15) & ~15u) : 0;
             CHK(ensure(c, cb.d_jobs, jobs.size() * sizeof(ChunkJob), st));
             CHK(ensure(c, cb.d_seg0, seg0.size() * 4, st));
+            if (cb.logs_ahead.valid()) { // (allocated ahead by a helper thread: see ChunkBufs)
+                const DevBuf ahead = cb.logs_ahead.get();
+                if (ahead.p && ahead.cap > cb.d_logs.cap) {
+                    if (cb.d_logs.p) {
+                        HIPCHK(c, hipStreamSynchronize(st));
+                        HIPCHK(c, hipFree(cb.d_logs.p));
+                    }
+                    cb.d_logs = ahead;
+                } else if (ahead.p)
+                    (void)hipFree(ahead.p);
+            }
             CHK(ensure(c, cb.d_logs, jobs.size() * (size_t)pl.cap * sizeof(ChunkState), st));
             CHK(ensure(c, cb.d_logn, jobs.size() * 4, st));
             if (MODE == MODE_ENCODE)
@@ -1928,6 +1950,28 @@ int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u
                 }
             }
             return AGC_HIP_OK;
+        }
+    }
+    if (b && !n_dev && MODE != MODE_ENCODE && forced != 0 && n >= 1024) {
+        // a big batch that was not worth chunks: the next one may be -- have the logs ready (sized for this batch's text + a half)
+        agc_hip_ctx::ChunkBufs &cb = c->chunk_bufs[lane];
+        if (!cb.logs_asked && cb.d_logs.cap == 0) {
+            uint64_t total = 0;
+            for (const SegDesc &sd : b->segs)
+                total += sd.text.len;
+            if (total >= (32u << 20)) {
+                cb.logs_asked = true;
+                const size_t n_jobs = (size_t)(total / 4096 + n), want = (n_jobs + n_jobs / 2) * (size_t)(4096 / 8 + 4) * sizeof(ChunkState);
+                const int dev = c->device;
+                cb.logs_ahead = std::async(std::launch::async, [want, dev] {
+                    DevBuf d;
+                    if (hipSetDevice(dev) == hipSuccess && hipMalloc(&d.p, want) == hipSuccess)
+                        d.cap = want;
+                    else
+                        d.p = nullptr;
+                    return d;
+                });
+            }
         }
     }
     static const bool chunk_log2 = getenv("AGC_HIP_CHUNK_LOG") != nullptr;

@@ -7,8 +7,9 @@ bookkeeping) over one synthetic human-scale sample that is resident in HBM as th
 FASTA file (BASELINE.json configs[2]: GRCh38-shaped reference, 0.1 % divergence, k=31 l=15 b=100;
 --prepacked: already in the 2-bit layout when the timer starts, round 4's region);
 the zstd packing the steps defer (packs flush every b samples) runs in Close(), which is
-inside the timed region.  The step is the same code path `agc_amd create` runs and whose
-archives are byte-identical to the reference's (tests/test_gpu_archive.py).
+inside the timed region.  The step is the code path `agc_amd create` runs -- AddSampleFiles converts a file's
+bytes with the same kernels (agc_hip_sample_pack_fasta) -- and whose archives are byte-identical to the reference's
+(tests/test_gpu_archive.py; this very input at full size: test_configs2_at_full_size_equals_the_reference_archive).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...

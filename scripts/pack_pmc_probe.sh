@@ -1,9 +1,9 @@
 #!/bin/bash
 # scripts/pack_pmc_probe.sh -- SQ counters of the FASTA -> 2-bit kernels alone (scripts/pack_alone.py), one rocprofv3 --pmc pass per
-# counter group; summary -> gpurun_out/r5/pack_pmc_summary.csv
+# counter group; summary -> gpurun_out/${PACK_PMC_TAG:-r6}/pack_pmc_summary.csv
 export TMPDIR=/tmp
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/r5/packpmc
+OUT=$ROOT/gpurun_out/${PACK_PMC_TAG:-r6}/packpmc
 mkdir -p $OUT
 B="python $ROOT/scripts/pack_alone.py 3.0 0"
 i=0
@@ -12,6 +12,6 @@ for set in "${SETS[@]}"; do
   i=$((i+1))
   (cd /tmp && timeout 200 rocprofv3 --pmc $set --output-format csv --kernel-include-regex "pack_fasta" -d $OUT/s$i -o p -- $B > $OUT/s$i.log 2>&1)
 done
-python scripts/pmc_summary.py $ROOT/gpurun_out/r5/pack_pmc_summary.csv $OUT/s*/
+python scripts/pmc_summary.py $ROOT/gpurun_out/${PACK_PMC_TAG:-r6}/pack_pmc_summary.csv $OUT/s*/
 find $OUT -name '*counter_collection.csv' -size +2M -delete
-cat $ROOT/gpurun_out/r5/pack_pmc_summary.csv
+cat $ROOT/gpurun_out/${PACK_PMC_TAG:-r6}/pack_pmc_summary.csv

@@ -24,6 +24,7 @@ if [ -x scripts/fetch_calib ]; then
   python scripts/pmc_summary.py $OUT/fetch_calib_pmc.csv $OUT/calib >> $OUT/fetch_calib.txt 2>&1
   cat $OUT/fetch_calib_pmc.csv >> $OUT/fetch_calib.txt
 fi
+python scripts/step_timeline.py $(find $OUT/ktrace -name "*kernel_trace.csv" | head -1) > $OUT/step_timeline.txt 2>&1
 # keep the merged-back volume small: the raw per-dispatch CSVs of the PMC passes are large
 find $OUT -name '*counter_collection.csv' -size +4M -delete
 find $OUT -name '*kernel_trace.csv' -size +8M -delete

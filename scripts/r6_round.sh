@@ -298,3 +298,37 @@ if [ "$PART" = z1 ]; then
   timeout 600 python scripts/fuzz_archives.py --big --from 92000 --count 20 > $OUT/fuzz_gpu_big_20_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_big_20_cases.log
   timeout 900 python scripts/fuzz_deals_gpu.py --from 93000 --count 24 > $OUT/fuzz_gpu_deals_24_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_deals_24_cases.log
 fi
+if [ "$PART" = z2 ]; then
+  # ---- end of round, part 2: rocprofv3 passes of the driver's command and of the c5slice CLI run, laps, --verify-entropy, pack counters, deals fuzz again
+  bash scripts/profile_round.sh r6 > $OUT/profile_round.log 2>&1; tail -3 $OUT/profile_round.log; cat $OUT/step_timeline.txt | head -12
+  timeout 200 python scripts/pack_alone.py 3.0 0 > $OUT/pack_alone.log 2>&1; tail -3 $OUT/pack_alone.log
+  bash scripts/pack_pmc_probe.sh > $OUT/pack_pmc_probe.log 2>&1; tail -5 $OUT/pack_pmc_probe.log
+  python - <<'PY'
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from agc_amd import synth
+td = "/dev/shm/c5prof"; os.makedirs(td, exist_ok=True)
+rng = np.random.default_rng(5)
+anc = synth.random_seq(rng, 5_000_000)
+plasmids = [synth.random_seq(rng, int(rng.integers(20_000, 90_000))) for _ in range(12)]
+with open(td + "/files.txt", "w") as fl:
+    for i in range(48):
+        ctg, nm = [synth.mutate(rng, anc, 0.025)], [f"NZ_CP{i:06d}.1 strain {i} chromosome"]
+        if i:
+            for pi in rng.permutation(12)[: int(rng.integers(0, 3))]:
+                ctg.append(synth.mutate(rng, plasmids[int(pi)], 0.025)); nm.append(f"NZ_CP{i:06d}p{int(pi)}.1 plasmid")
+        fn = f"{td}/GCF_{i:09d}.fa"; synth.to_fasta(fn, ctg, nm); fl.write(fn + "\n")
+PY
+  C5="agc_amd/bin/agc_amd create -a -t 16 -o /dev/shm/c5prof/o.agc $(cat /dev/shm/c5prof/files.txt | tr '\n' ' ')"
+  ROOT=$(pwd)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/c5_ktrace -o kt -- $ROOT/$C5 > $ROOT/$OUT/c5_ktrace.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv --kernel-include-regex agc -d $ROOT/$OUT/c5_pmc_fetch -o pf -- $ROOT/$C5 > $ROOT/$OUT/c5_pmc_fetch.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv --kernel-include-regex agc -d $ROOT/$OUT/c5_pmc_write -o pw -- $ROOT/$C5 > $ROOT/$OUT/c5_pmc_write.log 2>&1)
+  python scripts/pmc_summary.py $OUT/pmc_summary_c5slice.csv $OUT/c5_pmc_fetch $OUT/c5_pmc_write > $OUT/pmc_summary_c5slice.log 2>&1
+  find $OUT -name '*counter_collection.csv' -size +4M -delete; find $OUT -name '*kernel_trace.csv' -size +8M -delete
+  AGC_AMD_LAPS=1 AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_laps.json 2> $OUT/bench_laps_steps20_warmup5.txt; show $OUT/bench_laps.json
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --verify-entropy > $OUT/bench_verify_entropy.json 2> $OUT/bench_verify_entropy.log; grep -h "verify" $OUT/bench_verify_entropy.log | tail -3
+  timeout 900 python scripts/fuzz_deals_gpu.py --from 93000 --count 30 > $OUT/fuzz_gpu_deals_30_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_deals_30_cases.log
+  AGC_BENCH_ONE_GPU=1 AGC_AMD_DEAL_MIN_MB=-1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks_no_deals.json 2> /dev/null; show $OUT/bench_one_gpu_2_ranks_no_deals.json
+  find $OUT -name "*kernel_stats.csv" | head -3
+fi
