@@ -1955,13 +1955,13 @@ int launch_parse(agc_hip_ctx *c, uint32_t n, uint8_t *out_bytes, uint32_t *out_u
     if (b && !n_dev && MODE != MODE_ENCODE && forced != 0 && n >= 1024) {
         // a big batch that was not worth chunks: the next one may be -- have the logs ready (sized for this batch's text + a half)
         agc_hip_ctx::ChunkBufs &cb = c->chunk_bufs[lane];
-        if (!cb.logs_asked && cb.d_logs.cap == 0) {
+        if (!cb.logs_asked) {
             uint64_t total = 0;
             for (const SegDesc &sd : b->segs)
                 total += sd.text.len;
-            if (total >= (32u << 20)) {
+            const size_t n_jobs = (size_t)(total / 4096 + n), want = (n_jobs + n_jobs / 2) * (size_t)(4096 / 8 + 4) * sizeof(ChunkState);
+            if (total >= (32u << 20) && cb.d_logs.cap < want) { // (the few-texts launches of every step leave a small buffer behind)
                 cb.logs_asked = true;
-                const size_t n_jobs = (size_t)(total / 4096 + n), want = (n_jobs + n_jobs / 2) * (size_t)(4096 / 8 + 4) * sizeof(ChunkState);
                 const int dev = c->device;
                 cb.logs_ahead = std::async(std::launch::async, [want, dev] {
                     DevBuf d;

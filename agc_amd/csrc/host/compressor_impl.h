@@ -338,7 +338,13 @@ struct PinnedBytes {
         if (!keep)
             release();
         void *q = nullptr;
+        static const bool laps = getenv("AGC_AMD_LAPS") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t had = n;
         const bool pin = ctx && agc_hip_host_alloc(ctx, m, &q) == AGC_HIP_OK && q;
+        if (laps && m >= (4u << 20))
+            fprintf(stderr, "    pinned buffer: %.1f -> %.1f MB in %.3f ms\n", had / 1e6, m / 1e6,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (!pin)
             q = malloc(m);
         if (!q)

@@ -332,3 +332,35 @@ PY
   AGC_BENCH_ONE_GPU=1 AGC_AMD_DEAL_MIN_MB=-1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_one_gpu_2_ranks_no_deals.json 2> /dev/null; show $OUT/bench_one_gpu_2_ranks_no_deals.json
   find $OUT -name "*kernel_stats.csv" | head -3
 fi
+if [ "$PART" = q ]; then
+  # the chunk logs allocated ahead: the first run on a fresh box once more (laps: which buffers grow inside steps), then the GPU suite on the final build
+  AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/q_bench_first.json 2> $OUT/q_bench_first.txt; show $OUT/q_bench_first.json
+  grep -n "ensure:\|arena:" $OUT/q_bench_first.txt | tail -8
+  bench q_bench_2
+  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/q_gpu_tests.log 2>&1; tail -3 $OUT/q_gpu_tests.log
+  bench q_bench_3
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/q_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"])
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = r ]; then
+  AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/r_bench_first.json 2> $OUT/r_bench_first.txt; show $OUT/r_bench_first.json
+  grep -n "ensure:\|arena:" $OUT/r_bench_first.txt | tail -5
+  bench r_bench_2
+  timeout 600 python -m pytest tests/test_gpu_lz.py tests/test_gpu_archive.py -m gpu -x -q -k "not every_launch" > $OUT/r_tests.log 2>&1; tail -2 $OUT/r_tests.log
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/r_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        print(n.split("/")[-1], d["config"]["step_ms_each_rank0"])
+    except Exception as e:
+        print(n, e)
+PY
+fi

@@ -193,10 +193,10 @@ def test_switch_combinations_keep_the_archive(cli, name, env, tmp_path, monkeypa
     assert hashlib.sha256(got).hexdigest() == GOLD[name]["sha256"]
 
 
-@pytest.mark.parametrize("name,env", [("syn_c3_twin", {"AGC_AMD_FASTA_PACK": "0"}), ("syn_c4_twin", {"AGC_AMD_FASTA_PACK": "0"}),
+@pytest.mark.parametrize("name,env", [("syn_c4_twin", {"AGC_AMD_FASTA_PACK": "0"}),  # (the configs[2] twin per contig: tests/test_gpu_archive.py)
                                       ("syn_mixed", {"AGC_AMD_FASTA_PACK_MIN": "1"}), ("syn_shuffled", {"AGC_AMD_FASTA_PACK_MIN": "1", "AGC_AMD_WINDOW_MAX": "1"}),
                                       ("syn_viral", {"AGC_AMD_FASTA_PACK_MIN": "1"})],
-                         ids=["c3_twin_per_contig", "c4_twin_per_contig", "mixed_every_window", "shuffled_every_file_its_own_window", "viral_every_window"])
+                         ids=["c4_twin_per_contig", "mixed_every_window", "shuffled_every_file_its_own_window", "viral_every_window"])
 def test_file_path_with_and_without_the_one_pass_conversion(cli, name, env, tmp_path, monkeypatch):
     """AddSampleFiles: a window of raw contigs goes to the device as it is and is converted + packed there (agc_hip_sample_pack_fasta) --
     for every window however small (AGC_AMD_FASTA_PACK_MIN=1), or never (AGC_AMD_FASTA_PACK=0: preprocess_raw_contig per contig and a
