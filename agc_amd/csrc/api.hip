@@ -187,6 +187,14 @@ struct agc_hip_ctx {
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, zev0 = nullptr, zev1 = nullptr;
+    // KTimer's event pairs: recorded around a launch and READ LATER (when the ring comes round, or by agc_hip_timing_get) -- timing a
+    // run must not add a wait behind every kernel of the steps' stream (rounds 1-5 did: hipEventSynchronize in KTimer's destructor)
+    struct TimerPair {
+        hipEvent_t a = nullptr, b = nullptr;
+        int which = -1; // >= 0: recorded, not read yet
+    };
+    std::vector<TimerPair> tpairs;
+    size_t tpair_next = 0;
     double ms[AGC_HIP_K_COUNT] = {0};
     uint64_t launches[AGC_HIP_K_COUNT] = {0};
 };
@@ -288,23 +296,48 @@ int arena_alloc(agc_hip_ctx *c, size_t bytes, uint8_t **out)
     return AGC_HIP_OK;
 }
 
+void ktimer_read(agc_hip_ctx *c, agc_hip_ctx::TimerPair &p)
+{
+    if (p.which < 0)
+        return;
+    float ms = 0;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        c->ms[p.which] += ms;
+        c->launches[p.which] += 1;
+    }
+    p.which = -1;
+}
+
+void ktimer_read_all(agc_hip_ctx *c)
+{
+    for (auto &p : c->tpairs)
+        ktimer_read(c, p);
+}
+
 struct KTimer {
     agc_hip_ctx *c;
+    agc_hip_ctx::TimerPair *p = nullptr;
     int which;
     KTimer(agc_hip_ctx *c_, int w) : c(c_), which(w) // (w < 0: not timed -- a launch on the second lane)
     {
-        if (c->timing && which >= 0)
-            (void)hipEventRecord(c->ev0, c->stream);
+        if (!c->timing || which < 0)
+            return;
+        if (c->tpairs.empty())
+            c->tpairs.resize(256);
+        p = &c->tpairs[c->tpair_next];
+        c->tpair_next = (c->tpair_next + 1) % c->tpairs.size();
+        ktimer_read(c, *p); // (a pair recorded 256 launches ago: long done)
+        if ((!p->a && hipEventCreate(&p->a) != hipSuccess) || (!p->b && hipEventCreate(&p->b) != hipSuccess)) {
+            p = nullptr;
+            return;
+        }
+        (void)hipEventRecord(p->a, c->stream);
     }
     ~KTimer()
     {
-        if (c->timing && which >= 0) {
-            (void)hipEventRecord(c->ev1, c->stream);
-            (void)hipEventSynchronize(c->ev1);
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-            c->ms[which] += ms;
-            c->launches[which] += 1;
+        if (p) {
+            (void)hipEventRecord(p->b, c->stream);
+            p->which = which;
         }
     }
 };
@@ -596,6 +629,12 @@ void agc_hip_destroy(agc_hip_ctx *c)
         if (sp.p)
             (void)hipFree(sp.p);
     }
+    for (auto &tp : c->tpairs) {
+        if (tp.a)
+            (void)hipEventDestroy(tp.a);
+        if (tp.b)
+            (void)hipEventDestroy(tp.b);
+    }
     if (c->ev0)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
@@ -644,6 +683,7 @@ int agc_hip_timing_reset(agc_hip_ctx *c)
 {
     if (!c)
         return AGC_HIP_EINVAL;
+    ktimer_read_all(c);
     for (int i = 0; i < AGC_HIP_K_COUNT; ++i) {
         c->ms[i] = 0;
         c->launches[i] = 0;
@@ -655,6 +695,7 @@ int agc_hip_timing_get(agc_hip_ctx *c, int which, double *ms, uint64_t *launches
 {
     if (!c || which < 0 || which >= AGC_HIP_K_COUNT)
         return AGC_HIP_EINVAL;
+    ktimer_read_all(c); // (the pairs recorded since the last call: waits for the last of them)
     if (ms)
         *ms = c->ms[which];
     if (launches)
@@ -1588,6 +1629,8 @@ static int ref_register_impl(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_
         hipLaunchKernelGGL(idx_insert_kernel, dim3(n_refs * split), dim3(256), 0, c->stream, (const IdxBuild *)c->d_jobs.p, split);
     }
     HIPCHK(c, hipGetLastError());
+    // (whatever parses against these tables is ordered behind the insert -- the steps' stream itself, or a lane through the `ready`
+    // event its begin records there -- so this wait is not needed for them; without it the step measured the same, round 6)
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     if (c->refs.size() <= max_gid)
@@ -1690,6 +1733,7 @@ int agc_hip_ref_index_get(agc_hip_ctx *c, uint32_t gid, uint32_t *h_table, uint6
     *h_is16 = r.is_short;
     if (cap < hs)
         return AGC_HIP_ECAP;
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the insert of the registration may still be running)
     if (r.is_short) {
         std::vector<uint32_t> t(hs);
         HIPCHK(c, hipMemcpy(t.data(), r.table, hs * 4, hipMemcpyDeviceToHost));

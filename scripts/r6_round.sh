@@ -364,3 +364,30 @@ for n in sorted(glob.glob("gpurun_out/r6/r_bench_*.json")):
         print(n, e)
 PY
 fi
+if [ "$PART" = s ]; then
+  # timers read later instead of a wait behind every kernel; no wait behind the index build
+  timeout 1500 python -m pytest tests -m gpu -q > $OUT/s_tests.log 2>&1; tail -2 $OUT/s_tests.log
+  bench s_bench_1; bench s_bench_2; bench s_bench_3
+  timeout 300 python bench.py --config c5twin > $OUT/s_c5twin.json 2>/dev/null; show $OUT/s_c5twin.json
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/s_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        e = d["config"]["step_ms_each_rank0"]
+        print(n.split("/")[-1], "median", sorted(e)[len(e)//2], e)
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = t ]; then
+  # what a step that takes twice as long was waiting for: laps of the driving thread, three runs
+  for i in 1 2 3; do
+    AGC_AMD_LAPS=1 AGC_HIP_LAPS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/t_laps_$i.json 2> $OUT/t_laps_$i.txt; show $OUT/t_laps_$i.json
+    python scripts/lap_outliers.py $OUT/t_laps_$i.txt | cut -c1-600
+    python - $OUT/t_laps_$i.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(d["config"]["step_ms_each_rank0"])
+PY
+  done
+fi
