@@ -73,6 +73,8 @@ struct agc_hip_ctx {
     std::vector<RefDesc> refs;       // indexed by gid
     DevBuf d_refs;
     bool refs_dirty = true;
+    size_t refs_dirty_lo = 0, refs_dirty_hi = 0; // groups [lo, hi) changed since the table went to the device (refs_on_dev entries are there)
+    size_t refs_on_dev = 0;
     std::vector<ArenaChunk> arena;
     // agc_hip_ref_store_begin_packed / _end: two slots, a stream and buffers of their own (the steps' stream never waits for them)
     struct RefStore {
@@ -118,6 +120,16 @@ struct agc_hip_ctx {
     uint8_t *up_ring = nullptr;
     size_t up_cap = 0, up_head = 0;
     std::mutex up_mtx;
+    // the ring in UP_PARTS parts: a part remembers the streams that copied out of it and, when the head leaves it, an event on each;
+    // the head waits for those events when it comes back (a ring's length later: they are long done -- the whole-ring wait for
+    // every stream at the wrap cost a step 7 ms once in 16 samples)
+    static constexpr int UP_PARTS = 4, UP_STREAMS = 12;
+    struct UpPart {
+        hipStream_t st[UP_STREAMS] = {};
+        hipEvent_t ev[UP_STREAMS] = {};
+        int n = 0;         // streams noted since the head came in
+        int n_recorded = 0; // events recorded when it left
+    } up_part[UP_PARTS];
 
     // second LZ lane: agc_hip_lz_encode_begin_dev / _end run the encode of a whole sample on `stream2` with their own scratch,
     // beside the estimates / cost vectors / index builds the caller goes on with on `stream`
@@ -369,30 +381,52 @@ int ensure_z(agc_hip_ctx *c, DevBuf &b, size_t bytes) { return ensure(c, b, byte
 // tens of steps; the wrap waits for the LZ streams once to be sure).  Large copies go the ordinary way.
 int upload(agc_hip_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStream_t st)
 {
-    constexpr size_t RING = (size_t)64 << 20, MAX_PIECE = (size_t)8 << 20;
+    constexpr size_t RING = (size_t)64 << 20, MAX_PIECE = (size_t)8 << 20, PART = RING / agc_hip_ctx::UP_PARTS;
+    static_assert(PART >= 2 * MAX_PIECE, "a piece must fit a part");
     if (!bytes)
         return AGC_HIP_OK;
     if (bytes > MAX_PIECE) {
         HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
         return AGC_HIP_OK;
     }
-    uint8_t *slot;
-    {
-        std::lock_guard<std::mutex> lk(c->up_mtx);
-        if (!c->up_ring) {
-            HIPCHK(c, hipHostMalloc((void **)&c->up_ring, RING, hipHostMallocDefault));
-            c->up_cap = RING;
-        }
-        const size_t need = (bytes + 255) & ~(size_t)255;
-        if (c->up_head + need > c->up_cap) {
-            for (hipStream_t s_ : {c->stream, c->stream2, c->stream3, c->pf.stream, c->pfa.stream, c->ref_store_stream})
-                if (s_)
-                    HIPCHK(c, hipStreamSynchronize(s_));
-            c->up_head = 0;
-        }
-        slot = c->up_ring + c->up_head;
-        c->up_head += need;
+    // (the lock is held until the copy is queued: the event a part records on a stream when the head leaves is then behind every
+    // copy out of that part)
+    std::lock_guard<std::mutex> lk(c->up_mtx);
+    if (!c->up_ring) {
+        HIPCHK(c, hipHostMalloc((void **)&c->up_ring, RING, hipHostMallocDefault));
+        c->up_cap = RING;
     }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    size_t part = c->up_head ? (c->up_head - 1) / PART : 0; // (a head at a part's very end still belongs to it)
+    if (c->up_head + need > (part + 1) * PART) {
+        agc_hip_ctx::UpPart &old_part = c->up_part[part];
+        for (int i = 0; i < old_part.n; ++i) {
+            if (!old_part.ev[i])
+                HIPCHK(c, hipEventCreateWithFlags(&old_part.ev[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(old_part.ev[i], old_part.st[i]));
+        }
+        old_part.n_recorded = old_part.n;
+        old_part.n = 0;
+        part = (part + 1) % agc_hip_ctx::UP_PARTS;
+        c->up_head = part * PART;
+        agc_hip_ctx::UpPart &new_part = c->up_part[part];
+        for (int i = 0; i < new_part.n_recorded; ++i)
+            HIPCHK(c, hipEventSynchronize(new_part.ev[i]));
+        new_part.n_recorded = 0;
+    }
+    agc_hip_ctx::UpPart &P = c->up_part[part];
+    int k = 0;
+    while (k < P.n && P.st[k] != st)
+        ++k;
+    if (k == P.n) {
+        if (P.n == agc_hip_ctx::UP_STREAMS) { // (more streams than a part has room for: make room the slow way)
+            HIPCHK(c, hipStreamSynchronize(P.st[0]));
+            P.st[0] = st;
+        } else
+            P.st[P.n++] = st;
+    }
+    uint8_t *slot = c->up_ring + c->up_head;
+    c->up_head += need;
     std::memcpy(slot, h_src, bytes);
     HIPCHK(c, hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, st));
     return AGC_HIP_OK;
@@ -411,15 +445,29 @@ int upload_refs(agc_hip_ctx *c)
 {
     if (!c->refs_dirty)
         return AGC_HIP_OK;
-    for (auto *ln : {&c->l2, &c->l3})
-        if (ln->pending)
-            HIPCHK(c, hipStreamSynchronize(ln->s)); // the encode in flight reads the table that is about to be replaced
-    CHK(ensure(c, c->d_refs, std::max<size_t>(1, c->refs.size()) * sizeof(RefDesc)));
-    if (!c->refs.empty())
-        CHK(upload(c, c->d_refs.p, c->refs.data(), c->refs.size() * sizeof(RefDesc), c->stream));
-    if (c->refs.size() * sizeof(RefDesc) > ((size_t)8 << 20))
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // (beyond upload()'s staging: the vector may be reallocated by the next register)
+    // Only what changed goes over: a registration adds descriptors (a group gets its reference once, agc_hip_ref_register* refuses a
+    // second), it never changes one a parse in flight may be reading -- so no lane is waited for and a step moves some KB instead of
+    // the whole table (2.8 MB for the 50 k groups of a human sample: 0.3 ms of the driving thread and a twentieth of the pinned ring
+    // per sample; the wait for the whole-sample encode on lane 0 was 7 ms of the first step after an idle pipeline).  A table that has
+    // to move to a larger buffer is the exception: lanes first, then everything.
+    size_t lo = c->refs_dirty_lo, hi = std::min(c->refs_dirty_hi, c->refs.size());
+    const size_t need = std::max<size_t>(1, c->refs.size()) * sizeof(RefDesc);
+    if (need > c->d_refs.cap || c->refs_on_dev == 0) {
+        for (auto *ln : {&c->l2, &c->l3})
+            if (ln->pending)
+                HIPCHK(c, hipStreamSynchronize(ln->s)); // the encode in flight reads the buffer that is about to be freed
+        CHK(ensure(c, c->d_refs, need));
+        lo = 0;
+        hi = c->refs.size();
+    }
+    if (hi > lo) {
+        CHK(upload(c, (RefDesc *)c->d_refs.p + lo, c->refs.data() + lo, (hi - lo) * sizeof(RefDesc), c->stream));
+        if ((hi - lo) * sizeof(RefDesc) > ((size_t)8 << 20))
+            HIPCHK(c, hipStreamSynchronize(c->stream)); // (beyond upload()'s staging: the vector may be reallocated by the next register)
+    }
+    c->refs_on_dev = c->refs.size();
     c->refs_dirty = false;
+    c->refs_dirty_lo = c->refs_dirty_hi = 0;
     return AGC_HIP_OK;
 }
 
@@ -582,6 +630,10 @@ void agc_hip_destroy(agc_hip_ctx *c)
         (void)hipHostFree(hp);
     if (c->up_ring)
         (void)hipHostFree(c->up_ring);
+    for (auto &up : c->up_part)
+        for (hipEvent_t e : up.ev)
+            if (e)
+                (void)hipEventDestroy(e);
     for (auto *ln : {&c->l2, &c->l3})
         if (ln->h_lens)
             (void)hipHostFree(ln->h_lens);
@@ -1648,6 +1700,20 @@ static int ref_register_impl(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_
         r.min_match_len = min_match_len;
         r.is_short = jobs[i].is_short;
         r.valid = 1;
+    }
+    {
+        uint32_t min_gid = max_gid;
+        for (uint32_t i = 0; i < n_refs; ++i)
+            min_gid = std::min(min_gid, h_gid[i]);
+        if (!c->refs_dirty || c->refs_dirty_hi <= c->refs_dirty_lo) {
+            c->refs_dirty_lo = min_gid;
+            c->refs_dirty_hi = (size_t)max_gid + 1;
+        } else {
+            c->refs_dirty_lo = std::min<size_t>(c->refs_dirty_lo, min_gid);
+            c->refs_dirty_hi = std::max<size_t>(c->refs_dirty_hi, (size_t)max_gid + 1);
+        }
+        // (descriptors the resize above added between the old end and min_gid are invalid ones: they go over too)
+        c->refs_dirty_lo = std::min(c->refs_dirty_lo, c->refs_on_dev);
     }
     c->refs_dirty = true;
     return AGC_HIP_OK;

@@ -254,6 +254,18 @@ uint64_t CAGCCompressor::Impl::book_submit(std::unique_ptr<BookTask> &&t)
     return seq;
 }
 
+// room for the deltas of `text` symbols left in flight on a lane: 1/64 + 1/512 of the text is never reached by related genomes; a
+// first allocation takes a quarter more (the text the device knows grows by a percent or two from sample to sample for the first
+// samples of a collection, and every new maximum is a hipHostFree + hipHostMalloc of tens of MB on the thread that holds the lane:
+// 2.5 ms in each of the bench's first two timed steps); a buffer that does not hold the deltas after all answers ECAP
+static uint64_t delta_cap(uint64_t have, uint64_t text)
+{
+    const uint64_t want = text / 64 + text / 512 + (1u << 16);
+    if (have >= want)
+        return have;
+    return have == 0 ? want + want / 4 : want;
+}
+
 void CAGCCompressor::Impl::book_main()
 {
     for (;;) {
@@ -283,7 +295,7 @@ void CAGCCompressor::Impl::book_main()
                 }
             }
             if (ok) {
-                uint64_t cap = std::max<uint64_t>(enc.size(), text / 64 + text / 512 + (1u << 16));
+                uint64_t cap = delta_cap(enc.size(), text);
                 for (;;) {
                     if (!enc.resize(cap, false)) {
                         err("out of memory (delta buffer)");
@@ -322,7 +334,7 @@ void CAGCCompressor::Impl::book_main()
             }
             if (ok) {
                 PinnedBytes &enc = *t->enc_dst;
-                uint64_t cap = std::max<uint64_t>(enc.size(), t->enc_text / 64 + t->enc_text / 512 + (1u << 16));
+                uint64_t cap = delta_cap(enc.size(), t->enc_text);
                 for (;;) {
                     if (!enc.resize(cap, false)) {
                         err("out of memory (delta buffer)");
@@ -378,12 +390,19 @@ void CAGCCompressor::Impl::book_main()
         }
         const double t_c1 = now();
         book_on_thread = true;
-        ok = ok && finish_ref_store(t->cd, t->fetched) && book_and_store(t->cd);
+        ok = ok && finish_ref_store(t->cd, t->fetched);
+        const double t_c2 = now();
+        ok = ok && book_and_store(t->cd);
+        const double t_c3 = now();
         book_on_thread = false;
         t.reset();
         static const bool book_laps = getenv("AGC_AMD_LAPS") != nullptr;
-        if (book_laps)
-            std::cerr << "    book task: collect lane 0 " << (t_c0 - t0) * 1e3 << " ms, lane 1 " << (t_c1 - t_c0) * 1e3 << " ms, books " << (now() - t_c1) * 1e3 << " ms\n";
+        if (book_laps) {
+            char line[256];
+            snprintf(line, sizeof line, "    book task: collect lane 0 %.3f ms, lane 1 %.3f ms, reference store awaited %.3f ms, books %.3f ms, task freed %.3f ms\n",
+                     (t_c0 - t0) * 1e3, (t_c1 - t_c0) * 1e3, (t_c2 - t_c1) * 1e3, (t_c3 - t_c2) * 1e3, (now() - t_c3) * 1e3);
+            std::cerr << line;
+        }
         {
             std::lock_guard<std::mutex> lk(book_mtx);
             book_busy = false;
@@ -2771,7 +2790,7 @@ bool CAGCCompressor::Impl::book_and_store(CommitData &cdta)
                             if (f >= 0)
                                 igid = g.no_seqs - (uint32_t)(g.lzp_off.size() - (size_t)f);
                             else {
-                                Group::push(g.lzp_data, g.lzp_off, dp, dn);
+                                Group::push(g.lzp_data, g.lzp_off, dp, dn, pack_cardinality);
                                 ++g.no_seqs;
                                 igid = g.no_seqs - 1;
                             }

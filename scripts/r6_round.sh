@@ -391,3 +391,13 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(d["conf
 PY
   done
 fi
+if [ "$PART" = u ]; then
+  timeout 1500 python -m pytest tests/test_gpu_lz.py tests/test_gpu_archive.py tests/test_gpu_scan.py -m gpu -x -q > $OUT/u_tests.log 2>&1; tail -2 $OUT/u_tests.log
+fi
+if [ "$PART" = v ]; then
+  # what a large allocation on a helper thread costs the thread that drives kernels
+  hipcc --offload-arch=gfx950 -O2 -w -o /tmp/msp scripts/malloc_stall_probe.hip -lpthread || exit 1
+  { timeout 60 /tmp/msp 4 6; timeout 60 /tmp/msp 0 6; timeout 60 /tmp/msp 0 6; timeout 60 /tmp/msp 0 6 40; timeout 60 /tmp/msp 1 6 60; timeout 60 /tmp/msp 2 6 80
+    timeout 60 /tmp/msp 3 6 100; timeout 60 /tmp/msp 0 6 120; timeout 60 /tmp/msp 0 1 140; timeout 60 /tmp/msp 0 12 150; } > $OUT/v_malloc_stall.txt 2>&1
+  cat $OUT/v_malloc_stall.txt
+fi
