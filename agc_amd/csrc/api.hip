@@ -1930,7 +1930,7 @@ int prepare_batch(agc_hip_ctx *c, int mode, uint32_t n, const uint32_t *h_gid, c
         CHK(upload(c, c->d_fjobs.p, fjobs.data(), fjobs.size() * sizeof(FilterJob), L_stream));
         {
             KTimer t(c, AGC_HIP_K_FILTER);
-            hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(256), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
+            hipLaunchKernelGGL(key_filter_kernel, dim3((uint32_t)fjobs.size()), dim3(FILTER_THREADS), 0, L_stream, (const FilterJob *)c->d_fjobs.p);
         }
         HIPCHK(c, hipGetLastError()); // (fjobs is a local: upload() took its copy)
     }

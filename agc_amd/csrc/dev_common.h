@@ -43,23 +43,26 @@ __host__ __device__ inline uint32_t key_bloom_shift(uint32_t ref_size)
     return sh;
 }
 __host__ __device__ inline uint32_t key_bloom_half_words(uint32_t shift) { return 1u << (32 - shift); }
-__host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t shift, uint32_t &word, uint64_t &mask)
+// The filters as 32-bit words (a half = 2 * key_bloom_half_words u32 words): the word from the top bits of one product, the
+// three bit numbers from the low 5 bits of bytes 1-3 of a second one (the shifter reads them where they lie: SDWA) -- 10 vector
+// instructions per key instead of the ~25 of the 64-bit form of rounds 4-5 (key_filter_kernel tests one key per text position).
+__host__ __device__ inline uint32_t key_bloom_mask(uint32_t ml)
 {
-    const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
-    uint32_t h1 = (a ^ (b * 0x9E3779B1u)) * 0x85EBCA6Bu;
-    h1 ^= h1 >> 15;
-    const uint32_t h2 = h1 * 0xC2B2AE35u;
-    word = h1 >> shift;
-    mask = (1ULL << (h2 >> 26)) | (1ULL << ((h2 >> 20) & 63)) | (1ULL << ((h2 >> 14) & 63));
+    return (1u << ((ml >> 8) & 31)) | (1u << ((ml >> 16) & 31)) | (1u << ((ml >> 24) & 31));
 }
-__host__ __device__ inline void key_bloom_slot2(uint64_t key, uint32_t shift, uint32_t &word, uint64_t &mask)
+__host__ __device__ inline void key_bloom_slot(uint64_t key, uint32_t shift, uint32_t &word, uint32_t &mask)
 {
     const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
-    uint32_t h1 = ((a * 0xCC9E2D51u) ^ (b + 0x7F4A7C15u)) * 0x1B873593u;
-    h1 ^= h1 >> 13;
-    const uint32_t h2 = h1 * 0x27D4EB2Fu;
-    word = key_bloom_half_words(shift) + (h1 >> shift);
-    mask = (1ULL << (h2 >> 26)) | (1ULL << ((h2 >> 19) & 63)) | (1ULL << ((h2 >> 12) & 63));
+    const uint32_t h = (a ^ (b * 0x9E3779B1u)) * 0x85EBCA6Bu;
+    word = h >> (shift - 1);
+    mask = key_bloom_mask(h * 0xC2B2AE35u);
+}
+__host__ __device__ inline void key_bloom_slot2(uint64_t key, uint32_t shift, uint32_t &word, uint32_t &mask)
+{
+    const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
+    const uint32_t h = ((a * 0xCC9E2D51u) ^ (b + 0x7F4A7C15u)) * 0x1B873593u;
+    word = 2 * key_bloom_half_words(shift) + (h >> (shift - 1));
+    mask = key_bloom_mask(h * 0x27D4EB2Fu);
 }
 
 struct RefDesc {
@@ -119,12 +122,27 @@ struct PackedView {
     uint64_t n_symbols;
 };
 
-constexpr uint32_t SBLOOM_WORDS = 32768; // 128 KiB of LDS: filter over the last 16 symbols of the splitters (both strands)
+// Filter over the last 16 symbols of the splitters (both strands): 128 KiB of LDS, 3 bits per entry inside one 32-bit word.
+// Made for the instruction count of the scan's inner loop (one test per text position, round 6): the word's BYTE address is the
+// high product masked (no shift), the three bit numbers are the low 5 bits of bytes 1-3 of the low product (the shifter reads
+// them where they lie: v_lshlrev_b32_sdwa) -- 11 vector instructions per position instead of 15.5 (profiles/EXPERIMENTS.md).
+constexpr uint32_t SBLOOM_WORDS = 32768;
+__host__ __device__ inline void sbloom_addr_mask(uint32_t w16, uint32_t &byte_addr, uint32_t &mask)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t mh = __umulhi(w16, 0x9E3779B1u);
+#else
+    const uint32_t mh = (uint32_t)(((uint64_t)w16 * 0x9E3779B1u) >> 32);
+#endif
+    const uint32_t ml = w16 * 0x85EBCA6Bu;
+    byte_addr = mh & ((SBLOOM_WORDS - 1) << 2);
+    mask = (1u << ((ml >> 8) & 31)) | (1u << ((ml >> 16) & 31)) | (1u << ((ml >> 24) & 31));
+}
 __host__ __device__ inline void sbloom_slot(uint32_t w16, uint32_t &word, uint32_t &mask)
 {
-    const uint32_t m = w16 * 0x9E3779B1u;
-    word = m >> 17; // 15 bits
-    mask = (1u << ((m >> 12) & 31)) | (1u << ((m >> 7) & 31)) | (1u << ((m >> 2) & 31));
+    uint32_t a;
+    sbloom_addr_mask(w16, a, mask);
+    word = a >> 2;
 }
 
 struct ScanHit {

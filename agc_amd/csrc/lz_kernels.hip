@@ -1241,7 +1241,7 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t *__rest
 // multiplies for the filter hash, one LDS read.  Bit = 1 ("may match / let the exact step decide") when the key is in the
 // filter, contains a symbol outside ACGT, or runs past the end of the text.
 // ---------------------------------------------------------------------------
-constexpr uint32_t FILTER_CHUNK = 32768;
+constexpr uint32_t FILTER_CHUNK = 65536;
 
 struct FilterJob {
     SymView text;
@@ -1273,28 +1273,65 @@ template <class V> __device__ __forceinline__ void pack16(const V &tv, uint32_t 
     }
 }
 
-__global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__restrict__ jobs)
+// One pass of the first filter over the 16 positions of every lane (bit j of the result: the key at position j is in it).
+// V2:V1:V0 = the lane's 96-bit window shifted so that the key of position 15 starts at bit 0; the key of position j is then a
+// funnel shift by the constant 2 (15 - j).
+template <bool IN_LDS>
+__device__ __forceinline__ uint32_t key_filter_pass1(uint32_t V0, uint32_t V1, uint32_t V2, uint32_t kmask_lo, uint32_t kmask_hi, uint32_t bshift,
+                                                     const uint32_t *s_filter, g_u32 *g_filter)
+{
+    uint32_t pass = 0;
+#pragma unroll
+    for (int h = 1; h >= 0; --h) { // (eight reads in flight before the first outcome is needed)
+        uint32_t fw[8], bm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sh = 2 * (15 - (8 * h + i));
+            const uint32_t lo = (sh ? __builtin_amdgcn_alignbit(V1, V0, sh) : V0) & kmask_lo;
+            const uint32_t hi = (sh ? __builtin_amdgcn_alignbit(V2, V1, sh) : V1) & kmask_hi;
+            uint32_t bw;
+            key_bloom_slot(((uint64_t)hi << 32) | lo, bshift, bw, bm[i]);
+            fw[i] = IN_LDS ? s_filter[bw] : g_filter[bw];
+        }
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            const uint32_t missing = bm[i] & ~fw[i];
+            asm("v_cmp_eq_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(pass) : "v"(missing) : "vcc");
+        }
+    }
+    return pass;
+}
+
+// (256 threads per copy of the filter: 512 / 1024 were measured -- half / a quarter of the LDS per wavefront beside the scan's 128 KiB,
+// the kernel alone twice as fast -- but a block that needs 8 / 16 free wave slots on ONE CU at once waits for them while the
+// whole-sample encode holds the slots: the step's filter row 3.0-3.5 ms instead of 2.7, profiles/EXPERIMENTS.md)
+constexpr uint32_t FILTER_THREADS = 256;
+
+__global__ void __launch_bounds__(FILTER_THREADS) key_filter_kernel(const FilterJob *__restrict__ jobs)
 {
     const FilterJob jb = jobs[blockIdx.x];
     const SymViewG text = global_view(jb.text); // (global loads instead of FLAT ones: see SymViewG)
-    g_u64 *bloom = (g_u64 *)jb.bloom;
+    g_u32 *bloom = (g_u32 *)jb.bloom;
     unsigned long long __attribute__((address_space(1))) *out = (unsigned long long __attribute__((address_space(1))) *)jb.out;
-    // (the first filter in LDS; the second one is consulted for the 0.4 % of foreign keys that pass it, from HBM / L2)
+    // (the first filter in LDS; the second one is consulted for the keys that pass it -- a quarter of the positions of a text that
+    // matches its reference, 1 % of a foreign one's -- from HBM / L2)
     // (a filter of more than KEY_BLOOM_HALF words -- a reference of more than 64 k symbols -- is read where it lies: L2)
-    __shared__ __attribute__((aligned(16))) unsigned long long s_bloom[KEY_BLOOM_HALF];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bloom[2 * KEY_BLOOM_HALF];
     const uint32_t bshift = jb.bloom_shift;
     const bool in_lds = bshift == KEY_BLOOM_SHIFT0;
     if (in_lds)
-        for (uint32_t t = threadIdx.x; t < KEY_BLOOM_HALF; t += blockDim.x)
+        for (uint32_t t = threadIdx.x; t < 2 * KEY_BLOOM_HALF; t += blockDim.x)
             s_bloom[t] = bloom[t];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t k = jb.key_len;
-    const uint64_t kmask = (1ULL << (2 * k)) - 1ULL;     // key_len <= 29
+    const uint32_t k = jb.key_len;                        // key_len <= 29
+    const uint64_t kmask = (1ULL << (2 * k)) - 1ULL;
+    const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
     const uint32_t imask = (1u << k) - 1u;
+    const uint32_t r0 = 66 - 2 * k;                       // 8 .. 58: the key of position 15 starts r0 bits above the window's end
     const uint32_t len = text.len;
     const uint32_t end = min(len, jb.chunk + FILTER_CHUNK);
-    for (uint32_t base = jb.chunk + wave * 1024; base < end; base += 4 * 1024) {
+    for (uint32_t base = jb.chunk + wave * 1024; base < end; base += (blockDim.x >> 6) * 1024) {
         const uint32_t pos = base + lane * 16;
         uint32_t P, I;
         pack16(text, pos, P, I);
@@ -1304,29 +1341,43 @@ __global__ void __launch_bounds__(256) key_filter_kernel(const FilterJob *__rest
                 pack16(text, pos + 16, P1, I1);
             pack16(text, pos + 32, P2, I2);
         }
-        // 96-bit window: symbols 0..15 (P), 16..31 (P1), 32..47 (P2); symbol s at bits [94 - 2s, 95 - 2s]
-        const uint64_t hi = ((uint64_t)P << 32) | P1;            // symbols 0..31
-        const uint64_t inv = ((uint64_t)I << 32) | ((uint64_t)I1 << 16) | I2; // symbol s <-> bit 47 - s
+        // 96-bit window P:P1:P2: symbols 0..15 (P), 16..31 (P1), 32..47 (P2); symbol s at bits [94 - 2s, 95 - 2s]
+        uint32_t V0, V1, V2;
+        if (r0 < 32) {
+            V0 = __builtin_amdgcn_alignbit(P1, P2, r0);
+            V1 = __builtin_amdgcn_alignbit(P, P1, r0);
+            V2 = P >> r0;
+        } else {
+            V0 = __builtin_amdgcn_alignbit(P, P1, r0 - 32);
+            V1 = P >> (r0 - 32);
+            V2 = 0;
+        }
+        uint32_t cand = in_lds ? key_filter_pass1<true>(V0, V1, V2, kmask_lo, kmask_hi, bshift, s_bloom, bloom)
+                               : key_filter_pass1<false>(V0, V1, V2, kmask_lo, kmask_hi, bshift, s_bloom, bloom);
+        // keys that hold a symbol outside ACGT or run past the end of the text: "let the exact step decide" (the text's last lanes,
+        // N runs)
         uint32_t bits = 0;
+        const uint64_t inv = ((uint64_t)I << 32) | ((uint64_t)I1 << 16) | I2; // symbol s <-> bit 47 - s
+        if (inv != 0 || pos + 15 + k >= len) {
 #pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) {
-            // key = symbols j .. j+k-1
-            const uint32_t top = 2 * j;                           // bits consumed before the key
-            uint64_t w = hi << top;                               // symbols j.. left aligned
-            if (top)
-                w |= (uint64_t)P2 >> (32 - top);
-            const uint64_t key = (w >> (64 - 2 * k)) & kmask;
-            const bool bad = ((uint32_t)(inv >> (48 - j - k)) & imask) != 0;
-            uint32_t bw;
-            uint64_t bm;
-            key_bloom_slot(key, bshift, bw, bm);
-            bool in_f = ((in_lds ? s_bloom[bw] : bloom[bw]) & bm) == bm;
-            if (in_f && !bad) { // (0.4 % of the foreign keys get this far)
-                key_bloom_slot2(key, bshift, bw, bm);
-                in_f = (bloom[bw] & bm) == bm;
+            for (uint32_t j = 0; j < 16; ++j) {
+                const bool bad = ((uint32_t)(inv >> (48 - j - k)) & imask) != 0;
+                const bool past = !(pos + j + k < len);
+                bits |= (uint32_t)(bad || past) << j;
             }
-            const bool past = !(pos + j + k < len);
-            bits |= (uint32_t)(bad || in_f || past) << j;
+        }
+        cand &= ~bits;
+        // the second filter, for the keys the first one lets through
+        while (cand) {
+            const uint32_t j = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1;
+            const uint32_t sh = 2 * (15 - j);
+            const uint64_t V10 = ((uint64_t)V1 << 32) | V0, V21 = ((uint64_t)V2 << 32) | V1;
+            const uint32_t lo = (uint32_t)(V10 >> sh) & kmask_lo, hi = (uint32_t)(V21 >> sh) & kmask_hi;
+            uint32_t bw, bm;
+            key_bloom_slot2(((uint64_t)hi << 32) | lo, bshift, bw, bm);
+            if ((bloom[bw] & bm) == bm)
+                bits |= 1u << j;
         }
         // 4 lanes make one 64-bit word (positions ascending = bits ascending)
         const uint64_t mine = (uint64_t)bits << (16 * (lane & 3));
@@ -1459,13 +1510,12 @@ __device__ void idx_insert_one(const IdxBuild &jb, const SymView &rv, uint32_t t
     E *tab = (E *)jb.table;
     const uint64_t h = murmur64(x);
     if (jb.bloom) {
-        uint32_t bw;
-        uint64_t bm;
+        uint32_t bw, bm;
         const uint32_t bshift = key_bloom_shift(jb.ref_size);
         key_bloom_slot(x, bshift, bw, bm);
-        atomicOr(&jb.bloom[bw], (unsigned long long)bm);
+        atomicOr((uint32_t *)jb.bloom + bw, bm);
         key_bloom_slot2(x, bshift, bw, bm);
-        atomicOr(&jb.bloom[bw], (unsigned long long)bm);
+        atomicOr((uint32_t *)jb.bloom + bw, bm);
     }
     const E fp = FPBITS == 16 ? (E)(h >> 48) : (E)(h >> 32);
     E cur = ((E)t << FPBITS) | fp;

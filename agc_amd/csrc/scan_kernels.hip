@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(256) expand_codes_kernel(PackedView pv, uint8_
 // complement, and that 32-bit word costs one funnel shift of the packed stream per position -- no rolling of two strands,
 // no canonical select.  A 128 KiB filter over those words lives in LDS (one 1024-thread block per CU); the survivors
 // (~3 %) get the full k-mer, its canonical form, the second-level filter and the exact table as before.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 struct ScanPackedArgs {
     PackedView pv;
     const ScanRange *ranges;   // begin / end multiples of 16 symbols relative to the buffer, except at contig ends
@@ -443,13 +444,26 @@ __global__ void __launch_bounds__(1024, 4) scan_packed_kernel(ScanPackedArgs a)
                 continue;
 
             // pass 1: filter on the last 16 symbols of the k-mer ending at every own position
+            // (position 15 first: `pass` is doubled and takes the test's outcome as the carry -- v_cmp + v_addc, two
+            // instructions where a select, a shift and an or were three; the filter word is read through an LDS pointer made
+            // from the byte address itself: the dynamic LDS of this kernel starts at 0, and the compiler otherwise adds the base)
             uint32_t pass = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t w16 = j == 15 ? P : __builtin_amdgcn_alignbit(P1, P, 2 * (15 - j)); // symbols j-15 .. j
-                uint32_t bw, bm;
-                sbloom_slot(w16, bw, bm);
-                pass |= (uint32_t)((s_sbloom[bw] & bm) == bm) << j;
+            for (int h = 1; h >= 0; --h) { // (eight reads in flight before the first outcome is needed)
+                uint32_t fw[8], bm[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = 8 * h + i;
+                    const uint32_t w16 = j == 15 ? P : __builtin_amdgcn_alignbit(P1, P, 2 * (15 - j)); // symbols j-15 .. j
+                    uint32_t ba;
+                    sbloom_addr_mask(w16, ba, bm[i]);
+                    fw[i] = *(lds_cu32 *)(uintptr_t)ba;
+                }
+#pragma unroll
+                for (int i = 7; i >= 0; --i) {
+                    const uint32_t missing = bm[i] & ~fw[i];
+                    asm("v_cmp_eq_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(pass) : "v"(missing) : "vcc");
+                }
             }
             pass &= vmask;
             if (pass) {

@@ -401,3 +401,27 @@ if [ "$PART" = v ]; then
     timeout 60 /tmp/msp 3 6 100; timeout 60 /tmp/msp 0 6 120; timeout 60 /tmp/msp 0 1 140; timeout 60 /tmp/msp 0 12 150; } > $OUT/v_malloc_stall.txt 2>&1
   cat $OUT/v_malloc_stall.txt
 fi
+if [ "$PART" = w ]; then
+  timeout 1500 python -m pytest tests -m gpu -q > $OUT/w_tests.log 2>&1; tail -2 $OUT/w_tests.log
+  bench w_bench_1; bench w_bench_2; bench w_bench_3
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/w_bench_*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        e = d["config"]["step_ms_each_rank0"]
+        print(n.split("/")[-1], "median", sorted(e)[len(e)//2], e)
+    except Exception as e:
+        print(n, e)
+PY
+fi
+if [ "$PART" = x ]; then
+  # the scan's LDS filter with fewer instructions per position: parity, the kernel alone, the step
+  timeout 900 python -m pytest tests/test_gpu_scan.py tests/test_gpu_archive.py -m gpu -x -q > $OUT/x_tests.log 2>&1; tail -2 $OUT/x_tests.log
+  timeout 200 python scripts/scan_alone.py 3.0 > $OUT/x_scan_alone.txt 2>&1; tail -3 $OUT/x_scan_alone.txt
+  bench x_bench_1; bench x_bench_2
+fi
+if [ "$PART" = y ]; then
+  # key filter: 32-bit filter words, second filter only for the keys that pass the first; threads per copy of the filter
+  for t in 256 512 1024 256 512 1024; do bench y_bench_t${t}_$RANDOM AGC_HIP_FILTER_THREADS=$t; done
+fi
