@@ -425,3 +425,12 @@ if [ "$PART" = y ]; then
   # key filter: 32-bit filter words, second filter only for the keys that pass the first; threads per copy of the filter
   for t in 256 512 1024 256 512 1024; do bench y_bench_t${t}_$RANDOM AGC_HIP_FILTER_THREADS=$t; done
 fi
+if [ "$PART" = gantt ]; then
+  ROOT=$(pwd)
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/gantt_ktrace -o kt -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/$OUT/gantt_ktrace.log 2>&1)
+  F=$(find $OUT/gantt_ktrace -name "*kernel_trace.csv" | head -1)
+  python scripts/step_timeline.py $F > $OUT/gantt_step_timeline.txt 2>&1; head -30 $OUT/gantt_step_timeline.txt
+  python scripts/step_gantt.py $F 5 > $OUT/gantt_step.txt 2>&1; cat $OUT/gantt_step.txt
+  python scripts/step_gantt.py $F 9 >> $OUT/gantt_step.txt 2>&1
+  find $OUT/gantt_ktrace -name '*kernel_trace.csv' -size +8M -delete
+fi
