@@ -401,7 +401,9 @@ __global__ void __launch_bounds__(1024, 4) scan_packed_kernel(ScanPackedArgs a)
     const uint32_t lshift = 64 - 2 * k;
     const uint64_t wmask = k == 32 ? 0xFFFFFFFFULL : ((1ULL << k) - 1ULL);
 
-    for (uint32_t r = blockIdx.x * waves_per_block + wave; r < a.n_ranges; r += gridDim.x * waves_per_block) {
+    for (uint32_t r_ = blockIdx.x * waves_per_block + wave; r_ < a.n_ranges; r_ += gridDim.x * waves_per_block) {
+        // (a range per wave: its descriptor, the step's base and everything compared with them live in scalar registers)
+        const uint32_t r = __builtin_amdgcn_readfirstlane(r_);
         const ScanRange rg = a.ranges[r];
         const int64_t first = (int64_t)(rg.begin & ~(uint64_t)(PACK_BLOCK - 1));
         uint32_t carryP1, carryP2, carryI1, carryI2; // chunks right before the step (1 = immediately before)
@@ -409,39 +411,43 @@ __global__ void __launch_bounds__(1024, 4) scan_packed_kernel(ScanPackedArgs a)
             uint32_t P = 0, I = 0xFFFF;
             if (lane < 2)
                 load_chunk(a.pv, first - 16 * (int64_t)(lane + 1), rg.ctg_begin, rg.ctg_end, P, I);
-            carryP1 = __shfl(P, 0);
-            carryI1 = __shfl(I, 0);
-            carryP2 = __shfl(P, 1);
-            carryI2 = __shfl(I, 1);
+            carryP1 = __builtin_amdgcn_readlane(P, 0);
+            carryI1 = __builtin_amdgcn_readlane(I, 0);
+            carryP2 = __builtin_amdgcn_readlane(P, 1);
+            carryI2 = __builtin_amdgcn_readlane(I, 1);
         }
         for (int64_t base = first; base < (int64_t)rg.end; base += PACK_BLOCK) {
             const int64_t g = base + (int64_t)lane * 16;
             uint32_t P, I;
-            load_chunk(a.pv, g, rg.ctg_begin, rg.ctg_end, P, I);
-            uint32_t P1 = __shfl_up(P, 1), I1 = __shfl_up(I, 1);
-            uint32_t P2 = __shfl_up(P, 2), I2 = __shfl_up(I, 2);
-            if (lane == 0) {
-                P1 = carryP1;
-                I1 = carryI1;
-                P2 = carryP2;
-                I2 = carryI2;
-            } else if (lane == 1) {
-                P2 = carryP1;
-                I2 = carryI1;
-            }
-            carryP1 = __shfl(P, 63);
-            carryI1 = __shfl(I, 63);
-            carryP2 = __shfl(P, 62);
-            carryI2 = __shfl(I, 62);
+            // (a step whose 1024 symbols lie inside the contig, in a block without escapes -- all but a contig's ends and its
+            // N runs --: the lane's word, nothing to mask)
+            const bool plain = base >= (int64_t)rg.ctg_begin && base + (int64_t)PACK_BLOCK <= (int64_t)rg.ctg_end &&
+                               a.pv.esc_index[(uint64_t)base / PACK_BLOCK] < 0;
+            if (plain) {
+                P = rev2_32(a.pv.words[(uint64_t)g >> 4]);
+                I = 0;
+            } else
+                load_chunk(a.pv, g, rg.ctg_begin, rg.ctg_end, P, I);
+            // the two chunks before the lane's own: the lane below's, by a wave-wide DPP shift (lane 0 keeps the carry it is
+            // given as the old value: no shuffle through the LDS, no select)
+            const uint32_t P1 = __builtin_amdgcn_update_dpp(carryP1, P, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            const uint32_t I1 = __builtin_amdgcn_update_dpp(carryI1, I, 0x138, 0xF, 0xF, false);
+            const uint32_t P2 = __builtin_amdgcn_update_dpp(carryP2, P1, 0x138, 0xF, 0xF, false);
+            const uint32_t I2 = __builtin_amdgcn_update_dpp(carryI2, I1, 0x138, 0xF, 0xF, false);
+            carryP1 = __builtin_amdgcn_readlane(P, 63);
+            carryI1 = __builtin_amdgcn_readlane(I, 63);
+            carryP2 = __builtin_amdgcn_readlane(P, 62);
+            carryI2 = __builtin_amdgcn_readlane(I, 62);
 
             // positions of this chunk the range reports: begin <= g + j < end
             uint32_t vmask = 0xFFFFu;
-            if ((int64_t)rg.begin > g)
-                vmask &= (int64_t)rg.begin - g >= 16 ? 0u : (0xFFFFu << (uint32_t)((int64_t)rg.begin - g));
-            if ((int64_t)rg.end < g + 16)
-                vmask &= (int64_t)rg.end <= g ? 0u : (0xFFFFu >> (uint32_t)(g + 16 - (int64_t)rg.end));
-            if (!vmask)
-                continue;
+            if (!(base >= (int64_t)rg.begin && base + (int64_t)PACK_BLOCK <= (int64_t)rg.end)) { // (a range's first and last step)
+                if ((int64_t)rg.begin > g)
+                    vmask &= (int64_t)rg.begin - g >= 16 ? 0u : (0xFFFFu << (uint32_t)((int64_t)rg.begin - g));
+                if ((int64_t)rg.end < g + 16)
+                    vmask &= (int64_t)rg.end <= g ? 0u : (0xFFFFu >> (uint32_t)(g + 16 - (int64_t)rg.end));
+            }
+            // (no lane leaves the step early: the survivors below are dealt out over ALL lanes of the wave)
 
             // pass 1: filter on the last 16 symbols of the k-mer ending at every own position
             // (position 15 first: `pass` is doubled and takes the test's outcome as the carry -- v_cmp + v_addc, two
@@ -466,17 +472,49 @@ __global__ void __launch_bounds__(1024, 4) scan_packed_kernel(ScanPackedArgs a)
                 }
             }
             pass &= vmask;
-            if (pass) {
-                // window validity: symbols (j-k+1 .. j) <-> inv bits (15-j) .. (15-j+k-1)
-                const uint64_t inv = ((uint64_t)I2 << 32) | ((uint64_t)I1 << 16) | I;
-                const uint64_t hi = ((uint64_t)P2 << 32) | P1; // symbols -32..-1
-                const uint64_t w_lo = (hi << 32) | P;           // symbols -16..15
-                const uint64_t w_hi = hi >> 32;                 // symbols -32..-17
-                while (pass) {
-                    const uint32_t j = (uint32_t)__builtin_ctz(pass);
-                    pass &= pass - 1;
+            // pass 2: the survivors (2 % of the positions: 20 per step of a wave, 0-3 per lane) get the full k-mer, the second
+            // filter and the exact table.  Each lane used to walk its own: as many rounds as the unluckiest lane has survivors
+            // (2-3), each with a fraction of the lanes at work and a dependent load from the second filter -- that, not the
+            // filter pass, was most of the kernel's time.  Now the survivors of the wave are numbered (prefix sum of the lanes'
+            // counts) and lane t takes survivor t: it finds the owner by a binary search over the prefix sums, the owner's
+            // windows by shuffles -- one round for up to 64 survivors.
+            if (__ballot(pass != 0)) {
+                const uint32_t cnt = (uint32_t)__popc(pass);
+                uint32_t incl = cnt; // inclusive prefix sum over the wave: four steps inside the rows of 16, two across them
+                incl += __builtin_amdgcn_update_dpp(0u, incl, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+                incl += __builtin_amdgcn_update_dpp(0u, incl, 0x112 /* row_shr:2 */, 0xF, 0xF, false);
+                incl += __builtin_amdgcn_update_dpp(0u, incl, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+                incl += __builtin_amdgcn_update_dpp(0u, incl, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+                incl += __builtin_amdgcn_update_dpp(0u, incl, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+                incl += __builtin_amdgcn_update_dpp(0u, incl, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                for (uint32_t tb = 0; tb < total; tb += 64) {
+                    const uint32_t t = tb + lane;
+                    uint32_t src = 0; // the first lane whose inclusive count exceeds t
+#pragma unroll
+                    for (int b = 32; b; b >>= 1) {
+                        const uint32_t v = __shfl(incl, (int)(src + b - 1));
+                        if (v <= t)
+                            src += b;
+                    }
+                    if (src > 63)
+                        src = 63; // (t >= total: not a survivor, masked below)
+                    uint32_t r = t - (__shfl(incl, (int)src) - __shfl(cnt, (int)src)); // its rank among the owner's survivors
+                    uint32_t m = __shfl(pass, (int)src);
+                    const uint32_t oP = __shfl(P, (int)src), oP1 = __shfl(P1, (int)src), oP2 = __shfl(P2, (int)src);
+                    const uint32_t oI = __shfl(I, (int)src), oI1 = __shfl(I1, (int)src), oI2 = __shfl(I2, (int)src);
+                    if (t >= total)
+                        continue;
+                    for (; r; --r)
+                        m &= m - 1;
+                    const uint32_t j = (uint32_t)__builtin_ctz(m);
+                    // window validity: symbols (j-k+1 .. j) <-> inv bits (15-j) .. (15-j+k-1)
+                    const uint64_t inv = ((uint64_t)oI2 << 32) | ((uint64_t)oI1 << 16) | oI;
                     if (((inv >> (15 - j)) & wmask) != 0)
                         continue;
+                    const uint64_t hi = ((uint64_t)oP2 << 32) | oP1; // symbols -32..-1
+                    const uint64_t w_lo = (hi << 32) | oP;            // symbols -16..15
+                    const uint64_t w_hi = hi >> 32;                   // symbols -32..-17
                     const uint32_t sft = 2 * (15 - j);
                     uint64_t dir = w_lo >> sft;
                     if (sft)
@@ -496,7 +534,7 @@ __global__ void __launch_bounds__(1024, 4) scan_packed_kernel(ScanPackedArgs a)
                         if (e == can) {
                             const uint32_t idx = atomicAdd(a.n_hits, 1u);
                             if (idx < a.cap) {
-                                a.hits[idx].pos = (uint64_t)g + j;
+                                a.hits[idx].pos = (uint64_t)(base + (int64_t)src * 16) + j;
                                 a.hits[idx].dir = dl;
                                 a.hits[idx].rc = rl;
                             }
