@@ -1336,15 +1336,33 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
     }
     uint32_t n_enc = 0;
     if (enc) {
-        if (b.spec.size() != 2 * segs.size()) {
-            b.spec.assign(2 * segs.size(), BatchState::Spec());
+        // The launch first: it needs nothing from the host but the count (the device made the descriptors), and the table of
+        // speculative deltas below -- 100 k entries for a human sample, 0.6 ms -- used to be filled while the GPU had nothing to do
+        // at the step's front (profiles/r6/step_gantt.txt).
+        uint64_t known_text = 0;
+        for (size_t i = 0; i < n_segs; ++i)
+            if (is_known[i]) {
+                ++n_enc;
+                known_text += dsegs[i].len;
+            }
+        const bool fresh_spec = b.spec.size() != 2 * segs.size();
+        if (fresh_spec)
             b.spec_bytes = 0;
+        if (n_enc) {
+            b.dev_enc_n = n_enc;
+            b.known_text = known_text;
+            b.known_launch_due = true;
+            if (!launch_known_encode(b))
+                return 0;
         }
+        if (fresh_spec)
+            b.spec.assign(2 * segs.size(), BatchState::Spec());
+        uint32_t k_enc = 0;
         for (size_t i = 0; i < n_segs; ++i) {
             if (!is_known[i])
                 continue;
             const agc_hip_segment &d = dsegs[i];
-            // the delta of this segment is about to be made: matched to the placed item at commit time like every speculative delta
+            // the delta of this segment is being made: matched to the placed item at commit time like every speculative delta
             BatchState::Spec &sp = b.spec[2 * i];
             sp.valid = true;
             sp.gid = (uint32_t)d.map_gid;
@@ -1353,19 +1371,9 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             sp.rc = d.store_rc != 0;
             sp.enc_off = 0;
             sp.enc_len = 0;
-            sp.pending = (int32_t)n_enc++;
+            sp.pending = (int32_t)k_enc++;
             st.enc_text += d.len;
             st.enc_ref += groups[(uint32_t)d.map_gid].ref_size ? groups[(uint32_t)d.map_gid].ref_size - 1 : 0;
-        }
-        if (n_enc) {
-            b.dev_enc_n = n_enc;
-            b.known_text = 0;
-            for (size_t i = 0; i < n_segs; ++i)
-                if (is_known[i])
-                    b.known_text += dsegs[i].len;
-            b.known_launch_due = true;
-            if (!launch_known_encode(b))
-                return 0;
         }
         lap(b, "encode of the known segments launched");
     }
