@@ -355,7 +355,11 @@ class DistCompressor:
         rec = body = None
         if self.rank == owner:
             t0 = time.perf_counter()
-            self.cmp.add_sample_dev(sample_name, contig_names, d_codes, ctg_off)
+            try:
+                self.cmp.add_sample_dev(sample_name, contig_names, d_codes, ctg_off)
+            except Exception:
+                self._announce_failure()  # (the other ranks are waiting in the broadcast of this sample's record)
+                raise
             self.seconds["commit"] += time.perf_counter() - t0
             rec, body = self.cmp.last_record_framed(), self.cmp.last_record_body(copy=False)
         self._publish(owner, rec, body)
@@ -510,6 +514,20 @@ class DistCompressor:
                 dist.send(torch.from_numpy(frames).to(self.comm), dst=self.writer)
         self.cmp.close(n_threads)
 
+    def _announce_failure(self):
+        """the owner of the sample whose record everybody waits for could not make it: a header that says so goes out in the
+        record's place, so that the other ranks raise instead of waiting in the broadcast until its timeout"""
+        torch, dist = self.torch, self.dist
+        H, cap = self.MSG_HDR, self._cap
+        msg = self._dmsg if self._dmsg is not None else self._hmsg
+        hdr = np.zeros(H, np.uint8)
+        hdr.view(np.uint64)[0] = 0x58434741  # "AGCX"
+        msg[:H].copy_(torch.from_numpy(hdr))
+        try:
+            dist.broadcast(msg[:cap], src=self.rank)
+        except Exception:
+            pass  # (the failure that brought us here is the one to report)
+
     def _publish(self, owner, rec, body):
         """one sample's commit record: the head to every rank (one broadcast), the delta body to the writer only (point to point);
         ranks other than the owner apply it.  rec: the owner's head as the compressor frames it (numpy uint8 view of its pinned
@@ -523,6 +541,7 @@ class DistCompressor:
         msg = self._dmsg if on_dev else self._hmsg
         if rec is not None:
             if rec.size < H:
+                self._announce_failure()
                 raise RuntimeError("the compressor has no commit record for this sample")
             hdr = rec[:H].view(np.uint64)
             hdr[:] = 0
@@ -539,6 +558,8 @@ class DistCompressor:
                 hm[:guess].copy_(msg[:guess], non_blocking=True)
                 torch.cuda.current_stream(self.comm).synchronize()
             h = hm[:H].numpy().view(np.uint64)
+            if int(h[0]) == 0x58434741:  # "AGCX": _announce_failure
+                raise RuntimeError(f"rank {self.rank}: rank {owner} failed to commit its sample (its own message says why)")
             if int(h[0]) != 0x4D434741:
                 raise RuntimeError(f"rank {self.rank}: bad record message from rank {owner}")
             size = int(h[1])
@@ -629,7 +650,11 @@ class DistCompressor:
 
     def _commit_and_publish(self, i):
         t0 = time.perf_counter()
-        self.cmp.commit_prepared_head()
+        try:
+            self.cmp.commit_prepared_head()
+        except Exception:
+            self._announce_failure()
+            raise
         self.seconds["commit"] += time.perf_counter() - t0
         self._publish(self.rank, self.cmp.last_record_framed(), self._finish_commit)
         self.next_sample = i + 1

@@ -457,6 +457,98 @@ def _edge_run(world, tmp_path, prefetch, tag):
     return open(out, "rb").read(), res[0][2]
 
 
+def _failing_owner_worker(rank, world, port, out_path, q, prefetch, owner_side=False):
+    """as _edge_worker, but the sample rank 1 owns carries the name of the sample before it: the collection refuses it
+    (collection_v3.cpp:682-708) and the commit fails on its owner"""
+    try:
+        from agc_amd import host
+        from agc_amd.dist import DistCompressor
+        from tests.devsim import build as simbuild
+        lib = host.bind(C.CDLL(simbuild.SIM_HOST))
+        k, spl, samples = _edge_samples()
+        if not owner_side:
+            samples[1] = (samples[0][0], samples[1][1], samples[1][2])
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
+        cmp_ = host.Compressor(lib=lib)
+        cmp_.set_distributed(rank, world, 0)
+        cmp_.create(out_path if rank == 0 else "", pack_cardinality=3, k=k, ref_file=None, segment_size=1000, min_match_len=18, n_threads=2)
+        cmp_.set_splitters(spl)
+        keep = {}
+
+        def get_sample(i):
+            name, names, ctgs = samples[i]
+            off = np.zeros(len(ctgs) + 1, np.uint64)
+            off[1:] = np.cumsum([c.size for c in ctgs])
+            keep[i] = np.concatenate(ctgs + [np.full(64, 4, np.uint8)])
+            return name, names, keep[i].ctypes.data, off
+
+        dc = DistCompressor(cmp_, dist, rank, world, device=None)
+        t0 = __import__("time").perf_counter()
+        try:
+            if owner_side:  # the commit itself fails on the owner of sample 1: every rank goes through add_sample
+                for i in range(len(samples)):
+                    if i == 1 and rank == dc.owner_of(1):
+                        def boom(*a, **k):
+                            raise RuntimeError("the owner's commit failed")
+                        cmp_.add_sample_dev = boom
+                    dc.add_sample(*get_sample(i)) if rank == dc.owner_of(i) else dc.add_sample()
+            else:
+                dc.compress(len(samples), get_sample, prefetch=prefetch)
+            q.put((rank, "no error", 0.0))
+        except RuntimeError as e:
+            q.put((rank, "raised: %s" % (e,), __import__("time").perf_counter() - t0))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "error: %r" % (e,), 0.0))
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_a_sample_that_cannot_be_committed_stops_every_rank_at_once(prefetch, tmp_path):
+    """a sample that cannot be committed (here: a sample name the collection holds already) must stop every rank at once,
+    not leave the others waiting in a broadcast until the collective times out"""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    out = str(tmp_path / "never.agc")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_failing_owner_worker, args=(r, 2, port, out, q, prefetch)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=200) for _ in ps)
+    [p.join(timeout=30) for p in ps]
+    [p.kill() for p in ps if p.is_alive()]
+    # (the writer refuses the record when it applies it -- the collection's own check -- and says why on stderr; the owner learns
+    # of it at its next exchange with the writer.  A failure on the owner's side of the commit goes out as an "AGCX" header in the
+    # record's place: DistCompressor._announce_failure)
+    assert all(r[1].startswith("raised:") for r in res), res
+    assert "ApplyRecord failed" in res[0][1] or "failed to commit" in res[0][1], res
+    assert max(r[2] for r in res) < 60, res  # (at once, not at the collective's timeout)
+
+
+def test_a_commit_that_fails_on_its_owner_is_announced_in_the_record_s_place(tmp_path):
+    """the owner's commit raises before there is a record: the ranks waiting in that record's broadcast get an "AGCX" header and raise"""
+    from tests.devsim import build as simbuild
+    simbuild.build()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_failing_owner_worker, args=(r, 2, port, str(tmp_path / "never.agc"), q, False, True)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=200) for _ in ps)
+    [p.join(timeout=30) for p in ps]
+    [p.kill() for p in ps if p.is_alive()]
+    assert "the owner's commit failed" in res[1][1], res
+    assert "failed to commit its sample" in res[0][1], res
+    assert max(r[2] for r in res) < 60, res
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_one_sided_groups_minted_between_prepare_and_commit_and_an_empty_sample(world, tmp_path):
     """a group keyed (k-mer, none) minted by a sample committed between another rank's PrepareSampleDevice and CommitPrepared
