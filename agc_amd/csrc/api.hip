@@ -1682,7 +1682,7 @@ static int ref_register_impl(agc_hip_ctx *c, uint32_t n_refs, const uint32_t *h_
     }
     HIPCHK(c, hipGetLastError());
     // (whatever parses against these tables is ordered behind the insert -- the steps' stream itself, or a lane through the `ready`
-    // event its begin records there -- so this wait is not needed for them; without it the step measured the same, round 6)
+    // event its begin records there -- so this wait is not needed for them; without it the step measured the same, twice: round 6)
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     if (c->refs.size() <= max_gid)
