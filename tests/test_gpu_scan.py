@@ -306,6 +306,30 @@ def test_packed_scan_matches_oracle(hip_ctx, oracle, k):
 
 
 @pytest.mark.parametrize("k", [21, 31])
+def test_packed_scan_with_a_saturated_suffix_filter(hip_ctx, oracle, k):
+    """600 k decoy splitters that occur nowhere in the sample fill the 128 KiB suffix filter: most positions pass it, a wavefront has
+    hundreds of survivors per step of 1024 positions -- the hand-out of survivors over the lanes takes several rounds -- and the
+    second filter and the exact table must turn every one of them away: the hits are the oracle's"""
+    import torch
+    rng = np.random.default_rng(7000 + k)
+    spl, contigs = _packed_case(oracle, rng, k)
+    decoys = rng.integers(0, 1 << 62, 600_000, dtype=np.uint64) << np.uint64(2)
+    decoys &= ~np.uint64((1 << (64 - 2 * k)) - 1)  # left-aligned k-mers
+    all_spl = np.unique(np.concatenate([spl, decoys]))
+    off = np.zeros(len(contigs) + 1, np.uint64)
+    off[1:] = np.cumsum([c.size for c in contigs])
+    d = torch.from_numpy(np.concatenate(contigs)).cuda()
+    torch.cuda.synchronize()
+    pk, keep = hip_ctx.pack_dev(d)
+    hip_ctx.splitters_set(all_spl)
+    got = hip_ctx.scan_packed_dev(pk, off, k)
+    want = _oracle_hits(oracle, contigs, k, all_spl)
+    for g, w, name in zip(got, want, ("ctg", "pos", "dir", "rc")):
+        assert np.array_equal(g, w), name
+    assert want[0].size > 100
+
+
+@pytest.mark.parametrize("k", [21, 31])
 def test_prefetched_scan_matches_oracle(hip_ctx, oracle, k):
     """agc_hip_prefetch_packed_dev + agc_hip_scan_prefetched (the next sample's scan queued ahead on its own stream) deliver
     what the oracle's scan reports; the packed sample reads back symbol for symbol (agc_hip_fetch_slices_packed); a
