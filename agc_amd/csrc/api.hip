@@ -381,8 +381,14 @@ int ensure_z(agc_hip_ctx *c, DevBuf &b, size_t bytes) { return ensure(c, b, byte
 // tens of steps; the wrap waits for the LZ streams once to be sure).  Large copies go the ordinary way.
 int upload(agc_hip_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStream_t st)
 {
-    constexpr size_t RING = (size_t)64 << 20, MAX_PIECE = (size_t)8 << 20, PART = RING / agc_hip_ctx::UP_PARTS;
-    static_assert(PART >= 2 * MAX_PIECE, "a piece must fit a part");
+    // (AGC_HIP_UPLOAD_RING_MB: a smaller ring for the tests -- the head then comes back to a part, and waits for its events, many
+    // times in a small archive; a piece is at most half a part)
+    static const size_t RING = [] {
+        const char *e = getenv("AGC_HIP_UPLOAD_RING_MB");
+        const long mb = e ? atol(e) : 64;
+        return (size_t)(mb < 1 ? 1 : mb > 64 ? 64 : mb) << 20;
+    }();
+    const size_t PART = RING / agc_hip_ctx::UP_PARTS, MAX_PIECE = std::min<size_t>((size_t)8 << 20, PART / 2);
     if (!bytes)
         return AGC_HIP_OK;
     if (bytes > MAX_PIECE) {

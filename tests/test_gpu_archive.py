@@ -224,12 +224,15 @@ def test_whole_sample_encode_from_the_device_descriptors_for_small_samples_too(n
 # the seeded 3 Gbp GRCh38-shaped reference + ONE 3 Gbp sample at d = 1e-3, -k 31 -l 15 -b 100 -- recorded by
 @pytest.mark.parametrize("env", [{"AGC_AMD_FASTA_PACK": "0"}, {"AGC_AMD_FASTA_PACK_MIN": "1", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_AMD_EARLY_COLLECT": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
-                                 {"AGC_AMD_REF_STORE_ASYNC": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"}],
-                         ids=["per_contig_conversion", "one_pass_conversion_of_every_file", "encode_collected_by_the_registrations_task", "reference_store_waited_for"])
+                                 {"AGC_AMD_REF_STORE_ASYNC": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
+                                 {"AGC_HIP_UPLOAD_RING_MB": "1", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"}],
+                         ids=["per_contig_conversion", "one_pass_conversion_of_every_file", "encode_collected_by_the_registrations_task", "reference_store_waited_for",
+                              "upload_ring_of_1_MB_wraps_many_times"])
 @pytest.mark.parametrize("name", ["syn_c3_twin", "syn_mixed", "syn_adaptive"])
 def test_round6_switches_keep_the_archive(name, env, tmp_path, monkeypatch):
     """the file path with and without the one-pass FASTA conversion (agc_hip_sample_pack_fasta), the whole-sample encode collected by an
-    early task or by the registration's own, the reference store on a stream of its own or waited for: the real kernels, every sample on
+    early task or by the registration's own, the reference store on a stream of its own or waited for, a pinned upload ring so small that
+    its head comes back to every part (and waits for the part's events) many times: the real kernels, every sample on
     the device-launched encode and a window of its own where that matters -- the reference's archive every time (syn_adaptive is the
     collection that caught the packed buffers being packed again under the reference-store stream)"""
     from agc_amd import build
