@@ -184,6 +184,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         I.dev_segments = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_DEV_ENCODE_MIN"))
         I.dev_encode_min = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("AGC_AMD_PRE_LAUNCH_ENCODE"))
+        I.pre_launch_encode = atoi(e) != 0;
     if (!PkMap::hash_agrees()) {
         I.err("internal: the host's and the device library's group hash differ");
         return false;
@@ -380,6 +382,8 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         I.dev_segments = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_DEV_ENCODE_MIN"))
         I.dev_encode_min = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("AGC_AMD_PRE_LAUNCH_ENCODE"))
+        I.pre_launch_encode = atoi(e) != 0;
     if (!PkMap::hash_agrees()) {
         I.err("internal: the host's and the device library's group hash differ");
         return false;

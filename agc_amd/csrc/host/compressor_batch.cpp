@@ -1195,14 +1195,38 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
         dev_seg_buf.ctx = hip;
     uint64_t cap = std::max<uint64_t>(dev_seg_buf.size() / sizeof(agc_hip_segment), std::max<uint64_t>(4096, (ctg_off[n_ctg] - ctg_off[0]) / 1000 + n_ctg));
     uint64_t n_segs = 0;
+    // The whole-sample encode is launched INSIDE the call, right behind the group look-up, when everything that decides it is known
+    // beforehand (the rule of `enc` below with the segment count guessed from the sample's length): the device has the encode to
+    // work on while the segment table comes over and is converted -- 0.9 ms of an idle GPU at the front of every human-size step
+    // (profiles/r6/step_gantt.txt).  A guess that turns out wrong, or any way out of this function before the launch is adopted,
+    // drops the launch (PreLaunch's destructor).  Not in adaptive mode (the window may go the host's way) nor in the N-rank prepare.
+    struct PreLaunch {
+        Impl *I;
+        bool armed = false;
+        ~PreLaunch()
+        {
+            if (armed) {
+                (void)agc_hip_lz_encode_drop_on(I->hip, 0);
+                I->lane2_release();
+            }
+        }
+    } pre{this};
+    const bool pre_enc = pre_launch_encode && async_encode && book_can_async(1) && b.base_owned && ctgs.back().sample_idx == 0 && !adaptive && dist_world == 1 &&
+                         (ctg_off[n_ctg] - ctg_off[0]) / std::max<uint64_t>(segment_size, 1) >= (uint64_t)dev_encode_min;
+    if (pre_enc) {
+        lane2_acquire(); // (the previous sample's deltas were collected by its early task long ago)
+        pre.armed = true;
+        lap(b, "second lane free");
+    }
+    uint32_t n_pre_encoded = 0;
     for (;;) {
         if (!dev_seg_buf.resize(cap * sizeof(agc_hip_segment), false)) {
             err("out of memory (segment table)");
             return 0;
         }
-        const int rc = DEVT(agc_hip_segments_packed(hip, &b.pk, ctg_off.data(), n_ctg, k, scan_from_prefetch ? 1 : 0, 0, dev_seg_buf.size() / sizeof(agc_hip_segment),
-                                                    (agc_hip_segment *)dev_seg_buf.data(), &n_segs, nullptr));
-        if (rc == AGC_HIP_ECAP) {
+        const int rc = DEVT(agc_hip_segments_packed(hip, &b.pk, ctg_off.data(), n_ctg, k, scan_from_prefetch ? 1 : 0, pre_enc ? 1 : 0,
+                                                    dev_seg_buf.size() / sizeof(agc_hip_segment), (agc_hip_segment *)dev_seg_buf.data(), &n_segs, &n_pre_encoded));
+        if (rc == AGC_HIP_ECAP) { // (nothing was launched)
             cap = n_segs + n_segs / 8 + 64;
             continue;
         }
@@ -1348,11 +1372,17 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
         const bool fresh_spec = b.spec.size() != 2 * segs.size();
         if (fresh_spec)
             b.spec_bytes = 0;
+        if (pre.armed && n_enc != n_pre_encoded) {
+            err("internal: the device flags another number of segments for its encode than the host's rule");
+            return 0;
+        }
         if (n_enc) {
             b.dev_enc_n = n_enc;
             b.known_text = known_text;
             b.known_launch_due = true;
-            if (!launch_known_encode(b))
+            const bool adopted = pre.armed;
+            pre.armed = false; // (launch_known_encode owns the lane from here on)
+            if (!launch_known_encode(b, adopted))
                 return 0;
         }
         if (fresh_spec)
@@ -1384,7 +1414,7 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
 // The launch of the whole-sample encode from the descriptors the device made (stage_scan_dev), queued at once: beside the estimates
 // and the cost vectors.  (Behind the estimates, or behind the whole classification -- beside the announced scan and the FASTA
 // conversion --, was measured in round 6: median step 13.7-15.5 ms against 12.6-13.2, profiles/EXPERIMENTS.md.)
-bool CAGCCompressor::Impl::launch_known_encode(BatchState &b)
+bool CAGCCompressor::Impl::launch_known_encode(BatchState &b, bool launched_already)
 {
     if (!b.known_launch_due)
         return true;
@@ -1392,12 +1422,14 @@ bool CAGCCompressor::Impl::launch_known_encode(BatchState &b)
     const uint32_t n_enc = b.dev_enc_n;
     {
         {
-            lane2_acquire(); // (the previous sample's deltas have been collected: they were while the table came over)
-            lap(b, "second lane free");
-            if (!hip_ok(DEVT(agc_hip_segments_encode_known(hip)), "segments_encode_known")) {
-                lane2_release();
-                b.dev_enc_n = 0;
-                return false;
+            if (!launched_already) { // (launched_already: inside agc_hip_segments_packed, the lane taken before that call)
+                lane2_acquire(); // (the previous sample's deltas have been collected: they were while the table came over)
+                lap(b, "second lane free");
+                if (!hip_ok(DEVT(agc_hip_segments_encode_known(hip)), "segments_encode_known")) {
+                    lane2_release();
+                    b.dev_enc_n = 0;
+                    return false;
+                }
             }
             st.lz_encoded += n_enc;
             // The deltas are collected as soon as the kernel is done -- an early task of the bookkeeping thread, queued now -- when

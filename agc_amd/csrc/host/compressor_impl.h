@@ -985,8 +985,9 @@ struct CAGCCompressor::Impl {
         } sto;
     };
     bool stage_scan(BatchState &b);
-    bool launch_known_encode(BatchState &b);
+    bool launch_known_encode(BatchState &b, bool launched_already = false);
     int stage_scan_dev(BatchState &b);
+    bool pre_launch_encode = true;     // the whole-sample encode launched inside agc_hip_segments_packed (AGC_AMD_PRE_LAUNCH_ENCODE=0: behind the table)
     uint32_t dev_encode_min = 2048;    // segments a sample needs for the device-launched whole-sample encode (AGC_AMD_DEV_ENCODE_MIN: tests)
     bool use_dev_segments(const BatchState &b) const;
     // adaptive mode with windows of several registrations: only where the device delivers the segments (the cut of a window at

@@ -441,3 +441,18 @@ if [ "$PART" = fuzzlast ]; then
   timeout 1200 python scripts/fuzz_archives.py --big --from 97000 --count 40 > $OUT/fuzz_gpu_last_build_big_40_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_big_40_cases.log
   timeout 1500 python scripts/fuzz_deals_gpu.py --from 98000 --count 40 > $OUT/fuzz_gpu_last_build_deals_40_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_deals_40_cases.log
 fi
+if [ "$PART" = pre ]; then
+  # the whole-sample encode launched inside agc_hip_segments_packed (before the segment table comes over) or behind it: alternating on one box
+  [ -n "$PRE_TESTS" ] && { timeout 1500 python -m pytest tests/test_gpu_archive.py tests/test_gpu_scan.py tests/test_dist_single_archive.py -m gpu -x -q > $OUT/pre_tests.log 2>&1; tail -2 $OUT/pre_tests.log; }
+  for i in 1 2 3 4 5 6 7 8; do bench pre_on_$i AGC_AMD_PRE_LAUNCH_ENCODE=1; bench pre_off_$i AGC_AMD_PRE_LAUNCH_ENCODE=0; done
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/pre_o*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        e = d["config"]["step_ms_each_rank0"]
+        print(n.split("/")[-1], "value", d["value"], "median step", sorted(e)[len(e)//2], "mean", round(sum(e)/len(e), 2), "close", d["config"]["close_ms"])
+    except Exception as e:
+        print(n, e)
+PY
+fi
