@@ -436,10 +436,10 @@ if [ "$PART" = gantt ]; then
 fi
 if [ "$PART" = fuzzlast ]; then
   # more random collections through the real kernels on the round's last build (new seeds)
-  timeout 2400 python scripts/fuzz_archives.py --from 95000 --count 400 > $OUT/fuzz_gpu_last_build_400_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_400_cases.log
-  timeout 1200 python scripts/fuzz_archives.py --many --from 96000 --count 60 > $OUT/fuzz_gpu_last_build_many_60_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_many_60_cases.log
-  timeout 1200 python scripts/fuzz_archives.py --big --from 97000 --count 40 > $OUT/fuzz_gpu_last_build_big_40_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_big_40_cases.log
-  timeout 1500 python scripts/fuzz_deals_gpu.py --from 98000 --count 40 > $OUT/fuzz_gpu_last_build_deals_40_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_deals_40_cases.log
+  timeout 2400 python scripts/fuzz_archives.py --from ${FUZZ_FROM:-95000} --count 400 > $OUT/fuzz_gpu_last_build_400_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_400_cases.log
+  timeout 1200 python scripts/fuzz_archives.py --many --from $(( ${FUZZ_FROM:-95000} + 1000 )) --count 60 > $OUT/fuzz_gpu_last_build_many_60_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_many_60_cases.log
+  timeout 1200 python scripts/fuzz_archives.py --big --from $(( ${FUZZ_FROM:-95000} + 2000 )) --count 40 > $OUT/fuzz_gpu_last_build_big_40_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_big_40_cases.log
+  timeout 1500 python scripts/fuzz_deals_gpu.py --from $(( ${FUZZ_FROM:-95000} + 3000 )) --count 40 > $OUT/fuzz_gpu_last_build_deals_40_cases.log 2>&1; tail -2 $OUT/fuzz_gpu_last_build_deals_40_cases.log
 fi
 if [ "$PART" = pre ]; then
   # the whole-sample encode launched inside agc_hip_segments_packed (before the segment table comes over) or behind it: alternating on one box
