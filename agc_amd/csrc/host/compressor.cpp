@@ -186,6 +186,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         I.dev_encode_min = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("AGC_AMD_PRE_LAUNCH_ENCODE"))
         I.pre_launch_encode = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_PLACE_AHEAD"))
+        I.place_ahead = atoi(e);
     if (!PkMap::hash_agrees()) {
         I.err("internal: the host's and the device library's group hash differ");
         return false;
@@ -384,6 +386,8 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         I.dev_encode_min = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("AGC_AMD_PRE_LAUNCH_ENCODE"))
         I.pre_launch_encode = atoi(e) != 0;
+    if (const char *e = getenv("AGC_AMD_PLACE_AHEAD"))
+        I.place_ahead = atoi(e);
     if (!PkMap::hash_agrees()) {
         I.err("internal: the host's and the device library's group hash differ");
         return false;

@@ -1954,6 +1954,46 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     t0 = now();
     LAP("mids");
     std::vector<uint32_t> best_pos(mids.size(), 0);
+    // While this thread waits for the split points (4-5 ms at human scale) a helper places every segment that has no split-point
+    // job -- what stage_place would do for it, minus the part number: the host phase between the classification kernels and the
+    // index build is on the step's critical path (profiles/EXPERIMENTS.md), the wait is not.  Nothing the helper reads changes
+    // meanwhile: the group map and the segments are this thread's, and this thread is inside the device call.
+    std::future<void> place_helper;
+    b.place_ahead_valid = false;
+    if (place_ahead > 0 && !mids.empty() && (segs.size() >= 4096 || place_ahead > 1)) {
+        b.place_ahead.resize(segs.size());
+        b.place_ahead_ok.assign(segs.size(), 0);
+        place_helper = std::async(std::launch::async, [this, &b, &segs, &ctgs] {
+            for (uint32_t si = 0; si < segs.size(); ++si) {
+                const Seg &s = segs[si];
+                if (s.mid_job >= 0 || s.mid_job == -2)
+                    continue;
+                Placed &a = b.place_ahead[si];
+                a.ctg = s.ctg;
+                a.key = 2 * si;
+                a.off = ctgs[s.ctg].off + s.start;
+                a.len = s.len;
+                a.rc = s.store_rc;
+                a.pk = s.pk;
+                a.part_no = 0;
+                if (s.known_gid >= 0)
+                    a.gid = s.known_gid;
+                else {
+                    const int32_t *m = map_segments.find(s.pk);
+                    a.gid = m ? *m : -1;
+                }
+                b.place_ahead_ok[si] = 1;
+            }
+        });
+    }
+    struct JoinHelper { // (every way out of this function waits for the helper first)
+        std::future<void> &f;
+        ~JoinHelper()
+        {
+            if (f.valid())
+                f.wait();
+        }
+    } join_helper{place_helper};
     if (!mids.empty()) {
         size_t n = mids.size();
         std::vector<uint32_t> g1(n), g2(n), len(n);
@@ -1978,6 +2018,10 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
                                                                            p1.data(), r2.data(), p2.data(), best_pos.data(), nullptr)),
                     "lz_split_point_batch"))
             return false;
+    }
+    if (place_helper.valid()) {
+        place_helper.get();
+        b.place_ahead_valid = true;
     }
     for (size_t i = 0; i < mids.size(); ++i)
         segs[mids[i].seg].bp = best_pos[i];
@@ -2008,10 +2052,21 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
     std::vector<Placed> &placed = placed_buf;
     placed.clear();
     placed.reserve(segs.size() + segs.size() / 8 + 16);
+    const bool ahead = b.place_ahead_valid && b.place_ahead.size() == segs.size();
+    b.place_ahead_valid = false; // (a placement repeated after a revalidation reads the map as it is then)
     {
         uint32_t cur_ctg = ~0u, part_no = 0;
         for (uint32_t si = 0; si < segs.size(); ++si) {
             const Seg &s = segs[si];
+            if (ahead && b.place_ahead_ok[si]) { // (placed while the split points were on their way: only the part number is missing)
+                if (s.ctg != cur_ctg) {
+                    cur_ctg = s.ctg;
+                    part_no = 0;
+                }
+                placed.push_back(b.place_ahead[si]);
+                placed.back().part_no = part_no++;
+                continue;
+            }
             pk_t pk = s.pk;            // (placement never writes to the segment: it is repeated after a revalidation)
             bool store_rc = s.store_rc;
             if (s.ctg != cur_ctg) {
@@ -2118,7 +2173,7 @@ bool CAGCCompressor::Impl::stage_register(BatchState &b)
     commit_upto = n_samples; // exclusive
     for (const Placed &pl : placed) {
         const uint32_t sx = ctgs[pl.ctg].sample_idx;
-        if (sx >= s_from && (pl.gid < 0 || groups[pl.gid].packed) && sx + 1 < commit_upto)
+        if (sx >= s_from && sx + 1 < commit_upto && (pl.gid < 0 || groups[pl.gid].packed)) // (a window of one registration: never true)
             commit_upto = sx + 1;
     }
 

@@ -974,6 +974,11 @@ struct CAGCCompressor::Impl {
         std::vector<uint64_t> changed;             // k-mers whose terminator list changed in the last commit run
         uint32_t commit_upto = 0;                  // registrations of the window that are committed now
         std::vector<uint32_t> order;               // committed items in registration order
+        // the placement of the segments that have no split-point job (all but a few per cent), made on a helper thread while the
+        // driving thread waits for the split points: stage_place copies these and numbers the parts (place_ahead_valid: once)
+        std::vector<Placed> place_ahead;
+        std::vector<uint8_t> place_ahead_ok;
+        bool place_ahead_valid = false;
         std::vector<SampleLists> per_sample;
         struct Store {                             // stage_store's working set between its two halves
             std::vector<uint32_t> new_ref_items, raw_items, enc_items; // placed indices
@@ -987,6 +992,7 @@ struct CAGCCompressor::Impl {
     bool stage_scan(BatchState &b);
     bool launch_known_encode(BatchState &b, bool launched_already = false);
     int stage_scan_dev(BatchState &b);
+    int place_ahead = 1;               // placement of the segments without a split-point job beside the wait for the split points (AGC_AMD_PLACE_AHEAD=0: after it; 2: for windows of any size -- tests)
     bool pre_launch_encode = true;     // the whole-sample encode launched inside agc_hip_segments_packed (AGC_AMD_PRE_LAUNCH_ENCODE=0: behind the table)
     uint32_t dev_encode_min = 2048;    // segments a sample needs for the device-launched whole-sample encode (AGC_AMD_DEV_ENCODE_MIN: tests)
     bool use_dev_segments(const BatchState &b) const;
