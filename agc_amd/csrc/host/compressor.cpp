@@ -188,6 +188,8 @@ bool CAGCCompressor::Create(const std::string &file_name, uint32_t pack_cardinal
         I.pre_launch_encode = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_PLACE_AHEAD"))
         I.place_ahead = atoi(e);
+    if (const char *e = getenv("AGC_AMD_SPEC_FILL_AHEAD"))
+        I.spec_fill_ahead = atoi(e);
     if (!PkMap::hash_agrees()) {
         I.err("internal: the host's and the device library's group hash differ");
         return false;
@@ -388,6 +390,8 @@ bool CAGCCompressor::Append(const std::string &in_archive_name, const std::strin
         I.pre_launch_encode = atoi(e) != 0;
     if (const char *e = getenv("AGC_AMD_PLACE_AHEAD"))
         I.place_ahead = atoi(e);
+    if (const char *e = getenv("AGC_AMD_SPEC_FILL_AHEAD"))
+        I.spec_fill_ahead = atoi(e);
     if (!PkMap::hash_agrees()) {
         I.err("internal: the host's and the device library's group hash differ");
         return false;

@@ -962,6 +962,7 @@ bool CAGCCompressor::Impl::batch_commit(BatchState &b, uint32_t &n_committed)
 // (segment.cpp:41-48), so these deltas stay valid whatever earlier registrations of the window mint.
 bool CAGCCompressor::Impl::spec_encode(BatchState &b)
 {
+    finish_spec_fill(b);
     const std::vector<Placed> &placed = placed_buf;
     double &t0 = b.t0, &dev0 = b.dev0;
     if (b.spec.size() != 2 * seg_buf.size()) {
@@ -1033,6 +1034,7 @@ bool CAGCCompressor::Impl::spec_encode(BatchState &b)
 // matched to the placed items by (group, offset, length, orientation) at commit time like every speculative delta.
 bool CAGCCompressor::Impl::overlap_encode_begin(BatchState &b)
 {
+    finish_spec_fill(b);
     const std::vector<Contig> &ctgs = *b.ctgs;
     const std::vector<Seg> &segs = seg_buf;
     if (b.spec.size() != 2 * segs.size()) {
@@ -1074,6 +1076,7 @@ bool CAGCCompressor::Impl::overlap_encode_begin(BatchState &b)
 
 bool CAGCCompressor::Impl::overlap_encode_end(BatchState &b)
 {
+    finish_spec_fill(b);
     const size_t ne = b.flight_keys.size();
     std::vector<uint64_t> eoff(ne + 1, 0);
     uint64_t tot = 0;
@@ -1385,25 +1388,41 @@ int CAGCCompressor::Impl::stage_scan_dev(BatchState &b)
             if (!launch_known_encode(b, adopted))
                 return 0;
         }
-        if (fresh_spec)
-            b.spec.assign(2 * segs.size(), BatchState::Spec());
-        uint32_t k_enc = 0;
-        for (size_t i = 0; i < n_segs; ++i) {
-            if (!is_known[i])
-                continue;
-            const agc_hip_segment &d = dsegs[i];
-            // the delta of this segment is being made: matched to the placed item at commit time like every speculative delta
-            BatchState::Spec &sp = b.spec[2 * i];
-            sp.valid = true;
-            sp.gid = (uint32_t)d.map_gid;
-            sp.off = ctgs[d.ctg].off + d.start;
-            sp.len = d.len;
-            sp.rc = d.store_rc != 0;
-            sp.enc_off = 0;
-            sp.enc_len = 0;
-            sp.pending = (int32_t)k_enc++;
-            st.enc_text += d.len;
-            st.enc_ref += groups[(uint32_t)d.map_gid].ref_size ? groups[(uint32_t)d.map_gid].ref_size - 1 : 0;
+        // The table of speculative deltas (every delta being made is matched to the placed item at commit time, like every
+        // speculative delta) is first read by the placement stage: for a human-size sample -- 100 k entries, half a millisecond -- a
+        // helper thread fills it while this one goes on to the keys and the estimates, which the step's critical path runs through
+        // (profiles/r6/step_gantt.txt); finish_spec_fill() waits for it.  Nothing it reads changes before that: the segment table,
+        // the contigs, the groups that exist (new ones are appended by stage_register, behind the wait).
+        const size_t n_spec = 2 * segs.size();
+        auto fill = [this, &b, fresh_spec, n_spec, n_segs, dsegs, &ctgs, known = std::move(is_known)]() -> std::pair<uint64_t, uint64_t> {
+            if (fresh_spec)
+                b.spec.assign(n_spec, BatchState::Spec());
+            uint32_t k_enc = 0;
+            uint64_t text = 0, ref = 0;
+            for (size_t i = 0; i < n_segs; ++i) {
+                if (!known[i])
+                    continue;
+                const agc_hip_segment &d = dsegs[i];
+                BatchState::Spec &sp = b.spec[2 * i];
+                sp.valid = true;
+                sp.gid = (uint32_t)d.map_gid;
+                sp.off = ctgs[d.ctg].off + d.start;
+                sp.len = d.len;
+                sp.rc = d.store_rc != 0;
+                sp.enc_off = 0;
+                sp.enc_len = 0;
+                sp.pending = (int32_t)k_enc++;
+                text += d.len;
+                ref += groups[(uint32_t)d.map_gid].ref_size ? groups[(uint32_t)d.map_gid].ref_size - 1 : 0;
+            }
+            return {text, ref};
+        };
+        if (spec_fill_ahead > 0 && (n_segs >= 4096 || spec_fill_ahead > 1))
+            b.spec_fill = std::async(std::launch::async, std::move(fill));
+        else {
+            const auto tr = fill();
+            st.enc_text += tr.first;
+            st.enc_ref += tr.second;
         }
         lap(b, "encode of the known segments launched");
     }
@@ -2032,6 +2051,16 @@ bool CAGCCompressor::Impl::stage_classify(BatchState &b)
     return true;
 }
 
+// the helper that fills the table of speculative deltas (stage_scan_dev) is done: its symbol counts go to the statistics
+void CAGCCompressor::Impl::finish_spec_fill(BatchState &b)
+{
+    if (!b.spec_fill.valid())
+        return;
+    const auto tr = b.spec_fill.get();
+    st.enc_text += tr.first;
+    st.enc_ref += tr.second;
+}
+
 // add_segment, last part: the placed items (one or two per segment) with their part numbers
 bool CAGCCompressor::Impl::stage_place(BatchState &b)
 {
@@ -2043,6 +2072,7 @@ bool CAGCCompressor::Impl::stage_place(BatchState &b)
     (void)ctgs; (void)d_base; (void)n_ctg; (void)t0; (void)dev0; (void)LAP;
     std::vector<Seg> &segs = seg_buf;
     LAP("splitpoints");
+    finish_spec_fill(b);
     // the announced next sample: its expansion + scan are queued NOW -- the classification kernels of this sample are done, what
     // follows is host work (placement, ordering, new group ids: ~2.5 ms at human scale) before the encode needs the GPU again
     launch_prefetch();

@@ -976,6 +976,7 @@ struct CAGCCompressor::Impl {
         std::vector<uint32_t> order;               // committed items in registration order
         // the placement of the segments that have no split-point job (all but a few per cent), made on a helper thread while the
         // driving thread waits for the split points: stage_place copies these and numbers the parts (place_ahead_valid: once)
+        std::future<std::pair<uint64_t, uint64_t>> spec_fill; // the helper that fills `spec` for the whole-sample encode (finish_spec_fill)
         std::vector<Placed> place_ahead;
         std::vector<uint8_t> place_ahead_ok;
         bool place_ahead_valid = false;
@@ -991,7 +992,9 @@ struct CAGCCompressor::Impl {
     };
     bool stage_scan(BatchState &b);
     bool launch_known_encode(BatchState &b, bool launched_already = false);
+    void finish_spec_fill(BatchState &b);
     int stage_scan_dev(BatchState &b);
+    int spec_fill_ahead = 1;           // the table of speculative deltas of the whole-sample encode filled by a helper thread (AGC_AMD_SPEC_FILL_AHEAD=0: in line; 2: any size)
     int place_ahead = 1;               // placement of the segments without a split-point job beside the wait for the split points (AGC_AMD_PLACE_AHEAD=0: after it; 2: for windows of any size -- tests)
     bool pre_launch_encode = true;     // the whole-sample encode launched inside agc_hip_segments_packed (AGC_AMD_PRE_LAUNCH_ENCODE=0: behind the table)
     uint32_t dev_encode_min = 2048;    // segments a sample needs for the device-launched whole-sample encode (AGC_AMD_DEV_ENCODE_MIN: tests)

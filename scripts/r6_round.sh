@@ -472,3 +472,19 @@ for n in sorted(glob.glob("gpurun_out/r6/ahead_o*.json")):
         print(n, e)
 PY
 fi
+if [ "$PART" = specfill ]; then
+  # the table of speculative deltas filled by a helper thread (off the chain from the group look-up to the estimates): parity, then on / off
+  timeout 1500 python -m pytest tests/test_gpu_archive.py tests/test_dist_single_archive.py -m gpu -x -q > $OUT/specfill_tests.log 2>&1; tail -2 $OUT/specfill_tests.log
+  AGC_AMD_SPEC_FILL_AHEAD=2 AGC_AMD_PLACE_AHEAD=2 timeout 900 python scripts/fuzz_archives.py --from 130000 --count 150 > $OUT/specfill_fuzz_150_cases.log 2>&1; tail -1 $OUT/specfill_fuzz_150_cases.log
+  for i in 1 2 3 4 5 6; do bench specfill_on_$i AGC_AMD_SPEC_FILL_AHEAD=1; bench specfill_off_$i AGC_AMD_SPEC_FILL_AHEAD=0; done > /dev/null
+  python - <<'PY'
+import json, glob
+for n in sorted(glob.glob("gpurun_out/r6/specfill_o*.json")):
+    try:
+        d = json.loads(open(n).read().strip().splitlines()[-1])
+        e = d["config"]["step_ms_each_rank0"]
+        print(n.split("/")[-1], "value", d["value"], "median step", sorted(e)[len(e)//2], "mean", round(sum(e)/len(e), 2), "close", d["config"]["close_ms"])
+    except Exception as e:
+        print(n, e)
+PY
+fi

@@ -227,10 +227,11 @@ def test_whole_sample_encode_from_the_device_descriptors_for_small_samples_too(n
                                  {"AGC_AMD_REF_STORE_ASYNC": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_HIP_UPLOAD_RING_MB": "1", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_AMD_PRE_LAUNCH_ENCODE": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
-                                 {"AGC_AMD_PLACE_AHEAD": "2", "AGC_AMD_DEV_ENCODE_MIN": "0"}],
+                                 {"AGC_AMD_PLACE_AHEAD": "2", "AGC_AMD_DEV_ENCODE_MIN": "0"},
+                                 {"AGC_AMD_SPEC_FILL_AHEAD": "2", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"}],
                          ids=["per_contig_conversion", "one_pass_conversion_of_every_file", "encode_collected_by_the_registrations_task", "reference_store_waited_for",
                               "upload_ring_of_1_MB_wraps_many_times", "encode_launched_behind_the_segment_table",
-                              "placement_beside_the_wait_for_the_split_points"])
+                              "placement_beside_the_wait_for_the_split_points", "table_of_speculative_deltas_filled_by_a_helper"])
 @pytest.mark.parametrize("name", ["syn_c3_twin", "syn_mixed", "syn_adaptive"])
 def test_round6_switches_keep_the_archive(name, env, tmp_path, monkeypatch):
     """the file path with and without the one-pass FASTA conversion (agc_hip_sample_pack_fasta), the whole-sample encode collected by an

@@ -179,6 +179,7 @@ def test_bookkeeping_beside_the_next_registration_gives_the_same_archive(cli, na
                                  {"AGC_AMD_PRE_LAUNCH_ENCODE": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_AMD_PLACE_AHEAD": "2", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_AMD_PLACE_AHEAD": "2"},
+                                 {"AGC_AMD_SPEC_FILL_AHEAD": "2", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_AMD_REF_STORE_ASYNC": "0", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"},
                                  {"AGC_AMD_EARLY_COLLECT": "1", "AGC_AMD_REF_STORE_ASYNC": "1", "AGC_AMD_DEV_ENCODE_MIN": "0", "AGC_AMD_WINDOW_MAX": "1"}], ids=lambda e: "+".join(f"{k[8:] if k.startswith('AGC_AMD_') else k}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("name", ["syn_mixed", "syn_c4_twin"])
