@@ -99,6 +99,8 @@ struct agc_hip_ctx {
     size_t h_gmap_stage_cap = 0;
     hipEvent_t gmap_ev = nullptr;
     bool gmap_ev_valid = false;
+    uint32_t *h_zsizes = nullptr; // pinned: frame sizes of the entropy launch in flight (a pageable destination makes the "async" copy
+    size_t h_zsizes_cap = 0;      // wait for the launch inside the call, spinning: a core of the host pool's for the whole launch)
     void *h_segcounts = nullptr; // pinned: SegCounts of the call in flight (+ 64: the count of the encode launched from them)
     // what agc_hip_segments_packed left on the device for agc_hip_segments_encode_known
     struct SegState {
@@ -652,6 +654,8 @@ void agc_hip_destroy(agc_hip_ctx *c)
                       &c->l3.d_compact, &c->l2.d_n, &c->l3.d_n, &c->d_esc_jobs, &c->d_flags, &c->d_gmap, &c->d_gmap_stage, &c->d_segwork, &c->d_segtmp};
     if (c->h_segcounts)
         (void)hipHostFree(c->h_segcounts);
+    if (c->h_zsizes)
+        (void)hipHostFree(c->h_zsizes);
     if (c->h_gmap_stage)
         (void)hipHostFree(c->h_gmap_stage);
     if (c->gmap_ev)
@@ -3045,8 +3049,17 @@ static int zstd17_batch_impl(agc_hip_ctx *c, uint32_t n, const uint8_t *h_src, c
         HIPCHK(c, hipGetLastError());
         done += m;
     }
-    std::vector<uint32_t> sizes(n);
-    HIPCHK(c, hipMemcpyAsync(sizes.data(), c->d_zsize.p, (size_t)n * 4, hipMemcpyDeviceToHost, zs_));
+    if (c->h_zsizes_cap < n) {
+        if (c->h_zsizes)
+            HIPCHK(c, hipHostFree(c->h_zsizes));
+        c->h_zsizes = nullptr;
+        c->h_zsizes_cap = 0;
+        const size_t cap = (size_t)n + n / 4 + 1024;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_zsizes, cap * 4, hipHostMallocDefault));
+        c->h_zsizes_cap = cap;
+    }
+    uint32_t *sizes = c->h_zsizes;
+    HIPCHK(c, hipMemcpyAsync(sizes, c->d_zsize.p, (size_t)n * 4, hipMemcpyDeviceToHost, zs_));
     // (the launch lasts hundreds of ms and the host pool compresses its share of the packs meanwhile: this thread sleeps)
     HIPCHK(c, hipEventRecord(c->zev_wait, zs_));
     HIPCHK(c, hipEventSynchronize(c->zev_wait));
